@@ -1,0 +1,270 @@
+/*
+ * oc_packet.c -- CPU ORACLE (test infrastructure): Opus packet layer and per-frame mode dispatch.
+ * Restates the reference's src/opus_decoder.cpp: TOC helpers (:135-152, :460-556), frame
+ * splitting (:559-680), opus_decode_frame (:154-278), opus_decode_native (:280-348), init and
+ * OPUS_RESET_STATE (:82-118, :382-390).  Quirks kept: audiosize fixed at 960 (Q6), redundancy flag
+ * decoded and ignored (Q2), hybrid->SILK transition decodes CELT from the live range coder (Q4).
+ */
+#include <stdlib.h>
+#include "oc_opus.h"
+
+int oc_packet_mode(const u8 *d) { /* opus_decoder.cpp:135 */
+    if (d[0] & 0x80) return OC_MODE_CELT;
+    if ((d[0] & 0x60) == 0x60) return OC_MODE_HYBRID;
+    return OC_MODE_SILK;
+}
+
+int oc_packet_bandwidth(const u8 *d) { /* opus_decoder.cpp:460 */
+    int bw;
+    if (d[0] & 0x80) {
+        bw = OC_BW_MB + ((d[0] >> 5) & 0x3);
+        if (bw == OC_BW_MB) bw = OC_BW_NB;
+    } else if ((d[0] & 0x60) == 0x60)
+        bw = (d[0] & 0x10) ? OC_BW_FB : OC_BW_SWB;
+    else
+        bw = OC_BW_NB + ((d[0] >> 5) & 0x3);
+    return bw;
+}
+
+int oc_packet_channels(const u8 *d) { return (d[0] & 0x4) ? 2 : 1; } /* :474 */
+
+int oc_packet_samples_per_frame(const u8 *d, i32 Fs) { /* :541 */
+    int a;
+    if (d[0] & 0x80) {
+        a = (d[0] >> 3) & 0x3;
+        a = (Fs << a) / 400;
+    } else if ((d[0] & 0x60) == 0x60)
+        a = (d[0] & 0x08) ? Fs / 50 : Fs / 100;
+    else {
+        a = (d[0] >> 3) & 0x3;
+        a = a == 3 ? Fs * 60 / 1000 : (Fs << a) / 100;
+    }
+    return a;
+}
+
+static int parse_size(const u8 *d, i32 len, i16 *size) { /* :524 */
+    if (len < 1) {
+        *size = -1;
+        return -1;
+    }
+    if (d[0] < 252) {
+        *size = d[0];
+        return 1;
+    }
+    if (len < 2) {
+        *size = -1;
+        return -1;
+    }
+    *size = 4 * d[1] + d[0];
+    return 2;
+}
+
+int oc_packet_parse(const u8 *data, i32 len, int self_delimited, u8 *out_toc, i16 size[48], int *payload_offset,
+                    i32 *packet_offset) { /* :559 */
+    int i, bytes, count, cbr = 0, framesize;
+    u8 ch, toc;
+    i32 last_size, pad = 0;
+    const u8 *data0 = data;
+    if (size == NULL || len < 0) return OC_BAD_ARG;
+    if (len == 0) return OC_INVALID_PACKET;
+    framesize = oc_packet_samples_per_frame(data, 48000);
+    toc = *data++;
+    len--;
+    last_size = len;
+    switch (toc & 0x3) {
+        case 0: count = 1; break;
+        case 1:
+            count = 2;
+            cbr = 1;
+            if (!self_delimited) {
+                if (len & 0x1) return OC_INVALID_PACKET;
+                last_size = len / 2;
+                size[0] = (i16)last_size;
+            }
+            break;
+        case 2:
+            count = 2;
+            bytes = parse_size(data, len, size);
+            len -= bytes;
+            if (size[0] < 0 || size[0] > len) return OC_INVALID_PACKET;
+            data += bytes;
+            last_size = len - size[0];
+            break;
+        default:
+            if (len < 1) return OC_INVALID_PACKET;
+            ch = *data++;
+            count = ch & 0x3F;
+            if (count <= 0 || framesize * (i32)count > 5760) return OC_INVALID_PACKET;
+            len--;
+            if (ch & 0x40) {
+                int p;
+                do {
+                    int tmp;
+                    if (len <= 0) return OC_INVALID_PACKET;
+                    p = *data++;
+                    len--;
+                    tmp = p == 255 ? 254 : p;
+                    len -= tmp;
+                    pad += tmp;
+                } while (p == 255);
+            }
+            if (len < 0) return OC_INVALID_PACKET;
+            cbr = !(ch & 0x80);
+            if (!cbr) {
+                last_size = len;
+                for (i = 0; i < count - 1; i++) {
+                    bytes = parse_size(data, len, size + i);
+                    len -= bytes;
+                    if (size[i] < 0 || size[i] > len) return OC_INVALID_PACKET;
+                    data += bytes;
+                    last_size -= bytes + size[i];
+                }
+                if (last_size < 0) return OC_INVALID_PACKET;
+            } else if (!self_delimited) {
+                last_size = len / count;
+                if (last_size * count != len) return OC_INVALID_PACKET;
+                for (i = 0; i < count - 1; i++) size[i] = (i16)last_size;
+            }
+            break;
+    }
+    if (self_delimited) {
+        bytes = parse_size(data, len, size + count - 1);
+        len -= bytes;
+        if (size[count - 1] < 0 || size[count - 1] > len) return OC_INVALID_PACKET;
+        data += bytes;
+        if (cbr) {
+            if (size[count - 1] * count > len) return OC_INVALID_PACKET;
+            for (i = 0; i < count - 1; i++) size[i] = size[count - 1];
+        } else if (bytes + size[count - 1] > last_size)
+            return OC_INVALID_PACKET;
+    } else {
+        if (last_size > 1275) return OC_INVALID_PACKET;
+        size[count - 1] = (i16)last_size;
+    }
+    if (payload_offset) *payload_offset = (int)(data - data0);
+    for (i = 0; i < count; i++) data += size[i];
+    if (packet_offset) *packet_offset = pad + (i32)(data - data0);
+    if (out_toc) *out_toc = toc;
+    return count;
+}
+
+/* ---- decoder object ----------------------------------------------------------------------- */
+void oc_decoder_init(oc_decoder *d, int channels) { /* opus_decoder.cpp:82 */
+    oc_silk *silk = d->silk;
+    oc_celt_taps *taps = d->taps;
+    memset(d, 0, sizeof(*d));
+    d->silk = silk;
+    d->taps = taps;
+    d->channels = d->stream_channels = channels;
+    oc_silk_init(d->silk);
+    oc_celt_init(&d->celt, channels);
+    d->prev_mode = 0;
+    d->frame_size = 48000 / 400;
+}
+
+void oc_decoder_reset(oc_decoder *d) { /* opus_decoder.cpp:382 */
+    d->stream_channels = d->bandwidth = d->mode = d->prev_mode = d->frame_size = 0;
+    d->last_packet_duration = 0;
+    d->range_final = 0;
+    oc_celt_reset(&d->celt);
+    oc_silk_init(d->silk);
+    d->stream_channels = d->channels;
+    d->frame_size = 48000 / 400;
+}
+
+oc_decoder *oc_decoder_create(int channels) {
+    oc_decoder *d = (oc_decoder *)calloc(1, sizeof(*d));
+    if (!d) return NULL;
+    d->silk = (oc_silk *)calloc(1, oc_silk_sizeof());
+    if (!d->silk) {
+        free(d);
+        return NULL;
+    }
+    oc_decoder_init(d, channels);
+    return d;
+}
+
+void oc_decoder_destroy(oc_decoder *d) {
+    if (!d) return;
+    free(d->silk);
+    free(d);
+}
+
+/* opus_decoder.cpp:154 */
+static int decode_frame(oc_decoder *d, const u8 *inbuf, i32 len, i16 *out) {
+    const int mode = d->mode, ch = d->stream_channels, audiosize = 960;
+    int i, celt_ret = 0, start_band;
+    i16 pcm_silk[960 * 2];
+    oc_rc *rc = &d->rc;
+
+    oc_rc_init(rc, inbuf, len);
+    if (mode != OC_MODE_CELT) {
+        int decoded = 0, internal_hz;
+        i16 *p = pcm_silk;
+        if (d->prev_mode == OC_MODE_CELT) oc_silk_init(d->silk);
+        if (mode == OC_MODE_SILK) {
+            if (d->bandwidth == OC_BW_NB) internal_hz = 8000;
+            else if (d->bandwidth == OC_BW_MB) internal_hz = 12000;
+            else internal_hz = 16000;
+        } else
+            internal_hz = 16000;
+        do {
+            i32 n = 0;
+            int ret = oc_silk_decode(d->silk, rc, ch, internal_hz, decoded == 0, p, &n);
+            if (ret) return OC_INTERNAL_ERROR;
+            p += n * ch;
+            decoded += n;
+        } while (decoded < audiosize);
+    }
+    start_band = 0;
+    if (mode != OC_MODE_CELT && oc_rc_tell(rc) + 17 + 20 * (mode == OC_MODE_HYBRID) <= 8 * len) {
+        if (mode == OC_MODE_HYBRID) (void)oc_rc_bit_logp(rc, 12); /* redundancy flag: ignored (Q2) */
+    }
+    if (mode != OC_MODE_CELT) start_band = 17;
+    if (d->bandwidth) d->celt.stream_channels = ch; /* END_BAND request has no effect (Q1) */
+    d->celt.start_band = start_band;
+
+    if (mode != OC_MODE_SILK) {
+        if (mode != d->prev_mode && d->prev_mode > 0) oc_celt_reset(&d->celt);
+        celt_ret = oc_celt_decode(&d->celt, rc, out, audiosize, d->taps);
+    } else {
+        for (i = 0; i < audiosize * ch; i++) out[i] = 0;
+        if (d->prev_mode == OC_MODE_HYBRID) { /* Q4 */
+            d->celt.start_band = 0;
+            (void)oc_celt_decode(&d->celt, rc, out, 120, NULL);
+        }
+    }
+    if (mode != OC_MODE_CELT)
+        for (i = 0; i < audiosize * ch; i++) out[i] = sat16((i32)out[i] + pcm_silk[i]);
+    d->prev_mode = mode;
+    return celt_ret < 0 ? celt_ret : audiosize;
+}
+
+/* opus_decoder.cpp:280 (self_delimited = 0; data != NULL) */
+int oc_decode(oc_decoder *d, const u8 *data, i32 len, i16 *pcm, int frame_size) {
+    int i, nb_samples = 0, count, offset, pfs, pbw, pmode, pch;
+    i16 size[48];
+    u8 toc;
+    if (frame_size <= 0) return OC_BAD_ARG;
+    if (len <= 0 || data == NULL) return OC_BAD_ARG; /* no PLC in the reference (Q8) */
+    pmode = oc_packet_mode(data);
+    pbw = oc_packet_bandwidth(data);
+    pfs = oc_packet_samples_per_frame(data, 48000);
+    pch = oc_packet_channels(data);
+    count = oc_packet_parse(data, len, 0, &toc, size, &offset, NULL);
+    if (count < 0) return count;
+    data += offset;
+    if (count * pfs > frame_size) return OC_BUFFER_TOO_SMALL;
+    d->mode = pmode;
+    d->bandwidth = pbw;
+    d->frame_size = pfs;
+    d->stream_channels = pch;
+    for (i = 0; i < count; i++) {
+        int ret = decode_frame(d, data, size[i], pcm + nb_samples * d->channels);
+        if (ret < 0) return ret;
+        data += size[i];
+        nb_samples += ret;
+    }
+    d->last_packet_duration = nb_samples;
+    return nb_samples;
+}
