@@ -1,0 +1,335 @@
+// og_api.hip -- HIP kernels and the C ABI (include/opusgpu.h) of libopusgpu.so, gfx950 only.
+//
+// Launch shape: one workgroup == one wavefront (64 threads) == one 20 ms frame of one stream.  A
+// decode step over n streams launches n workgroups (n >> 256 CUs x 8 waves for the BASELINE configs),
+// each touching only its own stream record, so there is no inter-workgroup communication at all and
+// block -> XCD placement cannot matter for correctness; the per-stream records are private, so L2
+// affinity is not a concern either.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include <vector>
+#include "og_decode.hpp"
+#include "og_packet.hpp"
+
+using namespace og;
+
+static_assert(sizeof(opusgpu_frame_desc) == sizeof(FrameDesc), "descriptor layout");
+
+// ---- kernels --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_stream_init(StreamState *st, int first, int count, int channels, int full) {
+    const int s = first + (int)blockIdx.x;
+    if ((int)blockIdx.x >= count) return;
+    if (full)
+        stream_init(&st[s], channels);
+    else
+        stream_reset(&st[s]);
+}
+
+__global__ void __launch_bounds__(64) k_decode_step(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
+                                                   StreamState *st, i16 *pcm, i32 *result, int n, int n_streams,
+                                                   int pcm_stride) {
+    const int f = (int)blockIdx.x;
+    if (f >= n) return;
+    const FrameDesc d = descs[f];
+    int ret;
+    if (d.stream < 0 || d.stream >= n_streams) {
+        ret = BAD_ARG;
+    } else {
+        StreamState *s = &st[d.stream];
+        ret = decode_frame_wave(s, arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
+                                desc_channels(d.flags), pcm + (size_t)f * pcm_stride);
+    }
+    if (threadIdx.x == 0) result[f] = ret;
+}
+
+// ---- context ----------------------------------------------------------------------------------------
+struct opusgpu_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    StreamState *d_streams = nullptr;
+    int n_streams = 0, channels = 0;
+    // staging for the host-buffer path
+    void *d_descs = nullptr, *d_arena = nullptr, *d_pcm = nullptr, *d_result = nullptr;
+    size_t cap_descs = 0, cap_arena = 0, cap_pcm = 0, cap_result = 0;
+    char err[256] = {0};
+};
+
+static int fail(opusgpu_ctx *ctx, int code, const char *what, hipError_t e) {
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s: %s", what, hipGetErrorString(e));
+    return code;
+}
+#define HIPCHK(ctx, call)                                                \
+    do {                                                                 \
+        hipError_t e_ = (call);                                          \
+        if (e_ != hipSuccess) return fail(ctx, OPUSGPU_ERR_HIP, #call, e_); \
+    } while (0)
+
+extern "C" {
+
+int opusgpu_version(void) { return 100; }
+
+int opusgpu_ctx_create(int device, opusgpu_ctx **out) {
+    if (!out || device < 0) return OPUSGPU_BAD_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device >= count) return OPUSGPU_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return OPUSGPU_ERR_NO_DEVICE;
+    // the code object is gfx950-only: make sure the kernel image is loadable on this device
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k_decode_step)) != hipSuccess) {
+        (void)hipGetLastError();
+        return OPUSGPU_ERR_NO_DEVICE;
+    }
+    opusgpu_ctx *ctx = new (std::nothrow) opusgpu_ctx();
+    if (!ctx) return OPUSGPU_ALLOC_FAIL;
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return OPUSGPU_ERR_HIP;
+    }
+    *out = ctx;
+    return OPUSGPU_OK;
+}
+
+void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->d_streams);
+    (void)hipFree(ctx->d_descs);
+    (void)hipFree(ctx->d_arena);
+    (void)hipFree(ctx->d_pcm);
+    (void)hipFree(ctx->d_result);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *opusgpu_last_error(const opusgpu_ctx *ctx) { return ctx ? ctx->err : "no context"; }
+size_t opusgpu_stream_state_bytes(void) { return sizeof(StreamState); }
+int opusgpu_stream_count(const opusgpu_ctx *ctx) { return ctx ? ctx->n_streams : 0; }
+int opusgpu_stream_channels(const opusgpu_ctx *ctx) { return ctx ? ctx->channels : 0; }
+
+int opusgpu_streams_reset(opusgpu_ctx *ctx, int first, int count, int full) {
+    if (!ctx || first < 0 || count < 0 || first + count > ctx->n_streams) return OPUSGPU_BAD_ARG;
+    if (count == 0) return OPUSGPU_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_stream_init, dim3(count), dim3(64), 0, ctx->stream, ctx->d_streams, first, count, ctx->channels,
+                       full ? 1 : 0);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return OPUSGPU_OK;
+}
+
+int opusgpu_streams_alloc(opusgpu_ctx *ctx, int n_streams, int channels) {
+    if (!ctx || n_streams <= 0 || (channels != 1 && channels != 2)) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_streams) {
+        HIPCHK(ctx, hipFree(ctx->d_streams));
+        ctx->d_streams = nullptr;
+        ctx->n_streams = 0;
+    }
+    hipError_t e = hipMalloc((void **)&ctx->d_streams, sizeof(StreamState) * (size_t)n_streams);
+    if (e != hipSuccess) return fail(ctx, OPUSGPU_ALLOC_FAIL, "hipMalloc(streams)", e);
+    ctx->n_streams = n_streams;
+    ctx->channels = channels;
+    return opusgpu_streams_reset(ctx, 0, n_streams, 1);
+}
+
+int opusgpu_dev_alloc(opusgpu_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 4);
+    if (e != hipSuccess) return fail(ctx, OPUSGPU_ALLOC_FAIL, "hipMalloc", e);
+    return OPUSGPU_OK;
+}
+int opusgpu_dev_free(opusgpu_ctx *ctx, void *dptr) {
+    if (!ctx) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipFree(dptr));
+    return OPUSGPU_OK;
+}
+int opusgpu_memcpy_h2d(opusgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return OPUSGPU_OK;
+}
+int opusgpu_memcpy_d2h(opusgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return OPUSGPU_OK;
+}
+
+int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm,
+                               void *d_result, void *hip_stream) {
+    if (!ctx || n < 0 || !ctx->d_streams) return OPUSGPU_BAD_ARG;
+    if (n == 0) return OPUSGPU_OK;
+    if (!d_descs || !d_arena || !d_pcm || !d_result) return OPUSGPU_BAD_ARG;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
+                       ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams,
+                       OPUSGPU_FRAME_SAMPLES * ctx->channels);
+    HIPCHK(ctx, hipGetLastError());
+    return OPUSGPU_OK;
+}
+
+int opusgpu_synchronize(opusgpu_ctx *ctx) {
+    if (!ctx) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return OPUSGPU_OK;
+}
+
+int opusgpu_event_create(opusgpu_ctx *ctx, void **event) {
+    if (!ctx || !event) return OPUSGPU_BAD_ARG;
+    hipEvent_t e;
+    HIPCHK(ctx, hipEventCreate(&e));
+    *event = (void *)e;
+    return OPUSGPU_OK;
+}
+int opusgpu_event_record(opusgpu_ctx *ctx, void *event) {
+    if (!ctx || !event) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipEventRecord((hipEvent_t)event, ctx->stream));
+    return OPUSGPU_OK;
+}
+int opusgpu_event_elapsed_ms(opusgpu_ctx *ctx, void *start, void *stop, float *ms) {
+    if (!ctx || !start || !stop || !ms) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipEventSynchronize((hipEvent_t)stop));
+    HIPCHK(ctx, hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return OPUSGPU_OK;
+}
+int opusgpu_event_destroy(opusgpu_ctx *ctx, void *event) {
+    if (!ctx || !event) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipEventDestroy((hipEvent_t)event));
+    return OPUSGPU_OK;
+}
+
+int opusgpu_stream_state_get(opusgpu_ctx *ctx, int index, void *dst, size_t bytes) {
+    if (!ctx || !dst || index < 0 || index >= ctx->n_streams || bytes > sizeof(StreamState)) return OPUSGPU_BAD_ARG;
+    return opusgpu_memcpy_d2h(ctx, dst, &ctx->d_streams[index], bytes);
+}
+
+int opusgpu_packet_to_frames(const uint8_t *packet, int32_t len, int32_t stream, opusgpu_frame_desc descs[48]) {
+    if (!packet || !descs) return OPUSGPU_BAD_ARG;
+    if (len <= 0) return len == 0 ? OPUSGPU_INVALID_PACKET : OPUSGPU_BAD_ARG;
+    int16_t size[48];
+    uint8_t toc;
+    int offset = 0;
+    const int count = ogh::parse_packet(packet, len, 0, &toc, size, &offset, nullptr);
+    if (count < 0) return count;
+    const int32_t flags = ogh::toc_flags(toc);
+    for (int i = 0; i < count; i++) {
+        descs[i].stream = stream;
+        descs[i].offset = offset;
+        descs[i].len = size[i];
+        descs[i].flags = flags;
+        offset += size[i];
+    }
+    return count;
+}
+
+static int grow(opusgpu_ctx *ctx, void **p, size_t *cap, size_t need) {
+    if (*cap >= need) return OPUSGPU_OK;
+    if (*p) HIPCHK(ctx, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    size_t want = need + need / 2 + 256;
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) return fail(ctx, OPUSGPU_ALLOC_FAIL, "hipMalloc(staging)", e);
+    *cap = want;
+    return OPUSGPU_OK;
+}
+
+int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, const uint8_t *const *packets,
+                           const int32_t *lens, int16_t *pcm, int frame_capacity, int32_t *result) {
+    if (!ctx || n < 0 || !ctx->d_streams) return OPUSGPU_BAD_ARG;
+    if (n == 0) return OPUSGPU_OK;
+    if (!stream_ids || !packets || !lens || !pcm || !result || frame_capacity <= 0) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int CC = ctx->channels;
+    const size_t frame_pcm = (size_t)OPUSGPU_FRAME_SAMPLES * CC;
+    // 1. frame the packets on the host (opus_decode_native, src/opus_decoder.cpp:280-348)
+    std::vector<opusgpu_frame_desc> all;   // frames in (packet, frame) order
+    std::vector<int> first(n + 1, 0), nframes(n, 0);
+    std::vector<uint8_t> arena;
+    all.reserve(n);
+    int max_frames = 0;
+    for (int i = 0; i < n; i++) {
+        first[i] = (int)all.size();
+        result[i] = 0;
+        if (stream_ids[i] < 0 || stream_ids[i] >= ctx->n_streams || !packets[i] || lens[i] <= 0) {
+            result[i] = OPUSGPU_BAD_ARG; // no PLC in the reference: data==NULL/len==0 ends in an error (Q8)
+            continue;
+        }
+        opusgpu_frame_desc d[48];
+        const int count = opusgpu_packet_to_frames(packets[i], lens[i], stream_ids[i], d);
+        if (count < 0) {
+            result[i] = count;
+            continue;
+        }
+        // count * packet_frame_size > frame_size -> OPUS_BUFFER_TOO_SMALL (src/opus_decoder.cpp:323)
+        const int pfs = ogh::toc_samples_per_frame(packets[i][0], 48000);
+        if ((int64_t)count * pfs > (int64_t)frame_capacity * OPUSGPU_FRAME_SAMPLES || count > frame_capacity) {
+            result[i] = OPUSGPU_BUFFER_TOO_SMALL;
+            continue;
+        }
+        const size_t base = arena.size();
+        arena.insert(arena.end(), packets[i], packets[i] + lens[i]);
+        for (int k = 0; k < count; k++) {
+            d[k].offset += (int32_t)base;
+            all.push_back(d[k]);
+        }
+        nframes[i] = count;
+        if (count > max_frames) max_frames = count;
+    }
+    first[n] = (int)all.size();
+    if (all.empty()) return OPUSGPU_OK;
+    // 2. upload the arena once; run one step per frame index (frames of one packet are sequential)
+    int rc = grow(ctx, &ctx->d_arena, &ctx->cap_arena, arena.size() + 16);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_arena, arena.data(), arena.size(), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<opusgpu_frame_desc> step;
+    std::vector<int> owner;
+    std::vector<int16_t> h_pcm;
+    std::vector<int32_t> h_res;
+    for (int k = 0; k < max_frames; k++) {
+        step.clear();
+        owner.clear();
+        for (int i = 0; i < n; i++)
+            if (nframes[i] > k && result[i] >= 0) {
+                step.push_back(all[first[i] + k]);
+                owner.push_back(i);
+            }
+        const int m = (int)step.size();
+        if (m == 0) break;
+        if ((rc = grow(ctx, &ctx->d_descs, &ctx->cap_descs, sizeof(opusgpu_frame_desc) * m))) return rc;
+        if ((rc = grow(ctx, &ctx->d_pcm, &ctx->cap_pcm, frame_pcm * 2 * m))) return rc;
+        if ((rc = grow(ctx, &ctx->d_result, &ctx->cap_result, sizeof(int32_t) * m))) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_descs, step.data(), sizeof(opusgpu_frame_desc) * m, hipMemcpyHostToDevice,
+                                   ctx->stream));
+        rc = opusgpu_decode_step_device(ctx, m, ctx->d_descs, ctx->d_arena, ctx->d_pcm, ctx->d_result, nullptr);
+        if (rc) return rc;
+        h_pcm.resize(frame_pcm * m);
+        h_res.resize(m);
+        HIPCHK(ctx, hipMemcpyAsync(h_pcm.data(), ctx->d_pcm, frame_pcm * 2 * m, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(h_res.data(), ctx->d_result, sizeof(int32_t) * m, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int j = 0; j < m; j++) {
+            const int i = owner[j];
+            if (h_res[j] < 0) {
+                result[i] = h_res[j];
+                continue;
+            }
+            memcpy(pcm + ((size_t)i * frame_capacity + k) * frame_pcm, &h_pcm[(size_t)j * frame_pcm], frame_pcm * 2);
+            result[i] += h_res[j];
+        }
+    }
+    return OPUSGPU_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,835 @@
+// og_celt.hpp -- CELT frame decoder, one frame per wavefront.
+//
+// Flow per frame (reference driver: celt_decode_with_ec, src/celt.cpp:2162-2446):
+//   [scalar, wave-uniform]  header flags, coarse energy (Laplace), tf flags, dynalloc, allocation,
+//                           fine energy; band loop (og_celt_bands.hpp) with lane-parallel vector ops
+//   [lane-parallel]         denormalise + IMDCT pre-rotation straight from X (no `freq` array),
+//                           mixed-radix FFT in LDS (all 8 short blocks side by side), post-rotation,
+//                           TDAC windowing, pitch comb filter (chunked by the filter lag),
+//   [one lane per channel]  de-emphasis IIR (non-linear rounding => serial), PCM staged in LDS and
+//                           written out coalesced.
+// HBM traffic per frame: packet in, PCM out, 60-sample IMDCT tail + <= 1024+2 samples of comb history
+// read, 960 new history samples + tail + ~300 B of scalars written, per channel.
+#pragma once
+#include "og_celt_bands.hpp"
+
+namespace og {
+
+// ---- energies (src/celt.cpp:3613-3700) ------------------------------------------------------------
+OG_DEVN void coarse_energy(Rc &rc, int start, int end, int intra, int C, int LM) {
+    const u8 *pm = rom_eprob + (LM * 2 + intra) * 42;
+    i32 prev[2] = {0, 0};
+    i32 coef, beta;
+    if (intra) {
+        coef = 0;
+        beta = 4915;
+    } else {
+        beta = LM == 0 ? 30147 : LM == 1 ? 22282 : LM == 2 ? 12124 : 6554;
+        coef = LM == 0 ? 29440 : LM == 1 ? 26112 : LM == 2 ? 21248 : 16384;
+    }
+    const i32 budget = (i32)rc.storage * 8;
+    for (int i = start; i < end; i++) {
+        for (int c = 0; c < C; c++) {
+            int qi;
+            i32 tell = rc_tell(rc);
+            if (budget - tell >= 15) {
+                int pi = 2 * OG_MIN(i, 20);
+                qi = rc_laplace(rc, (u32)pm[pi] << 7, (int)pm[pi + 1] << 6);
+            } else if (budget - tell >= 2) {
+                // small_energy_icdf {2,1,0}, ftb 2
+                u32 s = rc.rng, d = rc.val, r = s >> 2, t;
+                int ret = -1;
+                do {
+                    t = s;
+                    ++ret;
+                    s = r * (u32)(2 - ret);
+                } while (d < s);
+                rc.val = d - s;
+                rc.rng = t - s;
+                rc_renorm(rc);
+                qi = (ret >> 1) ^ -(ret & 1);
+            } else if (budget - tell >= 1) {
+                qi = -rc_bit_logp(rc, 1);
+            } else
+                qi = -1;
+            i32 q = shl32(qi, 10);
+            i32 e = OG_MAX(-9 * 1024, (i32)S.bandE[i + c * NBANDS]);
+            i32 tmp = pshr32(mul16(coef, e), 8) + prev[c] + shl32(q, 7);
+            tmp = OG_MAX(-(28 << 17), tmp);
+            S.bandE[i + c * NBANDS] = (i16)pshr32(tmp, 7);
+            prev[c] = prev[c] + shl32(q, 7) - mul16(beta, pshr32(q, 8));
+        }
+    }
+}
+
+OG_DEV void fine_energy(Rc &rc, int start, int end, int C) {
+    for (int i = start; i < end; i++) {
+        int fq = S.fine_quant[i];
+        if (fq <= 0) continue;
+        for (int c = 0; c < C; c++) {
+            i32 q2 = (i32)rc_bits(rc, fq);
+            i32 offset = tr16(sub16((shl32(q2, 10) + 512) >> fq, 512));
+            S.bandE[i + c * NBANDS] = (i16)(S.bandE[i + c * NBANDS] + offset);
+        }
+    }
+}
+
+OG_DEV void energy_finalise(Rc &rc, int start, int end, int bits_left, int C) {
+    for (int prio = 0; prio < 2; prio++) {
+        for (int i = start; i < end && bits_left >= C; i++) {
+            if (S.fine_quant[i] >= 8 || S.fine_prio[i] != prio) continue;
+            for (int c = 0; c < C; c++) {
+                i32 q2 = (i32)rc_bits(rc, 1);
+                i32 offset = tr16((shl16(q2, 10) - 512) >> (S.fine_quant[i] + 1));
+                S.bandE[i + c * NBANDS] = (i16)(S.bandE[i + c * NBANDS] + offset);
+                bits_left--;
+            }
+        }
+    }
+}
+
+// tf_select_table (celt.cpp:903) for LM, index 4*transient + 2*tf_select + flag
+OG_DEV int tf_select(int LM, int idx) {
+    // rows packed as 8 signed nibbles, entry k at bits 4k
+    const u32 row0 = 0xF0F0F0F0u, row1 = 0xF101E0F0u, row2 = 0xF102D0E0u, row3 = 0xF103D0E0u;
+    u32 row = LM == 0 ? row0 : LM == 1 ? row1 : LM == 2 ? row2 : row3;
+    int v = (int)((row >> (4 * idx)) & 15);
+    return v >= 8 ? v - 16 : v;
+}
+
+OG_DEVN void tf_decode(Rc &rc, int start, int end, int transient, int LM) { // celt.cpp:2128
+    int curr = 0, tf_sel = 0, tf_changed = 0;
+    int logp = transient ? 2 : 4;
+    u32 budget = rc.storage * 8, tell = (u32)rc_tell(rc);
+    int rsv = LM > 0 && tell + logp + 1 <= budget;
+    budget -= rsv;
+    for (int i = start; i < end; i++) {
+        if (tell + logp <= budget) {
+            curr ^= rc_bit_logp(rc, logp);
+            tell = (u32)rc_tell(rc);
+            tf_changed |= curr;
+        }
+        S.tf_res[i] = curr;
+        logp = transient ? 4 : 5;
+    }
+    if (rsv && tf_select(LM, 4 * transient + 0 + tf_changed) != tf_select(LM, 4 * transient + 2 + tf_changed))
+        tf_sel = rc_bit_logp(rc, 1);
+    for (int i = start; i < end; i++) S.tf_res[i] = tf_select(LM, 4 * transient + 2 * tf_sel + S.tf_res[i]);
+}
+
+// ---- bit allocation (clt_compute_allocation celt.cpp:3523, interp_bits2pulses :3298) ----------------
+OG_DEVN int compute_allocation(Rc &rc, int start, int end, int alloc_trim, i32 &intensity, i32 &dual_stereo, i32 total,
+                               i32 &balance_out, int C, int LM) {
+    const i16 *eb = rom_eband;
+    int skip_start = start, intensity_rsv = 0, dual_stereo_rsv = 0;
+    total = OG_MAX(total, 0);
+    int skip_rsv = total >= 1 << BITRES ? 1 << BITRES : 0;
+    total -= skip_rsv;
+    if (C == 2) {
+        intensity_rsv = rom_log2_frac[end - start];
+        if (intensity_rsv > total)
+            intensity_rsv = 0;
+        else {
+            total -= intensity_rsv;
+            dual_stereo_rsv = total >= 1 << BITRES ? 1 << BITRES : 0;
+            total -= dual_stereo_rsv;
+        }
+    }
+    for (int j = start; j < end; j++) {
+        int w = eb[j + 1] - eb[j];
+        S.thresh[j] = OG_MAX(C << BITRES, (3 * w << LM << BITRES) >> 4);
+        i32 to = C * w * (alloc_trim - 5 - LM) * (end - j - 1) * (1 << (LM + BITRES)) >> 6;
+        if (w << LM == 1) to -= C << BITRES;
+        S.trim_off[j] = to;
+    }
+    int lo = 1, hi = 10;
+    do {
+        int done = 0, mid = (lo + hi) >> 1;
+        i32 psum = 0;
+        for (int j = end; j-- > start;) {
+            int w = eb[j + 1] - eb[j];
+            i32 bitsj = C * w * rom_band_alloc[mid * NBANDS + j] << LM >> 2;
+            if (bitsj > 0) bitsj = OG_MAX(0, bitsj + S.trim_off[j]);
+            bitsj += S.offsets[j];
+            if (bitsj >= S.thresh[j] || done) {
+                done = 1;
+                psum += OG_MIN(bitsj, S.cap[j]);
+            } else if (bitsj >= C << BITRES)
+                psum += C << BITRES;
+        }
+        if (psum > total) hi = mid - 1; else lo = mid + 1;
+    } while (lo <= hi);
+    hi = lo--;
+    for (int j = start; j < end; j++) {
+        int w = eb[j + 1] - eb[j];
+        i32 b1 = C * w * rom_band_alloc[lo * NBANDS + j] << LM >> 2;
+        i32 b2 = hi >= 11 ? S.cap[j] : C * w * rom_band_alloc[hi * NBANDS + j] << LM >> 2;
+        if (b1 > 0) b1 = OG_MAX(0, b1 + S.trim_off[j]);
+        if (b2 > 0) b2 = OG_MAX(0, b2 + S.trim_off[j]);
+        if (lo > 0) b1 += S.offsets[j];
+        b2 += S.offsets[j];
+        if (S.offsets[j] > 0) skip_start = j;
+        b2 = OG_MAX(0, b2 - b1);
+        S.bits1[j] = b1;
+        S.bits2[j] = b2;
+    }
+    // ---- interpolation between the two allocation vectors
+    const int alloc_floor = C << BITRES, stereo = C > 1, logM = LM << BITRES;
+    i32 psum;
+    lo = 0;
+    hi = 1 << 6;
+    for (int i = 0; i < 6; i++) {
+        int mid = (lo + hi) >> 1, done = 0;
+        psum = 0;
+        for (int j = end; j-- > start;) {
+            i32 tmp = S.bits1[j] + (mid * S.bits2[j] >> 6);
+            if (tmp >= S.thresh[j] || done) {
+                done = 1;
+                psum += OG_MIN(tmp, S.cap[j]);
+            } else if (tmp >= alloc_floor)
+                psum += alloc_floor;
+        }
+        if (psum > total) hi = mid; else lo = mid;
+    }
+    psum = 0;
+    {
+        int done = 0;
+        for (int j = end; j-- > start;) {
+            i32 tmp = S.bits1[j] + (lo * S.bits2[j] >> 6);
+            if (tmp < S.thresh[j] && !done)
+                tmp = tmp >= alloc_floor ? alloc_floor : 0;
+            else
+                done = 1;
+            tmp = OG_MIN(tmp, S.cap[j]);
+            S.pulses[j] = tmp;
+            psum += tmp;
+        }
+    }
+    int codedBands;
+    for (codedBands = end;; codedBands--) {
+        int j = codedBands - 1;
+        if (j <= skip_start) {
+            total += skip_rsv;
+            break;
+        }
+        i32 left = total - psum;
+        i32 percoeff = (i32)udiv((u32)left, (u32)(eb[codedBands] - eb[start]));
+        left -= (eb[codedBands] - eb[start]) * percoeff;
+        i32 rem = OG_MAX(left - (eb[j] - eb[start]), 0);
+        i32 band_width = eb[codedBands] - eb[j];
+        i32 band_bits = S.pulses[j] + percoeff * band_width + rem;
+        if (band_bits >= OG_MAX(S.thresh[j], alloc_floor + (1 << BITRES))) {
+            if (rc_bit_logp(rc, 1)) break;
+            psum += 1 << BITRES;
+            band_bits -= 1 << BITRES;
+        }
+        psum -= S.pulses[j] + intensity_rsv;
+        if (intensity_rsv > 0) intensity_rsv = rom_log2_frac[j - start];
+        psum += intensity_rsv;
+        if (band_bits >= alloc_floor) {
+            psum += alloc_floor;
+            S.pulses[j] = alloc_floor;
+        } else
+            S.pulses[j] = 0;
+    }
+    if (intensity_rsv > 0)
+        intensity = start + (i32)rc_uint(rc, codedBands + 1 - start);
+    else
+        intensity = 0;
+    if (intensity <= start) {
+        total += dual_stereo_rsv;
+        dual_stereo_rsv = 0;
+    }
+    dual_stereo = dual_stereo_rsv > 0 ? rc_bit_logp(rc, 1) : 0;
+
+    i32 left = total - psum;
+    i32 percoeff = (i32)udiv((u32)left, (u32)(eb[codedBands] - eb[start]));
+    left -= (eb[codedBands] - eb[start]) * percoeff;
+    for (int j = start; j < codedBands; j++) S.pulses[j] += percoeff * (eb[j + 1] - eb[j]);
+    for (int j = start; j < codedBands; j++) {
+        i32 tmp = OG_MIN(left, (i32)(eb[j + 1] - eb[j]));
+        S.pulses[j] += tmp;
+        left -= tmp;
+    }
+    i32 balance = 0;
+    int j;
+    for (j = start; j < codedBands; j++) {
+        i32 N0 = eb[j + 1] - eb[j], N = N0 << LM, excess;
+        i32 bit = S.pulses[j] + balance, bj, ej, fp;
+        if (N > 1) {
+            excess = OG_MAX(bit - S.cap[j], 0);
+            bj = bit - excess;
+            i32 den = C * N + ((C == 2 && N > 2 && !dual_stereo && j < intensity) ? 1 : 0);
+            i32 NClogN = den * (rom_logn[j] + logM);
+            i32 offset = (NClogN >> 1) - den * 21;
+            if (N == 2) offset += den << BITRES >> 2;
+            if (bj + offset < den * 2 << BITRES)
+                offset += NClogN >> 2;
+            else if (bj + offset < den * 3 << BITRES)
+                offset += NClogN >> 3;
+            ej = OG_MAX(0, bj + offset + (den << (BITRES - 1)));
+            ej = (i32)udiv((u32)ej, (u32)den) >> BITRES;
+            if (C * ej > (bj >> BITRES)) ej = bj >> stereo >> BITRES;
+            ej = OG_MIN(ej, 8);
+            fp = ej * (den << BITRES) >= bj + offset;
+            bj -= C * ej << BITRES;
+        } else {
+            excess = OG_MAX(0, bit - (C << BITRES));
+            bj = bit - excess;
+            ej = 0;
+            fp = 1;
+        }
+        if (excess > 0) {
+            i32 extra_fine = OG_MIN(excess >> (stereo + BITRES), 8 - ej);
+            ej += extra_fine;
+            i32 extra_bits = extra_fine * C << BITRES;
+            fp = extra_bits >= excess - balance;
+            excess -= extra_bits;
+        }
+        balance = excess;
+        S.pulses[j] = bj;
+        S.fine_quant[j] = ej;
+        S.fine_prio[j] = fp;
+    }
+    balance_out = balance;
+    for (; j < end; j++) {
+        i32 ej = S.pulses[j] >> stereo >> BITRES;
+        S.fine_quant[j] = ej;
+        S.pulses[j] = 0;
+        S.fine_prio[j] = ej < 1;
+    }
+    return codedBands;
+}
+
+// ---- synthesis ------------------------------------------------------------------------------------
+// Per-band linear gain for denormalise_bands (celt.cpp:948): g = 2^frac(lg), applied with a shift.
+OG_DEV void denorm_gains(int start, int end, int C, int silence) {
+    OG_SYNC();
+    OG_FOR_LANES(id, C * NBANDS) {
+        int c = id / NBANDS, i = id - c * NBANDS;
+        i32 g = 0, shift = 0;
+        if (!silence && i >= start && i < end) {
+            i32 lg = sat16((i32)S.bandE[c * NBANDS + i] + shl32((i32)rom_emeans[i], 6));
+            shift = 16 - (lg >> 10);
+            if (shift > 31) {
+                shift = 0;
+                g = 0;
+            } else
+                g = tr16(exp2_frac(lg & 1023));
+            if (shift < 0 && shift <= -2) { // extreme gains are capped (celt.cpp:991)
+                g = 16384;
+                shift = -2;
+            }
+        }
+        S.dn_g[id] = (i16)g;
+        S.dn_shift[id] = (i16)shift;
+    }
+    OG_FOR_LANES(bin, 100) { // 5 ms bin -> band
+        int b = 0;
+        while (rom_eband[b + 1] <= bin) b++;
+        S.bin2band[bin] = (u8)b;
+    }
+    OG_SYNC();
+}
+
+// denormalised MDCT coefficient j (0..N) of coded channel c
+OG_DEV i32 freq_coded(int c, int j, int N, int LM) {
+    int bin = j >> LM;
+    if (bin >= 100) return 0;
+    int band = S.bin2band[bin];
+    i32 g = S.dn_g[c * NBANDS + band], sh = S.dn_shift[c * NBANDS + band];
+    i32 p = mul16(S.v[V_X + c * N + j], g);
+    return sh < 0 ? shl32(p, -sh) : p >> sh;
+}
+// ... of OUTPUT channel co given the stream/decoder channel combination (celt_synthesis celt.cpp:2085-2119)
+OG_DEV i32 freq_out(int co, int j, int N, int LM, int C, int CC) {
+    if (CC == 2 && C == 1) return freq_coded(0, j, N, LM);
+    if (CC == 1 && C == 2) return addw(freq_coded(0, j, N, LM) >> 1, freq_coded(1, j, N, LM) >> 1);
+    return freq_coded(co, j, N, LM);
+}
+
+#define OG_SMUL(a, b) mul16x32_q15((b), (a)) /* S_MUL celt.h:192 */
+
+struct Cpx { i32 r, i; };
+OG_DEV Cpx cld(const i32 *p, int k) { Cpx v = {p[2 * k], p[2 * k + 1]}; return v; }
+OG_DEV void cst(i32 *p, int k, Cpx v) { p[2 * k] = v.r; p[2 * k + 1] = v.i; }
+OG_DEV Cpx cadd(Cpx a, Cpx b) { Cpx r = {addw(a.r, b.r), addw(a.i, b.i)}; return r; }
+OG_DEV Cpx csub(Cpx a, Cpx b) { Cpx r = {subw(a.r, b.r), subw(a.i, b.i)}; return r; }
+OG_DEV Cpx ctw(Cpx a, int tw) { // C_MUL celt.h:193 by twiddle index on the 480-point circle
+    i32 wr = rom_fft_tw[2 * tw], wi = rom_fft_tw[2 * tw + 1];
+    Cpx m = {subw(OG_SMUL(a.r, wr), OG_SMUL(a.i, wi)), addw(OG_SMUL(a.r, wi), OG_SMUL(a.i, wr))};
+    return m;
+}
+
+// One radix-p stage over `nfft_blocks` independent transforms of `nfft` points laid out `blk_stride`
+// i32 apart.  Butterfly (i, j): i in [0, Nrep), j in [0, m); element base i*mm + j.  Lanes split the
+// (block, i, j) space.  Arithmetic per butterfly = kf_bfly2/3/4/5 (celt.cpp:2794-2995).
+OG_DEV void fft_stage(i32 *base, int nblk, int blk_stride, int p, int m, int Nrep, int mm, int fstride) {
+    const int per_blk = (p == 2) ? Nrep * 4 : Nrep * m; // radix-2 stage always has m == 4
+    OG_SYNC();
+    OG_FOR_LANES(id, nblk * per_blk) {
+        int blk = id / per_blk, r = id - blk * per_blk;
+        i32 *F = base + blk * blk_stride;
+        if (p == 4) {
+            int i = r / m, j = r - i * m, o = i * mm + j;
+            if (m == 1) {
+                Cpx f0 = cld(F, o), f1 = cld(F, o + 1), f2 = cld(F, o + 2), f3 = cld(F, o + 3);
+                Cpx s0 = csub(f0, f2);
+                f0 = cadd(f0, f2);
+                Cpx s1 = cadd(f1, f3);
+                f2 = csub(f0, s1);
+                f0 = cadd(f0, s1);
+                s1 = csub(f1, f3);
+                f1.r = addw(s0.r, s1.i);
+                f1.i = subw(s0.i, s1.r);
+                f3.r = subw(s0.r, s1.i);
+                f3.i = addw(s0.i, s1.r);
+                cst(F, o, f0); cst(F, o + 1, f1); cst(F, o + 2, f2); cst(F, o + 3, f3);
+            } else {
+                Cpx f0 = cld(F, o);
+                Cpx a = ctw(cld(F, o + m), j * fstride), b = ctw(cld(F, o + 2 * m), 2 * j * fstride),
+                    c = ctw(cld(F, o + 3 * m), 3 * j * fstride);
+                Cpx s5 = csub(f0, b);
+                f0 = cadd(f0, b);
+                Cpx s3 = cadd(a, c), s4 = csub(a, c);
+                Cpx f2 = csub(f0, s3);
+                f0 = cadd(f0, s3);
+                Cpx f1 = {addw(s5.r, s4.i), subw(s5.i, s4.r)}, f3 = {subw(s5.r, s4.i), addw(s5.i, s4.r)};
+                cst(F, o, f0); cst(F, o + m, f1); cst(F, o + 2 * m, f2); cst(F, o + 3 * m, f3);
+            }
+        } else if (p == 2) {
+            // pairs (q, q+4) inside groups of 8; q selects the fixed twiddle 1, e^{-i pi/4}, -i, e^{-3i pi/4}
+            int i = r >> 2, q = r & 3, o = i * 8 + q;
+            Cpx a = cld(F, o), b = cld(F, o + 4), t;
+            const i32 tw = 23170;
+            if (q == 0)
+                t = b;
+            else if (q == 1) {
+                t.r = OG_SMUL(addw(b.r, b.i), tw);
+                t.i = OG_SMUL(subw(b.i, b.r), tw);
+            } else if (q == 2) {
+                t.r = b.i;
+                t.i = negw(b.r);
+            } else {
+                t.r = OG_SMUL(subw(b.i, b.r), tw);
+                t.i = OG_SMUL(negw(addw(b.i, b.r)), tw);
+            }
+            cst(F, o + 4, csub(a, t));
+            cst(F, o, cadd(a, t));
+        } else if (p == 3) {
+            int i = r / m, j = r - i * m, o = i * mm + j;
+            Cpx f0 = cld(F, o);
+            Cpx s1 = ctw(cld(F, o + m), j * fstride), s2 = ctw(cld(F, o + 2 * m), 2 * j * fstride);
+            Cpx s3 = cadd(s1, s2), s0 = csub(s1, s2);
+            Cpx f1 = {subw(f0.r, s3.r >> 1), subw(f0.i, s3.i >> 1)};
+            s0.r = OG_SMUL(s0.r, -28378);
+            s0.i = OG_SMUL(s0.i, -28378);
+            f0 = cadd(f0, s3);
+            Cpx f2 = {addw(f1.r, s0.i), subw(f1.i, s0.r)};
+            f1.r = subw(f1.r, s0.i);
+            f1.i = addw(f1.i, s0.r);
+            cst(F, o, f0); cst(F, o + m, f1); cst(F, o + 2 * m, f2);
+        } else { // p == 5
+            int i = r / m, u = r - i * m, o = i * mm + u;
+            const i32 ya_r = 10126, ya_i = -31164, yb_r = -26510, yb_i = -19261;
+            Cpx s0 = cld(F, o);
+            Cpx s1 = ctw(cld(F, o + m), u * fstride), s2 = ctw(cld(F, o + 2 * m), 2 * u * fstride);
+            Cpx s3 = ctw(cld(F, o + 3 * m), 3 * u * fstride), s4 = ctw(cld(F, o + 4 * m), 4 * u * fstride);
+            Cpx s7 = cadd(s1, s4), s10 = csub(s1, s4), s8 = cadd(s2, s3), s9 = csub(s2, s3);
+            Cpx f0 = {addw(s0.r, addw(s7.r, s8.r)), addw(s0.i, addw(s7.i, s8.i))};
+            Cpx s5 = {addw(s0.r, addw(OG_SMUL(s7.r, ya_r), OG_SMUL(s8.r, yb_r))),
+                      addw(s0.i, addw(OG_SMUL(s7.i, ya_r), OG_SMUL(s8.i, yb_r)))};
+            Cpx s6 = {addw(OG_SMUL(s10.i, ya_i), OG_SMUL(s9.i, yb_i)),
+                      negw(addw(OG_SMUL(s10.r, ya_i), OG_SMUL(s9.r, yb_i)))};
+            Cpx s11 = {addw(s0.r, addw(OG_SMUL(s7.r, yb_r), OG_SMUL(s8.r, ya_r))),
+                       addw(s0.i, addw(OG_SMUL(s7.i, yb_r), OG_SMUL(s8.i, ya_r)))};
+            Cpx s12 = {subw(OG_SMUL(s9.i, ya_i), OG_SMUL(s10.i, yb_i)), subw(OG_SMUL(s10.r, yb_i), OG_SMUL(s9.r, ya_i))};
+            cst(F, o, f0);
+            cst(F, o + m, csub(s5, s6));
+            cst(F, o + 4 * m, cadd(s5, s6));
+            cst(F, o + 2 * m, cadd(s11, s12));
+            cst(F, o + 3 * m, csub(s11, s12));
+        }
+    }
+    OG_SYNC();
+}
+
+// all stages of the 480- or 60-point transform (opus_fft_impl celt.cpp:2997; factor schedules :589-626)
+OG_DEV void fft_blocks(i32 *base, int nblk, int blk_stride, int shift) {
+    if (shift == 0) { // 480 = 5*3*4*2*4: innermost radix first
+        fft_stage(base, nblk, blk_stride, 4, 1, 120, 4, 120);
+        fft_stage(base, nblk, blk_stride, 2, 4, 60, 8, 60);
+        fft_stage(base, nblk, blk_stride, 4, 8, 15, 32, 15);
+        fft_stage(base, nblk, blk_stride, 3, 32, 5, 96, 5);
+        fft_stage(base, nblk, blk_stride, 5, 96, 1, 1, 1);
+    } else if (shift == 3) { // 60 = 5*3*4; twiddle stride scaled by 8
+        fft_stage(base, nblk, blk_stride, 4, 1, 15, 4, 15 << 3);
+        fft_stage(base, nblk, blk_stride, 3, 4, 5, 12, 5 << 3);
+        fft_stage(base, nblk, blk_stride, 5, 12, 1, 1, 1 << 3);
+    } else if (shift == 1) { // 240 = 5*3*4*4
+        fft_stage(base, nblk, blk_stride, 4, 1, 60, 4, 60 << 1);
+        fft_stage(base, nblk, blk_stride, 4, 4, 15, 16, 15 << 1);
+        fft_stage(base, nblk, blk_stride, 3, 16, 5, 48, 5 << 1);
+        fft_stage(base, nblk, blk_stride, 5, 48, 1, 1, 1 << 1);
+    } else { // 120 = 5*3*2*4
+        fft_stage(base, nblk, blk_stride, 4, 1, 30, 4, 30 << 2);
+        fft_stage(base, nblk, blk_stride, 2, 4, 15, 8, 15 << 2);
+        fft_stage(base, nblk, blk_stride, 3, 8, 5, 24, 5 << 2);
+        fft_stage(base, nblk, blk_stride, 5, 24, 1, 1, 1 << 2);
+    }
+}
+
+OG_DEV const i16 *bitrev_for(int shift) {
+    return shift == 0 ? rom_bitrev480 : shift == 1 ? rom_bitrev240 : shift == 2 ? rom_bitrev120 : rom_bitrev60;
+}
+
+// Inverse MDCT of every block of every output channel (clt_mdct_backward celt.cpp:3204), reading
+// the denormalised coefficients on the fly.  B blocks of NBk = N/B outputs, transform size 2*NBk.
+OG_DEVN void imdct_all(int N, int LM, int B, int shift, int C, int CC) {
+    const int NBk = N / B, N2 = NBk, N4 = N2 >> 1;
+    const i16 *trig = rom_mdct_trig + (shift == 0 ? 0 : shift == 1 ? 960 : shift == 2 ? 1440 : 1680);
+    const i16 *br = bitrev_for(shift);
+    for (int co = 0; co < CC; co++) {
+        OG_SYNC();
+        OG_FOR_LANES(id, B * N4) { // pre-rotation into digit-reversed order
+            int b = id / N4, i = id - b * N4;
+            i32 x1 = freq_out(co, b + B * (2 * i), N, LM, C, CC);
+            i32 x2 = freq_out(co, b + B * (N2 - 1 - 2 * i), N, LM, C, CC);
+            i32 t0 = trig[i], t1 = trig[N4 + i];
+            i32 yr = addw(OG_SMUL(x2, t0), OG_SMUL(x1, t1));
+            i32 yi = subw(OG_SMUL(x1, t0), OG_SMUL(x2, t1));
+            i32 *yp = &S.syn[co][NBk * b + (OVERLAP >> 1)];
+            int rev = br[i];
+            yp[2 * rev + 1] = yr;
+            yp[2 * rev] = yi;
+        }
+        fft_blocks(&S.syn[co][OVERLAP >> 1], B, NBk, shift);
+        OG_FOR_LANES(id, B * (N4 >> 1)) { // post-rotation, pairs (i, N4-1-i)
+            int b = id / (N4 >> 1), i = id - b * (N4 >> 1);
+            i32 *yp0 = &S.syn[co][NBk * b + (OVERLAP >> 1) + 2 * i];
+            i32 *yp1 = &S.syn[co][NBk * b + (OVERLAP >> 1) + N2 - 2 - 2 * i];
+            i32 re = yp0[1], im = yp0[0];
+            i32 t0 = trig[i], t1 = trig[N4 + i];
+            i32 yr = addw(OG_SMUL(re, t0), OG_SMUL(im, t1));
+            i32 yi = subw(OG_SMUL(re, t1), OG_SMUL(im, t0));
+            re = yp1[1];
+            im = yp1[0];
+            yp0[0] = yr;
+            yp1[1] = yi;
+            t0 = trig[N4 - i - 1];
+            t1 = trig[N2 - i - 1];
+            yr = addw(OG_SMUL(re, t0), OG_SMUL(im, t1));
+            yi = subw(OG_SMUL(re, t1), OG_SMUL(im, t0));
+            yp1[0] = yr;
+            yp0[1] = yi;
+        }
+        OG_SYNC();
+        OG_FOR_LANES(id, B * (OVERLAP / 2)) { // TDAC mirror
+            int b = id / (OVERLAP / 2), i = id - b * (OVERLAP / 2);
+            i32 *o = &S.syn[co][NBk * b];
+            i32 x1 = o[OVERLAP - 1 - i], x2 = o[i];
+            i32 w1 = rom_win120[i], w2 = rom_win120[OVERLAP - 1 - i];
+            o[i] = subw(mul16x32_q15(w2, x2), mul16x32_q15(w1, x1));
+            o[OVERLAP - 1 - i] = addw(mul16x32_q15(w1, x2), mul16x32_q15(w2, x1));
+        }
+        OG_SYNC();
+        OG_FOR_LANES(i, N) S.syn[co][i] = clampsym(S.syn[co][i], SIG_SAT);
+        OG_SYNC();
+    }
+}
+
+// sample `idx` of channel c's synthesis signal: >= 0 in LDS (this frame), < 0 in the HBM ring
+OG_DEV i32 syn_at(const CeltState *st, int c, int idx) {
+    return idx >= 0 ? S.syn[c][idx] : st->ring[c][(st->ring_pos + idx) & RING_MASK];
+}
+
+// In-place pitch comb filter on S.syn[c][off .. off+N) (comb_filter celt.cpp:848).  In place the filter
+// is recursive with delay >= min(T0,T1)-2 >= 13 samples, so samples are produced in chunks of that
+// many (at most 64), one lane each; all taps of a chunk are already final.
+OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, int N, i32 g0, i32 g1, int tap0, int tap1) {
+    if (g0 == 0 && g1 == 0) return;
+    // gains[tapset][0..2] Q15 (celt.cpp:854)
+    T0 = OG_MAX(T0, 15);
+    T1 = OG_MAX(T1, 15);
+    i32 ga0 = tap0 == 0 ? 10048 : tap0 == 1 ? 15200 : 26208, ga1 = tap0 == 0 ? 7112 : tap0 == 1 ? 8784 : 3280,
+        ga2 = tap0 == 0 ? 4248 : 0;
+    i32 gb0 = tap1 == 0 ? 10048 : tap1 == 1 ? 15200 : 26208, gb1 = tap1 == 0 ? 7112 : tap1 == 1 ? 8784 : 3280,
+        gb2 = tap1 == 0 ? 4248 : 0;
+    i32 g00 = tr16(mul16_p15(g0, ga0)), g01 = tr16(mul16_p15(g0, ga1)), g02 = tr16(mul16_p15(g0, ga2));
+    i32 g10 = tr16(mul16_p15(g1, gb0)), g11 = tr16(mul16_p15(g1, gb1)), g12 = tr16(mul16_p15(g1, gb2));
+    int overlap = (g0 == g1 && T0 == T1 && tap0 == tap1) ? 0 : OVERLAP;
+    int chunk = OG_MIN(OG_MIN(T0, T1) - 2, 64);
+    int end = g1 == 0 ? overlap : N; // with g1 == 0 only the cross-fade part changes the signal
+    for (int base = 0; base < end; base += chunk) {
+        OG_SYNC();
+        OG_FOR_LANES(l, chunk) {
+            const int i = base + l;
+            if (i >= end) continue;
+            int p = off + i;
+            i32 y = S.syn[c][p];
+            i32 a2 = syn_at(st, c, p - T1), a1 = syn_at(st, c, p - T1 + 1), a3 = syn_at(st, c, p - T1 - 1),
+                a0 = syn_at(st, c, p - T1 + 2), a4 = syn_at(st, c, p - T1 - 2);
+            if (i < overlap) {
+                i32 f = tr16(mul16_q15(rom_win120[i], rom_win120[i]));
+                y = y + mul16x32_q15(mul16_q15(32767 - f, g00), syn_at(st, c, p - T0)) +
+                    mul16x32_q15(mul16_q15(32767 - f, g01), syn_at(st, c, p - T0 + 1) + syn_at(st, c, p - T0 - 1)) +
+                    mul16x32_q15(mul16_q15(32767 - f, g02), syn_at(st, c, p - T0 + 2) + syn_at(st, c, p - T0 - 2)) +
+                    mul16x32_q15(mul16_q15(f, g10), a2) + mul16x32_q15(mul16_q15(f, g11), a1 + a3) +
+                    mul16x32_q15(mul16_q15(f, g12), a0 + a4);
+            } else {
+                y = y + mul16x32_q15(g10, a2) + mul16x32_q15(g11, a1 + a3) + mul16x32_q15(g12, a0 + a4);
+            }
+            S.syn[c][p] = clampsym(y, SIG_SAT);
+        }
+    }
+    OG_SYNC();
+}
+
+// ---- state helpers ----------------------------------------------------------------------------------
+OG_DEV void celt_reset_state(CeltState *st) { // OPUS_RESET_STATE celt.cpp:2479 (partial on purpose, Q5)
+    if (OG_LANE == 0) {
+        st->rng = 0;
+        st->error = 0;
+        st->pf_period = st->pf_period_old = 0;
+        st->pf_gain = st->pf_gain_old = 0;
+        st->pf_tapset = st->pf_tapset_old = 0;
+    }
+    OG_FOR_LANES(i, 2 * NBANDS) st->logE1[i] = st->logE2[i] = (i16)(-28 * 1024);
+}
+
+// Decode one CELT frame of `frame_size` samples (120 << LM) from the live range decoder.
+// pcm_out: LDS i16 buffer (interleaved, CC channels) -- S.v[V_X..] is reused for it after synthesis.
+// Returns frame_size or a negative code (wave-uniform).
+OG_DEVN int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int CC, int start, int disable_inv) {
+    const i16 *eb = rom_eband;
+    const int end = NBANDS;
+    int LM;
+    for (LM = 0; LM <= 3; LM++)
+        if (120 << LM == frame_size) break;
+    if (LM > 3) return BAD_ARG;
+    const int M = 1 << LM, N = M * 120;
+    if (rc.storage > 1275 || rc.storage <= 1) return BAD_ARG;
+
+    // ---- stage persistent scalars in LDS
+    OG_SYNC();
+    OG_FOR_LANES(i, 2 * NBANDS) {
+        S.bandE[i] = st->bandE[i];
+        S.logE1[i] = st->logE1[i];
+        S.logE2[i] = st->logE2[i];
+    }
+    OG_FOR_LANES(i, 2 * NBANDS) S.cmask[i] = 0;
+    OG_FOR_LANES(i, NBANDS) {
+        S.pulses[i] = 0;
+        S.fine_quant[i] = 0;
+        S.fine_prio[i] = 0;
+        S.offsets[i] = 0;
+    }
+    OG_FOR_LANES(i, 2 * N) S.v[V_X + i] = 0;
+    OG_FOR_LANES(i, 1248) S.v[V_NORM + i] = 0;
+    for (int c = 0; c < CC; c++) OG_FOR_LANES(i, OVERLAP / 2) S.syn[c][i] = st->tail[c][i];
+    OG_SYNC();
+    if (C == 1) {
+        OG_FOR_LANES(i, NBANDS) S.bandE[i] = OG_MAX(S.bandE[i], S.bandE[NBANDS + i]);
+        OG_SYNC();
+    }
+
+    // ---- header (celt.cpp:2239-2284)
+    i32 total_bits = (i32)rc.storage * 8;
+    i32 tell = rc_tell(rc);
+    int silence;
+    if (tell >= total_bits)
+        silence = 1;
+    else if (tell == 1)
+        silence = rc_bit_logp(rc, 15);
+    else
+        silence = 0;
+    if (silence) {
+        tell = (i32)rc.storage * 8;
+        rc.nbits_total += tell - rc_tell(rc);
+    }
+    int pf_pitch = 0, pf_tapset = 0;
+    i32 pf_gain = 0;
+    if (start == 0 && tell + 16 <= total_bits) {
+        if (rc_bit_logp(rc, 1)) {
+            int octave = (int)rc_uint(rc, 6);
+            pf_pitch = (16 << octave) + (int)rc_bits(rc, 4 + octave) - 1;
+            int qg = (int)rc_bits(rc, 3);
+            if (rc_tell(rc) + 2 <= total_bits) { // tapset_icdf {2,1,0}, ftb 2
+                u32 s = rc.rng, d = rc.val, r = s >> 2, t;
+                int ret = -1;
+                do {
+                    t = s;
+                    ++ret;
+                    s = r * (u32)(2 - ret);
+                } while (d < s);
+                rc.val = d - s;
+                rc.rng = t - s;
+                rc_renorm(rc);
+                pf_tapset = ret;
+            }
+            pf_gain = 3072 * (qg + 1);
+        }
+        tell = rc_tell(rc);
+    }
+    int transient = 0;
+    if (LM > 0 && tell + 3 <= total_bits) {
+        transient = rc_bit_logp(rc, 3);
+        tell = rc_tell(rc);
+    }
+    const int shortBlocks = transient ? M : 0;
+    const int intra = tell + 3 <= total_bits ? rc_bit_logp(rc, 3) : 0;
+    coarse_energy(rc, start, end, intra, C, LM);
+    tf_decode(rc, start, end, transient, LM);
+    tell = rc_tell(rc);
+    int spread = 2;
+    if (tell + 4 <= total_bits) { // spread_icdf {25,23,2,0}, ftb 5
+        u32 s = rc.rng, d = rc.val, r = s >> 5, t;
+        int ret = -1;
+        do {
+            t = s;
+            ++ret;
+            s = r * (u32)(ret == 0 ? 25 : ret == 1 ? 23 : ret == 2 ? 2 : 0);
+        } while (d < s);
+        rc.val = d - s;
+        rc.rng = t - s;
+        rc_renorm(rc);
+        spread = ret;
+    }
+    for (int i = 0; i < NBANDS; i++) { // init_caps celt.cpp:911
+        int Nb = (eb[i + 1] - eb[i]) << LM;
+        S.cap[i] = (rom_pulse_caps[NBANDS * (2 * LM + C - 1) + i] + 64) * C * Nb >> 2;
+    }
+    int dynalloc_logp = 6;
+    total_bits <<= BITRES;
+    tell = (i32)rc_tell_frac(rc);
+    for (int i = start; i < end; i++) {
+        int width = C * (eb[i + 1] - eb[i]) << LM;
+        int quanta = OG_MIN(width << BITRES, OG_MAX(6 << BITRES, width));
+        int loop_logp = dynalloc_logp, boost = 0;
+        while (tell + (loop_logp << BITRES) < total_bits && boost < S.cap[i]) {
+            int flag = rc_bit_logp(rc, loop_logp);
+            tell = (i32)rc_tell_frac(rc);
+            if (!flag) break;
+            boost += quanta;
+            total_bits -= quanta;
+            loop_logp = 1;
+        }
+        S.offsets[i] = boost;
+        if (boost > 0) dynalloc_logp = OG_MAX(2, dynalloc_logp - 1);
+    }
+    int alloc_trim = 5;
+    if (tell + (6 << BITRES) <= total_bits) { // trim_icdf, ftb 7
+        u32 s = rc.rng, d = rc.val, r = s >> 7, t;
+        int ret = -1;
+        do {
+            t = s;
+            ++ret;
+            // {126,124,119,109,87,41,19,9,4,2,0}
+            u32 ic = ret == 0 ? 126 : ret == 1 ? 124 : ret == 2 ? 119 : ret == 3 ? 109 : ret == 4 ? 87 : ret == 5 ? 41
+                   : ret == 6 ? 19 : ret == 7 ? 9 : ret == 8 ? 4 : ret == 9 ? 2 : 0;
+            s = r * ic;
+        } while (d < s);
+        rc.val = d - s;
+        rc.rng = t - s;
+        rc_renorm(rc);
+        alloc_trim = ret;
+    }
+    i32 bits = (((i32)rc.storage * 8) << BITRES) - (i32)rc_tell_frac(rc) - 1;
+    const int anti_collapse_rsv = transient && LM >= 2 && bits >= ((LM + 2) << BITRES) ? (1 << BITRES) : 0;
+    bits -= anti_collapse_rsv;
+    i32 intensity = 0, dual_stereo = 0, balance = 0;
+    const int codedBands = compute_allocation(rc, start, end, alloc_trim, intensity, dual_stereo, bits, balance, C, LM);
+    fine_energy(rc, start, end, C);
+
+    u32 seed = st->rng;
+    decode_all_bands(rc, start, end, C, N, shortBlocks, spread, dual_stereo, intensity,
+                     (i32)rc.storage * (8 << BITRES) - anti_collapse_rsv, balance, LM, codedBands, seed, disable_inv);
+    int anti_collapse_on = 0;
+    if (anti_collapse_rsv > 0) anti_collapse_on = (int)rc_bits(rc, 1);
+    energy_finalise(rc, start, end, (i32)rc.storage * 8 - rc_tell(rc), C);
+    if (anti_collapse_on) anti_collapse(LM, C, N, start, end, seed);
+    if (silence)
+        for (int i = 0; i < C * NBANDS; i++) S.bandE[i] = (i16)(-28 * 1024);
+
+    OG_TAP(1); // X and bandE final
+    // ---- synthesis
+    denorm_gains(start, end, C, silence);
+    const int B = transient ? M : 1, shift = transient ? 3 : 3 - LM;
+    imdct_all(N, LM, B, shift, C, CC);
+    OG_TAP(2); // IMDCT output
+
+    int pp = OG_MAX(st->pf_period, 15), ppo = OG_MAX(st->pf_period_old, 15);
+    i32 pg = st->pf_gain, pgo = st->pf_gain_old;
+    int pt = st->pf_tapset, pto = st->pf_tapset_old;
+    for (int c = 0; c < CC; c++) {
+        comb_filter(st, c, 0, ppo, pp, 120, pgo, pg, pto, pt);
+        if (LM != 0) comb_filter(st, c, 120, pp, pf_pitch, N - 120, pg, pf_gain, pt, pf_tapset);
+    }
+
+    OG_TAP(3); // comb filter output
+    // ---- energy history (celt.cpp:2404-2436)
+    OG_SYNC();
+    if (C == 1) {
+        OG_FOR_LANES(i, NBANDS) S.bandE[NBANDS + i] = S.bandE[i];
+        OG_SYNC();
+    }
+    OG_FOR_LANES(i, 2 * NBANDS) {
+        int band = i >= NBANDS ? i - NBANDS : i;
+        i32 e = S.bandE[i], l1 = S.logE1[i], l2 = S.logE2[i];
+        if (!transient) {
+            l2 = l1;
+            l1 = e;
+        } else
+            l1 = OG_MIN(l1, e);
+        if (band < start || band >= end) {
+            e = 0;
+            l1 = l2 = -28 * 1024;
+        }
+        st->bandE[i] = (i16)e;
+        st->logE1[i] = (i16)l1;
+        st->logE2[i] = (i16)l2;
+    }
+
+    // ---- de-emphasis (celt.cpp:1965-2055): one lane per channel, PCM staged in LDS over the dead X region
+    OG_SYNC();
+    OG_FOR_LANES(c, CC) {
+        i32 m = st->deemph[c];
+        for (int j = 0; j < N; j++) {
+            i32 tmp = S.syn[c][j] + m;
+            m = mul16x32_q15(27853, tmp);
+            S.v[V_X + j * CC + c] = (i16)sat16(pshr32(tmp, 12)); // sig2word16 celt.h:413
+        }
+        st->deemph[c] = m;
+    }
+    OG_SYNC();
+
+    // ---- write back history ring, overlap tail and scalars
+    const int pos = st->ring_pos;
+    for (int c = 0; c < CC; c++) {
+        OG_FOR_LANES(i, N) st->ring[c][(pos + i) & RING_MASK] = S.syn[c][i];
+        OG_FOR_LANES(i, OVERLAP / 2) st->tail[c][i] = S.syn[c][N + i];
+    }
+    OG_SYNC();
+    if (OG_LANE == 0) {
+        st->ring_pos = (pos + N) & RING_MASK;
+        st->rng = rc.rng;
+        int new_old_period = pp, new_old_tapset = pt;
+        i32 new_old_gain = pg;
+        if (LM != 0) {
+            new_old_period = pf_pitch;
+            new_old_gain = pf_gain;
+            new_old_tapset = pf_tapset;
+        }
+        st->pf_period_old = new_old_period;
+        st->pf_gain_old = new_old_gain;
+        st->pf_tapset_old = new_old_tapset;
+        st->pf_period = pf_pitch;
+        st->pf_gain = pf_gain;
+        st->pf_tapset = pf_tapset;
+        if (rc.error) st->error = 1;
+    }
+    if (rc_tell(rc) > 8 * (i32)rc.storage) return INTERNAL_ERROR;
+    return frame_size;
+}
+
+} // namespace og

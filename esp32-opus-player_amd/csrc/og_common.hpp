@@ -1,0 +1,129 @@
+// og_common.hpp -- shared definitions of the MI355X Opus decode kernels (gfx950, wave64).
+//
+// Execution model: ONE 20 ms FRAME PER WAVEFRONT.  A workgroup is exactly one wave (64 lanes); its
+// frame's packet bytes, normalised band vectors, folding history and synthesis buffer are staged
+// in LDS (struct FrameLds).  Entropy decoding is inherently serial: those parts are written as
+// plain scalar code that every lane executes identically (the compiler keeps wave-uniform values
+// in SGPRs / scalar ALU where it can); vector parts are written with OG_FOR_LANES so that the 64
+// lanes split the band / butterfly / sample loops.
+//
+// The same headers compile in a TEST-ONLY host emulation (OG_HOST_EMUL, used by tests/emul) where
+// a "wave" has a single lane; lane loops then run sequentially.  That build exists so the kernel
+// source can be fuzzed and run under ASan/UBSan on a CPU; it is not linked into the shipped
+// library and is not a fallback: the C-ABI fails with OPUSGPU_ERR_NO_DEVICE when HIP is unusable.
+#pragma once
+#include <stdint.h>
+
+typedef int8_t i8;
+typedef int16_t i16;
+typedef int32_t i32;
+typedef int64_t i64;
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#ifdef OG_HOST_EMUL
+#include <string.h>
+#define OG_DEV static inline
+#define OG_DEVN static
+#define OG_LANE 0
+#define OG_NLANES 1
+#define OG_SYNC() ((void)0)
+#define OG_LDS static
+#define OPUS_ROM static const
+#define OG_CLZ(x) __builtin_clz(x)
+extern "C" void og_emul_tap(int id); // stage taps for parity tests (host emulation only)
+#define OG_TAP(id) og_emul_tap(id)
+#else
+#include <hip/hip_runtime.h>
+#define OG_DEV static __device__ __forceinline__
+#define OG_DEVN static __device__ __noinline__
+#define OG_LANE ((int)threadIdx.x)
+#define OG_NLANES 64
+#define OG_SYNC() __syncthreads()
+#define OG_LDS __shared__
+#define OPUS_ROM static __device__ const
+#define OG_CLZ(x) __clz(x)
+#define OG_TAP(id) ((void)0)
+#endif
+
+#define OG_FOR_LANES(i, n) for (int i = OG_LANE; i < (n); i += OG_NLANES)
+
+#define OG_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define OG_MAX(a, b) ((a) > (b) ? (a) : (b))
+
+namespace og {
+
+// ---- error / mode codes (values follow the reference's opus_decoder.h / celt.h) -----------------
+enum { OK = 0, BAD_ARG = -1, BUFFER_TOO_SMALL = -2, INTERNAL_ERROR = -3, INVALID_PACKET = -4 };
+enum { MODE_SILK = 1000, MODE_HYBRID = 1001, MODE_CELT = 1002 };
+enum { BW_NB = 1101, BW_MB = 1102, BW_WB = 1103, BW_SWB = 1104, BW_FB = 1105 };
+
+// ---- fixed-point primitives; each names the reference macro it reproduces (src/celt.h) ----------
+OG_DEV i32 mul16(i32 a, i32 b) { return (i32)(i16)a * (i32)(i16)b; }                 // MULT16_16 :338
+OG_DEV i32 mul16_q15(i32 a, i32 b) { return mul16(a, b) >> 15; }                     // :355
+OG_DEV i32 mul16_q14(i32 a, i32 b) { return mul16(a, b) >> 14; }                     // :354
+OG_DEV i32 mul16_p15(i32 a, i32 b) { return (16384 + mul16(a, b)) >> 15; }           // :359
+OG_DEV i32 mul16x32_q15(i32 a, i32 b) { return (i32)(((i64)(i16)a * (i64)b) >> 15); } // MULT16_32_Q15 :263
+OG_DEV i32 mul32_q31(i32 a, i32 b) { return (i32)(((i64)a * (i64)b) >> 31); }        // :266
+OG_DEV i32 shl32(i32 a, int s) { return (i32)((u32)a << s); }                        // :292
+OG_DEV i32 pshr32(i32 a, int s) { return (a + ((1 << s) >> 1)) >> s; }               // :295
+OG_DEV i32 vshr32(i32 a, int s) { return s > 0 ? a >> s : shl32(a, -s); }            // :297
+OG_DEV i32 addw(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }                     // ADD32_ovflw :326
+OG_DEV i32 subw(i32 a, i32 b) { return (i32)((u32)a - (u32)b); }                     // SUB32_ovflw :328
+OG_DEV i32 negw(i32 a) { return (i32)(0u - (u32)a); }                                // NEG32_ovflw :331
+OG_DEV i32 clampsym(i32 x, i32 a) { return x > a ? a : (x < -a ? -a : x); }          // SATURATE :303
+OG_DEV i32 sat16(i32 x) { return x > 32767 ? 32767 : (x < -32768 ? -32768 : x); }    // SAT16 :401
+OG_DEV i32 add16(i32 a, i32 b) { return (i32)(i16)((i16)a + (i16)b); }               // ADD16 :317
+OG_DEV i32 sub16(i32 a, i32 b) { return (i32)(i16)a - (i32)(i16)b; }                 // SUB16 :319
+OG_DEV i32 shl16(i32 a, int s) { return (i32)(i16)((u16)a << s); }                   // SHL16 :288
+OG_DEV i32 tr16(i32 a) { return (i32)(i16)a; }                                       // EXTRACT16 :281
+OG_DEV i32 frac_mul16(i32 a, i32 b) { return (16384 + (i32)(i16)a * (i32)(i16)b) >> 15; } // :378
+OG_DEV int ilog(u32 x) { return x ? 32 - OG_CLZ(x) : 0; }                            // EC_ILOG :250
+OG_DEV int ilog2(i32 x) { return ilog((u32)x) - 1; }                                 // celt_ilog2 :469
+OG_DEV u32 udiv(u32 n, u32 d) { return n / d; }                                      // celt_udiv :405
+
+static constexpr i32 SIG_SAT = 300000000; // celt.h:234
+
+// ---- SILK flavour (src/silk.h) -------------------------------------------------------------------
+OG_DEV i32 smulwb(i32 a, i32 b) { return (i32)(((i64)a * (i64)(i16)b) >> 16); }      // silk_SMULWB :447
+OG_DEV i32 smlawb(i32 acc, i32 a, i32 b) { return addw(acc, smulwb(a, b)); }         // silk_SMLAWB :450
+OG_DEV i32 smulww(i32 a, i32 b) { return (i32)(((i64)a * (i64)b) >> 16); }           // silk_SMULWW :474
+OG_DEV i32 smulbb(i32 a, i32 b) { return (i32)(i16)a * (i32)(i16)b; }                // silk_SMULBB :459
+OG_DEV i32 smlabb(i32 acc, i32 a, i32 b) { return addw(acc, smulbb(a, b)); }         // silk_SMLABB :462
+OG_DEV i32 smmul(i32 a, i32 b) { return (i32)(((i64)a * (i64)b) >> 32); }            // silk_SMMUL :512
+OG_DEV i32 rshift_round(i32 a, int s) { return s == 1 ? (a >> 1) + (a & 1) : ((a >> (s - 1)) + 1) >> 1; } // :156
+OG_DEV i64 rshift_round64(i64 a, int s) { return s == 1 ? (a >> 1) + (a & 1) : ((a >> (s - 1)) + 1) >> 1; }
+OG_DEV i32 add_sat32(i32 a, i32 b) {                                                 // silk_ADD_SAT32 :480
+    i64 s = (i64)a + b;
+    return s > 2147483647LL ? 2147483647 : (s < -2147483648LL ? (i32)(-2147483647 - 1) : (i32)s);
+}
+OG_DEV i32 sub_sat32(i32 a, i32 b) {
+    i64 s = (i64)a - b;
+    return s > 2147483647LL ? 2147483647 : (s < -2147483648LL ? (i32)(-2147483647 - 1) : (i32)s);
+}
+OG_DEV i32 limit32(i32 a, i32 l1, i32 l2) {                                          // silk_LIMIT :427
+    return l1 > l2 ? (a > l1 ? l1 : (a < l2 ? l2 : a)) : (a > l2 ? l2 : (a < l1 ? l1 : a));
+}
+OG_DEV i32 lshift_sat32(i32 a, int s) {                                              // silk_LSHIFT_SAT32 :139
+    return shl32(limit32(a, (i32)(-2147483647 - 1) >> s, 2147483647 >> s), s);
+}
+OG_DEV int clz32(i32 x) { return x ? OG_CLZ((u32)x) : 32; }                          // silk_CLZ32 :492
+
+// ---- wave-level helpers ---------------------------------------------------------------------------
+// Sum / OR over the 64 lanes, result in every lane.  (Host emulation: one lane, identity.)
+OG_DEV i32 wave_sum(i32 v) {
+#ifndef OG_HOST_EMUL
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+#endif
+    return v;
+}
+OG_DEV u32 wave_or(u32 v) {
+#ifndef OG_HOST_EMUL
+    for (int off = 32; off > 0; off >>= 1) v |= (u32)__shfl_xor((int)v, off, 64);
+#endif
+    return v;
+}
+
+} // namespace og

@@ -1,0 +1,113 @@
+// og_decode.hpp -- per-frame mode dispatch of the wave decoder: the device-side equivalent of the
+// reference's opus_decode_frame (src/opus_decoder.cpp:154-278).  One call decodes one 20 ms frame of
+// one stream: range-decoder init, SILK (SILK-only / hybrid), CELT (CELT-only / hybrid, plus the
+// reference's hybrid->SILK transition quirk Q4), saturating mix, state update, PCM write-out.
+#pragma once
+#include "og_celt.hpp"
+#ifndef OG_NO_SILK
+#include "og_silk.hpp"
+#endif
+
+namespace og {
+
+// fresh stream == opus_multistream_decoder_init (src/opus_decoder.cpp:742 -> :82): everything zero,
+// then the CELT/SILK reset values.  Lane-parallel over the record's words.
+OG_DEV void stream_init(StreamState *st, int channels) {
+    u32 *w = reinterpret_cast<u32 *>(st);
+    const int nw = (int)(sizeof(StreamState) / 4);
+    OG_FOR_LANES(i, nw) w[i] = 0;
+    OG_SYNC();
+    OG_FOR_LANES(i, 2 * NBANDS) st->celt.logE1[i] = st->celt.logE2[i] = (i16)(-28 * 1024);
+    if (OG_LANE == 0) st->channels = channels;
+#ifndef OG_NO_SILK
+    silk_init_state(&st->silk);
+#endif
+    OG_SYNC();
+}
+
+// OPUS_RESET_STATE semantics (src/opus_decoder.cpp:382-390): partial CELT reset (Q5), full SILK init
+OG_DEV void stream_reset(StreamState *st) {
+    celt_reset_state(&st->celt);
+    if (OG_LANE == 0) {
+        st->prev_mode = 0;
+        st->range_final = 0;
+    }
+#ifndef OG_NO_SILK
+    silk_init_state(&st->silk);
+#endif
+    OG_SYNC();
+}
+
+// Decode one frame.  `payload` points at the frame's bytes in HBM; `pcm` at 960*channels int16 in HBM.
+// Returns samples per channel (960) or a negative OPUS_* code; the value is wave-uniform.
+OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mode, int bandwidth, int ch, i16 *pcm) {
+    const int audiosize = 960;
+    const int CC = st->channels;
+    if (len < 0 || len > 1275) return BAD_ARG;
+    OG_SYNC();
+    OG_FOR_LANES(i, len) S.pkt[i] = payload[i];
+    OG_SYNC();
+    Rc rc;
+    rc_init(rc, (u32)len);
+    const int prev_mode = st->prev_mode;
+    int celt_ret = 0;
+
+#ifndef OG_NO_SILK
+    if (mode != MODE_CELT) {
+        if (prev_mode == MODE_CELT) silk_init_state(&st->silk);
+        int internal_hz = 16000;
+        if (mode == MODE_SILK) internal_hz = bandwidth == BW_NB ? 8000 : (bandwidth == BW_MB ? 12000 : 16000);
+        int ret = silk_decode_20ms(&st->silk, rc, ch, internal_hz); // fills S.pcm_silk (48 kHz, interleaved)
+        if (ret) return INTERNAL_ERROR;
+    }
+#else
+    if (mode != MODE_CELT) return INTERNAL_ERROR;
+#endif
+    int start_band = 0;
+    if (mode != MODE_CELT && rc_tell(rc) + 17 + 20 * (mode == MODE_HYBRID) <= 8 * len) {
+        if (mode == MODE_HYBRID) (void)rc_bit_logp(rc, 12); // redundancy flag read and ignored (Q2)
+    }
+    if (mode != MODE_CELT) start_band = 17;
+    const int disable_inv = CC == 1;
+
+    if (mode != MODE_SILK) {
+        if (mode != prev_mode && prev_mode > 0) {
+            celt_reset_state(&st->celt);
+            OG_SYNC();
+        }
+        celt_ret = celt_decode_frame(&st->celt, rc, audiosize, ch, CC, start_band, disable_inv);
+    } else {
+        OG_SYNC();
+        OG_FOR_LANES(i, audiosize * CC) S.v[V_X + i] = 0;
+        OG_SYNC();
+        if (prev_mode == MODE_HYBRID) { // Q4: 2.5 ms CELT frame from the live range decoder, start band 0
+            // writes 120*CC samples at the head of the PCM staging area; the rest stays zero.  The
+            // reference ignores the return value here (src/opus_decoder.cpp:267).
+            (void)celt_decode_frame(&st->celt, rc, 120, ch, CC, 0, disable_inv);
+        }
+    }
+#ifndef OG_NO_SILK
+    if (mode != MODE_CELT) { // SAT16(outbuf + pcm_silk) over audiosize*stream_channels entries (Q3)
+        OG_SYNC();
+        OG_FOR_LANES(i, audiosize * ch) S.v[V_X + i] = (i16)sat16((i32)S.v[V_X + i] + (i32)S.pcm_silk[i]);
+        OG_SYNC();
+    }
+#endif
+    if (OG_LANE == 0) {
+        st->prev_mode = mode;
+        st->frames_decoded += 1;
+        st->range_final = rc.rng;
+    }
+    if (celt_ret < 0) return celt_ret;
+    // PCM: LDS staging -> HBM, two samples per lane-store, coalesced
+    OG_SYNC();
+    {
+        const u32 *src = reinterpret_cast<const u32 *>(&S.v[V_X]);
+        u32 *dst = reinterpret_cast<u32 *>(pcm);
+        OG_FOR_LANES(i, audiosize * CC / 2) dst[i] = src[i];
+    }
+    OG_SYNC();
+    return audiosize;
+}
+
+} // namespace og

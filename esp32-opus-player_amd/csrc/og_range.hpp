@@ -1,0 +1,171 @@
+// og_range.hpp -- the Opus range decoder, wave-uniform.
+//
+// Every lane of the wave runs this code on identical values (the packet bytes sit in LDS at
+// S.pkt, the coder state in registers), so the compiler keeps it on the scalar path.  Behaviour
+// follows the reference's ec_* functions (src/celt.cpp:2627-2792, :3041-3083); the state here is
+// a per-wave value instead of the reference's process-wide `s_ec`.
+#pragma once
+#include "og_state.hpp"
+
+namespace og {
+
+OG_LDS FrameLds S; // the wave's LDS working set (one workgroup == one wave == one frame)
+
+struct Rc {
+    u32 storage, end_offs, end_window;
+    i32 nend_bits, nbits_total;
+    u32 offs, rng, val, ext;
+    i32 rem, error;
+};
+
+OG_DEV int rc_next_byte(Rc &rc) { return rc.offs < rc.storage ? S.pkt[rc.offs++] : 0; }          // :2642
+OG_DEV int rc_next_byte_end(Rc &rc) {                                                           // :2644
+    return rc.end_offs < rc.storage ? S.pkt[rc.storage - ++rc.end_offs] : 0;
+}
+
+OG_DEV void rc_renorm(Rc &rc) { // ec_dec_normalize :2649
+    while (rc.rng <= (1u << 23)) {
+        rc.nbits_total += 8;
+        rc.rng <<= 8;
+        int sym = rc.rem;
+        rc.rem = rc_next_byte(rc);
+        sym = (sym << 8 | rc.rem) >> 1; // EC_SYM_BITS - EC_CODE_EXTRA = 1
+        rc.val = ((rc.val << 8) + (255u & ~(u32)sym)) & 0x7FFFFFFFu;
+    }
+}
+
+OG_DEV void rc_init(Rc &rc, u32 len) { // ec_dec_init :2666
+    rc.storage = len;
+    rc.end_offs = 0;
+    rc.end_window = 0;
+    rc.nend_bits = 0;
+    rc.nbits_total = 9;
+    rc.offs = 0;
+    rc.rng = 128;
+    rc.rem = rc_next_byte(rc);
+    rc.val = rc.rng - 1 - (rc.rem >> 1);
+    rc.ext = 0;
+    rc.error = 0;
+    rc_renorm(rc);
+}
+
+OG_DEV i32 rc_tell(const Rc &rc) { return rc.nbits_total - ilog(rc.rng); } // celt.h:420
+
+OG_DEV u32 rc_tell_frac(const Rc &rc) { // :2627
+    u32 nbits = (u32)rc.nbits_total << 3;
+    int l = ilog(rc.rng);
+    u32 r = rc.rng >> (l - 16);
+    u32 b = (r >> 12) - 8;
+    // thresholds 2^(k/8+15.x): {35733, 38967, 42495, 46340, 50535, 55109, 60097, 65535}
+    u32 corr = b == 0 ? 35733u : b == 1 ? 38967u : b == 2 ? 42495u : b == 3 ? 46340u
+             : b == 4 ? 50535u : b == 5 ? 55109u : b == 6 ? 60097u : 65535u;
+    b += r > corr;
+    return nbits - (u32)((l << 3) + b);
+}
+
+OG_DEV u32 rc_decode(Rc &rc, u32 ft) { // ec_decode :2683
+    rc.ext = rc.rng / ft;
+    u32 s = rc.val / rc.ext;
+    return ft - OG_MIN(s + 1, ft);
+}
+
+OG_DEV u32 rc_decode_bin(Rc &rc, unsigned bits) { // :2690
+    rc.ext = rc.rng >> bits;
+    u32 s = rc.val / rc.ext, top = 1u << bits;
+    return top - OG_MIN(s + 1u, top);
+}
+
+OG_DEV void rc_update(Rc &rc, u32 fl, u32 fh, u32 ft) { // ec_dec_update :2697
+    u32 s = rc.ext * (ft - fh);
+    rc.val -= s;
+    rc.rng = fl > 0 ? rc.ext * (fh - fl) : rc.rng - s;
+    rc_renorm(rc);
+}
+
+OG_DEV int rc_bit_logp(Rc &rc, unsigned logp) { // :2712
+    u32 r = rc.rng, d = rc.val, s = r >> logp;
+    int ret = d < s;
+    if (!ret) rc.val = d - s;
+    rc.rng = ret ? s : r - s;
+    rc_renorm(rc);
+    return ret;
+}
+
+// inverse-CDF symbol (:2727).  `icdf` is a ROM table (global/constant memory, uniform address).
+OG_DEV int rc_icdf(Rc &rc, const u8 *icdf, unsigned ftb) {
+    u32 s = rc.rng, d = rc.val, r = s >> ftb, t;
+    int ret = -1;
+    do {
+        t = s;
+        s = r * icdf[++ret];
+    } while (d < s);
+    rc.val = d - s;
+    rc.rng = t - s;
+    rc_renorm(rc);
+    return ret;
+}
+
+OG_DEV u32 rc_bits(Rc &rc, unsigned bits) { // ec_dec_bits :2773
+    u32 window = rc.end_window;
+    int available = rc.nend_bits;
+    if ((u32)available < bits) {
+        do {
+            window |= (u32)rc_next_byte_end(rc) << available;
+            available += 8;
+        } while (available <= 24);
+    }
+    u32 ret = window & ((1u << bits) - 1u);
+    rc.end_window = window >> bits;
+    rc.nend_bits = available - (int)bits;
+    rc.nbits_total += bits;
+    return ret;
+}
+
+OG_DEV u32 rc_uint(Rc &rc, u32 ft_in) { // ec_dec_uint :2747
+    ft_in--;
+    int ftb = ilog(ft_in);
+    if (ftb > 8) {
+        ftb -= 8;
+        u32 ft = (ft_in >> ftb) + 1;
+        u32 s = rc_decode(rc, ft);
+        rc_update(rc, s, s + 1, ft);
+        u32 t = s << ftb | rc_bits(rc, ftb);
+        if (t <= ft_in) return t;
+        rc.error = 1;
+        return ft_in;
+    }
+    ft_in++;
+    u32 s = rc_decode(rc, ft_in);
+    rc_update(rc, s, s + 1, ft_in);
+    return s;
+}
+
+OG_DEV int rc_laplace(Rc &rc, u32 fs, int decay) { // ec_laplace_decode :3047
+    int val = 0;
+    u32 fl = 0, fm = rc_decode_bin(rc, 15);
+    if (fm >= fs) {
+        val++;
+        fl = fs;
+        fs = ((32768u - 32u - fs) * (u32)(16384 - decay) >> 15) + 1; // ec_laplace_get_freq1 :3041
+        while (fs > 1 && fm >= fl + 2 * fs) {
+            fs *= 2;
+            fl += fs;
+            fs = ((fs - 2) * (u32)decay) >> 15;
+            fs += 1;
+            val++;
+        }
+        if (fs <= 1) {
+            int di = (int)((fm - fl) >> 1);
+            val += di;
+            fl += 2 * di;
+        }
+        if (fm < fl + fs)
+            val = -val;
+        else
+            fl += fs;
+    }
+    rc_update(rc, fl, OG_MIN(fl + fs, 32768u), 32768u);
+    return val;
+}
+
+} // namespace og

@@ -1,0 +1,107 @@
+// og_state.hpp -- HBM-resident per-stream decoder state, per-step frame descriptors and the
+// per-wave LDS working set.
+//
+// HBM layout: one StreamState record per stream, array-of-structures.  With one frame per
+// wavefront the 64 lanes of a wave read/write consecutive words of ONE record, so AoS is the
+// coalesced layout here.  The CELT synthesis history is a ring (2048 samples per channel) so a
+// frame appends its 960 new samples instead of shifting 1084 (the reference memmoves 17 KB per
+// frame, src/celt.cpp:2349); only what the pitch comb filter reaches back to (<= 1024 samples,
+// src/celt.cpp:833, :2262) is ever read again.
+#pragma once
+#include "og_common.hpp"
+
+namespace og {
+
+constexpr int NBANDS = 21;     // src/celt.cpp:632
+constexpr int OVERLAP = 120;   // src/celt.cpp:631
+constexpr int RING = 2048;
+constexpr int RING_MASK = RING - 1;
+
+struct CeltState {             // replaces CELTDecoder_t + trailing arrays (src/celt.h:150-171, celt.cpp:2202)
+    i32 ring[2][RING];         // comb-filtered synthesis output history (the live part of _decode_mem)
+    i32 tail[2][64];           // IMDCT overlap tail out_syn[N..N+60) carried to the next frame
+    i32 deemph[2];             // preemph_memD
+    u32 rng;
+    i32 ring_pos;              // ring index of out_syn[0] of the NEXT frame
+    i32 pf_period, pf_period_old, pf_gain, pf_gain_old, pf_tapset, pf_tapset_old;
+    i32 error;
+    i32 reserved;
+    i16 bandE[2 * NBANDS], logE1[2 * NBANDS], logE2[2 * NBANDS]; // oldBandE / oldLogE / oldLogE2
+    i16 pad[2];
+};
+
+// SILK per-channel state (src/silk.h:705-741 minus PLC/CNG, which never feed PCM: lostFlag == 0)
+struct SilkChannel {
+    i32 prev_gain_Q16;
+    i32 sLPC_Q14_buf[16];
+    i16 outBuf[480];
+    i32 lagPrev;
+    i32 LastGainIndex;         // int8 in the reference
+    i32 fs_kHz, nb_subfr, frame_length, subfr_length, ltp_mem_length, LPC_order;
+    i16 prevNLSF_Q15[16];
+    i32 first_frame_after_reset;
+    i32 nFramesDecoded, nFramesPerPacket;
+    i32 ec_prevSignalType, ec_prevLagIndex;
+    i32 VAD_flags[3], LBRR_flag, LBRR_flags[3];
+    i32 prevSignalType;        // from indices of the previous frame
+    i32 lossCnt;
+    // resampler (src/silk.h:654-670)
+    i32 rs_sIIR[6];
+    i16 rs_sFIR[8];
+    i16 rs_delayBuf[48];
+    i32 rs_function, rs_batchSize, rs_invRatio_Q16, rs_FIR_Order, rs_FIR_Fracs, rs_Fs_in_kHz, rs_Fs_out_kHz,
+        rs_inputDelay;
+    i32 rs_valid;
+};
+
+struct SilkState {             // silk_decoder_t (src/silk.h:758-764) + stereo state (:672-676)
+    SilkChannel ch[2];
+    i32 pred_prev_Q13[2];
+    i16 sMid[2], sSide[2];
+    i32 nChannelsAPI, nChannelsInternal, prev_decode_only_middle;
+    i32 initialized;
+};
+
+struct StreamState {
+    i32 channels;              // decoder channels (OpusHead)
+    i32 prev_mode;             // OpusDecoder.prev_mode (src/opus_decoder.cpp:54)
+    i32 frames_decoded;
+    u32 range_final;
+    CeltState celt;
+    SilkState silk;
+};
+
+// One frame of work for one stream in one decode step (host-built, SoA-free: 16 bytes).
+struct FrameDesc {
+    i32 stream;                // index into the StreamState array
+    i32 offset;                // byte offset of the frame payload (after TOC/size bytes) in the arena
+    i32 len;                   // payload bytes (<= 1275)
+    i32 flags;                 // bits 0-1: 0 SILK, 1 hybrid, 2 CELT; bits 2-4: bandwidth - 1101; bit 5: stereo
+};
+OG_DEV int desc_mode(i32 f) { return MODE_SILK + (f & 3); }
+OG_DEV int desc_bandwidth(i32 f) { return BW_NB + ((f >> 2) & 7); }
+OG_DEV int desc_channels(i32 f) { return (f & 32) ? 2 : 1; }
+
+// ---- per-wave LDS working set ---------------------------------------------------------------------
+// i16 vector arena: [X (2 x 960)] [norm (2 x 624)] [iy (192)] [tmp (192)]
+constexpr int V_X = 0;
+constexpr int V_NORM = 1920;
+constexpr int V_IY = V_NORM + 1248;
+constexpr int V_TMP = V_IY + 192;
+constexpr int V_TOTAL = V_TMP + 192;
+constexpr int SYN_LEN = 1088;  // 960 + 120 (+8 pad)
+
+struct FrameLds {
+    i32 syn[2][SYN_LEN];       // IMDCT work / out_syn per output channel
+    i16 v[V_TOTAL];
+    u8 pkt[1280];
+    i32 pulses[NBANDS], fine_quant[NBANDS], fine_prio[NBANDS], tf_res[NBANDS], cap[NBANDS], offsets[NBANDS];
+    i32 bits1[NBANDS], bits2[NBANDS], thresh[NBANDS], trim_off[NBANDS];
+    i16 bandE[2 * NBANDS], logE1[2 * NBANDS], logE2[2 * NBANDS];
+    i16 dn_g[2 * NBANDS], dn_shift[2 * NBANDS];
+    u8 cmask[2 * NBANDS];
+    u8 bin2band[120];
+    i16 pcm_silk[1920];        // SILK output at 48 kHz for the hybrid / SILK-only mix
+};
+
+} // namespace og

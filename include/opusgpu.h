@@ -1,0 +1,106 @@
+/*
+ * opusgpu.h -- C ABI of the MI355X batched Opus decoder (libopusgpu.so).
+ *
+ * This is the drop-in boundary for the reference's decode hot path
+ *   opus_multistream_decode -> opus_decode_native -> opus_decode_frame -> {ec_*, silk_Decode, celt_decode_with_ec}
+ *   (reference: src/opus_decoder.cpp:931, :280, :154; src/silk.cpp:1481; src/celt.cpp:2162).
+ * The reference decodes ONE stream per process with its codec state in file-scope globals; this
+ * library keeps one state record per stream in HBM and decodes one 20 ms frame of every submitted
+ * stream per step, one frame per wavefront.  PCM is bit-exact to the reference's fixed-point decoder.
+ *
+ * Plain C: opaque handle, plain pointers and sizes, negative OPUS_* error codes (reference values,
+ * src/opus_decoder.h:70-77).  No exceptions cross this boundary.  One host thread per context.
+ * The reference-compatible C++ entry points (opus_multistream_decode, op_read_stereo, ...) declared in
+ * include/opus_decoder.h and include/opusfile.h are implemented on top of this ABI.
+ */
+#ifndef OPUSGPU_H
+#define OPUSGPU_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPUSGPU_OK 0
+#define OPUSGPU_BAD_ARG (-1)          /* OPUS_BAD_ARG */
+#define OPUSGPU_BUFFER_TOO_SMALL (-2) /* OPUS_BUFFER_TOO_SMALL */
+#define OPUSGPU_INTERNAL_ERROR (-3)   /* OPUS_INTERNAL_ERROR */
+#define OPUSGPU_INVALID_PACKET (-4)   /* OPUS_INVALID_PACKET */
+#define OPUSGPU_UNIMPLEMENTED (-5)    /* OPUS_UNIMPLEMENTED */
+#define OPUSGPU_ALLOC_FAIL (-7)       /* OPUS_ALLOC_FAIL */
+#define OPUSGPU_ERR_NO_DEVICE (-100)  /* no usable HIP device / kernel image: there is NO CPU fallback */
+#define OPUSGPU_ERR_HIP (-101)        /* a HIP runtime call failed; see opusgpu_last_error() */
+
+#define OPUSGPU_FRAME_SAMPLES 960     /* the reference decodes 20 ms at 48 kHz only (src/opus_decoder.cpp:161) */
+#define OPUSGPU_MAX_FRAME_BYTES 1275
+
+typedef struct opusgpu_ctx opusgpu_ctx;
+
+/* One frame of work for one stream in one decode step (16 bytes, device layout).
+ * flags: bits 0-1 mode (0 SILK-only, 1 hybrid, 2 CELT-only); bits 2-4 bandwidth (0 NB .. 4 FB); bit 5 stereo.
+ * These are the TOC fields opus_decode_native derives (src/opus_decoder.cpp:312-315). */
+typedef struct opusgpu_frame_desc {
+    int32_t stream;  /* stream index in the context */
+    int32_t offset;  /* byte offset of the frame payload inside the packet arena */
+    int32_t len;     /* payload bytes, 0..1275 */
+    int32_t flags;
+} opusgpu_frame_desc;
+
+/* ---- context -------------------------------------------------------------------------------- */
+int opusgpu_version(void);
+/* Binds to HIP device `device` (>=0).  Fails with OPUSGPU_ERR_NO_DEVICE when no GPU is usable. */
+int opusgpu_ctx_create(int device, opusgpu_ctx **out);
+void opusgpu_ctx_destroy(opusgpu_ctx *ctx);
+const char *opusgpu_last_error(const opusgpu_ctx *ctx);
+
+/* ---- streams -------------------------------------------------------------------------------- */
+/* Allocates `n_streams` per-stream state records in HBM (replacing any previous set) and gives each
+ * the fresh state of opus_multistream_decoder_init(48000, channels, 1, channels-1, {0,1})
+ * (src/opus_decoder.cpp:742).  channels is 1 or 2. */
+int opusgpu_streams_alloc(opusgpu_ctx *ctx, int n_streams, int channels);
+/* full != 0: fresh state again (decoder_init).  full == 0: OPUS_RESET_STATE semantics of
+ * opus_multistream_decoder_ctl (src/opus_decoder.cpp:976 -> :382), which is NOT a full reset (CELT keeps
+ * its synthesis history, band energies and de-emphasis memory: src/celt.cpp:2479-2498). */
+int opusgpu_streams_reset(opusgpu_ctx *ctx, int first, int count, int full);
+int opusgpu_stream_count(const opusgpu_ctx *ctx);
+int opusgpu_stream_channels(const opusgpu_ctx *ctx);
+size_t opusgpu_stream_state_bytes(void);
+
+/* ---- host-buffer path: the batched equivalent of opus_multistream_decode (src/opus_decoder.cpp:931) --- */
+/* Decodes packets[i] (lens[i] bytes, TOC first) for stream stream_ids[i], i < n; a stream may appear
+ * at most once per call.  pcm receives n blocks of `frame_capacity` * 960 * channels interleaved int16;
+ * result[i] = samples per channel decoded for packet i (frames * 960) or a negative OPUS_* code.
+ * Packets with several frames (codes 1-3) are decoded frame after frame like opus_decode_native.
+ * Returns OPUSGPU_OK or a context-level error. */
+int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, const uint8_t *const *packets,
+                           const int32_t *lens, int16_t *pcm, int frame_capacity, int32_t *result);
+
+/* Splits one packet into frame descriptors exactly as opus_packet_parse_impl + the TOC helpers do
+ * (src/opus_decoder.cpp:559, :135, :460, :474).  descs[k].offset is relative to the packet start.
+ * Returns the frame count (1..48) or a negative OPUS_* code.  Pure host code. */
+int opusgpu_packet_to_frames(const uint8_t *packet, int32_t len, int32_t stream, opusgpu_frame_desc descs[48]);
+
+/* ---- device-resident path (inputs and outputs stay in HBM; used by bench.py and on-device consumers) -- */
+int opusgpu_dev_alloc(opusgpu_ctx *ctx, size_t bytes, void **dptr);
+int opusgpu_dev_free(opusgpu_ctx *ctx, void *dptr);
+int opusgpu_memcpy_h2d(opusgpu_ctx *ctx, void *dst, const void *src, size_t bytes);
+int opusgpu_memcpy_d2h(opusgpu_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* One decode step: n frames described by d_descs (device array of opusgpu_frame_desc), payload bytes in
+ * d_arena, PCM to d_pcm[n][960*channels] int16, per-frame result to d_result[n] int32.  Asynchronous on the
+ * context's stream (or on `hip_stream` if not NULL: a hipStream_t). */
+int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm,
+                               void *d_result, void *hip_stream);
+int opusgpu_synchronize(opusgpu_ctx *ctx);
+/* HIP events on the context's stream, for timing from hosts without HIP headers. */
+int opusgpu_event_create(opusgpu_ctx *ctx, void **event);
+int opusgpu_event_record(opusgpu_ctx *ctx, void *event);
+int opusgpu_event_elapsed_ms(opusgpu_ctx *ctx, void *start, void *stop, float *ms); /* synchronises on stop */
+int opusgpu_event_destroy(opusgpu_ctx *ctx, void *event);
+/* Copies stream `index`'s raw state record to the host (tests / checkpointing). */
+int opusgpu_stream_state_get(opusgpu_ctx *ctx, int index, void *dst, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

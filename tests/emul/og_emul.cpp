@@ -1,0 +1,29 @@
+// TEST-ONLY host emulation of the HIP decode kernels (see og_common.hpp, OG_HOST_EMUL).
+// Compiles the kernel headers for the CPU with a one-lane "wave" so the device source can be fuzzed
+// against the oracle and run under ASan/UBSan without a GPU.  Never linked into libopusgpu.so.
+#define OG_HOST_EMUL 1
+#include "og_decode.hpp"
+
+extern "C" {
+int emu_state_size(void) { return (int)sizeof(og::StreamState); }
+void emu_stream_init(void *st, int channels) { og::stream_init((og::StreamState *)st, channels); }
+void emu_stream_reset(void *st) { og::stream_reset((og::StreamState *)st); }
+int emu_decode_frame(void *st, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm) {
+    return og::decode_frame_wave((og::StreamState *)st, payload, len, mode, bw, ch, pcm);
+}
+}
+
+// ---- stage taps -------------------------------------------------------------------------------
+static int16_t tap_X[1920], tap_bandE[42];
+static int32_t tap_syn_pre[2][1080], tap_syn_post[2][1080];
+extern "C" void og_emul_tap(int id) {
+    if (id == 1) { memcpy(tap_X, &og::S.v[og::V_X], sizeof(tap_X)); memcpy(tap_bandE, og::S.bandE, sizeof(tap_bandE)); }
+    if (id == 2) for (int c = 0; c < 2; c++) memcpy(tap_syn_pre[c], og::S.syn[c], 1080 * 4);
+    if (id == 3) for (int c = 0; c < 2; c++) memcpy(tap_syn_post[c], og::S.syn[c], 1080 * 4);
+}
+extern "C" {
+const int16_t *emu_tap_X(void) { return tap_X; }
+const int16_t *emu_tap_bandE(void) { return tap_bandE; }
+const int32_t *emu_tap_syn_pre(int c) { return tap_syn_pre[c]; }
+const int32_t *emu_tap_syn_post(int c) { return tap_syn_post[c]; }
+}

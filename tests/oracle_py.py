@@ -1,0 +1,85 @@
+"""ctypes binding of the CPU oracle (oracle/liboc_oracle.so).  TEST INFRASTRUCTURE ONLY: used by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker, never by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "liboc_oracle.so")
+
+MODE_SILK, MODE_HYBRID, MODE_CELT = 1000, 1001, 1002
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        vp = C.c_void_p
+        lib.oc_decoder_create.restype = vp
+        lib.oc_decoder_create.argtypes = [C.c_int]
+        lib.oc_decoder_destroy.argtypes = [vp]
+        lib.oc_decoder_destroy.restype = None
+        lib.oc_decoder_init.argtypes = [vp, C.c_int]
+        lib.oc_decoder_init.restype = None
+        lib.oc_decoder_reset.argtypes = [vp]
+        lib.oc_decoder_reset.restype = None
+        lib.oc_decode.argtypes = [vp, C.c_char_p, C.c_int32, vp, C.c_int]
+        lib.oc_decode.restype = C.c_int
+
+    def decoder(self, channels):
+        return OracleDecoder(self, channels)
+
+    def decode_streams(self, channels, packets_per_stream):
+        """packets_per_stream: list (streams) of list (frames) of bytes -> int16 [streams, frames, 960, ch]
+        plus return codes [streams, frames].  Fresh state per stream."""
+        ns = len(packets_per_stream)
+        nf = max(len(p) for p in packets_per_stream)
+        pcm = np.zeros((ns, nf, 960, channels), dtype=np.int16)
+        rets = np.zeros((ns, nf), dtype=np.int32)
+        d = self.decoder(channels)
+        for s, pk in enumerate(packets_per_stream):
+            d.init()
+            for f, p in enumerate(pk):
+                out, r = d.decode(p)
+                rets[s, f] = r
+                if r > 0:
+                    pcm[s, f, :r] = out[:r]
+        return pcm, rets
+
+
+class OracleDecoder:
+    def __init__(self, o, channels):
+        self.o, self.channels = o, channels
+        self.h = o.lib.oc_decoder_create(channels)
+        self.buf = np.zeros((5760, channels), dtype=np.int16)
+
+    def init(self):
+        self.o.lib.oc_decoder_init(self.h, self.channels)
+
+    def reset(self):
+        self.o.lib.oc_decoder_reset(self.h)
+
+    def decode(self, packet: bytes):
+        r = self.o.lib.oc_decode(self.h, bytes(packet), len(packet), self.buf.ctypes.data, 5760)
+        return self.buf, r
+
+    def __del__(self):
+        try:
+            self.o.lib.oc_decoder_destroy(self.h)
+        except Exception:
+            pass
+
+
+def fnv1a_u16(samples, h=2166136261):
+    """FNV-1a over uint16 units (the hash the survey's KATs were recorded with)."""
+    u = np.ascontiguousarray(samples).view(np.uint16).reshape(-1)
+    for v in u.tolist():
+        h = ((h ^ v) * 16777619) & 0xFFFFFFFF
+    return h
+
+
+def load():
+    if not os.path.exists(LIB):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    return Oracle(C.CDLL(LIB))
