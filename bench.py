@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the Opus decode hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch: every stream of the batch decodes one 20 ms
+frame (stream state persists in HBM from step to step).  Workload at N=1 = BASELINE.json configs[1]:
+65,536 synthetic CELT-only fullband stereo streams, 160-byte LCG payloads.
+All packets of all timed steps are resident in HBM before the timed region starts.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  `value` = frames decoded by all ranks / max-over-ranks wall time.
+`roofline` prices the decode kernel against HBM peak using the ALGORITHMIC bytes per frame
+(B_celt = 21,633 B); `cpu_baseline` times the CPU oracle (a bit-identical port of
+the reference path) on a bounded sample of the same workload on this host's cores.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKLOADS = {
+    # name: (toc, payload bytes, algorithmic bytes per frame [SURVEY 8d], default streams per GPU)
+    "celt_fb_stereo_64k": (0xFC, 160, 21633, 65536),
+    "silk_nb_stereo_64k": (0x0C, 40, 5953, 65536),
+    "hybrid_fb_stereo_256k": (0x7C, 120, 24945, 262144),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def load_pkg():
+    name = "esp32_opus_player_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    path = os.path.join(ROOT, "esp32-opus-player_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location(name, path, submodule_search_locations=[os.path.dirname(path)])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cpu_baseline(toc, L, seconds_target=12.0):
+    """Time the CPU oracle (bit-identical port of the reference decode path) on a bounded sample."""
+    import oracle_py
+    o = oracle_py.load()
+    pkg = load_pkg()
+    cores = os.cpu_count() or 1
+    frames = 16
+    # calibrate on one core, then size the sample to ~seconds_target of total CPU work
+    pay = pkg.lcg_payloads(64, frames, L)
+    t0 = time.perf_counter()
+    o.batch_decode(2, toc, pay, want_pcm=False)
+    per_frame = (time.perf_counter() - t0) / (64 * frames)
+    streams = int(max(cores * 8, min(65536, seconds_target / per_frame / frames)))
+    streams -= streams % cores
+    pay = pkg.lcg_payloads(streams, frames, L)
+    oks = [0] * cores
+    chunk = streams // cores
+
+    def work(t):
+        _, oks[t] = o.batch_decode(2, toc, pay, s0=t * chunk, s1=(t + 1) * chunk, want_pcm=False)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+    t0 = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    total = sum(oks)
+    return {
+        "value": total / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": f"{streams} streams x {frames} frames of the same workload, {cores} threads "
+                  f"(one oracle decoder per stream), {dt:.2f} s wall",
+        "single_core_frames_per_s": 1.0 / per_frame,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="celt_fb_stereo_64k", choices=sorted(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    toc, L, bytes_per_frame, default_streams = WORKLOADS[args.workload]
+    n = args.streams or default_streams
+    K, W = args.steps, args.warmup
+
+    pkg = load_pkg()
+    ctx = pkg.Context(local_rank)
+    ctx.streams_alloc(n, 2)
+    # streams are sharded across ranks with no data-path exchange: each rank owns streams
+    # [rank*n, (rank+1)*n) of the global id space (seeds differ per global stream id)
+    pay = pkg.lcg_payloads(n, K + W, L, seed_base=0x9E3779B9 ^ (rank * 0x01000193))
+    d_arena, d_desc = [], []
+    for f in range(K + W):
+        arena, descs = pkg.build_step(toc, pay[f])
+        a = ctx.dev_alloc(arena.nbytes + 16)
+        d = ctx.dev_alloc(descs.nbytes)
+        ctx.h2d(a, arena)
+        ctx.h2d(d, descs)
+        d_arena.append(a)
+        d_desc.append(d)
+    d_pcm = ctx.dev_alloc(n * 960 * 2 * 2)
+    d_res = ctx.dev_alloc(4 * n)
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for f in range(W):
+        ctx.decode_step_device(n, d_desc[f], d_arena[f], d_pcm, d_res)
+    ctx.synchronize()
+    ev = [ctx.event() for _ in range(K + 1)]
+    barrier()
+    t0 = time.perf_counter()
+    ctx.event_record(ev[0])
+    for f in range(K):
+        ctx.decode_step_device(n, d_desc[W + f], d_arena[W + f], d_pcm, d_res)
+        ctx.event_record(ev[f + 1])
+    ctx.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = [ctx.event_elapsed_ms(ev[f], ev[f + 1]) for f in range(K)]
+    res = np.zeros(n, dtype=np.int32)
+    ctx.d2h(res, d_res)
+    if not (res == 960).all():
+        raise SystemExit(f"decode failed for {(res != 960).sum()} frames in the last step")
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        total_frames = n * K * world
+        value = total_frames / dt
+        avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
+        achieved = bytes_per_frame * n / avg_kernel_s / 1e9
+        line = {
+            "metric": "decoded 48 kHz stereo frames/sec/GPU (x real-time); HBM GB/s vs roofline",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32 fixed-point (int16/int32 with 64-bit products)", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {n} streams/GPU x 20 ms frames, 48 kHz stereo, "
+                                   f"TOC 0x{toc:02X}, {L}-byte LCG payloads, state persistent across steps",
+                       "streams_per_gpu": n, "sharding": "streams partitioned across ranks, no data-path collective"},
+            "x_realtime_per_gpu": value / world / 50.0,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_decode_step", "avg_launch_ms": avg_kernel_s * 1e3,
+                         "algorithmic_bytes_per_frame": bytes_per_frame, "frames_per_launch": n},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(toc, L)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libopusgpu.so")
+LIB_PATH = os.environ.get("OPUSGPU_LIB", os.path.join(HERE, "libopusgpu.so"))  # override: experiments only
 
 OPUSGPU_ERR_NO_DEVICE = -100
 FRAME = 960

@@ -27,7 +27,10 @@ __global__ void __launch_bounds__(64) k_stream_init(StreamState *st, int first, 
         stream_reset(&st[s]);
 }
 
-__global__ void __launch_bounds__(64) k_decode_step(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
+#ifndef OG_WAVES_PER_SIMD
+#define OG_WAVES_PER_SIMD 1
+#endif
+__global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
                                                    StreamState *st, i16 *pcm, i32 *result, int n, int n_streams,
                                                    int pcm_stride) {
     const int f = (int)blockIdx.x;

@@ -741,6 +741,9 @@ OG_DEVN int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int 
     const int codedBands = compute_allocation(rc, start, end, alloc_trim, intensity, dual_stereo, bits, balance, C, LM);
     fine_energy(rc, start, end, C);
 
+#if defined(OG_ABLATE) && OG_ABLATE == 1
+    return frame_size;
+#endif
     u32 seed = st->rng;
     decode_all_bands(rc, start, end, C, N, shortBlocks, spread, dual_stereo, intensity,
                      (i32)rc.storage * (8 << BITRES) - anti_collapse_rsv, balance, LM, codedBands, seed, disable_inv);
@@ -752,11 +755,17 @@ OG_DEVN int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int 
         for (int i = 0; i < C * NBANDS; i++) S.bandE[i] = (i16)(-28 * 1024);
 
     OG_TAP(1); // X and bandE final
+#if defined(OG_ABLATE) && OG_ABLATE == 2
+    return frame_size;
+#endif
     // ---- synthesis
     denorm_gains(start, end, C, silence);
     const int B = transient ? M : 1, shift = transient ? 3 : 3 - LM;
     imdct_all(N, LM, B, shift, C, CC);
     OG_TAP(2); // IMDCT output
+#if defined(OG_ABLATE) && OG_ABLATE == 3
+    return frame_size;
+#endif
 
     int pp = OG_MAX(st->pf_period, 15), ppo = OG_MAX(st->pf_period_old, 15);
     i32 pg = st->pf_gain, pgo = st->pf_gain_old;
@@ -767,6 +776,9 @@ OG_DEVN int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int 
     }
 
     OG_TAP(3); // comb filter output
+#if defined(OG_ABLATE) && OG_ABLATE == 4
+    return frame_size;
+#endif
     // ---- energy history (celt.cpp:2404-2436)
     OG_SYNC();
     if (C == 1) {

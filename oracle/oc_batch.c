@@ -1,0 +1,37 @@
+/*
+ * oc_batch.c -- CPU ORACLE (test infrastructure): decode many independent streams in one call.
+ * Used by tests (reference PCM for large batches) and by bench.py's cpu_baseline leg, where it is
+ * the thing being TIMED as the CPU baseline ("port" of the reference path), never the product.
+ */
+#include <stdlib.h>
+#include "oc_opus.h"
+
+/* payloads: [n_frames][n_streams][L] bytes; packet = toc + payload (code 0).  Streams [s0, s1) are decoded
+ * with a fresh decoder each; pcm (may be NULL): [n_streams][n_frames][960][channels].  Returns the number of
+ * frames decoded successfully. */
+long oc_batch_decode(int channels, int toc, const u8 *payloads, int n_streams, int n_frames, int L, int s0, int s1,
+                     i16 *pcm) {
+    oc_decoder *d = oc_decoder_create(channels);
+    i16 *tmp = (i16 *)malloc(sizeof(i16) * 5760 * 2);
+    u8 pkt[1300];
+    long ok = 0;
+    int s, f, i;
+    if (!d || !tmp || L > 1275) return -1;
+    for (s = s0; s < s1; s++) {
+        oc_decoder_init(d, channels);
+        for (f = 0; f < n_frames; f++) {
+            const u8 *p = payloads + ((size_t)f * n_streams + s) * L;
+            int r;
+            pkt[0] = (u8)toc;
+            for (i = 0; i < L; i++) pkt[1 + i] = p[i];
+            r = oc_decode(d, pkt, L + 1, tmp, 5760);
+            if (r == 960) {
+                ok++;
+                if (pcm) memcpy(pcm + (((size_t)s * n_frames + f) * 960) * channels, tmp, sizeof(i16) * 960 * channels);
+            }
+        }
+    }
+    free(tmp);
+    oc_decoder_destroy(d);
+    return ok;
+}

@@ -26,6 +26,18 @@ class Oracle:
         lib.oc_decoder_reset.restype = None
         lib.oc_decode.argtypes = [vp, C.c_char_p, C.c_int32, vp, C.c_int]
         lib.oc_decode.restype = C.c_int
+        lib.oc_batch_decode.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+        lib.oc_batch_decode.restype = C.c_long
+
+    def batch_decode(self, channels, toc, payloads, s0=0, s1=None, want_pcm=True):
+        """payloads uint8 [frames, streams, L] -> (pcm int16 [streams, frames, 960, ch] or None, frames_ok)."""
+        nf, ns, L = payloads.shape
+        s1 = ns if s1 is None else s1
+        pay = np.ascontiguousarray(payloads)
+        pcm = np.zeros((ns, nf, 960, channels), dtype=np.int16) if want_pcm else None
+        ok = self.lib.oc_batch_decode(channels, toc, pay.ctypes.data, ns, nf, L, s0, s1,
+                                      pcm.ctypes.data if want_pcm else None)
+        return pcm, ok
 
     def decoder(self, channels):
         return OracleDecoder(self, channels)
