@@ -120,7 +120,7 @@ OG_DEVN void tf_decode(Rc &rc, int start, int end, int transient, int LM) { // c
 // ---- bit allocation (clt_compute_allocation celt.cpp:3523, interp_bits2pulses :3298) ----------------
 OG_DEVN int compute_allocation(Rc &rc, int start, int end, int alloc_trim, i32 &intensity, i32 &dual_stereo, i32 total,
                                i32 &balance_out, int C, int LM) {
-    const i16 *eb = rom_eband;
+    const i32 *eb = rom_eband;
     int skip_start = start, intensity_rsv = 0, dual_stereo_rsv = 0;
     total = OG_MAX(total, 0);
     int skip_rsv = total >= 1 << BITRES ? 1 << BITRES : 0;
@@ -173,6 +173,15 @@ OG_DEVN int compute_allocation(Rc &rc, int start, int end, int alloc_trim, i32 &
         S.bits1[j] = b1;
         S.bits2[j] = b2;
     }
+#ifdef OG_DUMP1
+    for (int j = 0; j < NBANDS; j++) {
+        S.v[V_X + 300 + j] = (i16)S.thresh[j]; S.v[V_X + 332 + j] = (i16)S.trim_off[j];
+        S.v[V_X + 364 + j] = (i16)S.bits1[j]; S.v[V_X + 396 + j] = (i16)S.bits2[j];
+    }
+    S.v[V_X + 428] = (i16)total; S.v[V_X + 429] = (i16)lo; S.v[V_X + 430] = (i16)hi; S.v[V_X + 431] = (i16)skip_start;
+    S.v[V_X + 432] = (i16)intensity_rsv; S.v[V_X + 433] = (i16)dual_stereo_rsv; S.v[V_X + 434] = (i16)skip_rsv; S.v[V_X+435]=(i16)alloc_trim;
+    S.v[V_X + 436] = (i16)rom_band_alloc[5 * NBANDS + 3]; S.v[V_X + 437] = (i16)rom_log2_frac[21]; S.v[V_X+438]=(i16)rom_eband[21];
+#endif
     // ---- interpolation between the two allocation vectors
     const int alloc_floor = C << BITRES, stereo = C > 1, logM = LM << BITRES;
     i32 psum;
@@ -601,7 +610,7 @@ OG_DEV void celt_reset_state(CeltState *st) { // OPUS_RESET_STATE celt.cpp:2479 
 // pcm_out: LDS i16 buffer (interleaved, CC channels) -- S.v[V_X..] is reused for it after synthesis.
 // Returns frame_size or a negative code (wave-uniform).
 OG_DEVN int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int CC, int start, int disable_inv) {
-    const i16 *eb = rom_eband;
+    const i32 *eb = rom_eband;
     const int end = NBANDS;
     int LM;
     for (LM = 0; LM <= 3; LM++)
@@ -742,6 +751,19 @@ OG_DEVN int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int 
     fine_energy(rc, start, end, C);
 
 #if defined(OG_ABLATE) && OG_ABLATE == 1
+#ifdef OG_DUMP1
+    for (int i = 0; i < NBANDS; i++) {
+        S.v[V_X + i] = (i16)S.pulses[i];
+        S.v[V_X + 32 + i] = (i16)S.fine_quant[i];
+        S.v[V_X + 64 + i] = (i16)S.tf_res[i];
+        S.v[V_X + 96 + i] = (i16)S.cap[i];
+        S.v[V_X + 128 + i] = (i16)S.offsets[i];
+    }
+    S.v[V_X + 160] = (i16)codedBands; S.v[V_X + 161] = (i16)intensity; S.v[V_X + 162] = (i16)dual_stereo;
+    S.v[V_X + 163] = (i16)spread; S.v[V_X + 164] = (i16)transient; S.v[V_X + 165] = (i16)balance; S.v[V_X + 166] = (i16)alloc_trim;
+    S.v[V_X + 167] = (i16)rc_tell(rc); S.v[V_X + 168] = (i16)intra; S.v[V_X+169]=(i16)pf_pitch; S.v[V_X+170]=(i16)silence;
+    for (int i = 0; i < 42; i++) S.v[V_X + 192 + i] = S.bandE[i];
+#endif
     return frame_size;
 #endif
     u32 seed = st->rng;

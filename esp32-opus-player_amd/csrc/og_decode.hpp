@@ -84,6 +84,10 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
             // writes 120*CC samples at the head of the PCM staging area; the rest stays zero.  The
             // reference ignores the return value here (src/opus_decoder.cpp:267).
             (void)celt_decode_frame(&st->celt, rc, 120, ch, CC, 0, disable_inv);
+            // the CELT working vectors share the staging area: clear everything past the 120 decoded samples
+            OG_SYNC();
+            OG_FOR_LANES(i, (audiosize - 120) * CC) S.v[V_X + 120 * CC + i] = 0;
+            OG_SYNC();
         }
     }
 #ifndef OG_NO_SILK

@@ -1,0 +1,902 @@
+// og_silk.hpp -- SILK frame decoder, one frame (both channels) per wavefront.
+//
+// Behaviour reproduced: silk_Decode as the reference drives it (src/silk.cpp:1481; lostFlag == 0,
+// 20 ms payload, API rate 48 kHz, nChannelsAPI == nChannelsInternal == packet channels, src/opus_decoder.cpp:167-203).
+//
+// Mapping onto the wave:
+//   [scalar, wave-uniform]   VAD/LBRR flags, LBRR skip-decode, stereo predictor, then per channel:
+//                            side information, shell/sign pulse decode, gain dequantisation, NLSF decode +
+//                            stabilise, NLSF-to-LPC (even/odd polynomials, LPC fit, stability check).
+//                            All of it hangs off the range decoder or is a short dependent recurrence.
+//   [one lane per channel]   silk_decode_core: excitation, LTP and the order-10/16 LPC synthesis recurrence
+//                            (saturating, hence serial in time) -- mid and side are independent once their
+//                            parameters are known, so they run side by side; the 2x all-pass up-sampler
+//                            (three serial first-order sections per phase) likewise.
+//   [lane-parallel]          mid/side -> left/right, the 8-tap 12-phase FIR interpolation to 48 kHz,
+//                            interleave into S.pcm_silk.
+// Scratch lives in LDS, overlaid on the CELT synthesis buffer (SILK always runs before CELT in a frame).
+#pragma once
+#include "og_celt_math.hpp"
+
+namespace og {
+
+constexpr int SILK_MAX_LPC = 16;
+constexpr int SILK_MAX_FRAME = 320;
+
+struct SilkCtrl { // silk_decoder_control_t (src/silk.h:747) + the frame's side information (:588)
+    i32 pitchL[4], Gains_Q16[4];
+    i16 PredCoef_Q12[2][SILK_MAX_LPC];
+    i16 LTPCoef_Q14[20];
+    i32 LTP_scale_Q14;
+    i32 signalType, quantOffsetType, NLSFInterpCoef_Q2, Seed, lagIndex, contourIndex, PERIndex, LTP_scaleIndex;
+    i32 GainsIndices[4], LTPIndex[4], NLSFIndices[SILK_MAX_LPC + 1];
+    i32 coded; // channel has a coded frame this step
+};
+
+struct SilkLds {
+    i16 pulses[2][SILK_MAX_FRAME + 16];
+    i16 xq[2][SILK_MAX_FRAME + 8];      // [0..2) look-back slots, frame at +2 (samplesOut1_tmp, silk.cpp:1657)
+    i32 sLTP_Q15[2][2 * SILK_MAX_FRAME];
+    i16 sLTP[2][SILK_MAX_FRAME];
+    i16 up[2][8 + 2 * SILK_MAX_FRAME + 8];  // FIR history + 2x up-sampled frame
+    i16 hist[2][SILK_MAX_FRAME + 160];      // outBuf staged from HBM (+ 2 subframes for the mid-frame re-whitening)
+    SilkCtrl ctrl[2];
+    i32 sum_pulses[20], nLshifts[20];
+    i32 VAD_flags[2], LBRR_flag[2];
+    i16 nlsf[SILK_MAX_LPC], nlsf0[SILK_MAX_LPC], ec_ix[SILK_MAX_LPC], res_Q10[SILK_MAX_LPC];
+    i32 pred_Q8[SILK_MAX_LPC];
+    i32 cosLSF[SILK_MAX_LPC], P[SILK_MAX_LPC / 2 + 1], Q[SILK_MAX_LPC / 2 + 1], a32[SILK_MAX_LPC], Atmp[SILK_MAX_LPC];
+};
+static_assert(sizeof(SilkLds) <= sizeof(i32) * 2 * SYN_LEN + sizeof(i16) * V_TOTAL, "SILK scratch must fit the CELT overlay");
+
+OG_DEV SilkLds &SL() { return *reinterpret_cast<SilkLds *>(&S.syn[0][0]); }
+
+// ---- state ------------------------------------------------------------------------------------------
+OG_DEV void silk_chan_init(SilkChannel *c) { // silk_init_decoder silk.cpp:2192
+    u32 *w = reinterpret_cast<u32 *>(c);
+    OG_FOR_LANES(i, (int)(sizeof(SilkChannel) / 4)) w[i] = 0;
+    OG_SYNC();
+    if (OG_LANE == 0) {
+        c->first_frame_after_reset = 1;
+        c->prev_gain_Q16 = 65536;
+    }
+    OG_SYNC();
+}
+
+// silk_InitDecoder silk.cpp:1792.  The channel init clears fs_kHz, so the resampler part of the record is
+// re-initialised by the next frame exactly when the reference re-initialises its (separate) resampler state.
+OG_DEV void silk_init_state(SilkState *s) {
+    silk_chan_init(&s->ch[0]);
+    silk_chan_init(&s->ch[1]);
+    if (OG_LANE == 0) {
+        s->pred_prev_Q13[0] = s->pred_prev_Q13[1] = 0;
+        s->sMid[0] = s->sMid[1] = 0;
+        s->sSide[0] = s->sSide[1] = 0;
+        s->prev_decode_only_middle = 0;
+    }
+    OG_SYNC();
+}
+
+// ---- scalar helpers (src/silk.h:913-996, silk.cpp:2248) -------------------------------------------------
+OG_DEV i32 iabs(i32 a) { return a < 0 ? -a : a; }
+
+OG_DEV i32 silk_div32_varQ(i32 a32, i32 b32, int Qres) {
+    int a_headrm = clz32(iabs(a32)) - 1, b_headrm = clz32(iabs(b32)) - 1;
+    i32 a32_nrm = shl32(a32, a_headrm), b32_nrm = shl32(b32, b_headrm);
+    i32 b32_inv = (2147483647 >> 2) / (b32_nrm >> 16);
+    i32 result = smulwb(a32_nrm, b32_inv);
+    a32_nrm = subw(a32_nrm, shl32(smmul(b32_nrm, result), 3));
+    result = smlawb(result, a32_nrm, b32_inv);
+    int lshift = 29 + a_headrm - b_headrm - Qres;
+    if (lshift < 0) return lshift_sat32(result, -lshift);
+    return lshift < 32 ? result >> lshift : 0;
+}
+
+OG_DEV i32 silk_inverse32_varQ(i32 b32, int Qres) {
+    int b_headrm = clz32(iabs(b32)) - 1;
+    i32 b32_nrm = shl32(b32, b_headrm);
+    i32 b32_inv = (2147483647 >> 2) / (b32_nrm >> 16);
+    i32 result = shl32(b32_inv, 16);
+    i32 err_Q32 = shl32((1 << 29) - smulwb(b32_nrm, b32_inv), 3);
+    result = addw(result, smulww(err_Q32, b32_inv));
+    int lshift = 61 - b_headrm - Qres;
+    if (lshift <= 0) return lshift_sat32(result, -lshift);
+    return lshift < 32 ? result >> lshift : 0;
+}
+
+OG_DEV i32 silk_log2lin(i32 inLog_Q7) {
+    if (inLog_Q7 < 0) return 0;
+    if (inLog_Q7 >= 3967) return 2147483647;
+    i32 out = shl32(1, inLog_Q7 >> 7), frac_Q7 = inLog_Q7 & 0x7F;
+    i32 t = smlawb(frac_Q7, smulbb(frac_Q7, 128 - frac_Q7), -174);
+    if (inLog_Q7 < 2048) return out + ((out * t) >> 7);
+    return out + (out >> 7) * t;
+}
+
+// ---- codebooks (silk_NLSF_CB_struct instances silk.cpp:384-427) -------------------------------------------
+struct NlsfCb {
+    int order;
+    i32 quantStepSize_Q16;
+    const u8 *CB1_NLSF_Q8, *CB1_iCDF, *pred_Q8, *ec_sel, *ec_iCDF;
+    const i32 *CB1_Wght_Q9, *deltaMin_Q15;
+};
+OG_DEV NlsfCb nlsf_cb(int wb) {
+    NlsfCb cb;
+    if (wb) {
+        cb.order = 16;
+        cb.quantStepSize_Q16 = 9830;
+        cb.CB1_NLSF_Q8 = rom_silk_wb_cb1_q8;
+        cb.CB1_Wght_Q9 = rom_silk_wb_cb1_wght_q9;
+        cb.CB1_iCDF = rom_silk_wb_cb1_icdf;
+        cb.pred_Q8 = rom_silk_wb_pred_q8;
+        cb.ec_sel = rom_silk_wb_cb2_select;
+        cb.ec_iCDF = rom_silk_wb_cb2_icdf;
+        cb.deltaMin_Q15 = rom_silk_wb_delta_min_q15;
+    } else {
+        cb.order = 10;
+        cb.quantStepSize_Q16 = 11796;
+        cb.CB1_NLSF_Q8 = rom_silk_nb_cb1_q8;
+        cb.CB1_Wght_Q9 = rom_silk_nb_cb1_wght_q9;
+        cb.CB1_iCDF = rom_silk_nb_cb1_icdf;
+        cb.pred_Q8 = rom_silk_nb_pred_q8;
+        cb.ec_sel = rom_silk_nb_cb2_select;
+        cb.ec_iCDF = rom_silk_nb_cb2_icdf;
+        cb.deltaMin_Q15 = rom_silk_nb_delta_min_q15;
+    }
+    return cb;
+}
+
+OG_DEV void nlsf_unpack(const NlsfCb &cb, int CB1_index) { // silk_NLSF_unpack silk.cpp:2762 -> SL().ec_ix / pred_Q8
+    SilkLds &L = SL();
+    const u8 *sel = &cb.ec_sel[CB1_index * cb.order / 2];
+    for (int i = 0; i < cb.order; i += 2) {
+        int entry = *sel++;
+        L.ec_ix[i] = (i16)(((entry >> 1) & 7) * 9);
+        L.pred_Q8[i] = cb.pred_Q8[i + (entry & 1) * (cb.order - 1)];
+        L.ec_ix[i + 1] = (i16)(((entry >> 5) & 7) * 9);
+        L.pred_Q8[i + 1] = cb.pred_Q8[i + ((entry >> 4) & 1) * (cb.order - 1) + 1];
+    }
+}
+
+// ---- side information (silk_decode_indices silk.cpp:708) --------------------------------------------------
+OG_DEVN void silk_decode_indices(SilkChannel *c, SilkCtrl &k, Rc &rc, int fs_kHz, int vad, int decode_LBRR, int condCoding,
+                                 i32 &ec_prevSignalType, i32 &ec_prevLagIndex) {
+    SilkLds &L = SL();
+    (void)c;
+    const NlsfCb cb = nlsf_cb(fs_kHz == 16);
+    int Ix;
+    if (decode_LBRR || vad)
+        Ix = rc_icdf(rc, rom_silk_type_vad_icdf, 8) + 2;
+    else
+        Ix = rc_icdf(rc, rom_silk_type_novad_icdf, 8);
+    k.signalType = Ix >> 1;
+    k.quantOffsetType = Ix & 1;
+    if (condCoding == 2)
+        k.GainsIndices[0] = rc_icdf(rc, rom_silk_delta_gain_icdf, 8);
+    else {
+        k.GainsIndices[0] = rc_icdf(rc, rom_silk_gain_icdf + 8 * k.signalType, 8) << 3;
+        k.GainsIndices[0] += rc_icdf(rc, rom_silk_uniform8_icdf, 8);
+    }
+    for (int i = 1; i < 4; i++) k.GainsIndices[i] = rc_icdf(rc, rom_silk_delta_gain_icdf, 8);
+    k.NLSFIndices[0] = rc_icdf(rc, &cb.CB1_iCDF[(k.signalType >> 1) * 32], 8);
+    nlsf_unpack(cb, k.NLSFIndices[0]);
+    for (int i = 0; i < cb.order; i++) {
+        Ix = rc_icdf(rc, &cb.ec_iCDF[L.ec_ix[i]], 8);
+        if (Ix == 0)
+            Ix -= rc_icdf(rc, rom_silk_nlsf_ext_icdf, 8);
+        else if (Ix == 8)
+            Ix += rc_icdf(rc, rom_silk_nlsf_ext_icdf, 8);
+        k.NLSFIndices[i + 1] = Ix - 4;
+    }
+    k.NLSFInterpCoef_Q2 = rc_icdf(rc, rom_silk_nlsf_interp_icdf, 8); // nb_subfr == 4
+    if (k.signalType == 2) {
+        int decode_abs = 1;
+        const u8 *lowbits = fs_kHz == 16 ? rom_silk_uniform8_icdf : (fs_kHz == 12 ? rom_silk_uniform6_icdf : rom_silk_uniform4_icdf);
+        const u8 *contour = fs_kHz == 8 ? rom_silk_pitch_contour_nb_icdf : rom_silk_pitch_contour_icdf;
+        if (condCoding == 2 && ec_prevSignalType == 2) {
+            int delta = rc_icdf(rc, rom_silk_pitch_delta_icdf, 8);
+            if (delta > 0) {
+                delta -= 9;
+                k.lagIndex = tr16(ec_prevLagIndex + delta);
+                decode_abs = 0;
+            }
+        }
+        if (decode_abs) {
+            k.lagIndex = tr16(rc_icdf(rc, rom_silk_pitch_lag_icdf, 8) * (fs_kHz >> 1));
+            k.lagIndex = tr16(k.lagIndex + rc_icdf(rc, lowbits, 8));
+        }
+        ec_prevLagIndex = k.lagIndex;
+        k.contourIndex = rc_icdf(rc, contour, 8);
+        k.PERIndex = rc_icdf(rc, rom_silk_ltp_per_icdf, 8);
+        const u8 *t = k.PERIndex == 0 ? rom_silk_ltp_gain_icdf0 : (k.PERIndex == 1 ? rom_silk_ltp_gain_icdf1 : rom_silk_ltp_gain_icdf2);
+        for (int j = 0; j < 4; j++) k.LTPIndex[j] = rc_icdf(rc, t, 8);
+        k.LTP_scaleIndex = condCoding == 0 ? rc_icdf(rc, rom_silk_ltpscale_icdf, 8) : 0;
+    }
+    ec_prevSignalType = k.signalType;
+    k.Seed = rc_icdf(rc, rom_silk_uniform4_icdf, 8);
+}
+
+// ---- excitation pulses (silk_decode_pulses :898, silk_shell_decoder :1162, silk_decode_signs :1436) ----------
+OG_DEV void shell_split(Rc &rc, int &c1, int &c2, int p, const u8 *table) {
+    if (p > 0) {
+        c1 = rc_icdf(rc, &table[rom_silk_shell_offsets[p]], 8);
+        c2 = p - c1;
+    } else {
+        c1 = 0;
+        c2 = 0;
+    }
+}
+
+OG_DEVN void silk_decode_pulses(Rc &rc, int ch, int signalType, int quantOffsetType, int frame_length) {
+    SilkLds &L = SL();
+    i16 *pulses = L.pulses[ch];
+    int iter = frame_length >> 4;
+    if (iter * 16 < frame_length) iter++;
+    const int RateLevelIndex = rc_icdf(rc, rom_silk_rate_levels_icdf + 9 * (signalType >> 1), 8);
+    const u8 *cdf = rom_silk_pulses_per_block_icdf + 18 * RateLevelIndex;
+    for (int i = 0; i < iter; i++) {
+        int nl = 0, sp = rc_icdf(rc, cdf, 8);
+        while (sp == 17) {
+            nl++;
+            sp = rc_icdf(rc, rom_silk_pulses_per_block_icdf + 18 * 9 + (nl == 10), 8);
+        }
+        L.nLshifts[i] = nl;
+        L.sum_pulses[i] = sp;
+    }
+    for (int i = 0; i < iter; i++) {
+        i16 *p0 = &pulses[i * 16];
+        const int sp = L.sum_pulses[i];
+        if (sp > 0) {
+            // binary shell tree: 16 -> 8 -> 4 -> 2 -> 1, depth-first in the reference's order
+            int p3[2], p2[4], p1[8], a, b;
+            shell_split(rc, p3[0], p3[1], sp, rom_silk_shell3);
+            for (int h = 0; h < 2; h++) {
+                shell_split(rc, p2[2 * h], p2[2 * h + 1], p3[h], rom_silk_shell2);
+                for (int q = 0; q < 2; q++) {
+                    const int qi = 2 * h + q;
+                    shell_split(rc, p1[2 * qi], p1[2 * qi + 1], p2[qi], rom_silk_shell1);
+                    for (int e = 0; e < 2; e++) {
+                        const int ei = 2 * qi + e;
+                        shell_split(rc, a, b, p1[ei], rom_silk_shell0);
+                        p0[2 * ei] = (i16)a;
+                        p0[2 * ei + 1] = (i16)b;
+                    }
+                }
+            }
+        } else {
+            for (int j = 0; j < 16; j++) p0[j] = 0;
+        }
+    }
+    for (int i = 0; i < iter; i++) {
+        const int nLS = L.nLshifts[i];
+        if (nLS > 0) {
+            i16 *p = &pulses[i * 16];
+            for (int j = 0; j < 16; j++) {
+                i32 abs_q = p[j];
+                for (int b = 0; b < nLS; b++) {
+                    abs_q = shl32(abs_q, 1);
+                    abs_q += rc_icdf(rc, rom_silk_lsb_icdf, 8);
+                }
+                p[j] = (i16)abs_q;
+            }
+            L.sum_pulses[i] |= nLS << 5;
+        }
+    }
+    const u8 *icdf_ptr = &rom_silk_sign_icdf[7 * (quantOffsetType + (signalType << 1))];
+    const int length = (frame_length + 8) >> 4;
+    for (int i = 0; i < length; i++) {
+        const int p = L.sum_pulses[i];
+        if (p > 0) {
+            const u32 ic0 = icdf_ptr[OG_MIN(p & 0x1F, 6)];
+            i16 *q = &pulses[i * 16];
+            for (int j = 0; j < 16; j++) {
+                if (q[j] > 0) {
+                    // two-symbol iCDF {ic0, 0}, ftb 8
+                    u32 s = rc.rng, d = rc.val, r = s >> 8, t = s;
+                    int ret = 0;
+                    s = r * ic0;
+                    if (d < s) {
+                        t = s;
+                        s = 0;
+                        ret = 1;
+                    }
+                    rc.val = d - s;
+                    rc.rng = t - s;
+                    rc_renorm(rc);
+                    q[j] = (i16)(q[j] * ((ret << 1) - 1));
+                }
+            }
+        }
+    }
+}
+
+// ---- NLSF decode and NLSF -> LPC ------------------------------------------------------------------------------
+OG_DEVN void silk_nlsf_stabilize(i16 *NLSF_Q15, const i32 *NDeltaMin_Q15, int Lo) { // silk.cpp:2676
+    int I = 0;
+    for (int loops = 0; loops < 20; loops++) {
+        i32 min_diff = NLSF_Q15[0] - NDeltaMin_Q15[0], diff;
+        I = 0;
+        for (int i = 1; i <= Lo - 1; i++) {
+            diff = NLSF_Q15[i] - (NLSF_Q15[i - 1] + NDeltaMin_Q15[i]);
+            if (diff < min_diff) {
+                min_diff = diff;
+                I = i;
+            }
+        }
+        diff = (1 << 15) - (NLSF_Q15[Lo - 1] + NDeltaMin_Q15[Lo]);
+        if (diff < min_diff) {
+            min_diff = diff;
+            I = Lo;
+        }
+        if (min_diff >= 0) return;
+        if (I == 0)
+            NLSF_Q15[0] = NDeltaMin_Q15[0];
+        else if (I == Lo)
+            NLSF_Q15[Lo - 1] = (i16)((1 << 15) - NDeltaMin_Q15[Lo]);
+        else {
+            i32 min_center = 0, max_center = 1 << 15;
+            for (int k = 0; k < I; k++) min_center += NDeltaMin_Q15[k];
+            min_center += NDeltaMin_Q15[I] >> 1;
+            for (int k = Lo; k > I; k--) max_center -= NDeltaMin_Q15[k];
+            max_center -= NDeltaMin_Q15[I] >> 1;
+            i32 center = tr16(limit32(rshift_round((i32)NLSF_Q15[I - 1] + (i32)NLSF_Q15[I], 1), min_center, max_center));
+            NLSF_Q15[I - 1] = (i16)(center - (NDeltaMin_Q15[I] >> 1));
+            NLSF_Q15[I] = (i16)(NLSF_Q15[I - 1] + NDeltaMin_Q15[I]);
+        }
+    }
+    for (int i = 1; i < Lo; i++) { // fall-back: insertion sort, then spacing from both ends
+        i32 value = NLSF_Q15[i];
+        int j;
+        for (j = i - 1; j >= 0 && value < NLSF_Q15[j]; j--) NLSF_Q15[j + 1] = NLSF_Q15[j];
+        NLSF_Q15[j + 1] = (i16)value;
+    }
+    NLSF_Q15[0] = (i16)OG_MAX((i32)NLSF_Q15[0], (i32)NDeltaMin_Q15[0]);
+    for (int i = 1; i < Lo; i++)
+        NLSF_Q15[i] = (i16)OG_MAX((i32)NLSF_Q15[i], sat16((i32)NLSF_Q15[i - 1] + NDeltaMin_Q15[i]));
+    NLSF_Q15[Lo - 1] = (i16)OG_MIN((i32)NLSF_Q15[Lo - 1], (1 << 15) - NDeltaMin_Q15[Lo]);
+    for (int i = Lo - 2; i >= 0; i--) NLSF_Q15[i] = (i16)OG_MIN((i32)NLSF_Q15[i], NLSF_Q15[i + 1] - NDeltaMin_Q15[i + 1]);
+}
+
+OG_DEVN void silk_nlsf_decode(i16 *pNLSF_Q15, const i32 *NLSFIndices, const NlsfCb &cb) { // silk.cpp:2466, :2445
+    SilkLds &L = SL();
+    nlsf_unpack(cb, NLSFIndices[0]);
+    i32 out_Q10 = 0;
+    for (int i = cb.order - 1; i >= 0; i--) {
+        i32 pred_Q10 = smulbb(out_Q10, L.pred_Q8[i]) >> 8;
+        out_Q10 = shl32(NLSFIndices[1 + i], 10);
+        if (out_Q10 > 0)
+            out_Q10 -= 102;
+        else if (out_Q10 < 0)
+            out_Q10 += 102;
+        out_Q10 = smlawb(pred_Q10, out_Q10, cb.quantStepSize_Q16);
+        L.res_Q10[i] = (i16)out_Q10;
+    }
+    const u8 *pCB = &cb.CB1_NLSF_Q8[NLSFIndices[0] * cb.order];
+    const i32 *pW = &cb.CB1_Wght_Q9[NLSFIndices[0] * cb.order];
+    for (int i = 0; i < cb.order; i++) {
+        i32 t = shl32((i32)L.res_Q10[i], 14) / (i32)pW[i] + shl32((i32)pCB[i], 7);
+        pNLSF_Q15[i] = (i16)limit32(t, 0, 32767);
+    }
+    silk_nlsf_stabilize(pNLSF_Q15, cb.deltaMin_Q15, cb.order);
+}
+
+OG_DEV void silk_bwexpander_32(i32 *ar, int d, i32 chirp_Q16) { // silk.cpp:561
+    const i32 chirp_minus_one_Q16 = chirp_Q16 - 65536;
+    for (int i = 0; i < d - 1; i++) {
+        ar[i] = smulww(chirp_Q16, ar[i]);
+        chirp_Q16 += rshift_round(chirp_Q16 * chirp_minus_one_Q16, 16);
+    }
+    ar[d - 1] = smulww(chirp_Q16, ar[d - 1]);
+}
+
+OG_DEVN i32 silk_inverse_pred_gain(const i16 *A_Q12, int order) { // silk.cpp:2425 + :2359
+    i32 *A = SL().Atmp;
+    const i32 A_LIMIT = 16773022, MIN_INVGAIN = 107374;
+    i32 DC_resp = 0;
+    for (int k = 0; k < order; k++) {
+        DC_resp += (i32)A_Q12[k];
+        A[k] = shl32((i32)A_Q12[k], 12);
+    }
+    if (DC_resp >= 4096) return 0;
+    i32 invGain_Q30 = 1 << 30, rc_Q31, rc_mult1_Q30;
+    int k;
+    for (k = order - 1; k > 0; k--) {
+        if (A[k] > A_LIMIT || A[k] < -A_LIMIT) return 0;
+        rc_Q31 = -shl32(A[k], 7);
+        rc_mult1_Q30 = (1 << 30) - smmul(rc_Q31, rc_Q31);
+        invGain_Q30 = shl32(smmul(invGain_Q30, rc_mult1_Q30), 2);
+        if (invGain_Q30 < MIN_INVGAIN) return 0;
+        const int mult2Q = 32 - clz32(iabs(rc_mult1_Q30));
+        const i32 rc_mult2 = silk_inverse32_varQ(rc_mult1_Q30, mult2Q + 30);
+        for (int n = 0; n < (k + 1) >> 1; n++) {
+            const i32 tmp1 = A[n], tmp2 = A[k - n - 1];
+            i64 t64 = rshift_round64((i64)sub_sat32(tmp1, (i32)rshift_round64((i64)tmp2 * rc_Q31, 31)) * rc_mult2, mult2Q);
+            if (t64 > 2147483647LL || t64 < -2147483648LL) return 0;
+            A[n] = (i32)t64;
+            t64 = rshift_round64((i64)sub_sat32(tmp2, (i32)rshift_round64((i64)tmp1 * rc_Q31, 31)) * rc_mult2, mult2Q);
+            if (t64 > 2147483647LL || t64 < -2147483648LL) return 0;
+            A[k - n - 1] = (i32)t64;
+        }
+    }
+    if (A[k] > A_LIMIT || A[k] < -A_LIMIT) return 0;
+    rc_Q31 = -shl32(A[0], 7);
+    rc_mult1_Q30 = (1 << 30) - smmul(rc_Q31, rc_Q31);
+    invGain_Q30 = shl32(smmul(invGain_Q30, rc_mult1_Q30), 2);
+    if (invGain_Q30 < MIN_INVGAIN) return 0;
+    return invGain_Q30;
+}
+
+OG_DEV void silk_find_poly(i32 *out, const i32 *cLSF, int dd) { // silk.cpp:626
+    out[0] = 1 << 16;
+    out[1] = -cLSF[0];
+    for (int k = 1; k < dd; k++) {
+        const i32 ftmp = cLSF[2 * k];
+        out[k + 1] = shl32(out[k - 1], 1) - (i32)rshift_round64((i64)ftmp * out[k], 16);
+        for (int n = k; n > 1; n--) out[n] += out[n - 2] - (i32)rshift_round64((i64)ftmp * out[n - 1], 16);
+        out[1] -= ftmp;
+    }
+}
+
+OG_DEVN void silk_nlsf2a(i16 *a_Q12, const i16 *NLSF, int d) { // silk.cpp:642
+    SilkLds &L = SL();
+    // ordering16 = {0,15,8,7,4,11,12,3,2,13,10,5,6,9,14,1}; ordering10 = {0,9,6,3,4,5,8,1,2,7}: one nibble each
+    const u64 ord16 = 0x1E965AD23CB478F0ULL; // nibbles (k=0..15): 0,15,8,7,4,11,12,3,2,13,10,5,6,9,14,1
+    const u64 o10 = 0x0000007218543690ULL;   // nibbles (k=0..9): 0,9,6,3,4,5,8,1,2,7
+    for (int k = 0; k < d; k++) {
+        const i32 f_int = NLSF[k] >> 8, f_frac = NLSF[k] - shl32(f_int, 8);
+        const i32 cos_val = rom_silk_cos_q12[f_int], delta = rom_silk_cos_q12[f_int + 1] - cos_val;
+        const int o = (int)(((d == 16 ? ord16 : o10) >> (4 * k)) & 15);
+        L.cosLSF[o] = rshift_round(shl32(cos_val, 8) + delta * f_frac, 4);
+    }
+    const int dd = d >> 1;
+    silk_find_poly(L.P, &L.cosLSF[0], dd);
+    silk_find_poly(L.Q, &L.cosLSF[1], dd);
+    for (int k = 0; k < dd; k++) {
+        const i32 Ptmp = L.P[k + 1] + L.P[k], Qtmp = L.Q[k + 1] - L.Q[k];
+        L.a32[k] = -Qtmp - Ptmp;
+        L.a32[d - k - 1] = Qtmp - Ptmp;
+    }
+    { // silk_LPC_fit(a_Q12, a32, 12, 17, d) silk.cpp:2314
+        int i, idx = 0;
+        for (i = 0; i < 10; i++) {
+            i32 maxabs = 0;
+            for (int k = 0; k < d; k++) {
+                const i32 absval = iabs(L.a32[k]);
+                if (absval > maxabs) {
+                    maxabs = absval;
+                    idx = k;
+                }
+            }
+            maxabs = rshift_round(maxabs, 5);
+            if (maxabs > 32767) {
+                maxabs = OG_MIN(maxabs, 163838);
+                const i32 chirp_Q16 = 65470 - shl32(maxabs - 32767, 14) / ((maxabs * (idx + 1)) >> 2);
+                silk_bwexpander_32(L.a32, d, chirp_Q16);
+            } else
+                break;
+        }
+        if (i == 10) {
+            for (int k = 0; k < d; k++) {
+                a_Q12[k] = (i16)sat16(rshift_round(L.a32[k], 5));
+                L.a32[k] = shl32((i32)a_Q12[k], 5);
+            }
+        } else {
+            for (int k = 0; k < d; k++) a_Q12[k] = (i16)rshift_round(L.a32[k], 5);
+        }
+    }
+    for (int i = 0; silk_inverse_pred_gain(a_Q12, d) == 0 && i < 16; i++) {
+        silk_bwexpander_32(L.a32, d, 65536 - shl32(2, i));
+        for (int k = 0; k < d; k++) a_Q12[k] = (i16)rshift_round(L.a32[k], 5);
+    }
+}
+
+// silk_decode_parameters silk.cpp:827 (+ silk_gains_dequant :2148, silk_decode_pitch :2055)
+OG_DEVN void silk_decode_parameters(SilkChannel *c, SilkCtrl &k, int fs_kHz, int condCoding, i32 &LastGainIndex,
+                                    int first_frame_after_reset) {
+    SilkLds &L = SL();
+    const int order = fs_kHz == 16 ? 16 : 10;
+    const NlsfCb cb = nlsf_cb(fs_kHz == 16);
+    for (int j = 0; j < 4; j++) {
+        const int ind = k.GainsIndices[j];
+        i32 prev = LastGainIndex;
+        if (j == 0 && condCoding != 2)
+            prev = OG_MAX(ind, prev - 16);
+        else {
+            const int ind_tmp = ind - 4, thr = 2 * 36 - 64 + prev;
+            prev += ind_tmp > thr ? shl32(ind_tmp, 1) - thr : ind_tmp;
+        }
+        prev = (i32)(i8)prev;
+        prev = limit32(prev, 0, 63);
+        LastGainIndex = prev;
+        k.Gains_Q16[j] = silk_log2lin(OG_MIN(smulwb(1907825, prev) + 2090, 3967));
+    }
+    silk_nlsf_decode(L.nlsf, k.NLSFIndices, cb);
+    silk_nlsf2a(k.PredCoef_Q12[1], L.nlsf, order);
+    if (first_frame_after_reset == 1) k.NLSFInterpCoef_Q2 = 4;
+    if (k.NLSFInterpCoef_Q2 < 4) {
+        for (int i = 0; i < order; i++) {
+            const i32 pv = c->prevNLSF_Q15[i];
+            L.nlsf0[i] = (i16)(pv + ((k.NLSFInterpCoef_Q2 * ((i32)L.nlsf[i] - pv)) >> 2));
+        }
+        silk_nlsf2a(k.PredCoef_Q12[0], L.nlsf0, order);
+    } else {
+        for (int i = 0; i < order; i++) k.PredCoef_Q12[0][i] = k.PredCoef_Q12[1][i];
+    }
+    OG_SYNC();
+    OG_FOR_LANES(i, order) c->prevNLSF_Q15[i] = L.nlsf[i];
+    OG_SYNC();
+    if (k.signalType == 2) {
+        const i8 *cbk = k.PERIndex == 0 ? rom_silk_ltp_vq0 : (k.PERIndex == 1 ? rom_silk_ltp_vq1 : rom_silk_ltp_vq2);
+        const i8 *lagcb = fs_kHz == 8 ? rom_silk_lags_stage2 : rom_silk_lags_stage3;
+        const int cbk_size = fs_kHz == 8 ? 11 : 34;
+        const int min_lag = 2 * fs_kHz, max_lag = 18 * fs_kHz, lag = min_lag + k.lagIndex;
+        for (int j = 0; j < 4; j++) {
+            k.pitchL[j] = limit32(lag + lagcb[j * cbk_size + k.contourIndex], min_lag, max_lag);
+            for (int i = 0; i < 5; i++) k.LTPCoef_Q14[j * 5 + i] = (i16)shl32((i32)cbk[k.LTPIndex[j] * 5 + i], 7);
+        }
+        k.LTP_scale_Q14 = rom_silk_ltp_scales_q14[k.LTP_scaleIndex];
+    } else {
+        for (int j = 0; j < 4; j++) k.pitchL[j] = 0;
+        for (int j = 0; j < 20; j++) k.LTPCoef_Q14[j] = 0;
+        k.PERIndex = 0;
+        k.LTP_scale_Q14 = 0;
+    }
+}
+
+// ---- synthesis: one lane per channel (silk_decode_core silk.cpp:1806, LPC analysis filter :2268) --------------
+OG_DEVN void silk_decode_core_lane(SilkChannel *c, int ch, int fs_kHz) {
+    SilkLds &L = SL();
+    const SilkCtrl &k = L.ctrl[ch];
+    const int order = fs_kHz == 16 ? 16 : 10, subfr = 5 * fs_kHz, frame_length = 4 * subfr, ltp_mem = 20 * fs_kHz;
+    const i16 *pulses = L.pulses[ch];
+    i16 *xq = &L.xq[ch][2];
+    i32 *sLTP_Q15 = L.sLTP_Q15[ch];
+    i16 *sLTP = L.sLTP[ch];
+    const i32 offset_Q10 = rom_silk_quant_offsets_q10[(k.signalType >> 1) * 2 + k.quantOffsetType];
+    const int interp_flag = k.NLSFInterpCoef_Q2 < 4;
+    i32 sLPC[SILK_MAX_LPC]; // sLPC[j] = state sample (i-1-j): most recent first
+    for (int j = 0; j < SILK_MAX_LPC; j++) sLPC[j] = c->sLPC_Q14_buf[SILK_MAX_LPC - 1 - j];
+    i32 rand_seed = k.Seed;
+    i32 prev_gain_Q16 = c->prev_gain_Q16;
+    int sLTP_buf_idx = ltp_mem, lag = 0, pos = 0;
+    for (int sf = 0; sf < 4; sf++) {
+        const i16 *A_Q12 = k.PredCoef_Q12[sf >> 1];
+        const i16 *B_Q14 = &k.LTPCoef_Q14[sf * 5];
+        const i32 Gain_Q16 = k.Gains_Q16[sf], Gain_Q10 = Gain_Q16 >> 6;
+        i32 inv_gain_Q31 = silk_inverse32_varQ(Gain_Q16, 47), gain_adj_Q16;
+        if (Gain_Q16 != prev_gain_Q16) {
+            gain_adj_Q16 = silk_div32_varQ(prev_gain_Q16, Gain_Q16, 16);
+            for (int j = 0; j < SILK_MAX_LPC; j++) sLPC[j] = smulww(gain_adj_Q16, sLPC[j]);
+        } else
+            gain_adj_Q16 = 1 << 16;
+        prev_gain_Q16 = Gain_Q16;
+        const int voiced = k.signalType == 2;
+        if (voiced) {
+            lag = k.pitchL[sf];
+            if (sf == 0 || (sf == 2 && interp_flag)) { // re-whitening
+                const int start_idx = ltp_mem - lag - order - 2;
+                // input = outBuf history (staged in LDS) followed, for sf == 2, by the two subframes decoded so far
+                i16 *hist = L.hist[ch];
+                if (sf == 2)
+                    for (int i = 0; i < 2 * subfr; i++) hist[ltp_mem + i] = xq[i];
+                const i16 *in = &hist[start_idx + sf * subfr];
+                for (int ix = order; ix < ltp_mem - start_idx; ix++) {
+                    i32 acc = 0;
+                    for (int j = 0; j < order; j++) acc = smlabb(acc, in[ix - 1 - j], A_Q12[j]);
+                    sLTP[start_idx + ix] = (i16)sat16(rshift_round(subw(shl32((i32)in[ix], 12), acc), 12));
+                }
+                for (int j = 0; j < order; j++) sLTP[start_idx + j] = 0;
+                if (sf == 0) inv_gain_Q31 = shl32(smulwb(inv_gain_Q31, k.LTP_scale_Q14), 2);
+                for (int i = 0; i < lag + 2; i++) sLTP_Q15[sLTP_buf_idx - i - 1] = smulwb(inv_gain_Q31, sLTP[ltp_mem - i - 1]);
+            } else if (gain_adj_Q16 != 1 << 16) {
+                for (int i = 0; i < lag + 2; i++) sLTP_Q15[sLTP_buf_idx - i - 1] = smulww(gain_adj_Q16, sLTP_Q15[sLTP_buf_idx - i - 1]);
+            }
+        }
+        for (int i = 0; i < subfr; i++) {
+            // excitation (silk.cpp:1826-1835)
+            rand_seed = (i32)(907633515u + (u32)rand_seed * 196314165u);
+            const i32 pl = pulses[pos + i];
+            i32 exc = shl32(pl, 14);
+            if (exc > 0)
+                exc -= 80 << 4;
+            else if (exc < 0)
+                exc += 80 << 4;
+            exc += offset_Q10 << 4;
+            if (rand_seed < 0) exc = -exc;
+            rand_seed = addw(rand_seed, pl);
+            i32 res = exc;
+            if (voiced) {
+                const i32 *p = &sLTP_Q15[sLTP_buf_idx - lag + 2];
+                i32 LTP_pred_Q13 = 2;
+                LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[0], B_Q14[0]);
+                LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[-1], B_Q14[1]);
+                LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[-2], B_Q14[2]);
+                LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[-3], B_Q14[3]);
+                LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[-4], B_Q14[4]);
+                res = addw(exc, shl32(LTP_pred_Q13, 1));
+                sLTP_Q15[sLTP_buf_idx] = shl32(res, 1);
+                sLTP_buf_idx++;
+            }
+            i32 LPC_pred_Q10 = order >> 1;
+#pragma unroll
+            for (int j = 0; j < 10; j++) LPC_pred_Q10 = smlawb(LPC_pred_Q10, sLPC[j], A_Q12[j]);
+            if (order == 16) {
+#pragma unroll
+                for (int j = 10; j < 16; j++) LPC_pred_Q10 = smlawb(LPC_pred_Q10, sLPC[j], A_Q12[j]);
+            }
+            const i32 s = add_sat32(res, lshift_sat32(LPC_pred_Q10, 4));
+#pragma unroll
+            for (int j = SILK_MAX_LPC - 1; j > 0; j--) sLPC[j] = sLPC[j - 1];
+            sLPC[0] = s;
+            xq[pos + i] = (i16)sat16(rshift_round(smulww(s, Gain_Q10), 8));
+        }
+        pos += subfr;
+    }
+    for (int j = 0; j < SILK_MAX_LPC; j++) c->sLPC_Q14_buf[SILK_MAX_LPC - 1 - j] = sLPC[j];
+    c->prev_gain_Q16 = prev_gain_Q16;
+    (void)frame_length; // outBuf update happens lane-parallel in the caller
+    c->lagPrev = k.pitchL[3];
+    c->prevSignalType = k.signalType;
+    c->first_frame_after_reset = 0;
+}
+
+// 2x all-pass up-sampler for one channel, one lane (silk_resampler_private_up2_HQ silk.cpp:3515); the input
+// stream is [delayBuf (inputDelay old samples) | in[0 .. inLen - inputDelay)] (silk_resampler silk.cpp:3676)
+OG_DEVN void silk_up2_lane(SilkChannel *c, int ch, int inLen) {
+    SilkLds &L = SL();
+    const i16 *in = &L.xq[ch][1];
+    i16 *up = L.up[ch];
+    const int delay = c->rs_inputDelay;
+    i32 S0 = c->rs_sIIR[0], S1 = c->rs_sIIR[1], S2 = c->rs_sIIR[2], S3 = c->rs_sIIR[3], S4 = c->rs_sIIR[4], S5 = c->rs_sIIR[5];
+    const i32 a0 = rom_silk_up2_hq0[0], a1 = rom_silk_up2_hq0[1], a2 = rom_silk_up2_hq0[2];
+    const i32 b0 = rom_silk_up2_hq1[0], b1 = rom_silk_up2_hq1[1], b2 = rom_silk_up2_hq1[2];
+    for (int j = 0; j < 8; j++) up[j] = c->rs_sFIR[j];
+    for (int t = 0; t < inLen; t++) {
+        const i32 x = t < delay ? (i32)c->rs_delayBuf[t] : (i32)in[t - delay];
+        const i32 in32 = shl32(x, 10);
+        i32 Y, X, o1, o2;
+        Y = in32 - S0; X = smulwb(Y, a0); o1 = S0 + X; S0 = in32 + X;
+        Y = o1 - S1; X = smulwb(Y, a1); o2 = S1 + X; S1 = o1 + X;
+        Y = o2 - S2; X = smlawb(Y, Y, a2); o1 = S2 + X; S2 = o2 + X;
+        up[8 + 2 * t] = (i16)sat16(rshift_round(o1, 10));
+        Y = in32 - S3; X = smulwb(Y, b0); o1 = S3 + X; S3 = in32 + X;
+        Y = o1 - S4; X = smulwb(Y, b1); o2 = S4 + X; S4 = o1 + X;
+        Y = o2 - S5; X = smlawb(Y, Y, b2); o1 = S5 + X; S5 = o2 + X;
+        up[8 + 2 * t + 1] = (i16)sat16(rshift_round(o1, 10));
+    }
+    c->rs_sIIR[0] = S0; c->rs_sIIR[1] = S1; c->rs_sIIR[2] = S2; c->rs_sIIR[3] = S3; c->rs_sIIR[4] = S4; c->rs_sIIR[5] = S5;
+    for (int j = 0; j < 8; j++) c->rs_sFIR[j] = up[2 * inLen + j];
+    for (int j = 0; j < delay; j++) c->rs_delayBuf[j] = in[inLen - delay + j];
+}
+
+// silk_decoder_set_fs + silk_resampler_init for the 20 ms / 48 kHz case (silk.cpp:978, :3590)
+OG_DEV void silk_set_fs(SilkChannel *c, int fs_kHz) {
+    if (c->fs_kHz == fs_kHz) return; // fs_API_hz is constant, frame length follows fs_kHz
+    OG_SYNC();
+    OG_FOR_LANES(i, 320) c->outBuf[i] = 0;
+    OG_FOR_LANES(i, 16) {
+        c->sLPC_Q14_buf[i] = 0;
+        c->rs_delayBuf[i] = 0;
+    }
+    OG_FOR_LANES(i, 8) c->rs_sFIR[i] = 0;
+    OG_FOR_LANES(i, 6) c->rs_sIIR[i] = 0;
+    OG_SYNC();
+    if (OG_LANE == 0) {
+        c->first_frame_after_reset = 1;
+        c->lagPrev = 100;
+        c->LastGainIndex = 10;
+        c->prevSignalType = 0;
+        const i32 Fs_in = fs_kHz * 1000, Fs_out = 48000;
+        const int in_id = ((Fs_in >> 12) - (Fs_in > 16000)) - 1; // rateID silk.h:397
+        c->rs_inputDelay = rom_silk_delay_dec[in_id * 5 + 4];
+        c->rs_fs_in_kHz = fs_kHz;
+        i32 inv = shl32(shl32(Fs_in, 15) / Fs_out, 2);
+        while (smulww(inv, Fs_out) < shl32(Fs_in, 1)) inv++;
+        c->rs_invRatio_Q16 = inv;
+        c->fs_kHz = fs_kHz;
+    }
+    OG_SYNC();
+}
+
+OG_DEVN void silk_stereo_decode_pred(Rc &rc, i32 pred_Q13[2]) { // silk.cpp:592
+    int ix[2][3];
+    int n = rc_icdf(rc, rom_silk_stereo_joint_icdf, 8);
+    ix[0][2] = n / 5;
+    ix[1][2] = n - 5 * ix[0][2];
+    for (n = 0; n < 2; n++) {
+        ix[n][0] = rc_icdf(rc, rom_silk_uniform3_icdf, 8);
+        ix[n][1] = rc_icdf(rc, rom_silk_uniform5_icdf, 8);
+    }
+    for (n = 0; n < 2; n++) {
+        ix[n][0] += 3 * ix[n][2];
+        const i32 low_Q13 = rom_silk_stereo_pred_q13[ix[n][0]];
+        const i32 step_Q13 = smulwb(rom_silk_stereo_pred_q13[ix[n][0] + 1] - low_Q13, 6554);
+        pred_Q13[n] = smlabb(low_Q13, step_Q13, 2 * ix[n][1] + 1);
+    }
+    pred_Q13[0] -= pred_Q13[1];
+}
+
+// Decode one 20 ms SILK frame (mid + side / mono) into S.pcm_silk (48 kHz, interleaved when stereo).
+// Returns 0 or a non-zero error (wave-uniform).
+OG_DEVN int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz) {
+    SilkLds &L = SL();
+    const int fs_kHz = (internal_hz >> 10) + 1;
+    if (fs_kHz != 8 && fs_kHz != 12 && fs_kHz != 16) return -200;
+    const int frame_length = 20 * fs_kHz;
+    OG_SYNC();
+    // first (and only) frame of the packet: nFramesDecoded = 0 for the coded channels
+    if (channels > s->nChannelsInternal) silk_chan_init(&s->ch[1]);
+    for (int n = 0; n < channels; n++) silk_set_fs(&s->ch[n], fs_kHz);
+    if (channels == 2 && (s->nChannelsAPI == 1 || s->nChannelsInternal == 1)) {
+        OG_SYNC();
+        if (OG_LANE == 0) {
+            s->pred_prev_Q13[0] = s->pred_prev_Q13[1] = 0;
+            s->sSide[0] = s->sSide[1] = 0;
+        }
+        OG_SYNC();
+    }
+    // persistent scalars of both channels into registers (uniform)
+    i32 ecType[2], ecLag[2], lastGain[2], ffar[2];
+    for (int n = 0; n < 2; n++) {
+        ecType[n] = s->ch[n].ec_prevSignalType;
+        ecLag[n] = s->ch[n].ec_prevLagIndex;
+        lastGain[n] = s->ch[n].LastGainIndex;
+        ffar[n] = s->ch[n].first_frame_after_reset;
+    }
+    int vad[2] = {0, 0}, lbrr[2] = {0, 0};
+    for (int n = 0; n < channels; n++) {
+        vad[n] = rc_bit_logp(rc, 1);
+        lbrr[n] = rc_bit_logp(rc, 1);
+    }
+    i32 MS_pred_Q13[2] = {0, 0};
+    int decode_only_middle = 0;
+    for (int n = 0; n < channels; n++) { // regular decoding reads past the LBRR frame (silk.cpp:1590-1616)
+        if (lbrr[n]) {
+            if (channels == 2 && n == 0) {
+                silk_stereo_decode_pred(rc, MS_pred_Q13);
+                if (lbrr[1] == 0) decode_only_middle = rc_icdf(rc, rom_silk_mid_only_icdf, 8);
+            }
+            silk_decode_indices(&s->ch[n], L.ctrl[n], rc, fs_kHz, vad[n], 1, 0, ecType[n], ecLag[n]);
+            silk_decode_pulses(rc, n, L.ctrl[n].signalType, L.ctrl[n].quantOffsetType, frame_length);
+        }
+    }
+    if (channels == 2) {
+        silk_stereo_decode_pred(rc, MS_pred_Q13);
+        decode_only_middle = vad[1] == 0 ? rc_icdf(rc, rom_silk_mid_only_icdf, 8) : 0;
+    }
+    const int prev_dom = s->prev_decode_only_middle;
+    if (channels == 2 && decode_only_middle == 0 && prev_dom == 1) { // side channel restarts (silk.cpp:1639)
+        SilkChannel *c1 = &s->ch[1];
+        OG_SYNC();
+        OG_FOR_LANES(i, 320) c1->outBuf[i] = 0;
+        OG_FOR_LANES(i, 16) c1->sLPC_Q14_buf[i] = 0;
+        if (OG_LANE == 0) {
+            c1->lagPrev = 100;
+            c1->prevSignalType = 0;
+        }
+        OG_SYNC();
+        lastGain[1] = 10;
+        ffar[1] = 1;
+    }
+    const int has_side = !decode_only_middle;
+    for (int n = 0; n < channels; n++) {
+        L.ctrl[n].coded = (n == 0 || has_side);
+        if (L.ctrl[n].coded) {
+            // FrameIndex = nFramesDecoded - n = -n <= 0 -> independent coding (silk.cpp:1678-1681)
+            const int condCoding = 0;
+            silk_decode_indices(&s->ch[n], L.ctrl[n], rc, fs_kHz, vad[n], 0, condCoding, ecType[n], ecLag[n]);
+            silk_decode_pulses(rc, n, L.ctrl[n].signalType, L.ctrl[n].quantOffsetType, frame_length);
+            silk_decode_parameters(&s->ch[n], L.ctrl[n], fs_kHz, condCoding, lastGain[n], ffar[n]);
+        }
+    }
+    OG_SYNC();
+    if (OG_LANE == 0) {
+        for (int n = 0; n < 2; n++) {
+            s->ch[n].ec_prevSignalType = ecType[n];
+            s->ch[n].ec_prevLagIndex = ecLag[n];
+            s->ch[n].LastGainIndex = lastGain[n];
+        }
+        if (channels == 2 && decode_only_middle == 0 && prev_dom == 1) s->ch[1].first_frame_after_reset = 1;
+    }
+    OG_SYNC();
+    // ---- synthesis: stage the output history, then lane n = channel n
+    for (int n = 0; n < channels; n++)
+        if (L.ctrl[n].coded) OG_FOR_LANES(i, frame_length) L.hist[n][i] = s->ch[n].outBuf[i];
+    OG_SYNC();
+    OG_FOR_LANES(n, channels) {
+        if (L.ctrl[n].coded)
+            silk_decode_core_lane(&s->ch[n], n, fs_kHz);
+        else
+            for (int i = 0; i < frame_length; i++) L.xq[n][2 + i] = 0;
+    }
+    OG_SYNC();
+    // outBuf update (silk.cpp:2031-2034): ltp_mem_length == frame_length, so the history is exactly this frame
+    for (int n = 0; n < channels; n++)
+        if (L.ctrl[n].coded) OG_FOR_LANES(i, frame_length) s->ch[n].outBuf[i] = L.xq[n][2 + i];
+    OG_SYNC();
+    // ---- stereo un-mixing (silk_stereo_MS_to_LR silk.cpp:4028) or mono look-back buffering (:1705)
+    if (channels == 2) {
+        i16 *x1 = L.xq[0], *x2 = L.xq[1];
+        if (OG_LANE == 0) {
+            x1[0] = s->sMid[0]; x1[1] = s->sMid[1];
+            x2[0] = s->sSide[0]; x2[1] = s->sSide[1];
+            s->sMid[0] = x1[frame_length]; s->sMid[1] = x1[frame_length + 1];
+            s->sSide[0] = x2[frame_length]; s->sSide[1] = x2[frame_length + 1];
+        }
+        const i32 pp0 = s->pred_prev_Q13[0], pp1 = s->pred_prev_Q13[1];
+        const i32 denom_Q16 = (1 << 16) / (8 * fs_kHz);
+        const i32 delta0 = rshift_round(smulbb(MS_pred_Q13[0] - pp0, denom_Q16), 16);
+        const i32 delta1 = rshift_round(smulbb(MS_pred_Q13[1] - pp1, denom_Q16), 16);
+        OG_SYNC();
+        i32 side_new[(SILK_MAX_FRAME + OG_NLANES - 1) / OG_NLANES]; // each lane holds its own results until every lane has read the old side signal
+        int cnt = 0;
+        OG_FOR_LANES(n, frame_length) {
+            const i32 p0 = n < 8 * fs_kHz ? pp0 + (n + 1) * delta0 : MS_pred_Q13[0];
+            const i32 p1 = n < 8 * fs_kHz ? pp1 + (n + 1) * delta1 : MS_pred_Q13[1];
+            i32 sum = shl32(((i32)x1[n] + (i32)x1[n + 2]) + shl32((i32)x1[n + 1], 1), 9);
+            sum = smlawb(shl32((i32)x2[n + 1], 8), sum, p0);
+            sum = smlawb(sum, shl32((i32)x1[n + 1], 11), p1);
+            side_new[cnt++] = sat16(rshift_round(sum, 8));
+        }
+        OG_SYNC();
+        cnt = 0;
+        OG_FOR_LANES(n, frame_length) {
+            const i32 m = x1[n + 1], sd = side_new[cnt++];
+            x1[n + 1] = (i16)sat16(m + sd);
+            x2[n + 1] = (i16)sat16(m - sd);
+        }
+        if (OG_LANE == 0) {
+            s->pred_prev_Q13[0] = tr16(MS_pred_Q13[0]);
+            s->pred_prev_Q13[1] = tr16(MS_pred_Q13[1]);
+        }
+        OG_SYNC();
+    } else {
+        if (OG_LANE == 0) {
+            i16 *x1 = L.xq[0];
+            x1[0] = s->sMid[0]; x1[1] = s->sMid[1];
+            s->sMid[0] = x1[frame_length]; s->sMid[1] = x1[frame_length + 1];
+        }
+        OG_SYNC();
+    }
+    // ---- resample to 48 kHz: serial 2x all-pass per channel, then lane-parallel FIR interpolation
+    OG_FOR_LANES(n, channels) silk_up2_lane(&s->ch[n], n, frame_length);
+    OG_SYNC();
+    {
+        const i32 inv = s->ch[0].rs_invRatio_Q16; // both channels run at the same rate
+        // batches of the reference: [0, fs_kHz), then chunks of 10*fs_kHz (silk.cpp:3676, :3475)
+        int t0 = 0, out0 = 0;
+        while (t0 < frame_length) {
+            const int nIn = t0 == 0 ? fs_kHz : OG_MIN(frame_length - t0, 10 * fs_kHz);
+            const i32 max_index_Q16 = shl32(nIn, 17);
+            const int count = (int)udiv((u32)max_index_Q16 + (u32)inv - 1u, (u32)inv);
+            OG_FOR_LANES(id, count * channels) {
+                const int n = id / count, m = id - n * count;
+                const i32 index_Q16 = m * inv;
+                const int t = smulwb(index_Q16 & 0xFFFF, 12);
+                const i16 *b = &L.up[n][2 * t0 + (index_Q16 >> 16)];
+                const i16 *f0 = &rom_silk_frac_fir12[4 * t], *f1 = &rom_silk_frac_fir12[4 * (11 - t)];
+                i32 res = smulbb(b[0], f0[0]);
+                res = smlabb(res, b[1], f0[1]);
+                res = smlabb(res, b[2], f0[2]);
+                res = smlabb(res, b[3], f0[3]);
+                res = smlabb(res, b[4], f1[3]);
+                res = smlabb(res, b[5], f1[2]);
+                res = smlabb(res, b[6], f1[1]);
+                res = smlabb(res, b[7], f1[0]);
+                S.pcm_silk[(out0 + m) * channels + n] = (i16)sat16(rshift_round(res, 15));
+            }
+            t0 += nIn;
+            out0 += count;
+        }
+    }
+    OG_SYNC();
+    if (OG_LANE == 0) {
+        s->nChannelsAPI = channels;
+        s->nChannelsInternal = channels;
+        s->prev_decode_only_middle = decode_only_middle;
+    }
+    OG_SYNC();
+    return 0;
+}
+
+} // namespace og

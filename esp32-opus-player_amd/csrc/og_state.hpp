@@ -30,36 +30,35 @@ struct CeltState {             // replaces CELTDecoder_t + trailing arrays (src/
     i16 pad[2];
 };
 
-// SILK per-channel state (src/silk.h:705-741 minus PLC/CNG, which never feed PCM: lostFlag == 0)
+// SILK per-channel state: the live subset of silk_decoder_state_t (src/silk.h:705-741) plus the
+// channel's resampler (src/silk.h:654-670).  PLC/CNG state and exc_Q14 are not kept: with
+// lostFlag == 0 they never reach the PCM; for 20 ms frames outBuf is just the last
+// frame's output (ltp_mem_length == frame_length).
 struct SilkChannel {
     i32 prev_gain_Q16;
     i32 sLPC_Q14_buf[16];
-    i16 outBuf[480];
     i32 lagPrev;
-    i32 LastGainIndex;         // int8 in the reference
-    i32 fs_kHz, nb_subfr, frame_length, subfr_length, ltp_mem_length, LPC_order;
-    i16 prevNLSF_Q15[16];
+    i32 LastGainIndex;          // int8 in the reference
+    i32 fs_kHz;                 // 0 after init -> next frame re-derives everything (silk_decoder_set_fs)
     i32 first_frame_after_reset;
-    i32 nFramesDecoded, nFramesPerPacket;
     i32 ec_prevSignalType, ec_prevLagIndex;
-    i32 VAD_flags[3], LBRR_flag, LBRR_flags[3];
-    i32 prevSignalType;        // from indices of the previous frame
-    i32 lossCnt;
-    // resampler (src/silk.h:654-670)
+    i32 prevSignalType;
+    i32 nFramesDecoded;
+    // resampler
     i32 rs_sIIR[6];
+    i32 rs_invRatio_Q16, rs_inputDelay, rs_fs_in_kHz;
     i16 rs_sFIR[8];
-    i16 rs_delayBuf[48];
-    i32 rs_function, rs_batchSize, rs_invRatio_Q16, rs_FIR_Order, rs_FIR_Fracs, rs_Fs_in_kHz, rs_Fs_out_kHz,
-        rs_inputDelay;
-    i32 rs_valid;
+    i16 rs_delayBuf[16];
+    i16 prevNLSF_Q15[16];
+    i16 outBuf[320];
 };
 
-struct SilkState {             // silk_decoder_t (src/silk.h:758-764) + stereo state (:672-676)
+struct SilkState {              // silk_decoder_t (src/silk.h:758-764) incl. stereo state (:672-676)
     SilkChannel ch[2];
-    i32 pred_prev_Q13[2];
+    i32 pred_prev_Q13[2];       // int16 in the reference
     i16 sMid[2], sSide[2];
     i32 nChannelsAPI, nChannelsInternal, prev_decode_only_middle;
-    i32 initialized;
+    i32 reserved;
 };
 
 struct StreamState {

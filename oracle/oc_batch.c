@@ -35,3 +35,21 @@ long oc_batch_decode(int channels, int toc, const u8 *payloads, int n_streams, i
     oc_decoder_destroy(d);
     return ok;
 }
+
+/* stage taps for parity tests of the HIP kernels: enable once, then copy after each oc_decode() call */
+int oc_taps_enable(oc_decoder *d) {
+    if (!d->taps) d->taps = (oc_celt_taps *)calloc(1, sizeof(oc_celt_taps));
+    return d->taps != NULL;
+}
+/* what: 0 = X (i16[1920]), 1 = bandE (i16[42]), 2 = syn_pre ch c (i32[1080]), 3 = syn_post ch c (i32[960]) */
+int oc_taps_copy(const oc_decoder *d, int what, int c, void *dst) {
+    const oc_celt_taps *t = d->taps;
+    if (!t || !t->valid) return -1;
+    switch (what) {
+        case 0: memcpy(dst, t->X, sizeof(t->X)); return (int)sizeof(t->X);
+        case 1: memcpy(dst, t->bandE, sizeof(t->bandE)); return (int)sizeof(t->bandE);
+        case 2: memcpy(dst, t->syn_pre[c], sizeof(t->syn_pre[c])); return (int)sizeof(t->syn_pre[c]);
+        case 3: memcpy(dst, t->syn_post[c], sizeof(t->syn_post[c])); return (int)sizeof(t->syn_post[c]);
+    }
+    return -1;
+}

@@ -144,7 +144,7 @@ static int interp_bits2pulses(oc_rc *rc, int start, int end, int skip_start, con
     i32 psum, left, percoeff, balance;
     int lo = 0, hi = 1 << 6, i, j, done, codedBands;
     int alloc_floor = C << BITRES, stereo = C > 1, logM = LM << BITRES;
-    const i16 *eb = rom_eband;
+    const i32 *eb = rom_eband;
     for (i = 0; i < 6; i++) {
         int mid = (lo + hi) >> 1;
         psum = 0;
@@ -272,7 +272,7 @@ static int compute_allocation(oc_rc *rc, int start, int end, const i32 *offsets,
                               i32 *fine_priority, int C, int LM) {
     i32 bits1[NB], bits2[NB], thresh[NB], trim_offset[NB];
     int lo, hi, j, skip_start = start, skip_rsv, intensity_rsv = 0, dual_stereo_rsv = 0;
-    const i16 *eb = rom_eband;
+    const i32 *eb = rom_eband;
     total = OC_MAX(total, 0);
     skip_rsv = total >= 1 << BITRES ? 1 << BITRES : 0;
     total -= skip_rsv;
@@ -805,7 +805,7 @@ static u32 quant_band_stereo(bandctx *cx, i16 *X, i16 *Y, int N, i32 b, int B, i
 static void quant_all_bands(oc_rc *rc, int start, int end, i16 *X_, i16 *Y_, u8 *collapse_masks, const i32 *pulses,
                             int shortBlocks, int spread, int dual_stereo, int intensity, const i32 *tf_res,
                             i32 total_bits, i32 balance, int LM, int codedBands, u32 *seed, int disable_inv) {
-    const i16 *eb = rom_eband;
+    const i32 *eb = rom_eband;
     i16 normbuf[2 * 8 * 100]; /* C * (M*eBands[nbEBands-1] - norm_offset) */
     i16 *norm, *norm2, *lowband_scratch;
     int i, M = 1 << LM, B = shortBlocks ? M : 1, C = Y_ != NULL ? 2 : 1;
@@ -900,7 +900,7 @@ static void quant_all_bands(oc_rc *rc, int start, int end, i16 *X_, i16 *Y_, u8 
 /* celt.cpp:1010 */
 static void anti_collapse(i16 *X_, const u8 *collapse_masks, int LM, int C, int size, int start, int end,
                           const i16 *logE, const i16 *prev1logE, const i16 *prev2logE, const i32 *pulses, u32 seed) {
-    const i16 *eb = rom_eband;
+    const i32 *eb = rom_eband;
     int c, i, j, k;
     for (i = start; i < end; i++) {
         int N0 = eb[i + 1] - eb[i], depth, shift;
@@ -950,7 +950,7 @@ static void anti_collapse(i16 *X_, const u8 *collapse_masks, int LM, int C, int 
 /* ---- synthesis ---------------------------------------------------------------------------- */
 /* celt.cpp:948 (downsample == 1) */
 static void denormalise(const i16 *X, i32 *freq, const i16 *bandLogE, int start, int end, int M, int silence) {
-    const i16 *eb = rom_eband;
+    const i32 *eb = rom_eband;
     int i, N = M * 120, bound = M * eb[end];
     i32 *f = freq;
     const i16 *x;
@@ -1049,7 +1049,7 @@ static void deemphasis(i32 *in[2], i16 *pcm, int N, int C, i32 *mem) {
 
 /* ---- frame driver (celt.cpp:2162) --------------------------------------------------------- */
 int oc_celt_decode(oc_celt *st, oc_rc *rc, i16 *pcm, int frame_size, oc_celt_taps *taps) {
-    const i16 *eb = rom_eband;
+    const i32 *eb = rom_eband;
     const int CC = st->channels, C = st->stream_channels;
     i32 *out_syn[2];
     i16 X[2 * 960];
@@ -1142,8 +1142,9 @@ int oc_celt_decode(oc_celt *st, oc_rc *rc, i16 *pcm, int frame_size, oc_celt_tap
                                     pulses, fine_quant, fine_priority, C, LM);
     fine_energy(rc, start, end, bandE, fine_quant, C);
 
-    for (c = 0; c < CC; c++) /* history shift: celt.cpp:2349 keeps DECODE_BUFFER_SIZE-N+overlap/2 samples */
-        memmove(st->syn[c], st->syn[c] + N, (OC_HIST + OC_OVERLAP / 2) * sizeof(i32));
+    /* The reference shifts its END-anchored history left by N here (celt.cpp:2349).  This buffer is
+       START-anchored (out_syn at OC_HIST), so the equivalent shift is done after the frame, by the
+       frame's own N (see the end of this function): frames of different sizes may follow each other (Q4). */
 
     memset(collapse_masks, 0, sizeof(collapse_masks));
     memset(X, 0, sizeof(X)); /* reference: malloc'd; bands below `start` are never read by denormalise */
@@ -1220,6 +1221,8 @@ int oc_celt_decode(oc_celt *st, oc_rc *rc, i16 *pcm, int frame_size, oc_celt_tap
     if (taps) taps->rc_rng_end = rc->rng;
 
     deemphasis(out_syn, pcm, N, CC, st->deemph_mem);
+    for (c = 0; c < CC; c++) /* keep OC_HIST samples of history + the 60-sample overlap tail at out_syn[0..60) */
+        memmove(st->syn[c], st->syn[c] + N, (OC_HIST + OC_OVERLAP / 2) * sizeof(i32));
     if (oc_rc_tell(rc) > 8 * (i32)rc->storage) return OC_INTERNAL_ERROR;
     if (rc->error) st->error = 1;
     return frame_size;

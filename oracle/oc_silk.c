@@ -123,7 +123,7 @@ typedef struct {
     int order;
     i32 quantStepSize_Q16;
     const u8 *CB1_NLSF_Q8, *CB1_iCDF, *pred_Q8, *ec_sel, *ec_iCDF;
-    const i16 *CB1_Wght_Q9, *deltaMin_Q15;
+    const i32 *CB1_Wght_Q9, *deltaMin_Q15;
 } nlsf_cb;
 
 static void get_cb(nlsf_cb *cb, int wb) {
@@ -321,7 +321,7 @@ static void decode_pulses(oc_rc *rc, i16 pulses[], int signalType, int quantOffs
 
 /* ---- NLSF -> LPC ------------------------------------------------------------------------------------------ */
 /* silk_NLSF_stabilize silk.cpp:2676 */
-static void nlsf_stabilize(i16 *NLSF_Q15, const i16 *NDeltaMin_Q15, int L) {
+static void nlsf_stabilize(i16 *NLSF_Q15, const i32 *NDeltaMin_Q15, int L) {
     int i, I = 0, k, loops;
     i32 diff_Q15, min_diff_Q15, min_center_Q15, max_center_Q15;
     i16 center_freq_Q15;
@@ -380,7 +380,7 @@ static void nlsf_decode(i16 *pNLSF_Q15, const signed char *NLSFIndices, const nl
     i16 ec_ix[MAX_LPC], res_Q10[MAX_LPC];
     i32 out_Q10 = 0, pred_Q10;
     const u8 *pCB = &cb->CB1_NLSF_Q8[NLSFIndices[0] * cb->order];
-    const i16 *pW = &cb->CB1_Wght_Q9[NLSFIndices[0] * cb->order];
+    const i32 *pW = &cb->CB1_Wght_Q9[NLSFIndices[0] * cb->order];
     int i;
     nlsf_unpack(ec_ix, pred_Q8, cb, NLSFIndices[0]);
     for (i = cb->order - 1; i >= 0; i--) {

@@ -1,0 +1,141 @@
+"""GPU parity for the SILK and hybrid paths and for mode / bandwidth / channel switching (C ABI vs oracle)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_run(pkg, ctx, toc, pay, channels=2):
+    """Decode pay[frames, streams, L] through the device-resident path; returns int16 [streams, frames, 960, ch]."""
+    frames, n, L = pay.shape
+    ctx.streams_alloc(n, channels)
+    d_desc, d_arena = ctx.dev_alloc(16 * n), ctx.dev_alloc(n * (L + 1) + 16)
+    d_pcm, d_res = ctx.dev_alloc(n * 960 * channels * 2), ctx.dev_alloc(4 * n)
+    out = np.zeros((n, frames, 960, channels), dtype=np.int16)
+    tmp = np.zeros((n, 960, channels), dtype=np.int16)
+    res = np.zeros(n, dtype=np.int32)
+    for f in range(frames):
+        arena, descs = pkg.build_step(toc, pay[f])
+        ctx.h2d(d_arena, arena)
+        ctx.h2d(d_desc, descs)
+        ctx.decode_step_device(n, d_desc, d_arena, d_pcm, d_res)
+        ctx.synchronize()
+        ctx.d2h(tmp, d_pcm)
+        ctx.d2h(res, d_res)
+        assert (res == 960).all()
+        out[:, f] = tmp
+    for p in (d_desc, d_arena, d_pcm, d_res):
+        ctx.dev_free(p)
+    return out
+
+
+def test_silk_nb_stereo_every_sample(pkg, oracle, gpu_ctx):
+    """BASELINE config 3 in miniature: SILK-only NB stereo, every PCM sample compared."""
+    pay = pkg.lcg_payloads(1024, 8, 40)
+    ref, ok = oracle.batch_decode(2, pkg.TOC_SILK_NB_STEREO, pay)
+    assert ok == 1024 * 8
+    got = _device_run(pkg, gpu_ctx, pkg.TOC_SILK_NB_STEREO, pay)
+    assert np.array_equal(got, ref)
+
+
+def test_hybrid_fb_stereo(pkg, oracle, gpu_ctx):
+    pay = pkg.lcg_payloads(768, 6, 120)
+    ref, ok = oracle.batch_decode(2, pkg.TOC_HYBRID_FB_STEREO, pay)
+    assert ok == 768 * 6
+    got = _device_run(pkg, gpu_ctx, pkg.TOC_HYBRID_FB_STEREO, pay)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("toc,L", [(0x2C, 60), (0x4C, 80), (0x48, 70), (0x6C, 100), (0x08, 30)])
+def test_other_silk_and_hybrid_configs(pkg, oracle, gpu_ctx, toc, L):
+    """SILK MB / WB (stereo, mono), hybrid SWB, SILK NB mono."""
+    ch = 2 if toc & 4 else 1
+    pay = pkg.lcg_payloads(128, 5, L, seed_base=0x1234 + toc)
+    ref, ok = oracle.batch_decode(ch, toc, pay)
+    assert ok == 128 * 5
+    got = _device_run(pkg, gpu_ctx, toc, pay, channels=ch)
+    assert np.array_equal(got, ref)
+
+
+def test_mode_bandwidth_and_channel_switching(pkg, oracle, gpu_ctx):
+    """Random per-frame mode switches (incl. the reference's hybrid->SILK quirk Q4) through the host-buffer path."""
+    rng = np.random.default_rng(11)
+    cfgs = {0: [1, 5, 9], 1: [13, 15], 2: [19, 23, 27, 31]}
+    for channels in (1, 2):
+        n, frames = 160, 12
+        pk = []
+        for s in range(n):
+            row, mode = [], int(rng.integers(3))
+            for f in range(frames):
+                if rng.random() < 0.3:
+                    mode = int(rng.integers(3))
+                stereo = (channels == 2) if rng.random() < 0.9 else bool(rng.integers(2))
+                toc = (int(rng.choice(cfgs[mode])) << 3) | (4 if stereo else 0)
+                L = int(rng.choice([40, 120, 160, 7, 300]))
+                row.append(bytes([toc]) + rng.integers(0, 256, L, dtype=np.uint8).tobytes())
+            pk.append(row)
+        ref, rets = oracle.decode_streams(channels, pk)
+        ctx = gpu_ctx
+        ctx.streams_alloc(n, channels)
+        for f in range(frames):
+            pkts = [pk[s][f] for s in range(n)]
+            pcm, res = ctx.decode_packets(np.arange(n), pkts)
+            assert (res == rets[:, f]).all()
+            for s in range(n):
+                if res[s] <= 0:
+                    continue
+                toc = pkts[s][0]
+                pch = 2 if toc & 4 else 1
+                silk_only = not (toc & 0x80) and (toc & 0x60) != 0x60
+                # a mono SILK-only packet in a stereo decoder: the reference writes 960 entries only (Q3)
+                ncmp = 960 * pch if (silk_only and pch < channels) else 960 * channels
+                assert np.array_equal(pcm[s].reshape(-1)[:ncmp], ref[s, f].reshape(-1)[:ncmp]), (s, f, hex(toc))
+
+
+def test_reset_state_semantics(pkg, oracle, gpu_ctx):
+    """OPUS_RESET_STATE keeps CELT history (Q5): same packets after reset differ from a fresh stream, and match the oracle."""
+    n, L = 32, 160
+    pay = pkg.lcg_payloads(n, 6, L, seed_base=77)
+    ctx = gpu_ctx
+    ctx.streams_alloc(n, 2)
+    decs = [oracle.decoder(2) for _ in range(n)]
+    for f in range(6):
+        if f == 3:
+            ctx.streams_reset(0, n, full=False)
+            for d in decs:
+                d.reset()
+        pkts = [bytes([pkg.TOC_CELT_FB_STEREO]) + pay[f, s].tobytes() for s in range(n)]
+        pcm, res = ctx.decode_packets(np.arange(n), pkts)
+        assert (res == 960).all()
+        for s in range(n):
+            out, r = decs[s].decode(pkts[s])
+            assert r == 960 and np.array_equal(pcm[s], out[:960])
+
+
+def test_multiframe_packets_and_errors(pkg, oracle, gpu_ctx):
+    """Code 1/2/3 packets are decoded frame after frame; malformed packets return the reference's error codes."""
+    rng = np.random.default_rng(5)
+    ctx = gpu_ctx
+    n = 24
+    ctx.streams_alloc(n, 2)
+    decs = [oracle.decoder(2) for _ in range(n)]
+    for d in decs:
+        d.init()
+    pkts = []
+    for s in range(n):
+        body = rng.integers(0, 256, 2 * 60, dtype=np.uint8).tobytes()
+        kind = s % 4
+        if kind == 0:
+            pkts.append(bytes([0xFC | 1]) + body)                       # code 1: two CBR frames
+        elif kind == 1:
+            pkts.append(bytes([0xFC | 2, 50]) + body[:110])             # code 2: two VBR frames (50 + 60)
+        elif kind == 2:
+            pkts.append(bytes([0xFC | 3, 0x02]) + body)                 # code 3, 2 CBR frames
+        else:
+            pkts.append(bytes([0xFC | 1]) + body[:119])                 # odd payload for code 1 -> invalid
+    pcm, res = ctx.decode_packets(np.arange(n), pkts, frame_capacity=2)
+    for s in range(n):
+        out, r = decs[s].decode(pkts[s])
+        assert res[s] == r, (s, res[s], r)
+        if r > 0:
+            assert np.array_equal(pcm[s, :r], out[:r])

@@ -206,7 +206,19 @@ try:
 except ImportError:
     pass
 
+# int16 tables that the kernels index with wave-uniform indices are stored as int32: on gfx950 the compiler
+# turns adjacent sub-dword scalar loads into one s_load_dword, and a pair that starts on an odd 16-bit index is
+# split into a misaligned base + immediate that the scalar memory path does not honour.  (Lane-indexed tables
+# such as twiddles and windows stay 16-bit: they are fetched with vector loads.)
+WIDEN = {"rom_eband", "rom_logn", "rom_pulse_idx", "rom_silk_cos_q12", "rom_silk_stereo_pred_q13",
+         "rom_silk_nb_cb1_wght_q9", "rom_silk_wb_cb1_wght_q9", "rom_silk_nb_delta_min_q15",
+         "rom_silk_wb_delta_min_q15", "rom_silk_ltp_scales_q14", "rom_silk_quant_offsets_q10",
+         "rom_silk_up2_hq0", "rom_silk_up2_hq1"}
+
+
 def emit(name, ctype, vals, per=16):
+    if name in WIDEN:
+        ctype = "int32_t"
     s = f"OPUS_ROM {ctype} {name}[{len(vals)}] = {{\n"
     for i in range(0, len(vals), per):
         s += "    " + ", ".join(str(v) for v in vals[i:i + per]) + ",\n"
