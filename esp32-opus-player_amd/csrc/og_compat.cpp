@@ -1,0 +1,294 @@
+// og_compat.cpp -- the reference's C++ call surface (include/opus_decoder.h, include/opusfile.h) implemented
+// over the C ABI (include/opusgpu.h).  Host logic only: framing, channel mapping, ctl bookkeeping, the Ogg
+// container reader.  All codec arithmetic happens in opusgpu_decode_packets(), i.e. on the GPU.
+#include <new>
+#include <stdlib.h>
+#include <string.h>
+#include "og_container.hpp" // before opusfile.h: its OP_* macros would otherwise rewrite the enum of the same names
+#include "og_packet.hpp"
+#include "../../include/opus_decoder.h"
+#include "../../include/opusfile.h"
+#include "../../include/opusgpu.h"
+
+// ---- packet helpers -------------------------------------------------------------------------------------
+int opus_packet_get_bandwidth(uint8_t *data) { return ogh::toc_bandwidth(data[0]); }
+int opus_packet_get_samples_per_frame(uint8_t *data, int32_t Fs) { return ogh::toc_samples_per_frame(data[0], Fs); }
+int opus_packet_get_nb_channels(uint8_t *data) { return ogh::toc_channels(data[0]); }
+int opus_packet_get_nb_frames(uint8_t packet[], int32_t len) {
+    if (len < 1) return OPUS_BAD_ARG;
+    int count = packet[0] & 3;
+    if (count == 0) return 1;
+    if (count != 3) return 2;
+    if (len < 2) return OPUS_INVALID_PACKET;
+    return packet[1] & 0x3F;
+}
+int opus_packet_get_nb_samples(uint8_t packet[], int32_t len, int32_t Fs) {
+    int count = opus_packet_get_nb_frames(packet, len);
+    if (count < 0) return count;
+    int samples = count * opus_packet_get_samples_per_frame(packet, Fs);
+    return samples * 25 > Fs * 3 ? OPUS_INVALID_PACKET : samples;
+}
+int opus_packet_parse(uint8_t *data, int32_t len, unsigned char *out_toc, uint8_t *frames[48], int16_t size[48],
+                      int *payload_offset) {
+    int off = 0;
+    int n = ogh::parse_packet(data, len, 0, out_toc, size, &off, nullptr);
+    if (n < 0) return n;
+    if (payload_offset) *payload_offset = off;
+    if (frames) {
+        uint8_t *p = data + off;
+        for (int i = 0; i < n; i++) {
+            frames[i] = p;
+            p += size[i];
+        }
+    }
+    return n;
+}
+
+// ---- one GPU-backed elementary decoder ---------------------------------------------------------------------
+struct OpusDecoder {
+    opusgpu_ctx *ctx;
+    int channels;
+    int32_t Fs;
+    int decode_gain;
+    int bandwidth, last_packet_duration;
+};
+
+static int dec_open(OpusDecoder *d, int32_t Fs, int channels) {
+    if ((Fs != 48000 && Fs != 24000 && Fs != 16000 && Fs != 12000 && Fs != 8000) || (channels != 1 && channels != 2))
+        return OPUS_BAD_ARG;
+    if (Fs != 48000) return OPUS_UNIMPLEMENTED; // the reference pins the output rate to 48 kHz (src/opus_decoder.cpp:169)
+    memset(d, 0, sizeof(*d));
+    int rc = opusgpu_ctx_create(0, &d->ctx);
+    if (rc != OPUSGPU_OK) return rc == OPUSGPU_ALLOC_FAIL ? OPUS_ALLOC_FAIL : OPUS_INTERNAL_ERROR;
+    rc = opusgpu_streams_alloc(d->ctx, 1, channels);
+    if (rc != OPUSGPU_OK) {
+        opusgpu_ctx_destroy(d->ctx);
+        d->ctx = nullptr;
+        return OPUS_ALLOC_FAIL;
+    }
+    d->channels = channels;
+    d->Fs = Fs;
+    return OPUS_OK;
+}
+
+static int dec_decode(OpusDecoder *d, const uint8_t *data, int32_t len, int16_t *pcm, int frame_size) {
+    if (!d || !d->ctx || frame_size <= 0) return OPUS_BAD_ARG;
+    if (len <= 0 || data == nullptr) return OPUS_BAD_ARG; // no loss concealment in the reference (Q8)
+    const int pfs = ogh::toc_samples_per_frame(data[0], 48000);
+    uint8_t toc;
+    int16_t size[48];
+    const int count = ogh::parse_packet(data, len, 0, &toc, size, nullptr, nullptr);
+    if (count < 0) return count;
+    if (count * pfs > frame_size) return OPUS_BUFFER_TOO_SMALL;
+    // the GPU path writes 960 samples per frame (Q6); decode into a scratch block sized for `count` frames
+    int32_t id = 0, res = 0;
+    const uint8_t *pk = data;
+    int16_t *buf = (int16_t *)malloc(sizeof(int16_t) * (size_t)count * 960 * d->channels);
+    if (!buf) return OPUS_ALLOC_FAIL;
+    int rc = opusgpu_decode_packets(d->ctx, 1, &id, &pk, &len, buf, count, &res);
+    if (rc != OPUSGPU_OK) res = OPUS_INTERNAL_ERROR;
+    if (res > 0) {
+        int n = res < frame_size ? res : frame_size;
+        memcpy(pcm, buf, sizeof(int16_t) * (size_t)n * d->channels);
+        d->bandwidth = ogh::toc_bandwidth(toc);
+        d->last_packet_duration = res;
+    }
+    free(buf);
+    return res;
+}
+
+static int dec_ctl(OpusDecoder *d, int request, va_list ap) {
+    switch (request) {
+        case OPUS_GET_BANDWIDTH_REQUEST: { int32_t *v = va_arg(ap, int32_t *); if (!v) return OPUS_BAD_ARG; *v = d->bandwidth; return OPUS_OK; }
+        case OPUS_GET_SAMPLE_RATE_REQUEST: { int32_t *v = va_arg(ap, int32_t *); if (!v) return OPUS_BAD_ARG; *v = d->Fs; return OPUS_OK; }
+        case OPUS_GET_GAIN_REQUEST: { int32_t *v = va_arg(ap, int32_t *); if (!v) return OPUS_BAD_ARG; *v = d->decode_gain; return OPUS_OK; }
+        case OPUS_SET_GAIN_REQUEST: { int32_t v = va_arg(ap, int32_t); if (v < -32768 || v > 32767) return OPUS_BAD_ARG; d->decode_gain = v; return OPUS_OK; } // stored, never applied (Q7)
+        case OPUS_GET_LAST_PACKET_DURATION_REQUEST: { int32_t *v = va_arg(ap, int32_t *); if (!v) return OPUS_BAD_ARG; *v = d->last_packet_duration; return OPUS_OK; }
+        case OPUS_GET_FINAL_RANGE_REQUEST: {
+            uint32_t *v = va_arg(ap, uint32_t *);
+            if (!v) return OPUS_BAD_ARG;
+            int32_t head[4]; // channels, prev_mode, frames_decoded, range_final
+            if (opusgpu_stream_state_get(d->ctx, 0, head, sizeof(head)) != OPUSGPU_OK) return OPUS_INTERNAL_ERROR;
+            *v = (uint32_t)head[3];
+            return OPUS_OK;
+        }
+        case OPUS_RESET_STATE:
+            d->bandwidth = 0;
+            d->last_packet_duration = 0;
+            return opusgpu_streams_reset(d->ctx, 0, 1, 0) == OPUSGPU_OK ? OPUS_OK : OPUS_INTERNAL_ERROR;
+        default: return OPUS_UNIMPLEMENTED;
+    }
+}
+
+int opus_decoder_get_size(int channels) { return (channels < 1 || channels > 2) ? 0 : (int)sizeof(OpusDecoder); }
+int opus_decoder_init(OpusDecoder *st, int32_t Fs, int channels) { return st ? dec_open(st, Fs, channels) : OPUS_BAD_ARG; }
+int opus_decode(OpusDecoder *st, uint8_t *data, int32_t len, int16_t *pcm, int frame_size) {
+    return dec_decode(st, data, len, pcm, frame_size);
+}
+int opus_decoder_ctl(OpusDecoder *st, int request, ...) {
+    if (!st) return OPUS_BAD_ARG;
+    va_list ap;
+    va_start(ap, request);
+    int r = dec_ctl(st, request, ap);
+    va_end(ap);
+    return r;
+}
+void opus_decoder_destroy(OpusDecoder *st) {
+    if (!st) return;
+    if (st->ctx) opusgpu_ctx_destroy(st->ctx);
+    st->ctx = nullptr;
+}
+
+// ---- multistream wrapper ---------------------------------------------------------------------------------------
+struct MSImpl {
+    OpusMSDecoder_t pub; // must be first: callers see an OpusMSDecoder_t*
+    OpusDecoder dec;
+};
+
+int32_t opus_multistream_decoder_get_size(int streams, int coupled) {
+    if (streams < 1 || coupled > streams || coupled < 0) return 0;
+    return (int32_t)sizeof(MSImpl);
+}
+
+int opus_multistream_decoder_init(OpusMSDecoder_t *st, int32_t Fs, int channels, int streams, int coupled_streams,
+                                  const uint8_t *mapping) {
+    if (!st || channels > 255 || channels < 1 || coupled_streams > streams || streams < 1 || coupled_streams < 0 ||
+        streams > 255 - coupled_streams)
+        return OPUS_BAD_ARG;
+    if (streams != 1) return OPUS_UNIMPLEMENTED; // the reference cannot really run >1 stream either (global codec state)
+    MSImpl *m = reinterpret_cast<MSImpl *>(st);
+    for (int i = 0; i < channels; i++) {
+        if (mapping[i] >= streams + coupled_streams && mapping[i] != 255) return OPUS_BAD_ARG; // validate_layout
+    }
+    const int dch = coupled_streams ? 2 : 1;
+    if (m->dec.ctx && m->dec.channels == dch) { // re-init of an existing object: fresh codec state
+        if (opusgpu_streams_reset(m->dec.ctx, 0, 1, 1) != OPUSGPU_OK) return OPUS_INTERNAL_ERROR;
+        m->dec.bandwidth = m->dec.last_packet_duration = 0;
+    } else {
+        if (m->dec.ctx) opus_decoder_destroy(&m->dec);
+        int rc = dec_open(&m->dec, Fs, dch);
+        if (rc != OPUS_OK) return rc;
+    }
+    st->nb_channels = channels;
+    st->nb_streams = streams;
+    st->nb_coupled_streams = coupled_streams;
+    for (int i = 0; i < channels; i++) st->mapping[i] = mapping[i];
+    return OPUS_OK;
+}
+
+OpusMSDecoder_t *opus_multistream_decoder_create(int32_t Fs, int channels, int streams, int coupled_streams,
+                                                 const uint8_t *mapping, int *error) {
+    MSImpl *m = (MSImpl *)calloc(1, sizeof(MSImpl));
+    if (!m) {
+        if (error) *error = OPUS_ALLOC_FAIL;
+        return nullptr;
+    }
+    int ret = opus_multistream_decoder_init(&m->pub, Fs, channels, streams, coupled_streams, mapping);
+    if (error) *error = ret;
+    if (ret != OPUS_OK) {
+        free(m);
+        return nullptr;
+    }
+    return &m->pub;
+}
+
+int opus_multistream_decode(OpusMSDecoder_t *st, uint8_t *data, int32_t len, int16_t *pcm, int frame_size) {
+    if (!st || frame_size <= 0 || len < 0) return OPUS_BAD_ARG;
+    MSImpl *m = reinterpret_cast<MSImpl *>(st);
+    if (len == 0) return OPUS_BAD_ARG; // PLC path does not exist (Q8)
+    if (frame_size > 5760) frame_size = 5760;
+    const int dch = m->dec.channels;
+    int16_t *buf = (int16_t *)malloc(sizeof(int16_t) * 2 * (size_t)frame_size);
+    if (!buf) return OPUS_ALLOC_FAIL;
+    int ret = dec_decode(&m->dec, data, len, buf, frame_size);
+    if (ret > 0) { // opus_copy_channel_out_short by mapping (src/opus_decoder.cpp:881-910)
+        for (int c = 0; c < st->nb_channels; c++) {
+            const int mp = st->mapping[c];
+            for (int i = 0; i < ret; i++) {
+                int16_t v = 0;
+                if (mp != 255) v = (dch == 2) ? buf[2 * i + (mp & 1)] : buf[i];
+                pcm[i * st->nb_channels + c] = v;
+            }
+        }
+    }
+    free(buf);
+    return ret;
+}
+
+int opus_multistream_decoder_ctl(OpusMSDecoder_t *st, int request, ...) {
+    if (!st) return OPUS_BAD_ARG;
+    MSImpl *m = reinterpret_cast<MSImpl *>(st);
+    va_list ap;
+    va_start(ap, request);
+    int r;
+    if (request == OPUS_MULTISTREAM_GET_DECODER_STATE_REQUEST) {
+        int32_t id = va_arg(ap, int32_t);
+        OpusDecoder **v = va_arg(ap, OpusDecoder **);
+        if (id != 0 || !v) r = OPUS_BAD_ARG;
+        else { *v = &m->dec; r = OPUS_OK; }
+    } else
+        r = dec_ctl(&m->dec, request, ap);
+    va_end(ap);
+    return r;
+}
+
+void opus_multistream_decoder_destroy(OpusMSDecoder_t *st) {
+    if (!st) return;
+    MSImpl *m = reinterpret_cast<MSImpl *>(st);
+    opus_decoder_destroy(&m->dec);
+    free(m);
+}
+
+// ---- the player's container entry points -------------------------------------------------------------------
+struct OggOpusFile {
+    ogc::OpusFile *of;
+    OpusMSDecoder_t *od;
+};
+static OggOpusFile g_player = {nullptr, nullptr};
+
+static int player_decode(void *user, const uint8_t *pkt, int32_t len, int16_t *pcm, int frame_size) {
+    OggOpusFile *p = (OggOpusFile *)user;
+    return opus_multistream_decode(p->od, const_cast<uint8_t *>(pkt), len, pcm, frame_size);
+}
+
+int opus_head_parse(OpusHead_t *_head, uint8_t *_data, size_t _len) {
+    ogc::Head h;
+    int r = ogc::parse_head(&h, _data, _len);
+    if (r < 0 || !_head) return r;
+    _head->version = h.version; _head->channel_count = h.channel_count; _head->pre_skip = h.pre_skip;
+    _head->input_sample_rate = h.input_sample_rate; _head->output_gain = h.output_gain;
+    _head->mapping_family = h.mapping_family; _head->stream_count = h.stream_count; _head->coupled_count = h.coupled_count;
+    memcpy(_head->mapping, h.mapping, sizeof(_head->mapping));
+    return 0;
+}
+
+void opus_close_decoder() {
+    delete g_player.of;
+    g_player.of = nullptr;
+    if (g_player.od) opus_multistream_decoder_destroy(g_player.od);
+    g_player.od = nullptr;
+}
+
+OggOpusFile_t *opus_init_decoder() {
+    opus_close_decoder();
+    if (!SD_read) return nullptr;
+    g_player.of = new (std::nothrow) ogc::OpusFile(SD_read, player_decode, &g_player);
+    if (!g_player.of) return nullptr;
+    if (g_player.of->open() < 0) {
+        opus_close_decoder();
+        return nullptr;
+    }
+    const ogc::Head &h = g_player.of->head();
+    int err = 0;
+    g_player.od = opus_multistream_decoder_create(48000, h.channel_count, h.stream_count, h.coupled_count, h.mapping, &err);
+    if (!g_player.od) {
+        opus_close_decoder();
+        return nullptr;
+    }
+    return &g_player;
+}
+
+int op_read_stereo(int16_t *_pcm, int _buf_size) {
+    if (!g_player.of) return OP_EINVAL;
+    return g_player.of->read_stereo(_pcm, _buf_size);
+}

@@ -1,0 +1,65 @@
+"""CPU test of the KERNEL SOURCE: the HIP headers compiled in the test-only one-lane host emulation
+(tests/emul) are fuzzed against the oracle.  Catches arithmetic / control-flow slips in the device code
+without a GPU (cross-lane synchronisation is only exercised by the -m gpu tests)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMUL = os.path.join(ROOT, "tests", "emul", "libog_emul.so")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-C", os.path.dirname(EMUL), "-s"])
+    lib = C.CDLL(EMUL)
+    lib.emu_state_size.restype = C.c_int
+    lib.emu_stream_init.argtypes = [C.c_void_p, C.c_int]
+    lib.emu_stream_reset.argtypes = [C.c_void_p]
+    lib.emu_decode_frame.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    return lib
+
+
+def _mode_bw(toc):
+    if toc & 0x80:
+        bw = 1102 + ((toc >> 5) & 3)
+        return 1002, (1101 if bw == 1102 else bw)
+    if (toc & 0x60) == 0x60:
+        return 1001, (1105 if toc & 0x10 else 1104)
+    return 1000, 1101 + ((toc >> 5) & 3)
+
+
+CFGS = {0: [1, 5, 9], 1: [13, 15], 2: [19, 23, 27, 31]}
+
+
+@pytest.mark.parametrize("seed,modes,switch", [(1, [2], False), (2, [0], False), (3, [1], False), (4, [0, 1, 2], True)])
+def test_emulated_kernels_match_oracle(emu, oracle, seed, modes, switch):
+    rng = np.random.default_rng(seed)
+    st = C.create_string_buffer(emu.emu_state_size())
+    out = np.zeros((960, 2), dtype=np.int16)
+    for stream in range(40):
+        channels = int(rng.integers(1, 3))
+        d = oracle.decoder(channels)
+        d.init()
+        emu.emu_stream_init(st, channels)
+        mode = int(rng.choice(modes))
+        for f in range(8):
+            if switch and rng.random() < 0.3:
+                mode = int(rng.choice(modes))
+            stereo = (channels == 2) if (not switch or rng.random() < 0.9) else bool(rng.integers(2))
+            toc = (int(rng.choice(CFGS[mode])) << 3) | (4 if stereo else 0)
+            L = int(rng.choice([40, 120, 160, 3, 333]))
+            kind = int(rng.integers(12))
+            body = bytes(L) if kind == 0 else (b"\xff" * L if kind == 1 else rng.integers(0, 256, L, dtype=np.uint8).tobytes())
+            ref, r = d.decode(bytes([toc]) + body)
+            m, bw = _mode_bw(toc)
+            out[:] = 0
+            r2 = emu.emu_decode_frame(st, body, L, m, bw, 2 if stereo else 1, out.ctypes.data)
+            assert r == r2, (stream, f, hex(toc), r, r2)
+            if r > 0:
+                pch = 2 if stereo else 1
+                ncmp = 960 * pch if (m == 1000 and pch < channels) else 960 * channels  # Q3: see test_gpu_modes
+                assert np.array_equal(out.reshape(-1)[:ncmp], ref[:960].reshape(-1)[:ncmp]), (stream, f, hex(toc))
