@@ -16,7 +16,7 @@
 namespace og {
 
 // ---- energies (src/celt.cpp:3613-3700) ------------------------------------------------------------
-OG_DEVN void coarse_energy(Rc &rc, int start, int end, int intra, int C, int LM) {
+OG_DEV void coarse_energy(Rc &rc, int start, int end, int intra, int C, int LM) {
     const u8 *pm = rom_eprob + (LM * 2 + intra) * 42;
     i32 prev[2] = {0, 0};
     i32 coef, beta;
@@ -97,7 +97,7 @@ OG_DEV int tf_select(int LM, int idx) {
     return v >= 8 ? v - 16 : v;
 }
 
-OG_DEVN void tf_decode(Rc &rc, int start, int end, int transient, int LM) { // celt.cpp:2128
+OG_DEV void tf_decode(Rc &rc, int start, int end, int transient, int LM) { // celt.cpp:2128
     int curr = 0, tf_sel = 0, tf_changed = 0;
     int logp = transient ? 2 : 4;
     u32 budget = rc.storage * 8, tell = (u32)rc_tell(rc);
@@ -118,7 +118,7 @@ OG_DEVN void tf_decode(Rc &rc, int start, int end, int transient, int LM) { // c
 }
 
 // ---- bit allocation (clt_compute_allocation celt.cpp:3523, interp_bits2pulses :3298) ----------------
-OG_DEVN int compute_allocation(Rc &rc, int start, int end, int alloc_trim, i32 &intensity, i32 &dual_stereo, i32 total,
+OG_DEV int compute_allocation(Rc &rc, int start, int end, int alloc_trim, i32 &intensity, i32 &dual_stereo, i32 total,
                                i32 &balance_out, int C, int LM) {
     const i32 *eb = rom_eband;
     int skip_start = start, intensity_rsv = 0, dual_stereo_rsv = 0;
@@ -609,7 +609,7 @@ OG_DEV void celt_reset_state(CeltState *st) { // OPUS_RESET_STATE celt.cpp:2479 
 // Decode one CELT frame of `frame_size` samples (120 << LM) from the live range decoder.
 // pcm_out: LDS i16 buffer (interleaved, CC channels) -- S.v[V_X..] is reused for it after synthesis.
 // Returns frame_size or a negative code (wave-uniform).
-OG_DEVN int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int CC, int start, int disable_inv) {
+OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int CC, int start, int disable_inv) {
     const i32 *eb = rom_eband;
     const int end = NBANDS;
     int LM;
@@ -867,3 +867,6 @@ OG_DEVN int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int 
 }
 
 } // namespace og
+
+#undef OG_SYNC
+#define OG_SYNC() OG_FULL_SYNC()

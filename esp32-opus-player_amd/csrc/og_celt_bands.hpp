@@ -5,21 +5,31 @@
 // Vectors live in the LDS arena S.v and are addressed by index (X, the folding history `norm`, the
 // pulse vector and a scratch row).  The bit-budget bookkeeping and every range-decoder read are
 // wave-uniform scalar code; the per-coefficient loops are split over the 64 lanes.
+//
+// Structure (round-1 rework): everything here is force-inlined into ONE function so that the range
+// decoder state and the band context stay in (scalar) registers -- the first version passed them by
+// reference through non-inlined functions, which put them in scratch memory (~9 k flat accesses per
+// frame).  To keep the code size finite without out-of-line calls, the reference's call tree is turned
+// into loops with a single instance of each body:
+//   * the two quant_band() calls of a stereo / dual-stereo band become a loop over "jobs";
+//   * quant_partition()'s recursion (depth <= 4 splits) becomes an iterative walk with an explicit
+//     stack of split frames in LDS;
+//   * the PVQ codebook-size table U(n,k) sits in 48 VGPRs spread across the wave
+//     (lane l of register (row, seg) holds U(row, 64*seg + l)); a lookup is a v_readlane, and the search
+//     "largest k' <= k with U(n,k') <= i" along a row is three wave ballots instead of a dependent walk.
 // Reference behaviour: src/celt.cpp:684-815 (rotation, residual normalisation, collapse mask,
 // renormalise), :1010-1082 (anti-collapse), :1113-1213 (stereo merge, Hadamard, Haar),
-// :1215-1355 (theta), :1357-1741 (band / partition decode), :1754-1924 (band loop).
+// :1215-1355 (theta), :1357-1741 (band / partition decode), :1754-1924 (band loop), :2545-2620 (cwrsi).
 #pragma once
 #include "og_celt_math.hpp"
+
+// Every barrier in the CELT path orders LDS traffic between the lanes of the single wave only.
+#undef OG_SYNC
+#define OG_SYNC() OG_LSYNC()
 
 namespace og {
 
 constexpr int BITRES = 3;
-
-struct BandCtx {
-    int band, intensity, spread, tf_change, disable_inv;
-    i32 remaining_bits;
-    u32 seed;
-};
 
 OG_DEV const u8 *pulse_cache(int band, int LM) { return rom_pulse_bits + rom_pulse_idx[(LM + 1) * NBANDS + band]; }
 
@@ -36,6 +46,113 @@ OG_DEV int bits2pulses(int band, int LM, int bits) { // celt.h:537
 OG_DEV int pulses2bits(int band, int LM, int pulses) { return pulses == 0 ? 0 : pulse_cache(band, LM)[pulses] + 1; }
 OG_DEV int get_pulses(int i) { return i < 8 ? i : (8 + (i & 7)) << ((i >> 3) - 1); } // celt.h:533
 
+// ---- PVQ codebook-size table in registers -----------------------------------------------------------
+#ifndef OG_HOST_EMUL
+typedef u32 v16u __attribute__((ext_vector_type(16)));
+#endif
+
+struct PvqTab {
+#ifndef OG_HOST_EMUL
+    v16u t0, t1, t2; // row r (0..14) of U: columns [0,64) in t0[r], [64,128) in t1[r], [128,192) in t2[r]
+#endif
+    OG_MEMBER void load() {
+#ifndef OG_HOST_EMUL
+        const int l = OG_LANE;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            t0[r] = rom_pvq_u192[r * 192 + l];
+            t1[r] = rom_pvq_u192[r * 192 + 64 + l];
+            t2[r] = rom_pvq_u192[r * 192 + 128 + l];
+        }
+#endif
+    }
+    // U(a,b), symmetric; min(a,b) <= 14, max(a,b) <= 176
+    OG_MEMBER u32 u(int a, int b) const {
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+#ifdef OG_HOST_EMUL
+        return rom_pvq_u192[lo * 192 + hi];
+#else
+        const u32 v0 = t0[lo], v1 = t1[lo], v2 = t2[lo];
+        const int seg = hi >> 6;
+        const u32 v = seg == 0 ? v0 : (seg == 1 ? v1 : v2);
+        return (u32)__builtin_amdgcn_readlane((int)v, hi & 63);
+#endif
+    }
+    // largest k' in [0, k] with U(n, k') <= i (row n <= 14; U(n, .) is non-decreasing and U(n,0) == 0 for n > 0)
+    OG_MEMBER int row_search(int n, int k, u32 i) const {
+#ifdef OG_HOST_EMUL
+        int kk = k;
+        while (rom_pvq_u192[n * 192 + kk] > i) kk--;
+        return kk;
+#else
+        const u32 v0 = t0[n], v1 = t1[n], v2 = t2[n];
+        u64 m0 = __ballot(v0 <= i), m1 = __ballot(v1 <= i), m2 = __ballot(v2 <= i);
+        // keep columns <= k only
+        const int kc = k + 1; // number of admissible columns
+        m0 &= kc >= 64 ? ~0ull : ((1ull << kc) - 1);
+        m1 &= kc >= 128 ? ~0ull : (kc > 64 ? ((1ull << (kc - 64)) - 1) : 0ull);
+        m2 &= kc >= 192 ? ~0ull : (kc > 128 ? ((1ull << (kc - 128)) - 1) : 0ull);
+        if (m2) return 128 + 63 - __builtin_clzll(m2);
+        if (m1) return 64 + 63 - __builtin_clzll(m1);
+        return 63 - __builtin_clzll(m0 | 1ull);
+#endif
+    }
+};
+
+// Codeword index -> signed pulse vector in S.v[V_IY ...]; returns the sum of squares (cwrsi celt.cpp:2545).
+OG_DEV i32 pvq_decode_index(const PvqTab &T, int n, int k, u32 i) {
+    int pos = V_IY;
+    i32 yy = 0;
+    while (n > 2) {
+        if (k >= n) { // "lots of pulses": everything needed is on row n (U is symmetric, n <= 14 here)
+            const u32 p1 = T.u(n, k + 1);
+            const int s = -(int)(i >= p1);
+            i -= p1 & (u32)s;
+            const int k0 = k;
+            const u32 q = T.u(n, n);
+            k = T.row_search(n, q > i ? n - 1 : k, i);
+            i -= T.u(n, k);
+            const int val = tr16((k0 - k + s) ^ s);
+            S.v[pos++] = (i16)val;
+            yy += val * val;
+        } else { // "lots of dimensions": rows k and k+1, column n
+            const u32 p = T.u(k, n), q = T.u(k + 1, n);
+            if (p <= i && i < q) {
+                i -= p;
+                S.v[pos++] = 0;
+            } else {
+                const int s = -(int)(i >= q);
+                i -= q & (u32)s;
+                const int k0 = k;
+                u32 pp;
+                do pp = T.u(--k, n);
+                while (pp > i);
+                i -= pp;
+                const int val = tr16((k0 - k + s) ^ s);
+                S.v[pos++] = (i16)val;
+                yy += val * val;
+            }
+        }
+        n--;
+    }
+    {
+        const u32 p = 2 * (u32)k + 1;
+        int s = -(int)(i >= p);
+        i -= p & (u32)s;
+        const int k0 = k;
+        k = (int)((i + 1) >> 1);
+        if (k) i -= 2 * (u32)k - 1;
+        int val = tr16((k0 - k + s) ^ s);
+        S.v[pos++] = (i16)val;
+        yy += val * val;
+        s = -(int)i;
+        val = tr16((k + s) ^ s);
+        S.v[pos] = (i16)val;
+        yy += val * val;
+    }
+    return yy;
+}
+
 // ---- lane-parallel vector helpers ----------------------------------------------------------------
 // scale X[0..N) so that its norm becomes `gain` (renormalise_vector celt.cpp:797)
 OG_DEV void renormalise(int x, int N, i32 gain) {
@@ -51,31 +168,37 @@ OG_DEV void renormalise(int x, int N, i32 gain) {
 }
 
 // One pass of the 2-tap lattice along chains x[r], x[r+stride], ... (exp_rotation1 celt.cpp:684).
-// Inside one block of `len` samples the chains r = 0..stride-1 are independent of each other, and
-// the `nblk` blocks are independent too: one lane per (block, chain); along a chain it is serial.
+// Inside one block of `len` samples the chains r = 0..stride-1 are independent of each other, and the
+// `nblk` blocks are independent too: one lane per (block, chain).  Along a chain the recurrence is serial;
+// its running value is carried in a register (forward: the freshly rotated x[i+stride]; backward: x[i]),
+// so each step has one LDS load that does not depend on the previous step.
 OG_DEV void rotate_pass(int x, int len, int nblk, int stride, i32 c, i32 s) {
     OG_SYNC();
-    i32 ms = tr16(-s);
-    int nchain = nblk * stride;
+    const i32 ms = tr16(-s);
+    const int nchain = nblk * stride;
     OG_FOR_LANES(id, nchain) {
-        int blk = id / stride, r = id - blk * stride;
-        int base = x + blk * len;
-        // forward: i = r, r+stride, ... while i < len - stride
+        const int blk = id / stride, r = id - blk * stride;
+        const int base = x + blk * len;
         int i = r;
-        for (; i < len - stride; i += stride) {
-            i32 x1 = S.v[base + i], x2 = S.v[base + i + stride];
-            S.v[base + i + stride] = (i16)pshr32(mul16(c, x2) + mul16(s, x1), 15);
-            S.v[base + i] = (i16)pshr32(mul16(c, x1) + mul16(ms, x2), 15);
-        }
-        // backward: i = len-2*stride-1 down to 0, restricted to this chain's residue
-        int last = len - 2 * stride - 1;
-        if (last >= 0) {
-            int top = last - ((last - r) % stride + stride) % stride; // largest i <= last with i % stride == r
-            for (i = top; i >= 0; i -= stride) {
-                i32 x1 = S.v[base + i], x2 = S.v[base + i + stride];
-                S.v[base + i + stride] = (i16)pshr32(mul16(c, x2) + mul16(s, x1), 15);
+        if (i < len - stride) { // forward: i = r, r+stride, ... while i < len - stride
+            i32 x1 = S.v[base + i];
+            for (; i < len - stride; i += stride) {
+                const i32 x2 = S.v[base + i + stride];
                 S.v[base + i] = (i16)pshr32(mul16(c, x1) + mul16(ms, x2), 15);
+                x1 = tr16(pshr32(mul16(c, x2) + mul16(s, x1), 15));
             }
+            S.v[base + i] = (i16)x1; // i is now the chain's last index
+        }
+        const int last = len - 2 * stride - 1; // backward: i = last .. 0 on this chain's residue
+        if (last >= r) {
+            const int top = last - (last - r) % stride;
+            i32 x2 = S.v[base + top + stride];
+            for (i = top; i >= 0; i -= stride) {
+                const i32 x1 = S.v[base + i];
+                S.v[base + i + stride] = (i16)pshr32(mul16(c, x2) + mul16(s, x1), 15);
+                x2 = tr16(pshr32(mul16(c, x1) + mul16(ms, x2), 15));
+            }
+            S.v[base + r] = (i16)x2; // i + stride == r after the loop
         }
     }
     OG_SYNC();
@@ -99,23 +222,6 @@ OG_DEV void unspread(int x, int len, int stride, int K, int spread) {
     rotate_pass(x, blen, stride, 1, c, s);
 }
 
-// PVQ leaf: decode K pulses into X[0..N) with norm `gain` (alg_unquant celt.cpp:782)
-OG_DEVN u32 pvq_unquant(Rc &rc, int x, int N, int K, int spread, int B, i32 gain) {
-    i32 Ryy = pvq_decode_index(N, K, rc_uint(rc, pvq_v(N, K)));
-    int k = ilog2(Ryy) >> 1;
-    i32 t = vshr32(Ryy, 2 * (k - 7));
-    i32 g = tr16(mul16_p15(rsqrt_norm(t), gain));
-    OG_SYNC();
-    OG_FOR_LANES(j, N) S.v[x + j] = (i16)pshr32(mul16(g, S.v[V_IY + j]), k + 1); // normalise_residual :745
-    unspread(x, N, B, K, spread);
-    if (B <= 1) return 1;
-    u32 N0 = udiv((u32)N, (u32)B), m = 0; // extract_collapse_mask :760
-    OG_FOR_LANES(j, N) m |= (u32)(S.v[V_IY + j] != 0) << udiv((u32)j, N0);
-    m = wave_or(m);
-    OG_SYNC();
-    return m;
-}
-
 OG_DEV void haar1(int x, int N0, int stride) { // celt.cpp:1202
     N0 >>= 1;
     OG_SYNC();
@@ -137,26 +243,17 @@ OG_DEV int ordery(int stride, int i) {
     return (int)((t >> (4 * i)) & 15);
 }
 
-OG_DEV void deinterleave_hadamard(int x, int N0, int stride, int hadamard) { // celt.cpp:1162
+// hadamard reorder, dir = 0: de-interleave (celt.cpp:1162), dir = 1: interleave (:1183)
+OG_DEV void hadamard_reorder(int x, int N0, int stride, int hadamard, int dir) {
     int N = N0 * stride;
     OG_SYNC();
     OG_FOR_LANES(id, N) {
         int i = id / N0, j = id - i * N0;
-        int dst = (hadamard ? ordery(stride, i) : i) * N0 + j;
-        S.v[V_TMP + dst] = S.v[x + j * stride + i];
-    }
-    OG_SYNC();
-    OG_FOR_LANES(id, N) S.v[x + id] = S.v[V_TMP + id];
-    OG_SYNC();
-}
-
-OG_DEV void interleave_hadamard(int x, int N0, int stride, int hadamard) { // celt.cpp:1183
-    int N = N0 * stride;
-    OG_SYNC();
-    OG_FOR_LANES(id, N) {
-        int i = id / N0, j = id - i * N0;
-        int src = (hadamard ? ordery(stride, i) : i) * N0 + j;
-        S.v[V_TMP + j * stride + i] = S.v[x + src];
+        int blocked = (hadamard ? ordery(stride, i) : i) * N0 + j, inter = j * stride + i;
+        if (dir == 0)
+            S.v[V_TMP + blocked] = S.v[x + inter];
+        else
+            S.v[V_TMP + inter] = S.v[x + blocked];
     }
     OG_SYNC();
     OG_FOR_LANES(id, N) S.v[x + id] = S.v[V_TMP + id];
@@ -210,12 +307,14 @@ OG_DEV int compute_qn(int N, int b, int offset, int pulse_cap, int stereo) { // 
 
 struct Split { int inv, imid, iside, delta, itheta, qalloc; };
 
-OG_DEVN void compute_theta(Rc &rc, BandCtx &cx, Split &sc, int N, i32 &b, int B, int B0, int LM, int stereo, i32 &fill) {
-    int itheta = 0, inv = 0, i = cx.band;
-    int pulse_cap = rom_logn[i] + LM * (1 << BITRES);
+// compute_theta celt.cpp:1241 (decoder branches)
+OG_DEV void compute_theta(Rc &rc, int band, int intensity, int disable_inv, i32 remaining_bits, Split &sc, int N, i32 &b, int B,
+                          int B0, int LM, int stereo, i32 &fill) {
+    int itheta = 0, inv = 0;
+    int pulse_cap = rom_logn[band] + LM * (1 << BITRES);
     int offset = (pulse_cap >> 1) - (stereo && N == 2 ? 16 : 4);
     int qn = compute_qn(N, b, offset, pulse_cap, stereo);
-    if (stereo && i >= cx.intensity) qn = 1;
+    if (stereo && band >= intensity) qn = 1;
     u32 tell = rc_tell_frac(rc);
     if (qn != 1) {
         if (stereo && N > 2) {
@@ -243,8 +342,8 @@ OG_DEVN void compute_theta(Rc &rc, BandCtx &cx, Split &sc, int N, i32 &b, int B,
         }
         itheta = (int)udiv((u32)(itheta * 16384), (u32)qn);
     } else if (stereo) {
-        if (b > 2 << BITRES && cx.remaining_bits > 2 << BITRES) inv = rc_bit_logp(rc, 2);
-        if (cx.disable_inv) inv = 0;
+        if (b > 2 << BITRES && remaining_bits > 2 << BITRES) inv = rc_bit_logp(rc, 2);
+        if (disable_inv) inv = 0;
     }
     int qalloc = (int)(rc_tell_frac(rc) - tell);
     b -= qalloc;
@@ -273,20 +372,44 @@ OG_DEVN void compute_theta(Rc &rc, BandCtx &cx, Split &sc, int N, i32 &b, int B,
 }
 
 // ---- partitions -----------------------------------------------------------------------------------
-// Leaf of the partition tree: PVQ pulses, or (no pulses) zero / noise / folded-spectrum fill.
-// `low` < 0 means "no folding source".
-OG_DEVN u32 partition_leaf(Rc &rc, BandCtx &cx, int x, int N, i32 b, int B, int low, int LM, i32 gain, i32 fill) {
-    int i = cx.band;
-    int q = bits2pulses(i, LM, b), curr_bits = pulses2bits(i, LM, q);
-    cx.remaining_bits -= curr_bits;
-    while (cx.remaining_bits < 0 && q > 0) {
-        cx.remaining_bits += curr_bits;
+// Leaf of the partition tree: PVQ pulses, or (no pulses) zero / noise / folded-spectrum fill (celt.cpp:1463-1520,
+// alg_unquant :782).  `low` < 0 means "no folding source".
+OG_DEV u32 partition_leaf(Rc &rc, const PvqTab &T, int band, int spread, u32 &seed_io, i32 &remaining_bits, int x, int N, i32 b,
+                          int B, int low, int LM, i32 gain, i32 fill) {
+    int q = bits2pulses(band, LM, b), curr_bits = pulses2bits(band, LM, q);
+    remaining_bits -= curr_bits;
+    while (remaining_bits < 0 && q > 0) {
+        remaining_bits += curr_bits;
         q--;
-        curr_bits = pulses2bits(i, LM, q);
-        cx.remaining_bits -= curr_bits;
+        curr_bits = pulses2bits(band, LM, q);
+        remaining_bits -= curr_bits;
     }
-    if (q != 0) return pvq_unquant(rc, x, N, get_pulses(q), cx.spread, B, gain);
-    u32 cm_mask = (u32)((1ull << B) - 1), cm = 0;
+    if (q != 0) {
+        const int K = get_pulses(q);
+#ifdef OG_ABL_PVQ // timing experiment only (wrong output): skip the index -> pulse-vector conversion
+        const u32 idx = rc_uint(rc, T.u(N, K) + T.u(N, K + 1));
+        OG_FOR_LANES(j, N) S.v[V_IY + j] = (i16)(j == 0 ? K : 0);
+        const i32 Ryy = K * K + (i32)(idx & 0);
+#else
+        const i32 Ryy = pvq_decode_index(T, N, K, rc_uint(rc, T.u(N, K) + T.u(N, K + 1)));
+#endif
+        const int k = ilog2(Ryy) >> 1;
+        const i32 t = vshr32(Ryy, 2 * (k - 7));
+        const i32 g = tr16(mul16_p15(rsqrt_norm(t), gain));
+        OG_SYNC();
+        OG_FOR_LANES(j, N) S.v[x + j] = (i16)pshr32(mul16(g, S.v[V_IY + j]), k + 1); // normalise_residual :745
+#ifndef OG_ABL_ROT
+        unspread(x, N, B, K, spread);
+#endif
+        if (B <= 1) return 1;
+        const u32 N0 = udiv((u32)N, (u32)B); // extract_collapse_mask :760
+        u32 m = 0;
+        OG_FOR_LANES(j, N) m |= (u32)(S.v[V_IY + j] != 0) << udiv((u32)j, N0);
+        m = wave_or(m);
+        OG_SYNC();
+        return m;
+    }
+    const u32 cm_mask = (u32)((1ull << B) - 1);
     fill &= (i32)cm_mask;
     OG_SYNC();
     if (!fill) {
@@ -294,91 +417,123 @@ OG_DEVN u32 partition_leaf(Rc &rc, BandCtx &cx, int x, int N, i32 b, int B, int 
         OG_SYNC();
         return 0;
     }
-    u32 seed = cx.seed;
+    const u32 seed = seed_io;
+    u32 cm;
     if (low < 0) { // noise
         OG_FOR_LANES(j, N) S.v[x + j] = (i16)((i32)lcg_skip(seed, (u32)j + 1) >> 20);
         cm = cm_mask;
     } else { // folded spectrum, +-1/256 dither
         OG_FOR_LANES(j, N) {
-            u32 sj = lcg_skip(seed, (u32)j + 1);
+            const u32 sj = lcg_skip(seed, (u32)j + 1);
             S.v[x + j] = (i16)(S.v[low + j] + ((sj & 0x8000) ? 4 : -4));
         }
         cm = (u32)fill;
     }
-    cx.seed = lcg_skip(seed, (u32)N);
+    seed_io = lcg_skip(seed, (u32)N);
     renormalise(x, N, gain);
     return cm;
 }
 
-// quant_partition celt.cpp:1382.  The reference recurses (depth <= 4 splits); here the depth is a
-// template parameter so the call graph is static and needs no device stack.
-template <int LVL>
-OG_DEVN u32 partition(Rc &rc, BandCtx &cx, int x, int N, i32 b, int B, int low, int LM, i32 gain, i32 fill) {
-    if constexpr (LVL < 4) {
-        const u8 *cache = pulse_cache(cx.band, LM);
-        if (LM != -1 && b > cache[cache[0]] + 12 && N > 2) {
-            int B0 = B;
+// One split node of quant_partition (celt.cpp:1400-1462), kept in LDS while its children run.
+struct SplitFrame {
+    i32 x, N, B, B0, LM, low, low2, gain_mid, gain_side, fill, mbits, sbits, itheta, rebal, mid_first, stage, cm;
+};
+OG_LDS SplitFrame g_split[6];
+
+// quant_partition celt.cpp:1382: the reference recurses (depth <= 4 splits); here the walk is iterative.
+OG_DEV u32 partition_tree(Rc &rc, const PvqTab &T, int band, int spread, u32 &seed, i32 &remaining_bits, int x, int N, i32 b, int B,
+                          int low, int LM, i32 gain, i32 fill) {
+    int depth = 0;
+    for (;;) {
+        // ---- descend: split as long as the node asks for it
+        for (;;) {
+            const u8 *cache = pulse_cache(band, LM);
+            if (!(LM != -1 && b > cache[cache[0]] + 12 && N > 2)) break;
+            const int B0 = B;
             Split sc;
             N >>= 1;
-            int y = x + N;
             LM -= 1;
             if (B == 1) fill = (fill & 1) | (fill << 1);
             B = (B + 1) >> 1;
-            compute_theta(rc, cx, sc, N, b, B, B0, LM, 0, fill);
-            i32 mid = sc.imid, side = sc.iside, delta = sc.delta;
-            int itheta = sc.itheta;
+            compute_theta(rc, band, 0, 0, remaining_bits, sc, N, b, B, B0, LM, 0, fill);
+            i32 delta = sc.delta;
+            const int itheta = sc.itheta;
             if (B0 > 1 && (itheta & 0x3fff)) {
                 if (itheta > 8192)
                     delta -= delta >> (4 - LM);
                 else
                     delta = OG_MIN(0, delta + (N << BITRES >> (5 - LM)));
             }
-            i32 mbits = OG_MAX(0, OG_MIN(b, (b - delta) / 2));
-            i32 sbits = b - mbits;
-            cx.remaining_bits -= sc.qalloc;
-            int low2 = low >= 0 ? low + N : -1;
-            i32 rebalance = cx.remaining_bits;
-            u32 cm;
-            if (mbits >= sbits) {
-                cm = partition<LVL + 1>(rc, cx, x, N, mbits, B, low, LM, tr16(mul16_p15(gain, mid)), fill);
-                rebalance = mbits - (rebalance - cx.remaining_bits);
-                if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES);
-                cm |= partition<LVL + 1>(rc, cx, y, N, sbits, B, low2, LM, tr16(mul16_p15(gain, side)), fill >> B)
-                      << (B0 >> 1);
-            } else {
-                cm = partition<LVL + 1>(rc, cx, y, N, sbits, B, low2, LM, tr16(mul16_p15(gain, side)), fill >> B)
-                     << (B0 >> 1);
-                rebalance = sbits - (rebalance - cx.remaining_bits);
-                if (rebalance > 3 << BITRES && itheta != 16384) mbits += rebalance - (3 << BITRES);
-                cm |= partition<LVL + 1>(rc, cx, x, N, mbits, B, low, LM, tr16(mul16_p15(gain, mid)), fill);
+            const i32 mbits = OG_MAX(0, OG_MIN(b, (b - delta) / 2));
+            const i32 sbits = b - mbits;
+            remaining_bits -= sc.qalloc;
+            SplitFrame &F = g_split[depth];
+            F.x = x; F.N = N; F.B = B; F.B0 = B0; F.LM = LM; F.low = low; F.low2 = low >= 0 ? low + N : -1;
+            F.gain_mid = tr16(mul16_p15(gain, sc.imid)); F.gain_side = tr16(mul16_p15(gain, sc.iside));
+            F.fill = fill; F.mbits = mbits; F.sbits = sbits; F.itheta = itheta; F.rebal = remaining_bits;
+            F.mid_first = mbits >= sbits; F.stage = 1; F.cm = 0;
+            depth++;
+            if (mbits >= sbits) { // first child: mid
+                b = mbits;
+                gain = tr16(mul16_p15(gain, sc.imid));
+            } else {               // first child: side
+                x = x + N;
+                b = sbits;
+                low = low >= 0 ? low + N : -1;
+                gain = tr16(mul16_p15(gain, sc.iside));
+                fill = fill >> B;
             }
-            return cm;
+        }
+        // ---- leaf
+        u32 cm = partition_leaf(rc, T, band, spread, seed, remaining_bits, x, N, b, B, low, LM, gain, fill);
+        // ---- return to the parents
+        for (;;) {
+            if (depth == 0) return cm;
+            SplitFrame &F = g_split[depth - 1];
+            const int B0 = OG_UNI(F.B0), Bc = OG_UNI(F.B), stage = OG_UNI(F.stage), mid_first = OG_UNI(F.mid_first);
+            if (stage == 1) { // first child done -> rebalance and run the second child
+                const u32 c1 = mid_first ? cm : cm << (B0 >> 1);
+                i32 mbits = OG_UNI(F.mbits), sbits = OG_UNI(F.sbits);
+                const int itheta = OG_UNI(F.itheta);
+                i32 rebalance = (mid_first ? mbits : sbits) - (OG_UNI(F.rebal) - remaining_bits);
+                if (mid_first) {
+                    if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES);
+                } else {
+                    if (rebalance > 3 << BITRES && itheta != 16384) mbits += rebalance - (3 << BITRES);
+                }
+                F.cm = (i32)c1;
+                F.stage = 2;
+                N = OG_UNI(F.N);
+                B = Bc;
+                LM = OG_UNI(F.LM);
+                if (mid_first) { // second child: side
+                    x = OG_UNI(F.x) + N;
+                    b = sbits;
+                    low = OG_UNI(F.low2);
+                    gain = OG_UNI(F.gain_side);
+                    fill = OG_UNI(F.fill) >> Bc;
+                } else {          // second child: mid
+                    x = OG_UNI(F.x);
+                    b = mbits;
+                    low = OG_UNI(F.low);
+                    gain = OG_UNI(F.gain_mid);
+                    fill = OG_UNI(F.fill);
+                }
+                break; // decode that child (it may split again: frames from `depth` upward are free)
+            }
+            // both children done
+            cm = (u32)OG_UNI(F.cm) | (mid_first ? cm << (B0 >> 1) : cm);
+            depth--;
         }
     }
-    return partition_leaf(rc, cx, x, N, b, B, low, LM, gain, fill);
 }
 
-// one-coefficient bands: a sign bit each (quant_band_n1 celt.cpp:1357); y < 0 means mono
-OG_DEV u32 band_n1(Rc &rc, BandCtx &cx, int x, int y, int low_out) {
-    for (int c = 0; c < (y >= 0 ? 2 : 1); c++) {
-        int sign = 0;
-        if (cx.remaining_bits >= 1 << BITRES) {
-            sign = (int)rc_bits(rc, 1);
-            cx.remaining_bits -= 1 << BITRES;
-        }
-        S.v[c ? y : x] = (i16)(sign ? -16384 : 16384);
-    }
-    if (low_out >= 0) S.v[low_out] = (i16)(S.v[x] >> 4);
-    return 1;
-}
-
-// quant_band celt.cpp:1526 (mono band or one side of a stereo band)
-OG_DEVN u32 band_mono(Rc &rc, BandCtx &cx, int x, int N, i32 b, int B, int low, int LM, int low_out, i32 gain,
-                      int low_scratch, i32 fill) {
-    int N0 = N, N_B, B0 = B, time_divide = 0, recombine = 0, tf_change = cx.tf_change;
-    int longBlocks = B0 == 1;
+// quant_band celt.cpp:1526 (mono band or one side of a stereo band); N > 1
+OG_DEV u32 band_mono(Rc &rc, const PvqTab &T, int band, int spread, int tf_change, u32 &seed, i32 &remaining_bits, int x, int N, i32 b,
+                     int B, int low, int LM, int low_out, i32 gain, int low_scratch, i32 fill) {
+    int N0 = N, N_B, B0 = B, time_divide = 0, recombine = 0;
+    const int longBlocks = B0 == 1;
     N_B = (int)udiv((u32)N, (u32)B);
-    if (N == 1) return band_n1(rc, cx, x, -1, low_out);
     if (tf_change > 0) recombine = tf_change;
     if (low_scratch >= 0 && low >= 0 && (recombine || ((N_B & 1) == 0 && tf_change < 0) || B0 > 1)) {
         OG_SYNC();
@@ -404,10 +559,10 @@ OG_DEVN u32 band_mono(Rc &rc, BandCtx &cx, int x, int N, i32 b, int B, int low, 
         tf_change++;
     }
     B0 = B;
-    int N_B0 = N_B;
-    if (B0 > 1 && low >= 0) deinterleave_hadamard(low, N_B >> recombine, B0 << recombine, longBlocks);
-    u32 cm = partition<0>(rc, cx, x, N, b, B, low, LM, gain, fill);
-    if (B0 > 1) interleave_hadamard(x, N_B >> recombine, B0 << recombine, longBlocks);
+    const int N_B0 = N_B;
+    if (B0 > 1 && low >= 0) hadamard_reorder(low, N_B >> recombine, B0 << recombine, longBlocks, 0);
+    u32 cm = partition_tree(rc, T, band, spread, seed, remaining_bits, x, N, b, B, low, LM, gain, fill);
+    if (B0 > 1) hadamard_reorder(x, N_B >> recombine, B0 << recombine, longBlocks, 1);
     N_B = N_B0;
     B = B0;
     for (int k = 0; k < time_divide; k++) {
@@ -432,93 +587,29 @@ OG_DEVN u32 band_mono(Rc &rc, BandCtx &cx, int x, int N, i32 b, int B, int low, 
     return cm & ((1u << B) - 1);
 }
 
-// quant_band_stereo celt.cpp:1628
-OG_DEVN u32 band_stereo(Rc &rc, BandCtx &cx, int x, int y, int N, i32 b, int B, int low, int LM, int low_out,
-                        int low_scratch, i32 fill) {
-    if (N == 1) return band_n1(rc, cx, x, y, low_out);
-    i32 orig_fill = fill;
-    Split sc;
-    compute_theta(rc, cx, sc, N, b, B, B, LM, 1, fill);
-    i32 mid = sc.imid, side = sc.iside, delta = sc.delta;
-    int itheta = sc.itheta, qalloc = sc.qalloc, inv = sc.inv;
-    u32 cm;
-    if (N == 2) {
-        i32 mbits = b, sbits = 0;
-        if (itheta != 0 && itheta != 16384) sbits = 1 << BITRES;
-        mbits -= sbits;
-        int c = itheta > 8192;
-        cx.remaining_bits -= qalloc + sbits;
-        int x2 = c ? y : x, y2 = c ? x : y, sign = 0;
-        if (sbits) sign = (int)rc_bits(rc, 1);
-        sign = 1 - 2 * sign;
-        cm = band_mono(rc, cx, x2, N, mbits, B, low, LM, low_out, 32767, low_scratch, orig_fill);
-        OG_SYNC();
-        // all lanes compute the same four values (uniform)
-        i32 a0 = S.v[x2], a1 = S.v[x2 + 1];
-        i32 b0 = tr16(-sign * a1), b1 = tr16(sign * a0);
-        i32 X0 = c ? b0 : a0, X1 = c ? b1 : a1, Y0 = c ? a0 : b0, Y1 = c ? a1 : b1;
-        X0 = tr16(mul16_q15(mid, X0));
-        X1 = tr16(mul16_q15(mid, X1));
-        Y0 = tr16(mul16_q15(side, Y0));
-        Y1 = tr16(mul16_q15(side, Y1));
-        OG_SYNC();
-        S.v[x] = (i16)sub16(X0, Y0);
-        S.v[y] = (i16)add16(X0, Y0);
-        S.v[x + 1] = (i16)sub16(X1, Y1);
-        S.v[y + 1] = (i16)add16(X1, Y1);
-        OG_SYNC();
-    } else {
-        i32 mbits = OG_MAX(0, OG_MIN(b, (b - delta) / 2));
-        i32 sbits = b - mbits;
-        cx.remaining_bits -= qalloc;
-        i32 rebalance = cx.remaining_bits;
-        if (mbits >= sbits) {
-            cm = band_mono(rc, cx, x, N, mbits, B, low, LM, low_out, 32767, low_scratch, fill);
-            rebalance = mbits - (rebalance - cx.remaining_bits);
-            if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES);
-            cm |= band_mono(rc, cx, y, N, sbits, B, -1, LM, -1, side, -1, fill >> B);
-        } else {
-            cm = band_mono(rc, cx, y, N, sbits, B, -1, LM, -1, side, -1, fill >> B);
-            rebalance = sbits - (rebalance - cx.remaining_bits);
-            if (rebalance > 3 << BITRES && itheta != 16384) mbits += rebalance - (3 << BITRES);
-            cm |= band_mono(rc, cx, x, N, mbits, B, low, LM, low_out, 32767, low_scratch, fill);
-        }
-        stereo_merge(x, y, mid, N);
-    }
-    if (inv) {
-        OG_SYNC();
-        OG_FOR_LANES(j, N) S.v[y + j] = (i16)(-S.v[y + j]);
-        OG_SYNC();
-    }
-    return cm;
-}
-
-// quant_all_bands celt.cpp:1754.  N_ch = 120 << LM is the per-channel stride of X.
-OG_DEVN void decode_all_bands(Rc &rc, int start, int end, int C, int N_ch, int shortBlocks, int spread, int dual_stereo,
-                              int intensity, i32 total_bits, i32 balance, int LM, int codedBands, u32 &seed,
-                              int disable_inv) {
+// quant_all_bands celt.cpp:1754 with quant_band_stereo :1628 and quant_band_n1 :1357 folded into the loop.
+// N_ch = 120 << LM is the per-channel stride of X.
+OG_DEV void decode_all_bands(Rc &rc, int start, int end, int C, int N_ch, int shortBlocks, int spread, int dual_stereo,
+                             int intensity, i32 total_bits, i32 balance, int LM, int codedBands, u32 &seed_io, int disable_inv) {
     const int M = 1 << LM, B = shortBlocks ? M : 1;
     const int norm_offset = M * rom_eband[start];
     const int norm = V_NORM, norm2 = V_NORM + M * rom_eband[NBANDS - 1] - norm_offset;
     int low_scratch = V_X + M * rom_eband[NBANDS - 1];
     int lowband_offset = 0, update_lowband = 1;
-    BandCtx cx;
-    cx.intensity = intensity;
-    cx.seed = seed;
-    cx.spread = spread;
-    cx.disable_inv = disable_inv;
+    u32 seed = seed_io;
+    PvqTab T;
+    T.load();
     for (int i = start; i < end; i++) {
         const int last = i == end - 1;
         const int eb0 = M * rom_eband[i], N = M * rom_eband[i + 1] - eb0;
         const int x = V_X + eb0, y = C == 2 ? V_X + N_ch + eb0 : -1;
-        cx.band = i;
         i32 tell = (i32)rc_tell_frac(rc);
         if (i != start) balance -= tell;
         i32 remaining_bits = total_bits - tell - 1, b;
-        cx.remaining_bits = remaining_bits;
+        const i32 pulses_i = OG_UNI(S.pulses[i]);
         if (i <= codedBands - 1) {
             i32 curr_balance = balance / OG_MIN(3, codedBands - i);
-            b = OG_MAX(0, OG_MIN(16383, OG_MIN(remaining_bits + 1, S.pulses[i] + curr_balance)));
+            b = OG_MAX(0, OG_MIN(16383, OG_MIN(remaining_bits + 1, pulses_i + curr_balance)));
         } else
             b = 0;
         if ((eb0 - N >= M * rom_eband[start] || i == start + 1) && (update_lowband || lowband_offset == 0))
@@ -534,8 +625,7 @@ OG_DEVN void decode_all_bands(Rc &rc, int start, int end, int C, int N_ch, int s
                 OG_SYNC();
             }
         }
-        int tf_change = S.tf_res[i];
-        cx.tf_change = tf_change;
+        const int tf_change = OG_UNI(S.tf_res[i]);
         if (last) low_scratch = -1;
         int effective_lowband = -1;
         u32 x_cm, y_cm;
@@ -548,8 +638,8 @@ OG_DEVN void decode_all_bands(Rc &rc, int start, int end, int C, int N_ch, int s
             x_cm = y_cm = 0;
             int fold_i = fold_start;
             do {
-                x_cm |= S.cmask[fold_i * C + 0];
-                y_cm |= S.cmask[fold_i * C + C - 1];
+                x_cm |= (u32)OG_UNI(S.cmask[fold_i * C + 0]);
+                y_cm |= (u32)OG_UNI(S.cmask[fold_i * C + C - 1]);
             } while (++fold_i < fold_end);
         } else
             x_cm = y_cm = (1u << B) - 1;
@@ -560,30 +650,127 @@ OG_DEVN void decode_all_bands(Rc &rc, int start, int end, int C, int N_ch, int s
             OG_SYNC();
         }
         const int low1 = effective_lowband != -1 ? norm + effective_lowband : -1;
+        const int low2 = effective_lowband != -1 ? norm2 + effective_lowband : -1;
         const int out1 = last ? -1 : norm + eb0 - norm_offset;
-        if (dual_stereo) {
-            const int low2 = effective_lowband != -1 ? norm2 + effective_lowband : -1;
-            const int out2 = last ? -1 : norm2 + eb0 - norm_offset;
-            x_cm = band_mono(rc, cx, x, N, b / 2, B, low1, LM, out1, 32767, low_scratch, (i32)x_cm);
-            y_cm = band_mono(rc, cx, y, N, b / 2, B, low2, LM, out2, 32767, low_scratch, (i32)y_cm);
+        const int out2 = last ? -1 : norm2 + eb0 - norm_offset;
+
+        if (N == 1) { // quant_band_n1 celt.cpp:1357 (mono, stereo and dual stereo all end up here)
+            // dual stereo calls it once per channel with its own lowband_out; the bit consumption is identical
+            for (int c = 0; c < (y >= 0 ? 2 : 1); c++) {
+                int sign = 0;
+                if (remaining_bits >= 1 << BITRES) {
+                    sign = (int)rc_bits(rc, 1);
+                    remaining_bits -= 1 << BITRES;
+                }
+                S.v[c ? y : x] = (i16)(sign ? -16384 : 16384);
+            }
+            if (out1 >= 0) S.v[out1] = (i16)(S.v[x] >> 4);
+            if (dual_stereo && out2 >= 0) S.v[out2] = (i16)(S.v[y] >> 4);
+            x_cm = y_cm = 1;
         } else {
-            if (y >= 0)
-                x_cm = band_stereo(rc, cx, x, y, N, b, B, low1, LM, out1, low_scratch, (i32)(x_cm | y_cm));
-            else
-                x_cm = band_mono(rc, cx, x, N, b, B, low1, LM, out1, 32767, low_scratch, (i32)(x_cm | y_cm));
-            y_cm = x_cm;
+            // ---- set up one or two "mono band" jobs
+            const int stereo = (y >= 0) && !dual_stereo;
+            Split sc;
+            sc.inv = 0; sc.imid = 0; sc.iside = 0; sc.delta = 0; sc.itheta = 0; sc.qalloc = 0;
+            i32 bb = b, fill0 = (i32)(x_cm | y_cm), orig_fill = fill0;
+            i32 mbits = 0, sbits = 0, rebal0 = 0;
+            int n2case = 0, swap_c = 0, sign = 1, mid_first = 1, njobs = 1;
+            if (stereo) {
+                compute_theta(rc, i, intensity, disable_inv, remaining_bits, sc, N, bb, B, B, LM, 1, fill0);
+                if (N == 2) {
+                    n2case = 1;
+                    mbits = bb;
+                    sbits = 0;
+                    if (sc.itheta != 0 && sc.itheta != 16384) sbits = 1 << BITRES;
+                    mbits -= sbits;
+                    swap_c = sc.itheta > 8192;
+                    remaining_bits -= sc.qalloc + sbits;
+                    int sg = 0;
+                    if (sbits) sg = (int)rc_bits(rc, 1);
+                    sign = 1 - 2 * sg;
+                } else {
+                    mbits = OG_MAX(0, OG_MIN(bb, (bb - sc.delta) / 2));
+                    sbits = bb - mbits;
+                    remaining_bits -= sc.qalloc;
+                    rebal0 = remaining_bits;
+                    mid_first = mbits >= sbits;
+                    njobs = 2;
+                }
+            } else if (dual_stereo)
+                njobs = 2;
+            u32 cm0 = 0, cm1 = 0;
+            for (int jb = 0; jb < njobs; jb++) {
+                int jx, jlow, jout, jscr;
+                i32 jb_bits, jgain, jfill;
+                if (dual_stereo) {
+                    jx = jb ? y : x; jlow = jb ? low2 : low1; jout = jb ? out2 : out1; jscr = low_scratch;
+                    jb_bits = b / 2; jgain = 32767; jfill = (i32)(jb ? y_cm : x_cm);
+                } else if (!stereo) {
+                    jx = x; jlow = low1; jout = out1; jscr = low_scratch; jb_bits = b; jgain = 32767; jfill = fill0;
+                } else if (n2case) {
+                    jx = swap_c ? y : x; jlow = low1; jout = out1; jscr = low_scratch; jb_bits = mbits; jgain = 32767; jfill = orig_fill;
+                } else {
+                    const int is_mid = (jb == 0) == (mid_first != 0);
+                    if (jb == 1) { // rebalance between the two halves (celt.cpp:1711-1724)
+                        i32 rebalance = (mid_first ? mbits : sbits) - (rebal0 - remaining_bits);
+                        if (mid_first) {
+                            if (rebalance > 3 << BITRES && sc.itheta != 0) sbits += rebalance - (3 << BITRES);
+                        } else {
+                            if (rebalance > 3 << BITRES && sc.itheta != 16384) mbits += rebalance - (3 << BITRES);
+                        }
+                    }
+                    if (is_mid) {
+                        jx = x; jlow = low1; jout = out1; jscr = low_scratch; jb_bits = mbits; jgain = 32767; jfill = fill0;
+                    } else {
+                        jx = y; jlow = -1; jout = -1; jscr = -1; jb_bits = sbits; jgain = sc.iside; jfill = fill0 >> B;
+                    }
+                }
+                const u32 cmj = band_mono(rc, T, i, spread, tf_change, seed, remaining_bits, jx, N, jb_bits, B, jlow, LM, jout, jgain,
+                                          jscr, jfill);
+                if (jb == 0) cm0 = cmj; else cm1 = cmj;
+            }
+            if (stereo) {
+                if (n2case) { // N == 2: the side is the mid rotated by 90 degrees (celt.cpp:1659-1697)
+                    const int x2 = swap_c ? y : x;
+                    OG_SYNC();
+                    const i32 a0 = S.v[x2], a1 = S.v[x2 + 1];
+                    const i32 b0 = tr16(-sign * a1), b1 = tr16(sign * a0);
+                    i32 X0 = swap_c ? b0 : a0, X1 = swap_c ? b1 : a1, Y0 = swap_c ? a0 : b0, Y1 = swap_c ? a1 : b1;
+                    X0 = tr16(mul16_q15(sc.imid, X0));
+                    X1 = tr16(mul16_q15(sc.imid, X1));
+                    Y0 = tr16(mul16_q15(sc.iside, Y0));
+                    Y1 = tr16(mul16_q15(sc.iside, Y1));
+                    OG_SYNC();
+                    S.v[x] = (i16)sub16(X0, Y0);
+                    S.v[y] = (i16)add16(X0, Y0);
+                    S.v[x + 1] = (i16)sub16(X1, Y1);
+                    S.v[y + 1] = (i16)add16(X1, Y1);
+                    OG_SYNC();
+                } else
+                    stereo_merge(x, y, sc.imid, N);
+                if (sc.inv) {
+                    OG_SYNC();
+                    OG_FOR_LANES(j, N) S.v[y + j] = (i16)(-S.v[y + j]);
+                    OG_SYNC();
+                }
+                x_cm = y_cm = cm0 | cm1;
+            } else if (dual_stereo) { // collapse masks are per channel
+                x_cm = cm0;
+                y_cm = cm1;
+            } else
+                x_cm = y_cm = cm0;
         }
         S.cmask[i * C + 0] = (u8)x_cm;
         S.cmask[i * C + C - 1] = (u8)y_cm;
-        balance += S.pulses[i] + tell;
+        balance += pulses_i + tell;
         update_lowband = b > (N << BITRES);
     }
-    seed = cx.seed;
+    seed_io = seed;
 }
 
 // anti_collapse celt.cpp:1010 (transient frames only).  The noise for a collapsed short block k of a
 // band goes to X[(j<<LM)+k]; the LCG is stepped once per written sample, in (band, channel, k, j) order.
-OG_DEVN void anti_collapse(int LM, int C, int size, int start, int end, u32 seed) {
+OG_DEV void anti_collapse(int LM, int C, int size, int start, int end, u32 seed) {
     for (int i = start; i < end; i++) {
         int N0 = rom_eband[i + 1] - rom_eband[i];
         int depth = (int)(udiv((u32)(1 + S.pulses[i]), (u32)N0) >> LM);

@@ -114,75 +114,4 @@ OG_DEV u32 lcg_skip(u32 s, u32 n) {
     return ra * s + rc;
 }
 
-// ---- PVQ ------------------------------------------------------------------------------------------
-// U(n,k) is symmetric; the generated table is dense [15][177] so U(min,max) is always addressable.
-OG_DEV u32 pvq_u(int a, int b) {
-    int lo = a < b ? a : b, hi = a < b ? b : a;
-    return rom_pvq_u[lo * ROM_PVQ_COLS + hi];
-}
-OG_DEV u32 pvq_v(int n, int k) { return pvq_u(n, k) + pvq_u(n, k + 1); } // CELT_PVQ_V celt.cpp:660
-
-// Codeword index -> signed pulse vector in S.v[V_IY ...]; returns sum of squares (cwrsi celt.cpp:2545).
-// Serial by nature (each dimension's pulse count depends on the remaining index): wave-uniform.
-OG_DEVN i32 pvq_decode_index(int n, int k, u32 i) {
-    int pos = V_IY;
-    i32 yy = 0;
-    while (n > 2) {
-        u32 p, q;
-        int s, k0;
-        if (k >= n) {
-            p = pvq_u(n, k + 1);
-            s = -(int)(i >= p);
-            i -= p & (u32)s;
-            k0 = k;
-            q = pvq_u(n, n);
-            if (q > i) {
-                k = n;
-                do p = pvq_u(--k, n);
-                while (p > i);
-            } else {
-                for (p = pvq_u(n, k); p > i; p = pvq_u(n, k)) k--;
-            }
-            i -= p;
-            int val = tr16((k0 - k + s) ^ s);
-            S.v[pos++] = (i16)val;
-            yy += val * val;
-        } else {
-            p = pvq_u(k, n);
-            q = pvq_u(k + 1, n);
-            if (p <= i && i < q) {
-                i -= p;
-                S.v[pos++] = 0;
-            } else {
-                s = -(int)(i >= q);
-                i -= q & (u32)s;
-                k0 = k;
-                do p = pvq_u(--k, n);
-                while (p > i);
-                i -= p;
-                int val = tr16((k0 - k + s) ^ s);
-                S.v[pos++] = (i16)val;
-                yy += val * val;
-            }
-        }
-        n--;
-    }
-    {
-        u32 p = 2 * (u32)k + 1;
-        int s = -(int)(i >= p);
-        i -= p & (u32)s;
-        int k0 = k;
-        k = (int)((i + 1) >> 1);
-        if (k) i -= 2 * (u32)k - 1;
-        int val = tr16((k0 - k + s) ^ s);
-        S.v[pos++] = (i16)val;
-        yy += val * val;
-        s = -(int)i;
-        val = tr16((k + s) ^ s);
-        S.v[pos] = (i16)val;
-        yy += val * val;
-    }
-    return yy;
-}
-
 } // namespace og

@@ -27,9 +27,12 @@ typedef uint64_t u64;
 #include <string.h>
 #define OG_DEV static inline
 #define OG_DEVN static
+#define OG_MEMBER inline
 #define OG_LANE 0
 #define OG_NLANES 1
 #define OG_SYNC() ((void)0)
+#define OG_FULL_SYNC() ((void)0)
+#define OG_LSYNC() ((void)0)
 #define OG_LDS static
 #define OPUS_ROM static const
 #define OG_CLZ(x) __builtin_clz(x)
@@ -39,9 +42,23 @@ extern "C" void og_emul_tap(int id); // stage taps for parity tests (host emulat
 #include <hip/hip_runtime.h>
 #define OG_DEV static __device__ __forceinline__
 #define OG_DEVN static __device__ __noinline__
+#define OG_MEMBER __device__ __forceinline__
 #define OG_LANE ((int)threadIdx.x)
 #define OG_NLANES 64
-#define OG_SYNC() __syncthreads()
+#define OG_FULL_SYNC() __syncthreads()
+// LDS-only ordering between lanes of ONE wave: the LDS unit serves a wave's instructions in order, so only the
+// compiler has to be kept from moving LDS accesses across the point (no s_barrier, no s_waitcnt).
+#ifdef OG_LIGHT_SYNC
+#define OG_LSYNC()                                    \
+    do {                                              \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();              \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+#else
+#define OG_LSYNC() __syncthreads()
+#endif
+#define OG_SYNC() OG_FULL_SYNC()
 #define OG_LDS __shared__
 #define OPUS_ROM static __device__ const
 #define OG_CLZ(x) __clz(x)
@@ -113,15 +130,34 @@ OG_DEV int clz32(i32 x) { return x ? OG_CLZ((u32)x) : 32; }                     
 
 // ---- wave-level helpers ---------------------------------------------------------------------------
 // Sum / OR over the 64 lanes, result in every lane.  (Host emulation: one lane, identity.)
+// Must be called with all 64 lanes active.  Four DPP row rotations (ror 8/4/2/1) leave the sum of each
+// 16-lane row in all of its lanes; the four row sums are then combined on the scalar unit, so the result
+// is a wave-uniform (SGPR) value.
+#ifndef OG_HOST_EMUL
+#define OG_DPP_ROR(v, n) __builtin_amdgcn_update_dpp(0, (int)(v), 0x120 + (n), 0xf, 0xf, false)
+#define OG_UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
+#else
+#define OG_UNI(x) ((int)(x))
+#endif
 OG_DEV i32 wave_sum(i32 v) {
 #ifndef OG_HOST_EMUL
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v += OG_DPP_ROR(v, 8);
+    v += OG_DPP_ROR(v, 4);
+    v += OG_DPP_ROR(v, 2);
+    v += OG_DPP_ROR(v, 1);
+    v = __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+        __builtin_amdgcn_readlane(v, 48);
 #endif
     return v;
 }
 OG_DEV u32 wave_or(u32 v) {
 #ifndef OG_HOST_EMUL
-    for (int off = 32; off > 0; off >>= 1) v |= (u32)__shfl_xor((int)v, off, 64);
+    v |= (u32)OG_DPP_ROR(v, 8);
+    v |= (u32)OG_DPP_ROR(v, 4);
+    v |= (u32)OG_DPP_ROR(v, 2);
+    v |= (u32)OG_DPP_ROR(v, 1);
+    v = (u32)(__builtin_amdgcn_readlane((int)v, 0) | __builtin_amdgcn_readlane((int)v, 16) |
+              __builtin_amdgcn_readlane((int)v, 32) | __builtin_amdgcn_readlane((int)v, 48));
 #endif
     return v;
 }

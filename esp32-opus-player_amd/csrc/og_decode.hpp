@@ -57,7 +57,11 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
         if (prev_mode == MODE_CELT) silk_init_state(&st->silk);
         int internal_hz = 16000;
         if (mode == MODE_SILK) internal_hz = bandwidth == BW_NB ? 8000 : (bandwidth == BW_MB ? 12000 : 16000);
-        int ret = silk_decode_20ms(&st->silk, rc, ch, internal_hz); // fills S.pcm_silk (48 kHz, interleaved)
+        // SILK is compiled out of line and takes the range decoder by reference: hand it a copy, so that the
+        // decoder state used by the (inlined) CELT path never has its address taken and stays in registers.
+        Rc rcs = rc;
+        int ret = silk_decode_20ms(&st->silk, rcs, ch, internal_hz); // fills S.pcm_silk (48 kHz, interleaved)
+        rc = rcs;
         if (ret) return INTERNAL_ERROR;
     }
 #else
@@ -70,21 +74,31 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
     if (mode != MODE_CELT) start_band = 17;
     const int disable_inv = CC == 1;
 
+    // One CELT call site (the whole CELT decoder is inlined into it): the regular frame, or -- Q4 -- the 2.5 ms
+    // frame the reference decodes from the live range decoder on a hybrid -> SILK-only transition.
+    int do_celt = 0, celt_n = audiosize, celt_start = start_band;
     if (mode != MODE_SILK) {
         if (mode != prev_mode && prev_mode > 0) {
             celt_reset_state(&st->celt);
             OG_SYNC();
         }
-        celt_ret = celt_decode_frame(&st->celt, rc, audiosize, ch, CC, start_band, disable_inv);
+        do_celt = 1;
     } else {
         OG_SYNC();
         OG_FOR_LANES(i, audiosize * CC) S.v[V_X + i] = 0;
         OG_SYNC();
-        if (prev_mode == MODE_HYBRID) { // Q4: 2.5 ms CELT frame from the live range decoder, start band 0
-            // writes 120*CC samples at the head of the PCM staging area; the rest stays zero.  The
-            // reference ignores the return value here (src/opus_decoder.cpp:267).
-            (void)celt_decode_frame(&st->celt, rc, 120, ch, CC, 0, disable_inv);
-            // the CELT working vectors share the staging area: clear everything past the 120 decoded samples
+        if (prev_mode == MODE_HYBRID) { // Q4: start band 0, 120*CC samples at the head of the PCM staging area
+            do_celt = 1;
+            celt_n = 120;
+            celt_start = 0;
+        }
+    }
+    if (do_celt) {
+        const int r = celt_decode_frame(&st->celt, rc, celt_n, ch, CC, celt_start, disable_inv);
+        if (mode != MODE_SILK)
+            celt_ret = r;
+        else { // the reference ignores the return value here (src/opus_decoder.cpp:267); the CELT working vectors
+               // share the staging area: clear everything past the 120 decoded samples
             OG_SYNC();
             OG_FOR_LANES(i, (audiosize - 120) * CC) S.v[V_X + 120 * CC + i] = 0;
             OG_SYNC();

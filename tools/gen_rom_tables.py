@@ -230,6 +230,13 @@ def build_text():
     t += "#ifndef OPUS_ROM\n#define OPUS_ROM static const\n#endif\n\n"
     t += "#define ROM_PVQ_COLS 177\n"
     t += emit("rom_pvq_u", "uint32_t", pvq_u_table(), 8)
+    # the same table padded to 16 rows x 192 columns: lane l of register (row, seg) holds U(row, 64*seg + l)
+    u = pvq_u_table()
+    u192 = []
+    for r in range(16):
+        for c in range(192):
+            u192.append(u[r * 177 + c] if (r < 15 and c < 177) else 0)
+    t += emit("rom_pvq_u192", "uint32_t", u192, 8)
     t += emit("rom_band_alloc", "uint8_t", BAND_ALLOC, 21)
     t += emit("rom_eband", "int16_t", EBAND, 22)
     t += emit("rom_logn", "int16_t", LOGN, 21)
