@@ -32,18 +32,43 @@ __global__ void __launch_bounds__(64) k_stream_init(StreamState *st, int first, 
 #endif
 __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
                                                    StreamState *st, i16 *pcm, i32 *result, int n, int n_streams,
-                                                   int pcm_stride) {
+                                                   int pcm_stride, int skip_celt) {
     const int f = (int)blockIdx.x;
     if (f >= n) return;
     const FrameDesc d = descs[f];
     int ret;
     if (d.stream < 0 || d.stream >= n_streams) {
         ret = BAD_ARG;
+    } else if (skip_celt && desc_mode(d.flags) == MODE_CELT) {
+        return; // CELT-only frames take the split path (k_celt_parse + k_celt_recon)
     } else {
         StreamState *s = &st[d.stream];
         ret = decode_frame_wave(s, arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
                                 desc_channels(d.flags), pcm + (size_t)f * pcm_stride);
     }
+    if (threadIdx.x == 0) result[f] = ret;
+}
+
+// Split CELT path, first half: ONE FRAME PER LANE.  Lane l of workgroup g parses frame 64 g + l (range decoder,
+// energies, allocation, band budget logic, PVQ indices) into recs[frame]; no vector work, no cross-lane traffic.
+__global__ void __launch_bounds__(64, 2) k_celt_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
+                                                      const StreamState *st, ParseRec *recs, int n, int n_streams) {
+    const int f = (int)blockIdx.x * 64 + (int)threadIdx.x;
+    if (f >= n) return;
+    const FrameDesc d = descs[f];
+    if (d.stream < 0 || d.stream >= n_streams || desc_mode(d.flags) != MODE_CELT) return;
+    celt_parse_lane(&st[d.stream], arena + d.offset, d.len, desc_channels(d.flags), &recs[f]);
+}
+
+// Split CELT path, second half: one frame per wave, driven by the parse record.
+__global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_celt_recon(const FrameDesc *__restrict__ descs, StreamState *st,
+                                                                      const ParseRec *recs, i16 *pcm, i32 *result, int n,
+                                                                      int n_streams, int pcm_stride) {
+    const int f = (int)blockIdx.x;
+    if (f >= n) return;
+    const FrameDesc d = descs[f];
+    if (d.stream < 0 || d.stream >= n_streams || desc_mode(d.flags) != MODE_CELT) return;
+    const int ret = celt_recon_wave(&st[d.stream], &recs[f], MODE_CELT, desc_channels(d.flags), pcm + (size_t)f * pcm_stride);
     if (threadIdx.x == 0) result[f] = ret;
 }
 
@@ -56,6 +81,10 @@ struct opusgpu_ctx {
     // staging for the host-buffer path
     void *d_descs = nullptr, *d_arena = nullptr, *d_pcm = nullptr, *d_result = nullptr;
     size_t cap_descs = 0, cap_arena = 0, cap_pcm = 0, cap_result = 0;
+    // parse records of the split CELT path (one per frame of a step), grown on demand
+    void *d_recs = nullptr;
+    size_t cap_recs = 0;
+    int split_celt = 1; // OPUSGPU_SPLIT=0 forces the single-kernel path for every mode (A/B measurements)
     char err[256] = {0};
 };
 
@@ -70,6 +99,8 @@ static int fail(opusgpu_ctx *ctx, int code, const char *what, hipError_t e) {
     } while (0)
 
 extern "C" {
+
+static int grow(opusgpu_ctx *ctx, void **p, size_t *cap, size_t need);
 
 int opusgpu_version(void) { return 100; }
 
@@ -88,6 +119,7 @@ int opusgpu_ctx_create(int device, opusgpu_ctx **out) {
     opusgpu_ctx *ctx = new (std::nothrow) opusgpu_ctx();
     if (!ctx) return OPUSGPU_ALLOC_FAIL;
     ctx->device = device;
+    if (const char *e = getenv("OPUSGPU_SPLIT")) ctx->split_celt = e[0] != '0';
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return OPUSGPU_ERR_HIP;
@@ -105,6 +137,7 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     (void)hipFree(ctx->d_arena);
     (void)hipFree(ctx->d_pcm);
     (void)hipFree(ctx->d_result);
+    (void)hipFree(ctx->d_recs);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -175,9 +208,23 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
     if (n == 0) return OPUSGPU_OK;
     if (!d_descs || !d_arena || !d_pcm || !d_result) return OPUSGPU_BAD_ARG;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    const int pcm_stride = OPUSGPU_FRAME_SAMPLES * ctx->channels;
+    if (ctx->split_celt) {
+        // CELT-only frames: parse (one frame per lane) -> records in HBM -> reconstruct (one frame per wave).
+        // The records buffer only grows; growing it frees the old one, which waits for the device to go idle.
+        if (ctx->cap_recs < sizeof(ParseRec) * (size_t)n) {
+            HIPCHK(ctx, hipSetDevice(ctx->device));
+            const int rc = grow(ctx, &ctx->d_recs, &ctx->cap_recs, sizeof(ParseRec) * (size_t)n);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_celt_parse, dim3((n + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
+                           (const StreamState *)ctx->d_streams, (ParseRec *)ctx->d_recs, n, ctx->n_streams);
+        hipLaunchKernelGGL(k_celt_recon, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, ctx->d_streams,
+                           (const ParseRec *)ctx->d_recs, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride);
+    }
+    // every other mode (and stream-index errors): the single-kernel path
     hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
-                       ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams,
-                       OPUSGPU_FRAME_SAMPLES * ctx->channels);
+                       ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, ctx->split_celt);
     HIPCHK(ctx, hipGetLastError());
     return OPUSGPU_OK;
 }

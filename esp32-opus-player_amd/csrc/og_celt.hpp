@@ -15,10 +15,28 @@
 
 namespace og {
 
+// Working arrays of one frame.  The energy / allocation code below is written once against these accessors and
+// used by both execution shapes: wave-uniform (arrays in the wave's LDS record S; frame-per-wave path) and
+// lane-private (one frame per LANE in the parse kernel, og_celt_parse.hpp).
+struct WaveArr {
+    OG_MEMBER i32 &pulses(int i) const { return S.pulses[i]; }
+    OG_MEMBER i32 &fine_quant(int i) const { return S.fine_quant[i]; }
+    OG_MEMBER i32 &fine_prio(int i) const { return S.fine_prio[i]; }
+    OG_MEMBER i32 &tf_res(int i) const { return S.tf_res[i]; }
+    OG_MEMBER i32 &cap(int i) const { return S.cap[i]; }
+    OG_MEMBER i32 &offsets(int i) const { return S.offsets[i]; }
+    OG_MEMBER i32 &bits1(int i) const { return S.bits1[i]; }
+    OG_MEMBER i32 &bits2(int i) const { return S.bits2[i]; }
+    OG_MEMBER i32 &thresh(int i) const { return S.thresh[i]; }
+    OG_MEMBER i32 &trim_off(int i) const { return S.trim_off[i]; }
+    OG_MEMBER i16 &bandE(int i) const { return S.bandE[i]; }
+};
+
 // ---- energies (src/celt.cpp:3613-3700) ------------------------------------------------------------
-OG_DEV void coarse_energy(Rc &rc, int start, int end, int intra, int C, int LM) {
+template <class A, class R>
+OG_DEV void coarse_energy(A a, R &rc, int start, int end, int intra, int C, int LM) {
     const u8 *pm = rom_eprob + (LM * 2 + intra) * 42;
-    i32 prev[2] = {0, 0};
+    i32 prev0 = 0, prev1 = 0; // inter-band prediction per channel
     i32 coef, beta;
     if (intra) {
         coef = 0;
@@ -53,35 +71,39 @@ OG_DEV void coarse_energy(Rc &rc, int start, int end, int intra, int C, int LM) 
             } else
                 qi = -1;
             i32 q = shl32(qi, 10);
-            i32 e = OG_MAX(-9 * 1024, (i32)S.bandE[i + c * NBANDS]);
-            i32 tmp = pshr32(mul16(coef, e), 8) + prev[c] + shl32(q, 7);
+            i32 e = OG_MAX(-9 * 1024, (i32)a.bandE(i + c * NBANDS));
+            const i32 pv = c ? prev1 : prev0;
+            i32 tmp = pshr32(mul16(coef, e), 8) + pv + shl32(q, 7);
             tmp = OG_MAX(-(28 << 17), tmp);
-            S.bandE[i + c * NBANDS] = (i16)pshr32(tmp, 7);
-            prev[c] = prev[c] + shl32(q, 7) - mul16(beta, pshr32(q, 8));
+            a.bandE(i + c * NBANDS) = (i16)pshr32(tmp, 7);
+            const i32 nv = pv + shl32(q, 7) - mul16(beta, pshr32(q, 8));
+            if (c) prev1 = nv; else prev0 = nv;
         }
     }
 }
 
-OG_DEV void fine_energy(Rc &rc, int start, int end, int C) {
+template <class A, class R>
+OG_DEV void fine_energy(A a, R &rc, int start, int end, int C) {
     for (int i = start; i < end; i++) {
-        int fq = S.fine_quant[i];
+        int fq = a.fine_quant(i);
         if (fq <= 0) continue;
         for (int c = 0; c < C; c++) {
             i32 q2 = (i32)rc_bits(rc, fq);
             i32 offset = tr16(sub16((shl32(q2, 10) + 512) >> fq, 512));
-            S.bandE[i + c * NBANDS] = (i16)(S.bandE[i + c * NBANDS] + offset);
+            a.bandE(i + c * NBANDS) = (i16)(a.bandE(i + c * NBANDS) + offset);
         }
     }
 }
 
-OG_DEV void energy_finalise(Rc &rc, int start, int end, int bits_left, int C) {
+template <class A, class R>
+OG_DEV void energy_finalise(A a, R &rc, int start, int end, int bits_left, int C) {
     for (int prio = 0; prio < 2; prio++) {
         for (int i = start; i < end && bits_left >= C; i++) {
-            if (S.fine_quant[i] >= 8 || S.fine_prio[i] != prio) continue;
+            if (a.fine_quant(i) >= 8 || a.fine_prio(i) != prio) continue;
             for (int c = 0; c < C; c++) {
                 i32 q2 = (i32)rc_bits(rc, 1);
-                i32 offset = tr16((shl16(q2, 10) - 512) >> (S.fine_quant[i] + 1));
-                S.bandE[i + c * NBANDS] = (i16)(S.bandE[i + c * NBANDS] + offset);
+                i32 offset = tr16((shl16(q2, 10) - 512) >> (a.fine_quant(i) + 1));
+                a.bandE(i + c * NBANDS) = (i16)(a.bandE(i + c * NBANDS) + offset);
                 bits_left--;
             }
         }
@@ -97,7 +119,8 @@ OG_DEV int tf_select(int LM, int idx) {
     return v >= 8 ? v - 16 : v;
 }
 
-OG_DEV void tf_decode(Rc &rc, int start, int end, int transient, int LM) { // celt.cpp:2128
+template <class A, class R>
+OG_DEV void tf_decode(A a, R &rc, int start, int end, int transient, int LM) { // celt.cpp:2128
     int curr = 0, tf_sel = 0, tf_changed = 0;
     int logp = transient ? 2 : 4;
     u32 budget = rc.storage * 8, tell = (u32)rc_tell(rc);
@@ -109,16 +132,17 @@ OG_DEV void tf_decode(Rc &rc, int start, int end, int transient, int LM) { // ce
             tell = (u32)rc_tell(rc);
             tf_changed |= curr;
         }
-        S.tf_res[i] = curr;
+        a.tf_res(i) = curr;
         logp = transient ? 4 : 5;
     }
     if (rsv && tf_select(LM, 4 * transient + 0 + tf_changed) != tf_select(LM, 4 * transient + 2 + tf_changed))
         tf_sel = rc_bit_logp(rc, 1);
-    for (int i = start; i < end; i++) S.tf_res[i] = tf_select(LM, 4 * transient + 2 * tf_sel + S.tf_res[i]);
+    for (int i = start; i < end; i++) a.tf_res(i) = tf_select(LM, 4 * transient + 2 * tf_sel + a.tf_res(i));
 }
 
 // ---- bit allocation (clt_compute_allocation celt.cpp:3523, interp_bits2pulses :3298) ----------------
-OG_DEV int compute_allocation(Rc &rc, int start, int end, int alloc_trim, i32 &intensity, i32 &dual_stereo, i32 total,
+template <class A, class R>
+OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i32 &intensity, i32 &dual_stereo, i32 total,
                                i32 &balance_out, int C, int LM) {
     const i32 *eb = rom_eband;
     int skip_start = start, intensity_rsv = 0, dual_stereo_rsv = 0;
@@ -137,10 +161,10 @@ OG_DEV int compute_allocation(Rc &rc, int start, int end, int alloc_trim, i32 &i
     }
     for (int j = start; j < end; j++) {
         int w = eb[j + 1] - eb[j];
-        S.thresh[j] = OG_MAX(C << BITRES, (3 * w << LM << BITRES) >> 4);
+        a.thresh(j) = OG_MAX(C << BITRES, (3 * w << LM << BITRES) >> 4);
         i32 to = C * w * (alloc_trim - 5 - LM) * (end - j - 1) * (1 << (LM + BITRES)) >> 6;
         if (w << LM == 1) to -= C << BITRES;
-        S.trim_off[j] = to;
+        a.trim_off(j) = to;
     }
     int lo = 1, hi = 10;
     do {
@@ -149,11 +173,11 @@ OG_DEV int compute_allocation(Rc &rc, int start, int end, int alloc_trim, i32 &i
         for (int j = end; j-- > start;) {
             int w = eb[j + 1] - eb[j];
             i32 bitsj = C * w * rom_band_alloc[mid * NBANDS + j] << LM >> 2;
-            if (bitsj > 0) bitsj = OG_MAX(0, bitsj + S.trim_off[j]);
-            bitsj += S.offsets[j];
-            if (bitsj >= S.thresh[j] || done) {
+            if (bitsj > 0) bitsj = OG_MAX(0, bitsj + a.trim_off(j));
+            bitsj += a.offsets(j);
+            if (bitsj >= a.thresh(j) || done) {
                 done = 1;
-                psum += OG_MIN(bitsj, S.cap[j]);
+                psum += OG_MIN(bitsj, a.cap(j));
             } else if (bitsj >= C << BITRES)
                 psum += C << BITRES;
         }
@@ -163,25 +187,16 @@ OG_DEV int compute_allocation(Rc &rc, int start, int end, int alloc_trim, i32 &i
     for (int j = start; j < end; j++) {
         int w = eb[j + 1] - eb[j];
         i32 b1 = C * w * rom_band_alloc[lo * NBANDS + j] << LM >> 2;
-        i32 b2 = hi >= 11 ? S.cap[j] : C * w * rom_band_alloc[hi * NBANDS + j] << LM >> 2;
-        if (b1 > 0) b1 = OG_MAX(0, b1 + S.trim_off[j]);
-        if (b2 > 0) b2 = OG_MAX(0, b2 + S.trim_off[j]);
-        if (lo > 0) b1 += S.offsets[j];
-        b2 += S.offsets[j];
-        if (S.offsets[j] > 0) skip_start = j;
+        i32 b2 = hi >= 11 ? a.cap(j) : C * w * rom_band_alloc[hi * NBANDS + j] << LM >> 2;
+        if (b1 > 0) b1 = OG_MAX(0, b1 + a.trim_off(j));
+        if (b2 > 0) b2 = OG_MAX(0, b2 + a.trim_off(j));
+        if (lo > 0) b1 += a.offsets(j);
+        b2 += a.offsets(j);
+        if (a.offsets(j) > 0) skip_start = j;
         b2 = OG_MAX(0, b2 - b1);
-        S.bits1[j] = b1;
-        S.bits2[j] = b2;
+        a.bits1(j) = b1;
+        a.bits2(j) = b2;
     }
-#ifdef OG_DUMP1
-    for (int j = 0; j < NBANDS; j++) {
-        S.v[V_X + 300 + j] = (i16)S.thresh[j]; S.v[V_X + 332 + j] = (i16)S.trim_off[j];
-        S.v[V_X + 364 + j] = (i16)S.bits1[j]; S.v[V_X + 396 + j] = (i16)S.bits2[j];
-    }
-    S.v[V_X + 428] = (i16)total; S.v[V_X + 429] = (i16)lo; S.v[V_X + 430] = (i16)hi; S.v[V_X + 431] = (i16)skip_start;
-    S.v[V_X + 432] = (i16)intensity_rsv; S.v[V_X + 433] = (i16)dual_stereo_rsv; S.v[V_X + 434] = (i16)skip_rsv; S.v[V_X+435]=(i16)alloc_trim;
-    S.v[V_X + 436] = (i16)rom_band_alloc[5 * NBANDS + 3]; S.v[V_X + 437] = (i16)rom_log2_frac[21]; S.v[V_X+438]=(i16)rom_eband[21];
-#endif
     // ---- interpolation between the two allocation vectors
     const int alloc_floor = C << BITRES, stereo = C > 1, logM = LM << BITRES;
     i32 psum;
@@ -191,10 +206,10 @@ OG_DEV int compute_allocation(Rc &rc, int start, int end, int alloc_trim, i32 &i
         int mid = (lo + hi) >> 1, done = 0;
         psum = 0;
         for (int j = end; j-- > start;) {
-            i32 tmp = S.bits1[j] + (mid * S.bits2[j] >> 6);
-            if (tmp >= S.thresh[j] || done) {
+            i32 tmp = a.bits1(j) + (mid * a.bits2(j) >> 6);
+            if (tmp >= a.thresh(j) || done) {
                 done = 1;
-                psum += OG_MIN(tmp, S.cap[j]);
+                psum += OG_MIN(tmp, a.cap(j));
             } else if (tmp >= alloc_floor)
                 psum += alloc_floor;
         }
@@ -204,13 +219,13 @@ OG_DEV int compute_allocation(Rc &rc, int start, int end, int alloc_trim, i32 &i
     {
         int done = 0;
         for (int j = end; j-- > start;) {
-            i32 tmp = S.bits1[j] + (lo * S.bits2[j] >> 6);
-            if (tmp < S.thresh[j] && !done)
+            i32 tmp = a.bits1(j) + (lo * a.bits2(j) >> 6);
+            if (tmp < a.thresh(j) && !done)
                 tmp = tmp >= alloc_floor ? alloc_floor : 0;
             else
                 done = 1;
-            tmp = OG_MIN(tmp, S.cap[j]);
-            S.pulses[j] = tmp;
+            tmp = OG_MIN(tmp, a.cap(j));
+            a.pulses(j) = tmp;
             psum += tmp;
         }
     }
@@ -226,20 +241,20 @@ OG_DEV int compute_allocation(Rc &rc, int start, int end, int alloc_trim, i32 &i
         left -= (eb[codedBands] - eb[start]) * percoeff;
         i32 rem = OG_MAX(left - (eb[j] - eb[start]), 0);
         i32 band_width = eb[codedBands] - eb[j];
-        i32 band_bits = S.pulses[j] + percoeff * band_width + rem;
-        if (band_bits >= OG_MAX(S.thresh[j], alloc_floor + (1 << BITRES))) {
+        i32 band_bits = a.pulses(j) + percoeff * band_width + rem;
+        if (band_bits >= OG_MAX(a.thresh(j), alloc_floor + (1 << BITRES))) {
             if (rc_bit_logp(rc, 1)) break;
             psum += 1 << BITRES;
             band_bits -= 1 << BITRES;
         }
-        psum -= S.pulses[j] + intensity_rsv;
+        psum -= a.pulses(j) + intensity_rsv;
         if (intensity_rsv > 0) intensity_rsv = rom_log2_frac[j - start];
         psum += intensity_rsv;
         if (band_bits >= alloc_floor) {
             psum += alloc_floor;
-            S.pulses[j] = alloc_floor;
+            a.pulses(j) = alloc_floor;
         } else
-            S.pulses[j] = 0;
+            a.pulses(j) = 0;
     }
     if (intensity_rsv > 0)
         intensity = start + (i32)rc_uint(rc, codedBands + 1 - start);
@@ -254,19 +269,19 @@ OG_DEV int compute_allocation(Rc &rc, int start, int end, int alloc_trim, i32 &i
     i32 left = total - psum;
     i32 percoeff = (i32)udiv((u32)left, (u32)(eb[codedBands] - eb[start]));
     left -= (eb[codedBands] - eb[start]) * percoeff;
-    for (int j = start; j < codedBands; j++) S.pulses[j] += percoeff * (eb[j + 1] - eb[j]);
+    for (int j = start; j < codedBands; j++) a.pulses(j) += percoeff * (eb[j + 1] - eb[j]);
     for (int j = start; j < codedBands; j++) {
         i32 tmp = OG_MIN(left, (i32)(eb[j + 1] - eb[j]));
-        S.pulses[j] += tmp;
+        a.pulses(j) += tmp;
         left -= tmp;
     }
     i32 balance = 0;
     int j;
     for (j = start; j < codedBands; j++) {
         i32 N0 = eb[j + 1] - eb[j], N = N0 << LM, excess;
-        i32 bit = S.pulses[j] + balance, bj, ej, fp;
+        i32 bit = a.pulses(j) + balance, bj, ej, fp;
         if (N > 1) {
-            excess = OG_MAX(bit - S.cap[j], 0);
+            excess = OG_MAX(bit - a.cap(j), 0);
             bj = bit - excess;
             i32 den = C * N + ((C == 2 && N > 2 && !dual_stereo && j < intensity) ? 1 : 0);
             i32 NClogN = den * (rom_logn[j] + logM);
@@ -296,16 +311,16 @@ OG_DEV int compute_allocation(Rc &rc, int start, int end, int alloc_trim, i32 &i
             excess -= extra_bits;
         }
         balance = excess;
-        S.pulses[j] = bj;
-        S.fine_quant[j] = ej;
-        S.fine_prio[j] = fp;
+        a.pulses(j) = bj;
+        a.fine_quant(j) = ej;
+        a.fine_prio(j) = fp;
     }
     balance_out = balance;
     for (; j < end; j++) {
-        i32 ej = S.pulses[j] >> stereo >> BITRES;
-        S.fine_quant[j] = ej;
-        S.pulses[j] = 0;
-        S.fine_prio[j] = ej < 1;
+        i32 ej = a.pulses(j) >> stereo >> BITRES;
+        a.fine_quant(j) = ej;
+        a.pulses(j) = 0;
+        a.fine_prio(j) = ej < 1;
     }
     return codedBands;
 }
@@ -594,55 +609,17 @@ OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, in
     OG_SYNC();
 }
 
-// ---- state helpers ----------------------------------------------------------------------------------
-OG_DEV void celt_reset_state(CeltState *st) { // OPUS_RESET_STATE celt.cpp:2479 (partial on purpose, Q5)
-    if (OG_LANE == 0) {
-        st->rng = 0;
-        st->error = 0;
-        st->pf_period = st->pf_period_old = 0;
-        st->pf_gain = st->pf_gain_old = 0;
-        st->pf_tapset = st->pf_tapset_old = 0;
-    }
-    OG_FOR_LANES(i, 2 * NBANDS) st->logE1[i] = st->logE2[i] = (i16)(-28 * 1024);
-}
+// Everything the range decoder delivers before the band loop (celt_decode_with_ec celt.cpp:2239-2330): silence flag,
+// post-filter parameters, transient / intra flags, coarse energy, tf flags, spread, dynalloc boosts, allocation trim,
+// bit allocation, fine energy.  The band energies in a.bandE() are updated in place.
+struct CeltHeader {
+    int silence, transient, intra, spread, pf_pitch, pf_tapset, anti_collapse_rsv, codedBands;
+    i32 pf_gain, intensity, dual_stereo, balance;
+};
 
-// Decode one CELT frame of `frame_size` samples (120 << LM) from the live range decoder.
-// pcm_out: LDS i16 buffer (interleaved, CC channels) -- S.v[V_X..] is reused for it after synthesis.
-// Returns frame_size or a negative code (wave-uniform).
-OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int CC, int start, int disable_inv) {
+template <class A, class R>
+OG_DEV void celt_parse_header(A a, R &rc, int start, int end, int C, int LM, CeltHeader &h) {
     const i32 *eb = rom_eband;
-    const int end = NBANDS;
-    int LM;
-    for (LM = 0; LM <= 3; LM++)
-        if (120 << LM == frame_size) break;
-    if (LM > 3) return BAD_ARG;
-    const int M = 1 << LM, N = M * 120;
-    if (rc.storage > 1275 || rc.storage <= 1) return BAD_ARG;
-
-    // ---- stage persistent scalars in LDS
-    OG_SYNC();
-    OG_FOR_LANES(i, 2 * NBANDS) {
-        S.bandE[i] = st->bandE[i];
-        S.logE1[i] = st->logE1[i];
-        S.logE2[i] = st->logE2[i];
-    }
-    OG_FOR_LANES(i, 2 * NBANDS) S.cmask[i] = 0;
-    OG_FOR_LANES(i, NBANDS) {
-        S.pulses[i] = 0;
-        S.fine_quant[i] = 0;
-        S.fine_prio[i] = 0;
-        S.offsets[i] = 0;
-    }
-    OG_FOR_LANES(i, 2 * N) S.v[V_X + i] = 0;
-    OG_FOR_LANES(i, 1248) S.v[V_NORM + i] = 0;
-    for (int c = 0; c < CC; c++) OG_FOR_LANES(i, OVERLAP / 2) S.syn[c][i] = st->tail[c][i];
-    OG_SYNC();
-    if (C == 1) {
-        OG_FOR_LANES(i, NBANDS) S.bandE[i] = OG_MAX(S.bandE[i], S.bandE[NBANDS + i]);
-        OG_SYNC();
-    }
-
-    // ---- header (celt.cpp:2239-2284)
     i32 total_bits = (i32)rc.storage * 8;
     i32 tell = rc_tell(rc);
     int silence;
@@ -685,10 +662,9 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
         transient = rc_bit_logp(rc, 3);
         tell = rc_tell(rc);
     }
-    const int shortBlocks = transient ? M : 0;
     const int intra = tell + 3 <= total_bits ? rc_bit_logp(rc, 3) : 0;
-    coarse_energy(rc, start, end, intra, C, LM);
-    tf_decode(rc, start, end, transient, LM);
+    coarse_energy(a, rc, start, end, intra, C, LM);
+    tf_decode(a, rc, start, end, transient, LM);
     tell = rc_tell(rc);
     int spread = 2;
     if (tell + 4 <= total_bits) { // spread_icdf {25,23,2,0}, ftb 5
@@ -706,7 +682,7 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
     }
     for (int i = 0; i < NBANDS; i++) { // init_caps celt.cpp:911
         int Nb = (eb[i + 1] - eb[i]) << LM;
-        S.cap[i] = (rom_pulse_caps[NBANDS * (2 * LM + C - 1) + i] + 64) * C * Nb >> 2;
+        a.cap(i) = (rom_pulse_caps[NBANDS * (2 * LM + C - 1) + i] + 64) * C * Nb >> 2;
     }
     int dynalloc_logp = 6;
     total_bits <<= BITRES;
@@ -715,7 +691,7 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
         int width = C * (eb[i + 1] - eb[i]) << LM;
         int quanta = OG_MIN(width << BITRES, OG_MAX(6 << BITRES, width));
         int loop_logp = dynalloc_logp, boost = 0;
-        while (tell + (loop_logp << BITRES) < total_bits && boost < S.cap[i]) {
+        while (tell + (loop_logp << BITRES) < total_bits && boost < a.cap(i)) {
             int flag = rc_bit_logp(rc, loop_logp);
             tell = (i32)rc_tell_frac(rc);
             if (!flag) break;
@@ -723,7 +699,7 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
             total_bits -= quanta;
             loop_logp = 1;
         }
-        S.offsets[i] = boost;
+        a.offsets(i) = boost;
         if (boost > 0) dynalloc_logp = OG_MAX(2, dynalloc_logp - 1);
     }
     int alloc_trim = 5;
@@ -747,46 +723,57 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
     const int anti_collapse_rsv = transient && LM >= 2 && bits >= ((LM + 2) << BITRES) ? (1 << BITRES) : 0;
     bits -= anti_collapse_rsv;
     i32 intensity = 0, dual_stereo = 0, balance = 0;
-    const int codedBands = compute_allocation(rc, start, end, alloc_trim, intensity, dual_stereo, bits, balance, C, LM);
-    fine_energy(rc, start, end, C);
+    h.codedBands = compute_allocation(a, rc, start, end, alloc_trim, intensity, dual_stereo, bits, balance, C, LM);
+    fine_energy(a, rc, start, end, C);
 
-#if defined(OG_ABLATE) && OG_ABLATE == 1
-#ifdef OG_DUMP1
-    for (int i = 0; i < NBANDS; i++) {
-        S.v[V_X + i] = (i16)S.pulses[i];
-        S.v[V_X + 32 + i] = (i16)S.fine_quant[i];
-        S.v[V_X + 64 + i] = (i16)S.tf_res[i];
-        S.v[V_X + 96 + i] = (i16)S.cap[i];
-        S.v[V_X + 128 + i] = (i16)S.offsets[i];
+    h.silence = silence;
+    h.transient = transient;
+    h.intra = intra;
+    h.spread = spread;
+    h.pf_pitch = pf_pitch;
+    h.pf_tapset = pf_tapset;
+    h.pf_gain = pf_gain;
+    h.anti_collapse_rsv = anti_collapse_rsv;
+    h.intensity = intensity;
+    h.dual_stereo = dual_stereo;
+    h.balance = balance;
+}
+
+// ---- state helpers ----------------------------------------------------------------------------------
+OG_DEV void celt_reset_state(CeltState *st) { // OPUS_RESET_STATE celt.cpp:2479 (partial on purpose, Q5)
+    if (OG_LANE == 0) {
+        st->rng = 0;
+        st->error = 0;
+        st->pf_period = st->pf_period_old = 0;
+        st->pf_gain = st->pf_gain_old = 0;
+        st->pf_tapset = st->pf_tapset_old = 0;
     }
-    S.v[V_X + 160] = (i16)codedBands; S.v[V_X + 161] = (i16)intensity; S.v[V_X + 162] = (i16)dual_stereo;
-    S.v[V_X + 163] = (i16)spread; S.v[V_X + 164] = (i16)transient; S.v[V_X + 165] = (i16)balance; S.v[V_X + 166] = (i16)alloc_trim;
-    S.v[V_X + 167] = (i16)rc_tell(rc); S.v[V_X + 168] = (i16)intra; S.v[V_X+169]=(i16)pf_pitch; S.v[V_X+170]=(i16)silence;
-    for (int i = 0; i < 42; i++) S.v[V_X + 192 + i] = S.bandE[i];
-#endif
-    return frame_size;
-#endif
-    u32 seed = st->rng;
-    decode_all_bands(rc, start, end, C, N, shortBlocks, spread, dual_stereo, intensity,
-                     (i32)rc.storage * (8 << BITRES) - anti_collapse_rsv, balance, LM, codedBands, seed, disable_inv);
-    int anti_collapse_on = 0;
-    if (anti_collapse_rsv > 0) anti_collapse_on = (int)rc_bits(rc, 1);
-    energy_finalise(rc, start, end, (i32)rc.storage * 8 - rc_tell(rc), C);
-    if (anti_collapse_on) anti_collapse(LM, C, N, start, end, seed);
-    if (silence)
-        for (int i = 0; i < C * NBANDS; i++) S.bandE[i] = (i16)(-28 * 1024);
+    OG_FOR_LANES(i, 2 * NBANDS) st->logE1[i] = st->logE2[i] = (i16)(-28 * 1024);
+}
 
-    OG_TAP(1); // X and bandE final
-#if defined(OG_ABLATE) && OG_ABLATE == 2
-    return frame_size;
-#endif
-    // ---- synthesis
+// Synthesis half of a CELT frame (celt_synthesis celt.cpp:2057 onwards, then :2372-2440): from the normalised bands in
+// S.v[V_X..] and the final band energies in S.bandE to PCM staged in S.v[V_X..] (interleaved, CC channels), plus the
+// write-back of the stream's history.  Everything it needs from the entropy-decoding half is in CeltSynth, so the
+// same code serves the single-kernel path and the reconstruction kernel of the split path.
+struct CeltSynth {
+    int N, LM, C, CC, start, end, silence, transient, pf_pitch, pf_tapset;
+    i32 pf_gain;
+    u32 rng_final;
+    int rc_error;
+};
+
+OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
+    const int N = p.N, LM = p.LM, C = p.C, CC = p.CC, start = p.start, end = p.end, silence = p.silence, transient = p.transient;
+    const int pf_pitch = p.pf_pitch, pf_tapset = p.pf_tapset, M = 1 << LM;
+    const i32 pf_gain = p.pf_gain;
+    OG_SYNC();
+    for (int c = 0; c < CC; c++) OG_FOR_LANES(i, OVERLAP / 2) S.syn[c][i] = st->tail[c][i];
     denorm_gains(start, end, C, silence);
     const int B = transient ? M : 1, shift = transient ? 3 : 3 - LM;
     imdct_all(N, LM, B, shift, C, CC);
     OG_TAP(2); // IMDCT output
 #if defined(OG_ABLATE) && OG_ABLATE == 3
-    return frame_size;
+    return;
 #endif
 
     int pp = OG_MAX(st->pf_period, 15), ppo = OG_MAX(st->pf_period_old, 15);
@@ -799,7 +786,7 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
 
     OG_TAP(3); // comb filter output
 #if defined(OG_ABLATE) && OG_ABLATE == 4
-    return frame_size;
+    return;
 #endif
     // ---- energy history (celt.cpp:2404-2436)
     OG_SYNC();
@@ -846,7 +833,7 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
     OG_SYNC();
     if (OG_LANE == 0) {
         st->ring_pos = (pos + N) & RING_MASK;
-        st->rng = rc.rng;
+        st->rng = p.rng_final;
         int new_old_period = pp, new_old_tapset = pt;
         i32 new_old_gain = pg;
         if (LM != 0) {
@@ -860,8 +847,72 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
         st->pf_period = pf_pitch;
         st->pf_gain = pf_gain;
         st->pf_tapset = pf_tapset;
-        if (rc.error) st->error = 1;
+        if (p.rc_error) st->error = 1;
     }
+}
+
+// Decode one CELT frame of `frame_size` samples (120 << LM) from the live range decoder.
+// pcm_out: LDS i16 buffer (interleaved, CC channels) -- S.v[V_X..] is reused for it after synthesis.
+// Returns frame_size or a negative code (wave-uniform).
+OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int CC, int start, int disable_inv) {
+    const i32 *eb = rom_eband;
+    const int end = NBANDS;
+    int LM;
+    for (LM = 0; LM <= 3; LM++)
+        if (120 << LM == frame_size) break;
+    if (LM > 3) return BAD_ARG;
+    const int M = 1 << LM, N = M * 120;
+    if (rc.storage > 1275 || rc.storage <= 1) return BAD_ARG;
+
+    // ---- stage persistent scalars in LDS
+    OG_SYNC();
+    OG_FOR_LANES(i, 2 * NBANDS) {
+        S.bandE[i] = st->bandE[i];
+        S.logE1[i] = st->logE1[i];
+        S.logE2[i] = st->logE2[i];
+    }
+    OG_FOR_LANES(i, 2 * NBANDS) S.cmask[i] = 0;
+    OG_FOR_LANES(i, NBANDS) {
+        S.pulses[i] = 0;
+        S.fine_quant[i] = 0;
+        S.fine_prio[i] = 0;
+        S.offsets[i] = 0;
+    }
+    OG_FOR_LANES(i, 2 * N) S.v[V_X + i] = 0;
+    OG_FOR_LANES(i, 1248) S.v[V_NORM + i] = 0;
+    OG_SYNC();
+    if (C == 1) {
+        OG_FOR_LANES(i, NBANDS) S.bandE[i] = OG_MAX(S.bandE[i], S.bandE[NBANDS + i]);
+        OG_SYNC();
+    }
+
+    // ---- header, energies, allocation (all range-decoder work before the band loop)
+    CeltHeader h;
+    celt_parse_header(WaveArr(), rc, start, end, C, LM, h);
+    const int silence = h.silence, transient = h.transient, spread = h.spread, pf_pitch = h.pf_pitch, pf_tapset = h.pf_tapset;
+    const i32 pf_gain = h.pf_gain, intensity = h.intensity, dual_stereo = h.dual_stereo, balance = h.balance;
+    const int shortBlocks = transient ? M : 0, anti_collapse_rsv = h.anti_collapse_rsv, codedBands = h.codedBands;
+#if defined(OG_ABLATE) && OG_ABLATE == 1
+    return frame_size;
+#endif
+    u32 seed = st->rng;
+    decode_all_bands(rc, start, end, C, N, shortBlocks, spread, dual_stereo, intensity,
+                     (i32)rc.storage * (8 << BITRES) - anti_collapse_rsv, balance, LM, codedBands, seed, disable_inv);
+    int anti_collapse_on = 0;
+    if (anti_collapse_rsv > 0) anti_collapse_on = (int)rc_bits(rc, 1);
+    energy_finalise(WaveArr(), rc, start, end, (i32)rc.storage * 8 - rc_tell(rc), C);
+    if (anti_collapse_on) anti_collapse(LM, C, N, start, end, seed);
+    if (silence)
+        for (int i = 0; i < C * NBANDS; i++) S.bandE[i] = (i16)(-28 * 1024);
+
+    OG_TAP(1); // X and bandE final
+#if defined(OG_ABLATE) && OG_ABLATE == 2
+    return frame_size;
+#endif
+    CeltSynth sp;
+    sp.N = N; sp.LM = LM; sp.C = C; sp.CC = CC; sp.start = start; sp.end = end; sp.silence = silence; sp.transient = transient;
+    sp.pf_pitch = pf_pitch; sp.pf_tapset = pf_tapset; sp.pf_gain = pf_gain; sp.rng_final = rc.rng; sp.rc_error = rc.error;
+    celt_synthesis(st, sp);
     if (rc_tell(rc) > 8 * (i32)rc.storage) return INTERNAL_ERROR;
     return frame_size;
 }

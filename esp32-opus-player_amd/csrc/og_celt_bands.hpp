@@ -308,7 +308,8 @@ OG_DEV int compute_qn(int N, int b, int offset, int pulse_cap, int stereo) { // 
 struct Split { int inv, imid, iside, delta, itheta, qalloc; };
 
 // compute_theta celt.cpp:1241 (decoder branches)
-OG_DEV void compute_theta(Rc &rc, int band, int intensity, int disable_inv, i32 remaining_bits, Split &sc, int N, i32 &b, int B,
+template <class R>
+OG_DEV void compute_theta(R &rc, int band, int intensity, int disable_inv, i32 remaining_bits, Split &sc, int N, i32 &b, int B,
                           int B0, int LM, int stereo, i32 &fill) {
     int itheta = 0, inv = 0;
     int pulse_cap = rom_logn[band] + LM * (1 << BITRES);

@@ -1,0 +1,828 @@
+// og_celt_split.hpp -- the two-kernel CELT path: entropy decoding with ONE FRAME PER LANE, then vector
+// reconstruction with one frame per wave.
+//
+// Why: everything the range decoder touches is a serial dependency chain over wave-uniform values.  Run one frame
+// per wave it occupies a whole 64-lane SIMD for scalar work (measured on the single-kernel path: ~140 k vector +
+// ~43 k scalar instructions per frame, half of them walking the PVQ codebook).  None of that work depends on the
+// decoded spectrum: the bits a CELT frame reads are fully determined by the bit budget bookkeeping, never by the
+// pulse vectors, collapse masks or the noise seed (src/celt.cpp:1382-1741: `fill`, `cm` and `seed` only steer the
+// folding).  So the frame splits cleanly:
+//
+//   parse  (k_celt_parse, one frame per LANE, 64 frames per wave): header, energies, allocation, the band loop's
+//          budget logic, split angles and PVQ codeword indices.  Output: a ParseRec per frame in HBM -- a header,
+//          one word per band / split / leaf in decode order, and an array of (x, N, K, index) PVQ leaves.
+//   recon  (k_celt_recon, one frame per WAVE): index -> pulse vector for all leaves of the frame at once (one
+//          leaf per lane: cwrsi touches no coder state), then the band loop's vector half (normalisation,
+//          spreading rotation, folding, Haar / Hadamard, stereo merge, anti-collapse) driven by the record, then
+//          the shared synthesis half (og_celt.hpp: celt_synthesis).
+//
+// Both halves are restatements of the same reference functions as og_celt_bands.hpp (file:line cited there); the
+// single-kernel path remains for frames whose CELT part follows SILK data in the same range coder (hybrid) and for
+// the SILK-only transition frame (Q4).
+#pragma once
+#include "og_celt.hpp"
+
+#undef OG_SYNC
+#define OG_SYNC() OG_LSYNC()
+
+namespace og {
+
+// ---- the record ------------------------------------------------------------------------------------
+constexpr int REC_MAX_LEAVES = NBANDS * 2 * 16;      // <= 16 leaves per band and channel (4 split levels)
+constexpr int REC_MAX_WORDS = NBANDS * (1 + 2 * 31); // 1 band word + <= 31 tree nodes per band and channel
+
+enum { // ParseRec.flags
+    RF_SILENCE = 1, RF_TRANSIENT = 2, RF_LM_SHIFT = 2 /* 2 bits */, RF_STEREO = 16, RF_SPREAD_SHIFT = 5 /* 2 bits */,
+    RF_DUAL = 128, RF_ANTI_COLLAPSE = 256, RF_RC_ERROR = 512, RF_TELL_OVERFLOW = 1024,
+    RF_SKIP = 2048,    // descriptor rejected before any state change (decode_frame_wave's BAD_ARG)
+    RF_BAD_CELT = 4096 // celt_decode_frame's early BAD_ARG: bookkeeping only
+};
+enum { // band word
+    BW_UPDATE_LOW = 1, BW_SIGN0 = 2, BW_SIGN1 = 4, BW_ITHETA_SHIFT = 3 /* 15 bits */, BW_INV = 1 << 18, BW_SIGN = 1 << 19,
+    BW_MID_FIRST = 1 << 20
+};
+enum { NW_SPLIT = 1u << 31, NW_MID_FIRST = 1 << 15 }; // tree node word: SPLIT | mid_first | itheta, or the leaf's K
+
+struct ParseRec {
+    i32 ret;       // samples per channel (960) -- or the negative code the frame ends with
+    u32 rng_final; // range decoder's rng after the frame
+    u32 flags;
+    i32 intensity, pf_pitch, pf_gain, pf_tapset, start;
+    i32 n_leaves, n_words;
+    i32 reserved[6];
+    i16 bandE[2 * NBANDS]; // final band energies (coarse + fine + finalise)
+    i16 pulses[NBANDS];
+    i8 tf_res[NBANDS];
+    i8 pad[256 - 64 - 4 * NBANDS - 2 * NBANDS - NBANDS];
+    u32 leaf_idx[REC_MAX_LEAVES];  // PVQ codeword index
+    u32 leaf_geom[REC_MAX_LEAVES]; // x | N << 11 | K << 19   (x: offset into S.v[V_X..])
+    u32 words[REC_MAX_WORDS + 1];
+};
+static_assert(sizeof(ParseRec) % 16 == 0, "record alignment");
+
+// =====================================================================================================
+//  parse: one frame per lane
+// =====================================================================================================
+#define OG_PL_LANES OG_NLANES
+struct ParseLds { // [element][lane]: lanes of a wave touch consecutive addresses, no bank conflicts
+    i32 pulses[NBANDS][OG_PL_LANES];
+    i16 bandE[2 * NBANDS][OG_PL_LANES];
+    i16 cap[NBANDS][OG_PL_LANES], offsets[NBANDS][OG_PL_LANES];
+    i8 fine_quant[NBANDS][OG_PL_LANES], fine_prio[NBANDS][OG_PL_LANES], tf_res[NBANDS][OG_PL_LANES];
+    union {
+        struct { // live during compute_allocation only
+            i16 thresh[NBANDS][OG_PL_LANES], trim_off[NBANDS][OG_PL_LANES];
+            u16 bits1[NBANDS][OG_PL_LANES], bits2[NBANDS][OG_PL_LANES];
+        } al;
+        i32 stack[5][5][OG_PL_LANES]; // split frames of the partition walk: [depth][word][lane]
+    } u;
+};
+OG_LDS ParseLds PL;
+
+struct LaneArr {
+    OG_MEMBER i32 &pulses(int i) const { return PL.pulses[i][OG_LANE]; }
+    OG_MEMBER i8 &fine_quant(int i) const { return PL.fine_quant[i][OG_LANE]; }
+    OG_MEMBER i8 &fine_prio(int i) const { return PL.fine_prio[i][OG_LANE]; }
+    OG_MEMBER i8 &tf_res(int i) const { return PL.tf_res[i][OG_LANE]; }
+    OG_MEMBER i16 &cap(int i) const { return PL.cap[i][OG_LANE]; }
+    OG_MEMBER i16 &offsets(int i) const { return PL.offsets[i][OG_LANE]; }
+    OG_MEMBER u16 &bits1(int i) const { return PL.u.al.bits1[i][OG_LANE]; }
+    OG_MEMBER u16 &bits2(int i) const { return PL.u.al.bits2[i][OG_LANE]; }
+    OG_MEMBER i16 &thresh(int i) const { return PL.u.al.thresh[i][OG_LANE]; }
+    OG_MEMBER i16 &trim_off(int i) const { return PL.u.al.trim_off[i][OG_LANE]; }
+    OG_MEMBER i16 &bandE(int i) const { return PL.bandE[i][OG_LANE]; }
+};
+
+OG_DEV u32 pvq_u_rom(int a, int b) { // U(a,b) from the ROM table (lane-private lookups)
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    return rom_pvq_u[lo * ROM_PVQ_COLS + hi];
+}
+
+struct RecWriter {
+    ParseRec *rec;
+    int nw, nl;
+    OG_MEMBER void word(u32 w) {
+        if (nw < REC_MAX_WORDS) rec->words[nw] = w;
+        nw++;
+    }
+    OG_MEMBER void leaf(int x, int N, int K, u32 idx) {
+        if (nl < REC_MAX_LEAVES) {
+            rec->leaf_idx[nl] = idx;
+            rec->leaf_geom[nl] = (u32)x | (u32)N << 11 | (u32)K << 19;
+        }
+        nl++;
+    }
+};
+
+// quant_partition celt.cpp:1382, range-decoder half: split decisions, angles, pulse counts and PVQ indices.
+OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits, int x, int N, i32 b, int B, int LM) {
+    int depth = 0;
+    for (;;) {
+        for (;;) { // descend
+            const u8 *cache = pulse_cache(band, LM);
+            if (!(LM != -1 && b > cache[cache[0]] + 12 && N > 2)) break;
+            const int B0 = B;
+            Split sc;
+            i32 fill = 0;
+            N >>= 1;
+            LM -= 1;
+            B = (B + 1) >> 1;
+            compute_theta(rc, band, 0, 0, remaining_bits, sc, N, b, B, B0, LM, 0, fill);
+            i32 delta = sc.delta;
+            const int itheta = sc.itheta;
+            if (B0 > 1 && (itheta & 0x3fff)) {
+                if (itheta > 8192)
+                    delta -= delta >> (4 - LM);
+                else
+                    delta = OG_MIN(0, delta + (N << BITRES >> (5 - LM)));
+            }
+            const i32 mbits = OG_MAX(0, OG_MIN(b, (b - delta) / 2));
+            const i32 sbits = b - mbits;
+            remaining_bits -= sc.qalloc;
+            const int mid_first = mbits >= sbits;
+            out.word(NW_SPLIT | (mid_first ? NW_MID_FIRST : 0) | (u32)itheta);
+            i32 *F = &PL.u.stack[depth][0][OG_LANE];
+            F[0 * OG_PL_LANES] = x | N << 11 | (LM + 1) << 19 | B << 22 | mid_first << 27 | 1 << 28;
+            F[1 * OG_PL_LANES] = mbits;
+            F[2 * OG_PL_LANES] = sbits;
+            F[3 * OG_PL_LANES] = remaining_bits;
+            F[4 * OG_PL_LANES] = itheta;
+            depth++;
+            if (mid_first)
+                b = mbits;
+            else {
+                x += N;
+                b = sbits;
+            }
+        }
+        { // leaf: pulse count from the remaining budget, then the codeword index (celt.cpp:1463-1480)
+            int q = bits2pulses(band, LM, b), curr_bits = pulses2bits(band, LM, q);
+            remaining_bits -= curr_bits;
+            while (remaining_bits < 0 && q > 0) {
+                remaining_bits += curr_bits;
+                q--;
+                curr_bits = pulses2bits(band, LM, q);
+                remaining_bits -= curr_bits;
+            }
+            const int K = q ? get_pulses(q) : 0;
+            out.word((u32)K);
+            if (K) out.leaf(x, N, K, rc_uint(rc, pvq_u_rom(N, K) + pvq_u_rom(N, K + 1)));
+        }
+        for (;;) { // back to the parents
+            if (depth == 0) return;
+            i32 *F = &PL.u.stack[depth - 1][0][OG_LANE];
+            const i32 w0 = F[0];
+            const int mid_first = (w0 >> 27) & 1, stage = (w0 >> 28) & 3;
+            if (stage == 1) {
+                i32 mbits = F[1 * OG_PL_LANES], sbits = F[2 * OG_PL_LANES];
+                const int itheta = F[4 * OG_PL_LANES];
+                const i32 rebalance = (mid_first ? mbits : sbits) - (F[3 * OG_PL_LANES] - remaining_bits);
+                if (mid_first) {
+                    if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES);
+                } else {
+                    if (rebalance > 3 << BITRES && itheta != 16384) mbits += rebalance - (3 << BITRES);
+                }
+                F[0] = (w0 & ~(3 << 28)) | 2 << 28;
+                N = (w0 >> 11) & 255;
+                LM = ((w0 >> 19) & 7) - 1;
+                B = (w0 >> 22) & 31;
+                x = (w0 & 2047) + (mid_first ? N : 0);
+                b = mid_first ? sbits : mbits;
+                break;
+            }
+            depth--;
+        }
+    }
+}
+
+// quant_all_bands celt.cpp:1754, range-decoder half
+OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C, int N_ch, int shortBlocks, int dual_stereo,
+                            int intensity, i32 total_bits, i32 balance, int LM, int codedBands, int disable_inv) {
+    const LaneArr a;
+    const int M = 1 << LM, B = shortBlocks ? M : 1;
+    for (int i = start; i < end; i++) {
+        const int eb0 = M * rom_eband[i], N = M * rom_eband[i + 1] - eb0;
+        const int x = eb0, y = C == 2 ? N_ch + eb0 : -1;
+        const i32 tell = (i32)rc_tell_frac(rc);
+        if (i != start) balance -= tell;
+        i32 remaining_bits = total_bits - tell - 1, b;
+        const i32 pulses_i = a.pulses(i);
+        if (i <= codedBands - 1) {
+            const i32 curr_balance = balance / OG_MIN(3, codedBands - i);
+            b = OG_MAX(0, OG_MIN(16383, OG_MIN(remaining_bits + 1, pulses_i + curr_balance)));
+        } else
+            b = 0;
+        const int tf_change = a.tf_res(i);
+        if (dual_stereo && i == intensity) dual_stereo = 0;
+        u32 bw = b > (N << BITRES) ? BW_UPDATE_LOW : 0;
+        if (N == 1) { // quant_band_n1 celt.cpp:1357
+            for (int c = 0; c < (y >= 0 ? 2 : 1); c++) {
+                if (remaining_bits >= 1 << BITRES) {
+                    if (rc_bits(rc, 1)) bw |= c ? BW_SIGN1 : BW_SIGN0;
+                    remaining_bits -= 1 << BITRES;
+                }
+            }
+            out.word(bw);
+        } else {
+            const int stereo = (y >= 0) && !dual_stereo;
+            Split sc;
+            sc.inv = 0; sc.imid = 0; sc.iside = 0; sc.delta = 0; sc.itheta = 0; sc.qalloc = 0;
+            i32 bb = b, fill_unused = 0, mbits = 0, sbits = 0, rebal0 = 0;
+            int n2case = 0, swap_c = 0, mid_first = 1, njobs = 1;
+            if (stereo) { // quant_band_stereo celt.cpp:1628
+                compute_theta(rc, i, intensity, disable_inv, remaining_bits, sc, N, bb, B, B, LM, 1, fill_unused);
+                bw |= (u32)sc.itheta << BW_ITHETA_SHIFT;
+                if (sc.inv) bw |= BW_INV;
+                if (N == 2) {
+                    n2case = 1;
+                    mbits = bb;
+                    sbits = 0;
+                    if (sc.itheta != 0 && sc.itheta != 16384) sbits = 1 << BITRES;
+                    mbits -= sbits;
+                    swap_c = sc.itheta > 8192;
+                    remaining_bits -= sc.qalloc + sbits;
+                    if (sbits && rc_bits(rc, 1)) bw |= BW_SIGN;
+                } else {
+                    mbits = OG_MAX(0, OG_MIN(bb, (bb - sc.delta) / 2));
+                    sbits = bb - mbits;
+                    remaining_bits -= sc.qalloc;
+                    rebal0 = remaining_bits;
+                    mid_first = mbits >= sbits;
+                    njobs = 2;
+                }
+            } else if (dual_stereo)
+                njobs = 2;
+            if (mid_first) bw |= BW_MID_FIRST;
+            out.word(bw);
+            for (int jb = 0; jb < njobs; jb++) {
+                int jx;
+                i32 jbits;
+                if (dual_stereo) {
+                    jx = jb ? y : x;
+                    jbits = b / 2;
+                } else if (!stereo) {
+                    jx = x;
+                    jbits = b;
+                } else if (n2case) {
+                    jx = swap_c ? y : x;
+                    jbits = mbits;
+                } else {
+                    const int is_mid = (jb == 0) == (mid_first != 0);
+                    if (jb == 1) { // rebalance between the two halves (celt.cpp:1711-1724)
+                        const i32 rebalance = (mid_first ? mbits : sbits) - (rebal0 - remaining_bits);
+                        if (mid_first) {
+                            if (rebalance > 3 << BITRES && sc.itheta != 0) sbits += rebalance - (3 << BITRES);
+                        } else {
+                            if (rebalance > 3 << BITRES && sc.itheta != 16384) mbits += rebalance - (3 << BITRES);
+                        }
+                    }
+                    jx = is_mid ? x : y;
+                    jbits = is_mid ? mbits : sbits;
+                }
+                // quant_band celt.cpp:1526: only the block count reaches the partition walk's decisions
+                int Bj = B, N_B = (int)udiv((u32)N, (u32)B), tfc = tf_change;
+                const int recombine = tfc > 0 ? tfc : 0;
+                Bj >>= recombine;
+                N_B <<= recombine;
+                while ((N_B & 1) == 0 && tfc < 0) {
+                    Bj <<= 1;
+                    N_B >>= 1;
+                    tfc++;
+                }
+                parse_tree(rc, out, i, remaining_bits, jx, N, jbits, Bj, LM);
+            }
+        }
+        balance += pulses_i + tell;
+    }
+}
+
+// One CELT-only frame, lane-private.  `payload`/`len`: the frame's bytes; `ch`: channels coded in the packet,
+// CC: decoder channels.  Mirrors decode_frame_wave + celt_decode_frame up to (not including) every vector operation.
+OG_DEV void celt_parse_lane(const StreamState *st, const u8 *payload, int len, int ch, ParseRec *rec) {
+    const LaneArr a;
+    const int CC = st->channels, C = ch, LM = 3, frame_size = 960, start = 0, end = NBANDS;
+    rec->start = start;
+    rec->n_leaves = 0;
+    rec->n_words = 0;
+    if (len < 0 || len > 1275) {
+        rec->ret = BAD_ARG;
+        rec->flags = RF_SKIP;
+        return;
+    }
+    RcLane rc;
+    rc.buf = payload;
+    rc_init(rc, (u32)len);
+    if (rc.storage <= 1) { // celt_decode_frame's early exit
+        rec->ret = BAD_ARG;
+        rec->flags = RF_BAD_CELT;
+        rec->rng_final = rc.rng;
+        return;
+    }
+    const int disable_inv = CC == 1;
+    for (int i = 0; i < 2 * NBANDS; i++) a.bandE(i) = st->celt.bandE[i];
+    if (C == 1)
+        for (int i = 0; i < NBANDS; i++) a.bandE(i) = (i16)OG_MAX((i32)a.bandE(i), (i32)a.bandE(NBANDS + i));
+    for (int i = 0; i < NBANDS; i++) {
+        a.pulses(i) = 0;
+        a.fine_quant(i) = 0;
+        a.fine_prio(i) = 0;
+        a.offsets(i) = 0;
+    }
+    CeltHeader h;
+    celt_parse_header(a, rc, start, end, C, LM, h);
+    RecWriter out;
+    out.rec = rec;
+    out.nw = 0;
+    out.nl = 0;
+    const int M = 1 << LM, N = M * 120;
+    // tf_res and pulses are needed by the reconstruction (and pulses changes meaning nowhere after this point)
+    for (int i = 0; i < NBANDS; i++) {
+        rec->pulses[i] = (i16)a.pulses(i);
+        rec->tf_res[i] = a.tf_res(i);
+    }
+    parse_all_bands(rc, out, start, end, C, N, h.transient ? M : 0, h.dual_stereo, h.intensity,
+                    (i32)rc.storage * (8 << BITRES) - h.anti_collapse_rsv, h.balance, LM, h.codedBands, disable_inv);
+    int anti_collapse_on = 0;
+    if (h.anti_collapse_rsv > 0) anti_collapse_on = (int)rc_bits(rc, 1);
+    energy_finalise(a, rc, start, end, (i32)rc.storage * 8 - rc_tell(rc), C);
+    for (int i = 0; i < 2 * NBANDS; i++) rec->bandE[i] = a.bandE(i);
+    u32 flags = (u32)LM << RF_LM_SHIFT | (u32)h.spread << RF_SPREAD_SHIFT;
+    if (h.silence) flags |= RF_SILENCE;
+    if (h.transient) flags |= RF_TRANSIENT;
+    if (C == 2) flags |= RF_STEREO;
+    if (h.dual_stereo) flags |= RF_DUAL;
+    if (anti_collapse_on) flags |= RF_ANTI_COLLAPSE;
+    if (rc.error || out.nw > REC_MAX_WORDS || out.nl > REC_MAX_LEAVES) flags |= RF_RC_ERROR;
+    if (rc_tell(rc) > 8 * (i32)rc.storage) flags |= RF_TELL_OVERFLOW;
+    rec->flags = flags;
+    rec->ret = frame_size;
+    rec->rng_final = rc.rng;
+    rec->intensity = h.intensity;
+    rec->pf_pitch = h.pf_pitch;
+    rec->pf_gain = h.pf_gain;
+    rec->pf_tapset = h.pf_tapset;
+    rec->n_leaves = OG_MIN(out.nl, REC_MAX_LEAVES);
+    rec->n_words = OG_MIN(out.nw, REC_MAX_WORDS);
+}
+
+// =====================================================================================================
+//  recon: one frame per wave
+// =====================================================================================================
+// Codeword index -> signed pulse vector (cwrsi celt.cpp:2545), lane-private: one PVQ leaf per lane, pulses written as
+// i16 straight into the leaf's slot of the spectrum arena (the leaf operation normalises them in place later).
+OG_DEV void pvq_decode_lane(int n, int k, u32 i, int pos) {
+    while (n > 2) {
+        if (k >= n) {
+            const u32 *row = rom_pvq_u + n * ROM_PVQ_COLS; // n <= 14 here: U(n, .) is row n
+            u32 p = row[k + 1];
+            const int s = -(int)(i >= p);
+            i -= p & (u32)s;
+            const int k0 = k;
+            const u32 q = row[n];
+            if (q > i) k = n - 1;
+            // largest k' <= k with U(n, k') <= i: U(n, .) is increasing -> bisection
+            int lo = 0, hi = k;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (row[mid] <= i) lo = mid; else hi = mid - 1;
+            }
+            k = lo;
+            i -= row[k];
+            S.v[pos++] = (i16)((k0 - k + s) ^ s);
+        } else {
+            const u32 p = pvq_u_rom(k, n), q = pvq_u_rom(k + 1, n);
+            if (p <= i && i < q) {
+                i -= p;
+                S.v[pos++] = 0;
+            } else {
+                const int s = -(int)(i >= q);
+                i -= q & (u32)s;
+                const int k0 = k;
+                u32 pp;
+                do pp = pvq_u_rom(--k, n);
+                while (pp > i);
+                i -= pp;
+                S.v[pos++] = (i16)((k0 - k + s) ^ s);
+            }
+        }
+        n--;
+    }
+    const u32 p = 2 * (u32)k + 1;
+    int s = -(int)(i >= p);
+    i -= p & (u32)s;
+    const int k0 = k;
+    k = (int)((i + 1) >> 1);
+    if (k) i -= 2 * (u32)k - 1;
+    S.v[pos++] = (i16)((k0 - k + s) ^ s);
+    s = -(int)i;
+    S.v[pos] = (i16)((k + s) ^ s);
+}
+
+// The record's words, staged in LDS over the (not yet needed) synthesis buffer.
+OG_DEV u32 *rec_words() { return reinterpret_cast<u32 *>(&S.syn[0][0]); }
+static_assert(sizeof(FrameLds::syn) >= sizeof(u32) * (REC_MAX_WORDS + 1), "record words must fit the synthesis buffer");
+
+// Leaf of the partition tree, vector half (celt.cpp:1463-1520, alg_unquant :782); the pulses of a K > 0 leaf are
+// already in S.v[x..x+N).
+OG_DEV u32 recon_leaf(int K, int spread, u32 &seed_io, int x, int N, int B, int low, i32 gain, i32 fill) {
+    if (K != 0) {
+        OG_SYNC();
+        const u32 N0 = B > 1 ? udiv((u32)N, (u32)B) : (u32)N;
+        i32 part = 0;
+        u32 m = 0;
+        OG_FOR_LANES(j, N) {
+            const i32 v = S.v[x + j];
+            part += v * v;
+            m |= (u32)(v != 0) << udiv((u32)j, N0);
+        }
+        const i32 Ryy = wave_sum(part);
+        const int k = ilog2(Ryy) >> 1;
+        const i32 t = vshr32(Ryy, 2 * (k - 7));
+        const i32 g = tr16(mul16_p15(rsqrt_norm(t), gain));
+        OG_FOR_LANES(j, N) S.v[x + j] = (i16)pshr32(mul16(g, S.v[x + j]), k + 1); // normalise_residual :745
+        unspread(x, N, B, K, spread);
+        if (B <= 1) return 1;
+        return wave_or(m); // extract_collapse_mask :760
+    }
+    const u32 cm_mask = (u32)((1ull << B) - 1);
+    fill &= (i32)cm_mask;
+    OG_SYNC();
+    if (!fill) {
+        OG_FOR_LANES(j, N) S.v[x + j] = 0;
+        OG_SYNC();
+        return 0;
+    }
+    const u32 seed = seed_io;
+    u32 cm;
+    if (low < 0) { // noise
+        OG_FOR_LANES(j, N) S.v[x + j] = (i16)((i32)lcg_skip(seed, (u32)j + 1) >> 20);
+        cm = cm_mask;
+    } else { // folded spectrum, +-1/256 dither
+        OG_FOR_LANES(j, N) {
+            const u32 sj = lcg_skip(seed, (u32)j + 1);
+            S.v[x + j] = (i16)(S.v[low + j] + ((sj & 0x8000) ? 4 : -4));
+        }
+        cm = (u32)fill;
+    }
+    seed_io = lcg_skip(seed, (u32)N);
+    renormalise(x, N, gain);
+    return cm;
+}
+
+struct ReconFrame { i32 x, N, B, B0, LM, low, low2, gain_mid, gain_side, fill, mid_first, stage, cm; };
+OG_LDS ReconFrame g_rframe[5];
+
+// imid / iside of a split angle and its effect on the fill mask (tail of compute_theta, celt.cpp:1320-1353)
+OG_DEV void theta_gains(int itheta, int B, i32 &imid, i32 &iside, i32 &fill) {
+    if (itheta == 0) {
+        imid = 32767;
+        iside = 0;
+        fill &= (1 << B) - 1;
+    } else if (itheta == 16384) {
+        imid = 0;
+        iside = 32767;
+        fill &= ((1 << B) - 1) << B;
+    } else {
+        imid = bitexact_cos(itheta);
+        iside = bitexact_cos(16384 - itheta);
+    }
+}
+
+// quant_partition celt.cpp:1382, vector half, driven by the record's node words
+OG_DEV u32 recon_tree(int &cur, int spread, u32 &seed, int x, int N, int B, int low, int LM, i32 gain, i32 fill) {
+    const u32 *W = rec_words();
+    int depth = 0;
+    for (;;) {
+        u32 w = (u32)OG_UNI(W[cur]);
+        cur++;
+        while (w & NW_SPLIT) {
+            const int itheta = (int)(w & 0x7fff), mid_first = (w & NW_MID_FIRST) != 0, B0 = B;
+            N >>= 1;
+            LM -= 1;
+            if (B == 1) fill = (fill & 1) | (fill << 1);
+            B = (B + 1) >> 1;
+            i32 imid, iside;
+            theta_gains(itheta, B, imid, iside, fill);
+            ReconFrame &F = g_rframe[depth];
+            F.x = x; F.N = N; F.B = B; F.B0 = B0; F.LM = LM; F.low = low; F.low2 = low >= 0 ? low + N : -1;
+            F.gain_mid = tr16(mul16_p15(gain, imid)); F.gain_side = tr16(mul16_p15(gain, iside));
+            F.fill = fill; F.mid_first = mid_first; F.stage = 1; F.cm = 0;
+            depth++;
+            if (mid_first)
+                gain = tr16(mul16_p15(gain, imid));
+            else {
+                x = x + N;
+                low = low >= 0 ? low + N : -1;
+                gain = tr16(mul16_p15(gain, iside));
+                fill = fill >> B;
+            }
+            w = (u32)OG_UNI(W[cur]);
+            cur++;
+        }
+        u32 cm = recon_leaf((int)(w & 255), spread, seed, x, N, B, low, gain, fill);
+        for (;;) {
+            if (depth == 0) return cm;
+            ReconFrame &F = g_rframe[depth - 1];
+            const int B0 = OG_UNI(F.B0), Bc = OG_UNI(F.B), stage = OG_UNI(F.stage), mid_first = OG_UNI(F.mid_first);
+            if (stage == 1) {
+                F.cm = (i32)(mid_first ? cm : cm << (B0 >> 1));
+                F.stage = 2;
+                N = OG_UNI(F.N);
+                B = Bc;
+                LM = OG_UNI(F.LM);
+                if (mid_first) {
+                    x = OG_UNI(F.x) + N;
+                    low = OG_UNI(F.low2);
+                    gain = OG_UNI(F.gain_side);
+                    fill = OG_UNI(F.fill) >> Bc;
+                } else {
+                    x = OG_UNI(F.x);
+                    low = OG_UNI(F.low);
+                    gain = OG_UNI(F.gain_mid);
+                    fill = OG_UNI(F.fill);
+                }
+                break;
+            }
+            cm = (u32)OG_UNI(F.cm) | (mid_first ? cm << (B0 >> 1) : cm);
+            depth--;
+        }
+    }
+}
+
+// quant_band celt.cpp:1526, vector half; N > 1
+OG_DEV u32 recon_band_mono(int &cur, int spread, int tf_change, u32 &seed, int x, int N, int B, int low, int LM, int low_out,
+                           i32 gain, int low_scratch, i32 fill) {
+    int N0 = N, N_B, B0 = B, time_divide = 0, recombine = 0;
+    const int longBlocks = B0 == 1;
+    N_B = (int)udiv((u32)N, (u32)B);
+    if (tf_change > 0) recombine = tf_change;
+    if (low_scratch >= 0 && low >= 0 && (recombine || ((N_B & 1) == 0 && tf_change < 0) || B0 > 1)) {
+        OG_SYNC();
+        OG_FOR_LANES(j, N) S.v[low_scratch + j] = S.v[low + j];
+        OG_SYNC();
+        low = low_scratch;
+    }
+    for (int k = 0; k < recombine; k++) {
+        if (low >= 0) haar1(low, N >> k, 1 << k);
+        int lo = fill & 0xF, hi = fill >> 4; // bit_interleave_table celt.cpp:1560
+        int tl = (lo & 3 ? 1 : 0) | (lo & 12 ? 2 : 0), th = (hi & 3 ? 1 : 0) | (hi & 12 ? 2 : 0);
+        fill = tl | th << 2;
+    }
+    B >>= recombine;
+    N_B <<= recombine;
+    while ((N_B & 1) == 0 && tf_change < 0) {
+        if (low >= 0) haar1(low, N_B, B);
+        fill |= fill << B;
+        B <<= 1;
+        N_B >>= 1;
+        time_divide++;
+        tf_change++;
+    }
+    B0 = B;
+    const int N_B0 = N_B;
+    if (B0 > 1 && low >= 0) hadamard_reorder(low, N_B >> recombine, B0 << recombine, longBlocks, 0);
+    u32 cm = recon_tree(cur, spread, seed, x, N, B, low, LM, gain, fill);
+    if (B0 > 1) hadamard_reorder(x, N_B >> recombine, B0 << recombine, longBlocks, 1);
+    N_B = N_B0;
+    B = B0;
+    for (int k = 0; k < time_divide; k++) {
+        B >>= 1;
+        N_B <<= 1;
+        cm |= cm >> B;
+        haar1(x, N_B, B);
+    }
+    for (int k = 0; k < recombine; k++) {
+        u32 c4 = cm & 0xF; // bit_deinterleave_table celt.cpp:1606
+        cm = ((c4 & 1) * 0x03) | ((c4 >> 1 & 1) * 0x0C) | ((c4 >> 2 & 1) * 0x30) | ((c4 >> 3 & 1) * 0xC0);
+        haar1(x, N0 >> k, 1 << k);
+    }
+    B <<= recombine;
+    if (low_out >= 0) {
+        i32 n = tr16(celt_sqrt(shl32(N0, 22)));
+        OG_SYNC();
+        OG_FOR_LANES(j, N0) S.v[low_out + j] = (i16)mul16_q15(n, S.v[x + j]);
+        OG_SYNC();
+    }
+    return cm & ((1u << B) - 1);
+}
+
+// quant_all_bands celt.cpp:1754, vector half
+OG_DEV void recon_all_bands(int start, int end, int C, int N_ch, int shortBlocks, int spread, int dual_stereo, int intensity, int LM,
+                            u32 &seed_io) {
+    const u32 *W = rec_words();
+    const int M = 1 << LM, B = shortBlocks ? M : 1;
+    const int norm_offset = M * rom_eband[start];
+    const int norm = V_NORM, norm2 = V_NORM + M * rom_eband[NBANDS - 1] - norm_offset;
+    // The reference borrows the last band's spectrum slot as scratch; here that slot already holds the band's
+    // decoded pulses, so the scratch row lives in the (otherwise unused) pulse row.
+    int low_scratch = V_IY;
+    int lowband_offset = 0, update_lowband = 1, cur = 0;
+    u32 seed = seed_io;
+    for (int i = start; i < end; i++) {
+        const int last = i == end - 1;
+        const int eb0 = M * rom_eband[i], N = M * rom_eband[i + 1] - eb0;
+        const int x = V_X + eb0, y = C == 2 ? V_X + N_ch + eb0 : -1;
+        const u32 bw = (u32)OG_UNI(W[cur]);
+        cur++;
+        if ((eb0 - N >= M * rom_eband[start] || i == start + 1) && (update_lowband || lowband_offset == 0))
+            lowband_offset = i;
+        if (i == start + 1) { // special_hybrid_folding celt.cpp:1743
+            int n1 = M * (rom_eband[start + 1] - rom_eband[start]), n2 = M * (rom_eband[start + 2] - rom_eband[start + 1]);
+            if (n2 > n1) {
+                OG_SYNC();
+                OG_FOR_LANES(j, n2 - n1) {
+                    S.v[norm + n1 + j] = S.v[norm + 2 * n1 - n2 + j];
+                    if (dual_stereo) S.v[norm2 + n1 + j] = S.v[norm2 + 2 * n1 - n2 + j];
+                }
+                OG_SYNC();
+            }
+        }
+        const int tf_change = OG_UNI(S.tf_res[i]);
+        if (last) low_scratch = -1;
+        int effective_lowband = -1;
+        u32 x_cm, y_cm;
+        if (lowband_offset != 0 && (spread != 3 || B > 1 || tf_change < 0)) {
+            effective_lowband = OG_MAX(0, M * rom_eband[lowband_offset] - norm_offset - N);
+            int fold_start = lowband_offset;
+            while (M * rom_eband[--fold_start] > effective_lowband + norm_offset) {}
+            int fold_end = lowband_offset - 1;
+            while (++fold_end < i && M * rom_eband[fold_end] < effective_lowband + norm_offset + N) {}
+            x_cm = y_cm = 0;
+            int fold_i = fold_start;
+            do {
+                x_cm |= (u32)OG_UNI(S.cmask[fold_i * C + 0]);
+                y_cm |= (u32)OG_UNI(S.cmask[fold_i * C + C - 1]);
+            } while (++fold_i < fold_end);
+        } else
+            x_cm = y_cm = (1u << B) - 1;
+        if (dual_stereo && i == intensity) {
+            dual_stereo = 0;
+            OG_SYNC();
+            OG_FOR_LANES(j, eb0 - norm_offset) S.v[norm + j] = (i16)((S.v[norm + j] + S.v[norm2 + j]) >> 1);
+            OG_SYNC();
+        }
+        const int low1 = effective_lowband != -1 ? norm + effective_lowband : -1;
+        const int low2 = effective_lowband != -1 ? norm2 + effective_lowband : -1;
+        const int out1 = last ? -1 : norm + eb0 - norm_offset;
+        const int out2 = last ? -1 : norm2 + eb0 - norm_offset;
+
+        if (N == 1) { // quant_band_n1 celt.cpp:1357
+            OG_SYNC();
+            S.v[x] = (i16)((bw & BW_SIGN0) ? -16384 : 16384);
+            if (y >= 0) S.v[y] = (i16)((bw & BW_SIGN1) ? -16384 : 16384);
+            OG_SYNC();
+            if (out1 >= 0) S.v[out1] = (i16)(S.v[x] >> 4);
+            if (dual_stereo && out2 >= 0) S.v[out2] = (i16)(S.v[y] >> 4);
+            OG_SYNC();
+            x_cm = y_cm = 1;
+        } else {
+            const int stereo = (y >= 0) && !dual_stereo;
+            i32 fill0 = (i32)(x_cm | y_cm);
+            const i32 orig_fill = fill0;
+            i32 imid = 0, iside = 0;
+            const int itheta = (int)((bw >> BW_ITHETA_SHIFT) & 0x7fff), mid_first = (bw & BW_MID_FIRST) != 0;
+            int n2case = 0, swap_c = 0, njobs = 1;
+            if (stereo) {
+                theta_gains(itheta, B, imid, iside, fill0);
+                if (N == 2) {
+                    n2case = 1;
+                    swap_c = itheta > 8192;
+                } else
+                    njobs = 2;
+            } else if (dual_stereo)
+                njobs = 2;
+            u32 cm0 = 0, cm1 = 0;
+            for (int jb = 0; jb < njobs; jb++) {
+                int jx, jlow, jout, jscr;
+                i32 jgain, jfill;
+                if (dual_stereo) {
+                    jx = jb ? y : x; jlow = jb ? low2 : low1; jout = jb ? out2 : out1; jscr = low_scratch;
+                    jgain = 32767; jfill = (i32)(jb ? y_cm : x_cm);
+                } else if (!stereo) {
+                    jx = x; jlow = low1; jout = out1; jscr = low_scratch; jgain = 32767; jfill = fill0;
+                } else if (n2case) {
+                    jx = swap_c ? y : x; jlow = low1; jout = out1; jscr = low_scratch; jgain = 32767; jfill = orig_fill;
+                } else if ((jb == 0) == (mid_first != 0)) {
+                    jx = x; jlow = low1; jout = out1; jscr = low_scratch; jgain = 32767; jfill = fill0;
+                } else {
+                    jx = y; jlow = -1; jout = -1; jscr = -1; jgain = iside; jfill = fill0 >> B;
+                }
+                const u32 cmj = recon_band_mono(cur, spread, tf_change, seed, jx, N, B, jlow, LM, jout, jgain, jscr, jfill);
+                if (jb == 0) cm0 = cmj; else cm1 = cmj;
+            }
+            if (stereo) {
+                if (n2case) { // N == 2: the side is the mid rotated by 90 degrees (celt.cpp:1659-1697)
+                    const int x2 = swap_c ? y : x, sign = (bw & BW_SIGN) ? -1 : 1;
+                    OG_SYNC();
+                    const i32 a0 = S.v[x2], a1 = S.v[x2 + 1];
+                    const i32 b0 = tr16(-sign * a1), b1 = tr16(sign * a0);
+                    i32 X0 = swap_c ? b0 : a0, X1 = swap_c ? b1 : a1, Y0 = swap_c ? a0 : b0, Y1 = swap_c ? a1 : b1;
+                    X0 = tr16(mul16_q15(imid, X0));
+                    X1 = tr16(mul16_q15(imid, X1));
+                    Y0 = tr16(mul16_q15(iside, Y0));
+                    Y1 = tr16(mul16_q15(iside, Y1));
+                    OG_SYNC();
+                    S.v[x] = (i16)sub16(X0, Y0);
+                    S.v[y] = (i16)add16(X0, Y0);
+                    S.v[x + 1] = (i16)sub16(X1, Y1);
+                    S.v[y + 1] = (i16)add16(X1, Y1);
+                    OG_SYNC();
+                } else
+                    stereo_merge(x, y, imid, N);
+                if (bw & BW_INV) {
+                    OG_SYNC();
+                    OG_FOR_LANES(j, N) S.v[y + j] = (i16)(-S.v[y + j]);
+                    OG_SYNC();
+                }
+                x_cm = y_cm = cm0 | cm1;
+            } else if (dual_stereo) {
+                x_cm = cm0;
+                y_cm = cm1;
+            } else
+                x_cm = y_cm = cm0;
+        }
+        S.cmask[i * C + 0] = (u8)x_cm;
+        S.cmask[i * C + C - 1] = (u8)y_cm;
+        update_lowband = (bw & BW_UPDATE_LOW) != 0;
+    }
+    seed_io = seed;
+}
+
+// One CELT-only frame, vector half + synthesis + stream bookkeeping (decode_frame_wave's CELT branch).
+// Returns the frame's result code (wave-uniform); PCM goes to `pcm` (960 * CC int16) on success.
+OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int ch, i16 *pcm) {
+    const u32 flags = (u32)OG_UNI(rec->flags);
+    const int ret = OG_UNI(rec->ret);
+    if (flags & RF_SKIP) return ret;
+    const int CC = st->channels, C = ch, prev_mode = st->prev_mode;
+    if (mode != prev_mode && prev_mode > 0) {
+        celt_reset_state(&st->celt);
+        OG_SYNC();
+    }
+    const u32 rng_final = (u32)OG_UNI(rec->rng_final);
+    int result = ret;
+    if (!(flags & RF_BAD_CELT)) {
+        const int LM = (int)(flags >> RF_LM_SHIFT) & 3, M = 1 << LM, N = M * 120;
+        const int transient = (flags & RF_TRANSIENT) != 0, silence = (flags & RF_SILENCE) != 0;
+        const int spread = (int)(flags >> RF_SPREAD_SHIFT) & 3, start = OG_UNI(rec->start), end = NBANDS;
+        const int n_leaves = OG_UNI(rec->n_leaves), n_words = OG_UNI(rec->n_words);
+        CeltState *cs = &st->celt;
+        // ---- stage the record and the persistent scalars
+        OG_SYNC();
+        OG_FOR_LANES(i, 2 * NBANDS) {
+            S.bandE[i] = rec->bandE[i];
+            S.logE1[i] = cs->logE1[i];
+            S.logE2[i] = cs->logE2[i];
+            S.cmask[i] = 0;
+        }
+        OG_FOR_LANES(i, NBANDS) {
+            S.pulses[i] = rec->pulses[i];
+            S.tf_res[i] = rec->tf_res[i];
+        }
+        OG_FOR_LANES(i, 2 * N) S.v[V_X + i] = 0;
+        OG_FOR_LANES(i, 1248) S.v[V_NORM + i] = 0;
+        {
+            u32 *W = rec_words();
+            OG_FOR_LANES(i, n_words) W[i] = rec->words[i];
+        }
+        OG_SYNC();
+        // ---- all PVQ leaves of the frame, one per lane
+        OG_FOR_LANES(t, n_leaves) {
+            const u32 g = rec->leaf_geom[t];
+            pvq_decode_lane((int)(g >> 11) & 255, (int)(g >> 19) & 255, rec->leaf_idx[t], V_X + (int)(g & 2047));
+        }
+        OG_SYNC();
+        u32 seed = cs->rng;
+        recon_all_bands(start, end, C, N, transient ? M : 0, spread, (flags & RF_DUAL) != 0, OG_UNI(rec->intensity), LM, seed);
+        if (flags & RF_ANTI_COLLAPSE) anti_collapse(LM, C, N, start, end, seed);
+        if (silence) {
+            OG_SYNC();
+            OG_FOR_LANES(i, C * NBANDS) S.bandE[i] = (i16)(-28 * 1024);
+        }
+        OG_TAP(1);
+        CeltSynth sp;
+        sp.N = N; sp.LM = LM; sp.C = C; sp.CC = CC; sp.start = start; sp.end = end; sp.silence = silence; sp.transient = transient;
+        sp.pf_pitch = OG_UNI(rec->pf_pitch); sp.pf_tapset = OG_UNI(rec->pf_tapset); sp.pf_gain = OG_UNI(rec->pf_gain);
+        sp.rng_final = rng_final; sp.rc_error = (flags & RF_RC_ERROR) != 0;
+        celt_synthesis(cs, sp);
+        if (flags & RF_TELL_OVERFLOW) result = INTERNAL_ERROR;
+    }
+    if (OG_LANE == 0) {
+        st->prev_mode = mode;
+        st->frames_decoded += 1;
+        st->range_final = rng_final;
+    }
+    if (result < 0) return result;
+    OG_SYNC();
+    {
+        const u32 *src = reinterpret_cast<const u32 *>(&S.v[V_X]);
+        u32 *dst = reinterpret_cast<u32 *>(pcm);
+        OG_FOR_LANES(i, 960 * CC / 2) dst[i] = src[i];
+    }
+    return result;
+}
+
+} // namespace og
+
+#undef OG_SYNC
+#define OG_SYNC() OG_FULL_SYNC()

@@ -4,6 +4,7 @@
 // reference's hybrid->SILK transition quirk Q4), saturating mix, state update, PCM write-out.
 #pragma once
 #include "og_celt.hpp"
+#include "og_celt_split.hpp"
 #ifndef OG_NO_SILK
 #include "og_silk.hpp"
 #endif

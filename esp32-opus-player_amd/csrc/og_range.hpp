@@ -17,13 +17,21 @@ struct Rc {
     u32 offs, rng, val, ext;
     i32 rem, error;
 };
+// Lane-private flavour for the one-frame-per-LANE parse kernel: the same coder state, packet bytes read from
+// HBM through a per-lane pointer (every rc_* function below is a template over the two).
+struct RcLane : Rc {
+    const u8 *buf;
+};
 
 OG_DEV int rc_next_byte(Rc &rc) { return rc.offs < rc.storage ? S.pkt[rc.offs++] : 0; }          // :2642
 OG_DEV int rc_next_byte_end(Rc &rc) {                                                           // :2644
     return rc.end_offs < rc.storage ? S.pkt[rc.storage - ++rc.end_offs] : 0;
 }
+OG_DEV int rc_next_byte(RcLane &rc) { return rc.offs < rc.storage ? rc.buf[rc.offs++] : 0; }
+OG_DEV int rc_next_byte_end(RcLane &rc) { return rc.end_offs < rc.storage ? rc.buf[rc.storage - ++rc.end_offs] : 0; }
 
-OG_DEV void rc_renorm(Rc &rc) { // ec_dec_normalize :2649
+template <class R>
+OG_DEV void rc_renorm(R &rc) { // ec_dec_normalize :2649
     while (rc.rng <= (1u << 23)) {
         rc.nbits_total += 8;
         rc.rng <<= 8;
@@ -34,7 +42,8 @@ OG_DEV void rc_renorm(Rc &rc) { // ec_dec_normalize :2649
     }
 }
 
-OG_DEV void rc_init(Rc &rc, u32 len) { // ec_dec_init :2666
+template <class R>
+OG_DEV void rc_init(R &rc, u32 len) { // ec_dec_init :2666
     rc.storage = len;
     rc.end_offs = 0;
     rc.end_window = 0;
@@ -49,9 +58,11 @@ OG_DEV void rc_init(Rc &rc, u32 len) { // ec_dec_init :2666
     rc_renorm(rc);
 }
 
-OG_DEV i32 rc_tell(const Rc &rc) { return rc.nbits_total - ilog(rc.rng); } // celt.h:420
+template <class R>
+OG_DEV i32 rc_tell(const R &rc) { return rc.nbits_total - ilog(rc.rng); } // celt.h:420
 
-OG_DEV u32 rc_tell_frac(const Rc &rc) { // :2627
+template <class R>
+OG_DEV u32 rc_tell_frac(const R &rc) { // :2627
     u32 nbits = (u32)rc.nbits_total << 3;
     int l = ilog(rc.rng);
     u32 r = rc.rng >> (l - 16);
@@ -63,26 +74,30 @@ OG_DEV u32 rc_tell_frac(const Rc &rc) { // :2627
     return nbits - (u32)((l << 3) + b);
 }
 
-OG_DEV u32 rc_decode(Rc &rc, u32 ft) { // ec_decode :2683
+template <class R>
+OG_DEV u32 rc_decode(R &rc, u32 ft) { // ec_decode :2683
     rc.ext = rc.rng / ft;
     u32 s = rc.val / rc.ext;
     return ft - OG_MIN(s + 1, ft);
 }
 
-OG_DEV u32 rc_decode_bin(Rc &rc, unsigned bits) { // :2690
+template <class R>
+OG_DEV u32 rc_decode_bin(R &rc, unsigned bits) { // :2690
     rc.ext = rc.rng >> bits;
     u32 s = rc.val / rc.ext, top = 1u << bits;
     return top - OG_MIN(s + 1u, top);
 }
 
-OG_DEV void rc_update(Rc &rc, u32 fl, u32 fh, u32 ft) { // ec_dec_update :2697
+template <class R>
+OG_DEV void rc_update(R &rc, u32 fl, u32 fh, u32 ft) { // ec_dec_update :2697
     u32 s = rc.ext * (ft - fh);
     rc.val -= s;
     rc.rng = fl > 0 ? rc.ext * (fh - fl) : rc.rng - s;
     rc_renorm(rc);
 }
 
-OG_DEV int rc_bit_logp(Rc &rc, unsigned logp) { // :2712
+template <class R>
+OG_DEV int rc_bit_logp(R &rc, unsigned logp) { // :2712
     u32 r = rc.rng, d = rc.val, s = r >> logp;
     int ret = d < s;
     if (!ret) rc.val = d - s;
@@ -92,7 +107,8 @@ OG_DEV int rc_bit_logp(Rc &rc, unsigned logp) { // :2712
 }
 
 // inverse-CDF symbol (:2727).  `icdf` is a ROM table (global/constant memory, uniform address).
-OG_DEV int rc_icdf(Rc &rc, const u8 *icdf, unsigned ftb) {
+template <class R>
+OG_DEV int rc_icdf(R &rc, const u8 *icdf, unsigned ftb) {
     u32 s = rc.rng, d = rc.val, r = s >> ftb, t;
     int ret = -1;
     do {
@@ -105,7 +121,8 @@ OG_DEV int rc_icdf(Rc &rc, const u8 *icdf, unsigned ftb) {
     return ret;
 }
 
-OG_DEV u32 rc_bits(Rc &rc, unsigned bits) { // ec_dec_bits :2773
+template <class R>
+OG_DEV u32 rc_bits(R &rc, unsigned bits) { // ec_dec_bits :2773
     u32 window = rc.end_window;
     int available = rc.nend_bits;
     if ((u32)available < bits) {
@@ -121,7 +138,8 @@ OG_DEV u32 rc_bits(Rc &rc, unsigned bits) { // ec_dec_bits :2773
     return ret;
 }
 
-OG_DEV u32 rc_uint(Rc &rc, u32 ft_in) { // ec_dec_uint :2747
+template <class R>
+OG_DEV u32 rc_uint(R &rc, u32 ft_in) { // ec_dec_uint :2747
     ft_in--;
     int ftb = ilog(ft_in);
     if (ftb > 8) {
@@ -140,7 +158,8 @@ OG_DEV u32 rc_uint(Rc &rc, u32 ft_in) { // ec_dec_uint :2747
     return s;
 }
 
-OG_DEV int rc_laplace(Rc &rc, u32 fs, int decay) { // ec_laplace_decode :3047
+template <class R>
+OG_DEV int rc_laplace(R &rc, u32 fs, int decay) { // ec_laplace_decode :3047
     int val = 0;
     u32 fl = 0, fm = rc_decode_bin(rc, 15);
     if (fm >= fs) {

@@ -8,9 +8,18 @@ extern "C" {
 int emu_state_size(void) { return (int)sizeof(og::StreamState); }
 void emu_stream_init(void *st, int channels) { og::stream_init((og::StreamState *)st, channels); }
 void emu_stream_reset(void *st) { og::stream_reset((og::StreamState *)st); }
-int emu_decode_frame(void *st, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm) {
+// the single-kernel path (every mode)
+int emu_decode_frame_single(void *st, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm) {
     return og::decode_frame_wave((og::StreamState *)st, payload, len, mode, bw, ch, pcm);
 }
+// what the library dispatches: CELT-only frames take the split path (parse per lane, reconstruct per wave)
+int emu_decode_frame(void *st, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm) {
+    if (mode != og::MODE_CELT) return og::decode_frame_wave((og::StreamState *)st, payload, len, mode, bw, ch, pcm);
+    static og::ParseRec rec;
+    og::celt_parse_lane((const og::StreamState *)st, payload, len, ch, &rec);
+    return og::celt_recon_wave((og::StreamState *)st, &rec, mode, ch, pcm);
+}
+int emu_last_record_words(void) { return 0; }
 }
 
 // ---- stage taps -------------------------------------------------------------------------------
