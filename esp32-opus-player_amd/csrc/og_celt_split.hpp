@@ -55,7 +55,8 @@ struct ParseRec {
     i8 tf_res[NBANDS];
     i8 pad[256 - 64 - 4 * NBANDS - 2 * NBANDS - NBANDS];
     u32 leaf_idx[REC_MAX_LEAVES];  // PVQ codeword index
-    u32 leaf_geom[REC_MAX_LEAVES]; // x | N << 11 | K << 19   (x: offset into S.v[V_X..])
+    u32 leaf_geom[REC_MAX_LEAVES]; // x | N << 11 | K << 19 | (B - 1) << 27   (x: offset into S.v[V_X..])
+    i16 leaf_gain[REC_MAX_LEAVES]; // the leaf's gain (product of the split gains above it), Q15
     u32 words[REC_MAX_WORDS + 1];
 };
 static_assert(sizeof(ParseRec) % 16 == 0, "record alignment");
@@ -74,7 +75,7 @@ struct ParseLds { // [element][lane]: lanes of a wave touch consecutive addresse
             i16 thresh[NBANDS][OG_PL_LANES], trim_off[NBANDS][OG_PL_LANES];
             u16 bits1[NBANDS][OG_PL_LANES], bits2[NBANDS][OG_PL_LANES];
         } al;
-        i32 stack[5][5][OG_PL_LANES]; // split frames of the partition walk: [depth][word][lane]
+        i32 stack[5][6][OG_PL_LANES]; // split frames of the partition walk: [depth][word][lane]
     } u;
 };
 OG_LDS ParseLds PL;
@@ -105,17 +106,18 @@ struct RecWriter {
         if (nw < REC_MAX_WORDS) rec->words[nw] = w;
         nw++;
     }
-    OG_MEMBER void leaf(int x, int N, int K, u32 idx) {
+    OG_MEMBER void leaf(int x, int N, int K, int B, i32 gain, u32 idx) {
         if (nl < REC_MAX_LEAVES) {
             rec->leaf_idx[nl] = idx;
-            rec->leaf_geom[nl] = (u32)x | (u32)N << 11 | (u32)K << 19;
+            rec->leaf_geom[nl] = (u32)x | (u32)N << 11 | (u32)K << 19 | (u32)(B - 1) << 27;
+            rec->leaf_gain[nl] = (i16)gain;
         }
         nl++;
     }
 };
 
 // quant_partition celt.cpp:1382, range-decoder half: split decisions, angles, pulse counts and PVQ indices.
-OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits, int x, int N, i32 b, int B, int LM) {
+OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits, int x, int N, i32 b, int B, int LM, i32 gain) {
     int depth = 0;
     for (;;) {
         for (;;) { // descend
@@ -147,12 +149,16 @@ OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits
             F[2 * OG_PL_LANES] = sbits;
             F[3 * OG_PL_LANES] = remaining_bits;
             F[4 * OG_PL_LANES] = itheta;
+            const i32 gain_mid = tr16(mul16_p15(gain, sc.imid)), gain_side = tr16(mul16_p15(gain, sc.iside));
+            F[5 * OG_PL_LANES] = (gain_mid & 0xffff) | gain_side << 16;
             depth++;
-            if (mid_first)
+            if (mid_first) {
                 b = mbits;
-            else {
+                gain = gain_mid;
+            } else {
                 x += N;
                 b = sbits;
+                gain = gain_side;
             }
         }
         { // leaf: pulse count from the remaining budget, then the codeword index (celt.cpp:1463-1480)
@@ -166,7 +172,7 @@ OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits
             }
             const int K = q ? get_pulses(q) : 0;
             out.word((u32)K);
-            if (K) out.leaf(x, N, K, rc_uint(rc, pvq_u_rom(N, K) + pvq_u_rom(N, K + 1)));
+            if (K) out.leaf(x, N, K, B, gain, rc_uint(rc, pvq_u_rom(N, K) + pvq_u_rom(N, K + 1)));
         }
         for (;;) { // back to the parents
             if (depth == 0) return;
@@ -188,6 +194,7 @@ OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits
                 B = (w0 >> 22) & 31;
                 x = (w0 & 2047) + (mid_first ? N : 0);
                 b = mid_first ? sbits : mbits;
+                gain = mid_first ? F[5 * OG_PL_LANES] >> 16 : (i32)(i16)F[5 * OG_PL_LANES];
                 break;
             }
             depth--;
@@ -256,7 +263,7 @@ OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int 
             out.word(bw);
             for (int jb = 0; jb < njobs; jb++) {
                 int jx;
-                i32 jbits;
+                i32 jbits, jgain = 32767;
                 if (dual_stereo) {
                     jx = jb ? y : x;
                     jbits = b / 2;
@@ -278,6 +285,7 @@ OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int 
                     }
                     jx = is_mid ? x : y;
                     jbits = is_mid ? mbits : sbits;
+                    if (!is_mid) jgain = sc.iside;
                 }
                 // quant_band celt.cpp:1526: only the block count reaches the partition walk's decisions
                 int Bj = B, N_B = (int)udiv((u32)N, (u32)B), tfc = tf_change;
@@ -289,7 +297,7 @@ OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int 
                     N_B >>= 1;
                     tfc++;
                 }
-                parse_tree(rc, out, i, remaining_bits, jx, N, jbits, Bj, LM);
+                parse_tree(rc, out, i, remaining_bits, jx, N, jbits, Bj, LM, jgain);
             }
         }
         balance += pulses_i + tell;
@@ -368,10 +376,29 @@ OG_DEV void celt_parse_lane(const StreamState *st, const u8 *payload, int len, i
 // =====================================================================================================
 //  recon: one frame per wave
 // =====================================================================================================
-// Codeword index -> signed pulse vector (cwrsi celt.cpp:2545), lane-private: one PVQ leaf per lane, pulses written as
-// i16 straight into the leaf's slot of the spectrum arena (the leaf operation normalises them in place later).
-OG_DEV void pvq_decode_lane(int n, int k, u32 i, int pos) {
+// One PVQ leaf, lane-private (alg_unquant celt.cpp:782): codeword index -> signed pulse vector (cwrsi :2545),
+// scaled to the leaf's gain (normalise_residual :745), spreading rotation undone (exp_rotation :707, dir = -1),
+// collapse mask (extract_collapse_mask :760).  Everything is a serial chain per leaf, so the frame's leaves run
+// one per lane; the result is written in place at S.v[pos .. pos+n).  Returns the collapse mask.
+OG_DEV void rotate1_lane(int x, int len, int stride, i32 c, i32 s) { // exp_rotation1 celt.cpp:684
+    const i32 ms = tr16(-s);
+    for (int i = 0; i < len - stride; i++) {
+        const i32 x1 = S.v[x + i], x2 = S.v[x + i + stride];
+        S.v[x + i + stride] = (i16)pshr32(mul16(c, x2) + mul16(s, x1), 15);
+        S.v[x + i] = (i16)pshr32(mul16(c, x1) + mul16(ms, x2), 15);
+    }
+    for (int i = len - 2 * stride - 1; i >= 0; i--) {
+        const i32 x1 = S.v[x + i], x2 = S.v[x + i + stride];
+        S.v[x + i + stride] = (i16)pshr32(mul16(c, x2) + mul16(s, x1), 15);
+        S.v[x + i] = (i16)pshr32(mul16(c, x1) + mul16(ms, x2), 15);
+    }
+}
+
+OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spread) {
+    const int N = n, K = k, x = pos;
+    i32 yy = 0;
     while (n > 2) {
+        int val;
         if (k >= n) {
             const u32 *row = rom_pvq_u + n * ROM_PVQ_COLS; // n <= 14 here: U(n, .) is row n
             u32 p = row[k + 1];
@@ -388,12 +415,12 @@ OG_DEV void pvq_decode_lane(int n, int k, u32 i, int pos) {
             }
             k = lo;
             i -= row[k];
-            S.v[pos++] = (i16)((k0 - k + s) ^ s);
+            val = (k0 - k + s) ^ s;
         } else {
             const u32 p = pvq_u_rom(k, n), q = pvq_u_rom(k + 1, n);
             if (p <= i && i < q) {
                 i -= p;
-                S.v[pos++] = 0;
+                val = 0;
             } else {
                 const int s = -(int)(i >= q);
                 i -= q & (u32)s;
@@ -402,47 +429,79 @@ OG_DEV void pvq_decode_lane(int n, int k, u32 i, int pos) {
                 do pp = pvq_u_rom(--k, n);
                 while (pp > i);
                 i -= pp;
-                S.v[pos++] = (i16)((k0 - k + s) ^ s);
+                val = (k0 - k + s) ^ s;
             }
         }
+        S.v[pos++] = (i16)val;
+        yy += val * val;
         n--;
     }
-    const u32 p = 2 * (u32)k + 1;
-    int s = -(int)(i >= p);
-    i -= p & (u32)s;
-    const int k0 = k;
-    k = (int)((i + 1) >> 1);
-    if (k) i -= 2 * (u32)k - 1;
-    S.v[pos++] = (i16)((k0 - k + s) ^ s);
-    s = -(int)i;
-    S.v[pos] = (i16)((k + s) ^ s);
+    {
+        const u32 p = 2 * (u32)k + 1;
+        int s = -(int)(i >= p);
+        i -= p & (u32)s;
+        const int k0 = k;
+        k = (int)((i + 1) >> 1);
+        if (k) i -= 2 * (u32)k - 1;
+        int val = (k0 - k + s) ^ s;
+        S.v[pos++] = (i16)val;
+        yy += val * val;
+        s = -(int)i;
+        val = (k + s) ^ s;
+        S.v[pos] = (i16)val;
+        yy += val * val;
+    }
+    // collapse mask from the pulses, then scale them in place
+    u32 cm = 1;
+    if (B > 1) {
+        const int N0 = (int)udiv((u32)N, (u32)B);
+        cm = 0;
+        for (int b = 0, j = 0; b < B; b++) {
+            u32 any = 0;
+            for (int e = 0; e < N0; e++, j++) any |= (u32)(u16)S.v[x + j];
+            cm |= (u32)(any != 0) << b;
+        }
+    }
+    const int kk = ilog2(yy) >> 1;
+    const i32 t = vshr32(yy, 2 * (kk - 7));
+    const i32 g = tr16(mul16_p15(rsqrt_norm(t), gain));
+    for (int j = 0; j < N; j++) S.v[x + j] = (i16)pshr32(mul16(g, S.v[x + j]), kk + 1);
+    if (2 * K < N && spread != 0) {
+        const int factor = spread == 1 ? 15 : (spread == 2 ? 10 : 5);
+        const i32 rg = tr16(mul32_q31(mul16(32767, N), celt_rcp(N + factor * K))); // celt_div celt.h:367
+        const i32 theta = tr16(mul16_q15(rg, rg) >> 1);
+        const i32 c = cos_norm(theta), s = cos_norm(sub16(32767, theta));
+        int stride2 = 0;
+        if (N >= 8 * B) {
+            stride2 = 1;
+            while ((stride2 * stride2 + stride2) * B + (B >> 2) < N) stride2++;
+        }
+        const int blen = (int)udiv((u32)N, (u32)B);
+        for (int blk = 0; blk < B; blk++) {
+            if (stride2) rotate1_lane(x + blk * blen, blen, stride2, s, c);
+            rotate1_lane(x + blk * blen, blen, 1, c, s);
+        }
+    }
+    return cm;
 }
+
+// Collapse masks of the frame's PVQ leaves, in decode order (LDS: the packet staging area is unused on this path).
+OG_DEV u16 *leaf_masks() { return reinterpret_cast<u16 *>(&S.pkt[0]); }
+static_assert(sizeof(FrameLds::pkt) >= sizeof(u16) * REC_MAX_LEAVES, "leaf masks must fit the packet buffer");
 
 // The record's words, staged in LDS over the (not yet needed) synthesis buffer.
 OG_DEV u32 *rec_words() { return reinterpret_cast<u32 *>(&S.syn[0][0]); }
 static_assert(sizeof(FrameLds::syn) >= sizeof(u32) * (REC_MAX_WORDS + 1), "record words must fit the synthesis buffer");
 
-// Leaf of the partition tree, vector half (celt.cpp:1463-1520, alg_unquant :782); the pulses of a K > 0 leaf are
-// already in S.v[x..x+N).
-OG_DEV u32 recon_leaf(int K, int spread, u32 &seed_io, int x, int N, int B, int low, i32 gain, i32 fill) {
-    if (K != 0) {
-        OG_SYNC();
-        const u32 N0 = B > 1 ? udiv((u32)N, (u32)B) : (u32)N;
-        i32 part = 0;
-        u32 m = 0;
-        OG_FOR_LANES(j, N) {
-            const i32 v = S.v[x + j];
-            part += v * v;
-            m |= (u32)(v != 0) << udiv((u32)j, N0);
-        }
-        const i32 Ryy = wave_sum(part);
-        const int k = ilog2(Ryy) >> 1;
-        const i32 t = vshr32(Ryy, 2 * (k - 7));
-        const i32 g = tr16(mul16_p15(rsqrt_norm(t), gain));
-        OG_FOR_LANES(j, N) S.v[x + j] = (i16)pshr32(mul16(g, S.v[x + j]), k + 1); // normalise_residual :745
-        unspread(x, N, B, K, spread);
-        if (B <= 1) return 1;
-        return wave_or(m); // extract_collapse_mask :760
+// Leaf of the partition tree, vector half (celt.cpp:1463-1520): a K > 0 leaf is complete already (pvq_leaf_lane),
+// a leaf without pulses is zeroed, noise-filled or folded from the lower band.
+struct RecCur { int w, leaf; }; // read positions in the record: next word, next PVQ leaf
+
+OG_DEV u32 recon_leaf(RecCur &cur, int K, u32 &seed_io, int x, int N, int B, int low, i32 gain, i32 fill) {
+    if (K != 0) { // decoded, scaled and de-rotated by the leaf pass already: only the collapse mask is needed
+        const u32 cm = (u32)OG_UNI(leaf_masks()[cur.leaf]);
+        cur.leaf++;
+        return cm;
     }
     const u32 cm_mask = (u32)((1ull << B) - 1);
     fill &= (i32)cm_mask;
@@ -489,12 +548,12 @@ OG_DEV void theta_gains(int itheta, int B, i32 &imid, i32 &iside, i32 &fill) {
 }
 
 // quant_partition celt.cpp:1382, vector half, driven by the record's node words
-OG_DEV u32 recon_tree(int &cur, int spread, u32 &seed, int x, int N, int B, int low, int LM, i32 gain, i32 fill) {
+OG_DEV u32 recon_tree(RecCur &cur, int spread, u32 &seed, int x, int N, int B, int low, int LM, i32 gain, i32 fill) {
     const u32 *W = rec_words();
     int depth = 0;
     for (;;) {
-        u32 w = (u32)OG_UNI(W[cur]);
-        cur++;
+        u32 w = (u32)OG_UNI(W[cur.w]);
+        cur.w++;
         while (w & NW_SPLIT) {
             const int itheta = (int)(w & 0x7fff), mid_first = (w & NW_MID_FIRST) != 0, B0 = B;
             N >>= 1;
@@ -516,10 +575,10 @@ OG_DEV u32 recon_tree(int &cur, int spread, u32 &seed, int x, int N, int B, int 
                 gain = tr16(mul16_p15(gain, iside));
                 fill = fill >> B;
             }
-            w = (u32)OG_UNI(W[cur]);
-            cur++;
+            w = (u32)OG_UNI(W[cur.w]);
+            cur.w++;
         }
-        u32 cm = recon_leaf((int)(w & 255), spread, seed, x, N, B, low, gain, fill);
+        u32 cm = recon_leaf(cur, (int)(w & 255), seed, x, N, B, low, gain, fill);
         for (;;) {
             if (depth == 0) return cm;
             ReconFrame &F = g_rframe[depth - 1];
@@ -550,7 +609,7 @@ OG_DEV u32 recon_tree(int &cur, int spread, u32 &seed, int x, int N, int B, int 
 }
 
 // quant_band celt.cpp:1526, vector half; N > 1
-OG_DEV u32 recon_band_mono(int &cur, int spread, int tf_change, u32 &seed, int x, int N, int B, int low, int LM, int low_out,
+OG_DEV u32 recon_band_mono(RecCur &cur, int spread, int tf_change, u32 &seed, int x, int N, int B, int low, int LM, int low_out,
                            i32 gain, int low_scratch, i32 fill) {
     int N0 = N, N_B, B0 = B, time_divide = 0, recombine = 0;
     const int longBlocks = B0 == 1;
@@ -616,14 +675,17 @@ OG_DEV void recon_all_bands(int start, int end, int C, int N_ch, int shortBlocks
     // The reference borrows the last band's spectrum slot as scratch; here that slot already holds the band's
     // decoded pulses, so the scratch row lives in the (otherwise unused) pulse row.
     int low_scratch = V_IY;
-    int lowband_offset = 0, update_lowband = 1, cur = 0;
+    int lowband_offset = 0, update_lowband = 1;
+    RecCur cur;
+    cur.w = 0;
+    cur.leaf = 0;
     u32 seed = seed_io;
     for (int i = start; i < end; i++) {
         const int last = i == end - 1;
         const int eb0 = M * rom_eband[i], N = M * rom_eband[i + 1] - eb0;
         const int x = V_X + eb0, y = C == 2 ? V_X + N_ch + eb0 : -1;
-        const u32 bw = (u32)OG_UNI(W[cur]);
-        cur++;
+        const u32 bw = (u32)OG_UNI(W[cur.w]);
+        cur.w++;
         if ((eb0 - N >= M * rom_eband[start] || i == start + 1) && (update_lowband || lowband_offset == 0))
             lowband_offset = i;
         if (i == start + 1) { // special_hybrid_folding celt.cpp:1743
@@ -786,12 +848,19 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
             OG_FOR_LANES(i, n_words) W[i] = rec->words[i];
         }
         OG_SYNC();
+#if defined(OG_RABL) && OG_RABL == 1
+        return ret;
+#endif
         // ---- all PVQ leaves of the frame, one per lane
         OG_FOR_LANES(t, n_leaves) {
             const u32 g = rec->leaf_geom[t];
-            pvq_decode_lane((int)(g >> 11) & 255, (int)(g >> 19) & 255, rec->leaf_idx[t], V_X + (int)(g & 2047));
+            leaf_masks()[t] = (u16)pvq_leaf_lane((int)(g >> 11) & 255, (int)(g >> 19) & 255, rec->leaf_idx[t], V_X + (int)(g & 2047),
+                                                 (int)(g >> 27) + 1, rec->leaf_gain[t], spread);
         }
         OG_SYNC();
+#if defined(OG_RABL) && OG_RABL == 2
+        return ret;
+#endif
         u32 seed = cs->rng;
         recon_all_bands(start, end, C, N, transient ? M : 0, spread, (flags & RF_DUAL) != 0, OG_UNI(rec->intensity), LM, seed);
         if (flags & RF_ANTI_COLLAPSE) anti_collapse(LM, C, N, start, end, seed);
@@ -800,6 +869,9 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
             OG_FOR_LANES(i, C * NBANDS) S.bandE[i] = (i16)(-28 * 1024);
         }
         OG_TAP(1);
+#if defined(OG_RABL) && OG_RABL == 3
+        return ret;
+#endif
         CeltSynth sp;
         sp.N = N; sp.LM = LM; sp.C = C; sp.CC = CC; sp.start = start; sp.end = end; sp.silence = silence; sp.transient = transient;
         sp.pf_pitch = OG_UNI(rec->pf_pitch); sp.pf_tapset = OG_UNI(rec->pf_tapset); sp.pf_gain = OG_UNI(rec->pf_gain);

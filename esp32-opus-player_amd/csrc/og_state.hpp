@@ -93,7 +93,7 @@ constexpr int SYN_LEN = 1088;  // 960 + 120 (+8 pad)
 struct FrameLds {
     i32 syn[2][SYN_LEN];       // IMDCT work / out_syn per output channel
     i16 v[V_TOTAL];
-    u8 pkt[1280];
+    u8 pkt[1344];              // packet bytes (<= 1275); the split path keeps its per-leaf collapse masks here
     i32 pulses[NBANDS], fine_quant[NBANDS], fine_prio[NBANDS], tf_res[NBANDS], cap[NBANDS], offsets[NBANDS];
     i32 bits1[NBANDS], bits2[NBANDS], thresh[NBANDS], trim_off[NBANDS];
     i16 bandE[2 * NBANDS], logE1[2 * NBANDS], logE2[2 * NBANDS];
