@@ -30,6 +30,9 @@ __global__ void __launch_bounds__(64) k_stream_init(StreamState *st, int first, 
 #ifndef OG_WAVES_PER_SIMD
 #define OG_WAVES_PER_SIMD 1
 #endif
+#ifndef OG_RECON_WAVES
+#define OG_RECON_WAVES 2
+#endif
 __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
                                                    StreamState *st, i16 *pcm, i32 *result, int n, int n_streams,
                                                    int pcm_stride, int skip_celt) {
@@ -61,7 +64,7 @@ __global__ void __launch_bounds__(64, 2) k_celt_parse(const FrameDesc *__restric
 }
 
 // Split CELT path, second half: one frame per wave, driven by the parse record.
-__global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_celt_recon(const FrameDesc *__restrict__ descs, StreamState *st,
+__global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDesc *__restrict__ descs, StreamState *st,
                                                                       const ParseRec *recs, i16 *pcm, i32 *result, int n,
                                                                       int n_streams, int pcm_stride) {
     const int f = (int)blockIdx.x;

@@ -108,7 +108,7 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
 #ifndef OG_NO_SILK
     if (mode != MODE_CELT) { // SAT16(outbuf + pcm_silk) over audiosize*stream_channels entries (Q3)
         OG_SYNC();
-        OG_FOR_LANES(i, audiosize * ch) S.v[V_X + i] = (i16)sat16((i32)S.v[V_X + i] + (i32)S.pcm_silk[i]);
+        OG_FOR_LANES(i, audiosize * ch) S.v[V_X + i] = (i16)sat16((i32)S.v[V_X + i] + (i32)g_pcm_silk[i]);
         OG_SYNC();
     }
 #endif

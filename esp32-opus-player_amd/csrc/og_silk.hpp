@@ -883,7 +883,7 @@ OG_DEVN int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz
                 res = smlabb(res, b[5], f1[2]);
                 res = smlabb(res, b[6], f1[1]);
                 res = smlabb(res, b[7], f1[0]);
-                S.pcm_silk[(out0 + m) * channels + n] = (i16)sat16(rshift_round(res, 15));
+                g_pcm_silk[(out0 + m) * channels + n] = (i16)sat16(rshift_round(res, 15));
             }
             t0 += nIn;
             out0 += count;

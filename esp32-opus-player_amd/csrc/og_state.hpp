@@ -100,7 +100,7 @@ struct FrameLds {
     i16 dn_g[2 * NBANDS], dn_shift[2 * NBANDS];
     u8 cmask[2 * NBANDS];
     u8 bin2band[120];
-    i16 pcm_silk[1920];        // SILK output at 48 kHz for the hybrid / SILK-only mix
+
 };
 
 } // namespace og
