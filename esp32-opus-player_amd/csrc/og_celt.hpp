@@ -507,13 +507,31 @@ OG_DEV const i16 *bitrev_for(int shift) {
     return shift == 0 ? rom_bitrev480 : shift == 1 ? rom_bitrev240 : shift == 2 ? rom_bitrev120 : rom_bitrev60;
 }
 
-// Inverse MDCT of every block of every output channel (clt_mdct_backward celt.cpp:3204), reading
+// The i32 synthesis buffer of the channel being synthesised (overlays norm | iy | tmp | pkt, see og_state.hpp).
+OG_DEV i32 *syn_buf() { return reinterpret_cast<i32 *>(&S.v[V_NORM]); }
+// Where channel co's PCM plane (960 x i16) goes inside the dead X region: the half this and later channels no longer read.
+OG_DEV int pcm_plane(int co, int C, int CC) { return V_X + 960 * ((C == 1 && CC == 2) ? 1 - co : co); }
+
+// PCM planes in LDS -> interleaved int16 PCM in HBM, two samples per lane-store, coalesced.
+OG_DEV void pcm_store(i16 *pcm, int n, int C, int CC) {
+    u32 *dst = reinterpret_cast<u32 *>(pcm);
+    if (CC == 2) {
+        const int p0 = pcm_plane(0, C, CC), p1 = pcm_plane(1, C, CC);
+        OG_FOR_LANES(j, n) dst[j] = (u32)(u16)S.v[p0 + j] | (u32)(u16)S.v[p1 + j] << 16;
+    } else {
+        const u32 *src = reinterpret_cast<const u32 *>(&S.v[pcm_plane(0, C, CC)]);
+        OG_FOR_LANES(i, n / 2) dst[i] = src[i];
+    }
+}
+
+// Inverse MDCT of every block of one output channel (clt_mdct_backward celt.cpp:3204), reading
 // the denormalised coefficients on the fly.  B blocks of NBk = N/B outputs, transform size 2*NBk.
-OG_DEVN void imdct_all(int N, int LM, int B, int shift, int C, int CC) {
+OG_DEVN void imdct_channel(int co, int N, int LM, int B, int shift, int C, int CC) {
     const int NBk = N / B, N2 = NBk, N4 = N2 >> 1;
     const i16 *trig = rom_mdct_trig + (shift == 0 ? 0 : shift == 1 ? 960 : shift == 2 ? 1440 : 1680);
     const i16 *br = bitrev_for(shift);
-    for (int co = 0; co < CC; co++) {
+    i32 *const SY = syn_buf();
+    {
         OG_SYNC();
         OG_FOR_LANES(id, B * N4) { // pre-rotation into digit-reversed order
             int b = id / N4, i = id - b * N4;
@@ -522,16 +540,16 @@ OG_DEVN void imdct_all(int N, int LM, int B, int shift, int C, int CC) {
             i32 t0 = trig[i], t1 = trig[N4 + i];
             i32 yr = addw(OG_SMUL(x2, t0), OG_SMUL(x1, t1));
             i32 yi = subw(OG_SMUL(x1, t0), OG_SMUL(x2, t1));
-            i32 *yp = &S.syn[co][NBk * b + (OVERLAP >> 1)];
+            i32 *yp = &SY[NBk * b + (OVERLAP >> 1)];
             int rev = br[i];
             yp[2 * rev + 1] = yr;
             yp[2 * rev] = yi;
         }
-        fft_blocks(&S.syn[co][OVERLAP >> 1], B, NBk, shift);
+        fft_blocks(&SY[OVERLAP >> 1], B, NBk, shift);
         OG_FOR_LANES(id, B * (N4 >> 1)) { // post-rotation, pairs (i, N4-1-i)
             int b = id / (N4 >> 1), i = id - b * (N4 >> 1);
-            i32 *yp0 = &S.syn[co][NBk * b + (OVERLAP >> 1) + 2 * i];
-            i32 *yp1 = &S.syn[co][NBk * b + (OVERLAP >> 1) + N2 - 2 - 2 * i];
+            i32 *yp0 = &SY[NBk * b + (OVERLAP >> 1) + 2 * i];
+            i32 *yp1 = &SY[NBk * b + (OVERLAP >> 1) + N2 - 2 - 2 * i];
             i32 re = yp0[1], im = yp0[0];
             i32 t0 = trig[i], t1 = trig[N4 + i];
             i32 yr = addw(OG_SMUL(re, t0), OG_SMUL(im, t1));
@@ -550,24 +568,24 @@ OG_DEVN void imdct_all(int N, int LM, int B, int shift, int C, int CC) {
         OG_SYNC();
         OG_FOR_LANES(id, B * (OVERLAP / 2)) { // TDAC mirror
             int b = id / (OVERLAP / 2), i = id - b * (OVERLAP / 2);
-            i32 *o = &S.syn[co][NBk * b];
+            i32 *o = &SY[NBk * b];
             i32 x1 = o[OVERLAP - 1 - i], x2 = o[i];
             i32 w1 = rom_win120[i], w2 = rom_win120[OVERLAP - 1 - i];
             o[i] = subw(mul16x32_q15(w2, x2), mul16x32_q15(w1, x1));
             o[OVERLAP - 1 - i] = addw(mul16x32_q15(w1, x2), mul16x32_q15(w2, x1));
         }
         OG_SYNC();
-        OG_FOR_LANES(i, N) S.syn[co][i] = clampsym(S.syn[co][i], SIG_SAT);
+        OG_FOR_LANES(i, N) SY[i] = clampsym(SY[i], SIG_SAT);
         OG_SYNC();
     }
 }
 
 // sample `idx` of channel c's synthesis signal: >= 0 in LDS (this frame), < 0 in the HBM ring
 OG_DEV i32 syn_at(const CeltState *st, int c, int idx) {
-    return idx >= 0 ? S.syn[c][idx] : st->ring[c][(st->ring_pos + idx) & RING_MASK];
+    return idx >= 0 ? syn_buf()[idx] : st->ring[c][(st->ring_pos + idx) & RING_MASK];
 }
 
-// In-place pitch comb filter on S.syn[c][off .. off+N) (comb_filter celt.cpp:848).  In place the filter
+// In-place pitch comb filter on the synthesis buffer [off .. off+N) of channel c (comb_filter celt.cpp:848).  In place the filter
 // is recursive with delay >= min(T0,T1)-2 >= 13 samples, so samples are produced in chunks of that
 // many (at most 64), one lane each; all taps of a chunk are already final.
 OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, int N, i32 g0, i32 g1, int tap0, int tap1) {
@@ -590,7 +608,7 @@ OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, in
             const int i = base + l;
             if (i >= end) continue;
             int p = off + i;
-            i32 y = S.syn[c][p];
+            i32 y = syn_buf()[p];
             i32 a2 = syn_at(st, c, p - T1), a1 = syn_at(st, c, p - T1 + 1), a3 = syn_at(st, c, p - T1 - 1),
                 a0 = syn_at(st, c, p - T1 + 2), a4 = syn_at(st, c, p - T1 - 2);
             if (i < overlap) {
@@ -603,7 +621,7 @@ OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, in
             } else {
                 y = y + mul16x32_q15(g10, a2) + mul16x32_q15(g11, a1 + a3) + mul16x32_q15(g12, a0 + a4);
             }
-            S.syn[c][p] = clampsym(y, SIG_SAT);
+            syn_buf()[p] = clampsym(y, SIG_SAT);
         }
     }
     OG_SYNC();
@@ -766,28 +784,7 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
     const int N = p.N, LM = p.LM, C = p.C, CC = p.CC, start = p.start, end = p.end, silence = p.silence, transient = p.transient;
     const int pf_pitch = p.pf_pitch, pf_tapset = p.pf_tapset, M = 1 << LM;
     const i32 pf_gain = p.pf_gain;
-    OG_SYNC();
-    for (int c = 0; c < CC; c++) OG_FOR_LANES(i, OVERLAP / 2) S.syn[c][i] = st->tail[c][i];
     denorm_gains(start, end, C, silence);
-    const int B = transient ? M : 1, shift = transient ? 3 : 3 - LM;
-    imdct_all(N, LM, B, shift, C, CC);
-    OG_TAP(2); // IMDCT output
-#if defined(OG_ABLATE) && OG_ABLATE == 3
-    return;
-#endif
-
-    int pp = OG_MAX(st->pf_period, 15), ppo = OG_MAX(st->pf_period_old, 15);
-    i32 pg = st->pf_gain, pgo = st->pf_gain_old;
-    int pt = st->pf_tapset, pto = st->pf_tapset_old;
-    for (int c = 0; c < CC; c++) {
-        comb_filter(st, c, 0, ppo, pp, 120, pgo, pg, pto, pt);
-        if (LM != 0) comb_filter(st, c, 120, pp, pf_pitch, N - 120, pg, pf_gain, pt, pf_tapset);
-    }
-
-    OG_TAP(3); // comb filter output
-#if defined(OG_ABLATE) && OG_ABLATE == 4
-    return;
-#endif
     // ---- energy history (celt.cpp:2404-2436)
     OG_SYNC();
     if (C == 1) {
@@ -810,25 +807,41 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
         st->logE1[i] = (i16)l1;
         st->logE2[i] = (i16)l2;
     }
-
-    // ---- de-emphasis (celt.cpp:1965-2055): one lane per channel, PCM staged in LDS over the dead X region
-    OG_SYNC();
-    OG_FOR_LANES(c, CC) {
-        i32 m = st->deemph[c];
-        for (int j = 0; j < N; j++) {
-            i32 tmp = S.syn[c][j] + m;
-            m = mul16x32_q15(27853, tmp);
-            S.v[V_X + j * CC + c] = (i16)sat16(pshr32(tmp, 12)); // sig2word16 celt.h:413
-        }
-        st->deemph[c] = m;
-    }
-    OG_SYNC();
-
-    // ---- write back history ring, overlap tail and scalars
+    const int B = transient ? M : 1, shift = transient ? 3 : 3 - LM;
+    const int pp = OG_MAX(st->pf_period, 15), ppo = OG_MAX(st->pf_period_old, 15);
+    const i32 pg = st->pf_gain, pgo = st->pf_gain_old;
+    const int pt = st->pf_tapset, pto = st->pf_tapset_old;
     const int pos = st->ring_pos;
+    i32 *const SY = syn_buf();
+    // ---- one output channel at a time through the single synthesis buffer
     for (int c = 0; c < CC; c++) {
-        OG_FOR_LANES(i, N) st->ring[c][(pos + i) & RING_MASK] = S.syn[c][i];
-        OG_FOR_LANES(i, OVERLAP / 2) st->tail[c][i] = S.syn[c][N + i];
+        OG_SYNC();
+        OG_FOR_LANES(i, OVERLAP / 2) SY[i] = st->tail[c][i];
+        imdct_channel(c, N, LM, B, shift, C, CC);
+        OG_TAP(2 + 16 * c); // IMDCT output
+#if !(defined(OG_ABLATE) && OG_ABLATE == 3)
+        comb_filter(st, c, 0, ppo, pp, 120, pgo, pg, pto, pt);
+        if (LM != 0) comb_filter(st, c, 120, pp, pf_pitch, N - 120, pg, pf_gain, pt, pf_tapset);
+        OG_TAP(3 + 16 * c); // comb filter output
+#if !(defined(OG_ABLATE) && OG_ABLATE == 4)
+        // de-emphasis (celt.cpp:1965-2055): a rounding IIR, serial; the PCM plane replaces a dead half of X
+        OG_SYNC();
+        if (OG_LANE == 0) {
+            const int plane = pcm_plane(c, C, CC);
+            i32 m = st->deemph[c];
+            for (int j = 0; j < N; j++) {
+                i32 tmp = SY[j] + m;
+                m = mul16x32_q15(27853, tmp);
+                S.v[plane + j] = (i16)sat16(pshr32(tmp, 12)); // sig2word16 celt.h:413
+            }
+            st->deemph[c] = m;
+        }
+        OG_SYNC();
+        // history ring and overlap tail
+        OG_FOR_LANES(i, N) st->ring[c][(pos + i) & RING_MASK] = SY[i];
+        OG_FOR_LANES(i, OVERLAP / 2) st->tail[c][i] = SY[N + i];
+#endif
+#endif
     }
     OG_SYNC();
     if (OG_LANE == 0) {

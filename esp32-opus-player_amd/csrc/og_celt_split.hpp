@@ -57,7 +57,7 @@ struct ParseRec {
     u32 leaf_idx[REC_MAX_LEAVES];  // PVQ codeword index
     u32 leaf_geom[REC_MAX_LEAVES]; // x | N << 11 | K << 19 | (B - 1) << 27   (x: offset into S.v[V_X..])
     i16 leaf_gain[REC_MAX_LEAVES]; // the leaf's gain (product of the split gains above it), Q15
-    u32 words[REC_MAX_WORDS + 1];
+    u32 words[(REC_MAX_WORDS + 64) / 64 * 64]; // read in windows of 64
 };
 static_assert(sizeof(ParseRec) % 16 == 0, "record alignment");
 
@@ -489,14 +489,24 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
 OG_DEV u16 *leaf_masks() { return reinterpret_cast<u16 *>(&S.pkt[0]); }
 static_assert(sizeof(FrameLds::pkt) >= sizeof(u16) * REC_MAX_LEAVES, "leaf masks must fit the packet buffer");
 
-// The record's words, staged in LDS over the (not yet needed) synthesis buffer.
-OG_DEV u32 *rec_words() { return reinterpret_cast<u32 *>(&S.syn[0][0]); }
-static_assert(sizeof(FrameLds::syn) >= sizeof(u32) * (REC_MAX_WORDS + 1), "record words must fit the synthesis buffer");
+// The record's word stream is consumed strictly in order: a 64-word window in LDS, refilled by one coalesced load.
+struct RecCur { // read positions in the record: next word, next PVQ leaf
+    const u32 *words;
+    int w, leaf;
+};
+OG_DEV u32 rec_word(RecCur &cur) {
+    if ((cur.w & 63) == 0) {
+        OG_SYNC();
+        OG_FOR_LANES(l, 64) S.win[l] = cur.words[cur.w + l];
+        OG_SYNC();
+    }
+    const u32 w = (u32)OG_UNI(S.win[cur.w & 63]);
+    cur.w++;
+    return w;
+}
 
 // Leaf of the partition tree, vector half (celt.cpp:1463-1520): a K > 0 leaf is complete already (pvq_leaf_lane),
 // a leaf without pulses is zeroed, noise-filled or folded from the lower band.
-struct RecCur { int w, leaf; }; // read positions in the record: next word, next PVQ leaf
-
 OG_DEV u32 recon_leaf(RecCur &cur, int K, u32 &seed_io, int x, int N, int B, int low, i32 gain, i32 fill) {
     if (K != 0) { // decoded, scaled and de-rotated by the leaf pass already: only the collapse mask is needed
         const u32 cm = (u32)OG_UNI(leaf_masks()[cur.leaf]);
@@ -549,11 +559,9 @@ OG_DEV void theta_gains(int itheta, int B, i32 &imid, i32 &iside, i32 &fill) {
 
 // quant_partition celt.cpp:1382, vector half, driven by the record's node words
 OG_DEV u32 recon_tree(RecCur &cur, int spread, u32 &seed, int x, int N, int B, int low, int LM, i32 gain, i32 fill) {
-    const u32 *W = rec_words();
     int depth = 0;
     for (;;) {
-        u32 w = (u32)OG_UNI(W[cur.w]);
-        cur.w++;
+        u32 w = rec_word(cur);
         while (w & NW_SPLIT) {
             const int itheta = (int)(w & 0x7fff), mid_first = (w & NW_MID_FIRST) != 0, B0 = B;
             N >>= 1;
@@ -575,8 +583,7 @@ OG_DEV u32 recon_tree(RecCur &cur, int spread, u32 &seed, int x, int N, int B, i
                 gain = tr16(mul16_p15(gain, iside));
                 fill = fill >> B;
             }
-            w = (u32)OG_UNI(W[cur.w]);
-            cur.w++;
+            w = rec_word(cur);
         }
         u32 cm = recon_leaf(cur, (int)(w & 255), seed, x, N, B, low, gain, fill);
         for (;;) {
@@ -666,9 +673,8 @@ OG_DEV u32 recon_band_mono(RecCur &cur, int spread, int tf_change, u32 &seed, in
 }
 
 // quant_all_bands celt.cpp:1754, vector half
-OG_DEV void recon_all_bands(int start, int end, int C, int N_ch, int shortBlocks, int spread, int dual_stereo, int intensity, int LM,
+OG_DEV void recon_all_bands(const u32 *words, int start, int end, int C, int N_ch, int shortBlocks, int spread, int dual_stereo, int intensity, int LM,
                             u32 &seed_io) {
-    const u32 *W = rec_words();
     const int M = 1 << LM, B = shortBlocks ? M : 1;
     const int norm_offset = M * rom_eband[start];
     const int norm = V_NORM, norm2 = V_NORM + M * rom_eband[NBANDS - 1] - norm_offset;
@@ -677,6 +683,7 @@ OG_DEV void recon_all_bands(int start, int end, int C, int N_ch, int shortBlocks
     int low_scratch = V_IY;
     int lowband_offset = 0, update_lowband = 1;
     RecCur cur;
+    cur.words = words;
     cur.w = 0;
     cur.leaf = 0;
     u32 seed = seed_io;
@@ -684,8 +691,7 @@ OG_DEV void recon_all_bands(int start, int end, int C, int N_ch, int shortBlocks
         const int last = i == end - 1;
         const int eb0 = M * rom_eband[i], N = M * rom_eband[i + 1] - eb0;
         const int x = V_X + eb0, y = C == 2 ? V_X + N_ch + eb0 : -1;
-        const u32 bw = (u32)OG_UNI(W[cur.w]);
-        cur.w++;
+        const u32 bw = rec_word(cur);
         if ((eb0 - N >= M * rom_eband[start] || i == start + 1) && (update_lowband || lowband_offset == 0))
             lowband_offset = i;
         if (i == start + 1) { // special_hybrid_folding celt.cpp:1743
@@ -843,10 +849,6 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         }
         OG_FOR_LANES(i, 2 * N) S.v[V_X + i] = 0;
         OG_FOR_LANES(i, 1248) S.v[V_NORM + i] = 0;
-        {
-            u32 *W = rec_words();
-            OG_FOR_LANES(i, n_words) W[i] = rec->words[i];
-        }
         OG_SYNC();
 #if defined(OG_RABL) && OG_RABL == 1
         return ret;
@@ -862,7 +864,7 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         return ret;
 #endif
         u32 seed = cs->rng;
-        recon_all_bands(start, end, C, N, transient ? M : 0, spread, (flags & RF_DUAL) != 0, OG_UNI(rec->intensity), LM, seed);
+        recon_all_bands(rec->words, start, end, C, N, transient ? M : 0, spread, (flags & RF_DUAL) != 0, OG_UNI(rec->intensity), LM, seed);
         if (flags & RF_ANTI_COLLAPSE) anti_collapse(LM, C, N, start, end, seed);
         if (silence) {
             OG_SYNC();
@@ -886,11 +888,7 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
     }
     if (result < 0) return result;
     OG_SYNC();
-    {
-        const u32 *src = reinterpret_cast<const u32 *>(&S.v[V_X]);
-        u32 *dst = reinterpret_cast<u32 *>(pcm);
-        OG_FOR_LANES(i, 960 * CC / 2) dst[i] = src[i];
-    }
+    pcm_store(pcm, 960, C, CC);
     return result;
 }
 

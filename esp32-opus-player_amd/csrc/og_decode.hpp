@@ -86,7 +86,7 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
         do_celt = 1;
     } else {
         OG_SYNC();
-        OG_FOR_LANES(i, audiosize * CC) S.v[V_X + i] = 0;
+        OG_FOR_LANES(i, audiosize * 2) S.v[V_X + i] = 0;
         OG_SYNC();
         if (prev_mode == MODE_HYBRID) { // Q4: start band 0, 120*CC samples at the head of the PCM staging area
             do_celt = 1;
@@ -98,17 +98,24 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
         const int r = celt_decode_frame(&st->celt, rc, celt_n, ch, CC, celt_start, disable_inv);
         if (mode != MODE_SILK)
             celt_ret = r;
-        else { // the reference ignores the return value here (src/opus_decoder.cpp:267); the CELT working vectors
-               // share the staging area: clear everything past the 120 decoded samples
+        else { // the reference ignores the return value here (src/opus_decoder.cpp:267).  Only the 120 decoded
+               // samples per channel survive; the rest of the PCM planes (which shared X with CELT's work) is zero.
             OG_SYNC();
-            OG_FOR_LANES(i, (audiosize - 120) * CC) S.v[V_X + 120 * CC + i] = 0;
+            for (int c = 0; c < CC; c++) OG_FOR_LANES(j, 120) S.v[V_IY + 120 * c + j] = S.v[pcm_plane(c, ch, CC) + j];
+            OG_SYNC();
+            OG_FOR_LANES(i, audiosize * 2) S.v[V_X + i] = 0;
+            OG_SYNC();
+            for (int c = 0; c < CC; c++) OG_FOR_LANES(j, 120) S.v[pcm_plane(c, ch, CC) + j] = S.v[V_IY + 120 * c + j];
             OG_SYNC();
         }
     }
 #ifndef OG_NO_SILK
     if (mode != MODE_CELT) { // SAT16(outbuf + pcm_silk) over audiosize*stream_channels entries (Q3)
         OG_SYNC();
-        OG_FOR_LANES(i, audiosize * ch) S.v[V_X + i] = (i16)sat16((i32)S.v[V_X + i] + (i32)g_pcm_silk[i]);
+        OG_FOR_LANES(i, audiosize * ch) { // i indexes the interleaved PCM; sample j of channel c lives in plane c
+            const int c = CC == 2 ? (i & 1) : 0, j = CC == 2 ? (i >> 1) : i, at = pcm_plane(c, ch, CC) + j;
+            S.v[at] = (i16)sat16((i32)S.v[at] + (i32)g_pcm_silk[i]);
+        }
         OG_SYNC();
     }
 #endif
@@ -120,11 +127,7 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
     if (celt_ret < 0) return celt_ret;
     // PCM: LDS staging -> HBM, two samples per lane-store, coalesced
     OG_SYNC();
-    {
-        const u32 *src = reinterpret_cast<const u32 *>(&S.v[V_X]);
-        u32 *dst = reinterpret_cast<u32 *>(pcm);
-        OG_FOR_LANES(i, audiosize * CC / 2) dst[i] = src[i];
-    }
+    pcm_store(pcm, audiosize, ch, CC);
     OG_SYNC();
     return audiosize;
 }

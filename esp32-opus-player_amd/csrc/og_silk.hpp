@@ -47,9 +47,9 @@ struct SilkLds {
     i32 pred_Q8[SILK_MAX_LPC];
     i32 cosLSF[SILK_MAX_LPC], P[SILK_MAX_LPC / 2 + 1], Q[SILK_MAX_LPC / 2 + 1], a32[SILK_MAX_LPC], Atmp[SILK_MAX_LPC];
 };
-static_assert(sizeof(SilkLds) <= sizeof(i32) * 2 * SYN_LEN + sizeof(i16) * V_TOTAL, "SILK scratch must fit the CELT overlay");
-
-OG_DEV SilkLds &SL() { return *reinterpret_cast<SilkLds *>(&S.syn[0][0]); }
+// SILK's working set is its own LDS object: only the single-kernel path (which runs SILK) pays for it.
+OG_LDS SilkLds g_silk_lds;
+OG_DEV SilkLds &SL() { return g_silk_lds; }
 
 // ---- state ------------------------------------------------------------------------------------------
 OG_DEV void silk_chan_init(SilkChannel *c) { // silk_init_decoder silk.cpp:2192

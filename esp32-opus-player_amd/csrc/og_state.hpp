@@ -90,17 +90,21 @@ constexpr int V_TMP = V_IY + 192;
 constexpr int V_TOTAL = V_TMP + 192;
 constexpr int SYN_LEN = 1088;  // 960 + 120 (+8 pad)
 
+// Two phases share the bytes behind X: while the bands are decoded they hold the folding history, the pulse /
+// scratch rows and the packet (or, on the split path, the per-leaf collapse masks); during synthesis they hold the
+// i32 IMDCT / output buffer of ONE channel at a time (syn_buf(), og_celt.hpp).  After a channel's synthesis its PCM
+// goes to a half of the (by then dead) X region as a plane of 960 samples.
 struct FrameLds {
-    i32 syn[2][SYN_LEN];       // IMDCT work / out_syn per output channel
     i16 v[V_TOTAL];
     u8 pkt[1344];              // packet bytes (<= 1275); the split path keeps its per-leaf collapse masks here
+    u32 win[64];               // split path: window of the parse record's word stream
     i32 pulses[NBANDS], fine_quant[NBANDS], fine_prio[NBANDS], tf_res[NBANDS], cap[NBANDS], offsets[NBANDS];
     i32 bits1[NBANDS], bits2[NBANDS], thresh[NBANDS], trim_off[NBANDS];
     i16 bandE[2 * NBANDS], logE1[2 * NBANDS], logE2[2 * NBANDS];
     i16 dn_g[2 * NBANDS], dn_shift[2 * NBANDS];
     u8 cmask[2 * NBANDS];
     u8 bin2band[120];
-
 };
+static_assert((V_TOTAL - V_NORM) * 2 + 1344 >= SYN_LEN * 4, "the synthesis buffer overlays norm | iy | tmp | pkt");
 
 } // namespace og

@@ -27,8 +27,9 @@ static int16_t tap_X[1920], tap_bandE[42];
 static int32_t tap_syn_pre[2][1080], tap_syn_post[2][1080];
 extern "C" void og_emul_tap(int id) {
     if (id == 1) { memcpy(tap_X, &og::S.v[og::V_X], sizeof(tap_X)); memcpy(tap_bandE, og::S.bandE, sizeof(tap_bandE)); }
-    if (id == 2) for (int c = 0; c < 2; c++) memcpy(tap_syn_pre[c], og::S.syn[c], 1080 * 4);
-    if (id == 3) for (int c = 0; c < 2; c++) memcpy(tap_syn_post[c], og::S.syn[c], 1080 * 4);
+    // synthesis taps come once per channel: id = 2 (IMDCT output) or 3 (comb filter output), + 16 * channel
+    if ((id & 15) == 2) memcpy(tap_syn_pre[id >> 4], og::syn_buf(), 1080 * 4);
+    if ((id & 15) == 3) memcpy(tap_syn_post[id >> 4], og::syn_buf(), 1080 * 4);
 }
 extern "C" {
 const int16_t *emu_tap_X(void) { return tap_X; }
