@@ -71,8 +71,21 @@ __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDe
     if (f >= n) return;
     const FrameDesc d = descs[f];
     if (d.stream < 0 || d.stream >= n_streams || desc_mode(d.flags) != MODE_CELT) return;
-    const int ret = celt_recon_wave(&st[d.stream], &recs[f], MODE_CELT, desc_channels(d.flags), pcm + (size_t)f * pcm_stride);
+    const int ret = celt_recon_wave(&st[d.stream], &recs[f], MODE_CELT, desc_channels(d.flags));
     if (threadIdx.x == 0) result[f] = ret;
+}
+
+// Split CELT path, third step: de-emphasis (a rounding IIR: strictly serial per channel) and int16 PCM, one
+// (frame, channel) per lane, from the samples k_celt_recon appended to the history ring.
+__global__ void __launch_bounds__(64) k_celt_post(const FrameDesc *__restrict__ descs, StreamState *st, const ParseRec *recs,
+                                                  const i32 *__restrict__ result, i16 *pcm, int n, int n_streams, int channels,
+                                                  int pcm_stride) {
+    const int t = (int)blockIdx.x * 64 + (int)threadIdx.x;
+    const int f = channels == 2 ? t >> 1 : t, c = channels == 2 ? t & 1 : 0;
+    if (f >= n) return;
+    const FrameDesc d = descs[f];
+    if (d.stream < 0 || d.stream >= n_streams || desc_mode(d.flags) != MODE_CELT) return;
+    celt_post(&st[d.stream], &recs[f], result[f], c, pcm + (size_t)f * pcm_stride);
 }
 
 // ---- context ----------------------------------------------------------------------------------------
@@ -224,6 +237,9 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
                            (const StreamState *)ctx->d_streams, (ParseRec *)ctx->d_recs, n, ctx->n_streams);
         hipLaunchKernelGGL(k_celt_recon, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, ctx->d_streams,
                            (const ParseRec *)ctx->d_recs, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride);
+        hipLaunchKernelGGL(k_celt_post, dim3((n * ctx->channels + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs,
+                           ctx->d_streams, (const ParseRec *)ctx->d_recs, (const i32 *)d_result, (i16 *)d_pcm, n, ctx->n_streams,
+                           ctx->channels, pcm_stride);
     }
     // every other mode (and stream-index errors): the single-kernel path
     hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,

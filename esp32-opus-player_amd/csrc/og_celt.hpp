@@ -778,7 +778,68 @@ struct CeltSynth {
     i32 pf_gain;
     u32 rng_final;
     int rc_error;
+    int inline_deemph; // 1: de-emphasis + PCM planes here (single-kernel path); 0: left to celt_post_lane (split path)
 };
+
+// De-emphasis and float-to-int16 of one channel of one frame, lane-private (celt.cpp:1965-2055, sig2word16 celt.h:413):
+// the split path's third kernel runs this with one (frame, channel) per lane, reading the comb-filtered samples the
+// reconstruction kernel appended to the stream's history ring.  `pcm` may be null (state update only).
+OG_DEV void celt_post_lane(CeltState *st, int c, int CC, int N, i16 *pcm) {
+    const int pos = (st->ring_pos - N) & RING_MASK; // the frame's first sample (N is a multiple of 8, so is ring_pos)
+    const i32 *ring = st->ring[c];
+    i32 m = st->deemph[c];
+    for (int j = 0; j < N; j += 4) {
+#ifdef OG_HOST_EMUL
+        const i32 *src = &ring[(pos + j) & RING_MASK];
+        const i32 s0 = src[0], s1 = src[1], s2 = src[2], s3 = src[3];
+#else
+        typedef i32 v4i __attribute__((ext_vector_type(4)));
+        const v4i sv = *reinterpret_cast<const v4i *>(&ring[(pos + j) & RING_MASK]); // 16-byte aligned, never wraps
+        const i32 s0 = sv.x, s1 = sv.y, s2 = sv.z, s3 = sv.w;
+#endif
+        i32 t0 = s0 + m;
+        m = mul16x32_q15(27853, t0);
+        i32 t1 = s1 + m;
+        m = mul16x32_q15(27853, t1);
+        i32 t2 = s2 + m;
+        m = mul16x32_q15(27853, t2);
+        i32 t3 = s3 + m;
+        m = mul16x32_q15(27853, t3);
+#ifdef OG_HOST_EMUL
+        if (pcm) {
+            pcm[(j + 0) * CC + c] = (i16)sat16(pshr32(t0, 12));
+            pcm[(j + 1) * CC + c] = (i16)sat16(pshr32(t1, 12));
+            pcm[(j + 2) * CC + c] = (i16)sat16(pshr32(t2, 12));
+            pcm[(j + 3) * CC + c] = (i16)sat16(pshr32(t3, 12));
+        }
+#else
+        // four samples of this channel as two packed words; with two channels the lanes of a (left, right) pair swap
+        // halves so that each of them writes 8 contiguous bytes of the interleaved PCM
+        const u32 w01 = (u32)(u16)sat16(pshr32(t0, 12)) | (u32)(u16)sat16(pshr32(t1, 12)) << 16;
+        const u32 w23 = (u32)(u16)sat16(pshr32(t2, 12)) | (u32)(u16)sat16(pshr32(t3, 12)) << 16;
+        typedef u32 v2u __attribute__((ext_vector_type(2)));
+        v2u out;
+        int at;
+        if (CC == 2) {
+            const u32 p01 = (u32)__shfl_xor((int)w01, 1, 64), p23 = (u32)__shfl_xor((int)w23, 1, 64);
+            if (c == 0) { // samples j, j+1: L0 R0 L1 R1
+                out.x = (w01 & 0xffffu) | p01 << 16;
+                out.y = w01 >> 16 | (p01 & 0xffff0000u);
+            } else { // samples j+2, j+3: L2 R2 L3 R3
+                out.x = (p23 & 0xffffu) | w23 << 16;
+                out.y = p23 >> 16 | (w23 & 0xffff0000u);
+            }
+            at = (j + 2 * c) * 2;
+        } else {
+            out.x = w01;
+            out.y = w23;
+            at = j;
+        }
+        if (pcm) *reinterpret_cast<v2u *>(pcm + at) = out;
+#endif
+    }
+    st->deemph[c] = m;
+}
 
 OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
     const int N = p.N, LM = p.LM, C = p.C, CC = p.CC, start = p.start, end = p.end, silence = p.silence, transient = p.transient;
@@ -826,7 +887,7 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
 #if !(defined(OG_ABLATE) && OG_ABLATE == 4)
         // de-emphasis (celt.cpp:1965-2055): a rounding IIR, serial; the PCM plane replaces a dead half of X
         OG_SYNC();
-        if (OG_LANE == 0) {
+        if (p.inline_deemph && OG_LANE == 0) {
             const int plane = pcm_plane(c, C, CC);
             i32 m = st->deemph[c];
             for (int j = 0; j < N; j++) {
@@ -924,7 +985,7 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
 #endif
     CeltSynth sp;
     sp.N = N; sp.LM = LM; sp.C = C; sp.CC = CC; sp.start = start; sp.end = end; sp.silence = silence; sp.transient = transient;
-    sp.pf_pitch = pf_pitch; sp.pf_tapset = pf_tapset; sp.pf_gain = pf_gain; sp.rng_final = rc.rng; sp.rc_error = rc.error;
+    sp.pf_pitch = pf_pitch; sp.pf_tapset = pf_tapset; sp.pf_gain = pf_gain; sp.rng_final = rc.rng; sp.rc_error = rc.error; sp.inline_deemph = 1;
     celt_synthesis(st, sp);
     if (rc_tell(rc) > 8 * (i32)rc.storage) return INTERNAL_ERROR;
     return frame_size;

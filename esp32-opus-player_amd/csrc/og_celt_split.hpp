@@ -817,8 +817,9 @@ OG_DEV void recon_all_bands(const u32 *words, int start, int end, int C, int N_c
 }
 
 // One CELT-only frame, vector half + synthesis + stream bookkeeping (decode_frame_wave's CELT branch).
-// Returns the frame's result code (wave-uniform); PCM goes to `pcm` (960 * CC int16) on success.
-OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int ch, i16 *pcm) {
+// Returns the frame's result code (wave-uniform).  The comb-filtered output goes to the stream's history ring; the
+// last, strictly serial step -- de-emphasis to int16 PCM -- is celt_post_lane's, one (frame, channel) per lane.
+OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int ch) {
     const u32 flags = (u32)OG_UNI(rec->flags);
     const int ret = OG_UNI(rec->ret);
     if (flags & RF_SKIP) return ret;
@@ -877,7 +878,7 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         CeltSynth sp;
         sp.N = N; sp.LM = LM; sp.C = C; sp.CC = CC; sp.start = start; sp.end = end; sp.silence = silence; sp.transient = transient;
         sp.pf_pitch = OG_UNI(rec->pf_pitch); sp.pf_tapset = OG_UNI(rec->pf_tapset); sp.pf_gain = OG_UNI(rec->pf_gain);
-        sp.rng_final = rng_final; sp.rc_error = (flags & RF_RC_ERROR) != 0;
+        sp.rng_final = rng_final; sp.rc_error = (flags & RF_RC_ERROR) != 0; sp.inline_deemph = 0;
         celt_synthesis(cs, sp);
         if (flags & RF_TELL_OVERFLOW) result = INTERNAL_ERROR;
     }
@@ -886,10 +887,14 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         st->frames_decoded += 1;
         st->range_final = rng_final;
     }
-    if (result < 0) return result;
-    OG_SYNC();
-    pcm_store(pcm, 960, C, CC);
-    return result;
+    return result; // de-emphasis and PCM: celt_post_lane (k_celt_post), from the history ring
+
+}
+
+// Third step of the split path for (frame, channel c): runs whenever the frame was synthesised; PCM only on success.
+OG_DEV void celt_post(StreamState *st, const ParseRec *rec, int result, int c, i16 *pcm) {
+    if (rec->flags & (RF_SKIP | RF_BAD_CELT)) return;
+    celt_post_lane(&st->celt, c, st->channels, 960, result >= 0 ? pcm : nullptr);
 }
 
 } // namespace og

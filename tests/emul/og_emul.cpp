@@ -17,7 +17,9 @@ int emu_decode_frame(void *st, const uint8_t *payload, int len, int mode, int bw
     if (mode != og::MODE_CELT) return og::decode_frame_wave((og::StreamState *)st, payload, len, mode, bw, ch, pcm);
     static og::ParseRec rec;
     og::celt_parse_lane((const og::StreamState *)st, payload, len, ch, &rec);
-    return og::celt_recon_wave((og::StreamState *)st, &rec, mode, ch, pcm);
+    const int ret = og::celt_recon_wave((og::StreamState *)st, &rec, mode, ch);
+    for (int c = 0; c < ((og::StreamState *)st)->channels; c++) og::celt_post((og::StreamState *)st, &rec, ret, c, pcm);
+    return ret;
 }
 int emu_last_record_words(void) { return 0; }
 }
