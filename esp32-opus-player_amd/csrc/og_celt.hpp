@@ -784,62 +784,84 @@ struct CeltSynth {
 // De-emphasis and float-to-int16 of one channel of one frame, lane-private (celt.cpp:1965-2055, sig2word16 celt.h:413):
 // the split path's third kernel runs this with one (frame, channel) per lane, reading the comb-filtered samples the
 // reconstruction kernel appended to the stream's history ring.  `pcm` may be null (state update only).
+#ifndef OG_HOST_EMUL
+typedef i32 og_v4i __attribute__((ext_vector_type(4)));
+typedef u32 og_v2u __attribute__((ext_vector_type(2)));
+#endif
+// four consecutive samples of one channel: the recurrence, then int16 PCM
+OG_DEV void celt_post4(i32 &m, i32 s0, i32 s1, i32 s2, i32 s3, int j, int c, int CC, i16 *pcm) {
+    const i32 t0 = s0 + m;
+    m = mul16x32_q15(27853, t0);
+    const i32 t1 = s1 + m;
+    m = mul16x32_q15(27853, t1);
+    const i32 t2 = s2 + m;
+    m = mul16x32_q15(27853, t2);
+    const i32 t3 = s3 + m;
+    m = mul16x32_q15(27853, t3);
+#ifdef OG_HOST_EMUL
+    if (pcm) {
+        pcm[(j + 0) * CC + c] = (i16)sat16(pshr32(t0, 12));
+        pcm[(j + 1) * CC + c] = (i16)sat16(pshr32(t1, 12));
+        pcm[(j + 2) * CC + c] = (i16)sat16(pshr32(t2, 12));
+        pcm[(j + 3) * CC + c] = (i16)sat16(pshr32(t3, 12));
+    }
+#else
+    // two packed words; with two channels the lanes of a (left, right) pair swap halves so that each of them writes 8
+    // contiguous bytes of the interleaved PCM
+    const u32 w01 = (u32)(u16)sat16(pshr32(t0, 12)) | (u32)(u16)sat16(pshr32(t1, 12)) << 16;
+    const u32 w23 = (u32)(u16)sat16(pshr32(t2, 12)) | (u32)(u16)sat16(pshr32(t3, 12)) << 16;
+    og_v2u out;
+    int at;
+    if (CC == 2) {
+        const u32 p01 = (u32)__shfl_xor((int)w01, 1, 64), p23 = (u32)__shfl_xor((int)w23, 1, 64);
+        if (c == 0) { // samples j, j+1: L0 R0 L1 R1
+            out.x = (w01 & 0xffffu) | p01 << 16;
+            out.y = w01 >> 16 | (p01 & 0xffff0000u);
+        } else { // samples j+2, j+3: L2 R2 L3 R3
+            out.x = (p23 & 0xffffu) | w23 << 16;
+            out.y = p23 >> 16 | (w23 & 0xffff0000u);
+        }
+        at = (j + 2 * c) * 2;
+    } else {
+        out.x = w01;
+        out.y = w23;
+        at = j;
+    }
+    if (pcm) *reinterpret_cast<og_v2u *>(pcm + at) = out;
+#endif
+}
+
 OG_DEV void celt_post_lane(CeltState *st, int c, int CC, int N, i16 *pcm) {
     const int pos = (st->ring_pos - N) & RING_MASK; // the frame's first sample (N is a multiple of 8, so is ring_pos)
     const i32 *ring = st->ring[c];
     i32 m = st->deemph[c];
+#ifdef OG_HOST_EMUL
     for (int j = 0; j < N; j += 4) {
-#ifdef OG_HOST_EMUL
         const i32 *src = &ring[(pos + j) & RING_MASK];
-        const i32 s0 = src[0], s1 = src[1], s2 = src[2], s3 = src[3];
-#else
-        typedef i32 v4i __attribute__((ext_vector_type(4)));
-        const v4i sv = *reinterpret_cast<const v4i *>(&ring[(pos + j) & RING_MASK]); // 16-byte aligned, never wraps
-        const i32 s0 = sv.x, s1 = sv.y, s2 = sv.z, s3 = sv.w;
-#endif
-        i32 t0 = s0 + m;
-        m = mul16x32_q15(27853, t0);
-        i32 t1 = s1 + m;
-        m = mul16x32_q15(27853, t1);
-        i32 t2 = s2 + m;
-        m = mul16x32_q15(27853, t2);
-        i32 t3 = s3 + m;
-        m = mul16x32_q15(27853, t3);
-#ifdef OG_HOST_EMUL
-        if (pcm) {
-            pcm[(j + 0) * CC + c] = (i16)sat16(pshr32(t0, 12));
-            pcm[(j + 1) * CC + c] = (i16)sat16(pshr32(t1, 12));
-            pcm[(j + 2) * CC + c] = (i16)sat16(pshr32(t2, 12));
-            pcm[(j + 3) * CC + c] = (i16)sat16(pshr32(t3, 12));
-        }
-#else
-        // four samples of this channel as two packed words; with two channels the lanes of a (left, right) pair swap
-        // halves so that each of them writes 8 contiguous bytes of the interleaved PCM
-        const u32 w01 = (u32)(u16)sat16(pshr32(t0, 12)) | (u32)(u16)sat16(pshr32(t1, 12)) << 16;
-        const u32 w23 = (u32)(u16)sat16(pshr32(t2, 12)) | (u32)(u16)sat16(pshr32(t3, 12)) << 16;
-        typedef u32 v2u __attribute__((ext_vector_type(2)));
-        v2u out;
-        int at;
-        if (CC == 2) {
-            const u32 p01 = (u32)__shfl_xor((int)w01, 1, 64), p23 = (u32)__shfl_xor((int)w23, 1, 64);
-            if (c == 0) { // samples j, j+1: L0 R0 L1 R1
-                out.x = (w01 & 0xffffu) | p01 << 16;
-                out.y = w01 >> 16 | (p01 & 0xffff0000u);
-            } else { // samples j+2, j+3: L2 R2 L3 R3
-                out.x = (p23 & 0xffffu) | w23 << 16;
-                out.y = p23 >> 16 | (w23 & 0xffff0000u);
-            }
-            at = (j + 2 * c) * 2;
-        } else {
-            out.x = w01;
-            out.y = w23;
-            at = j;
-        }
-        if (pcm) *reinterpret_cast<v2u *>(pcm + at) = out;
-#endif
+        celt_post4(m, src[0], src[1], src[2], src[3], j, c, CC, pcm);
     }
+#else
+    // 16 samples per iteration; the next 16 are requested before the current ones are consumed (the loads do not
+    // depend on the recurrence, and nothing else hides their latency).  Groups of 4 are 16-byte aligned, never wrap.
+#define OG_LD4(j) (*reinterpret_cast<const og_v4i *>(&ring[(pos + (j)) & RING_MASK]))
+    og_v4i a0 = OG_LD4(0), a1 = OG_LD4(4), a2 = OG_LD4(8), a3 = OG_LD4(12);
+    for (int j = 0; j < N; j += 16) {
+        const int jn = j + 16 < N ? j + 16 : j;
+        const og_v4i b0 = OG_LD4(jn), b1 = OG_LD4(jn + 4), b2 = OG_LD4(jn + 8), b3 = OG_LD4(jn + 12);
+        celt_post4(m, a0.x, a0.y, a0.z, a0.w, j, c, CC, pcm);
+        celt_post4(m, a1.x, a1.y, a1.z, a1.w, j + 4, c, CC, pcm);
+        celt_post4(m, a2.x, a2.y, a2.z, a2.w, j + 8, c, CC, pcm);
+        celt_post4(m, a3.x, a3.y, a3.z, a3.w, j + 12, c, CC, pcm);
+        a0 = b0;
+        a1 = b1;
+        a2 = b2;
+        a3 = b3;
+    }
+#undef OG_LD4
+#endif
     st->deemph[c] = m;
 }
+
 
 OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
     const int N = p.N, LM = p.LM, C = p.C, CC = p.CC, start = p.start, end = p.end, silence = p.silence, transient = p.transient;
