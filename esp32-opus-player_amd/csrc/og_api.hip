@@ -71,8 +71,10 @@ __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDe
     if (f >= n) return;
     const FrameDesc d = descs[f];
     if (d.stream < 0 || d.stream >= n_streams || desc_mode(d.flags) != MODE_CELT) return;
+    OG_PROF_INIT();
     const int ret = celt_recon_wave(&st[d.stream], &recs[f], MODE_CELT, desc_channels(d.flags));
     if (threadIdx.x == 0) result[f] = ret;
+    OG_PROF_FLUSH();
 }
 
 // Split CELT path, third step: de-emphasis (a rounding IIR: strictly serial per channel) and int16 PCM, one
@@ -247,6 +249,18 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
     HIPCHK(ctx, hipGetLastError());
     return OPUSGPU_OK;
 }
+
+#ifdef OG_PROF
+// profiling builds only: per-section wave-cycle totals of k_celt_recon (see OG_MARK), optionally cleared after the read
+int opusgpu_debug_prof(unsigned long long *out64, int reset) {
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[64] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 int opusgpu_synchronize(opusgpu_ctx *ctx) {
     if (!ctx) return OPUSGPU_BAD_ARG;

@@ -899,8 +899,10 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
     // ---- one output channel at a time through the single synthesis buffer
     for (int c = 0; c < CC; c++) {
         OG_SYNC();
+        OG_MARK(14);
         OG_FOR_LANES(i, OVERLAP / 2) SY[i] = st->tail[c][i];
         imdct_channel(c, N, LM, B, shift, C, CC);
+        OG_MARK(15);
         OG_TAP(2 + 16 * c); // IMDCT output
 #if !(defined(OG_ABLATE) && OG_ABLATE == 3)
         comb_filter(st, c, 0, ppo, pp, 120, pgo, pg, pto, pt);
@@ -921,6 +923,7 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
         }
         OG_SYNC();
         // history ring and overlap tail
+        OG_MARK(16);
         OG_FOR_LANES(i, N) st->ring[c][(pos + i) & RING_MASK] = SY[i];
         OG_FOR_LANES(i, OVERLAP / 2) st->tail[c][i] = SY[N + i];
 #endif

@@ -585,7 +585,9 @@ OG_DEV u32 recon_tree(RecCur &cur, int spread, u32 &seed, int x, int N, int B, i
             }
             w = rec_word(cur);
         }
+        OG_MARK(7);
         u32 cm = recon_leaf(cur, (int)(w & 255), seed, x, N, B, low, gain, fill);
+        OG_MARK(6);
         for (;;) {
             if (depth == 0) return cm;
             ReconFrame &F = g_rframe[depth - 1];
@@ -647,7 +649,9 @@ OG_DEV u32 recon_band_mono(RecCur &cur, int spread, int tf_change, u32 &seed, in
     B0 = B;
     const int N_B0 = N_B;
     if (B0 > 1 && low >= 0) hadamard_reorder(low, N_B >> recombine, B0 << recombine, longBlocks, 0);
+    OG_MARK(6);
     u32 cm = recon_tree(cur, spread, seed, x, N, B, low, LM, gain, fill);
+    OG_MARK(8);
     if (B0 > 1) hadamard_reorder(x, N_B >> recombine, B0 << recombine, longBlocks, 1);
     N_B = N_B0;
     B = B0;
@@ -663,6 +667,7 @@ OG_DEV u32 recon_band_mono(RecCur &cur, int spread, int tf_change, u32 &seed, in
         haar1(x, N0 >> k, 1 << k);
     }
     B <<= recombine;
+    OG_MARK(9);
     if (low_out >= 0) {
         i32 n = tr16(celt_sqrt(shl32(N0, 22)));
         OG_SYNC();
@@ -691,6 +696,7 @@ OG_DEV void recon_all_bands(const u32 *words, int start, int end, int C, int N_c
         const int last = i == end - 1;
         const int eb0 = M * rom_eband[i], N = M * rom_eband[i + 1] - eb0;
         const int x = V_X + eb0, y = C == 2 ? V_X + N_ch + eb0 : -1;
+        OG_MARK(3);
         const u32 bw = rec_word(cur);
         if ((eb0 - N >= M * rom_eband[start] || i == start + 1) && (update_lowband || lowband_offset == 0))
             lowband_offset = i;
@@ -735,6 +741,7 @@ OG_DEV void recon_all_bands(const u32 *words, int start, int end, int C, int N_c
         const int out2 = last ? -1 : norm2 + eb0 - norm_offset;
 
         if (N == 1) { // quant_band_n1 celt.cpp:1357
+            OG_MARK(11);
             OG_SYNC();
             S.v[x] = (i16)((bw & BW_SIGN0) ? -16384 : 16384);
             if (y >= 0) S.v[y] = (i16)((bw & BW_SIGN1) ? -16384 : 16384);
@@ -750,6 +757,7 @@ OG_DEV void recon_all_bands(const u32 *words, int start, int end, int C, int N_c
             i32 imid = 0, iside = 0;
             const int itheta = (int)((bw >> BW_ITHETA_SHIFT) & 0x7fff), mid_first = (bw & BW_MID_FIRST) != 0;
             int n2case = 0, swap_c = 0, njobs = 1;
+            OG_MARK(4);
             if (stereo) {
                 theta_gains(itheta, B, imid, iside, fill0);
                 if (N == 2) {
@@ -775,9 +783,11 @@ OG_DEV void recon_all_bands(const u32 *words, int start, int end, int C, int N_c
                 } else {
                     jx = y; jlow = -1; jout = -1; jscr = -1; jgain = iside; jfill = fill0 >> B;
                 }
+                OG_MARK(5);
                 const u32 cmj = recon_band_mono(cur, spread, tf_change, seed, jx, N, B, jlow, LM, jout, jgain, jscr, jfill);
                 if (jb == 0) cm0 = cmj; else cm1 = cmj;
             }
+            OG_MARK(10);
             if (stereo) {
                 if (n2case) { // N == 2: the side is the mid rotated by 90 degrees (celt.cpp:1659-1697)
                     const int x2 = swap_c ? y : x, sign = (bw & BW_SIGN) ? -1 : 1;
@@ -837,6 +847,7 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         const int n_leaves = OG_UNI(rec->n_leaves), n_words = OG_UNI(rec->n_words);
         CeltState *cs = &st->celt;
         // ---- stage the record and the persistent scalars
+        OG_MARK(1);
         OG_SYNC();
         OG_FOR_LANES(i, 2 * NBANDS) {
             S.bandE[i] = rec->bandE[i];
@@ -855,6 +866,7 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         return ret;
 #endif
         // ---- all PVQ leaves of the frame, one per lane
+        OG_MARK(2);
         OG_FOR_LANES(t, n_leaves) {
             const u32 g = rec->leaf_geom[t];
             leaf_masks()[t] = (u16)pvq_leaf_lane((int)(g >> 11) & 255, (int)(g >> 19) & 255, rec->leaf_idx[t], V_X + (int)(g & 2047),
@@ -866,6 +878,7 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
 #endif
         u32 seed = cs->rng;
         recon_all_bands(rec->words, start, end, C, N, transient ? M : 0, spread, (flags & RF_DUAL) != 0, OG_UNI(rec->intensity), LM, seed);
+        OG_MARK(12);
         if (flags & RF_ANTI_COLLAPSE) anti_collapse(LM, C, N, start, end, seed);
         if (silence) {
             OG_SYNC();
@@ -879,7 +892,9 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         sp.N = N; sp.LM = LM; sp.C = C; sp.CC = CC; sp.start = start; sp.end = end; sp.silence = silence; sp.transient = transient;
         sp.pf_pitch = OG_UNI(rec->pf_pitch); sp.pf_tapset = OG_UNI(rec->pf_tapset); sp.pf_gain = OG_UNI(rec->pf_gain);
         sp.rng_final = rng_final; sp.rc_error = (flags & RF_RC_ERROR) != 0; sp.inline_deemph = 0;
+        OG_MARK(13);
         celt_synthesis(cs, sp);
+        OG_MARK(17);
         if (flags & RF_TELL_OVERFLOW) result = INTERNAL_ERROR;
     }
     if (OG_LANE == 0) {

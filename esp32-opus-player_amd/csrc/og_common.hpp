@@ -67,6 +67,43 @@ extern "C" void og_emul_tap(int id); // stage taps for parity tests (host emulat
 
 #define OG_FOR_LANES(i, n) for (int i = OG_LANE; i < (n); i += OG_NLANES)
 
+// Section timers for profiling builds (-DOG_PROF, never in the shipped library): OG_MARK(id) closes the running section
+// and opens section `id`; per-wave cycle totals accumulate in LDS and are added to g_prof[] when the kernel ends.
+#if defined(OG_PROF) && !defined(OG_HOST_EMUL)
+__device__ unsigned long long g_prof[64];
+__shared__ unsigned int s_prof[64];
+__shared__ unsigned long long s_prof_t;
+__shared__ int s_prof_cur;
+#define OG_PROF_INIT()                                                  \
+    do {                                                                \
+        s_prof[threadIdx.x & 63] = 0;                                   \
+        if (threadIdx.x == 0) {                                         \
+            s_prof_cur = 0;                                             \
+            s_prof_t = __builtin_amdgcn_s_memtime();                    \
+        }                                                               \
+        __syncthreads();                                                \
+    } while (0)
+#define OG_MARK(id)                                                     \
+    do {                                                                \
+        if (threadIdx.x == 0) {                                         \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+            s_prof[s_prof_cur] += (unsigned int)(t_ - s_prof_t);        \
+            s_prof_cur = (id);                                          \
+            s_prof_t = t_;                                              \
+        }                                                               \
+    } while (0)
+#define OG_PROF_FLUSH()                                                 \
+    do {                                                                \
+        OG_MARK(0);                                                     \
+        __syncthreads();                                                \
+        atomicAdd(&g_prof[threadIdx.x & 63], (unsigned long long)s_prof[threadIdx.x & 63]); \
+    } while (0)
+#else
+#define OG_PROF_INIT() ((void)0)
+#define OG_MARK(id) ((void)0)
+#define OG_PROF_FLUSH() ((void)0)
+#endif
+
 #define OG_MIN(a, b) ((a) < (b) ? (a) : (b))
 #define OG_MAX(a, b) ((a) > (b) ? (a) : (b))
 

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Section profile of k_celt_recon from a -DOG_PROF build (OPUSGPU_LIB=<that .so>): share of wave cycles per OG_MARK id.
+usage (GPU box): OPUSGPU_LIB=$PWD/build_exp/lib_prof.so python3 tools/prof_sections.py [streams] [steps]"""
+import ctypes
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+here = os.path.dirname(os.path.abspath(__file__))
+spec = importlib.util.spec_from_file_location("opusgpu_pkg", os.path.join(here, "..", "esp32-opus-player_amd", "__init__.py"))
+pkg = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(pkg)
+
+NAMES = {0: "outside", 1: "stage record", 2: "leaf pass", 3: "band prologue", 4: "stereo setup", 5: "band_mono pre",
+         6: "tree walk", 7: "leaf (fill)", 8: "band_mono post", 9: "lowband out", 10: "stereo merge", 11: "N==1 band",
+         12: "anti-collapse", 13: "synth prologue", 14: "imdct", 15: "comb filter", 16: "ring write", 17: "epilogue"}
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+ctx = pkg.Context(0)
+ctx.streams_alloc(n, 2)
+lib = pkg.load_lib()
+lib.opusgpu_debug_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
+buf = (ctypes.c_ulonglong * 64)()
+pay = pkg.lcg_payloads(n, steps, 160)
+for s in range(steps):
+    pkts = [bytes([pkg.TOC_CELT_FB_STEREO]) + pay[s, i].tobytes() for i in range(n)]
+    if s == 1:
+        lib.opusgpu_debug_prof(buf, 1)  # drop the first (cold) step
+    ctx.decode_packets(list(range(n)), pkts)
+lib.opusgpu_debug_prof(buf, 0)
+tot = sum(buf)
+print("section                 cycles/frame   share")
+for i in range(64):
+    if buf[i]:
+        print("%2d %-20s %10.0f   %5.1f%%" % (i, NAMES.get(i, "?"), buf[i] / (n * (steps - 1)), 100.0 * buf[i] / tot))
+print("total cycles/frame %.0f" % (tot / (n * (steps - 1))))
