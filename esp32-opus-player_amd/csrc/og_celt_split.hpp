@@ -1,5 +1,5 @@
-// og_celt_split.hpp -- the two-kernel CELT path: entropy decoding with ONE FRAME PER LANE, then vector
-// reconstruction with one frame per wave.
+// og_celt_split.hpp -- the split CELT path: entropy decoding with ONE FRAME PER LANE, then vector reconstruction with
+// one frame per wave, then de-emphasis with one (frame, channel) per lane.
 //
 // Why: everything the range decoder touches is a serial dependency chain over wave-uniform values.  Run one frame
 // per wave it occupies a whole 64-lane SIMD for scalar work (measured on the single-kernel path: ~140 k vector +
@@ -9,16 +9,19 @@
 // folding).  So the frame splits cleanly:
 //
 //   parse  (k_celt_parse, one frame per LANE, 64 frames per wave): header, energies, allocation, the band loop's
-//          budget logic, split angles and PVQ codeword indices.  Output: a ParseRec per frame in HBM -- a header,
-//          one word per band / split / leaf in decode order, and an array of (x, N, K, index) PVQ leaves.
-//   recon  (k_celt_recon, one frame per WAVE): index -> pulse vector for all leaves of the frame at once (one
-//          leaf per lane: cwrsi touches no coder state), then the band loop's vector half (normalisation,
-//          spreading rotation, folding, Haar / Hadamard, stereo merge, anti-collapse) driven by the record, then
-//          the shared synthesis half (og_celt.hpp: celt_synthesis).
+//          budget logic, split angles and PVQ codeword indices -- and every other wave-uniform quantity of the band
+//          loop that does not depend on decoded data (folding offsets, gains, scale factors).  Output: a ParseRec
+//          per frame in HBM: a header, a word stream in decode order (4 words per band, 1 per split / leaf) and an
+//          array of PVQ leaves (index, position, N, K, blocks, gain).
+//   recon  (k_celt_recon, one frame per WAVE): all PVQ leaves of the frame at once, one leaf per lane (index ->
+//          pulses -> scaled, de-rotated coefficients + collapse mask: serial per leaf, independent across leaves);
+//          then the band loop's vector half (folding / noise fill, Haar / Hadamard, stereo merge, collapse-mask
+//          bookkeeping, anti-collapse) interpreting the word stream; then the synthesis half (og_celt.hpp).
+//   post   (k_celt_post, one (frame, channel) per lane): the de-emphasis IIR (rounding => serial) and int16 PCM.
 //
-// Both halves are restatements of the same reference functions as og_celt_bands.hpp (file:line cited there); the
-// single-kernel path remains for frames whose CELT part follows SILK data in the same range coder (hybrid) and for
-// the SILK-only transition frame (Q4).
+// All halves restate the same reference functions as og_celt_bands.hpp (file:line cited there); the single-kernel
+// path remains for frames whose CELT part follows SILK data in the same range coder (hybrid) and for the SILK-only
+// transition frame (Q4).
 #pragma once
 #include "og_celt.hpp"
 
@@ -28,8 +31,9 @@
 namespace og {
 
 // ---- the record ------------------------------------------------------------------------------------
-constexpr int REC_MAX_LEAVES = NBANDS * 2 * 16;      // <= 16 leaves per band and channel (4 split levels)
-constexpr int REC_MAX_WORDS = NBANDS * (1 + 2 * 31); // 1 band word + <= 31 tree nodes per band and channel
+constexpr int REC_BAND_WORDS = 4;
+constexpr int REC_MAX_LEAVES = NBANDS * 2 * 16;                   // <= 16 leaves per band and channel (4 split levels)
+constexpr int REC_MAX_WORDS = NBANDS * (REC_BAND_WORDS + 2 * 31); // band words + <= 31 tree nodes per band and channel
 
 enum { // ParseRec.flags
     RF_SILENCE = 1, RF_TRANSIENT = 2, RF_LM_SHIFT = 2 /* 2 bits */, RF_STEREO = 16, RF_SPREAD_SHIFT = 5 /* 2 bits */,
@@ -37,11 +41,16 @@ enum { // ParseRec.flags
     RF_SKIP = 2048,    // descriptor rejected before any state change (decode_frame_wave's BAD_ARG)
     RF_BAD_CELT = 4096 // celt_decode_frame's early BAD_ARG: bookkeeping only
 };
-enum { // band word
-    BW_UPDATE_LOW = 1, BW_SIGN0 = 2, BW_SIGN1 = 4, BW_ITHETA_SHIFT = 3 /* 15 bits */, BW_INV = 1 << 18, BW_SIGN = 1 << 19,
-    BW_MID_FIRST = 1 << 20
+// Band words.  W0: flags below; W1: eff_low | x << 11 | N << 22 (positions relative to their arena rows);
+// W2: imid | iside << 16 (stereo split gains, Q15); W3: lowband_out scale sqrt(N) (Q?) in the low 16 bits.
+enum {
+    BW_SIGN0 = 1, BW_SIGN1 = 2, BW_INV = 4, BW_SIGN = 8, BW_MID_FIRST = 16, BW_SWAP = 32,
+    BW_THETA0 = 64, BW_THETA1 = 128,   // the stereo angle is exactly 0 / exactly 16384 (fill mask halves)
+    BW_TF_SHIFT = 8 /* tf_change + 4, 3 bits */, BW_FOLD0_SHIFT = 11 /* 5 bits */, BW_FOLD1_SHIFT = 16 /* 5 bits */,
+    BW_HAS_LOW = 1 << 21, BW_DUAL = 1 << 22, BW_DUAL_END = 1 << 23, BW_STEREO = 1 << 24
 };
-enum { NW_SPLIT = 1u << 31, NW_MID_FIRST = 1 << 15 }; // tree node word: SPLIT | mid_first | itheta, or the leaf's K
+// Tree node words.  Split: NW_SPLIT | NW_MID_FIRST? | NW_THETA0/1?; leaf: K | gain << 8.
+enum { NW_SPLIT = 1u << 31, NW_MID_FIRST = 1, NW_THETA0 = 2, NW_THETA1 = 4 };
 
 struct ParseRec {
     i32 ret;       // samples per channel (960) -- or the negative code the frame ends with
@@ -142,7 +151,7 @@ OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits
             const i32 sbits = b - mbits;
             remaining_bits -= sc.qalloc;
             const int mid_first = mbits >= sbits;
-            out.word(NW_SPLIT | (mid_first ? NW_MID_FIRST : 0) | (u32)itheta);
+            out.word(NW_SPLIT | (mid_first ? NW_MID_FIRST : 0) | (itheta == 0 ? NW_THETA0 : 0) | (itheta == 16384 ? NW_THETA1 : 0));
             i32 *F = &PL.u.stack[depth][0][OG_LANE];
             F[0 * OG_PL_LANES] = x | N << 11 | (LM + 1) << 19 | B << 22 | mid_first << 27 | 1 << 28;
             F[1 * OG_PL_LANES] = mbits;
@@ -171,7 +180,7 @@ OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits
                 remaining_bits -= curr_bits;
             }
             const int K = q ? get_pulses(q) : 0;
-            out.word((u32)K);
+            out.word((u32)K | (u32)(gain & 0xffff) << 8);
             if (K) out.leaf(x, N, K, B, gain, rc_uint(rc, pvq_u_rom(N, K) + pvq_u_rom(N, K + 1)));
         }
         for (;;) { // back to the parents
@@ -202,11 +211,14 @@ OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits
     }
 }
 
-// quant_all_bands celt.cpp:1754, range-decoder half
-OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C, int N_ch, int shortBlocks, int dual_stereo,
-                            int intensity, i32 total_bits, i32 balance, int LM, int codedBands, int disable_inv) {
+// quant_all_bands celt.cpp:1754: the range-decoder half, plus everything else about a band that is known without the
+// decoded spectrum (folding source and mask range, stereo gains, the folding-history scale).
+OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C, int N_ch, int shortBlocks, int spread,
+                            int dual_stereo, int intensity, i32 total_bits, i32 balance, int LM, int codedBands, int disable_inv) {
     const LaneArr a;
     const int M = 1 << LM, B = shortBlocks ? M : 1;
+    const int norm_offset = M * rom_eband[start];
+    int lowband_offset = 0, update_lowband = 1;
     for (int i = start; i < end; i++) {
         const int eb0 = M * rom_eband[i], N = M * rom_eband[i + 1] - eb0;
         const int x = eb0, y = C == 2 ? N_ch + eb0 : -1;
@@ -220,16 +232,36 @@ OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int 
         } else
             b = 0;
         const int tf_change = a.tf_res(i);
-        if (dual_stereo && i == intensity) dual_stereo = 0;
-        u32 bw = b > (N << BITRES) ? BW_UPDATE_LOW : 0;
+        // ---- folding source (celt.cpp:1812-1850): offsets into the folding history and the bands whose collapse
+        //      masks feed this band's fill mask
+        if ((eb0 - N >= M * rom_eband[start] || i == start + 1) && (update_lowband || lowband_offset == 0)) lowband_offset = i;
+        u32 w0 = (u32)(tf_change + 4) << BW_TF_SHIFT, w1 = (u32)eb0 << 11 | (u32)N << 22;
+        if (lowband_offset != 0 && (spread != 3 || B > 1 || tf_change < 0)) {
+            const int effective_lowband = OG_MAX(0, M * rom_eband[lowband_offset] - norm_offset - N);
+            int fold_start = lowband_offset;
+            while (M * rom_eband[--fold_start] > effective_lowband + norm_offset) {}
+            int fold_end = lowband_offset - 1;
+            while (++fold_end < i && M * rom_eband[fold_end] < effective_lowband + norm_offset + N) {}
+            w0 |= BW_HAS_LOW | (u32)fold_start << BW_FOLD0_SHIFT | (u32)fold_end << BW_FOLD1_SHIFT;
+            w1 |= (u32)effective_lowband;
+        }
+        if (dual_stereo && i == intensity) {
+            dual_stereo = 0;
+            w0 |= BW_DUAL_END;
+        }
+        if (dual_stereo) w0 |= BW_DUAL;
+        u32 w2 = 0;
         if (N == 1) { // quant_band_n1 celt.cpp:1357
             for (int c = 0; c < (y >= 0 ? 2 : 1); c++) {
                 if (remaining_bits >= 1 << BITRES) {
-                    if (rc_bits(rc, 1)) bw |= c ? BW_SIGN1 : BW_SIGN0;
+                    if (rc_bits(rc, 1)) w0 |= c ? BW_SIGN1 : BW_SIGN0;
                     remaining_bits -= 1 << BITRES;
                 }
             }
-            out.word(bw);
+            out.word(w0);
+            out.word(w1);
+            out.word(0);
+            out.word(0);
         } else {
             const int stereo = (y >= 0) && !dual_stereo;
             Split sc;
@@ -238,8 +270,12 @@ OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int 
             int n2case = 0, swap_c = 0, mid_first = 1, njobs = 1;
             if (stereo) { // quant_band_stereo celt.cpp:1628
                 compute_theta(rc, i, intensity, disable_inv, remaining_bits, sc, N, bb, B, B, LM, 1, fill_unused);
-                bw |= (u32)sc.itheta << BW_ITHETA_SHIFT;
-                if (sc.inv) bw |= BW_INV;
+                w0 |= BW_STEREO;
+                if (sc.itheta == 0) w0 |= BW_THETA0;
+                if (sc.itheta == 16384) w0 |= BW_THETA1;
+                if (sc.itheta > 8192) w0 |= BW_SWAP;
+                if (sc.inv) w0 |= BW_INV;
+                w2 = (u32)(sc.imid & 0xffff) | (u32)sc.iside << 16;
                 if (N == 2) {
                     n2case = 1;
                     mbits = bb;
@@ -248,7 +284,7 @@ OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int 
                     mbits -= sbits;
                     swap_c = sc.itheta > 8192;
                     remaining_bits -= sc.qalloc + sbits;
-                    if (sbits && rc_bits(rc, 1)) bw |= BW_SIGN;
+                    if (sbits && rc_bits(rc, 1)) w0 |= BW_SIGN;
                 } else {
                     mbits = OG_MAX(0, OG_MIN(bb, (bb - sc.delta) / 2));
                     sbits = bb - mbits;
@@ -259,8 +295,11 @@ OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int 
                 }
             } else if (dual_stereo)
                 njobs = 2;
-            if (mid_first) bw |= BW_MID_FIRST;
-            out.word(bw);
+            if (mid_first) w0 |= BW_MID_FIRST;
+            out.word(w0);
+            out.word(w1);
+            out.word(w2);
+            out.word((u32)(u16)tr16(celt_sqrt(shl32(N, 22)))); // scale of the folding history (celt.cpp:1617)
             for (int jb = 0; jb < njobs; jb++) {
                 int jx;
                 i32 jbits, jgain = 32767;
@@ -301,6 +340,7 @@ OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int 
             }
         }
         balance += pulses_i + tell;
+        update_lowband = b > (N << BITRES);
     }
 }
 
@@ -348,7 +388,7 @@ OG_DEV void celt_parse_lane(const StreamState *st, const u8 *payload, int len, i
         rec->pulses[i] = (i16)a.pulses(i);
         rec->tf_res[i] = a.tf_res(i);
     }
-    parse_all_bands(rc, out, start, end, C, N, h.transient ? M : 0, h.dual_stereo, h.intensity,
+    parse_all_bands(rc, out, start, end, C, N, h.transient ? M : 0, h.spread, h.dual_stereo, h.intensity,
                     (i32)rc.storage * (8 << BITRES) - h.anti_collapse_rsv, h.balance, LM, h.codedBands, disable_inv);
     int anti_collapse_on = 0;
     if (h.anti_collapse_rsv > 0) anti_collapse_on = (int)rc_bits(rc, 1);
@@ -452,13 +492,13 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
         yy += val * val;
     }
     // collapse mask from the pulses, then scale them in place
+    const int logB = ilog2(B), blen = N >> logB; // B is a power of two
     u32 cm = 1;
     if (B > 1) {
-        const int N0 = (int)udiv((u32)N, (u32)B);
         cm = 0;
         for (int b = 0, j = 0; b < B; b++) {
             u32 any = 0;
-            for (int e = 0; e < N0; e++, j++) any |= (u32)(u16)S.v[x + j];
+            for (int e = 0; e < blen; e++, j++) any |= (u32)(u16)S.v[x + j];
             cm |= (u32)(any != 0) << b;
         }
     }
@@ -476,7 +516,6 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
             stride2 = 1;
             while ((stride2 * stride2 + stride2) * B + (B >> 2) < N) stride2++;
         }
-        const int blen = (int)udiv((u32)N, (u32)B);
         for (int blk = 0; blk < B; blk++) {
             if (stride2) rotate1_lane(x + blk * blen, blen, stride2, s, c);
             rotate1_lane(x + blk * blen, blen, 1, c, s);
@@ -505,14 +544,46 @@ OG_DEV u32 rec_word(RecCur &cur) {
     return w;
 }
 
+// The noise generator jumped ahead (lcg_skip) by n = lane + 1, lane + 65, lane + 129 steps: s -> a s + c.  Computed
+// once per frame; every noise / dither pass then costs one multiply-add per coefficient.
+struct LcgTab {
+    u32 a[3], c[3];
+    OG_MEMBER void init() {
+        for (int k = 0; k < 3; k++) {
+            u32 n = (u32)(OG_LANE + 64 * k + 1), ra = 1u, rc = 0u, ba = 1664525u, bc = 1013904223u;
+            while (n) {
+                if (n & 1u) {
+                    ra = ba * ra;
+                    rc = ba * rc + bc;
+                }
+                bc = ba * bc + bc;
+                ba = ba * ba;
+                n >>= 1;
+            }
+            a[k] = ra;
+            c[k] = rc;
+        }
+    }
+    // seed advanced by (j + 1) steps, j = lane + 64 k   [host emulation: one lane, j arbitrary]
+    OG_MEMBER u32 at(u32 seed, int j) const {
+#ifdef OG_HOST_EMUL
+        return lcg_skip(seed, (u32)j + 1);
+#else
+        const int k = j >> 6;
+        return (k == 0 ? a[0] : k == 1 ? a[1] : a[2]) * seed + (k == 0 ? c[0] : k == 1 ? c[1] : c[2]);
+#endif
+    }
+};
+
 // Leaf of the partition tree, vector half (celt.cpp:1463-1520): a K > 0 leaf is complete already (pvq_leaf_lane),
 // a leaf without pulses is zeroed, noise-filled or folded from the lower band.
-OG_DEV u32 recon_leaf(RecCur &cur, int K, u32 &seed_io, int x, int N, int B, int low, i32 gain, i32 fill) {
-    if (K != 0) { // decoded, scaled and de-rotated by the leaf pass already: only the collapse mask is needed
+OG_DEV u32 recon_leaf(RecCur &cur, const LcgTab &lcg, u32 w, u32 &seed_io, int x, int N, int B, int low, i32 fill) {
+    if (w & 255) { // decoded, scaled and de-rotated by the leaf pass: only the collapse mask is needed
         const u32 cm = (u32)OG_UNI(leaf_masks()[cur.leaf]);
         cur.leaf++;
         return cm;
     }
+    const i32 gain = (i32)((w >> 8) & 0xffff);
     const u32 cm_mask = (u32)((1ull << B) - 1);
     fill &= (i32)cm_mask;
     OG_SYNC();
@@ -524,13 +595,10 @@ OG_DEV u32 recon_leaf(RecCur &cur, int K, u32 &seed_io, int x, int N, int B, int
     const u32 seed = seed_io;
     u32 cm;
     if (low < 0) { // noise
-        OG_FOR_LANES(j, N) S.v[x + j] = (i16)((i32)lcg_skip(seed, (u32)j + 1) >> 20);
+        OG_FOR_LANES(j, N) S.v[x + j] = (i16)((i32)lcg.at(seed, j) >> 20);
         cm = cm_mask;
     } else { // folded spectrum, +-1/256 dither
-        OG_FOR_LANES(j, N) {
-            const u32 sj = lcg_skip(seed, (u32)j + 1);
-            S.v[x + j] = (i16)(S.v[low + j] + ((sj & 0x8000) ? 4 : -4));
-        }
+        OG_FOR_LANES(j, N) S.v[x + j] = (i16)(S.v[low + j] + ((lcg.at(seed, j) & 0x8000) ? 4 : -4));
         cm = (u32)fill;
     }
     seed_io = lcg_skip(seed, (u32)N);
@@ -538,147 +606,127 @@ OG_DEV u32 recon_leaf(RecCur &cur, int K, u32 &seed_io, int x, int N, int B, int
     return cm;
 }
 
-struct ReconFrame { i32 x, N, B, B0, LM, low, low2, gain_mid, gain_side, fill, mid_first, stage, cm; };
-OG_LDS ReconFrame g_rframe[5];
-
-// imid / iside of a split angle and its effect on the fill mask (tail of compute_theta, celt.cpp:1320-1353)
-OG_DEV void theta_gains(int itheta, int B, i32 &imid, i32 &iside, i32 &fill) {
-    if (itheta == 0) {
-        imid = 32767;
-        iside = 0;
-        fill &= (1 << B) - 1;
-    } else if (itheta == 16384) {
-        imid = 0;
-        iside = 32767;
-        fill &= ((1 << B) - 1) << B;
-    } else {
-        imid = bitexact_cos(itheta);
-        iside = bitexact_cos(16384 - itheta);
-    }
-}
-
-// quant_partition celt.cpp:1382, vector half, driven by the record's node words
-OG_DEV u32 recon_tree(RecCur &cur, int spread, u32 &seed, int x, int N, int B, int low, int LM, i32 gain, i32 fill) {
-    int depth = 0;
-    for (;;) {
-        u32 w = rec_word(cur);
-        while (w & NW_SPLIT) {
-            const int itheta = (int)(w & 0x7fff), mid_first = (w & NW_MID_FIRST) != 0, B0 = B;
+// quant_partition celt.cpp:1382, vector half, driven by the record's node words.  The reference's recursion (<= 4
+// splits deep) is kept as a compile-time recursion with ONE call site per level (the two children run in a loop), so
+// every level's state sits in scalar registers and the code size grows linearly with the depth.
+template <int LVL>
+OG_DEV u32 recon_node(RecCur &cur, const LcgTab &lcg, u32 &seed, int x, int N, int B, int low, i32 fill) {
+    const u32 w = rec_word(cur);
+    if constexpr (LVL < 4) {
+        if (w & NW_SPLIT) {
+            const int mid_first = (w & NW_MID_FIRST) != 0, B0 = B;
             N >>= 1;
-            LM -= 1;
             if (B == 1) fill = (fill & 1) | (fill << 1);
             B = (B + 1) >> 1;
-            i32 imid, iside;
-            theta_gains(itheta, B, imid, iside, fill);
-            ReconFrame &F = g_rframe[depth];
-            F.x = x; F.N = N; F.B = B; F.B0 = B0; F.LM = LM; F.low = low; F.low2 = low >= 0 ? low + N : -1;
-            F.gain_mid = tr16(mul16_p15(gain, imid)); F.gain_side = tr16(mul16_p15(gain, iside));
-            F.fill = fill; F.mid_first = mid_first; F.stage = 1; F.cm = 0;
-            depth++;
-            if (mid_first)
-                gain = tr16(mul16_p15(gain, imid));
-            else {
-                x = x + N;
-                low = low >= 0 ? low + N : -1;
-                gain = tr16(mul16_p15(gain, iside));
-                fill = fill >> B;
+            if (w & NW_THETA0) fill &= (1 << B) - 1;          // side is silent
+            if (w & NW_THETA1) fill &= ((1 << B) - 1) << B;   // mid is silent
+            u32 cm = 0;
+#pragma nounroll
+            for (int k = 0; k < 2; k++) {
+                const int is_mid = (k == 0) == mid_first;
+                const u32 c = recon_node<LVL + 1>(cur, lcg, seed, is_mid ? x : x + N, N, B, is_mid || low < 0 ? low : low + N,
+                                                  is_mid ? fill : fill >> B);
+                cm |= is_mid ? c : c << (B0 >> 1);
             }
-            w = rec_word(cur);
-        }
-        OG_MARK(7);
-        u32 cm = recon_leaf(cur, (int)(w & 255), seed, x, N, B, low, gain, fill);
-        OG_MARK(6);
-        for (;;) {
-            if (depth == 0) return cm;
-            ReconFrame &F = g_rframe[depth - 1];
-            const int B0 = OG_UNI(F.B0), Bc = OG_UNI(F.B), stage = OG_UNI(F.stage), mid_first = OG_UNI(F.mid_first);
-            if (stage == 1) {
-                F.cm = (i32)(mid_first ? cm : cm << (B0 >> 1));
-                F.stage = 2;
-                N = OG_UNI(F.N);
-                B = Bc;
-                LM = OG_UNI(F.LM);
-                if (mid_first) {
-                    x = OG_UNI(F.x) + N;
-                    low = OG_UNI(F.low2);
-                    gain = OG_UNI(F.gain_side);
-                    fill = OG_UNI(F.fill) >> Bc;
-                } else {
-                    x = OG_UNI(F.x);
-                    low = OG_UNI(F.low);
-                    gain = OG_UNI(F.gain_mid);
-                    fill = OG_UNI(F.fill);
-                }
-                break;
-            }
-            cm = (u32)OG_UNI(F.cm) | (mid_first ? cm << (B0 >> 1) : cm);
-            depth--;
+            return cm;
         }
     }
+    OG_MARK(7);
+    const u32 cm = recon_leaf(cur, lcg, w, seed, x, N, B, low, fill);
+    OG_MARK(6);
+    return cm;
 }
 
-// quant_band celt.cpp:1526, vector half; N > 1
-OG_DEV u32 recon_band_mono(RecCur &cur, int spread, int tf_change, u32 &seed, int x, int N, int B, int low, int LM, int low_out,
-                           i32 gain, int low_scratch, i32 fill) {
-    int N0 = N, N_B, B0 = B, time_divide = 0, recombine = 0;
-    const int longBlocks = B0 == 1;
-    N_B = (int)udiv((u32)N, (u32)B);
+// Haar / Hadamard helpers with power-of-two strides taken as shifts (no integer division in the lane loops)
+OG_DEV void haar1_p2(int x, int N0, int log_stride) { // haar1 celt.cpp:1202, stride = 1 << log_stride
+    N0 >>= 1;
+    const int stride = 1 << log_stride;
+    OG_SYNC();
+    OG_FOR_LANES(id, N0 << log_stride) {
+        const int j = id >> log_stride, i = id & (stride - 1);
+        const int a = x + stride * 2 * j + i, b = a + stride;
+        const i32 t1 = mul16(23170, S.v[a]), t2 = mul16(23170, S.v[b]);
+        S.v[a] = (i16)pshr32(t1 + t2, 15);
+        S.v[b] = (i16)pshr32(t1 - t2, 15);
+    }
+    OG_SYNC();
+}
+// (de)interleave_hadamard celt.cpp:1162 / :1183; stride = 1 << log_stride.  Lanes enumerate the interleaved index.
+OG_DEV void hadamard_p2(int x, int N0, int log_stride, int hadamard, int dir) {
+    const int stride = 1 << log_stride, N = N0 << log_stride;
+    OG_SYNC();
+    OG_FOR_LANES(inter, N) {
+        const int j = inter >> log_stride, i = inter & (stride - 1);
+        const int blocked = (hadamard ? ordery(stride, i) : i) * N0 + j;
+        if (dir == 0)
+            S.v[V_TMP + blocked] = S.v[x + inter];
+        else
+            S.v[V_TMP + inter] = S.v[x + blocked];
+    }
+    OG_SYNC();
+    OG_FOR_LANES(id, N) S.v[x + id] = S.v[V_TMP + id];
+    OG_SYNC();
+}
+
+// quant_band celt.cpp:1526, vector half; N > 1.  `scale`: sqrt(N) for the folding history (from the record).
+OG_DEV u32 recon_band_mono(RecCur &cur, const LcgTab &lcg, int tf_change, u32 &seed, int x, int N, int B, int low, int low_out,
+                           i32 scale, int low_scratch, i32 fill) {
+    const int N0 = N, longBlocks = B == 1;
+    int logB = ilog2(B), time_divide = 0, recombine = 0;
+    int N_B = N >> logB;
     if (tf_change > 0) recombine = tf_change;
-    if (low_scratch >= 0 && low >= 0 && (recombine || ((N_B & 1) == 0 && tf_change < 0) || B0 > 1)) {
+    if (low_scratch >= 0 && low >= 0 && (recombine || ((N_B & 1) == 0 && tf_change < 0) || B > 1)) {
         OG_SYNC();
         OG_FOR_LANES(j, N) S.v[low_scratch + j] = S.v[low + j];
         OG_SYNC();
         low = low_scratch;
     }
     for (int k = 0; k < recombine; k++) {
-        if (low >= 0) haar1(low, N >> k, 1 << k);
+        if (low >= 0) haar1_p2(low, N >> k, k);
         int lo = fill & 0xF, hi = fill >> 4; // bit_interleave_table celt.cpp:1560
         int tl = (lo & 3 ? 1 : 0) | (lo & 12 ? 2 : 0), th = (hi & 3 ? 1 : 0) | (hi & 12 ? 2 : 0);
         fill = tl | th << 2;
     }
-    B >>= recombine;
+    logB -= recombine;
     N_B <<= recombine;
     while ((N_B & 1) == 0 && tf_change < 0) {
-        if (low >= 0) haar1(low, N_B, B);
-        fill |= fill << B;
-        B <<= 1;
+        if (low >= 0) haar1_p2(low, N_B, logB);
+        fill |= fill << (1 << logB);
+        logB++;
         N_B >>= 1;
         time_divide++;
         tf_change++;
     }
-    B0 = B;
-    const int N_B0 = N_B;
-    if (B0 > 1 && low >= 0) hadamard_reorder(low, N_B >> recombine, B0 << recombine, longBlocks, 0);
+    const int logB0 = logB, N_B0 = N_B, B0 = 1 << logB0;
+    if (B0 > 1 && low >= 0) hadamard_p2(low, N_B >> recombine, logB0 + recombine, longBlocks, 0);
     OG_MARK(6);
-    u32 cm = recon_tree(cur, spread, seed, x, N, B, low, LM, gain, fill);
+    u32 cm = recon_node<0>(cur, lcg, seed, x, N, B0, low, fill);
     OG_MARK(8);
-    if (B0 > 1) hadamard_reorder(x, N_B >> recombine, B0 << recombine, longBlocks, 1);
+    if (B0 > 1) hadamard_p2(x, N_B >> recombine, logB0 + recombine, longBlocks, 1);
     N_B = N_B0;
-    B = B0;
     for (int k = 0; k < time_divide; k++) {
-        B >>= 1;
+        logB--;
         N_B <<= 1;
-        cm |= cm >> B;
-        haar1(x, N_B, B);
+        cm |= cm >> (1 << logB);
+        haar1_p2(x, N_B, logB);
     }
     for (int k = 0; k < recombine; k++) {
         u32 c4 = cm & 0xF; // bit_deinterleave_table celt.cpp:1606
         cm = ((c4 & 1) * 0x03) | ((c4 >> 1 & 1) * 0x0C) | ((c4 >> 2 & 1) * 0x30) | ((c4 >> 3 & 1) * 0xC0);
-        haar1(x, N0 >> k, 1 << k);
+        haar1_p2(x, N0 >> k, k);
     }
-    B <<= recombine;
+    logB += recombine;
     OG_MARK(9);
     if (low_out >= 0) {
-        i32 n = tr16(celt_sqrt(shl32(N0, 22)));
         OG_SYNC();
-        OG_FOR_LANES(j, N0) S.v[low_out + j] = (i16)mul16_q15(n, S.v[x + j]);
+        OG_FOR_LANES(j, N0) S.v[low_out + j] = (i16)mul16_q15(scale, S.v[x + j]);
         OG_SYNC();
     }
-    return cm & ((1u << B) - 1);
+    return cm & ((1u << (1 << logB)) - 1);
 }
 
-// quant_all_bands celt.cpp:1754, vector half
-OG_DEV void recon_all_bands(const u32 *words, int start, int end, int C, int N_ch, int shortBlocks, int spread, int dual_stereo, int intensity, int LM,
+// quant_all_bands celt.cpp:1754, vector half: an interpreter of the record's word stream
+OG_DEV void recon_all_bands(const u32 *words, const LcgTab &lcg, int start, int end, int C, int N_ch, int shortBlocks, int LM,
                             u32 &seed_io) {
     const int M = 1 << LM, B = shortBlocks ? M : 1;
     const int norm_offset = M * rom_eband[start];
@@ -686,20 +734,18 @@ OG_DEV void recon_all_bands(const u32 *words, int start, int end, int C, int N_c
     // The reference borrows the last band's spectrum slot as scratch; here that slot already holds the band's
     // decoded pulses, so the scratch row lives in the (otherwise unused) pulse row.
     int low_scratch = V_IY;
-    int lowband_offset = 0, update_lowband = 1;
     RecCur cur;
     cur.words = words;
     cur.w = 0;
     cur.leaf = 0;
     u32 seed = seed_io;
     for (int i = start; i < end; i++) {
-        const int last = i == end - 1;
-        const int eb0 = M * rom_eband[i], N = M * rom_eband[i + 1] - eb0;
-        const int x = V_X + eb0, y = C == 2 ? V_X + N_ch + eb0 : -1;
         OG_MARK(3);
-        const u32 bw = rec_word(cur);
-        if ((eb0 - N >= M * rom_eband[start] || i == start + 1) && (update_lowband || lowband_offset == 0))
-            lowband_offset = i;
+        const int last = i == end - 1;
+        const u32 w0 = rec_word(cur), w1 = rec_word(cur), w2 = rec_word(cur), w3 = rec_word(cur);
+        const int eb0 = (int)(w1 >> 11) & 2047, N = (int)(w1 >> 22) & 255;
+        const int x = V_X + eb0, y = C == 2 ? V_X + N_ch + eb0 : -1;
+        const int dual_stereo = (w0 & BW_DUAL) != 0;
         if (i == start + 1) { // special_hybrid_folding celt.cpp:1743
             int n1 = M * (rom_eband[start + 1] - rom_eband[start]), n2 = M * (rom_eband[start + 2] - rom_eband[start + 1]);
             if (n2 > n1) {
@@ -711,86 +757,79 @@ OG_DEV void recon_all_bands(const u32 *words, int start, int end, int C, int N_c
                 OG_SYNC();
             }
         }
-        const int tf_change = OG_UNI(S.tf_res[i]);
+        const int tf_change = (int)((w0 >> BW_TF_SHIFT) & 7) - 4;
         if (last) low_scratch = -1;
-        int effective_lowband = -1;
         u32 x_cm, y_cm;
-        if (lowband_offset != 0 && (spread != 3 || B > 1 || tf_change < 0)) {
-            effective_lowband = OG_MAX(0, M * rom_eband[lowband_offset] - norm_offset - N);
-            int fold_start = lowband_offset;
-            while (M * rom_eband[--fold_start] > effective_lowband + norm_offset) {}
-            int fold_end = lowband_offset - 1;
-            while (++fold_end < i && M * rom_eband[fold_end] < effective_lowband + norm_offset + N) {}
+        if (w0 & BW_HAS_LOW) {
+            const int fold_end = (int)(w0 >> BW_FOLD1_SHIFT) & 31;
+            int fold_i = (int)(w0 >> BW_FOLD0_SHIFT) & 31;
             x_cm = y_cm = 0;
-            int fold_i = fold_start;
             do {
                 x_cm |= (u32)OG_UNI(S.cmask[fold_i * C + 0]);
                 y_cm |= (u32)OG_UNI(S.cmask[fold_i * C + C - 1]);
             } while (++fold_i < fold_end);
         } else
             x_cm = y_cm = (1u << B) - 1;
-        if (dual_stereo && i == intensity) {
-            dual_stereo = 0;
+        if (w0 & BW_DUAL_END) {
             OG_SYNC();
             OG_FOR_LANES(j, eb0 - norm_offset) S.v[norm + j] = (i16)((S.v[norm + j] + S.v[norm2 + j]) >> 1);
             OG_SYNC();
         }
-        const int low1 = effective_lowband != -1 ? norm + effective_lowband : -1;
-        const int low2 = effective_lowband != -1 ? norm2 + effective_lowband : -1;
-        const int out1 = last ? -1 : norm + eb0 - norm_offset;
-        const int out2 = last ? -1 : norm2 + eb0 - norm_offset;
+        const int eff = (w0 & BW_HAS_LOW) ? (int)(w1 & 2047) : -1;
+        const int low1 = eff >= 0 ? norm + eff : -1, low2 = eff >= 0 ? norm2 + eff : -1;
+        const int out1 = last ? -1 : norm + eb0 - norm_offset, out2 = last ? -1 : norm2 + eb0 - norm_offset;
 
         if (N == 1) { // quant_band_n1 celt.cpp:1357
             OG_MARK(11);
             OG_SYNC();
-            S.v[x] = (i16)((bw & BW_SIGN0) ? -16384 : 16384);
-            if (y >= 0) S.v[y] = (i16)((bw & BW_SIGN1) ? -16384 : 16384);
+            S.v[x] = (i16)((w0 & BW_SIGN0) ? -16384 : 16384);
+            if (y >= 0) S.v[y] = (i16)((w0 & BW_SIGN1) ? -16384 : 16384);
             OG_SYNC();
             if (out1 >= 0) S.v[out1] = (i16)(S.v[x] >> 4);
             if (dual_stereo && out2 >= 0) S.v[out2] = (i16)(S.v[y] >> 4);
             OG_SYNC();
             x_cm = y_cm = 1;
         } else {
-            const int stereo = (y >= 0) && !dual_stereo;
+            OG_MARK(4);
+            const int stereo = (w0 & BW_STEREO) != 0, mid_first = (w0 & BW_MID_FIRST) != 0, swap_c = (w0 & BW_SWAP) != 0;
+            const i32 imid = (i32)(i16)(w2 & 0xffff), iside = (i32)(w2 >> 16), scale = (i32)(i16)(w3 & 0xffff);
             i32 fill0 = (i32)(x_cm | y_cm);
             const i32 orig_fill = fill0;
-            i32 imid = 0, iside = 0;
-            const int itheta = (int)((bw >> BW_ITHETA_SHIFT) & 0x7fff), mid_first = (bw & BW_MID_FIRST) != 0;
-            int n2case = 0, swap_c = 0, njobs = 1;
-            OG_MARK(4);
+            int n2case = 0, njobs = 1;
             if (stereo) {
-                theta_gains(itheta, B, imid, iside, fill0);
-                if (N == 2) {
+                if (w0 & BW_THETA0) fill0 &= (1 << B) - 1;
+                if (w0 & BW_THETA1) fill0 &= ((1 << B) - 1) << B;
+                if (N == 2)
                     n2case = 1;
-                    swap_c = itheta > 8192;
-                } else
+                else
                     njobs = 2;
             } else if (dual_stereo)
                 njobs = 2;
             u32 cm0 = 0, cm1 = 0;
+#pragma nounroll
             for (int jb = 0; jb < njobs; jb++) {
                 int jx, jlow, jout, jscr;
-                i32 jgain, jfill;
+                i32 jfill;
                 if (dual_stereo) {
                     jx = jb ? y : x; jlow = jb ? low2 : low1; jout = jb ? out2 : out1; jscr = low_scratch;
-                    jgain = 32767; jfill = (i32)(jb ? y_cm : x_cm);
+                    jfill = (i32)(jb ? y_cm : x_cm);
                 } else if (!stereo) {
-                    jx = x; jlow = low1; jout = out1; jscr = low_scratch; jgain = 32767; jfill = fill0;
+                    jx = x; jlow = low1; jout = out1; jscr = low_scratch; jfill = fill0;
                 } else if (n2case) {
-                    jx = swap_c ? y : x; jlow = low1; jout = out1; jscr = low_scratch; jgain = 32767; jfill = orig_fill;
+                    jx = swap_c ? y : x; jlow = low1; jout = out1; jscr = low_scratch; jfill = orig_fill;
                 } else if ((jb == 0) == (mid_first != 0)) {
-                    jx = x; jlow = low1; jout = out1; jscr = low_scratch; jgain = 32767; jfill = fill0;
+                    jx = x; jlow = low1; jout = out1; jscr = low_scratch; jfill = fill0;
                 } else {
-                    jx = y; jlow = -1; jout = -1; jscr = -1; jgain = iside; jfill = fill0 >> B;
+                    jx = y; jlow = -1; jout = -1; jscr = -1; jfill = fill0 >> B;
                 }
                 OG_MARK(5);
-                const u32 cmj = recon_band_mono(cur, spread, tf_change, seed, jx, N, B, jlow, LM, jout, jgain, jscr, jfill);
+                const u32 cmj = recon_band_mono(cur, lcg, tf_change, seed, jx, N, B, jlow, jout, scale, jscr, jfill);
                 if (jb == 0) cm0 = cmj; else cm1 = cmj;
             }
             OG_MARK(10);
             if (stereo) {
                 if (n2case) { // N == 2: the side is the mid rotated by 90 degrees (celt.cpp:1659-1697)
-                    const int x2 = swap_c ? y : x, sign = (bw & BW_SIGN) ? -1 : 1;
+                    const int x2 = swap_c ? y : x, sign = (w0 & BW_SIGN) ? -1 : 1;
                     OG_SYNC();
                     const i32 a0 = S.v[x2], a1 = S.v[x2 + 1];
                     const i32 b0 = tr16(-sign * a1), b1 = tr16(sign * a0);
@@ -807,7 +846,7 @@ OG_DEV void recon_all_bands(const u32 *words, int start, int end, int C, int N_c
                     OG_SYNC();
                 } else
                     stereo_merge(x, y, imid, N);
-                if (bw & BW_INV) {
+                if (w0 & BW_INV) {
                     OG_SYNC();
                     OG_FOR_LANES(j, N) S.v[y + j] = (i16)(-S.v[y + j]);
                     OG_SYNC();
@@ -821,7 +860,6 @@ OG_DEV void recon_all_bands(const u32 *words, int start, int end, int C, int N_c
         }
         S.cmask[i * C + 0] = (u8)x_cm;
         S.cmask[i * C + C - 1] = (u8)y_cm;
-        update_lowband = (bw & BW_UPDATE_LOW) != 0;
     }
     seed_io = seed;
 }
@@ -844,9 +882,9 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         const int LM = (int)(flags >> RF_LM_SHIFT) & 3, M = 1 << LM, N = M * 120;
         const int transient = (flags & RF_TRANSIENT) != 0, silence = (flags & RF_SILENCE) != 0;
         const int spread = (int)(flags >> RF_SPREAD_SHIFT) & 3, start = OG_UNI(rec->start), end = NBANDS;
-        const int n_leaves = OG_UNI(rec->n_leaves), n_words = OG_UNI(rec->n_words);
+        const int n_leaves = OG_UNI(rec->n_leaves);
         CeltState *cs = &st->celt;
-        // ---- stage the record and the persistent scalars
+        // ---- stage the record's header arrays and the persistent scalars
         OG_MARK(1);
         OG_SYNC();
         OG_FOR_LANES(i, 2 * NBANDS) {
@@ -861,6 +899,8 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         }
         OG_FOR_LANES(i, 2 * N) S.v[V_X + i] = 0;
         OG_FOR_LANES(i, 1248) S.v[V_NORM + i] = 0;
+        LcgTab lcg;
+        lcg.init();
         OG_SYNC();
 #if defined(OG_RABL) && OG_RABL == 1
         return ret;
@@ -877,7 +917,7 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         return ret;
 #endif
         u32 seed = cs->rng;
-        recon_all_bands(rec->words, start, end, C, N, transient ? M : 0, spread, (flags & RF_DUAL) != 0, OG_UNI(rec->intensity), LM, seed);
+        recon_all_bands(rec->words, lcg, start, end, C, N, transient ? M : 0, LM, seed);
         OG_MARK(12);
         if (flags & RF_ANTI_COLLAPSE) anti_collapse(LM, C, N, start, end, seed);
         if (silence) {
@@ -903,7 +943,6 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         st->range_final = rng_final;
     }
     return result; // de-emphasis and PCM: celt_post_lane (k_celt_post), from the history ring
-
 }
 
 // Third step of the split path for (frame, channel c): runs whenever the frame was synthesised; PCM only on success.
