@@ -33,7 +33,7 @@ namespace og {
 // ---- the record ------------------------------------------------------------------------------------
 constexpr int REC_BAND_WORDS = 4;
 constexpr int REC_MAX_LEAVES = NBANDS * 2 * 16;                   // <= 16 leaves per band and channel (4 split levels)
-constexpr int REC_MAX_WORDS = NBANDS * (REC_BAND_WORDS + 2 * 31); // band words + <= 31 tree nodes per band and channel
+constexpr int REC_MAX_WORDS = NBANDS * (REC_BAND_WORDS + 2 * 32); // band words + <= 16 leaves x 2 words per band and channel
 
 enum { // ParseRec.flags
     RF_SILENCE = 1, RF_TRANSIENT = 2, RF_LM_SHIFT = 2 /* 2 bits */, RF_STEREO = 16, RF_SPREAD_SHIFT = 5 /* 2 bits */,
@@ -49,8 +49,12 @@ enum {
     BW_TF_SHIFT = 8 /* tf_change + 4, 3 bits */, BW_FOLD0_SHIFT = 11 /* 5 bits */, BW_FOLD1_SHIFT = 16 /* 5 bits */,
     BW_HAS_LOW = 1 << 21, BW_DUAL = 1 << 22, BW_DUAL_END = 1 << 23, BW_STEREO = 1 << 24
 };
-// Tree node words.  Split: NW_SPLIT | NW_MID_FIRST? | NW_THETA0/1?; leaf: K | gain << 8.
-enum { NW_SPLIT = 1u << 31, NW_MID_FIRST = 1, NW_THETA0 = 2, NW_THETA1 = 4 };
+// Leaf words (the leaves of one band-and-channel "job" in decode order).  L0: K | off | B-1 | N | flags; a leaf without
+// pulses (K == 0, LW_TWO) has a second word: x | gain << 11.
+enum {
+    LW_OFF_SHIFT = 8 /* 4 bits */, LW_B_SHIFT = 12 /* 4 bits */, LW_N_SHIFT = 16 /* 8 bits */, LW_SILENT = 1 << 24,
+    LW_TWO = 1 << 30, LW_LAST = 1u << 31
+};
 
 struct ParseRec {
     i32 ret;       // samples per channel (960) -- or the negative code the frame ends with
@@ -125,9 +129,16 @@ struct RecWriter {
     }
 };
 
-// quant_partition celt.cpp:1382, range-decoder half: split decisions, angles, pulse counts and PVQ indices.
+// quant_partition celt.cpp:1382, range-decoder half: split decisions, angles, pulse counts and PVQ indices.  The
+// partition tree itself does not reach the record: the reconstruction only needs its LEAVES in decode order, each with
+// what the tree implies for it -- position, size, gain, and how the band's fill / collapse masks map onto the leaf:
+//   fill(leaf) = silent ? 0 : (fill(job) >> off) & ((1 << B) - 1)        cm(job) |= cm(leaf) << off
+// (`off` sums B0 >> 1 over the splits whose side branch leads to the leaf; a split with angle 0 silences its side
+// branch, one with angle 16384 its mid branch: compute_theta's fill masks, celt.cpp:1320-1353.)
 OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits, int x, int N, i32 b, int B, int LM, i32 gain) {
-    int depth = 0;
+    int depth = 0, off = 0, silent = 0;
+    u32 pending0 = 0, pending1 = 0; // the previous leaf's words: held back so the job's last leaf can be flagged
+    int have_pending = 0;
     for (;;) {
         for (;;) { // descend
             const u8 *cache = pulse_cache(band, LM);
@@ -151,23 +162,27 @@ OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits
             const i32 sbits = b - mbits;
             remaining_bits -= sc.qalloc;
             const int mid_first = mbits >= sbits;
-            out.word(NW_SPLIT | (mid_first ? NW_MID_FIRST : 0) | (itheta == 0 ? NW_THETA0 : 0) | (itheta == 16384 ? NW_THETA1 : 0));
+            const int off_side = off + (B0 >> 1), silent_mid = silent | (itheta == 16384), silent_side = silent | (itheta == 0);
             i32 *F = &PL.u.stack[depth][0][OG_LANE];
             F[0 * OG_PL_LANES] = x | N << 11 | (LM + 1) << 19 | B << 22 | mid_first << 27 | 1 << 28;
             F[1 * OG_PL_LANES] = mbits;
             F[2 * OG_PL_LANES] = sbits;
             F[3 * OG_PL_LANES] = remaining_bits;
-            F[4 * OG_PL_LANES] = itheta;
+            // what the second child needs: its mask offset and whether it is silent
+            F[4 * OG_PL_LANES] = itheta | (mid_first ? off_side : off) << 16 | (mid_first ? silent_side : silent_mid) << 24;
             const i32 gain_mid = tr16(mul16_p15(gain, sc.imid)), gain_side = tr16(mul16_p15(gain, sc.iside));
             F[5 * OG_PL_LANES] = (gain_mid & 0xffff) | gain_side << 16;
             depth++;
             if (mid_first) {
                 b = mbits;
                 gain = gain_mid;
+                silent = silent_mid;
             } else {
                 x += N;
                 b = sbits;
                 gain = gain_side;
+                off = off_side;
+                silent = silent_side;
             }
         }
         { // leaf: pulse count from the remaining budget, then the codeword index (celt.cpp:1463-1480)
@@ -180,17 +195,28 @@ OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits
                 remaining_bits -= curr_bits;
             }
             const int K = q ? get_pulses(q) : 0;
-            out.word((u32)K | (u32)(gain & 0xffff) << 8);
+            if (have_pending) {
+                out.word(pending0);
+                if (pending0 & LW_TWO) out.word(pending1);
+            }
+            pending0 = (u32)K | (u32)off << LW_OFF_SHIFT | (u32)(B - 1) << LW_B_SHIFT | (u32)N << LW_N_SHIFT | (silent ? LW_SILENT : 0) |
+                       (K ? 0 : LW_TWO);
+            pending1 = (u32)x | (u32)(gain & 0xffff) << 11;
+            have_pending = 1;
             if (K) out.leaf(x, N, K, B, gain, rc_uint(rc, pvq_u_rom(N, K) + pvq_u_rom(N, K + 1)));
         }
         for (;;) { // back to the parents
-            if (depth == 0) return;
+            if (depth == 0) {
+                out.word(pending0 | LW_LAST);
+                if (pending0 & LW_TWO) out.word(pending1);
+                return;
+            }
             i32 *F = &PL.u.stack[depth - 1][0][OG_LANE];
             const i32 w0 = F[0];
             const int mid_first = (w0 >> 27) & 1, stage = (w0 >> 28) & 3;
             if (stage == 1) {
                 i32 mbits = F[1 * OG_PL_LANES], sbits = F[2 * OG_PL_LANES];
-                const int itheta = F[4 * OG_PL_LANES];
+                const int itheta = F[4 * OG_PL_LANES] & 0x7fff;
                 const i32 rebalance = (mid_first ? mbits : sbits) - (F[3 * OG_PL_LANES] - remaining_bits);
                 if (mid_first) {
                     if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES);
@@ -204,6 +230,8 @@ OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits
                 x = (w0 & 2047) + (mid_first ? N : 0);
                 b = mid_first ? sbits : mbits;
                 gain = mid_first ? F[5 * OG_PL_LANES] >> 16 : (i32)(i16)F[5 * OG_PL_LANES];
+                off = (F[4 * OG_PL_LANES] >> 16) & 15;
+                silent = (F[4 * OG_PL_LANES] >> 24) & 1;
                 break;
             }
             depth--;
@@ -575,66 +603,48 @@ struct LcgTab {
     }
 };
 
-// Leaf of the partition tree, vector half (celt.cpp:1463-1520): a K > 0 leaf is complete already (pvq_leaf_lane),
-// a leaf without pulses is zeroed, noise-filled or folded from the lower band.
-OG_DEV u32 recon_leaf(RecCur &cur, const LcgTab &lcg, u32 w, u32 &seed_io, int x, int N, int B, int low, i32 fill) {
-    if (w & 255) { // decoded, scaled and de-rotated by the leaf pass: only the collapse mask is needed
-        const u32 cm = (u32)OG_UNI(leaf_masks()[cur.leaf]);
-        cur.leaf++;
-        return cm;
-    }
-    const i32 gain = (i32)((w >> 8) & 0xffff);
-    const u32 cm_mask = (u32)((1ull << B) - 1);
-    fill &= (i32)cm_mask;
-    OG_SYNC();
-    if (!fill) {
-        OG_FOR_LANES(j, N) S.v[x + j] = 0;
-        OG_SYNC();
-        return 0;
-    }
-    const u32 seed = seed_io;
-    u32 cm;
-    if (low < 0) { // noise
-        OG_FOR_LANES(j, N) S.v[x + j] = (i16)((i32)lcg.at(seed, j) >> 20);
-        cm = cm_mask;
-    } else { // folded spectrum, +-1/256 dither
-        OG_FOR_LANES(j, N) S.v[x + j] = (i16)(S.v[low + j] + ((lcg.at(seed, j) & 0x8000) ? 4 : -4));
-        cm = (u32)fill;
-    }
-    seed_io = lcg_skip(seed, (u32)N);
-    renormalise(x, N, gain);
-    return cm;
-}
-
-// quant_partition celt.cpp:1382, vector half, driven by the record's node words.  The reference's recursion (<= 4
-// splits deep) is kept as a compile-time recursion with ONE call site per level (the two children run in a loop), so
-// every level's state sits in scalar registers and the code size grows linearly with the depth.
-template <int LVL>
-OG_DEV u32 recon_node(RecCur &cur, const LcgTab &lcg, u32 &seed, int x, int N, int B, int low, i32 fill) {
-    const u32 w = rec_word(cur);
-    if constexpr (LVL < 4) {
-        if (w & NW_SPLIT) {
-            const int mid_first = (w & NW_MID_FIRST) != 0, B0 = B;
-            N >>= 1;
-            if (B == 1) fill = (fill & 1) | (fill << 1);
-            B = (B + 1) >> 1;
-            if (w & NW_THETA0) fill &= (1 << B) - 1;          // side is silent
-            if (w & NW_THETA1) fill &= ((1 << B) - 1) << B;   // mid is silent
-            u32 cm = 0;
-#pragma nounroll
-            for (int k = 0; k < 2; k++) {
-                const int is_mid = (k == 0) == mid_first;
-                const u32 c = recon_node<LVL + 1>(cur, lcg, seed, is_mid ? x : x + N, N, B, is_mid || low < 0 ? low : low + N,
-                                                  is_mid ? fill : fill >> B);
-                cm |= is_mid ? c : c << (B0 >> 1);
+// The leaves of one job (quant_partition celt.cpp:1382 flattened by the parse kernel), vector half: a leaf with pulses
+// is complete already (pvq_leaf_lane) and only contributes its collapse mask; a leaf without pulses is zeroed,
+// noise-filled or folded from the lower band (celt.cpp:1481-1520).  Returns the job's collapse mask.
+OG_DEV u32 recon_job_leaves(RecCur &cur, const LcgTab &lcg, u32 &seed_io, int x_job, int low_job, i32 fill_job) {
+    u32 cm_job = 0, w;
+    do {
+        w = rec_word(cur);
+        const int off = (int)(w >> LW_OFF_SHIFT) & 15;
+        u32 cm;
+        if (!(w & LW_TWO)) {
+            cm = (u32)OG_UNI(leaf_masks()[cur.leaf]);
+            cur.leaf++;
+        } else {
+            OG_MARK(7);
+            const u32 w1 = rec_word(cur);
+            const int B = ((int)(w >> LW_B_SHIFT) & 15) + 1, N = (int)(w >> LW_N_SHIFT) & 255, x = V_X + (int)(w1 & 2047);
+            const i32 gain = (i32)((w1 >> 11) & 0xffff);
+            const u32 cm_mask = (u32)((1ull << B) - 1);
+            const i32 fill = (w & LW_SILENT) ? 0 : (i32)((u32)(fill_job >> off) & cm_mask);
+            OG_SYNC();
+            if (!fill) {
+                OG_FOR_LANES(j, N) S.v[x + j] = 0;
+                OG_SYNC();
+                cm = 0;
+            } else {
+                const u32 seed = seed_io;
+                if (low_job < 0) { // noise
+                    OG_FOR_LANES(j, N) S.v[x + j] = (i16)((i32)lcg.at(seed, j) >> 20);
+                    cm = cm_mask;
+                } else { // folded spectrum, +-1/256 dither
+                    const int low = low_job + (x - x_job);
+                    OG_FOR_LANES(j, N) S.v[x + j] = (i16)(S.v[low + j] + ((lcg.at(seed, j) & 0x8000) ? 4 : -4));
+                    cm = (u32)fill;
+                }
+                seed_io = lcg_skip(seed, (u32)N);
+                renormalise(x, N, gain);
             }
-            return cm;
+            OG_MARK(6);
         }
-    }
-    OG_MARK(7);
-    const u32 cm = recon_leaf(cur, lcg, w, seed, x, N, B, low, fill);
-    OG_MARK(6);
-    return cm;
+        cm_job |= cm << off;
+    } while (!(w & LW_LAST));
+    return cm_job;
 }
 
 // Haar / Hadamard helpers with power-of-two strides taken as shifts (no integer division in the lane loops)
@@ -700,7 +710,7 @@ OG_DEV u32 recon_band_mono(RecCur &cur, const LcgTab &lcg, int tf_change, u32 &s
     const int logB0 = logB, N_B0 = N_B, B0 = 1 << logB0;
     if (B0 > 1 && low >= 0) hadamard_p2(low, N_B >> recombine, logB0 + recombine, longBlocks, 0);
     OG_MARK(6);
-    u32 cm = recon_node<0>(cur, lcg, seed, x, N, B0, low, fill);
+    u32 cm = recon_job_leaves(cur, lcg, seed, x, low, fill);
     OG_MARK(8);
     if (B0 > 1) hadamard_p2(x, N_B >> recombine, logB0 + recombine, longBlocks, 1);
     N_B = N_B0;
