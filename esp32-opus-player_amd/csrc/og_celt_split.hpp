@@ -448,6 +448,7 @@ OG_DEV void celt_parse_lane(const StreamState *st, const u8 *payload, int len, i
 // scaled to the leaf's gain (normalise_residual :745), spreading rotation undone (exp_rotation :707, dir = -1),
 // collapse mask (extract_collapse_mask :760).  Everything is a serial chain per leaf, so the frame's leaves run
 // one per lane; the result is written in place at S.v[pos .. pos+n).  Returns the collapse mask.
+#ifdef OG_LEAF_ROT_SIMPLE
 OG_DEV void rotate1_lane(int x, int len, int stride, i32 c, i32 s) { // exp_rotation1 celt.cpp:684
     const i32 ms = tr16(-s);
     for (int i = 0; i < len - stride; i++) {
@@ -461,44 +462,70 @@ OG_DEV void rotate1_lane(int x, int len, int stride, i32 c, i32 s) { // exp_rota
         S.v[x + i] = (i16)pshr32(mul16(c, x1) + mul16(ms, x2), 15);
     }
 }
+#else
+OG_DEV void rotate1_lane(int x, int len, int stride, i32 c, i32 s) { // exp_rotation1 celt.cpp:684
+    // The reference sweeps i = 0 .. len-stride-1 forward, then len-2*stride-1 .. 0 backward, over pairs (i, i+stride).
+    // Pairs with different i mod stride never touch the same element, so each residue class ("chain") can be walked
+    // on its own, carrying the element both consecutive steps share in a register: one LDS read and one write per step.
+    const i32 ms = tr16(-s);
+    for (int r = 0; r < stride; r++) {
+        if (r < len - stride) { // forward along the chain r, r+stride, ...
+            int i = r;
+            i32 x1 = S.v[x + i];
+            for (; i < len - stride; i += stride) {
+                const i32 x2 = S.v[x + i + stride];
+                S.v[x + i] = (i16)pshr32(mul16(c, x1) + mul16(ms, x2), 15);
+                x1 = tr16(pshr32(mul16(c, x2) + mul16(s, x1), 15));
+            }
+            S.v[x + i] = (i16)x1;
+        }
+        const int last = len - 2 * stride - 1;
+        if (last >= r) { // backward: from the chain's highest start index <= last down to r
+            int i = last - (last - r) % stride;
+            i32 x2 = S.v[x + i + stride];
+            for (; i >= 0; i -= stride) {
+                const i32 x1 = S.v[x + i];
+                S.v[x + i + stride] = (i16)pshr32(mul16(c, x2) + mul16(s, x1), 15);
+                x2 = tr16(pshr32(mul16(c, x1) + mul16(ms, x2), 15));
+            }
+            S.v[x + r] = (i16)x2;
+        }
+    }
+}
+#endif
 
 OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spread) {
     const int N = n, K = k, x = pos;
+    const int logB = ilog2(B), blen = N >> logB; // B is a power of two
     i32 yy = 0;
+    // cwrsi celt.cpp:2545.  The reference has two code paths (k >= n: "lots of pulses", k < n: "lots of dimensions")
+    // that differ only in how they walk its triangular table; with U(a, b) available for any pair both are
+    //   s = (i >= U(n, k+1));  i -= s ? U(n, k+1) : 0;  k' = max { k' <= k : U(n, k') <= i };  value = +-(k - k');  i -= U(n, k')
+    // One formulation matters here: the lanes of a wave decode different leaves, and a wave pays for every path any of
+    // its lanes takes.  k' == k (a zero) is by far the most common outcome and is tested first; otherwise bisection.
     while (n > 2) {
-        int val;
-        if (k >= n) {
-            const u32 *row = rom_pvq_u + n * ROM_PVQ_COLS; // n <= 14 here: U(n, .) is row n
-            u32 p = row[k + 1];
-            const int s = -(int)(i >= p);
-            i -= p & (u32)s;
+        const u32 p1 = pvq_u_rom(n, k + 1), p0 = pvq_u_rom(n, k);
+        const int s = -(int)(i >= p1);
+        i -= p1 & (u32)s;
+        int val = 0;
+        if (p0 <= i && s == 0) {
+            i -= p0;
+        } else {
             const int k0 = k;
-            const u32 q = row[n];
-            if (q > i) k = n - 1;
-            // largest k' <= k with U(n, k') <= i: U(n, .) is increasing -> bisection
-            int lo = 0, hi = k;
+            int lo = 0, hi = k - 1; // U(n, 0) = 0 <= i; U(n, k) > i here
+            u32 plo = 0;
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
-                if (row[mid] <= i) lo = mid; else hi = mid - 1;
+                const u32 pm = pvq_u_rom(n, mid);
+                if (pm <= i) {
+                    lo = mid;
+                    plo = pm;
+                } else
+                    hi = mid - 1;
             }
             k = lo;
-            i -= row[k];
+            i -= plo;
             val = (k0 - k + s) ^ s;
-        } else {
-            const u32 p = pvq_u_rom(k, n), q = pvq_u_rom(k + 1, n);
-            if (p <= i && i < q) {
-                i -= p;
-                val = 0;
-            } else {
-                const int s = -(int)(i >= q);
-                i -= q & (u32)s;
-                const int k0 = k;
-                u32 pp;
-                do pp = pvq_u_rom(--k, n);
-                while (pp > i);
-                i -= pp;
-                val = (k0 - k + s) ^ s;
-            }
         }
         S.v[pos++] = (i16)val;
         yy += val * val;
@@ -519,8 +546,7 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
         S.v[pos] = (i16)val;
         yy += val * val;
     }
-    // collapse mask from the pulses, then scale them in place
-    const int logB = ilog2(B), blen = N >> logB; // B is a power of two
+    // collapse mask from the pulses
     u32 cm = 1;
     if (B > 1) {
         cm = 0;
@@ -530,6 +556,7 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
             cm |= (u32)(any != 0) << b;
         }
     }
+    // scale the pulses in place
     const int kk = ilog2(yy) >> 1;
     const i32 t = vshr32(yy, 2 * (kk - 7));
     const i32 g = tr16(mul16_p15(rsqrt_norm(t), gain));
@@ -544,9 +571,9 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
             stride2 = 1;
             while ((stride2 * stride2 + stride2) * B + (B >> 2) < N) stride2++;
         }
-        for (int blk = 0; blk < B; blk++) {
-            if (stride2) rotate1_lane(x + blk * blen, blen, stride2, s, c);
-            rotate1_lane(x + blk * blen, blen, 1, c, s);
+        for (int blk2 = 0; blk2 < B; blk2++) {
+            if (stride2) rotate1_lane(x + blk2 * blen, blen, stride2, s, c);
+            rotate1_lane(x + blk2 * blen, blen, 1, c, s);
         }
     }
     return cm;
