@@ -56,6 +56,7 @@ __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const Fra
 // energies, allocation, band budget logic, PVQ indices) into recs[frame]; no vector work, no cross-lane traffic.
 __global__ void __launch_bounds__(64, 2) k_celt_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
                                                       const StreamState *st, ParseRec *recs, int n, int n_streams) {
+    parse_tables_load();
     const int f = (int)blockIdx.x * 64 + (int)threadIdx.x;
     if (f >= n) return;
     const FrameDesc d = descs[f];

@@ -19,6 +19,7 @@ namespace og {
 // used by both execution shapes: wave-uniform (arrays in the wave's LDS record S; frame-per-wave path) and
 // lane-private (one frame per LANE in the parse kernel, og_celt_parse.hpp).
 struct WaveArr {
+    typedef RomGlobal Rom;
     OG_MEMBER i32 &pulses(int i) const { return S.pulses[i]; }
     OG_MEMBER i32 &fine_quant(int i) const { return S.fine_quant[i]; }
     OG_MEMBER i32 &fine_prio(int i) const { return S.fine_prio[i]; }
@@ -35,7 +36,8 @@ struct WaveArr {
 // ---- energies (src/celt.cpp:3613-3700) ------------------------------------------------------------
 template <class A, class R>
 OG_DEV void coarse_energy(A a, R &rc, int start, int end, int intra, int C, int LM) {
-    const u8 *pm = rom_eprob + (LM * 2 + intra) * 42;
+    typedef typename A::Rom T;
+    const int pm = (LM * 2 + intra) * 42; // base into the e_prob_model table
     i32 prev0 = 0, prev1 = 0; // inter-band prediction per channel
     i32 coef, beta;
     if (intra) {
@@ -52,7 +54,7 @@ OG_DEV void coarse_energy(A a, R &rc, int start, int end, int intra, int C, int 
             i32 tell = rc_tell(rc);
             if (budget - tell >= 15) {
                 int pi = 2 * OG_MIN(i, 20);
-                qi = rc_laplace(rc, (u32)pm[pi] << 7, (int)pm[pi + 1] << 6);
+                qi = rc_laplace(rc, (u32)T::eprob(pm + pi) << 7, (int)T::eprob(pm + pi + 1) << 6);
             } else if (budget - tell >= 2) {
                 // small_energy_icdf {2,1,0}, ftb 2
                 u32 s = rc.rng, d = rc.val, r = s >> 2, t;
@@ -144,13 +146,13 @@ OG_DEV void tf_decode(A a, R &rc, int start, int end, int transient, int LM) { /
 template <class A, class R>
 OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i32 &intensity, i32 &dual_stereo, i32 total,
                                i32 &balance_out, int C, int LM) {
-    const i32 *eb = rom_eband;
+    typedef typename A::Rom T;
     int skip_start = start, intensity_rsv = 0, dual_stereo_rsv = 0;
     total = OG_MAX(total, 0);
     int skip_rsv = total >= 1 << BITRES ? 1 << BITRES : 0;
     total -= skip_rsv;
     if (C == 2) {
-        intensity_rsv = rom_log2_frac[end - start];
+        intensity_rsv = T::log2_frac(end - start);
         if (intensity_rsv > total)
             intensity_rsv = 0;
         else {
@@ -160,7 +162,7 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
         }
     }
     for (int j = start; j < end; j++) {
-        int w = eb[j + 1] - eb[j];
+        int w = T::eband(j + 1) - T::eband(j);
         a.thresh(j) = OG_MAX(C << BITRES, (3 * w << LM << BITRES) >> 4);
         i32 to = C * w * (alloc_trim - 5 - LM) * (end - j - 1) * (1 << (LM + BITRES)) >> 6;
         if (w << LM == 1) to -= C << BITRES;
@@ -171,8 +173,8 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
         int done = 0, mid = (lo + hi) >> 1;
         i32 psum = 0;
         for (int j = end; j-- > start;) {
-            int w = eb[j + 1] - eb[j];
-            i32 bitsj = C * w * rom_band_alloc[mid * NBANDS + j] << LM >> 2;
+            int w = T::eband(j + 1) - T::eband(j);
+            i32 bitsj = C * w * T::band_alloc(mid * NBANDS + j) << LM >> 2;
             if (bitsj > 0) bitsj = OG_MAX(0, bitsj + a.trim_off(j));
             bitsj += a.offsets(j);
             if (bitsj >= a.thresh(j) || done) {
@@ -185,9 +187,9 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
     } while (lo <= hi);
     hi = lo--;
     for (int j = start; j < end; j++) {
-        int w = eb[j + 1] - eb[j];
-        i32 b1 = C * w * rom_band_alloc[lo * NBANDS + j] << LM >> 2;
-        i32 b2 = hi >= 11 ? a.cap(j) : C * w * rom_band_alloc[hi * NBANDS + j] << LM >> 2;
+        int w = T::eband(j + 1) - T::eband(j);
+        i32 b1 = C * w * T::band_alloc(lo * NBANDS + j) << LM >> 2;
+        i32 b2 = hi >= 11 ? a.cap(j) : C * w * T::band_alloc(hi * NBANDS + j) << LM >> 2;
         if (b1 > 0) b1 = OG_MAX(0, b1 + a.trim_off(j));
         if (b2 > 0) b2 = OG_MAX(0, b2 + a.trim_off(j));
         if (lo > 0) b1 += a.offsets(j);
@@ -237,10 +239,10 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
             break;
         }
         i32 left = total - psum;
-        i32 percoeff = (i32)udiv((u32)left, (u32)(eb[codedBands] - eb[start]));
-        left -= (eb[codedBands] - eb[start]) * percoeff;
-        i32 rem = OG_MAX(left - (eb[j] - eb[start]), 0);
-        i32 band_width = eb[codedBands] - eb[j];
+        i32 percoeff = (i32)udiv((u32)left, (u32)(T::eband(codedBands) - T::eband(start)));
+        left -= (T::eband(codedBands) - T::eband(start)) * percoeff;
+        i32 rem = OG_MAX(left - (T::eband(j) - T::eband(start)), 0);
+        i32 band_width = T::eband(codedBands) - T::eband(j);
         i32 band_bits = a.pulses(j) + percoeff * band_width + rem;
         if (band_bits >= OG_MAX(a.thresh(j), alloc_floor + (1 << BITRES))) {
             if (rc_bit_logp(rc, 1)) break;
@@ -248,7 +250,7 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
             band_bits -= 1 << BITRES;
         }
         psum -= a.pulses(j) + intensity_rsv;
-        if (intensity_rsv > 0) intensity_rsv = rom_log2_frac[j - start];
+        if (intensity_rsv > 0) intensity_rsv = T::log2_frac(j - start);
         psum += intensity_rsv;
         if (band_bits >= alloc_floor) {
             psum += alloc_floor;
@@ -267,24 +269,24 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
     dual_stereo = dual_stereo_rsv > 0 ? rc_bit_logp(rc, 1) : 0;
 
     i32 left = total - psum;
-    i32 percoeff = (i32)udiv((u32)left, (u32)(eb[codedBands] - eb[start]));
-    left -= (eb[codedBands] - eb[start]) * percoeff;
-    for (int j = start; j < codedBands; j++) a.pulses(j) += percoeff * (eb[j + 1] - eb[j]);
+    i32 percoeff = (i32)udiv((u32)left, (u32)(T::eband(codedBands) - T::eband(start)));
+    left -= (T::eband(codedBands) - T::eband(start)) * percoeff;
+    for (int j = start; j < codedBands; j++) a.pulses(j) += percoeff * (T::eband(j + 1) - T::eband(j));
     for (int j = start; j < codedBands; j++) {
-        i32 tmp = OG_MIN(left, (i32)(eb[j + 1] - eb[j]));
+        i32 tmp = OG_MIN(left, (i32)(T::eband(j + 1) - T::eband(j)));
         a.pulses(j) += tmp;
         left -= tmp;
     }
     i32 balance = 0;
     int j;
     for (j = start; j < codedBands; j++) {
-        i32 N0 = eb[j + 1] - eb[j], N = N0 << LM, excess;
+        i32 N0 = T::eband(j + 1) - T::eband(j), N = N0 << LM, excess;
         i32 bit = a.pulses(j) + balance, bj, ej, fp;
         if (N > 1) {
             excess = OG_MAX(bit - a.cap(j), 0);
             bj = bit - excess;
             i32 den = C * N + ((C == 2 && N > 2 && !dual_stereo && j < intensity) ? 1 : 0);
-            i32 NClogN = den * (rom_logn[j] + logM);
+            i32 NClogN = den * (T::logn(j) + logM);
             i32 offset = (NClogN >> 1) - den * 21;
             if (N == 2) offset += den << BITRES >> 2;
             if (bj + offset < den * 2 << BITRES)
@@ -637,7 +639,7 @@ struct CeltHeader {
 
 template <class A, class R>
 OG_DEV void celt_parse_header(A a, R &rc, int start, int end, int C, int LM, CeltHeader &h) {
-    const i32 *eb = rom_eband;
+    typedef typename A::Rom T;
     i32 total_bits = (i32)rc.storage * 8;
     i32 tell = rc_tell(rc);
     int silence;
@@ -699,14 +701,14 @@ OG_DEV void celt_parse_header(A a, R &rc, int start, int end, int C, int LM, Cel
         spread = ret;
     }
     for (int i = 0; i < NBANDS; i++) { // init_caps celt.cpp:911
-        int Nb = (eb[i + 1] - eb[i]) << LM;
-        a.cap(i) = (rom_pulse_caps[NBANDS * (2 * LM + C - 1) + i] + 64) * C * Nb >> 2;
+        int Nb = (T::eband(i + 1) - T::eband(i)) << LM;
+        a.cap(i) = (T::pulse_caps(NBANDS * (2 * LM + C - 1) + i) + 64) * C * Nb >> 2;
     }
     int dynalloc_logp = 6;
     total_bits <<= BITRES;
     tell = (i32)rc_tell_frac(rc);
     for (int i = start; i < end; i++) {
-        int width = C * (eb[i + 1] - eb[i]) << LM;
+        int width = C * (T::eband(i + 1) - T::eband(i)) << LM;
         int quanta = OG_MIN(width << BITRES, OG_MAX(6 << BITRES, width));
         int loop_logp = dynalloc_logp, boost = 0;
         while (tell + (loop_logp << BITRES) < total_bits && boost < a.cap(i)) {

@@ -31,19 +31,41 @@ namespace og {
 
 constexpr int BITRES = 3;
 
-OG_DEV const u8 *pulse_cache(int band, int LM) { return rom_pulse_bits + rom_pulse_idx[(LM + 1) * NBANDS + band]; }
+// The small ROM tables of the entropy-decoding half sit behind a provider type, so the same code can read them from
+// global memory (single-kernel path) or from a per-workgroup LDS copy (parse kernel, where a table lookup on the
+// critical path of 64 serial decoders should cost an LDS access, not a trip to L2).
+struct RomGlobal {
+    static OG_MEMBER i32 eband(int i) { return rom_eband[i]; }
+    static OG_MEMBER i32 logn(int i) { return rom_logn[i]; }
+    static OG_MEMBER i32 pulse_idx(int i) { return rom_pulse_idx[i]; }
+    static OG_MEMBER i32 pulse_bits(int i) { return rom_pulse_bits[i]; }
+    static OG_MEMBER i32 band_alloc(int i) { return rom_band_alloc[i]; }
+    static OG_MEMBER i32 pulse_caps(int i) { return rom_pulse_caps[i]; }
+    static OG_MEMBER i32 log2_frac(int i) { return rom_log2_frac[i]; }
+    static OG_MEMBER i32 eprob(int i) { return rom_eprob[i]; }
+};
 
+// pulse cache of (band, LM): entry 0 = number of entries, entry q = bits (minus one) for q pulses (celt.h:537)
+template <class T>
+OG_DEV int pulse_cache(int band, int LM) { return T::pulse_idx((LM + 1) * NBANDS + band); }
+template <class T>
+OG_DEV int pulse_cache_max(int band, int LM) { // cache[cache[0]]
+    const int base = pulse_cache<T>(band, LM);
+    return T::pulse_bits(base + T::pulse_bits(base));
+}
+template <class T>
 OG_DEV int bits2pulses(int band, int LM, int bits) { // celt.h:537
-    const u8 *cache = pulse_cache(band, LM);
-    int lo = 0, hi = cache[0];
+    const int base = pulse_cache<T>(band, LM);
+    int lo = 0, hi = T::pulse_bits(base);
     bits--;
     for (int i = 0; i < 6; i++) {
         int mid = (lo + hi + 1) >> 1;
-        if ((int)cache[mid] >= bits) hi = mid; else lo = mid;
+        if (T::pulse_bits(base + mid) >= bits) hi = mid; else lo = mid;
     }
-    return bits - (lo == 0 ? -1 : (int)cache[lo]) <= (int)cache[hi] - bits ? lo : hi;
+    return bits - (lo == 0 ? -1 : T::pulse_bits(base + lo)) <= T::pulse_bits(base + hi) - bits ? lo : hi;
 }
-OG_DEV int pulses2bits(int band, int LM, int pulses) { return pulses == 0 ? 0 : pulse_cache(band, LM)[pulses] + 1; }
+template <class T>
+OG_DEV int pulses2bits(int band, int LM, int pulses) { return pulses == 0 ? 0 : T::pulse_bits(pulse_cache<T>(band, LM) + pulses) + 1; }
 OG_DEV int get_pulses(int i) { return i < 8 ? i : (8 + (i & 7)) << ((i >> 3) - 1); } // celt.h:533
 
 // ---- PVQ codebook-size table in registers -----------------------------------------------------------
@@ -308,11 +330,11 @@ OG_DEV int compute_qn(int N, int b, int offset, int pulse_cap, int stereo) { // 
 struct Split { int inv, imid, iside, delta, itheta, qalloc; };
 
 // compute_theta celt.cpp:1241 (decoder branches)
-template <class R>
+template <class T, class R>
 OG_DEV void compute_theta(R &rc, int band, int intensity, int disable_inv, i32 remaining_bits, Split &sc, int N, i32 &b, int B,
                           int B0, int LM, int stereo, i32 &fill) {
     int itheta = 0, inv = 0;
-    int pulse_cap = rom_logn[band] + LM * (1 << BITRES);
+    int pulse_cap = T::logn(band) + LM * (1 << BITRES);
     int offset = (pulse_cap >> 1) - (stereo && N == 2 ? 16 : 4);
     int qn = compute_qn(N, b, offset, pulse_cap, stereo);
     if (stereo && band >= intensity) qn = 1;
@@ -377,12 +399,12 @@ OG_DEV void compute_theta(R &rc, int band, int intensity, int disable_inv, i32 r
 // alg_unquant :782).  `low` < 0 means "no folding source".
 OG_DEV u32 partition_leaf(Rc &rc, const PvqTab &T, int band, int spread, u32 &seed_io, i32 &remaining_bits, int x, int N, i32 b,
                           int B, int low, int LM, i32 gain, i32 fill) {
-    int q = bits2pulses(band, LM, b), curr_bits = pulses2bits(band, LM, q);
+    int q = bits2pulses<RomGlobal>(band, LM, b), curr_bits = pulses2bits<RomGlobal>(band, LM, q);
     remaining_bits -= curr_bits;
     while (remaining_bits < 0 && q > 0) {
         remaining_bits += curr_bits;
         q--;
-        curr_bits = pulses2bits(band, LM, q);
+        curr_bits = pulses2bits<RomGlobal>(band, LM, q);
         remaining_bits -= curr_bits;
     }
     if (q != 0) {
@@ -448,15 +470,14 @@ OG_DEV u32 partition_tree(Rc &rc, const PvqTab &T, int band, int spread, u32 &se
     for (;;) {
         // ---- descend: split as long as the node asks for it
         for (;;) {
-            const u8 *cache = pulse_cache(band, LM);
-            if (!(LM != -1 && b > cache[cache[0]] + 12 && N > 2)) break;
+            if (!(LM != -1 && b > pulse_cache_max<RomGlobal>(band, LM) + 12 && N > 2)) break;
             const int B0 = B;
             Split sc;
             N >>= 1;
             LM -= 1;
             if (B == 1) fill = (fill & 1) | (fill << 1);
             B = (B + 1) >> 1;
-            compute_theta(rc, band, 0, 0, remaining_bits, sc, N, b, B, B0, LM, 0, fill);
+            compute_theta<RomGlobal>(rc, band, 0, 0, remaining_bits, sc, N, b, B, B0, LM, 0, fill);
             i32 delta = sc.delta;
             const int itheta = sc.itheta;
             if (B0 > 1 && (itheta & 0x3fff)) {
@@ -677,7 +698,7 @@ OG_DEV void decode_all_bands(Rc &rc, int start, int end, int C, int N_ch, int sh
             i32 mbits = 0, sbits = 0, rebal0 = 0;
             int n2case = 0, swap_c = 0, sign = 1, mid_first = 1, njobs = 1;
             if (stereo) {
-                compute_theta(rc, i, intensity, disable_inv, remaining_bits, sc, N, bb, B, B, LM, 1, fill0);
+                compute_theta<RomGlobal>(rc, i, intensity, disable_inv, remaining_bits, sc, N, bb, B, B, LM, 1, fill0);
                 if (N == 2) {
                     n2case = 1;
                     mbits = bb;

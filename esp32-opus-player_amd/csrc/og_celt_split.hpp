@@ -93,7 +93,37 @@ struct ParseLds { // [element][lane]: lanes of a wave touch consecutive addresse
 };
 OG_LDS ParseLds PL;
 
+// LDS copy of the entropy-decoding ROM tables (see RomGlobal, og_celt_bands.hpp), loaded once per workgroup
+struct ParseTabLds {
+    i32 eband[NBANDS + 1], logn[NBANDS], pulse_idx[105];
+    u8 pulse_bits[392], band_alloc[231], pulse_caps[168], log2_frac[24], eprob[336];
+};
+OG_LDS ParseTabLds PT;
+struct RomLds {
+    static OG_MEMBER i32 eband(int i) { return PT.eband[i]; }
+    static OG_MEMBER i32 logn(int i) { return PT.logn[i]; }
+    static OG_MEMBER i32 pulse_idx(int i) { return PT.pulse_idx[i]; }
+    static OG_MEMBER i32 pulse_bits(int i) { return PT.pulse_bits[i]; }
+    static OG_MEMBER i32 band_alloc(int i) { return PT.band_alloc[i]; }
+    static OG_MEMBER i32 pulse_caps(int i) { return PT.pulse_caps[i]; }
+    static OG_MEMBER i32 log2_frac(int i) { return PT.log2_frac[i]; }
+    static OG_MEMBER i32 eprob(int i) { return PT.eprob[i]; }
+};
+// cooperative load by the whole workgroup (call before any lane leaves the kernel); ends with a barrier
+OG_DEV void parse_tables_load() {
+    OG_FOR_LANES(i, NBANDS + 1) PT.eband[i] = rom_eband[i];
+    OG_FOR_LANES(i, NBANDS) PT.logn[i] = rom_logn[i];
+    OG_FOR_LANES(i, 105) PT.pulse_idx[i] = rom_pulse_idx[i];
+    OG_FOR_LANES(i, 392) PT.pulse_bits[i] = rom_pulse_bits[i];
+    OG_FOR_LANES(i, 231) PT.band_alloc[i] = rom_band_alloc[i];
+    OG_FOR_LANES(i, 168) PT.pulse_caps[i] = rom_pulse_caps[i];
+    OG_FOR_LANES(i, 24) PT.log2_frac[i] = rom_log2_frac[i];
+    OG_FOR_LANES(i, 336) PT.eprob[i] = rom_eprob[i];
+    OG_FULL_SYNC();
+}
+
 struct LaneArr {
+    typedef RomLds Rom;
     OG_MEMBER i32 &pulses(int i) const { return PL.pulses[i][OG_LANE]; }
     OG_MEMBER i8 &fine_quant(int i) const { return PL.fine_quant[i][OG_LANE]; }
     OG_MEMBER i8 &fine_prio(int i) const { return PL.fine_prio[i][OG_LANE]; }
@@ -141,15 +171,14 @@ OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits
     int have_pending = 0;
     for (;;) {
         for (;;) { // descend
-            const u8 *cache = pulse_cache(band, LM);
-            if (!(LM != -1 && b > cache[cache[0]] + 12 && N > 2)) break;
+            if (!(LM != -1 && b > pulse_cache_max<RomLds>(band, LM) + 12 && N > 2)) break;
             const int B0 = B;
             Split sc;
             i32 fill = 0;
             N >>= 1;
             LM -= 1;
             B = (B + 1) >> 1;
-            compute_theta(rc, band, 0, 0, remaining_bits, sc, N, b, B, B0, LM, 0, fill);
+            compute_theta<RomLds>(rc, band, 0, 0, remaining_bits, sc, N, b, B, B0, LM, 0, fill);
             i32 delta = sc.delta;
             const int itheta = sc.itheta;
             if (B0 > 1 && (itheta & 0x3fff)) {
@@ -186,12 +215,12 @@ OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits
             }
         }
         { // leaf: pulse count from the remaining budget, then the codeword index (celt.cpp:1463-1480)
-            int q = bits2pulses(band, LM, b), curr_bits = pulses2bits(band, LM, q);
+            int q = bits2pulses<RomLds>(band, LM, b), curr_bits = pulses2bits<RomLds>(band, LM, q);
             remaining_bits -= curr_bits;
             while (remaining_bits < 0 && q > 0) {
                 remaining_bits += curr_bits;
                 q--;
-                curr_bits = pulses2bits(band, LM, q);
+                curr_bits = pulses2bits<RomLds>(band, LM, q);
                 remaining_bits -= curr_bits;
             }
             const int K = q ? get_pulses(q) : 0;
@@ -245,10 +274,10 @@ OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int 
                             int dual_stereo, int intensity, i32 total_bits, i32 balance, int LM, int codedBands, int disable_inv) {
     const LaneArr a;
     const int M = 1 << LM, B = shortBlocks ? M : 1;
-    const int norm_offset = M * rom_eband[start];
+    const int norm_offset = M * RomLds::eband(start);
     int lowband_offset = 0, update_lowband = 1;
     for (int i = start; i < end; i++) {
-        const int eb0 = M * rom_eband[i], N = M * rom_eband[i + 1] - eb0;
+        const int eb0 = M * RomLds::eband(i), N = M * RomLds::eband(i + 1) - eb0;
         const int x = eb0, y = C == 2 ? N_ch + eb0 : -1;
         const i32 tell = (i32)rc_tell_frac(rc);
         if (i != start) balance -= tell;
@@ -262,14 +291,14 @@ OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int 
         const int tf_change = a.tf_res(i);
         // ---- folding source (celt.cpp:1812-1850): offsets into the folding history and the bands whose collapse
         //      masks feed this band's fill mask
-        if ((eb0 - N >= M * rom_eband[start] || i == start + 1) && (update_lowband || lowband_offset == 0)) lowband_offset = i;
+        if ((eb0 - N >= M * RomLds::eband(start) || i == start + 1) && (update_lowband || lowband_offset == 0)) lowband_offset = i;
         u32 w0 = (u32)(tf_change + 4) << BW_TF_SHIFT, w1 = (u32)eb0 << 11 | (u32)N << 22;
         if (lowband_offset != 0 && (spread != 3 || B > 1 || tf_change < 0)) {
-            const int effective_lowband = OG_MAX(0, M * rom_eband[lowband_offset] - norm_offset - N);
+            const int effective_lowband = OG_MAX(0, M * RomLds::eband(lowband_offset) - norm_offset - N);
             int fold_start = lowband_offset;
-            while (M * rom_eband[--fold_start] > effective_lowband + norm_offset) {}
+            while (M * RomLds::eband(--fold_start) > effective_lowband + norm_offset) {}
             int fold_end = lowband_offset - 1;
-            while (++fold_end < i && M * rom_eband[fold_end] < effective_lowband + norm_offset + N) {}
+            while (++fold_end < i && M * RomLds::eband(fold_end) < effective_lowband + norm_offset + N) {}
             w0 |= BW_HAS_LOW | (u32)fold_start << BW_FOLD0_SHIFT | (u32)fold_end << BW_FOLD1_SHIFT;
             w1 |= (u32)effective_lowband;
         }
@@ -297,7 +326,7 @@ OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int 
             i32 bb = b, fill_unused = 0, mbits = 0, sbits = 0, rebal0 = 0;
             int n2case = 0, swap_c = 0, mid_first = 1, njobs = 1;
             if (stereo) { // quant_band_stereo celt.cpp:1628
-                compute_theta(rc, i, intensity, disable_inv, remaining_bits, sc, N, bb, B, B, LM, 1, fill_unused);
+                compute_theta<RomLds>(rc, i, intensity, disable_inv, remaining_bits, sc, N, bb, B, B, LM, 1, fill_unused);
                 w0 |= BW_STEREO;
                 if (sc.itheta == 0) w0 |= BW_THETA0;
                 if (sc.itheta == 16384) w0 |= BW_THETA1;

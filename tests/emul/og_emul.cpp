@@ -16,6 +16,7 @@ int emu_decode_frame_single(void *st, const uint8_t *payload, int len, int mode,
 int emu_decode_frame(void *st, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm) {
     if (mode != og::MODE_CELT) return og::decode_frame_wave((og::StreamState *)st, payload, len, mode, bw, ch, pcm);
     static og::ParseRec rec;
+    og::parse_tables_load();
     og::celt_parse_lane((const og::StreamState *)st, payload, len, ch, &rec);
     const int ret = og::celt_recon_wave((og::StreamState *)st, &rec, mode, ch);
     for (int c = 0; c < ((og::StreamState *)st)->channels; c++) og::celt_post((og::StreamState *)st, &rec, ret, c, pcm);
