@@ -415,7 +415,7 @@ OG_DEV void celt_parse_lane(const StreamState *st, const u8 *payload, int len, i
         return;
     }
     RcLane rc;
-    rc.buf = payload;
+    rc_lane_attach(rc, payload, (u32)len);
     rc_init(rc, (u32)len);
     if (rc.storage <= 1) { // celt_decode_frame's early exit
         rec->ret = BAD_ARG;

@@ -22,16 +22,70 @@ struct Rc {
 };
 // Lane-private flavour for the one-frame-per-LANE parse kernel: the same coder state, packet bytes read from
 // HBM through a per-lane pointer (every rc_* function below is a template over the two).
+// On the GPU a byte fetch straight from HBM would put a full memory latency on the decoder's critical path at every
+// renormalisation, so the packet is read as aligned 32-bit words through two small windows -- one walking forward
+// from the first byte (range-coded data), one walking backward from the last (raw bits) -- each holding the current
+// word and, already requested, the next one in its direction.  Only words that overlap the packet are ever loaded.
 struct RcLane : Rc {
     const u8 *buf;
+#ifndef OG_HOST_EMUL
+    const u32 *words; // buf rounded down to a 4-byte boundary
+    u32 shift;        // buf - (const u8 *)words
+    i32 last_word;    // index of the last word that overlaps the packet
+    u32 f_cur, f_next, b_cur, b_next;
+    i32 f_idx, b_idx; // word indices of f_cur / b_cur
+#endif
 };
 
 OG_DEV int rc_next_byte(Rc &rc) { return rc.offs < rc.storage ? S.pkt[rc.offs++] : 0; }          // :2642
 OG_DEV int rc_next_byte_end(Rc &rc) {                                                           // :2644
     return rc.end_offs < rc.storage ? S.pkt[rc.storage - ++rc.end_offs] : 0;
 }
+#ifdef OG_HOST_EMUL
+OG_DEV void rc_lane_attach(RcLane &rc, const u8 *buf, u32 len) {
+    rc.buf = buf;
+    (void)len;
+}
 OG_DEV int rc_next_byte(RcLane &rc) { return rc.offs < rc.storage ? rc.buf[rc.offs++] : 0; }
 OG_DEV int rc_next_byte_end(RcLane &rc) { return rc.end_offs < rc.storage ? rc.buf[rc.storage - ++rc.end_offs] : 0; }
+#else
+OG_DEV u32 rc_lane_word(const RcLane &rc, i32 w) { return (w >= 0 && w <= rc.last_word) ? rc.words[w] : 0u; }
+OG_DEV void rc_lane_attach(RcLane &rc, const u8 *buf, u32 len) { // call before rc_init
+    rc.buf = buf;
+    const unsigned long long a = (unsigned long long)buf;
+    rc.words = reinterpret_cast<const u32 *>(a & ~3ull);
+    rc.shift = (u32)(a & 3ull);
+    rc.last_word = len ? (i32)((rc.shift + len - 1) >> 2) : -1;
+    rc.f_idx = 0;
+    rc.f_cur = rc_lane_word(rc, 0);
+    rc.f_next = rc_lane_word(rc, 1);
+    rc.b_idx = rc.last_word;
+    rc.b_cur = rc_lane_word(rc, rc.b_idx);
+    rc.b_next = rc_lane_word(rc, rc.b_idx - 1);
+}
+OG_DEV int rc_next_byte(RcLane &rc) {
+    if (rc.offs >= rc.storage) return 0;
+    const u32 pos = rc.offs++ + rc.shift;
+    const i32 w = (i32)(pos >> 2);
+    if (w != rc.f_idx) { // sequential: w == f_idx + 1
+        rc.f_cur = rc.f_next;
+        rc.f_idx = w;
+        rc.f_next = rc_lane_word(rc, w + 1);
+    }
+    return (int)((rc.f_cur >> (8 * (pos & 3))) & 255u);
+}
+OG_DEV int rc_next_byte_end(RcLane &rc) {
+    if (rc.end_offs >= rc.storage) return 0;
+    const u32 pos = rc.storage - ++rc.end_offs + rc.shift;
+    const i32 w = (i32)(pos >> 2);
+    if (w != rc.b_idx) { // sequential: w == b_idx - 1
+        rc.b_cur = rc.b_next;
+        rc.b_idx = w;
+        rc.b_next = rc_lane_word(rc, w - 1);
+    }
+    return (int)((rc.b_cur >> (8 * (pos & 3))) & 255u);
+}
+#endif
 
 template <class R>
 OG_DEV void rc_renorm(R &rc) { // ec_dec_normalize :2649
