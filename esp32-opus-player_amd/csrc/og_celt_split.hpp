@@ -33,7 +33,7 @@ namespace og {
 // ---- the record ------------------------------------------------------------------------------------
 constexpr int REC_BAND_WORDS = 4;
 constexpr int REC_MAX_LEAVES = NBANDS * 2 * 16;                   // <= 16 leaves per band and channel (4 split levels)
-constexpr int REC_MAX_WORDS = NBANDS * (REC_BAND_WORDS + 2 * 32); // band words + <= 16 leaves x 2 words per band and channel
+constexpr int REC_MAX_WORDS = NBANDS * (REC_BAND_WORDS + 2 * 33); // band words + per job: header + <= 16 leaves x 2 words
 
 enum { // ParseRec.flags
     RF_SILENCE = 1, RF_TRANSIENT = 2, RF_LM_SHIFT = 2 /* 2 bits */, RF_STEREO = 16, RF_SPREAD_SHIFT = 5 /* 2 bits */,
@@ -49,11 +49,12 @@ enum {
     BW_TF_SHIFT = 8 /* tf_change + 4, 3 bits */, BW_FOLD0_SHIFT = 11 /* 5 bits */, BW_FOLD1_SHIFT = 16 /* 5 bits */,
     BW_HAS_LOW = 1 << 21, BW_DUAL = 1 << 22, BW_DUAL_END = 1 << 23, BW_STEREO = 1 << 24
 };
-// Leaf words (the leaves of one band-and-channel "job" in decode order).  L0: K | off | B-1 | N | flags; a leaf without
-// pulses (K == 0, LW_TWO) has a second word: x | gain << 11.
+// Job words (a "job" = one band of one channel, or the mid / side part of a stereo band).  Header: number of leaves
+// without pulses that follow | number of PVQ leaves << 5 | index of its first PVQ leaf << 10 | JW_NEED_LOW.  Then,
+// per (non-silent) leaf without pulses, in decode order: L0 = off | B-1 | N (LW_* shifts), L1 = x | gain << 11.
 enum {
-    LW_OFF_SHIFT = 8 /* 4 bits */, LW_B_SHIFT = 12 /* 4 bits */, LW_N_SHIFT = 16 /* 8 bits */, LW_SILENT = 1 << 24,
-    LW_TWO = 1 << 30, LW_LAST = 1u << 31
+    JW_NPVQ_SHIFT = 5 /* 5 bits */, JW_FIRST_SHIFT = 10 /* 10 bits */, JW_NEED_LOW = 1 << 20,
+    LW_OFF_SHIFT = 8 /* 4 bits */, LW_B_SHIFT = 12 /* 4 bits */, LW_N_SHIFT = 16 /* 8 bits */
 };
 
 struct ParseRec {
@@ -62,14 +63,15 @@ struct ParseRec {
     u32 flags;
     i32 intensity, pf_pitch, pf_gain, pf_tapset, start;
     i32 n_leaves, n_words;
-    i32 reserved[6];
+    u32 need_norm; // bands whose folding history is read by a later band
+    i32 reserved[5];
     i16 bandE[2 * NBANDS]; // final band energies (coarse + fine + finalise)
     i16 pulses[NBANDS];
     i8 tf_res[NBANDS];
     i8 pad[256 - 64 - 4 * NBANDS - 2 * NBANDS - NBANDS];
     u32 leaf_idx[REC_MAX_LEAVES];  // PVQ codeword index
     u32 leaf_geom[REC_MAX_LEAVES]; // x | N << 11 | K << 19 | (B - 1) << 27   (x: offset into S.v[V_X..])
-    i16 leaf_gain[REC_MAX_LEAVES]; // the leaf's gain (product of the split gains above it), Q15
+    u32 leaf_aux[REC_MAX_LEAVES];  // gain (product of the split gains above the leaf, Q15) | mask offset << 16
     u32 words[(REC_MAX_WORDS + 64) / 64 * 64]; // read in windows of 64
 };
 static_assert(sizeof(ParseRec) % 16 == 0, "record alignment");
@@ -149,11 +151,15 @@ struct RecWriter {
         if (nw < REC_MAX_WORDS) rec->words[nw] = w;
         nw++;
     }
-    OG_MEMBER void leaf(int x, int N, int K, int B, i32 gain, u32 idx) {
+    OG_MEMBER int reserve() { return nw++; } // a slot to be filled in later by patch()
+    OG_MEMBER void patch(int at, u32 w) {
+        if (at < REC_MAX_WORDS) rec->words[at] = w;
+    }
+    OG_MEMBER void leaf(int x, int N, int K, int B, i32 gain, int off, u32 idx) {
         if (nl < REC_MAX_LEAVES) {
             rec->leaf_idx[nl] = idx;
             rec->leaf_geom[nl] = (u32)x | (u32)N << 11 | (u32)K << 19 | (u32)(B - 1) << 27;
-            rec->leaf_gain[nl] = (i16)gain;
+            rec->leaf_aux[nl] = (u32)(gain & 0xffff) | (u32)off << 16;
         }
         nl++;
     }
@@ -165,10 +171,13 @@ struct RecWriter {
 //   fill(leaf) = silent ? 0 : (fill(job) >> off) & ((1 << B) - 1)        cm(job) |= cm(leaf) << off
 // (`off` sums B0 >> 1 over the splits whose side branch leads to the leaf; a split with angle 0 silences its side
 // branch, one with angle 16384 its mid branch: compute_theta's fill masks, celt.cpp:1320-1353.)
-OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits, int x, int N, i32 b, int B, int LM, i32 gain) {
-    int depth = 0, off = 0, silent = 0;
-    u32 pending0 = 0, pending1 = 0; // the previous leaf's words: held back so the job's last leaf can be flagged
-    int have_pending = 0;
+// In the word stream a job is one header word (JW_*: how many leaves without pulses follow, which PVQ leaves are its
+// own, whether it needs its folding source at all) followed by two words per non-silent leaf without pulses; leaves
+// with pulses only exist in the leaf arrays.  Returns 1 when the job needs the folding source.
+OG_DEV int parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits, int x, int N, i32 b, int B, int LM, i32 gain,
+                      int has_low) {
+    int depth = 0, off = 0, silent = 0, n_fill = 0;
+    const int jpos = out.reserve(), first_pvq = out.nl;
     for (;;) {
         for (;;) { // descend
             if (!(LM != -1 && b > pulse_cache_max<RomLds>(band, LM) + 12 && N > 2)) break;
@@ -224,21 +233,20 @@ OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits
                 remaining_bits -= curr_bits;
             }
             const int K = q ? get_pulses(q) : 0;
-            if (have_pending) {
-                out.word(pending0);
-                if (pending0 & LW_TWO) out.word(pending1);
+            if (K)
+                out.leaf(x, N, K, B, gain, off, rc_uint(rc, pvq_u_rom(N, K) + pvq_u_rom(N, K + 1)));
+            else if (!silent) { // (a silent leaf stays zero, as the spectrum was initialised: nothing to record)
+                out.word((u32)off << LW_OFF_SHIFT | (u32)(B - 1) << LW_B_SHIFT | (u32)N << LW_N_SHIFT);
+                out.word((u32)x | (u32)(gain & 0xffff) << 11);
+                n_fill++;
             }
-            pending0 = (u32)K | (u32)off << LW_OFF_SHIFT | (u32)(B - 1) << LW_B_SHIFT | (u32)N << LW_N_SHIFT | (silent ? LW_SILENT : 0) |
-                       (K ? 0 : LW_TWO);
-            pending1 = (u32)x | (u32)(gain & 0xffff) << 11;
-            have_pending = 1;
-            if (K) out.leaf(x, N, K, B, gain, rc_uint(rc, pvq_u_rom(N, K) + pvq_u_rom(N, K + 1)));
         }
         for (;;) { // back to the parents
             if (depth == 0) {
-                out.word(pending0 | LW_LAST);
-                if (pending0 & LW_TWO) out.word(pending1);
-                return;
+                const int need_low = has_low && n_fill > 0;
+                out.patch(jpos, (u32)n_fill | (u32)(out.nl - first_pvq) << JW_NPVQ_SHIFT | (u32)first_pvq << JW_FIRST_SHIFT |
+                                    (need_low ? JW_NEED_LOW : 0));
+                return need_low;
             }
             i32 *F = &PL.u.stack[depth - 1][0][OG_LANE];
             const i32 w0 = F[0];
@@ -270,12 +278,14 @@ OG_DEV void parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits
 
 // quant_all_bands celt.cpp:1754: the range-decoder half, plus everything else about a band that is known without the
 // decoded spectrum (folding source and mask range, stereo gains, the folding-history scale).
-OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C, int N_ch, int shortBlocks, int spread,
-                            int dual_stereo, int intensity, i32 total_bits, i32 balance, int LM, int codedBands, int disable_inv) {
+// Returns the set of bands (bit i = band i) whose folding history some later band actually reads.
+OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C, int N_ch, int shortBlocks, int spread,
+                           int dual_stereo, int intensity, i32 total_bits, i32 balance, int LM, int codedBands, int disable_inv) {
     const LaneArr a;
     const int M = 1 << LM, B = shortBlocks ? M : 1;
     const int norm_offset = M * RomLds::eband(start);
     int lowband_offset = 0, update_lowband = 1;
+    u32 need_norm = 0;
     for (int i = start; i < end; i++) {
         const int eb0 = M * RomLds::eband(i), N = M * RomLds::eband(i + 1) - eb0;
         const int x = eb0, y = C == 2 ? N_ch + eb0 : -1;
@@ -293,6 +303,8 @@ OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int 
         //      masks feed this band's fill mask
         if ((eb0 - N >= M * RomLds::eband(start) || i == start + 1) && (update_lowband || lowband_offset == 0)) lowband_offset = i;
         u32 w0 = (u32)(tf_change + 4) << BW_TF_SHIFT, w1 = (u32)eb0 << 11 | (u32)N << 22;
+        int has_low = 0;
+        u32 fold_bands = 0; // the bands the folding source overlaps
         if (lowband_offset != 0 && (spread != 3 || B > 1 || tf_change < 0)) {
             const int effective_lowband = OG_MAX(0, M * RomLds::eband(lowband_offset) - norm_offset - N);
             int fold_start = lowband_offset;
@@ -301,6 +313,8 @@ OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int 
             while (++fold_end < i && M * RomLds::eband(fold_end) < effective_lowband + norm_offset + N) {}
             w0 |= BW_HAS_LOW | (u32)fold_start << BW_FOLD0_SHIFT | (u32)fold_end << BW_FOLD1_SHIFT;
             w1 |= (u32)effective_lowband;
+            has_low = 1;
+            fold_bands = (1u << fold_end) - (1u << fold_start);
         }
         if (dual_stereo && i == intensity) {
             dual_stereo = 0;
@@ -358,7 +372,7 @@ OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int 
             out.word(w2);
             out.word((u32)(u16)tr16(celt_sqrt(shl32(N, 22)))); // scale of the folding history (celt.cpp:1617)
             for (int jb = 0; jb < njobs; jb++) {
-                int jx;
+                int jx, jlow = has_low;
                 i32 jbits, jgain = 32767;
                 if (dual_stereo) {
                     jx = jb ? y : x;
@@ -381,7 +395,10 @@ OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int 
                     }
                     jx = is_mid ? x : y;
                     jbits = is_mid ? mbits : sbits;
-                    if (!is_mid) jgain = sc.iside;
+                    if (!is_mid) {
+                        jgain = sc.iside;
+                        jlow = 0; // the side never folds (celt.cpp:1709)
+                    }
                 }
                 // quant_band celt.cpp:1526: only the block count reaches the partition walk's decisions
                 int Bj = B, N_B = (int)udiv((u32)N, (u32)B), tfc = tf_change;
@@ -393,12 +410,13 @@ OG_DEV void parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int 
                     N_B >>= 1;
                     tfc++;
                 }
-                parse_tree(rc, out, i, remaining_bits, jx, N, jbits, Bj, LM, jgain);
+                if (parse_tree(rc, out, i, remaining_bits, jx, N, jbits, Bj, LM, jgain, jlow)) need_norm |= fold_bands;
             }
         }
         balance += pulses_i + tell;
         update_lowband = b > (N << BITRES);
     }
+    return need_norm;
 }
 
 // One CELT-only frame, lane-private.  `payload`/`len`: the frame's bytes; `ch`: channels coded in the packet,
@@ -445,8 +463,8 @@ OG_DEV void celt_parse_lane(const StreamState *st, const u8 *payload, int len, i
         rec->pulses[i] = (i16)a.pulses(i);
         rec->tf_res[i] = a.tf_res(i);
     }
-    parse_all_bands(rc, out, start, end, C, N, h.transient ? M : 0, h.spread, h.dual_stereo, h.intensity,
-                    (i32)rc.storage * (8 << BITRES) - h.anti_collapse_rsv, h.balance, LM, h.codedBands, disable_inv);
+    rec->need_norm = parse_all_bands(rc, out, start, end, C, N, h.transient ? M : 0, h.spread, h.dual_stereo, h.intensity,
+                                     (i32)rc.storage * (8 << BITRES) - h.anti_collapse_rsv, h.balance, LM, h.codedBands, disable_inv);
     int anti_collapse_on = 0;
     if (h.anti_collapse_rsv > 0) anti_collapse_on = (int)rc_bits(rc, 1);
     energy_finalise(a, rc, start, end, (i32)rc.storage * 8 - rc_tell(rc), C);
@@ -659,47 +677,44 @@ struct LcgTab {
     }
 };
 
-// The leaves of one job (quant_partition celt.cpp:1382 flattened by the parse kernel), vector half: a leaf with pulses
-// is complete already (pvq_leaf_lane) and only contributes its collapse mask; a leaf without pulses is zeroed,
-// noise-filled or folded from the lower band (celt.cpp:1481-1520).  Returns the job's collapse mask.
-OG_DEV u32 recon_job_leaves(RecCur &cur, const LcgTab &lcg, u32 &seed_io, int x_job, int low_job, i32 fill_job) {
-    u32 cm_job = 0, w;
-    do {
-        w = rec_word(cur);
-        const int off = (int)(w >> LW_OFF_SHIFT) & 15;
-        u32 cm;
-        if (!(w & LW_TWO)) {
-            cm = (u32)OG_UNI(leaf_masks()[cur.leaf]);
-            cur.leaf++;
-        } else {
-            OG_MARK(7);
-            const u32 w1 = rec_word(cur);
-            const int B = ((int)(w >> LW_B_SHIFT) & 15) + 1, N = (int)(w >> LW_N_SHIFT) & 255, x = V_X + (int)(w1 & 2047);
-            const i32 gain = (i32)((w1 >> 11) & 0xffff);
-            const u32 cm_mask = (u32)((1ull << B) - 1);
-            const i32 fill = (w & LW_SILENT) ? 0 : (i32)((u32)(fill_job >> off) & cm_mask);
+// The leaves of one job (quant_partition celt.cpp:1382 flattened by the parse kernel), vector half.  The leaves with
+// pulses are complete already (pvq_leaf_lane) and only contribute their collapse masks, stored pre-shifted by the leaf
+// pass: one wave-wide OR.  A leaf without pulses is zeroed, noise-filled or folded from the lower band
+// (celt.cpp:1481-1520).  `jw`: the job's header word.  Returns the job's collapse mask.
+OG_DEV u32 recon_job_leaves(RecCur &cur, const LcgTab &lcg, u32 jw, u32 &seed_io, int x_job, int low_job, i32 fill_job) {
+    const int n_fill = (int)(jw & 31), n_pvq = (int)(jw >> JW_NPVQ_SHIFT) & 31, first = (int)(jw >> JW_FIRST_SHIFT) & 1023;
+    u32 cm_job = 0;
+    if (n_pvq) {
+        u32 m = 0;
+        OG_FOR_LANES(l, n_pvq) m |= leaf_masks()[first + l];
+        cm_job = wave_or(m);
+    }
+    for (int f = 0; f < n_fill; f++) {
+        OG_MARK(7);
+        const u32 w = rec_word(cur), w1 = rec_word(cur);
+        const int off = (int)(w >> LW_OFF_SHIFT) & 15, B = ((int)(w >> LW_B_SHIFT) & 15) + 1, N = (int)(w >> LW_N_SHIFT) & 255;
+        const int x = V_X + (int)(w1 & 2047);
+        const i32 gain = (i32)((w1 >> 11) & 0xffff);
+        const u32 cm_mask = (u32)((1ull << B) - 1);
+        const i32 fill = (i32)((u32)(fill_job >> off) & cm_mask);
+        if (fill) { // (no fill: the leaf stays zero, as the spectrum was initialised)
+            const u32 seed = seed_io;
+            u32 cm;
             OG_SYNC();
-            if (!fill) {
-                OG_FOR_LANES(j, N) S.v[x + j] = 0;
-                OG_SYNC();
-                cm = 0;
-            } else {
-                const u32 seed = seed_io;
-                if (low_job < 0) { // noise
-                    OG_FOR_LANES(j, N) S.v[x + j] = (i16)((i32)lcg.at(seed, j) >> 20);
-                    cm = cm_mask;
-                } else { // folded spectrum, +-1/256 dither
-                    const int low = low_job + (x - x_job);
-                    OG_FOR_LANES(j, N) S.v[x + j] = (i16)(S.v[low + j] + ((lcg.at(seed, j) & 0x8000) ? 4 : -4));
-                    cm = (u32)fill;
-                }
-                seed_io = lcg_skip(seed, (u32)N);
-                renormalise(x, N, gain);
+            if (low_job < 0) { // noise
+                OG_FOR_LANES(j, N) S.v[x + j] = (i16)((i32)lcg.at(seed, j) >> 20);
+                cm = cm_mask;
+            } else { // folded spectrum, +-1/256 dither
+                const int low = low_job + (x - x_job);
+                OG_FOR_LANES(j, N) S.v[x + j] = (i16)(S.v[low + j] + ((lcg.at(seed, j) & 0x8000) ? 4 : -4));
+                cm = (u32)fill;
             }
-            OG_MARK(6);
+            seed_io = lcg_skip(seed, (u32)N);
+            renormalise(x, N, gain);
+            cm_job |= cm << off;
         }
-        cm_job |= cm << off;
-    } while (!(w & LW_LAST));
+        OG_MARK(6);
+    }
     return cm_job;
 }
 
@@ -740,6 +755,8 @@ OG_DEV u32 recon_band_mono(RecCur &cur, const LcgTab &lcg, int tf_change, u32 &s
     const int N0 = N, longBlocks = B == 1;
     int logB = ilog2(B), time_divide = 0, recombine = 0;
     int N_B = N >> logB;
+    const u32 jw = rec_word(cur);
+    if (!(jw & JW_NEED_LOW)) low = -1; // no leaf of this job folds: skip the whole preparation of the folding source
     if (tf_change > 0) recombine = tf_change;
     if (low_scratch >= 0 && low >= 0 && (recombine || ((N_B & 1) == 0 && tf_change < 0) || B > 1)) {
         OG_SYNC();
@@ -766,7 +783,7 @@ OG_DEV u32 recon_band_mono(RecCur &cur, const LcgTab &lcg, int tf_change, u32 &s
     const int logB0 = logB, N_B0 = N_B, B0 = 1 << logB0;
     if (B0 > 1 && low >= 0) hadamard_p2(low, N_B >> recombine, logB0 + recombine, longBlocks, 0);
     OG_MARK(6);
-    u32 cm = recon_job_leaves(cur, lcg, seed, x, low, fill);
+    u32 cm = recon_job_leaves(cur, lcg, jw, seed, x, low, fill);
     OG_MARK(8);
     if (B0 > 1) hadamard_p2(x, N_B >> recombine, logB0 + recombine, longBlocks, 1);
     N_B = N_B0;
@@ -792,7 +809,7 @@ OG_DEV u32 recon_band_mono(RecCur &cur, const LcgTab &lcg, int tf_change, u32 &s
 }
 
 // quant_all_bands celt.cpp:1754, vector half: an interpreter of the record's word stream
-OG_DEV void recon_all_bands(const u32 *words, const LcgTab &lcg, int start, int end, int C, int N_ch, int shortBlocks, int LM,
+OG_DEV void recon_all_bands(const u32 *words, u32 need_norm, const LcgTab &lcg, int start, int end, int C, int N_ch, int shortBlocks, int LM,
                             u32 &seed_io) {
     const int M = 1 << LM, B = shortBlocks ? M : 1;
     const int norm_offset = M * rom_eband[start];
@@ -843,7 +860,9 @@ OG_DEV void recon_all_bands(const u32 *words, const LcgTab &lcg, int start, int 
         }
         const int eff = (w0 & BW_HAS_LOW) ? (int)(w1 & 2047) : -1;
         const int low1 = eff >= 0 ? norm + eff : -1, low2 = eff >= 0 ? norm2 + eff : -1;
-        const int out1 = last ? -1 : norm + eb0 - norm_offset, out2 = last ? -1 : norm2 + eb0 - norm_offset;
+        // the folding history of a band nobody folds from is not computed at all
+        const int want_out = !last && ((need_norm >> i) & 1u);
+        const int out1 = want_out ? norm + eb0 - norm_offset : -1, out2 = want_out ? norm2 + eb0 - norm_offset : -1;
 
         if (N == 1) { // quant_band_n1 celt.cpp:1357
             OG_MARK(11);
@@ -975,15 +994,17 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         OG_MARK(2);
         OG_FOR_LANES(t, n_leaves) {
             const u32 g = rec->leaf_geom[t];
-            leaf_masks()[t] = (u16)pvq_leaf_lane((int)(g >> 11) & 255, (int)(g >> 19) & 255, rec->leaf_idx[t], V_X + (int)(g & 2047),
-                                                 (int)(g >> 27) + 1, rec->leaf_gain[t], spread);
+            const u32 aux = rec->leaf_aux[t];
+            leaf_masks()[t] = (u16)(pvq_leaf_lane((int)(g >> 11) & 255, (int)(g >> 19) & 255, rec->leaf_idx[t], V_X + (int)(g & 2047),
+                                                  (int)(g >> 27) + 1, (i32)(aux & 0xffff), spread)
+                                    << (aux >> 16));
         }
         OG_SYNC();
 #if defined(OG_RABL) && OG_RABL == 2
         return ret;
 #endif
         u32 seed = cs->rng;
-        recon_all_bands(rec->words, lcg, start, end, C, N, transient ? M : 0, LM, seed);
+        recon_all_bands(rec->words, (u32)OG_UNI(rec->need_norm), lcg, start, end, C, N, transient ? M : 0, LM, seed);
         OG_MARK(12);
         if (flags & RF_ANTI_COLLAPSE) anti_collapse(LM, C, N, start, end, seed);
         if (silence) {
