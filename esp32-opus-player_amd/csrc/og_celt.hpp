@@ -589,7 +589,7 @@ OG_DEV i32 syn_at(const CeltState *st, int c, int idx) {
 
 // In-place pitch comb filter on the synthesis buffer [off .. off+N) of channel c (comb_filter celt.cpp:848).  In place the filter
 // is recursive with delay >= min(T0,T1)-2 >= 13 samples, so samples are produced in chunks of that
-// many (at most 64), one lane each; all taps of a chunk are already final.
+// many, spread over the lanes; all taps of a chunk are already final.
 OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, int N, i32 g0, i32 g1, int tap0, int tap1) {
     if (g0 == 0 && g1 == 0) return;
     // gains[tapset][0..2] Q15 (celt.cpp:854)
@@ -602,7 +602,9 @@ OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, in
     i32 g00 = tr16(mul16_p15(g0, ga0)), g01 = tr16(mul16_p15(g0, ga1)), g02 = tr16(mul16_p15(g0, ga2));
     i32 g10 = tr16(mul16_p15(g1, gb0)), g11 = tr16(mul16_p15(g1, gb1)), g12 = tr16(mul16_p15(g1, gb2));
     int overlap = (g0 == g1 && T0 == T1 && tap0 == tap1) ? 0 : OVERLAP;
-    int chunk = OG_MIN(OG_MIN(T0, T1) - 2, 64);
+    // every tap of a sample lies >= min(T0, T1) - 2 samples back: that many samples can be filtered without looking
+    // at each other's results (no barrier in between, their history loads overlap)
+    int chunk = OG_MIN(T0, T1) - 2;
     int end = g1 == 0 ? overlap : N; // with g1 == 0 only the cross-fade part changes the signal
     for (int base = 0; base < end; base += chunk) {
         OG_SYNC();
