@@ -47,6 +47,18 @@ def load_pkg():
     return mod
 
 
+def load_shard():
+    pkg = load_pkg()
+    name = pkg.__name__ + ".shard"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "esp32-opus-player_amd", "shard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def cpu_baseline(toc, L, seconds_target=12.0):
     """Time the CPU oracle (bit-identical port of the reference decode path) on a bounded sample."""
     import oracle_py
@@ -94,16 +106,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    # one process per GPU; streams are partitioned across the ranks (esp32-opus-player_amd/shard.py): RCCL carries
+    # nothing but the barrier around the timed region and the MAX / SUM of the per-rank figures
+    ranks = load_shard().Ranks(backend="nccl")
+    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
     toc, L, bytes_per_frame, default_streams = WORKLOADS[args.workload]
     n = args.streams or default_streams
     K, W = args.steps, args.warmup
@@ -113,7 +119,7 @@ def main():
     ctx.streams_alloc(n, 2)
     # streams are sharded across ranks with no data-path exchange: each rank owns streams
     # [rank*n, (rank+1)*n) of the global id space (seeds differ per global stream id)
-    pay = pkg.lcg_payloads(n, K + W, L, seed_base=0x9E3779B9 ^ (rank * 0x01000193))
+    pay = pkg.lcg_payloads(n, K + W, L, seed_base=ranks.seed_base())
     d_arena, d_desc = [], []
     for f in range(K + W):
         arena, descs = pkg.build_step(toc, pay[f])
@@ -127,10 +133,7 @@ def main():
     d_res = ctx.dev_alloc(4 * n)
 
     def barrier():
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
+        ranks.barrier()
         ctx.synchronize()
 
     for f in range(W):
@@ -152,16 +155,22 @@ def main():
     if not (res == 960).all():
         raise SystemExit(f"decode failed for {(res != 960).sum()} frames in the last step")
 
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    value, dt, total_frames = load_shard().aggregate_throughput(ranks, n * K, dt)
     if rank == 0:
-        total_frames = n * K * world
-        value = total_frames / dt
         avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
         achieved = bytes_per_frame * n / avg_kernel_s / 1e9
+        # HBM traffic of one step from the committed PMC profile of this workload (tools/prof_pmc.sh), if it was taken
+        # at this batch size; null otherwise
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01", f"traffic_{args.workload}.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            if tj.get("frames_per_launch") == n:
+                traffic = tj["hbm_bytes_per_step"]
+        celt_split = args.workload.startswith("celt") and os.environ.get("OPUSGPU_SPLIT", "1") != "0"
+        kernel_name = ("decode step = k_celt_parse + k_celt_recon + k_celt_post (launched back to back)" if celt_split
+                       else "k_decode_step")
         line = {
             "metric": "decoded 48 kHz stereo frames/sec/GPU (x real-time); HBM GB/s vs roofline",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -172,16 +181,14 @@ def main():
                        "streams_per_gpu": n, "sharding": "streams partitioned across ranks, no data-path collective"},
             "x_realtime_per_gpu": value / world / 50.0,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_decode_step", "avg_launch_ms": avg_kernel_s * 1e3,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": kernel_name, "avg_launch_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_frame": bytes_per_frame, "frames_per_launch": n},
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(toc, L)
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
     ctx.close()
 
 

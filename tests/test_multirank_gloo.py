@@ -1,0 +1,36 @@
+"""N>1 path on CPU: two gloo ranks run the sharding / timing plumbing bench.py uses under torch.distributed.run."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_partition_and_aggregate(tmp_path):
+    env = dict(os.environ, OG_TEST_OUT=str(tmp_path), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "multirank_worker.py")]
+    subprocess.run(cmd, check=True, env=env, cwd=ROOT, timeout=300)
+    r = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(2)]
+    assert [x["world"] for x in r] == [2, 2]
+    # stream ids: disjoint, contiguous, cover [0, 2n)
+    assert (r[0]["lo"], r[0]["hi"]) == (0, 6) and (r[1]["lo"], r[1]["hi"]) == (6, 12)
+    # different global streams -> different payloads and different PCM
+    assert r[0]["pay_crc"] != r[1]["pay_crc"] and r[0]["crc"] != r[1]["crc"]
+    # every frame of every rank decoded; the job's figure is all frames / the slowest rank's time, on both ranks
+    assert r[0]["ok"] == r[1]["ok"] == 6 * 3
+    for x in r:
+        assert x["total"] == 36
+        assert abs(x["dt_max"] - max(r[0]["dt"], r[1]["dt"])) < 1e-6
+        assert abs(x["value"] - 36 / x["dt_max"]) < 1e-6
+    assert r[1]["dt"] > r[0]["dt"]
