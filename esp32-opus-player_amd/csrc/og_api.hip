@@ -61,7 +61,13 @@ __global__ void __launch_bounds__(64, 2) k_celt_parse(const FrameDesc *__restric
     if (f >= n) return;
     const FrameDesc d = descs[f];
     if (d.stream < 0 || d.stream >= n_streams || desc_mode(d.flags) != MODE_CELT) return;
+#ifdef OG_PROF_PARSE // profiling builds: time the sections of the parse kernel instead of the recon kernel (full batches only)
+    OG_PROF_INIT();
+#endif
     celt_parse_lane(&st[d.stream], arena + d.offset, d.len, desc_channels(d.flags), &recs[f]);
+#ifdef OG_PROF_PARSE
+    OG_PROF_FLUSH();
+#endif
 }
 
 // Split CELT path, second half: one frame per wave, driven by the parse record.
@@ -72,10 +78,14 @@ __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDe
     if (f >= n) return;
     const FrameDesc d = descs[f];
     if (d.stream < 0 || d.stream >= n_streams || desc_mode(d.flags) != MODE_CELT) return;
+#ifndef OG_PROF_PARSE
     OG_PROF_INIT();
+#endif
     const int ret = celt_recon_wave(&st[d.stream], &recs[f], MODE_CELT, desc_channels(d.flags));
     if (threadIdx.x == 0) result[f] = ret;
+#ifndef OG_PROF_PARSE
     OG_PROF_FLUSH();
+#endif
 }
 
 // Split CELT path, third step: de-emphasis (a rounding IIR: strictly serial per channel) and int16 PCM, one

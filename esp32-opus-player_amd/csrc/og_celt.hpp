@@ -685,7 +685,9 @@ OG_DEV void celt_parse_header(A a, R &rc, int start, int end, int C, int LM, Cel
         tell = rc_tell(rc);
     }
     const int intra = tell + 3 <= total_bits ? rc_bit_logp(rc, 3) : 0;
+    OG_MARK(21);
     coarse_energy(a, rc, start, end, intra, C, LM);
+    OG_MARK(22);
     tf_decode(a, rc, start, end, transient, LM);
     tell = rc_tell(rc);
     int spread = 2;
@@ -745,8 +747,11 @@ OG_DEV void celt_parse_header(A a, R &rc, int start, int end, int C, int LM, Cel
     const int anti_collapse_rsv = transient && LM >= 2 && bits >= ((LM + 2) << BITRES) ? (1 << BITRES) : 0;
     bits -= anti_collapse_rsv;
     i32 intensity = 0, dual_stereo = 0, balance = 0;
+    OG_MARK(23);
     h.codedBands = compute_allocation(a, rc, start, end, alloc_trim, intensity, dual_stereo, bits, balance, C, LM);
+    OG_MARK(24);
     fine_energy(a, rc, start, end, C);
+    OG_MARK(25);
 
     h.silence = silence;
     h.transient = transient;

@@ -452,6 +452,7 @@ OG_DEV void celt_parse_lane(const StreamState *st, const u8 *payload, int len, i
         a.offsets(i) = 0;
     }
     CeltHeader h;
+    OG_MARK(20);
     celt_parse_header(a, rc, start, end, C, LM, h);
     RecWriter out;
     out.rec = rec;
@@ -463,8 +464,10 @@ OG_DEV void celt_parse_lane(const StreamState *st, const u8 *payload, int len, i
         rec->pulses[i] = (i16)a.pulses(i);
         rec->tf_res[i] = a.tf_res(i);
     }
+    OG_MARK(26);
     rec->need_norm = parse_all_bands(rc, out, start, end, C, N, h.transient ? M : 0, h.spread, h.dual_stereo, h.intensity,
                                      (i32)rc.storage * (8 << BITRES) - h.anti_collapse_rsv, h.balance, LM, h.codedBands, disable_inv);
+    OG_MARK(27);
     int anti_collapse_on = 0;
     if (h.anti_collapse_rsv > 0) anti_collapse_on = (int)rc_bits(rc, 1);
     energy_finalise(a, rc, start, end, (i32)rc.storage * 8 - rc_tell(rc), C);

@@ -119,7 +119,16 @@ OG_DEV i32 mul16(i32 a, i32 b) { return (i32)(i16)a * (i32)(i16)b; }            
 OG_DEV i32 mul16_q15(i32 a, i32 b) { return mul16(a, b) >> 15; }                     // :355
 OG_DEV i32 mul16_q14(i32 a, i32 b) { return mul16(a, b) >> 14; }                     // :354
 OG_DEV i32 mul16_p15(i32 a, i32 b) { return (16384 + mul16(a, b)) >> 15; }           // :359
+#if defined(OG_HOST_EMUL) || defined(OG_MUL64)
 OG_DEV i32 mul16x32_q15(i32 a, i32 b) { return (i32)(((i64)(i16)a * (i64)b) >> 15); } // MULT16_32_Q15 :263
+#else
+// Same value without a 64-bit product (v_mul_hi/lo are quarter-rate): with b = bh * 65536 + bl (bl unsigned 16 bit),
+// (a * b) >> 15 = 2 * (a * bh) + ((a * bl) >> 15) exactly, and both partial products fit 24 x 24 -> 32 bit multiplies.
+OG_DEV i32 mul16x32_q15(i32 a, i32 b) { // MULT16_32_Q15 :263
+    const i32 as = (i32)(i16)a;
+    return (i32)(((u32)__mul24(as, b >> 16) << 1) + (u32)(__mul24(as, (i32)((u32)b & 0xffffu)) >> 15));
+}
+#endif
 OG_DEV i32 mul32_q31(i32 a, i32 b) { return (i32)(((i64)a * (i64)b) >> 31); }        // :266
 OG_DEV i32 shl32(i32 a, int s) { return (i32)((u32)a << s); }                        // :292
 OG_DEV i32 pshr32(i32 a, int s) { return (a + ((1 << s) >> 1)) >> s; }               // :295

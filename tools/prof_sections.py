@@ -15,7 +15,9 @@ spec.loader.exec_module(pkg)
 
 NAMES = {0: "outside", 1: "stage record", 2: "leaf pass", 3: "band prologue", 4: "stereo setup", 5: "band_mono pre",
          6: "tree walk", 7: "leaf (fill)", 8: "band_mono post", 9: "lowband out", 10: "stereo merge", 11: "N==1 band",
-         12: "anti-collapse", 13: "synth prologue", 14: "imdct", 15: "comb filter", 16: "ring write", 17: "epilogue"}
+         12: "anti-collapse", 13: "synth prologue", 14: "imdct", 15: "comb filter", 16: "ring write", 17: "epilogue",
+         20: "parse: init", 21: "parse: flags", 22: "parse: coarse energy", 23: "parse: tf/spread/dynalloc", 24: "parse: allocation",
+         25: "parse: fine energy", 26: "parse: bands", 27: "parse: finalise"}
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
