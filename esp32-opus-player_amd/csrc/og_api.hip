@@ -46,8 +46,14 @@ __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const Fra
         return; // CELT-only frames take the split path (k_celt_parse + k_celt_recon)
     } else {
         StreamState *s = &st[d.stream];
+#ifdef OG_PROF_SINGLE // profiling builds: time the sections of the single-kernel path
+        OG_PROF_INIT();
+#endif
         ret = decode_frame_wave(s, arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
                                 desc_channels(d.flags), pcm + (size_t)f * pcm_stride);
+#ifdef OG_PROF_SINGLE
+        OG_PROF_FLUSH();
+#endif
     }
     if (threadIdx.x == 0) result[f] = ret;
 }
@@ -78,12 +84,12 @@ __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDe
     if (f >= n) return;
     const FrameDesc d = descs[f];
     if (d.stream < 0 || d.stream >= n_streams || desc_mode(d.flags) != MODE_CELT) return;
-#ifndef OG_PROF_PARSE
+#if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE)
     OG_PROF_INIT();
 #endif
     const int ret = celt_recon_wave(&st[d.stream], &recs[f], MODE_CELT, desc_channels(d.flags));
     if (threadIdx.x == 0) result[f] = ret;
-#ifndef OG_PROF_PARSE
+#if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE)
     OG_PROF_FLUSH();
 #endif
 }

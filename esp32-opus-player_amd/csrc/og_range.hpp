@@ -178,6 +178,24 @@ OG_DEV int rc_icdf(R &rc, const u8 *icdf, unsigned ftb) {
     return ret;
 }
 
+#ifndef OG_HOST_EMUL
+// Wave-uniform decoder, SILK's workhorse: the reference's linear search is a chain of dependent table loads.  Here lane l
+// evaluates entry l (tables have <= 42 entries and 64 bytes of padding behind them, tools/gen_rom_tables.py): the symbol
+// is the first entry with val >= r * icdf[entry] -- one coalesced load, one ballot.  All 64 lanes must be active.
+OG_DEV int rc_icdf(Rc &rc, const u8 *icdf, unsigned ftb) {
+    const u32 d = rc.val, r = rc.rng >> ftb;
+    const u32 s_l = r * (u32)icdf[OG_LANE];
+    const u64 hit = __ballot(d >= s_l); // the terminating 0 entry always hits
+    const int ret = (int)__builtin_ctzll(hit);
+    const u32 s = (u32)__builtin_amdgcn_readlane((int)s_l, ret);
+    const u32 t = ret ? (u32)__builtin_amdgcn_readlane((int)s_l, ret - 1) : rc.rng;
+    rc.val = d - s;
+    rc.rng = t - s;
+    rc_renorm(rc);
+    return ret;
+}
+#endif
+
 template <class R>
 OG_DEV u32 rc_bits(R &rc, unsigned bits) { // ec_dec_bits :2773
     u32 window = rc.end_window;

@@ -744,6 +744,7 @@ OG_DEVN int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz
         ffar[n] = s->ch[n].first_frame_after_reset;
     }
     int vad[2] = {0, 0}, lbrr[2] = {0, 0};
+    OG_MARK(30);
     for (int n = 0; n < channels; n++) {
         vad[n] = rc_bit_logp(rc, 1);
         lbrr[n] = rc_bit_logp(rc, 1);
@@ -784,9 +785,13 @@ OG_DEVN int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz
         if (L.ctrl[n].coded) {
             // FrameIndex = nFramesDecoded - n = -n <= 0 -> independent coding (silk.cpp:1678-1681)
             const int condCoding = 0;
+            OG_MARK(30);
             silk_decode_indices(&s->ch[n], L.ctrl[n], rc, fs_kHz, vad[n], 0, condCoding, ecType[n], ecLag[n]);
+            OG_MARK(31);
             silk_decode_pulses(rc, n, L.ctrl[n].signalType, L.ctrl[n].quantOffsetType, frame_length);
+            OG_MARK(32);
             silk_decode_parameters(&s->ch[n], L.ctrl[n], fs_kHz, condCoding, lastGain[n], ffar[n]);
+            OG_MARK(33);
         }
     }
     OG_SYNC();
@@ -800,6 +805,7 @@ OG_DEVN int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz
     }
     OG_SYNC();
     // ---- synthesis: stage the output history, then lane n = channel n
+    OG_MARK(34);
     for (int n = 0; n < channels; n++)
         if (L.ctrl[n].coded) OG_FOR_LANES(i, frame_length) L.hist[n][i] = s->ch[n].outBuf[i];
     OG_SYNC();
@@ -810,6 +816,7 @@ OG_DEVN int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz
             for (int i = 0; i < frame_length; i++) L.xq[n][2 + i] = 0;
     }
     OG_SYNC();
+    OG_MARK(35);
     // outBuf update (silk.cpp:2031-2034): ltp_mem_length == frame_length, so the history is exactly this frame
     for (int n = 0; n < channels; n++)
         if (L.ctrl[n].coded) OG_FOR_LANES(i, frame_length) s->ch[n].outBuf[i] = L.xq[n][2 + i];
@@ -859,8 +866,10 @@ OG_DEVN int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz
         OG_SYNC();
     }
     // ---- resample to 48 kHz: serial 2x all-pass per channel, then lane-parallel FIR interpolation
+    OG_MARK(36);
     OG_FOR_LANES(n, channels) silk_up2_lane(&s->ch[n], n, frame_length);
     OG_SYNC();
+    OG_MARK(37);
     {
         const i32 inv = s->ch[0].rs_invRatio_Q16; // both channels run at the same rate
         // batches of the reference: [0, fs_kHz), then chunks of 10*fs_kHz (silk.cpp:3676, :3475)
@@ -890,6 +899,7 @@ OG_DEVN int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz
         }
     }
     OG_SYNC();
+    OG_MARK(38);
     if (OG_LANE == 0) {
         s->nChannelsAPI = channels;
         s->nChannelsInternal = channels;

@@ -216,10 +216,16 @@ WIDEN = {"rom_eband", "rom_logn", "rom_pulse_idx", "rom_silk_cos_q12", "rom_silk
          "rom_silk_up2_hq0", "rom_silk_up2_hq1"}
 
 
+# SILK's inverse-CDF tables are searched by a whole wave at once (lane l looks at entry l, og_range.hpp: rc_icdf), from any
+# starting offset inside a table: 64 bytes of zero padding behind each keep those reads inside the array.
+ICDF_PAD = 64
+
+
 def emit(name, ctype, vals, per=16):
     if name in WIDEN:
         ctype = "int32_t"
-    s = f"OPUS_ROM {ctype} {name}[{len(vals)}] = {{\n"
+    size = len(vals) + (ICDF_PAD if name.startswith("rom_silk") and ctype == "uint8_t" else 0)
+    s = f"OPUS_ROM {ctype} {name}[{size}] = {{\n"
     for i in range(0, len(vals), per):
         s += "    " + ", ".join(str(v) for v in vals[i:i + per]) + ",\n"
     return s + "};\n\n"

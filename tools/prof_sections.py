@@ -17,18 +17,22 @@ NAMES = {0: "outside", 1: "stage record", 2: "leaf pass", 3: "band prologue", 4:
          6: "tree walk", 7: "leaf (fill)", 8: "band_mono post", 9: "lowband out", 10: "stereo merge", 11: "N==1 band",
          12: "anti-collapse", 13: "synth prologue", 14: "imdct", 15: "comb filter", 16: "ring write", 17: "epilogue",
          20: "parse: init", 21: "parse: flags", 22: "parse: coarse energy", 23: "parse: tf/spread/dynalloc", 24: "parse: allocation",
-         25: "parse: fine energy", 26: "parse: bands", 27: "parse: finalise"}
+         25: "parse: fine energy", 26: "parse: bands", 27: "parse: finalise",
+         30: "silk: flags/stereo", 31: "silk: indices", 32: "silk: pulses", 33: "silk: parameters", 34: "silk: state/stage",
+         35: "silk: core (LTP/LPC)", 36: "silk: outBuf + MS->LR", 37: "silk: up2 (serial)", 38: "silk: FIR to 48k"}
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+toc, plen = {"celt": (pkg.TOC_CELT_FB_STEREO, 160), "silk": (pkg.TOC_SILK_NB_STEREO, 40),
+             "hybrid": (pkg.TOC_HYBRID_FB_STEREO, 120)}[sys.argv[3] if len(sys.argv) > 3 else "celt"]
 ctx = pkg.Context(0)
 ctx.streams_alloc(n, 2)
 lib = pkg.load_lib()
 lib.opusgpu_debug_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = (ctypes.c_ulonglong * 64)()
-pay = pkg.lcg_payloads(n, steps, 160)
+pay = pkg.lcg_payloads(n, steps, plen)
 for s in range(steps):
-    pkts = [bytes([pkg.TOC_CELT_FB_STEREO]) + pay[s, i].tobytes() for i in range(n)]
+    pkts = [bytes([toc]) + pay[s, i].tobytes() for i in range(n)]
     if s == 1:
         lib.opusgpu_debug_prof(buf, 1)  # drop the first (cold) step
     ctx.decode_packets(list(range(n)), pkts)
