@@ -159,7 +159,7 @@ OG_DEV void nlsf_unpack(const NlsfCb &cb, int CB1_index) { // silk_NLSF_unpack s
 }
 
 // ---- side information (silk_decode_indices silk.cpp:708) --------------------------------------------------
-OG_DEVN void silk_decode_indices(SilkChannel *c, SilkCtrl &k, Rc &rc, int fs_kHz, int vad, int decode_LBRR, int condCoding,
+OG_DEV void silk_decode_indices(SilkChannel *c, SilkCtrl &k, Rc &rc, int fs_kHz, int vad, int decode_LBRR, int condCoding,
                                  i32 &ec_prevSignalType, i32 &ec_prevLagIndex) {
     SilkLds &L = SL();
     (void)c;
@@ -227,7 +227,7 @@ OG_DEV void shell_split(Rc &rc, int &c1, int &c2, int p, const u8 *table) {
     }
 }
 
-OG_DEVN void silk_decode_pulses(Rc &rc, int ch, int signalType, int quantOffsetType, int frame_length) {
+OG_DEV void silk_decode_pulses(Rc &rc, int ch, int signalType, int quantOffsetType, int frame_length) {
     SilkLds &L = SL();
     i16 *pulses = L.pulses[ch];
     int iter = frame_length >> 4;
@@ -698,7 +698,7 @@ OG_DEV void silk_set_fs(SilkChannel *c, int fs_kHz) {
     OG_SYNC();
 }
 
-OG_DEVN void silk_stereo_decode_pred(Rc &rc, i32 pred_Q13[2]) { // silk.cpp:592
+OG_DEV void silk_stereo_decode_pred(Rc &rc, i32 pred_Q13[2]) { // silk.cpp:592
     int ix[2][3];
     int n = rc_icdf(rc, rom_silk_stereo_joint_icdf, 8);
     ix[0][2] = n / 5;
@@ -718,7 +718,7 @@ OG_DEVN void silk_stereo_decode_pred(Rc &rc, i32 pred_Q13[2]) { // silk.cpp:592
 
 // Decode one 20 ms SILK frame (mid + side / mono) into S.pcm_silk (48 kHz, interleaved when stereo).
 // Returns 0 or a non-zero error (wave-uniform).
-OG_DEVN int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz) {
+OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz) {
     SilkLds &L = SL();
     const int fs_kHz = (internal_hz >> 10) + 1;
     if (fs_kHz != 8 && fs_kHz != 12 && fs_kHz != 16) return -200;
