@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(64) k_stream_init(StreamState *st, int first, 
 #endif
 __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
                                                    StreamState *st, i16 *pcm, i32 *result, int n, int n_streams,
-                                                   int pcm_stride, int skip_celt) {
+                                                   int pcm_stride, int skip_celt, SilkHandoff *handoff) {
     const int f = (int)blockIdx.x;
     if (f >= n) return;
     const FrameDesc d = descs[f];
@@ -49,11 +49,14 @@ __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const Fra
 #ifdef OG_PROF_SINGLE // profiling builds: time the sections of the single-kernel path
         OG_PROF_INIT();
 #endif
+        SilkHandoff *h = handoff ? &handoff[f] : nullptr;
+        if (h && desc_mode(d.flags) == MODE_HYBRID && threadIdx.x == 0) h->valid = 0;
         ret = decode_frame_wave(s, arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
-                                desc_channels(d.flags), pcm + (size_t)f * pcm_stride);
+                                desc_channels(d.flags), pcm + (size_t)f * pcm_stride, h);
 #ifdef OG_PROF_SINGLE
         OG_PROF_FLUSH();
 #endif
+        if (ret == CONTINUE_SPLIT) return; // the split path finishes this frame and reports its result
     }
     if (threadIdx.x == 0) result[f] = ret;
 }
@@ -61,16 +64,18 @@ __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const Fra
 // Split CELT path, first half: ONE FRAME PER LANE.  Lane l of workgroup g parses frame 64 g + l (range decoder,
 // energies, allocation, band budget logic, PVQ indices) into recs[frame]; no vector work, no cross-lane traffic.
 __global__ void __launch_bounds__(64, 2) k_celt_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
-                                                      const StreamState *st, ParseRec *recs, int n, int n_streams) {
+                                                      const StreamState *st, ParseRec *recs, int n, int n_streams,
+                                                      const SilkHandoff *handoff) {
     parse_tables_load();
     const int f = (int)blockIdx.x * 64 + (int)threadIdx.x;
     if (f >= n) return;
     const FrameDesc d = descs[f];
-    if (d.stream < 0 || d.stream >= n_streams || desc_mode(d.flags) != MODE_CELT) return;
+    const int mode = desc_mode(d.flags);
+    if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && handoff))) return;
 #ifdef OG_PROF_PARSE // profiling builds: time the sections of the parse kernel instead of the recon kernel (full batches only)
     OG_PROF_INIT();
 #endif
-    celt_parse_lane(&st[d.stream], arena + d.offset, d.len, desc_channels(d.flags), &recs[f]);
+    celt_parse_lane(&st[d.stream], arena + d.offset, d.len, desc_channels(d.flags), &recs[f], mode == MODE_HYBRID ? &handoff[f] : nullptr);
 #ifdef OG_PROF_PARSE
     OG_PROF_FLUSH();
 #endif
@@ -79,15 +84,17 @@ __global__ void __launch_bounds__(64, 2) k_celt_parse(const FrameDesc *__restric
 // Split CELT path, second half: one frame per wave, driven by the parse record.
 __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDesc *__restrict__ descs, StreamState *st,
                                                                       const ParseRec *recs, i16 *pcm, i32 *result, int n,
-                                                                      int n_streams, int pcm_stride) {
+                                                                      int n_streams, int pcm_stride, int hybrid) {
     const int f = (int)blockIdx.x;
     if (f >= n) return;
     const FrameDesc d = descs[f];
-    if (d.stream < 0 || d.stream >= n_streams || desc_mode(d.flags) != MODE_CELT) return;
+    const int mode = desc_mode(d.flags);
+    if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && hybrid))) return;
+    if (mode == MODE_HYBRID && (recs[f].flags & RF_SKIP)) return; // the single-kernel path already reported this frame
 #if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE)
     OG_PROF_INIT();
 #endif
-    const int ret = celt_recon_wave(&st[d.stream], &recs[f], MODE_CELT, desc_channels(d.flags));
+    const int ret = celt_recon_wave(&st[d.stream], &recs[f], mode, desc_channels(d.flags));
     if (threadIdx.x == 0) result[f] = ret;
 #if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE)
     OG_PROF_FLUSH();
@@ -98,13 +105,15 @@ __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDe
 // (frame, channel) per lane, from the samples k_celt_recon appended to the history ring.
 __global__ void __launch_bounds__(64) k_celt_post(const FrameDesc *__restrict__ descs, StreamState *st, const ParseRec *recs,
                                                   const i32 *__restrict__ result, i16 *pcm, int n, int n_streams, int channels,
-                                                  int pcm_stride) {
+                                                  int pcm_stride, const SilkHandoff *handoff) {
     const int t = (int)blockIdx.x * 64 + (int)threadIdx.x;
     const int f = channels == 2 ? t >> 1 : t, c = channels == 2 ? t & 1 : 0;
     if (f >= n) return;
     const FrameDesc d = descs[f];
-    if (d.stream < 0 || d.stream >= n_streams || desc_mode(d.flags) != MODE_CELT) return;
-    celt_post(&st[d.stream], &recs[f], result[f], c, pcm + (size_t)f * pcm_stride);
+    const int mode = desc_mode(d.flags);
+    if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && handoff))) return;
+    celt_post(&st[d.stream], &recs[f], result[f], c, pcm + (size_t)f * pcm_stride, mode == MODE_HYBRID ? handoff[f].pcm : nullptr,
+              desc_channels(d.flags));
 }
 
 // ---- context ----------------------------------------------------------------------------------------
@@ -117,9 +126,10 @@ struct opusgpu_ctx {
     void *d_descs = nullptr, *d_arena = nullptr, *d_pcm = nullptr, *d_result = nullptr;
     size_t cap_descs = 0, cap_arena = 0, cap_pcm = 0, cap_result = 0;
     // parse records of the split CELT path (one per frame of a step), grown on demand
-    void *d_recs = nullptr;
-    size_t cap_recs = 0;
-    int split_celt = 1; // OPUSGPU_SPLIT=0 forces the single-kernel path for every mode (A/B measurements)
+    void *d_recs = nullptr, *d_handoff = nullptr;
+    size_t cap_recs = 0, cap_handoff = 0;
+    int split_celt = 1;   // OPUSGPU_SPLIT=0 forces the single-kernel path for every mode (A/B measurements)
+    int split_hybrid = 1; // OPUSGPU_SPLIT_HYBRID=0 keeps hybrid frames entirely on the single-kernel path
     char err[256] = {0};
 };
 
@@ -155,6 +165,7 @@ int opusgpu_ctx_create(int device, opusgpu_ctx **out) {
     if (!ctx) return OPUSGPU_ALLOC_FAIL;
     ctx->device = device;
     if (const char *e = getenv("OPUSGPU_SPLIT")) ctx->split_celt = e[0] != '0';
+    if (const char *e = getenv("OPUSGPU_SPLIT_HYBRID")) ctx->split_hybrid = e[0] != '0';
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return OPUSGPU_ERR_HIP;
@@ -173,6 +184,7 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     (void)hipFree(ctx->d_pcm);
     (void)hipFree(ctx->d_result);
     (void)hipFree(ctx->d_recs);
+    (void)hipFree(ctx->d_handoff);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -244,25 +256,40 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
     if (!d_descs || !d_arena || !d_pcm || !d_result) return OPUSGPU_BAD_ARG;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
     const int pcm_stride = OPUSGPU_FRAME_SAMPLES * ctx->channels;
+    SilkHandoff *handoff = nullptr;
     if (ctx->split_celt) {
-        // CELT-only frames: parse (one frame per lane) -> records in HBM -> reconstruct (one frame per wave).
-        // The records buffer only grows; growing it frees the old one, which waits for the device to go idle.
+        // The records / hand-off buffers only grow; growing frees the old one, which waits for the device to go idle.
         if (ctx->cap_recs < sizeof(ParseRec) * (size_t)n) {
             HIPCHK(ctx, hipSetDevice(ctx->device));
             const int rc = grow(ctx, &ctx->d_recs, &ctx->cap_recs, sizeof(ParseRec) * (size_t)n);
             if (rc) return rc;
         }
+        if (ctx->split_hybrid) {
+            if (ctx->cap_handoff < sizeof(SilkHandoff) * (size_t)n) {
+                HIPCHK(ctx, hipSetDevice(ctx->device));
+                const int rc = grow(ctx, &ctx->d_handoff, &ctx->cap_handoff, sizeof(SilkHandoff) * (size_t)n);
+                if (rc) return rc;
+            }
+            handoff = (SilkHandoff *)ctx->d_handoff;
+        }
+    }
+    // SILK-only frames, the SILK half of hybrid frames (CELT half handed to the split path), stream-index errors;
+    // without the split path: every frame
+    hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
+                       ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, ctx->split_celt, handoff);
+    if (ctx->split_celt) {
+        // CELT-only frames and the CELT half of hybrid frames: parse (one frame per lane) -> records in HBM ->
+        // reconstruct (one frame per wave) -> de-emphasis, SILK mix and PCM (one (frame, channel) per lane)
         hipLaunchKernelGGL(k_celt_parse, dim3((n + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
-                           (const StreamState *)ctx->d_streams, (ParseRec *)ctx->d_recs, n, ctx->n_streams);
+                           (const StreamState *)ctx->d_streams, (ParseRec *)ctx->d_recs, n, ctx->n_streams,
+                           (const SilkHandoff *)handoff);
         hipLaunchKernelGGL(k_celt_recon, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, ctx->d_streams,
-                           (const ParseRec *)ctx->d_recs, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride);
+                           (const ParseRec *)ctx->d_recs, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride,
+                           handoff ? 1 : 0);
         hipLaunchKernelGGL(k_celt_post, dim3((n * ctx->channels + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs,
                            ctx->d_streams, (const ParseRec *)ctx->d_recs, (const i32 *)d_result, (i16 *)d_pcm, n, ctx->n_streams,
-                           ctx->channels, pcm_stride);
+                           ctx->channels, pcm_stride, (const SilkHandoff *)handoff);
     }
-    // every other mode (and stream-index errors): the single-kernel path
-    hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
-                       ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, ctx->split_celt);
     HIPCHK(ctx, hipGetLastError());
     return OPUSGPU_OK;
 }

@@ -798,7 +798,11 @@ typedef i32 og_v4i __attribute__((ext_vector_type(4)));
 typedef u32 og_v2u __attribute__((ext_vector_type(2)));
 #endif
 // four consecutive samples of one channel: the recurrence, then int16 PCM
-OG_DEV void celt_post4(i32 &m, i32 s0, i32 s1, i32 s2, i32 s3, int j, int c, int CC, i16 *pcm) {
+// `silk`: optional second signal (interleaved like the PCM) added with saturation to the entries below `silk_n`.
+OG_DEV i32 post_mix(i32 v, const i16 *silk, int silk_n, int at) {
+    return (silk && at < silk_n) ? sat16(v + (i32)silk[at]) : v;
+}
+OG_DEV void celt_post4(i32 &m, i32 s0, i32 s1, i32 s2, i32 s3, int j, int c, int CC, i16 *pcm, const i16 *silk, int silk_n) {
     const i32 t0 = s0 + m;
     m = mul16x32_q15(27853, t0);
     const i32 t1 = s1 + m;
@@ -807,18 +811,20 @@ OG_DEV void celt_post4(i32 &m, i32 s0, i32 s1, i32 s2, i32 s3, int j, int c, int
     m = mul16x32_q15(27853, t2);
     const i32 t3 = s3 + m;
     m = mul16x32_q15(27853, t3);
+    const i32 o0 = post_mix(sat16(pshr32(t0, 12)), silk, silk_n, (j + 0) * CC + c), o1 = post_mix(sat16(pshr32(t1, 12)), silk, silk_n, (j + 1) * CC + c);
+    const i32 o2 = post_mix(sat16(pshr32(t2, 12)), silk, silk_n, (j + 2) * CC + c), o3 = post_mix(sat16(pshr32(t3, 12)), silk, silk_n, (j + 3) * CC + c);
 #ifdef OG_HOST_EMUL
     if (pcm) {
-        pcm[(j + 0) * CC + c] = (i16)sat16(pshr32(t0, 12));
-        pcm[(j + 1) * CC + c] = (i16)sat16(pshr32(t1, 12));
-        pcm[(j + 2) * CC + c] = (i16)sat16(pshr32(t2, 12));
-        pcm[(j + 3) * CC + c] = (i16)sat16(pshr32(t3, 12));
+        pcm[(j + 0) * CC + c] = (i16)o0;
+        pcm[(j + 1) * CC + c] = (i16)o1;
+        pcm[(j + 2) * CC + c] = (i16)o2;
+        pcm[(j + 3) * CC + c] = (i16)o3;
     }
 #else
     // two packed words; with two channels the lanes of a (left, right) pair swap halves so that each of them writes 8
     // contiguous bytes of the interleaved PCM
-    const u32 w01 = (u32)(u16)sat16(pshr32(t0, 12)) | (u32)(u16)sat16(pshr32(t1, 12)) << 16;
-    const u32 w23 = (u32)(u16)sat16(pshr32(t2, 12)) | (u32)(u16)sat16(pshr32(t3, 12)) << 16;
+    const u32 w01 = (u32)(u16)o0 | (u32)(u16)o1 << 16;
+    const u32 w23 = (u32)(u16)o2 | (u32)(u16)o3 << 16;
     og_v2u out;
     int at;
     if (CC == 2) {
@@ -840,14 +846,14 @@ OG_DEV void celt_post4(i32 &m, i32 s0, i32 s1, i32 s2, i32 s3, int j, int c, int
 #endif
 }
 
-OG_DEV void celt_post_lane(CeltState *st, int c, int CC, int N, i16 *pcm) {
+OG_DEV void celt_post_lane(CeltState *st, int c, int CC, int N, i16 *pcm, const i16 *silk, int silk_n) {
     const int pos = (st->ring_pos - N) & RING_MASK; // the frame's first sample (N is a multiple of 8, so is ring_pos)
     const i32 *ring = st->ring[c];
     i32 m = st->deemph[c];
 #ifdef OG_HOST_EMUL
     for (int j = 0; j < N; j += 4) {
         const i32 *src = &ring[(pos + j) & RING_MASK];
-        celt_post4(m, src[0], src[1], src[2], src[3], j, c, CC, pcm);
+        celt_post4(m, src[0], src[1], src[2], src[3], j, c, CC, pcm, silk, silk_n);
     }
 #else
     // 16 samples per iteration; the next 16 are requested before the current ones are consumed (the loads do not
@@ -857,10 +863,10 @@ OG_DEV void celt_post_lane(CeltState *st, int c, int CC, int N, i16 *pcm) {
     for (int j = 0; j < N; j += 16) {
         const int jn = j + 16 < N ? j + 16 : j;
         const og_v4i b0 = OG_LD4(jn), b1 = OG_LD4(jn + 4), b2 = OG_LD4(jn + 8), b3 = OG_LD4(jn + 12);
-        celt_post4(m, a0.x, a0.y, a0.z, a0.w, j, c, CC, pcm);
-        celt_post4(m, a1.x, a1.y, a1.z, a1.w, j + 4, c, CC, pcm);
-        celt_post4(m, a2.x, a2.y, a2.z, a2.w, j + 8, c, CC, pcm);
-        celt_post4(m, a3.x, a3.y, a3.z, a3.w, j + 12, c, CC, pcm);
+        celt_post4(m, a0.x, a0.y, a0.z, a0.w, j, c, CC, pcm, silk, silk_n);
+        celt_post4(m, a1.x, a1.y, a1.z, a1.w, j + 4, c, CC, pcm, silk, silk_n);
+        celt_post4(m, a2.x, a2.y, a2.z, a2.w, j + 8, c, CC, pcm, silk, silk_n);
+        celt_post4(m, a3.x, a3.y, a3.z, a3.w, j + 12, c, CC, pcm, silk, silk_n);
         a0 = b0;
         a1 = b1;
         a2 = b2;

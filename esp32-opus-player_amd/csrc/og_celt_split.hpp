@@ -23,6 +23,7 @@
 // path remains for frames whose CELT part follows SILK data in the same range coder (hybrid) and for the SILK-only
 // transition frame (Q4).
 #pragma once
+#include <stddef.h>
 #include "og_celt.hpp"
 
 #undef OG_SYNC
@@ -38,7 +39,8 @@ constexpr int REC_MAX_WORDS = NBANDS * (REC_BAND_WORDS + 2 * 33); // band words 
 enum { // ParseRec.flags
     RF_SILENCE = 1, RF_TRANSIENT = 2, RF_LM_SHIFT = 2 /* 2 bits */, RF_STEREO = 16, RF_SPREAD_SHIFT = 5 /* 2 bits */,
     RF_DUAL = 128, RF_ANTI_COLLAPSE = 256, RF_RC_ERROR = 512, RF_TELL_OVERFLOW = 1024,
-    RF_SKIP = 2048,    // descriptor rejected before any state change (decode_frame_wave's BAD_ARG)
+    RF_SKIP = 2048,    // descriptor rejected before any state change (decode_frame_wave's BAD_ARG), or (hybrid) the
+                       // single-kernel path already reported the frame's error: nothing to do, result untouched
     RF_BAD_CELT = 4096 // celt_decode_frame's early BAD_ARG: bookkeeping only
 };
 // Band words.  W0: flags below; W1: eff_low | x << 11 | N << 22 (positions relative to their arena rows);
@@ -47,7 +49,8 @@ enum {
     BW_SIGN0 = 1, BW_SIGN1 = 2, BW_INV = 4, BW_SIGN = 8, BW_MID_FIRST = 16, BW_SWAP = 32,
     BW_THETA0 = 64, BW_THETA1 = 128,   // the stereo angle is exactly 0 / exactly 16384 (fill mask halves)
     BW_TF_SHIFT = 8 /* tf_change + 4, 3 bits */, BW_FOLD0_SHIFT = 11 /* 5 bits */, BW_FOLD1_SHIFT = 16 /* 5 bits */,
-    BW_HAS_LOW = 1 << 21, BW_DUAL = 1 << 22, BW_DUAL_END = 1 << 23, BW_STEREO = 1 << 24
+    BW_HAS_LOW = 1 << 21, BW_DUAL = 1 << 22, BW_DUAL_END = 1 << 23, BW_STEREO = 1 << 24,
+    BW_DUAL_PRE = 1 << 25 // dual stereo still on when the band starts (before a switch-off at the intensity band)
 };
 // Job words (a "job" = one band of one channel, or the mid / side part of a stereo band).  Header: number of leaves
 // without pulses that follow | number of PVQ leaves << 5 | index of its first PVQ leaf << 10 | JW_NEED_LOW.  Then,
@@ -56,6 +59,18 @@ enum {
     JW_NPVQ_SHIFT = 5 /* 5 bits */, JW_FIRST_SHIFT = 10 /* 10 bits */, JW_NEED_LOW = 1 << 20,
     LW_OFF_SHIFT = 8 /* 4 bits */, LW_B_SHIFT = 12 /* 4 bits */, LW_N_SHIFT = 16 /* 8 bits */
 };
+
+// Hybrid frames: the single-kernel path decodes the SILK half (wave per frame), then hands the live range decoder and
+// the SILK PCM over to the split path, which decodes the CELT half (bands 17..20) and mixes the two in k_celt_post.
+struct SilkHandoff {
+    u32 valid; // 1: SILK half decoded, coder state below is live
+    u32 storage, end_offs, end_window;
+    i32 nend_bits, nbits_total;
+    u32 offs, rng, val, ext;
+    i32 rem, error;
+    i16 pcm[1920]; // SILK output at 48 kHz, interleaved over the packet's channels
+};
+static_assert(sizeof(SilkHandoff) % 16 == 0 && offsetof(SilkHandoff, pcm) % 16 == 0, "handoff alignment");
 
 struct ParseRec {
     i32 ret;       // samples per channel (960) -- or the negative code the frame ends with
@@ -316,6 +331,7 @@ OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C
             has_low = 1;
             fold_bands = (1u << fold_end) - (1u << fold_start);
         }
+        if (dual_stereo) w0 |= BW_DUAL_PRE;
         if (dual_stereo && i == intensity) {
             dual_stereo = 0;
             w0 |= BW_DUAL_END;
@@ -421,20 +437,27 @@ OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C
 
 // One CELT-only frame, lane-private.  `payload`/`len`: the frame's bytes; `ch`: channels coded in the packet,
 // CC: decoder channels.  Mirrors decode_frame_wave + celt_decode_frame up to (not including) every vector operation.
-OG_DEV void celt_parse_lane(const StreamState *st, const u8 *payload, int len, int ch, ParseRec *rec) {
+// `handoff` (hybrid frames): resume the range decoder where the SILK half left it and start at band 17.
+OG_DEV void celt_parse_lane(const StreamState *st, const u8 *payload, int len, int ch, ParseRec *rec, const SilkHandoff *handoff) {
     const LaneArr a;
-    const int CC = st->channels, C = ch, LM = 3, frame_size = 960, start = 0, end = NBANDS;
+    const int CC = st->channels, C = ch, LM = 3, frame_size = 960, start = handoff ? 17 : 0, end = NBANDS;
     rec->start = start;
     rec->n_leaves = 0;
     rec->n_words = 0;
-    if (len < 0 || len > 1275) {
+    if (len < 0 || len > 1275 || (handoff && !handoff->valid)) {
         rec->ret = BAD_ARG;
         rec->flags = RF_SKIP;
         return;
     }
     RcLane rc;
     rc_lane_attach(rc, payload, (u32)len);
-    rc_init(rc, (u32)len);
+    if (handoff) {
+        rc.storage = handoff->storage; rc.end_offs = handoff->end_offs; rc.end_window = handoff->end_window;
+        rc.nend_bits = handoff->nend_bits; rc.nbits_total = handoff->nbits_total; rc.offs = handoff->offs; rc.rng = handoff->rng;
+        rc.val = handoff->val; rc.ext = handoff->ext; rc.rem = handoff->rem; rc.error = handoff->error;
+        rc_lane_resume(rc);
+    } else
+        rc_init(rc, (u32)len);
     if (rc.storage <= 1) { // celt_decode_frame's early exit
         rec->ret = BAD_ARG;
         rec->flags = RF_BAD_CELT;
@@ -838,7 +861,7 @@ OG_DEV void recon_all_bands(const u32 *words, u32 need_norm, const LcgTab &lcg, 
                 OG_SYNC();
                 OG_FOR_LANES(j, n2 - n1) {
                     S.v[norm + n1 + j] = S.v[norm + 2 * n1 - n2 + j];
-                    if (dual_stereo) S.v[norm2 + n1 + j] = S.v[norm2 + 2 * n1 - n2 + j];
+                    if (w0 & BW_DUAL_PRE) S.v[norm2 + n1 + j] = S.v[norm2 + 2 * n1 - n2 + j];
                 }
                 OG_SYNC();
             }
@@ -1036,9 +1059,11 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
 }
 
 // Third step of the split path for (frame, channel c): runs whenever the frame was synthesised; PCM only on success.
-OG_DEV void celt_post(StreamState *st, const ParseRec *rec, int result, int c, i16 *pcm) {
+// `silk` (hybrid frames): the SILK half's PCM, added with saturation over the first 960 * ch interleaved entries
+// (opus_decode_frame src/opus_decoder.cpp:271-273, Q3).
+OG_DEV void celt_post(StreamState *st, const ParseRec *rec, int result, int c, i16 *pcm, const i16 *silk, int ch) {
     if (rec->flags & (RF_SKIP | RF_BAD_CELT)) return;
-    celt_post_lane(&st->celt, c, st->channels, 960, result >= 0 ? pcm : nullptr);
+    celt_post_lane(&st->celt, c, st->channels, 960, result >= 0 ? pcm : nullptr, silk, 960 * ch);
 }
 
 } // namespace og

@@ -41,7 +41,11 @@ OG_DEV void stream_reset(StreamState *st) {
 
 // Decode one frame.  `payload` points at the frame's bytes in HBM; `pcm` at 960*channels int16 in HBM.
 // Returns samples per channel (960) or a negative OPUS_* code; the value is wave-uniform.
-OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mode, int bandwidth, int ch, i16 *pcm) {
+// `handoff` != null (split path enabled): a hybrid frame's CELT half is left to the split path -- after the SILK half
+// the live coder state and the SILK PCM go to *handoff and CONTINUE_SPLIT is returned (no result, no bookkeeping yet).
+enum { CONTINUE_SPLIT = 1 };
+OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mode, int bandwidth, int ch, i16 *pcm,
+                             SilkHandoff *handoff = nullptr) {
     const int audiosize = 960;
     const int CC = st->channels;
     if (len < 0 || len > 1275) return BAD_ARG;
@@ -74,6 +78,24 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
     }
     if (mode != MODE_CELT) start_band = 17;
     const int disable_inv = CC == 1;
+#ifndef OG_NO_SILK
+    if (handoff && mode == MODE_HYBRID) {
+        OG_SYNC();
+        if (OG_LANE == 0) {
+            handoff->storage = rc.storage; handoff->end_offs = rc.end_offs; handoff->end_window = rc.end_window;
+            handoff->nend_bits = rc.nend_bits; handoff->nbits_total = rc.nbits_total; handoff->offs = rc.offs;
+            handoff->rng = rc.rng; handoff->val = rc.val; handoff->ext = rc.ext; handoff->rem = rc.rem; handoff->error = rc.error;
+            handoff->valid = 1;
+        }
+        {
+            const u32 *src = reinterpret_cast<const u32 *>(g_pcm_silk);
+            u32 *dst = reinterpret_cast<u32 *>(handoff->pcm);
+            OG_FOR_LANES(i, audiosize * ch / 2) dst[i] = src[i];
+        }
+        OG_SYNC();
+        return CONTINUE_SPLIT;
+    }
+#endif
 
     // One CELT call site (the whole CELT decoder is inlined into it): the regular frame, or -- Q4 -- the 2.5 ms
     // frame the reference decodes from the live range decoder on a hybrid -> SILK-only transition.

@@ -46,6 +46,7 @@ OG_DEV void rc_lane_attach(RcLane &rc, const u8 *buf, u32 len) {
     rc.buf = buf;
     (void)len;
 }
+OG_DEV void rc_lane_resume(RcLane &rc) {}
 OG_DEV int rc_next_byte(RcLane &rc) { return rc.offs < rc.storage ? rc.buf[rc.offs++] : 0; }
 OG_DEV int rc_next_byte_end(RcLane &rc) { return rc.end_offs < rc.storage ? rc.buf[rc.storage - ++rc.end_offs] : 0; }
 #else
@@ -60,6 +61,15 @@ OG_DEV void rc_lane_attach(RcLane &rc, const u8 *buf, u32 len) { // call before 
     rc.f_cur = rc_lane_word(rc, 0);
     rc.f_next = rc_lane_word(rc, 1);
     rc.b_idx = rc.last_word;
+    rc.b_cur = rc_lane_word(rc, rc.b_idx);
+    rc.b_next = rc_lane_word(rc, rc.b_idx - 1);
+}
+// after the coder state (offs, end_offs, ...) was restored from elsewhere: re-position both windows
+OG_DEV void rc_lane_resume(RcLane &rc) {
+    rc.f_idx = (i32)((rc.offs + rc.shift) >> 2);
+    rc.f_cur = rc_lane_word(rc, rc.f_idx);
+    rc.f_next = rc_lane_word(rc, rc.f_idx + 1);
+    rc.b_idx = rc.end_offs < rc.storage ? (i32)((rc.storage - rc.end_offs - 1 + rc.shift) >> 2) : rc.last_word;
     rc.b_cur = rc_lane_word(rc, rc.b_idx);
     rc.b_next = rc_lane_word(rc, rc.b_idx - 1);
 }

@@ -12,14 +12,24 @@ void emu_stream_reset(void *st) { og::stream_reset((og::StreamState *)st); }
 int emu_decode_frame_single(void *st, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm) {
     return og::decode_frame_wave((og::StreamState *)st, payload, len, mode, bw, ch, pcm);
 }
-// what the library dispatches: CELT-only frames take the split path (parse per lane, reconstruct per wave)
-int emu_decode_frame(void *st, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm) {
-    if (mode != og::MODE_CELT) return og::decode_frame_wave((og::StreamState *)st, payload, len, mode, bw, ch, pcm);
+// what the library dispatches: CELT-only frames take the split path (parse per lane, reconstruct per wave, post per
+// channel); hybrid frames decode their SILK half on the single-kernel path and hand the CELT half over
+int emu_decode_frame(void *stv, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm) {
+    og::StreamState *st = (og::StreamState *)stv;
     static og::ParseRec rec;
+    static og::SilkHandoff handoff;
+    const og::SilkHandoff *h = nullptr;
+    if (mode == og::MODE_SILK) return og::decode_frame_wave(st, payload, len, mode, bw, ch, pcm);
+    if (mode == og::MODE_HYBRID) {
+        handoff.valid = 0;
+        const int r = og::decode_frame_wave(st, payload, len, mode, bw, ch, pcm, &handoff);
+        if (r != og::CONTINUE_SPLIT) return r;
+        h = &handoff;
+    }
     og::parse_tables_load();
-    og::celt_parse_lane((const og::StreamState *)st, payload, len, ch, &rec);
-    const int ret = og::celt_recon_wave((og::StreamState *)st, &rec, mode, ch);
-    for (int c = 0; c < ((og::StreamState *)st)->channels; c++) og::celt_post((og::StreamState *)st, &rec, ret, c, pcm);
+    og::celt_parse_lane(st, payload, len, ch, &rec, h);
+    const int ret = og::celt_recon_wave(st, &rec, mode, ch);
+    for (int c = 0; c < st->channels; c++) og::celt_post(st, &rec, ret, c, pcm, h ? h->pcm : nullptr, ch);
     return ret;
 }
 int emu_last_record_words(void) { return 0; }
