@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(64) k_stream_init(StreamState *st, int first, 
 #endif
 __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
                                                    StreamState *st, i16 *pcm, i32 *result, int n, int n_streams,
-                                                   int pcm_stride, int skip_celt, SilkHandoff *handoff) {
+                                                   int pcm_stride, int skip_celt, SilkHandoff *handoff, const SilkRec *srecs) {
     const int f = (int)blockIdx.x;
     if (f >= n) return;
     const FrameDesc d = descs[f];
@@ -49,16 +49,29 @@ __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const Fra
 #ifdef OG_PROF_SINGLE // profiling builds: time the sections of the single-kernel path
         OG_PROF_INIT();
 #endif
-        SilkHandoff *h = handoff ? &handoff[f] : nullptr;
-        if (h && desc_mode(d.flags) == MODE_HYBRID && threadIdx.x == 0) h->valid = 0;
         ret = decode_frame_wave(s, arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
-                                desc_channels(d.flags), pcm + (size_t)f * pcm_stride, h);
+                                desc_channels(d.flags), pcm + (size_t)f * pcm_stride, handoff ? &handoff[f] : nullptr,
+                                srecs ? &srecs[f] : nullptr);
 #ifdef OG_PROF_SINGLE
         OG_PROF_FLUSH();
 #endif
         if (ret == CONTINUE_SPLIT) return; // the split path finishes this frame and reports its result
     }
     if (threadIdx.x == 0) result[f] = ret;
+}
+
+// SILK-only and hybrid frames, entropy half: ONE FRAME PER LANE (og_silk_parse.hpp).  Lane l of workgroup g decodes the
+// side information and pulses of frame 64 g + l into srecs[frame] and leaves the coder state in handoff[frame].
+__global__ void __launch_bounds__(64, 2) k_silk_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
+                                                      const StreamState *st, SilkRec *srecs, SilkHandoff *handoff, int n,
+                                                      int n_streams) {
+    silk_tables_load();
+    const int f = (int)blockIdx.x * 64 + (int)threadIdx.x;
+    if (f >= n) return;
+    const FrameDesc d = descs[f];
+    const int mode = desc_mode(d.flags);
+    if (d.stream < 0 || d.stream >= n_streams || mode == MODE_CELT) return;
+    silk_parse_lane(&st[d.stream], arena + d.offset, d.len, mode, desc_bandwidth(d.flags), desc_channels(d.flags), &srecs[f], &handoff[f]);
 }
 
 // Split CELT path, first half: ONE FRAME PER LANE.  Lane l of workgroup g parses frame 64 g + l (range decoder,
@@ -126,10 +139,10 @@ struct opusgpu_ctx {
     void *d_descs = nullptr, *d_arena = nullptr, *d_pcm = nullptr, *d_result = nullptr;
     size_t cap_descs = 0, cap_arena = 0, cap_pcm = 0, cap_result = 0;
     // parse records of the split CELT path (one per frame of a step), grown on demand
-    void *d_recs = nullptr, *d_handoff = nullptr;
-    size_t cap_recs = 0, cap_handoff = 0;
+    void *d_recs = nullptr, *d_handoff = nullptr, *d_srecs = nullptr;
+    size_t cap_recs = 0, cap_handoff = 0, cap_srecs = 0;
     int split_celt = 1;   // OPUSGPU_SPLIT=0 forces the single-kernel path for every mode (A/B measurements)
-    int split_hybrid = 1; // OPUSGPU_SPLIT_HYBRID=0 keeps hybrid frames entirely on the single-kernel path
+    int split_hybrid = 1; // OPUSGPU_SPLIT_HYBRID=0 keeps SILK-only and hybrid frames entirely on the single-kernel path
     char err[256] = {0};
 };
 
@@ -185,6 +198,7 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     (void)hipFree(ctx->d_result);
     (void)hipFree(ctx->d_recs);
     (void)hipFree(ctx->d_handoff);
+    (void)hipFree(ctx->d_srecs);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -257,6 +271,7 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
     const int pcm_stride = OPUSGPU_FRAME_SAMPLES * ctx->channels;
     SilkHandoff *handoff = nullptr;
+    SilkRec *srecs = nullptr;
     if (ctx->split_celt) {
         // The records / hand-off buffers only grow; growing frees the old one, which waits for the device to go idle.
         if (ctx->cap_recs < sizeof(ParseRec) * (size_t)n) {
@@ -270,13 +285,23 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
                 const int rc = grow(ctx, &ctx->d_handoff, &ctx->cap_handoff, sizeof(SilkHandoff) * (size_t)n);
                 if (rc) return rc;
             }
+            if (ctx->cap_srecs < sizeof(SilkRec) * (size_t)n) {
+                HIPCHK(ctx, hipSetDevice(ctx->device));
+                const int rc = grow(ctx, &ctx->d_srecs, &ctx->cap_srecs, sizeof(SilkRec) * (size_t)n);
+                if (rc) return rc;
+            }
             handoff = (SilkHandoff *)ctx->d_handoff;
+            srecs = (SilkRec *)ctx->d_srecs;
+            // SILK-only and hybrid frames: entropy half, one frame per lane
+            hipLaunchKernelGGL(k_silk_parse, dim3((n + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
+                               (const StreamState *)ctx->d_streams, srecs, handoff, n, ctx->n_streams);
         }
     }
     // SILK-only frames, the SILK half of hybrid frames (CELT half handed to the split path), stream-index errors;
     // without the split path: every frame
     hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
-                       ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, ctx->split_celt, handoff);
+                       ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, ctx->split_celt, handoff,
+                       (const SilkRec *)srecs);
     if (ctx->split_celt) {
         // CELT-only frames and the CELT half of hybrid frames: parse (one frame per lane) -> records in HBM ->
         // reconstruct (one frame per wave) -> de-emphasis, SILK mix and PCM (one (frame, channel) per lane)

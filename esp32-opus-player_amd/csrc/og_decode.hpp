@@ -41,20 +41,38 @@ OG_DEV void stream_reset(StreamState *st) {
 
 // Decode one frame.  `payload` points at the frame's bytes in HBM; `pcm` at 960*channels int16 in HBM.
 // Returns samples per channel (960) or a negative OPUS_* code; the value is wave-uniform.
-// `handoff` != null (split path enabled): a hybrid frame's CELT half is left to the split path -- after the SILK half
-// the live coder state and the SILK PCM go to *handoff and CONTINUE_SPLIT is returned (no result, no bookkeeping yet).
+// With the split path enabled (`handoff`, `srec` != null) SILK-only and hybrid frames arrive with their entropy half
+// already decoded by the lane-per-frame parse kernel: `srec` holds the SILK indices / pulses, `handoff` the live coder
+// state.  A hybrid frame's CELT half is then left to the split path: the SILK PCM goes to handoff->pcm and
+// CONTINUE_SPLIT is returned (no result, no bookkeeping yet).
 enum { CONTINUE_SPLIT = 1 };
 OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mode, int bandwidth, int ch, i16 *pcm,
-                             SilkHandoff *handoff = nullptr) {
+                             SilkHandoff *handoff = nullptr, const SilkRec *srec = nullptr) {
     const int audiosize = 960;
     const int CC = st->channels;
     if (len < 0 || len > 1275) return BAD_ARG;
-    OG_SYNC();
-    OG_FOR_LANES(i, len) S.pkt[i] = payload[i];
-    OG_SYNC();
-    Rc rc;
-    rc_init(rc, (u32)len);
     const int prev_mode = st->prev_mode;
+    Rc rc;
+    if (srec) {
+        const int r0 = OG_UNI(srec->ret);
+        if (r0 < 0) return r0;
+        // the coder state after the SILK half (+ redundancy flag); the packet itself is only needed again by Q4
+        rc.storage = (u32)OG_UNI(handoff->storage); rc.end_offs = (u32)OG_UNI(handoff->end_offs);
+        rc.end_window = (u32)OG_UNI(handoff->end_window); rc.nend_bits = OG_UNI(handoff->nend_bits);
+        rc.nbits_total = OG_UNI(handoff->nbits_total); rc.offs = (u32)OG_UNI(handoff->offs); rc.rng = (u32)OG_UNI(handoff->rng);
+        rc.val = (u32)OG_UNI(handoff->val); rc.ext = (u32)OG_UNI(handoff->ext); rc.rem = OG_UNI(handoff->rem);
+        rc.error = OG_UNI(handoff->error);
+        if (mode == MODE_SILK && prev_mode == MODE_HYBRID) {
+            OG_SYNC();
+            OG_FOR_LANES(i, len) S.pkt[i] = payload[i];
+            OG_SYNC();
+        }
+    } else {
+        OG_SYNC();
+        OG_FOR_LANES(i, len) S.pkt[i] = payload[i];
+        OG_SYNC();
+        rc_init(rc, (u32)len);
+    }
     int celt_ret = 0;
 
 #ifndef OG_NO_SILK
@@ -62,18 +80,14 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
         if (prev_mode == MODE_CELT) silk_init_state(&st->silk);
         int internal_hz = 16000;
         if (mode == MODE_SILK) internal_hz = bandwidth == BW_NB ? 8000 : (bandwidth == BW_MB ? 12000 : 16000);
-        // SILK is compiled out of line and takes the range decoder by reference: hand it a copy, so that the
-        // decoder state used by the (inlined) CELT path never has its address taken and stays in registers.
-        Rc rcs = rc;
-        int ret = silk_decode_20ms(&st->silk, rcs, ch, internal_hz); // fills S.pcm_silk (48 kHz, interleaved)
-        rc = rcs;
+        int ret = silk_decode_20ms(&st->silk, rc, ch, internal_hz, srec); // fills g_pcm_silk (48 kHz, interleaved)
         if (ret) return INTERNAL_ERROR;
     }
 #else
     if (mode != MODE_CELT) return INTERNAL_ERROR;
 #endif
     int start_band = 0;
-    if (mode != MODE_CELT && rc_tell(rc) + 17 + 20 * (mode == MODE_HYBRID) <= 8 * len) {
+    if (!srec && mode != MODE_CELT && rc_tell(rc) + 17 + 20 * (mode == MODE_HYBRID) <= 8 * len) {
         if (mode == MODE_HYBRID) (void)rc_bit_logp(rc, 12); // redundancy flag read and ignored (Q2)
     }
     if (mode != MODE_CELT) start_band = 17;
@@ -81,12 +95,6 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
 #ifndef OG_NO_SILK
     if (handoff && mode == MODE_HYBRID) {
         OG_SYNC();
-        if (OG_LANE == 0) {
-            handoff->storage = rc.storage; handoff->end_offs = rc.end_offs; handoff->end_window = rc.end_window;
-            handoff->nend_bits = rc.nend_bits; handoff->nbits_total = rc.nbits_total; handoff->offs = rc.offs;
-            handoff->rng = rc.rng; handoff->val = rc.val; handoff->ext = rc.ext; handoff->rem = rc.rem; handoff->error = rc.error;
-            handoff->valid = 1;
-        }
         {
             const u32 *src = reinterpret_cast<const u32 *>(g_pcm_silk);
             u32 *dst = reinterpret_cast<u32 *>(handoff->pcm);

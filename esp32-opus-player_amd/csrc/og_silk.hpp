@@ -17,6 +17,7 @@
 // Scratch lives in LDS, overlaid on the CELT synthesis buffer (SILK always runs before CELT in a frame).
 #pragma once
 #include "og_celt_math.hpp"
+#include "og_silk_parse.hpp"
 
 namespace og {
 
@@ -718,7 +719,8 @@ OG_DEV void silk_stereo_decode_pred(Rc &rc, i32 pred_Q13[2]) { // silk.cpp:592
 
 // Decode one 20 ms SILK frame (mid + side / mono) into S.pcm_silk (48 kHz, interleaved when stereo).
 // Returns 0 or a non-zero error (wave-uniform).
-OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz) {
+// `rec` != null: the frame's entropy half comes from the parse kernel's record and `rc` is not touched.
+OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz, const SilkRec *rec = nullptr) {
     SilkLds &L = SL();
     const int fs_kHz = (internal_hz >> 10) + 1;
     if (fs_kHz != 8 && fs_kHz != 12 && fs_kHz != 16) return -200;
@@ -745,12 +747,21 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz)
     }
     int vad[2] = {0, 0}, lbrr[2] = {0, 0};
     OG_MARK(30);
+    i32 MS_pred_Q13[2] = {0, 0};
+    int decode_only_middle = 0;
+    if (rec) { // the entropy half was done by the lane-per-frame parse kernel (og_silk_parse.hpp)
+        MS_pred_Q13[0] = OG_UNI(rec->MS_pred_Q13[0]);
+        MS_pred_Q13[1] = OG_UNI(rec->MS_pred_Q13[1]);
+        decode_only_middle = OG_UNI(rec->decode_only_middle);
+        for (int n = 0; n < 2; n++) {
+            ecType[n] = OG_UNI(rec->ch[n].ec_prevSignalType);
+            ecLag[n] = OG_UNI(rec->ch[n].ec_prevLagIndex);
+        }
+    } else {
     for (int n = 0; n < channels; n++) {
         vad[n] = rc_bit_logp(rc, 1);
         lbrr[n] = rc_bit_logp(rc, 1);
     }
-    i32 MS_pred_Q13[2] = {0, 0};
-    int decode_only_middle = 0;
     for (int n = 0; n < channels; n++) { // regular decoding reads past the LBRR frame (silk.cpp:1590-1616)
         if (lbrr[n]) {
             if (channels == 2 && n == 0) {
@@ -764,6 +775,7 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz)
     if (channels == 2) {
         silk_stereo_decode_pred(rc, MS_pred_Q13);
         decode_only_middle = vad[1] == 0 ? rc_icdf(rc, rom_silk_mid_only_icdf, 8) : 0;
+    }
     }
     const int prev_dom = s->prev_decode_only_middle;
     if (channels == 2 && decode_only_middle == 0 && prev_dom == 1) { // side channel restarts (silk.cpp:1639)
@@ -786,9 +798,20 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz)
             // FrameIndex = nFramesDecoded - n = -n <= 0 -> independent coding (silk.cpp:1678-1681)
             const int condCoding = 0;
             OG_MARK(30);
+            if (rec) { // indices (33 words, same order as SilkCtrl's index block) and pulses from the record
+                OG_SYNC();
+                const i32 *src = &rec->ch[n].signalType;
+                i32 *dst = &L.ctrl[n].signalType;
+                OG_FOR_LANES(i, 8 + 4 + 4 + SILK_MAX_LPC + 1) dst[i] = src[i];
+                const u32 *ps = reinterpret_cast<const u32 *>(rec->ch[n].pulses);
+                u32 *pd = reinterpret_cast<u32 *>(L.pulses[n]);
+                OG_FOR_LANES(i, (frame_length + 16) / 2) pd[i] = ps[i];
+                OG_SYNC();
+            } else {
             silk_decode_indices(&s->ch[n], L.ctrl[n], rc, fs_kHz, vad[n], 0, condCoding, ecType[n], ecLag[n]);
             OG_MARK(31);
             silk_decode_pulses(rc, n, L.ctrl[n].signalType, L.ctrl[n].quantOffsetType, frame_length);
+            }
             OG_MARK(32);
             silk_decode_parameters(&s->ch[n], L.ctrl[n], fs_kHz, condCoding, lastGain[n], ffar[n]);
             OG_MARK(33);

@@ -1,0 +1,318 @@
+// og_silk_parse.hpp -- SILK entropy decoding with ONE FRAME PER LANE (k_silk_parse).
+//
+// SILK's side information and excitation pulses are a long chain of inverse-CDF symbols (several hundred per frame
+// at 20 ms stereo) with no data-parallel work in between: run one frame per wave it keeps a 64-lane SIMD busy with
+// scalar code.  Here each lane is an ordinary serial decoder for its own frame; the 8-bit probability tables sit in
+// LDS (one copy per workgroup, rom_silk_u8_blob), packet bytes arrive through RcLane's word windows.  The lane writes
+// a SilkRec (indices of both channels, pulses, stereo predictor, flags) to HBM; the frame-per-wave kernel picks it
+// up for everything that is arithmetic on decoded values (parameter dequantisation, NLSF -> LPC, LTP / LPC synthesis,
+// stereo un-mixing, resampling: og_silk.hpp).  For hybrid frames the lane also leaves the live coder state in the
+// frame's SilkHandoff for the CELT parse kernel.
+//
+// Reference behaviour: silk_Decode's entropy half (src/silk.cpp:1481-1700), silk_decode_indices (:708),
+// silk_decode_pulses (:898) with silk_shell_decoder (:1162) and silk_decode_signs (:1436), silk_stereo_decode_pred (:592).
+#pragma once
+#include "og_celt_split.hpp"
+
+namespace og {
+
+constexpr int SILK_REC_LPC = 16, SILK_REC_FRAME = 320;
+
+struct SilkRecCh {
+    // same order as SilkCtrl's index block (signalType .. NLSFIndices): copied as 33 words
+    i32 signalType, quantOffsetType, NLSFInterpCoef_Q2, Seed, lagIndex, contourIndex, PERIndex, LTP_scaleIndex;
+    i32 GainsIndices[4], LTPIndex[4], NLSFIndices[SILK_REC_LPC + 1];
+    i32 ec_prevSignalType, ec_prevLagIndex; // entropy-side state after the frame (written back by the wave kernel)
+    i32 pad;
+    i16 pulses[SILK_REC_FRAME + 16];
+};
+struct SilkRec {
+    i32 ret; // 0, or the negative code the frame ends with (then nothing else is valid)
+    i32 decode_only_middle;
+    i32 MS_pred_Q13[2];
+    SilkRecCh ch[2];
+};
+static_assert(sizeof(SilkRec) % 16 == 0, "record alignment");
+
+OG_LDS u8 g_silk_tab[SILK_BLOB_SIZE]; // LDS copy of rom_silk_u8_blob
+OG_DEV void silk_tables_load() {      // cooperative, whole workgroup; ends with a barrier
+    const u32 *src = reinterpret_cast<const u32 *>(rom_silk_u8_blob);
+    u32 *dst = reinterpret_cast<u32 *>(g_silk_tab);
+    OG_FOR_LANES(i, SILK_BLOB_SIZE / 4) dst[i] = src[i];
+    OG_FULL_SYNC();
+}
+
+// inverse-CDF symbol from the LDS table blob (ec_dec_icdf celt.cpp:2727, ftb = 8 throughout SILK)
+OG_DEV int rc_icdf_tab(RcLane &rc, int off) {
+    u32 s = rc.rng, d = rc.val, r = s >> 8, t;
+    int ret = -1;
+    do {
+        t = s;
+        s = r * (u32)g_silk_tab[off + ++ret];
+    } while (d < s);
+    rc.val = d - s;
+    rc.rng = t - s;
+    rc_renorm(rc);
+    return ret;
+}
+
+// silk_decode_indices silk.cpp:708 (20 ms: nb_subfr == 4).  Indices go straight to the record.
+OG_DEV void silk_parse_indices(RcLane &rc, SilkRecCh *o, int fs_kHz, int vad, int decode_LBRR, int condCoding, i32 &ec_prevSignalType,
+                               i32 &ec_prevLagIndex) {
+    const int wb = fs_kHz == 16, order = wb ? 16 : 10;
+    const int CB1_iCDF = wb ? SILK_BLOB_wb_cb1_icdf : SILK_BLOB_nb_cb1_icdf, ec_sel = wb ? SILK_BLOB_wb_cb2_select : SILK_BLOB_nb_cb2_select;
+    const int ec_iCDF = wb ? SILK_BLOB_wb_cb2_icdf : SILK_BLOB_nb_cb2_icdf;
+    int Ix;
+    if (decode_LBRR || vad)
+        Ix = rc_icdf_tab(rc, SILK_BLOB_type_vad_icdf) + 2;
+    else
+        Ix = rc_icdf_tab(rc, SILK_BLOB_type_novad_icdf);
+    const int signalType = Ix >> 1;
+    o->signalType = signalType;
+    o->quantOffsetType = Ix & 1;
+    if (condCoding == 2)
+        o->GainsIndices[0] = rc_icdf_tab(rc, SILK_BLOB_delta_gain_icdf);
+    else {
+        int g = rc_icdf_tab(rc, SILK_BLOB_gain_icdf + 8 * signalType) << 3;
+        g += rc_icdf_tab(rc, SILK_BLOB_uniform8_icdf);
+        o->GainsIndices[0] = g;
+    }
+    for (int i = 1; i < 4; i++) o->GainsIndices[i] = rc_icdf_tab(rc, SILK_BLOB_delta_gain_icdf);
+    const int cb1 = rc_icdf_tab(rc, CB1_iCDF + (signalType >> 1) * 32);
+    o->NLSFIndices[0] = cb1;
+    for (int i = 0; i < order; i++) { // silk_NLSF_unpack silk.cpp:2762: the entropy table of coefficient i
+        const int entry = g_silk_tab[ec_sel + cb1 * order / 2 + (i >> 1)];
+        const int ec_ix = ((entry >> (1 + 4 * (i & 1))) & 7) * 9;
+        Ix = rc_icdf_tab(rc, ec_iCDF + ec_ix);
+        if (Ix == 0)
+            Ix -= rc_icdf_tab(rc, SILK_BLOB_nlsf_ext_icdf);
+        else if (Ix == 8)
+            Ix += rc_icdf_tab(rc, SILK_BLOB_nlsf_ext_icdf);
+        o->NLSFIndices[i + 1] = Ix - 4;
+    }
+    o->NLSFInterpCoef_Q2 = rc_icdf_tab(rc, SILK_BLOB_nlsf_interp_icdf);
+    if (signalType == 2) {
+        int decode_abs = 1, lagIndex = 0;
+        const int lowbits = fs_kHz == 16 ? SILK_BLOB_uniform8_icdf : (fs_kHz == 12 ? SILK_BLOB_uniform6_icdf : SILK_BLOB_uniform4_icdf);
+        const int contour = fs_kHz == 8 ? SILK_BLOB_pitch_contour_nb_icdf : SILK_BLOB_pitch_contour_icdf;
+        if (condCoding == 2 && ec_prevSignalType == 2) {
+            int delta = rc_icdf_tab(rc, SILK_BLOB_pitch_delta_icdf);
+            if (delta > 0) {
+                delta -= 9;
+                lagIndex = tr16(ec_prevLagIndex + delta);
+                decode_abs = 0;
+            }
+        }
+        if (decode_abs) {
+            lagIndex = tr16(rc_icdf_tab(rc, SILK_BLOB_pitch_lag_icdf) * (fs_kHz >> 1));
+            lagIndex = tr16(lagIndex + rc_icdf_tab(rc, lowbits));
+        }
+        o->lagIndex = lagIndex;
+        ec_prevLagIndex = lagIndex;
+        o->contourIndex = rc_icdf_tab(rc, contour);
+        const int per = rc_icdf_tab(rc, SILK_BLOB_ltp_per_icdf);
+        o->PERIndex = per;
+        const int t = per == 0 ? SILK_BLOB_ltp_gain_icdf0 : (per == 1 ? SILK_BLOB_ltp_gain_icdf1 : SILK_BLOB_ltp_gain_icdf2);
+        for (int j = 0; j < 4; j++) o->LTPIndex[j] = rc_icdf_tab(rc, t);
+        o->LTP_scaleIndex = condCoding == 0 ? rc_icdf_tab(rc, SILK_BLOB_ltpscale_icdf) : 0;
+    }
+    ec_prevSignalType = signalType;
+    o->Seed = rc_icdf_tab(rc, SILK_BLOB_uniform4_icdf);
+}
+
+OG_DEV void shell_split_tab(RcLane &rc, int &c1, int &c2, int p, int table) {
+    if (p > 0) {
+        c1 = rc_icdf_tab(rc, table + g_silk_tab[SILK_BLOB_shell_offsets + p]);
+        c2 = p - c1;
+    } else {
+        c1 = 0;
+        c2 = 0;
+    }
+}
+
+// per-lane block bookkeeping of the pulse decoder: sum_pulses (<= 16) | nLshifts (<= 10) << 5 per 16-sample block
+OG_LDS u16 g_silk_blk[SILK_REC_FRAME / 16][OG_NLANES];
+
+// silk_decode_pulses silk.cpp:898.  The pulses of a channel go to the record (HBM) as they are produced; the later
+// passes (LSBs, signs) re-read them, one value ahead of their use.
+OG_DEV void silk_parse_pulses(RcLane &rc, i16 *pulses, int signalType, int quantOffsetType, int frame_length) {
+    int iter = frame_length >> 4;
+    if (iter * 16 < frame_length) iter++;
+    const int RateLevelIndex = rc_icdf_tab(rc, SILK_BLOB_rate_levels_icdf + 9 * (signalType >> 1));
+    const int cdf = SILK_BLOB_pulses_per_block_icdf + 18 * RateLevelIndex;
+    for (int i = 0; i < iter; i++) {
+        int nl = 0, sp = rc_icdf_tab(rc, cdf);
+        while (sp == 17) {
+            nl++;
+            sp = rc_icdf_tab(rc, SILK_BLOB_pulses_per_block_icdf + 18 * 9 + (nl == 10));
+        }
+        g_silk_blk[i][OG_LANE] = (u16)(sp | nl << 5);
+    }
+    for (int i = 0; i < iter; i++) {
+        i16 *p0 = &pulses[i * 16];
+        const int sp = g_silk_blk[i][OG_LANE] & 31;
+        if (sp > 0) {
+            // binary shell tree: 16 -> 8 -> 4 -> 2 -> 1, depth-first in the reference's order
+            int p3[2], p2[4], p1[8], a, b;
+            shell_split_tab(rc, p3[0], p3[1], sp, SILK_BLOB_shell3);
+            for (int h = 0; h < 2; h++) {
+                shell_split_tab(rc, p2[2 * h], p2[2 * h + 1], p3[h], SILK_BLOB_shell2);
+                for (int q = 0; q < 2; q++) {
+                    const int qi = 2 * h + q;
+                    shell_split_tab(rc, p1[2 * qi], p1[2 * qi + 1], p2[qi], SILK_BLOB_shell1);
+                    for (int e = 0; e < 2; e++) {
+                        const int ei = 2 * qi + e;
+                        shell_split_tab(rc, a, b, p1[ei], SILK_BLOB_shell0);
+                        p0[2 * ei] = (i16)a;
+                        p0[2 * ei + 1] = (i16)b;
+                    }
+                }
+            }
+        } else {
+            for (int j = 0; j < 16; j++) p0[j] = 0;
+        }
+    }
+    for (int i = 0; i < iter; i++) {
+        const int nLS = g_silk_blk[i][OG_LANE] >> 5;
+        if (nLS > 0) {
+            i16 *p = &pulses[i * 16];
+            for (int j = 0; j < 16; j++) {
+                i32 abs_q = p[j];
+                for (int b = 0; b < nLS; b++) {
+                    abs_q = shl32(abs_q, 1);
+                    abs_q += rc_icdf_tab(rc, SILK_BLOB_lsb_icdf);
+                }
+                p[j] = (i16)abs_q;
+            }
+        }
+    }
+    const int icdf_ptr = SILK_BLOB_sign_icdf + 7 * (quantOffsetType + (signalType << 1));
+    const int length = (frame_length + 8) >> 4;
+    for (int i = 0; i < length; i++) {
+        const int blk = g_silk_blk[i][OG_LANE];
+        // the reference tests sum_pulses[i] > 0 after OR-ing nLshifts << 5 into it (silk.cpp:966)
+        if (blk > 0) {
+            const u32 ic0 = g_silk_tab[icdf_ptr + OG_MIN(blk & 0x1F, 6)];
+            i16 *q = &pulses[i * 16];
+            i32 cur = q[0];
+            for (int j = 0; j < 16; j++) {
+                const i32 nxt = j < 15 ? q[j + 1] : 0; // requested one step ahead of its use
+                if (cur > 0) {
+                    // two-symbol iCDF {ic0, 0}, ftb 8
+                    u32 s = rc.rng, d = rc.val, r = s >> 8, t = s;
+                    int ret = 0;
+                    s = r * ic0;
+                    if (d < s) {
+                        t = s;
+                        s = 0;
+                        ret = 1;
+                    }
+                    rc.val = d - s;
+                    rc.rng = t - s;
+                    rc_renorm(rc);
+                    q[j] = (i16)(cur * ((ret << 1) - 1));
+                }
+                cur = nxt;
+            }
+        }
+    }
+}
+
+OG_DEV void silk_parse_stereo_pred(RcLane &rc, i32 pred_Q13[2]) { // silk_stereo_decode_pred silk.cpp:592
+    int n = rc_icdf_tab(rc, SILK_BLOB_stereo_joint_icdf);
+    const int ix02 = n / 5, ix12 = n - 5 * ix02;
+    int ix00 = rc_icdf_tab(rc, SILK_BLOB_uniform3_icdf);
+    const int ix01 = rc_icdf_tab(rc, SILK_BLOB_uniform5_icdf);
+    int ix10 = rc_icdf_tab(rc, SILK_BLOB_uniform3_icdf);
+    const int ix11 = rc_icdf_tab(rc, SILK_BLOB_uniform5_icdf);
+    ix00 += 3 * ix02;
+    ix10 += 3 * ix12;
+    {
+        const i32 low_Q13 = rom_silk_stereo_pred_q13[ix00];
+        const i32 step_Q13 = smulwb(rom_silk_stereo_pred_q13[ix00 + 1] - low_Q13, 6554);
+        pred_Q13[0] = smlabb(low_Q13, step_Q13, 2 * ix01 + 1);
+    }
+    {
+        const i32 low_Q13 = rom_silk_stereo_pred_q13[ix10];
+        const i32 step_Q13 = smulwb(rom_silk_stereo_pred_q13[ix10 + 1] - low_Q13, 6554);
+        pred_Q13[1] = smlabb(low_Q13, step_Q13, 2 * ix11 + 1);
+    }
+    pred_Q13[0] -= pred_Q13[1];
+}
+
+// The entropy half of one SILK-only or hybrid frame, lane-private (decode_frame_wave's head + silk_Decode's).
+// Reads the stream's state, writes only the record and the hand-off.
+OG_DEV void silk_parse_lane(const StreamState *st, const u8 *payload, int len, int mode, int bandwidth, int channels, SilkRec *rec,
+                            SilkHandoff *handoff) {
+    handoff->valid = 0;
+    if (len < 0 || len > 1275) {
+        rec->ret = BAD_ARG;
+        return;
+    }
+    int internal_hz = 16000;
+    if (mode == MODE_SILK) internal_hz = bandwidth == BW_NB ? 8000 : (bandwidth == BW_MB ? 12000 : 16000);
+    const int fs_kHz = (internal_hz >> 10) + 1;
+    if (fs_kHz != 8 && fs_kHz != 12 && fs_kHz != 16) {
+        rec->ret = INTERNAL_ERROR;
+        return;
+    }
+    const int frame_length = 20 * fs_kHz;
+    RcLane rc;
+    rc_lane_attach(rc, payload, (u32)len);
+    rc_init(rc, (u32)len);
+    // entropy-side state, as the wave kernel will see it after its own (re-)initialisations:
+    // silk_init_state on a CELT -> SILK/hybrid switch, channel 1 init when the packet adds a channel
+    const SilkState *s = &st->silk;
+    const int fresh_all = st->prev_mode == MODE_CELT, fresh_ch1 = channels > s->nChannelsInternal;
+    i32 ecType0 = fresh_all ? 0 : s->ch[0].ec_prevSignalType, ecLag0 = fresh_all ? 0 : s->ch[0].ec_prevLagIndex;
+    i32 ecType1 = (fresh_all || fresh_ch1) ? 0 : s->ch[1].ec_prevSignalType, ecLag1 = (fresh_all || fresh_ch1) ? 0 : s->ch[1].ec_prevLagIndex;
+    int vad0 = rc_bit_logp(rc, 1), lbrr0 = rc_bit_logp(rc, 1), vad1 = 0, lbrr1 = 0;
+    if (channels == 2) {
+        vad1 = rc_bit_logp(rc, 1);
+        lbrr1 = rc_bit_logp(rc, 1);
+    }
+    i32 MS_pred_Q13[2] = {0, 0};
+    int decode_only_middle = 0;
+    // regular decoding reads past the LBRR frames (silk.cpp:1590-1616); their content is discarded
+    if (lbrr0) {
+        if (channels == 2) {
+            silk_parse_stereo_pred(rc, MS_pred_Q13);
+            if (lbrr1 == 0) decode_only_middle = rc_icdf_tab(rc, SILK_BLOB_mid_only_icdf);
+        }
+        silk_parse_indices(rc, &rec->ch[0], fs_kHz, vad0, 1, 0, ecType0, ecLag0);
+        silk_parse_pulses(rc, rec->ch[0].pulses, rec->ch[0].signalType, rec->ch[0].quantOffsetType, frame_length);
+    }
+    if (channels == 2 && lbrr1) {
+        silk_parse_indices(rc, &rec->ch[1], fs_kHz, vad1, 1, 0, ecType1, ecLag1);
+        silk_parse_pulses(rc, rec->ch[1].pulses, rec->ch[1].signalType, rec->ch[1].quantOffsetType, frame_length);
+    }
+    if (channels == 2) {
+        silk_parse_stereo_pred(rc, MS_pred_Q13);
+        decode_only_middle = vad1 == 0 ? rc_icdf_tab(rc, SILK_BLOB_mid_only_icdf) : 0;
+    }
+    const int has_side = !decode_only_middle;
+    silk_parse_indices(rc, &rec->ch[0], fs_kHz, vad0, 0, 0, ecType0, ecLag0);
+    silk_parse_pulses(rc, rec->ch[0].pulses, rec->ch[0].signalType, rec->ch[0].quantOffsetType, frame_length);
+    if (channels == 2 && has_side) {
+        silk_parse_indices(rc, &rec->ch[1], fs_kHz, vad1, 0, 0, ecType1, ecLag1);
+        silk_parse_pulses(rc, rec->ch[1].pulses, rec->ch[1].signalType, rec->ch[1].quantOffsetType, frame_length);
+    }
+    rec->ch[0].ec_prevSignalType = ecType0;
+    rec->ch[0].ec_prevLagIndex = ecLag0;
+    rec->ch[1].ec_prevSignalType = ecType1;
+    rec->ch[1].ec_prevLagIndex = ecLag1;
+    rec->decode_only_middle = decode_only_middle;
+    rec->MS_pred_Q13[0] = MS_pred_Q13[0];
+    rec->MS_pred_Q13[1] = MS_pred_Q13[1];
+    rec->ret = 0;
+    // opus_decode_frame src/opus_decoder.cpp:218-221: hybrid redundancy flag, read and ignored (Q2)
+    if (rc_tell(rc) + 17 + 20 * (mode == MODE_HYBRID) <= 8 * len) {
+        if (mode == MODE_HYBRID) (void)rc_bit_logp(rc, 12);
+    }
+    handoff->storage = rc.storage; handoff->end_offs = rc.end_offs; handoff->end_window = rc.end_window;
+    handoff->nend_bits = rc.nend_bits; handoff->nbits_total = rc.nbits_total; handoff->offs = rc.offs;
+    handoff->rng = rc.rng; handoff->val = rc.val; handoff->ext = rc.ext; handoff->rem = rc.rem; handoff->error = rc.error;
+    handoff->valid = 1;
+}
+
+} // namespace og

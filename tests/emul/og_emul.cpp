@@ -18,11 +18,12 @@ int emu_decode_frame(void *stv, const uint8_t *payload, int len, int mode, int b
     og::StreamState *st = (og::StreamState *)stv;
     static og::ParseRec rec;
     static og::SilkHandoff handoff;
+    static og::SilkRec srec;
     const og::SilkHandoff *h = nullptr;
-    if (mode == og::MODE_SILK) return og::decode_frame_wave(st, payload, len, mode, bw, ch, pcm);
-    if (mode == og::MODE_HYBRID) {
-        handoff.valid = 0;
-        const int r = og::decode_frame_wave(st, payload, len, mode, bw, ch, pcm, &handoff);
+    if (mode != og::MODE_CELT) { // SILK entropy half per lane, then the frame-per-wave kernel from the record
+        og::silk_tables_load();
+        og::silk_parse_lane(st, payload, len, mode, bw, ch, &srec, &handoff);
+        const int r = og::decode_frame_wave(st, payload, len, mode, bw, ch, pcm, &handoff, &srec);
         if (r != og::CONTINUE_SPLIT) return r;
         h = &handoff;
     }

@@ -259,6 +259,17 @@ def build_text():
         t += emit(f"rom_bitrev{n}", "int16_t", digit_reversal(FFT_FACTORS[n], n), 20)
     for name, (ctype, vals) in SILK_TABLES.items():
         t += emit(name, ctype, vals, 16)
+    # Every 8-bit SILK table once more as ONE blob (+ offsets): the lane-per-frame SILK parse kernel copies it to LDS in
+    # one go and addresses tables as SILK_BLOB_<name> + index.
+    blob, offs = [], []
+    for name, (ctype, vals) in SILK_TABLES.items():
+        if ctype == "uint8_t":
+            offs.append((name[len("rom_silk_"):], len(blob)))
+            blob += list(vals)
+    if blob:
+        blob += [0] * ((-len(blob)) % 4)
+        t += "enum {\n" + "".join(f"    SILK_BLOB_{n} = {o},\n" for n, o in offs) + f"    SILK_BLOB_SIZE = {len(blob)}\n}};\n"
+        t += emit("rom_silk_u8_blob", "uint8_t", blob, 24).replace(f"[{len(blob) + ICDF_PAD}]", f"[{len(blob)}]")
     t += "#endif\n"
     return t
 
