@@ -72,6 +72,7 @@ __global__ void __launch_bounds__(64, 2) k_silk_parse(const FrameDesc *__restric
     const int mode = desc_mode(d.flags);
     if (d.stream < 0 || d.stream >= n_streams || mode == MODE_CELT) return;
     silk_parse_lane(&st[d.stream], arena + d.offset, d.len, mode, desc_bandwidth(d.flags), desc_channels(d.flags), &srecs[f], &handoff[f]);
+    silk_params_lane(&st[d.stream], mode, desc_bandwidth(d.flags), desc_channels(d.flags), &srecs[f]);
 }
 
 // Split CELT path, first half: ONE FRAME PER LANE.  Lane l of workgroup g parses frame 64 g + l (range decoder,

@@ -312,7 +312,31 @@ OG_DEV void silk_decode_pulses(Rc &rc, int ch, int signalType, int quantOffsetTy
 }
 
 // ---- NLSF decode and NLSF -> LPC ------------------------------------------------------------------------------
-OG_DEVN void silk_nlsf_stabilize(i16 *NLSF_Q15, const i32 *NDeltaMin_Q15, int Lo) { // silk.cpp:2676
+// The parameter-decoding functions below are written once against array views and a storage provider, and used in two
+// shapes: wave-uniform (arrays contiguous in the wave's SilkLds) and lane-private (one frame per lane in the parse
+// kernel, arrays laid out [element][lane] in LDS: og_silk_parse.hpp instantiates them with SilkParLane).
+template <class T, int STRIDE>
+struct ArrV {
+    T *p;
+    OG_MEMBER T &operator[](int i) const { return p[i * STRIDE]; }
+    OG_MEMBER ArrV at(int o) const { ArrV r = {p + o * STRIDE}; return r; }
+};
+struct SilkParWave {
+    typedef ArrV<i16, 1> A16;
+    typedef ArrV<i32, 1> A32;
+    static OG_MEMBER A16 nlsf() { A16 r = {SL().nlsf}; return r; }
+    static OG_MEMBER A16 nlsf0() { A16 r = {SL().nlsf0}; return r; }
+    static OG_MEMBER A16 res_Q10() { A16 r = {SL().res_Q10}; return r; }
+    static OG_MEMBER A32 pred_Q8() { A32 r = {SL().pred_Q8}; return r; }
+    static OG_MEMBER A32 cosLSF() { A32 r = {SL().cosLSF}; return r; }
+    static OG_MEMBER A32 P() { A32 r = {SL().P}; return r; }
+    static OG_MEMBER A32 Q() { A32 r = {SL().Q}; return r; }
+    static OG_MEMBER A32 a32() { A32 r = {SL().a32}; return r; }
+    static OG_MEMBER A32 Atmp() { A32 r = {SL().Atmp}; return r; }
+};
+
+template <class A16>
+OG_DEV void silk_nlsf_stabilize(A16 NLSF_Q15, const i32 *NDeltaMin_Q15, int Lo) { // silk.cpp:2676
     int I = 0;
     for (int loops = 0; loops < 20; loops++) {
         i32 min_diff = NLSF_Q15[0] - NDeltaMin_Q15[0], diff;
@@ -358,30 +382,40 @@ OG_DEVN void silk_nlsf_stabilize(i16 *NLSF_Q15, const i32 *NDeltaMin_Q15, int Lo
     for (int i = Lo - 2; i >= 0; i--) NLSF_Q15[i] = (i16)OG_MIN((i32)NLSF_Q15[i], NLSF_Q15[i + 1] - NDeltaMin_Q15[i + 1]);
 }
 
-OG_DEVN void silk_nlsf_decode(i16 *pNLSF_Q15, const i32 *NLSFIndices, const NlsfCb &cb) { // silk.cpp:2466, :2445
-    SilkLds &L = SL();
-    nlsf_unpack(cb, NLSFIndices[0]);
+template <class W>
+OG_DEV void silk_nlsf_decode(typename W::A16 pNLSF_Q15, const i32 *NLSFIndices, const NlsfCb &cb) { // silk.cpp:2466, :2445
+    const typename W::A16 res_Q10 = W::res_Q10();
+    const typename W::A32 pred_Q8 = W::pred_Q8();
+    { // silk_NLSF_unpack silk.cpp:2762 (the predictor weights; the entropy tables belong to the parse)
+        const u8 *sel = &cb.ec_sel[NLSFIndices[0] * cb.order / 2];
+        for (int i = 0; i < cb.order; i += 2) {
+            const int entry = *sel++;
+            pred_Q8[i] = cb.pred_Q8[i + (entry & 1) * (cb.order - 1)];
+            pred_Q8[i + 1] = cb.pred_Q8[i + ((entry >> 4) & 1) * (cb.order - 1) + 1];
+        }
+    }
     i32 out_Q10 = 0;
     for (int i = cb.order - 1; i >= 0; i--) {
-        i32 pred_Q10 = smulbb(out_Q10, L.pred_Q8[i]) >> 8;
+        i32 pred_Q10 = smulbb(out_Q10, pred_Q8[i]) >> 8;
         out_Q10 = shl32(NLSFIndices[1 + i], 10);
         if (out_Q10 > 0)
             out_Q10 -= 102;
         else if (out_Q10 < 0)
             out_Q10 += 102;
         out_Q10 = smlawb(pred_Q10, out_Q10, cb.quantStepSize_Q16);
-        L.res_Q10[i] = (i16)out_Q10;
+        res_Q10[i] = (i16)out_Q10;
     }
     const u8 *pCB = &cb.CB1_NLSF_Q8[NLSFIndices[0] * cb.order];
     const i32 *pW = &cb.CB1_Wght_Q9[NLSFIndices[0] * cb.order];
     for (int i = 0; i < cb.order; i++) {
-        i32 t = shl32((i32)L.res_Q10[i], 14) / (i32)pW[i] + shl32((i32)pCB[i], 7);
+        i32 t = shl32((i32)res_Q10[i], 14) / (i32)pW[i] + shl32((i32)pCB[i], 7);
         pNLSF_Q15[i] = (i16)limit32(t, 0, 32767);
     }
     silk_nlsf_stabilize(pNLSF_Q15, cb.deltaMin_Q15, cb.order);
 }
 
-OG_DEV void silk_bwexpander_32(i32 *ar, int d, i32 chirp_Q16) { // silk.cpp:561
+template <class A32>
+OG_DEV void silk_bwexpander_32(A32 ar, int d, i32 chirp_Q16) { // silk.cpp:561
     const i32 chirp_minus_one_Q16 = chirp_Q16 - 65536;
     for (int i = 0; i < d - 1; i++) {
         ar[i] = smulww(chirp_Q16, ar[i]);
@@ -390,8 +424,9 @@ OG_DEV void silk_bwexpander_32(i32 *ar, int d, i32 chirp_Q16) { // silk.cpp:561
     ar[d - 1] = smulww(chirp_Q16, ar[d - 1]);
 }
 
-OG_DEVN i32 silk_inverse_pred_gain(const i16 *A_Q12, int order) { // silk.cpp:2425 + :2359
-    i32 *A = SL().Atmp;
+template <class W, class AQ>
+OG_DEV i32 silk_inverse_pred_gain(AQ A_Q12, int order) { // silk.cpp:2425 + :2359
+    const typename W::A32 A = W::Atmp();
     const i32 A_LIMIT = 16773022, MIN_INVGAIN = 107374;
     i32 DC_resp = 0;
     for (int k = 0; k < order; k++) {
@@ -427,7 +462,8 @@ OG_DEVN i32 silk_inverse_pred_gain(const i16 *A_Q12, int order) { // silk.cpp:24
     return invGain_Q30;
 }
 
-OG_DEV void silk_find_poly(i32 *out, const i32 *cLSF, int dd) { // silk.cpp:626
+template <class A32>
+OG_DEV void silk_find_poly(A32 out, A32 cLSF, int dd) { // silk.cpp:626
     out[0] = 1 << 16;
     out[1] = -cLSF[0];
     for (int k = 1; k < dd; k++) {
@@ -438,8 +474,9 @@ OG_DEV void silk_find_poly(i32 *out, const i32 *cLSF, int dd) { // silk.cpp:626
     }
 }
 
-OG_DEVN void silk_nlsf2a(i16 *a_Q12, const i16 *NLSF, int d) { // silk.cpp:642
-    SilkLds &L = SL();
+template <class W, class AQ>
+OG_DEV void silk_nlsf2a(AQ a_Q12, typename W::A16 NLSF, int d) { // silk.cpp:642
+    struct { typename W::A32 cosLSF, P, Q, a32; } L = {W::cosLSF(), W::P(), W::Q(), W::a32()};
     // ordering16 = {0,15,8,7,4,11,12,3,2,13,10,5,6,9,14,1}; ordering10 = {0,9,6,3,4,5,8,1,2,7}: one nibble each
     const u64 ord16 = 0x1E965AD23CB478F0ULL; // nibbles (k=0..15): 0,15,8,7,4,11,12,3,2,13,10,5,6,9,14,1
     const u64 o10 = 0x0000007218543690ULL;   // nibbles (k=0..9): 0,9,6,3,4,5,8,1,2,7
@@ -450,8 +487,8 @@ OG_DEVN void silk_nlsf2a(i16 *a_Q12, const i16 *NLSF, int d) { // silk.cpp:642
         L.cosLSF[o] = rshift_round(shl32(cos_val, 8) + delta * f_frac, 4);
     }
     const int dd = d >> 1;
-    silk_find_poly(L.P, &L.cosLSF[0], dd);
-    silk_find_poly(L.Q, &L.cosLSF[1], dd);
+    silk_find_poly(L.P, L.cosLSF, dd);
+    silk_find_poly(L.Q, L.cosLSF.at(1), dd);
     for (int k = 0; k < dd; k++) {
         const i32 Ptmp = L.P[k + 1] + L.P[k], Qtmp = L.Q[k + 1] - L.Q[k];
         L.a32[k] = -Qtmp - Ptmp;
@@ -485,16 +522,20 @@ OG_DEVN void silk_nlsf2a(i16 *a_Q12, const i16 *NLSF, int d) { // silk.cpp:642
             for (int k = 0; k < d; k++) a_Q12[k] = (i16)rshift_round(L.a32[k], 5);
         }
     }
-    for (int i = 0; silk_inverse_pred_gain(a_Q12, d) == 0 && i < 16; i++) {
+    for (int i = 0; silk_inverse_pred_gain<W>(a_Q12, d) == 0 && i < 16; i++) {
         silk_bwexpander_32(L.a32, d, 65536 - shl32(2, i));
         for (int k = 0; k < d; k++) a_Q12[k] = (i16)rshift_round(L.a32[k], 5);
     }
 }
 
 // silk_decode_parameters silk.cpp:827 (+ silk_gains_dequant :2148, silk_decode_pitch :2055)
-OG_DEVN void silk_decode_parameters(SilkChannel *c, SilkCtrl &k, int fs_kHz, int condCoding, i32 &LastGainIndex,
-                                    int first_frame_after_reset) {
-    SilkLds &L = SL();
+// `k`: the frame's indices in, dequantised parameters out (SilkCtrl in LDS, or the record's SilkRecCh in HBM).  The
+// stabilised NLSFs are left in W::nlsf() for the caller to store as the next frame's prevNLSF.
+template <class W, class K>
+OG_DEV void silk_decode_parameters(const i16 *prevNLSF_Q15, K &k, int fs_kHz, int condCoding, i32 &LastGainIndex,
+                                   int first_frame_after_reset) {
+    typedef ArrV<i16, 1> AQ;
+    struct { typename W::A16 nlsf, nlsf0; } L = {W::nlsf(), W::nlsf0()};
     const int order = fs_kHz == 16 ? 16 : 10;
     const NlsfCb cb = nlsf_cb(fs_kHz == 16);
     for (int j = 0; j < 4; j++) {
@@ -511,21 +552,18 @@ OG_DEVN void silk_decode_parameters(SilkChannel *c, SilkCtrl &k, int fs_kHz, int
         LastGainIndex = prev;
         k.Gains_Q16[j] = silk_log2lin(OG_MIN(smulwb(1907825, prev) + 2090, 3967));
     }
-    silk_nlsf_decode(L.nlsf, k.NLSFIndices, cb);
-    silk_nlsf2a(k.PredCoef_Q12[1], L.nlsf, order);
+    silk_nlsf_decode<W>(L.nlsf, k.NLSFIndices, cb);
+    { AQ a1 = {k.PredCoef_Q12[1]}; silk_nlsf2a<W>(a1, L.nlsf, order); }
     if (first_frame_after_reset == 1) k.NLSFInterpCoef_Q2 = 4;
     if (k.NLSFInterpCoef_Q2 < 4) {
         for (int i = 0; i < order; i++) {
-            const i32 pv = c->prevNLSF_Q15[i];
+            const i32 pv = prevNLSF_Q15[i];
             L.nlsf0[i] = (i16)(pv + ((k.NLSFInterpCoef_Q2 * ((i32)L.nlsf[i] - pv)) >> 2));
         }
-        silk_nlsf2a(k.PredCoef_Q12[0], L.nlsf0, order);
+        { AQ a0 = {k.PredCoef_Q12[0]}; silk_nlsf2a<W>(a0, L.nlsf0, order); }
     } else {
         for (int i = 0; i < order; i++) k.PredCoef_Q12[0][i] = k.PredCoef_Q12[1][i];
     }
-    OG_SYNC();
-    OG_FOR_LANES(i, order) c->prevNLSF_Q15[i] = L.nlsf[i];
-    OG_SYNC();
     if (k.signalType == 2) {
         const i8 *cbk = k.PERIndex == 0 ? rom_silk_ltp_vq0 : (k.PERIndex == 1 ? rom_silk_ltp_vq1 : rom_silk_ltp_vq2);
         const i8 *lagcb = fs_kHz == 8 ? rom_silk_lags_stage2 : rom_silk_lags_stage3;
@@ -541,6 +579,59 @@ OG_DEVN void silk_decode_parameters(SilkChannel *c, SilkCtrl &k, int fs_kHz, int
         for (int j = 0; j < 20; j++) k.LTPCoef_Q14[j] = 0;
         k.PERIndex = 0;
         k.LTP_scale_Q14 = 0;
+    }
+}
+
+// ---- lane-private parameter decoding for the parse kernel ----------------------------------------------------------
+struct SilkParLds { // [element][lane]
+    i16 nlsf[SILK_MAX_LPC][OG_NLANES], nlsf0[SILK_MAX_LPC][OG_NLANES], res_Q10[SILK_MAX_LPC][OG_NLANES];
+    i32 pred_Q8[SILK_MAX_LPC][OG_NLANES], cosLSF[SILK_MAX_LPC][OG_NLANES], P[SILK_MAX_LPC / 2 + 1][OG_NLANES],
+        Q[SILK_MAX_LPC / 2 + 1][OG_NLANES], a32[SILK_MAX_LPC][OG_NLANES], Atmp[SILK_MAX_LPC][OG_NLANES];
+};
+OG_LDS SilkParLds g_silk_par;
+struct SilkParLane {
+    typedef ArrV<i16, OG_NLANES> A16;
+    typedef ArrV<i32, OG_NLANES> A32;
+    static OG_MEMBER A16 nlsf() { A16 r = {&g_silk_par.nlsf[0][OG_LANE]}; return r; }
+    static OG_MEMBER A16 nlsf0() { A16 r = {&g_silk_par.nlsf0[0][OG_LANE]}; return r; }
+    static OG_MEMBER A16 res_Q10() { A16 r = {&g_silk_par.res_Q10[0][OG_LANE]}; return r; }
+    static OG_MEMBER A32 pred_Q8() { A32 r = {&g_silk_par.pred_Q8[0][OG_LANE]}; return r; }
+    static OG_MEMBER A32 cosLSF() { A32 r = {&g_silk_par.cosLSF[0][OG_LANE]}; return r; }
+    static OG_MEMBER A32 P() { A32 r = {&g_silk_par.P[0][OG_LANE]}; return r; }
+    static OG_MEMBER A32 Q() { A32 r = {&g_silk_par.Q[0][OG_LANE]}; return r; }
+    static OG_MEMBER A32 a32() { A32 r = {&g_silk_par.a32[0][OG_LANE]}; return r; }
+    static OG_MEMBER A32 Atmp() { A32 r = {&g_silk_par.Atmp[0][OG_LANE]}; return r; }
+};
+static_assert(sizeof(SilkCtrl) == 4 * (SILK_REC_CTRL_WORDS + 1), "SilkRecCh mirrors SilkCtrl");
+
+// Second half of the parse kernel's lane: silk_decode_parameters for the coded channels, from the indices just
+// written to the record.  The inputs that live in the stream state (LastGainIndex, first_frame_after_reset, previous
+// NLSFs) are taken as the wave kernel will see them after its own (re-)initialisations: decoder init on a CELT ->
+// SILK/hybrid switch, channel 1 init when the packet adds a channel, silk_decoder_set_fs on a rate change, side-channel
+// restart after a mid-only frame (silk.cpp:1639).  Nothing but the record is written.
+OG_DEV void silk_params_lane(const StreamState *st, int mode, int bandwidth, int channels, SilkRec *rec) {
+    if (rec->ret < 0) return;
+    int internal_hz = 16000;
+    if (mode == MODE_SILK) internal_hz = bandwidth == BW_NB ? 8000 : (bandwidth == BW_MB ? 12000 : 16000);
+    const int fs_kHz = (internal_hz >> 10) + 1, order = fs_kHz == 16 ? 16 : 10;
+    const SilkState *s = &st->silk;
+    const int fresh_all = st->prev_mode == MODE_CELT, fresh_ch1 = channels > s->nChannelsInternal;
+    const int prev_dom = fresh_all ? 0 : s->prev_decode_only_middle, dom = rec->decode_only_middle;
+    for (int n = 0; n < channels; n++) {
+        if (n == 1 && dom) continue; // no side channel this frame
+        const SilkChannel *c = &s->ch[n];
+        const int fresh = fresh_all || (n == 1 && fresh_ch1), changed = fresh || c->fs_kHz != fs_kHz;
+        i32 lastGain = changed ? 10 : c->LastGainIndex;
+        int ffar = changed ? 1 : c->first_frame_after_reset;
+        if (n == 1 && channels == 2 && dom == 0 && prev_dom == 1) {
+            lastGain = 10;
+            ffar = 1;
+        }
+        SilkRecCh &k = rec->ch[n];
+        silk_decode_parameters<SilkParLane>(c->prevNLSF_Q15, k, fs_kHz, 0, lastGain, ffar);
+        k.LastGainIndex = lastGain;
+        const SilkParLane::A16 nl = SilkParLane::nlsf();
+        for (int i = 0; i < order; i++) k.nlsf[i] = nl[i];
     }
 }
 
@@ -798,11 +889,13 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz,
             // FrameIndex = nFramesDecoded - n = -n <= 0 -> independent coding (silk.cpp:1678-1681)
             const int condCoding = 0;
             OG_MARK(30);
-            if (rec) { // indices (33 words, same order as SilkCtrl's index block) and pulses from the record
+            if (rec) { // parameters + indices (68 words laid out like SilkCtrl) and pulses from the record
                 OG_SYNC();
-                const i32 *src = &rec->ch[n].signalType;
-                i32 *dst = &L.ctrl[n].signalType;
-                OG_FOR_LANES(i, 8 + 4 + 4 + SILK_MAX_LPC + 1) dst[i] = src[i];
+                const i32 *src = rec->ch[n].pitchL;
+                i32 *dst = L.ctrl[n].pitchL;
+                OG_FOR_LANES(i, SILK_REC_CTRL_WORDS) dst[i] = src[i];
+                OG_FOR_LANES(i, SILK_MAX_LPC) L.nlsf[i] = rec->ch[n].nlsf[i];
+                lastGain[n] = OG_UNI(rec->ch[n].LastGainIndex);
                 const u32 *ps = reinterpret_cast<const u32 *>(rec->ch[n].pulses);
                 u32 *pd = reinterpret_cast<u32 *>(L.pulses[n]);
                 OG_FOR_LANES(i, (frame_length + 16) / 2) pd[i] = ps[i];
@@ -813,7 +906,10 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz,
             silk_decode_pulses(rc, n, L.ctrl[n].signalType, L.ctrl[n].quantOffsetType, frame_length);
             }
             OG_MARK(32);
-            silk_decode_parameters(&s->ch[n], L.ctrl[n], fs_kHz, condCoding, lastGain[n], ffar[n]);
+            if (!rec) silk_decode_parameters<SilkParWave>(s->ch[n].prevNLSF_Q15, L.ctrl[n], fs_kHz, condCoding, lastGain[n], ffar[n]);
+            OG_SYNC();
+            OG_FOR_LANES(i, fs_kHz == 16 ? 16 : 10) s->ch[n].prevNLSF_Q15[i] = L.nlsf[i];
+            OG_SYNC();
             OG_MARK(33);
         }
     }

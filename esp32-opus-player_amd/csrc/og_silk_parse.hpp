@@ -19,13 +19,21 @@ namespace og {
 constexpr int SILK_REC_LPC = 16, SILK_REC_FRAME = 320;
 
 struct SilkRecCh {
-    // same order as SilkCtrl's index block (signalType .. NLSFIndices): copied as 33 words
+    // the first 68 words mirror SilkCtrl (og_silk.hpp) so the wave kernel takes them over with one copy:
+    // dequantised parameters (silk_params_lane), then the indices (silk_parse_indices)
+    i32 pitchL[4], Gains_Q16[4];
+    i16 PredCoef_Q12[2][SILK_REC_LPC];
+    i16 LTPCoef_Q14[20];
+    i32 LTP_scale_Q14;
     i32 signalType, quantOffsetType, NLSFInterpCoef_Q2, Seed, lagIndex, contourIndex, PERIndex, LTP_scaleIndex;
     i32 GainsIndices[4], LTPIndex[4], NLSFIndices[SILK_REC_LPC + 1];
-    i32 ec_prevSignalType, ec_prevLagIndex; // entropy-side state after the frame (written back by the wave kernel)
+    // state after the frame, written back by the wave kernel
+    i32 ec_prevSignalType, ec_prevLagIndex, LastGainIndex;
     i32 pad;
+    i16 nlsf[SILK_REC_LPC]; // stabilised NLSFs of this frame (the next frame's prevNLSF_Q15)
     i16 pulses[SILK_REC_FRAME + 16];
 };
+constexpr int SILK_REC_CTRL_WORDS = 4 + 4 + SILK_REC_LPC + 10 + 1 + 8 + 4 + 4 + SILK_REC_LPC + 1;
 struct SilkRec {
     i32 ret; // 0, or the negative code the frame ends with (then nothing else is valid)
     i32 decode_only_middle;

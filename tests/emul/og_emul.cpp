@@ -23,6 +23,7 @@ int emu_decode_frame(void *stv, const uint8_t *payload, int len, int mode, int b
     if (mode != og::MODE_CELT) { // SILK entropy half per lane, then the frame-per-wave kernel from the record
         og::silk_tables_load();
         og::silk_parse_lane(st, payload, len, mode, bw, ch, &srec, &handoff);
+        og::silk_params_lane(st, mode, bw, ch, &srec);
         const int r = og::decode_frame_wave(st, payload, len, mode, bw, ch, pcm, &handoff, &srec);
         if (r != og::CONTINUE_SPLIT) return r;
         h = &handoff;
