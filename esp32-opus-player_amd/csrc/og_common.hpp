@@ -150,7 +150,15 @@ OG_DEV u32 udiv(u32 n, u32 d) { return n / d; }                                 
 static constexpr i32 SIG_SAT = 300000000; // celt.h:234
 
 // ---- SILK flavour (src/silk.h) -------------------------------------------------------------------
+#if defined(OG_HOST_EMUL) || defined(OG_MUL64)
 OG_DEV i32 smulwb(i32 a, i32 b) { return (i32)(((i64)a * (i64)(i16)b) >> 16); }      // silk_SMULWB :447
+#else
+// (a * (i16)b) >> 16 with a = ah * 65536 + al (al unsigned 16 bit): ah * b + ((al * b) >> 16), exact, two 24-bit multiplies
+OG_DEV i32 smulwb(i32 a, i32 b) {                                                    // silk_SMULWB :447
+    const i32 bs = (i32)(i16)b;
+    return __mul24(a >> 16, bs) + (__mul24((i32)((u32)a & 0xffffu), bs) >> 16);
+}
+#endif
 OG_DEV i32 smlawb(i32 acc, i32 a, i32 b) { return addw(acc, smulwb(a, b)); }         // silk_SMLAWB :450
 OG_DEV i32 smulww(i32 a, i32 b) { return (i32)(((i64)a * (i64)b) >> 16); }           // silk_SMULWW :474
 OG_DEV i32 smulbb(i32 a, i32 b) { return (i32)(i16)a * (i32)(i16)b; }                // silk_SMULBB :459

@@ -732,6 +732,130 @@ OG_DEVN void silk_decode_core_lane(SilkChannel *c, int ch, int fs_kHz) {
     c->first_frame_after_reset = 0;
 }
 
+#ifndef OG_HOST_EMUL
+// The same synthesis with one 16-lane ROW per channel (row 0 = channel 0, row 1 = channel 1; wave64 = 4 DPP rows).
+// The order-10/16 LPC recurrence is a chain of 16 dependent multiply-adds per sample when one lane runs it; here lane j
+// of the row keeps state sample (i-1-j) and coefficient j, the prediction is one multiply plus a 4-step DPP row
+// all-reduce, and the state shifts by one lane per sample (row_shr:1).  Everything else (excitation, LTP, gains) is
+// computed redundantly by the 16 lanes of the row; the re-whitening FIR and the LTP-state scaling are spread over them.
+// Must be entered by all 64 lanes.  Same arithmetic as silk_decode_core_lane (silk_decode_core silk.cpp:1806).
+#define OG_ROW_SYNC()                                                   \
+    do {                                                                \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          \
+        __builtin_amdgcn_wave_barrier();                                \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          \
+    } while (0)
+OG_DEV i32 row_sum16(i32 v) { // sum over the 16 lanes of a DPP row, result in every lane of the row
+    v += OG_DPP_ROR(v, 8);
+    v += OG_DPP_ROR(v, 4);
+    v += OG_DPP_ROR(v, 2);
+    v += OG_DPP_ROR(v, 1);
+    return v;
+}
+OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels) {
+    SilkLds &L = SL();
+    const int row = OG_LANE >> 4, j = OG_LANE & 15;
+    if (row >= channels) return;
+    const int ch = row;
+    const int order = fs_kHz == 16 ? 16 : 10, subfr = 5 * fs_kHz, ltp_mem = 20 * fs_kHz, frame_length = 4 * subfr;
+    i16 *xq = &L.xq[ch][2];
+    if (!L.ctrl[ch].coded) {
+        for (int i = j; i < frame_length; i += 16) xq[i] = 0;
+        return;
+    }
+    SilkChannel *c = &st->ch[ch];
+    const SilkCtrl &k = L.ctrl[ch];
+    const i16 *pulses = L.pulses[ch];
+    i32 *sLTP_Q15 = L.sLTP_Q15[ch];
+    i16 *sLTP = L.sLTP[ch];
+    const i32 offset_Q10 = rom_silk_quant_offsets_q10[(k.signalType >> 1) * 2 + k.quantOffsetType];
+    const int interp_flag = k.NLSFInterpCoef_Q2 < 4, voiced = k.signalType == 2;
+    i32 sLPC = c->sLPC_Q14_buf[SILK_MAX_LPC - 1 - j]; // state sample (i-1-j)
+    i32 rand_seed = k.Seed;
+    i32 prev_gain_Q16 = c->prev_gain_Q16;
+    int sLTP_buf_idx = ltp_mem, lag = 0, pos = 0;
+    for (int sf = 0; sf < 4; sf++) {
+        const i16 *A_Q12 = k.PredCoef_Q12[sf >> 1];
+        const i16 *B_Q14 = &k.LTPCoef_Q14[sf * 5];
+        const i32 A_j = j < order ? (i32)A_Q12[j] : 0;
+        const i32 Gain_Q16 = k.Gains_Q16[sf], Gain_Q10 = Gain_Q16 >> 6;
+        i32 inv_gain_Q31 = silk_inverse32_varQ(Gain_Q16, 47), gain_adj_Q16;
+        if (Gain_Q16 != prev_gain_Q16) {
+            gain_adj_Q16 = silk_div32_varQ(prev_gain_Q16, Gain_Q16, 16);
+            sLPC = smulww(gain_adj_Q16, sLPC);
+        } else
+            gain_adj_Q16 = 1 << 16;
+        prev_gain_Q16 = Gain_Q16;
+        if (voiced) {
+            lag = k.pitchL[sf];
+            if (sf == 0 || (sf == 2 && interp_flag)) { // re-whitening: a FIR, one output per lane and step
+                const int start_idx = ltp_mem - lag - order - 2;
+                i16 *hist = L.hist[ch];
+                if (sf == 2) {
+                    for (int i = j; i < 2 * subfr; i += 16) hist[ltp_mem + i] = xq[i];
+                    OG_ROW_SYNC();
+                }
+                const i16 *in = &hist[start_idx + sf * subfr];
+                for (int ix = order + j; ix < ltp_mem - start_idx; ix += 16) {
+                    i32 acc = 0;
+                    for (int t = 0; t < order; t++) acc = smlabb(acc, in[ix - 1 - t], A_Q12[t]);
+                    sLTP[start_idx + ix] = (i16)sat16(rshift_round(subw(shl32((i32)in[ix], 12), acc), 12));
+                }
+                if (j < order) sLTP[start_idx + j] = 0;
+                if (sf == 0) inv_gain_Q31 = shl32(smulwb(inv_gain_Q31, k.LTP_scale_Q14), 2);
+                OG_ROW_SYNC();
+                for (int i = j; i < lag + 2; i += 16) sLTP_Q15[sLTP_buf_idx - i - 1] = smulwb(inv_gain_Q31, sLTP[ltp_mem - i - 1]);
+                OG_ROW_SYNC();
+            } else if (gain_adj_Q16 != 1 << 16) {
+                for (int i = j; i < lag + 2; i += 16) sLTP_Q15[sLTP_buf_idx - i - 1] = smulww(gain_adj_Q16, sLTP_Q15[sLTP_buf_idx - i - 1]);
+                OG_ROW_SYNC();
+            }
+        }
+        for (int i = 0; i < subfr; i++) {
+            // excitation (silk.cpp:1826-1835), identical in the 16 lanes of the row
+            rand_seed = (i32)(907633515u + (u32)rand_seed * 196314165u);
+            const i32 pl = pulses[pos + i];
+            i32 exc = shl32(pl, 14);
+            if (exc > 0)
+                exc -= 80 << 4;
+            else if (exc < 0)
+                exc += 80 << 4;
+            exc += offset_Q10 << 4;
+            if (rand_seed < 0) exc = -exc;
+            rand_seed = addw(rand_seed, pl);
+            i32 res = exc;
+            if (voiced) {
+                const i32 *p = &sLTP_Q15[sLTP_buf_idx - lag + 2];
+                i32 LTP_pred_Q13 = 2;
+                LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[0], B_Q14[0]);
+                LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[-1], B_Q14[1]);
+                LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[-2], B_Q14[2]);
+                LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[-3], B_Q14[3]);
+                LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[-4], B_Q14[4]);
+                res = addw(exc, shl32(LTP_pred_Q13, 1));
+                if (j == 0) sLTP_Q15[sLTP_buf_idx] = shl32(res, 1);
+                sLTP_buf_idx++;
+            }
+            // silk_SMLAWB wraps (ADD32_ovflw): the order of the 16 additions does not matter
+            const i32 LPC_pred_Q10 = addw(order >> 1, row_sum16(smulwb(sLPC, A_j)));
+            const i32 s = add_sat32(res, lshift_sat32(LPC_pred_Q10, 4));
+            const i32 shifted = __builtin_amdgcn_update_dpp(0, sLPC, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+            sLPC = j == 0 ? s : shifted;
+            if (j == 0) xq[pos + i] = (i16)sat16(rshift_round(smulww(s, Gain_Q10), 8));
+        }
+        pos += subfr;
+        if (voiced) OG_ROW_SYNC(); // this subframe's sLTP_Q15 / xq writes before the next subframe's reads
+    }
+    c->sLPC_Q14_buf[SILK_MAX_LPC - 1 - j] = sLPC;
+    if (j == 0) {
+        c->prev_gain_Q16 = prev_gain_Q16;
+        c->lagPrev = k.pitchL[3];
+        c->prevSignalType = k.signalType;
+        c->first_frame_after_reset = 0;
+    }
+}
+#endif
+
 // 2x all-pass up-sampler for one channel, one lane (silk_resampler_private_up2_HQ silk.cpp:3515); the input
 // stream is [delayBuf (inputDelay old samples) | in[0 .. inLen - inputDelay)] (silk_resampler silk.cpp:3676)
 OG_DEVN void silk_up2_lane(SilkChannel *c, int ch, int inLen) {
@@ -928,12 +1052,16 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz,
     for (int n = 0; n < channels; n++)
         if (L.ctrl[n].coded) OG_FOR_LANES(i, frame_length) L.hist[n][i] = s->ch[n].outBuf[i];
     OG_SYNC();
+#ifdef OG_HOST_EMUL
     OG_FOR_LANES(n, channels) {
         if (L.ctrl[n].coded)
             silk_decode_core_lane(&s->ch[n], n, fs_kHz);
         else
             for (int i = 0; i < frame_length; i++) L.xq[n][2 + i] = 0;
     }
+#else
+    silk_decode_core_rows(s, fs_kHz, channels);
+#endif
     OG_SYNC();
     OG_MARK(35);
     // outBuf update (silk.cpp:2031-2034): ltp_mem_length == frame_length, so the history is exactly this frame
