@@ -914,6 +914,49 @@ OG_DEV void silk_set_fs(SilkChannel *c, int fs_kHz) {
     OG_SYNC();
 }
 
+#ifndef OG_HOST_EMUL
+// The same up-sampler as a systolic array: per channel (one 16-lane row each) the two output phases are two cascades of
+// three first-order all-pass sections; lane (phase, section) owns one section's state, takes its input from the lane
+// before it (row_shr:1, the previous step's output) and works on sample t = step - section.  inLen + 2 steps of one
+// section each instead of inLen steps of six.  Must be entered by all 64 lanes.
+OG_DEV void silk_up2_rows(SilkState *st, int channels, int inLen) {
+    SilkLds &L = SL();
+    const int row = OG_LANE >> 4, j = OG_LANE & 15;
+    if (row >= channels) return;
+    SilkChannel *c = &st->ch[row];
+    const i16 *in = &L.xq[row][1];
+    i16 *up = L.up[row];
+    const int delay = c->rs_inputDelay;
+    if (j < 8) up[j] = c->rs_sFIR[j];
+    if (j < 6) {
+        const int ph = j >= 3, sec = j - 3 * ph;
+        const i32 coef = ph ? rom_silk_up2_hq1[sec] : rom_silk_up2_hq0[sec];
+        i32 S = c->rs_sIIR[j], out = 0;
+        for (int u = 0; u < inLen + 2; u++) {
+            const i32 prev_out = __builtin_amdgcn_update_dpp(0, out, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+            const int t = u - sec;
+            if (t >= 0 && t < inLen) {
+                i32 v;
+                if (sec == 0) {
+                    const i32 x = t < delay ? (i32)c->rs_delayBuf[t] : (i32)in[t - delay];
+                    v = shl32(x, 10);
+                } else
+                    v = prev_out;
+                const i32 Y = v - S;
+                const i32 X = sec == 2 ? smlawb(Y, Y, coef) : smulwb(Y, coef);
+                out = S + X;
+                S = v + X;
+                if (sec == 2) up[8 + 2 * t + ph] = (i16)sat16(rshift_round(out, 10));
+            }
+        }
+        c->rs_sIIR[j] = S;
+    }
+    OG_ROW_SYNC();
+    if (j < 8) c->rs_sFIR[j] = up[2 * inLen + j];
+    if (j < delay) c->rs_delayBuf[j] = in[inLen - delay + j];
+}
+#endif
+
 OG_DEV void silk_stereo_decode_pred(Rc &rc, i32 pred_Q13[2]) { // silk.cpp:592
     int ix[2][3];
     int n = rc_icdf(rc, rom_silk_stereo_joint_icdf, 8);
@@ -1112,9 +1155,13 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz,
         }
         OG_SYNC();
     }
-    // ---- resample to 48 kHz: serial 2x all-pass per channel, then lane-parallel FIR interpolation
+    // ---- resample to 48 kHz: 2x all-pass per channel (serial in time), then lane-parallel FIR interpolation
     OG_MARK(36);
+#ifdef OG_HOST_EMUL
     OG_FOR_LANES(n, channels) silk_up2_lane(&s->ch[n], n, frame_length);
+#else
+    silk_up2_rows(s, channels, frame_length);
+#endif
     OG_SYNC();
     OG_MARK(37);
     {
