@@ -928,26 +928,26 @@ OG_DEV void silk_up2_rows(SilkState *st, int channels, int inLen) {
     i16 *up = L.up[row];
     const int delay = c->rs_inputDelay;
     if (j < 8) up[j] = c->rs_sFIR[j];
+    // the input stream [delayBuf | in] as 32-bit Q10 values, staged once (the sLTP_Q15 row of this channel is free by now)
+    i32 *in32 = L.sLTP_Q15[row];
+    for (int t = j; t < inLen; t += 16) in32[t] = shl32(t < delay ? (i32)c->rs_delayBuf[t] : (i32)in[t - delay], 10);
+    OG_ROW_SYNC();
     if (j < 6) {
         const int ph = j >= 3, sec = j - 3 * ph;
         const i32 coef = ph ? rom_silk_up2_hq1[sec] : rom_silk_up2_hq0[sec];
         i32 S = c->rs_sIIR[j], out = 0;
-        for (int u = 0; u < inLen + 2; u++) {
+        i16 *dst = &up[8 + ph];
+        for (int u = 0; u < inLen + 2; u++) { // branch-free body: every lane runs one section step, results kept if t is in range
             const i32 prev_out = __builtin_amdgcn_update_dpp(0, out, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
             const int t = u - sec;
-            if (t >= 0 && t < inLen) {
-                i32 v;
-                if (sec == 0) {
-                    const i32 x = t < delay ? (i32)c->rs_delayBuf[t] : (i32)in[t - delay];
-                    v = shl32(x, 10);
-                } else
-                    v = prev_out;
-                const i32 Y = v - S;
-                const i32 X = sec == 2 ? smlawb(Y, Y, coef) : smulwb(Y, coef);
-                out = S + X;
-                S = v + X;
-                if (sec == 2) up[8 + 2 * t + ph] = (i16)sat16(rshift_round(out, 10));
-            }
+            const bool live = (unsigned)t < (unsigned)inLen;
+            const i32 v = sec == 0 ? in32[live ? t : 0] : prev_out;
+            const i32 Y = v - S;
+            const i32 X = smulwb(Y, coef) + (sec == 2 ? Y : 0);
+            const i32 o = S + X;
+            out = live ? o : out;
+            S = live ? v + X : S;
+            if (live && sec == 2) dst[2 * t] = (i16)sat16(rshift_round(o, 10));
         }
         c->rs_sIIR[j] = S;
     }
