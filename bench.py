@@ -168,9 +168,16 @@ def main():
                 tj = json.load(fh)
             if tj.get("frames_per_launch") == n:
                 traffic = tj["hbm_bytes_per_step"]
-        celt_split = args.workload.startswith("celt") and os.environ.get("OPUSGPU_SPLIT", "1") != "0"
-        kernel_name = ("decode step = k_celt_parse + k_celt_recon + k_celt_post (launched back to back)" if celt_split
+        split = os.environ.get("OPUSGPU_SPLIT", "1") != "0"
+        split_silk = split and os.environ.get("OPUSGPU_SPLIT_HYBRID", "1") != "0"
+        if args.workload.startswith("celt"):
+            kernels = "k_celt_parse + k_celt_recon + k_celt_post" if split else "k_decode_step"
+        elif args.workload.startswith("silk"):
+            kernels = "k_silk_parse + k_decode_step" if split_silk else "k_decode_step"
+        else:
+            kernels = ("k_silk_parse + k_decode_step + k_celt_parse + k_celt_recon + k_celt_post" if split_silk
                        else "k_decode_step")
+        kernel_name = f"decode step = {kernels} (launched back to back)"
         line = {
             "metric": "decoded 48 kHz stereo frames/sec/GPU (x real-time); HBM GB/s vs roofline",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
