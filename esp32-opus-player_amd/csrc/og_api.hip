@@ -33,9 +33,13 @@ __global__ void __launch_bounds__(64) k_stream_init(StreamState *st, int first, 
 #ifndef OG_RECON_WAVES
 #define OG_RECON_WAVES 2
 #endif
+#ifndef OG_SILK_WAVES
+#define OG_SILK_WAVES 2
+#endif
 __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
                                                    StreamState *st, i16 *pcm, i32 *result, int n, int n_streams,
-                                                   int pcm_stride, int skip_celt, SilkHandoff *handoff, const SilkRec *srecs) {
+                                                   int pcm_stride, int skip_celt, SilkHandoff *handoff, const SilkRec *srecs,
+                                                   int q4_only) {
     const int f = (int)blockIdx.x;
     if (f >= n) return;
     const FrameDesc d = descs[f];
@@ -44,18 +48,40 @@ __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const Fra
         ret = BAD_ARG;
     } else if (skip_celt && desc_mode(d.flags) == MODE_CELT) {
         return; // CELT-only frames take the split path (k_celt_parse + k_celt_recon)
+    } else if (q4_only && !(desc_mode(d.flags) == MODE_SILK && handoff[f].valid == 2)) {
+        return; // second pass of the split path: only the parked Q4 transition frames
     } else {
         StreamState *s = &st[d.stream];
 #ifdef OG_PROF_SINGLE // profiling builds: time the sections of the single-kernel path
         OG_PROF_INIT();
 #endif
-        ret = decode_frame_wave(s, arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
-                                desc_channels(d.flags), pcm + (size_t)f * pcm_stride, handoff ? &handoff[f] : nullptr,
-                                srecs ? &srecs[f] : nullptr);
+        ret = decode_frame_wave<true>(s, arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
+                                      desc_channels(d.flags), pcm + (size_t)f * pcm_stride, handoff ? &handoff[f] : nullptr,
+                                      srecs ? &srecs[f] : nullptr, q4_only);
 #ifdef OG_PROF_SINGLE
         OG_PROF_FLUSH();
 #endif
         if (ret == CONTINUE_SPLIT) return; // the split path finishes this frame and reports its result
+    }
+    if (threadIdx.x == 0) result[f] = ret;
+}
+
+// SILK-only and hybrid frames on the split path, arithmetic half: one frame per wave, no CELT code (see decode_frame_wave).
+__global__ void __launch_bounds__(64, OG_SILK_WAVES) k_silk_synth(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
+                                                                   StreamState *st, i16 *pcm, i32 *result, int n, int n_streams,
+                                                                   int pcm_stride, SilkHandoff *handoff, const SilkRec *srecs) {
+    const int f = (int)blockIdx.x;
+    if (f >= n) return;
+    const FrameDesc d = descs[f];
+    int ret;
+    if (d.stream < 0 || d.stream >= n_streams) {
+        ret = BAD_ARG;
+    } else if (desc_mode(d.flags) == MODE_CELT) {
+        return;
+    } else {
+        ret = decode_frame_wave<false>(&st[d.stream], arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
+                                       desc_channels(d.flags), pcm + (size_t)f * pcm_stride, &handoff[f], &srecs[f]);
+        if (ret == CONTINUE_SPLIT || ret == CONTINUE_Q4) return;
     }
     if (threadIdx.x == 0) result[f] = ret;
 }
@@ -298,11 +324,20 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
                                (const StreamState *)ctx->d_streams, srecs, handoff, n, ctx->n_streams);
         }
     }
-    // SILK-only frames, the SILK half of hybrid frames (CELT half handed to the split path), stream-index errors;
-    // without the split path: every frame
-    hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
-                       ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, ctx->split_celt, handoff,
-                       (const SilkRec *)srecs);
+    if (srecs) {
+        // SILK-only frames and the SILK half of hybrid frames: arithmetic half, one frame per wave (also reports
+        // stream-index errors); then the rare hybrid -> SILK-only transition frames (Q4) through the full kernel
+        hipLaunchKernelGGL(k_silk_synth, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams,
+                           (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, handoff, (const SilkRec *)srecs);
+        hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
+                           ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, 1, handoff,
+                           (const SilkRec *)srecs, 1);
+    } else {
+        // every frame (OPUSGPU_SPLIT=0), or every frame that is not CELT-only (OPUSGPU_SPLIT_HYBRID=0)
+        hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
+                           ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, ctx->split_celt, nullptr,
+                           nullptr, 0);
+    }
     if (ctx->split_celt) {
         // CELT-only frames and the CELT half of hybrid frames: parse (one frame per lane) -> records in HBM ->
         // reconstruct (one frame per wave) -> de-emphasis, SILK mix and PCM (one (frame, channel) per lane)

@@ -45,9 +45,15 @@ OG_DEV void stream_reset(StreamState *st) {
 // already decoded by the lane-per-frame parse kernel: `srec` holds the SILK indices / pulses, `handoff` the live coder
 // state.  A hybrid frame's CELT half is then left to the split path: the SILK PCM goes to handoff->pcm and
 // CONTINUE_SPLIT is returned (no result, no bookkeeping yet).
-enum { CONTINUE_SPLIT = 1 };
+//
+// WITH_CELT = false is the split path's SILK synthesis kernel: it contains no CELT code at all (and so needs neither
+// the CELT working set in LDS nor its registers).  SILK-only frames finish there -- their PCM is the SILK PCM -- except
+// the Q4 transition frame (SILK-only right after hybrid), whose 120-sample CELT frame needs the CELT decoder: that one
+// is parked (handoff->valid = 2, CONTINUE_Q4) and finished by a second pass of the full kernel with q4_resume = 1.
+enum { CONTINUE_SPLIT = 1, CONTINUE_Q4 = 2 };
+template <bool WITH_CELT>
 OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mode, int bandwidth, int ch, i16 *pcm,
-                             SilkHandoff *handoff = nullptr, const SilkRec *srec = nullptr) {
+                             SilkHandoff *handoff = nullptr, const SilkRec *srec = nullptr, int q4_resume = 0) {
     const int audiosize = 960;
     const int CC = st->channels;
     if (len < 0 || len > 1275) return BAD_ARG;
@@ -62,21 +68,27 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
         rc.nbits_total = OG_UNI(handoff->nbits_total); rc.offs = (u32)OG_UNI(handoff->offs); rc.rng = (u32)OG_UNI(handoff->rng);
         rc.val = (u32)OG_UNI(handoff->val); rc.ext = (u32)OG_UNI(handoff->ext); rc.rem = OG_UNI(handoff->rem);
         rc.error = OG_UNI(handoff->error);
-        if (mode == MODE_SILK && prev_mode == MODE_HYBRID) {
+        if (WITH_CELT && mode == MODE_SILK && prev_mode == MODE_HYBRID) {
             OG_SYNC();
             OG_FOR_LANES(i, len) S.pkt[i] = payload[i];
+            if (q4_resume) { // the SILK half ran in the synthesis kernel: take its PCM back
+                const u32 *src = reinterpret_cast<const u32 *>(handoff->pcm);
+                u32 *dst = reinterpret_cast<u32 *>(SL().u.out.pcm);
+                OG_FOR_LANES(i, audiosize * ch / 2) dst[i] = src[i];
+            }
             OG_SYNC();
         }
-    } else {
+    } else if (WITH_CELT) {
         OG_SYNC();
         OG_FOR_LANES(i, len) S.pkt[i] = payload[i];
         OG_SYNC();
         rc_init(rc, (u32)len);
-    }
+    } else
+        return INTERNAL_ERROR; // the synthesis kernel only exists behind the parse kernel
     int celt_ret = 0;
 
 #ifndef OG_NO_SILK
-    if (mode != MODE_CELT) {
+    if (mode != MODE_CELT && !q4_resume) {
         if (prev_mode == MODE_CELT) silk_init_state(&st->silk);
         int internal_hz = 16000;
         if (mode == MODE_SILK) internal_hz = bandwidth == BW_NB ? 8000 : (bandwidth == BW_MB ? 12000 : 16000);
@@ -96,15 +108,41 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
     if (handoff && mode == MODE_HYBRID) {
         OG_SYNC();
         {
-            const u32 *src = reinterpret_cast<const u32 *>(g_pcm_silk);
+            const u32 *src = reinterpret_cast<const u32 *>(SL().u.out.pcm);
             u32 *dst = reinterpret_cast<u32 *>(handoff->pcm);
             OG_FOR_LANES(i, audiosize * ch / 2) dst[i] = src[i];
         }
         OG_SYNC();
         return CONTINUE_SPLIT;
     }
+    if (!WITH_CELT) { // SILK-only frame on the split path
+        if (mode != MODE_SILK) return INTERNAL_ERROR;
+        OG_SYNC();
+        if (prev_mode == MODE_HYBRID) { // Q4: park the frame for the full kernel
+            const u32 *src = reinterpret_cast<const u32 *>(SL().u.out.pcm);
+            u32 *dst = reinterpret_cast<u32 *>(handoff->pcm);
+            OG_FOR_LANES(i, audiosize * ch / 2) dst[i] = src[i];
+            if (OG_LANE == 0) handoff->valid = 2;
+            OG_SYNC();
+            return CONTINUE_Q4;
+        }
+        // PCM = SAT16(0 + pcm_silk) over the first 960 * ch interleaved entries, zero beyond (Q3)
+        {
+            const u32 *src = reinterpret_cast<const u32 *>(SL().u.out.pcm);
+            u32 *dst = reinterpret_cast<u32 *>(pcm);
+            OG_FOR_LANES(i, audiosize * CC / 2) dst[i] = i < audiosize * ch / 2 ? src[i] : 0u;
+        }
+        if (OG_LANE == 0) {
+            st->prev_mode = mode;
+            st->frames_decoded += 1;
+            st->range_final = rc.rng;
+        }
+        OG_SYNC();
+        return audiosize;
+    }
 #endif
 
+    if constexpr (WITH_CELT) {
     // One CELT call site (the whole CELT decoder is inlined into it): the regular frame, or -- Q4 -- the 2.5 ms
     // frame the reference decodes from the live range decoder on a hybrid -> SILK-only transition.
     int do_celt = 0, celt_n = audiosize, celt_start = start_band;
@@ -144,7 +182,7 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
         OG_SYNC();
         OG_FOR_LANES(i, audiosize * ch) { // i indexes the interleaved PCM; sample j of channel c lives in plane c
             const int c = CC == 2 ? (i & 1) : 0, j = CC == 2 ? (i >> 1) : i, at = pcm_plane(c, ch, CC) + j;
-            S.v[at] = (i16)sat16((i32)S.v[at] + (i32)g_pcm_silk[i]);
+            S.v[at] = (i16)sat16((i32)S.v[at] + (i32)SL().u.out.pcm[i]);
         }
         OG_SYNC();
     }
@@ -160,6 +198,8 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
     pcm_store(pcm, audiosize, ch, CC);
     OG_SYNC();
     return audiosize;
+    } else
+        return INTERNAL_ERROR;
 }
 
 } // namespace og

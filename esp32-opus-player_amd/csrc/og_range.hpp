@@ -10,9 +10,6 @@
 namespace og {
 
 OG_LDS FrameLds S; // the wave's LDS working set (one workgroup == one wave == one frame)
-// SILK output at 48 kHz for the hybrid / SILK-only mix (single-kernel path only: a separate LDS object, so kernels
-// that never touch it do not pay for it)
-OG_LDS i16 g_pcm_silk[1920];
 
 struct Rc {
     u32 storage, end_offs, end_window;

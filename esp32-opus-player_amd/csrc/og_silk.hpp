@@ -37,10 +37,20 @@ struct SilkCtrl { // silk_decoder_control_t (src/silk.h:747) + the frame's side 
 struct SilkLds {
     i16 pulses[2][SILK_MAX_FRAME + 16];
     i16 xq[2][SILK_MAX_FRAME + 8];      // [0..2) look-back slots, frame at +2 (samplesOut1_tmp, silk.cpp:1657)
-    i32 sLTP_Q15[2][2 * SILK_MAX_FRAME];
-    i16 sLTP[2][SILK_MAX_FRAME];
-    i16 up[2][8 + 2 * SILK_MAX_FRAME + 8];  // FIR history + 2x up-sampled frame
-    i16 hist[2][SILK_MAX_FRAME + 160];      // outBuf staged from HBM (+ 2 subframes for the mid-frame re-whitening)
+    // Two phases share these bytes: the synthesis recurrence (LTP state, whitened history, staged outBuf) and, once
+    // that is done, the resampler (48 kHz PCM of both channels, 2x up-sampled signals).  The up-sampler's staged
+    // 32-bit input lives in sLTP_Q15[ch][0..320), i.e. under `pcm`, and is dead before the FIR writes `pcm`.
+    union {
+        struct {
+            i32 sLTP_Q15[2][2 * SILK_MAX_FRAME];
+            i16 sLTP[2][SILK_MAX_FRAME];
+            i16 hist[2][SILK_MAX_FRAME + 160]; // outBuf staged from HBM (+ 2 subframes for the mid-frame re-whitening)
+        } core;
+        struct {
+            i16 pcm[1920];                          // SILK output at 48 kHz, interleaved over the packet's channels
+            i16 up[2][8 + 2 * SILK_MAX_FRAME + 8];  // FIR history + 2x up-sampled frame
+        } out;
+    } u;
     SilkCtrl ctrl[2];
     i32 sum_pulses[20], nLshifts[20];
     i32 VAD_flags[2], LBRR_flag[2];
@@ -603,6 +613,7 @@ struct SilkParLane {
     static OG_MEMBER A32 Atmp() { A32 r = {&g_silk_par.Atmp[0][OG_LANE]}; return r; }
 };
 static_assert(sizeof(SilkCtrl) == 4 * (SILK_REC_CTRL_WORDS + 1), "SilkRecCh mirrors SilkCtrl");
+static_assert(2 * SILK_MAX_FRAME * 4 * 2 >= 1920 * 2 && SILK_MAX_FRAME * 4 * 2 <= 1920 * 2 + 0 * 1, "up-sampler input staging sits under pcm");
 
 // Second half of the parse kernel's lane: silk_decode_parameters for the coded channels, from the indices just
 // written to the record.  The inputs that live in the stream state (LastGainIndex, first_frame_after_reset, previous
@@ -642,8 +653,8 @@ OG_DEVN void silk_decode_core_lane(SilkChannel *c, int ch, int fs_kHz) {
     const int order = fs_kHz == 16 ? 16 : 10, subfr = 5 * fs_kHz, frame_length = 4 * subfr, ltp_mem = 20 * fs_kHz;
     const i16 *pulses = L.pulses[ch];
     i16 *xq = &L.xq[ch][2];
-    i32 *sLTP_Q15 = L.sLTP_Q15[ch];
-    i16 *sLTP = L.sLTP[ch];
+    i32 *sLTP_Q15 = L.u.core.sLTP_Q15[ch];
+    i16 *sLTP = L.u.core.sLTP[ch];
     const i32 offset_Q10 = rom_silk_quant_offsets_q10[(k.signalType >> 1) * 2 + k.quantOffsetType];
     const int interp_flag = k.NLSFInterpCoef_Q2 < 4;
     i32 sLPC[SILK_MAX_LPC]; // sLPC[j] = state sample (i-1-j): most recent first
@@ -668,7 +679,7 @@ OG_DEVN void silk_decode_core_lane(SilkChannel *c, int ch, int fs_kHz) {
             if (sf == 0 || (sf == 2 && interp_flag)) { // re-whitening
                 const int start_idx = ltp_mem - lag - order - 2;
                 // input = outBuf history (staged in LDS) followed, for sf == 2, by the two subframes decoded so far
-                i16 *hist = L.hist[ch];
+                i16 *hist = L.u.core.hist[ch];
                 if (sf == 2)
                     for (int i = 0; i < 2 * subfr; i++) hist[ltp_mem + i] = xq[i];
                 const i16 *in = &hist[start_idx + sf * subfr];
@@ -766,8 +777,8 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels) {
     SilkChannel *c = &st->ch[ch];
     const SilkCtrl &k = L.ctrl[ch];
     const i16 *pulses = L.pulses[ch];
-    i32 *sLTP_Q15 = L.sLTP_Q15[ch];
-    i16 *sLTP = L.sLTP[ch];
+    i32 *sLTP_Q15 = L.u.core.sLTP_Q15[ch];
+    i16 *sLTP = L.u.core.sLTP[ch];
     const i32 offset_Q10 = rom_silk_quant_offsets_q10[(k.signalType >> 1) * 2 + k.quantOffsetType];
     const int interp_flag = k.NLSFInterpCoef_Q2 < 4, voiced = k.signalType == 2;
     i32 sLPC = c->sLPC_Q14_buf[SILK_MAX_LPC - 1 - j]; // state sample (i-1-j)
@@ -790,7 +801,7 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels) {
             lag = k.pitchL[sf];
             if (sf == 0 || (sf == 2 && interp_flag)) { // re-whitening: a FIR, one output per lane and step
                 const int start_idx = ltp_mem - lag - order - 2;
-                i16 *hist = L.hist[ch];
+                i16 *hist = L.u.core.hist[ch];
                 if (sf == 2) {
                     for (int i = j; i < 2 * subfr; i += 16) hist[ltp_mem + i] = xq[i];
                     OG_ROW_SYNC();
@@ -861,7 +872,7 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels) {
 OG_DEVN void silk_up2_lane(SilkChannel *c, int ch, int inLen) {
     SilkLds &L = SL();
     const i16 *in = &L.xq[ch][1];
-    i16 *up = L.up[ch];
+    i16 *up = L.u.out.up[ch];
     const int delay = c->rs_inputDelay;
     i32 S0 = c->rs_sIIR[0], S1 = c->rs_sIIR[1], S2 = c->rs_sIIR[2], S3 = c->rs_sIIR[3], S4 = c->rs_sIIR[4], S5 = c->rs_sIIR[5];
     const i32 a0 = rom_silk_up2_hq0[0], a1 = rom_silk_up2_hq0[1], a2 = rom_silk_up2_hq0[2];
@@ -925,11 +936,11 @@ OG_DEV void silk_up2_rows(SilkState *st, int channels, int inLen) {
     if (row >= channels) return;
     SilkChannel *c = &st->ch[row];
     const i16 *in = &L.xq[row][1];
-    i16 *up = L.up[row];
+    i16 *up = L.u.out.up[row];
     const int delay = c->rs_inputDelay;
     if (j < 8) up[j] = c->rs_sFIR[j];
     // the input stream [delayBuf | in] as 32-bit Q10 values, staged once (the sLTP_Q15 row of this channel is free by now)
-    i32 *in32 = L.sLTP_Q15[row];
+    i32 *in32 = L.u.core.sLTP_Q15[row];
     for (int t = j; t < inLen; t += 16) in32[t] = shl32(t < delay ? (i32)c->rs_delayBuf[t] : (i32)in[t - delay], 10);
     OG_ROW_SYNC();
     if (j < 6) {
@@ -1093,7 +1104,7 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz,
     // ---- synthesis: stage the output history, then lane n = channel n
     OG_MARK(34);
     for (int n = 0; n < channels; n++)
-        if (L.ctrl[n].coded) OG_FOR_LANES(i, frame_length) L.hist[n][i] = s->ch[n].outBuf[i];
+        if (L.ctrl[n].coded) OG_FOR_LANES(i, frame_length) L.u.core.hist[n][i] = s->ch[n].outBuf[i];
     OG_SYNC();
 #ifdef OG_HOST_EMUL
     OG_FOR_LANES(n, channels) {
@@ -1176,7 +1187,7 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz,
                 const int n = id / count, m = id - n * count;
                 const i32 index_Q16 = m * inv;
                 const int t = smulwb(index_Q16 & 0xFFFF, 12);
-                const i16 *b = &L.up[n][2 * t0 + (index_Q16 >> 16)];
+                const i16 *b = &L.u.out.up[n][2 * t0 + (index_Q16 >> 16)];
                 const i16 *f0 = &rom_silk_frac_fir12[4 * t], *f1 = &rom_silk_frac_fir12[4 * (11 - t)];
                 i32 res = smulbb(b[0], f0[0]);
                 res = smlabb(res, b[1], f0[1]);
@@ -1186,7 +1197,7 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz,
                 res = smlabb(res, b[5], f1[2]);
                 res = smlabb(res, b[6], f1[1]);
                 res = smlabb(res, b[7], f1[0]);
-                g_pcm_silk[(out0 + m) * channels + n] = (i16)sat16(rshift_round(res, 15));
+                SL().u.out.pcm[(out0 + m) * channels + n] = (i16)sat16(rshift_round(res, 15));
             }
             t0 += nIn;
             out0 += count;

@@ -10,7 +10,7 @@ void emu_stream_init(void *st, int channels) { og::stream_init((og::StreamState 
 void emu_stream_reset(void *st) { og::stream_reset((og::StreamState *)st); }
 // the single-kernel path (every mode)
 int emu_decode_frame_single(void *st, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm) {
-    return og::decode_frame_wave((og::StreamState *)st, payload, len, mode, bw, ch, pcm);
+    return og::decode_frame_wave<true>((og::StreamState *)st, payload, len, mode, bw, ch, pcm);
 }
 // what the library dispatches: CELT-only frames take the split path (parse per lane, reconstruct per wave, post per
 // channel); hybrid frames decode their SILK half on the single-kernel path and hand the CELT half over
@@ -24,7 +24,8 @@ int emu_decode_frame(void *stv, const uint8_t *payload, int len, int mode, int b
         og::silk_tables_load();
         og::silk_parse_lane(st, payload, len, mode, bw, ch, &srec, &handoff);
         og::silk_params_lane(st, mode, bw, ch, &srec);
-        const int r = og::decode_frame_wave(st, payload, len, mode, bw, ch, pcm, &handoff, &srec);
+        int r = og::decode_frame_wave<false>(st, payload, len, mode, bw, ch, pcm, &handoff, &srec);
+        if (r == og::CONTINUE_Q4) return og::decode_frame_wave<true>(st, payload, len, mode, bw, ch, pcm, &handoff, &srec, 1);
         if (r != og::CONTINUE_SPLIT) return r;
         h = &handoff;
     }
