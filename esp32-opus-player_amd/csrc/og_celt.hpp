@@ -802,7 +802,28 @@ typedef u32 og_v2u __attribute__((ext_vector_type(2)));
 OG_DEV i32 post_mix(i32 v, const i16 *silk, int silk_n, int at) {
     return (silk && at < silk_n) ? sat16(v + (i32)silk[at]) : v;
 }
-OG_DEV void celt_post4(i32 &m, i32 s0, i32 s1, i32 s2, i32 s3, int j, int c, int CC, i16 *pcm, const i16 *silk, int silk_n) {
+#ifndef OG_HOST_EMUL
+// the four addends of samples j..j+3 of channel c with one vector load (all four entries lie on the same side of
+// silk_n: it is a multiple of 4 * CC); zeros when there is nothing to add
+struct PostAdd { i32 a0, a1, a2, a3; };
+OG_DEV PostAdd post_addends(const i16 *silk, int silk_n, int j, int c, int CC) {
+    PostAdd r = {0, 0, 0, 0};
+    if (silk && (j + 3) * CC + c < silk_n) {
+        if (CC == 2) {
+            const og_v4i v = *reinterpret_cast<const og_v4i *>(silk + 2 * j); // L0 R0 L1 R1 | L2 R2 L3 R3, 16-byte aligned
+            const int sh = 16 * c;
+            r.a0 = (i32)(i16)((u32)v.x >> sh); r.a1 = (i32)(i16)((u32)v.y >> sh);
+            r.a2 = (i32)(i16)((u32)v.z >> sh); r.a3 = (i32)(i16)((u32)v.w >> sh);
+        } else {
+            const og_v2u v = *reinterpret_cast<const og_v2u *>(silk + j);
+            r.a0 = (i32)(i16)v.x; r.a1 = (i32)(i16)(v.x >> 16); r.a2 = (i32)(i16)v.y; r.a3 = (i32)(i16)(v.y >> 16);
+        }
+    }
+    return r;
+}
+#endif
+OG_DEV void celt_post4(i32 &m, i32 s0, i32 s1, i32 s2, i32 s3, int j, int c, int CC, i16 *__restrict__ pcm,
+                      const i16 *__restrict__ silk, int silk_n) {
     const i32 t0 = s0 + m;
     m = mul16x32_q15(27853, t0);
     const i32 t1 = s1 + m;
@@ -811,8 +832,14 @@ OG_DEV void celt_post4(i32 &m, i32 s0, i32 s1, i32 s2, i32 s3, int j, int c, int
     m = mul16x32_q15(27853, t2);
     const i32 t3 = s3 + m;
     m = mul16x32_q15(27853, t3);
+#ifdef OG_HOST_EMUL
     const i32 o0 = post_mix(sat16(pshr32(t0, 12)), silk, silk_n, (j + 0) * CC + c), o1 = post_mix(sat16(pshr32(t1, 12)), silk, silk_n, (j + 1) * CC + c);
     const i32 o2 = post_mix(sat16(pshr32(t2, 12)), silk, silk_n, (j + 2) * CC + c), o3 = post_mix(sat16(pshr32(t3, 12)), silk, silk_n, (j + 3) * CC + c);
+#else
+    const PostAdd ad = post_addends(silk, silk_n, j, c, CC);
+    const i32 o0 = sat16(sat16(pshr32(t0, 12)) + ad.a0), o1 = sat16(sat16(pshr32(t1, 12)) + ad.a1);
+    const i32 o2 = sat16(sat16(pshr32(t2, 12)) + ad.a2), o3 = sat16(sat16(pshr32(t3, 12)) + ad.a3);
+#endif
 #ifdef OG_HOST_EMUL
     if (pcm) {
         pcm[(j + 0) * CC + c] = (i16)o0;
@@ -846,7 +873,7 @@ OG_DEV void celt_post4(i32 &m, i32 s0, i32 s1, i32 s2, i32 s3, int j, int c, int
 #endif
 }
 
-OG_DEV void celt_post_lane(CeltState *st, int c, int CC, int N, i16 *pcm, const i16 *silk, int silk_n) {
+OG_DEV void celt_post_lane(CeltState *st, int c, int CC, int N, i16 *__restrict__ pcm, const i16 *__restrict__ silk, int silk_n) {
     const int pos = (st->ring_pos - N) & RING_MASK; // the frame's first sample (N is a multiple of 8, so is ring_pos)
     const i32 *ring = st->ring[c];
     i32 m = st->deemph[c];
