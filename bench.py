@@ -173,9 +173,9 @@ def main():
         if args.workload.startswith("celt"):
             kernels = "k_celt_parse + k_celt_recon + k_celt_post" if split else "k_decode_step"
         elif args.workload.startswith("silk"):
-            kernels = "k_silk_parse + k_decode_step" if split_silk else "k_decode_step"
+            kernels = "k_silk_parse + k_silk_synth" if split_silk else "k_decode_step"
         else:
-            kernels = ("k_silk_parse + k_decode_step + k_celt_parse + k_celt_recon + k_celt_post" if split_silk
+            kernels = ("k_silk_parse + k_silk_synth + k_celt_parse + k_celt_recon + k_celt_post" if split_silk
                        else "k_decode_step")
         kernel_name = f"decode step = {kernels} (launched back to back)"
         line = {

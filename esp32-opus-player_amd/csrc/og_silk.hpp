@@ -3,18 +3,18 @@
 // Behaviour reproduced: silk_Decode as the reference drives it (src/silk.cpp:1481; lostFlag == 0,
 // 20 ms payload, API rate 48 kHz, nChannelsAPI == nChannelsInternal == packet channels, src/opus_decoder.cpp:167-203).
 //
-// Mapping onto the wave:
-//   [scalar, wave-uniform]   VAD/LBRR flags, LBRR skip-decode, stereo predictor, then per channel:
-//                            side information, shell/sign pulse decode, gain dequantisation, NLSF decode +
-//                            stabilise, NLSF-to-LPC (even/odd polynomials, LPC fit, stability check).
-//                            All of it hangs off the range decoder or is a short dependent recurrence.
-//   [one lane per channel]   silk_decode_core: excitation, LTP and the order-10/16 LPC synthesis recurrence
-//                            (saturating, hence serial in time) -- mid and side are independent once their
-//                            parameters are known, so they run side by side; the 2x all-pass up-sampler
-//                            (three serial first-order sections per phase) likewise.
-//   [lane-parallel]          mid/side -> left/right, the 8-tap 12-phase FIR interpolation to 48 kHz,
-//                            interleave into S.pcm_silk.
-// Scratch lives in LDS, overlaid on the CELT synthesis buffer (SILK always runs before CELT in a frame).
+// Mapping onto the wave (one frame per wave):
+//   [scalar, wave-uniform]   only without the split path (OPUSGPU_SPLIT=0): VAD/LBRR flags, LBRR skip-decode, stereo
+//                            predictor, side information, shell/sign pulse decode (inverse-CDF symbols searched by the
+//                            whole wave at once: og_range.hpp), parameter dequantisation, NLSF -> LPC.  On the split
+//                            path all of that is done one frame per LANE by k_silk_parse (og_silk_parse.hpp, and
+//                            silk_params_lane below) and arrives as a SilkRec.
+//   [16-lane row per channel] silk_decode_core: excitation, LTP and the order-10/16 LPC synthesis recurrence
+//                            (saturating, hence serial in time): lane j of the row holds state sample i-1-j and
+//                            coefficient j, the prediction is one multiply + a DPP row all-reduce.
+//   [lane = all-pass section] the 2x up-sampler as a systolic array (2 phases x 3 sections per channel).
+//   [lane-parallel]          re-whitening FIR, mid/side -> left/right, the 8-tap 12-phase FIR interpolation to 48 kHz.
+// Scratch lives in its own LDS object (SilkLds); the resampler buffers overlay the synthesis buffers.
 #pragma once
 #include "og_celt_math.hpp"
 #include "og_silk_parse.hpp"
