@@ -50,18 +50,22 @@ OG_DEV void silk_tables_load() {      // cooperative, whole workgroup; ends with
     OG_FULL_SYNC();
 }
 
-// inverse-CDF symbol from the LDS table blob (ec_dec_icdf celt.cpp:2727, ftb = 8 throughout SILK)
-OG_DEV int rc_icdf_tab(RcLane &rc, int off) {
-    u32 s = rc.rng, d = rc.val, r = s >> 8, t;
-    int ret = -1;
-    do {
-        t = s;
-        s = r * (u32)g_silk_tab[off + ++ret];
-    } while (d < s);
+// inverse-CDF symbol from the LDS table blob (ec_dec_icdf celt.cpp:2727, ftb = 8 throughout SILK).  `n`: entries of
+// the table including its terminating 0.  The reference scans linearly; the table is monotone, so the same symbol is
+// found by bisection -- log2(n) dependent LDS reads, and (almost) the same trip count in every lane of the wave.
+OG_DEV int rc_icdf_tab(RcLane &rc, int off, int n) {
+    const u32 d = rc.val, r = rc.rng >> 8;
+    int lo = 0, hi = n - 1; // smallest index with val >= r * icdf[index]; the last entry (0) always qualifies
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (d >= r * (u32)g_silk_tab[off + mid]) hi = mid; else lo = mid + 1;
+    }
+    const u32 s = r * (u32)g_silk_tab[off + lo];
+    const u32 t = lo ? r * (u32)g_silk_tab[off + lo - 1] : rc.rng;
     rc.val = d - s;
     rc.rng = t - s;
     rc_renorm(rc);
-    return ret;
+    return lo;
 }
 
 // silk_decode_indices silk.cpp:708 (20 ms: nb_subfr == 4).  Indices go straight to the record.
@@ -72,39 +76,41 @@ OG_DEV void silk_parse_indices(RcLane &rc, SilkRecCh *o, int fs_kHz, int vad, in
     const int ec_iCDF = wb ? SILK_BLOB_wb_cb2_icdf : SILK_BLOB_nb_cb2_icdf;
     int Ix;
     if (decode_LBRR || vad)
-        Ix = rc_icdf_tab(rc, SILK_BLOB_type_vad_icdf) + 2;
+        Ix = rc_icdf_tab(rc, SILK_BLOB_type_vad_icdf, 4) + 2;
     else
-        Ix = rc_icdf_tab(rc, SILK_BLOB_type_novad_icdf);
+        Ix = rc_icdf_tab(rc, SILK_BLOB_type_novad_icdf, 2);
     const int signalType = Ix >> 1;
     o->signalType = signalType;
     o->quantOffsetType = Ix & 1;
     if (condCoding == 2)
-        o->GainsIndices[0] = rc_icdf_tab(rc, SILK_BLOB_delta_gain_icdf);
+        o->GainsIndices[0] = rc_icdf_tab(rc, SILK_BLOB_delta_gain_icdf, 41);
     else {
-        int g = rc_icdf_tab(rc, SILK_BLOB_gain_icdf + 8 * signalType) << 3;
-        g += rc_icdf_tab(rc, SILK_BLOB_uniform8_icdf);
+        int g = rc_icdf_tab(rc, SILK_BLOB_gain_icdf + 8 * signalType, 8) << 3;
+        g += rc_icdf_tab(rc, SILK_BLOB_uniform8_icdf, 8);
         o->GainsIndices[0] = g;
     }
-    for (int i = 1; i < 4; i++) o->GainsIndices[i] = rc_icdf_tab(rc, SILK_BLOB_delta_gain_icdf);
-    const int cb1 = rc_icdf_tab(rc, CB1_iCDF + (signalType >> 1) * 32);
+    for (int i = 1; i < 4; i++) o->GainsIndices[i] = rc_icdf_tab(rc, SILK_BLOB_delta_gain_icdf, 41);
+    const int cb1 = rc_icdf_tab(rc, CB1_iCDF + (signalType >> 1) * 32, 32);
     o->NLSFIndices[0] = cb1;
     for (int i = 0; i < order; i++) { // silk_NLSF_unpack silk.cpp:2762: the entropy table of coefficient i
         const int entry = g_silk_tab[ec_sel + cb1 * order / 2 + (i >> 1)];
         const int ec_ix = ((entry >> (1 + 4 * (i & 1))) & 7) * 9;
-        Ix = rc_icdf_tab(rc, ec_iCDF + ec_ix);
+        Ix = rc_icdf_tab(rc, ec_iCDF + ec_ix, 9);
         if (Ix == 0)
-            Ix -= rc_icdf_tab(rc, SILK_BLOB_nlsf_ext_icdf);
+            Ix -= rc_icdf_tab(rc, SILK_BLOB_nlsf_ext_icdf, 7);
         else if (Ix == 8)
-            Ix += rc_icdf_tab(rc, SILK_BLOB_nlsf_ext_icdf);
+            Ix += rc_icdf_tab(rc, SILK_BLOB_nlsf_ext_icdf, 7);
         o->NLSFIndices[i + 1] = Ix - 4;
     }
-    o->NLSFInterpCoef_Q2 = rc_icdf_tab(rc, SILK_BLOB_nlsf_interp_icdf);
+    o->NLSFInterpCoef_Q2 = rc_icdf_tab(rc, SILK_BLOB_nlsf_interp_icdf, 5);
     if (signalType == 2) {
         int decode_abs = 1, lagIndex = 0;
         const int lowbits = fs_kHz == 16 ? SILK_BLOB_uniform8_icdf : (fs_kHz == 12 ? SILK_BLOB_uniform6_icdf : SILK_BLOB_uniform4_icdf);
+        const int lowbits_n = fs_kHz >> 1;
         const int contour = fs_kHz == 8 ? SILK_BLOB_pitch_contour_nb_icdf : SILK_BLOB_pitch_contour_icdf;
+        const int contour_n = fs_kHz == 8 ? 11 : 34;
         if (condCoding == 2 && ec_prevSignalType == 2) {
-            int delta = rc_icdf_tab(rc, SILK_BLOB_pitch_delta_icdf);
+            int delta = rc_icdf_tab(rc, SILK_BLOB_pitch_delta_icdf, 21);
             if (delta > 0) {
                 delta -= 9;
                 lagIndex = tr16(ec_prevLagIndex + delta);
@@ -112,25 +118,25 @@ OG_DEV void silk_parse_indices(RcLane &rc, SilkRecCh *o, int fs_kHz, int vad, in
             }
         }
         if (decode_abs) {
-            lagIndex = tr16(rc_icdf_tab(rc, SILK_BLOB_pitch_lag_icdf) * (fs_kHz >> 1));
-            lagIndex = tr16(lagIndex + rc_icdf_tab(rc, lowbits));
+            lagIndex = tr16(rc_icdf_tab(rc, SILK_BLOB_pitch_lag_icdf, 32) * (fs_kHz >> 1));
+            lagIndex = tr16(lagIndex + rc_icdf_tab(rc, lowbits, lowbits_n));
         }
         o->lagIndex = lagIndex;
         ec_prevLagIndex = lagIndex;
-        o->contourIndex = rc_icdf_tab(rc, contour);
-        const int per = rc_icdf_tab(rc, SILK_BLOB_ltp_per_icdf);
+        o->contourIndex = rc_icdf_tab(rc, contour, contour_n);
+        const int per = rc_icdf_tab(rc, SILK_BLOB_ltp_per_icdf, 3);
         o->PERIndex = per;
         const int t = per == 0 ? SILK_BLOB_ltp_gain_icdf0 : (per == 1 ? SILK_BLOB_ltp_gain_icdf1 : SILK_BLOB_ltp_gain_icdf2);
-        for (int j = 0; j < 4; j++) o->LTPIndex[j] = rc_icdf_tab(rc, t);
-        o->LTP_scaleIndex = condCoding == 0 ? rc_icdf_tab(rc, SILK_BLOB_ltpscale_icdf) : 0;
+        for (int j = 0; j < 4; j++) o->LTPIndex[j] = rc_icdf_tab(rc, t, 8 << per);
+        o->LTP_scaleIndex = condCoding == 0 ? rc_icdf_tab(rc, SILK_BLOB_ltpscale_icdf, 3) : 0;
     }
     ec_prevSignalType = signalType;
-    o->Seed = rc_icdf_tab(rc, SILK_BLOB_uniform4_icdf);
+    o->Seed = rc_icdf_tab(rc, SILK_BLOB_uniform4_icdf, 4);
 }
 
 OG_DEV void shell_split_tab(RcLane &rc, int &c1, int &c2, int p, int table) {
     if (p > 0) {
-        c1 = rc_icdf_tab(rc, table + g_silk_tab[SILK_BLOB_shell_offsets + p]);
+        c1 = rc_icdf_tab(rc, table + g_silk_tab[SILK_BLOB_shell_offsets + p], p + 1);
         c2 = p - c1;
     } else {
         c1 = 0;
@@ -146,13 +152,13 @@ OG_LDS u16 g_silk_blk[SILK_REC_FRAME / 16][OG_NLANES];
 OG_DEV void silk_parse_pulses(RcLane &rc, i16 *pulses, int signalType, int quantOffsetType, int frame_length) {
     int iter = frame_length >> 4;
     if (iter * 16 < frame_length) iter++;
-    const int RateLevelIndex = rc_icdf_tab(rc, SILK_BLOB_rate_levels_icdf + 9 * (signalType >> 1));
+    const int RateLevelIndex = rc_icdf_tab(rc, SILK_BLOB_rate_levels_icdf + 9 * (signalType >> 1), 9);
     const int cdf = SILK_BLOB_pulses_per_block_icdf + 18 * RateLevelIndex;
     for (int i = 0; i < iter; i++) {
-        int nl = 0, sp = rc_icdf_tab(rc, cdf);
+        int nl = 0, sp = rc_icdf_tab(rc, cdf, 18);
         while (sp == 17) {
             nl++;
-            sp = rc_icdf_tab(rc, SILK_BLOB_pulses_per_block_icdf + 18 * 9 + (nl == 10));
+            sp = rc_icdf_tab(rc, SILK_BLOB_pulses_per_block_icdf + 18 * 9 + (nl == 10), 18 - (nl == 10));
         }
         g_silk_blk[i][OG_LANE] = (u16)(sp | nl << 5);
     }
@@ -188,7 +194,7 @@ OG_DEV void silk_parse_pulses(RcLane &rc, i16 *pulses, int signalType, int quant
                 i32 abs_q = p[j];
                 for (int b = 0; b < nLS; b++) {
                     abs_q = shl32(abs_q, 1);
-                    abs_q += rc_icdf_tab(rc, SILK_BLOB_lsb_icdf);
+                    abs_q += rc_icdf_tab(rc, SILK_BLOB_lsb_icdf, 2);
                 }
                 p[j] = (i16)abs_q;
             }
@@ -227,12 +233,12 @@ OG_DEV void silk_parse_pulses(RcLane &rc, i16 *pulses, int signalType, int quant
 }
 
 OG_DEV void silk_parse_stereo_pred(RcLane &rc, i32 pred_Q13[2]) { // silk_stereo_decode_pred silk.cpp:592
-    int n = rc_icdf_tab(rc, SILK_BLOB_stereo_joint_icdf);
+    int n = rc_icdf_tab(rc, SILK_BLOB_stereo_joint_icdf, 25);
     const int ix02 = n / 5, ix12 = n - 5 * ix02;
-    int ix00 = rc_icdf_tab(rc, SILK_BLOB_uniform3_icdf);
-    const int ix01 = rc_icdf_tab(rc, SILK_BLOB_uniform5_icdf);
-    int ix10 = rc_icdf_tab(rc, SILK_BLOB_uniform3_icdf);
-    const int ix11 = rc_icdf_tab(rc, SILK_BLOB_uniform5_icdf);
+    int ix00 = rc_icdf_tab(rc, SILK_BLOB_uniform3_icdf, 3);
+    const int ix01 = rc_icdf_tab(rc, SILK_BLOB_uniform5_icdf, 5);
+    int ix10 = rc_icdf_tab(rc, SILK_BLOB_uniform3_icdf, 3);
+    const int ix11 = rc_icdf_tab(rc, SILK_BLOB_uniform5_icdf, 5);
     ix00 += 3 * ix02;
     ix10 += 3 * ix12;
     {
@@ -285,7 +291,7 @@ OG_DEV void silk_parse_lane(const StreamState *st, const u8 *payload, int len, i
     if (lbrr0) {
         if (channels == 2) {
             silk_parse_stereo_pred(rc, MS_pred_Q13);
-            if (lbrr1 == 0) decode_only_middle = rc_icdf_tab(rc, SILK_BLOB_mid_only_icdf);
+            if (lbrr1 == 0) decode_only_middle = rc_icdf_tab(rc, SILK_BLOB_mid_only_icdf, 2);
         }
         silk_parse_indices(rc, &rec->ch[0], fs_kHz, vad0, 1, 0, ecType0, ecLag0);
         silk_parse_pulses(rc, rec->ch[0].pulses, rec->ch[0].signalType, rec->ch[0].quantOffsetType, frame_length);
@@ -296,7 +302,7 @@ OG_DEV void silk_parse_lane(const StreamState *st, const u8 *payload, int len, i
     }
     if (channels == 2) {
         silk_parse_stereo_pred(rc, MS_pred_Q13);
-        decode_only_middle = vad1 == 0 ? rc_icdf_tab(rc, SILK_BLOB_mid_only_icdf) : 0;
+        decode_only_middle = vad1 == 0 ? rc_icdf_tab(rc, SILK_BLOB_mid_only_icdf, 2) : 0;
     }
     const int has_side = !decode_only_middle;
     silk_parse_indices(rc, &rec->ch[0], fs_kHz, vad0, 0, 0, ecType0, ecLag0);
