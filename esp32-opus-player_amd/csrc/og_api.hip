@@ -97,8 +97,14 @@ __global__ void __launch_bounds__(64, 2) k_silk_parse(const FrameDesc *__restric
     const FrameDesc d = descs[f];
     const int mode = desc_mode(d.flags);
     if (d.stream < 0 || d.stream >= n_streams || mode == MODE_CELT) return;
+#ifdef OG_PROF_SPARSE // profiling builds: time the sections of the SILK parse kernel (full batches only)
+    OG_PROF_INIT();
+#endif
     silk_parse_lane(&st[d.stream], arena + d.offset, d.len, mode, desc_bandwidth(d.flags), desc_channels(d.flags), &srecs[f], &handoff[f]);
     silk_params_lane(&st[d.stream], mode, desc_bandwidth(d.flags), desc_channels(d.flags), &srecs[f]);
+#ifdef OG_PROF_SPARSE
+    OG_PROF_FLUSH();
+#endif
 }
 
 // Split CELT path, first half: ONE FRAME PER LANE.  Lane l of workgroup g parses frame 64 g + l (range decoder,
@@ -131,12 +137,12 @@ __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDe
     const int mode = desc_mode(d.flags);
     if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && hybrid))) return;
     if (mode == MODE_HYBRID && (recs[f].flags & RF_SKIP)) return; // the single-kernel path already reported this frame
-#if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE)
+#if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE) && !defined(OG_PROF_SPARSE)
     OG_PROF_INIT();
 #endif
     const int ret = celt_recon_wave(&st[d.stream], &recs[f], mode, desc_channels(d.flags));
     if (threadIdx.x == 0) result[f] = ret;
-#if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE)
+#if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE) && !defined(OG_PROF_SPARSE)
     OG_PROF_FLUSH();
 #endif
 }

@@ -639,6 +639,7 @@ OG_DEV void silk_params_lane(const StreamState *st, int mode, int bandwidth, int
             ffar = 1;
         }
         SilkRecCh &k = rec->ch[n];
+        OG_MARK(53);
         silk_decode_parameters<SilkParLane>(c->prevNLSF_Q15, k, fs_kHz, 0, lastGain, ffar);
         k.LastGainIndex = lastGain;
         const SilkParLane::A16 nl = SilkParLane::nlsf();

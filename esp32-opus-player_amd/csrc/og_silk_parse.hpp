@@ -272,6 +272,7 @@ OG_DEV void silk_parse_lane(const StreamState *st, const u8 *payload, int len, i
     }
     const int frame_length = 20 * fs_kHz;
     RcLane rc;
+    OG_MARK(50);
     rc_lane_attach(rc, payload, (u32)len);
     rc_init(rc, (u32)len);
     // entropy-side state, as the wave kernel will see it after its own (re-)initialisations:
@@ -305,12 +306,17 @@ OG_DEV void silk_parse_lane(const StreamState *st, const u8 *payload, int len, i
         decode_only_middle = vad1 == 0 ? rc_icdf_tab(rc, SILK_BLOB_mid_only_icdf, 2) : 0;
     }
     const int has_side = !decode_only_middle;
+    OG_MARK(51);
     silk_parse_indices(rc, &rec->ch[0], fs_kHz, vad0, 0, 0, ecType0, ecLag0);
+    OG_MARK(52);
     silk_parse_pulses(rc, rec->ch[0].pulses, rec->ch[0].signalType, rec->ch[0].quantOffsetType, frame_length);
     if (channels == 2 && has_side) {
+        OG_MARK(51);
         silk_parse_indices(rc, &rec->ch[1], fs_kHz, vad1, 0, 0, ecType1, ecLag1);
+        OG_MARK(52);
         silk_parse_pulses(rc, rec->ch[1].pulses, rec->ch[1].signalType, rec->ch[1].quantOffsetType, frame_length);
     }
+    OG_MARK(54);
     rec->ch[0].ec_prevSignalType = ecType0;
     rec->ch[0].ec_prevLagIndex = ecLag0;
     rec->ch[1].ec_prevSignalType = ecType1;
