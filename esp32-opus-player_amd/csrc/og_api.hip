@@ -152,14 +152,112 @@ __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDe
 __global__ void __launch_bounds__(64) k_celt_post(const FrameDesc *__restrict__ descs, StreamState *st, const ParseRec *recs,
                                                   const i32 *__restrict__ result, i16 *pcm, int n, int n_streams, int channels,
                                                   int pcm_stride, const SilkHandoff *handoff) {
-    const int t = (int)blockIdx.x * 64 + (int)threadIdx.x;
+    // Fast path (two-channel decoder, every row of the wave live, ring positions on a 16-sample boundary): the 64 rows'
+    // next 16 samples are fetched as full 64-byte lines by the whole wave (lane = quarter line of a row), transposed
+    // through LDS to one row per lane for the recurrence, and the PCM goes out the same way (lane = 16 bytes of a frame's
+    // interleaved output).  Anything else takes the row-per-lane path with its 16-byte accesses (celt_post_lane).
+    struct RowInfo {
+        const i32 *ring;
+        i16 *pcm;
+        const i16 *silk;
+        int pos, silk_n;
+    };
+    __shared__ RowInfo rows[64];
+    __shared__ __attribute__((aligned(16))) i32 tin[2][64][20]; // 16 samples per row, rows padded to 80 bytes
+    __shared__ __attribute__((aligned(16))) i16 tout[64][24];   // 16 outputs per row, rows padded to 48 bytes
+    const int lane = (int)threadIdx.x;
+    const int t = (int)blockIdx.x * 64 + lane;
     const int f = channels == 2 ? t >> 1 : t, c = channels == 2 ? t & 1 : 0;
-    if (f >= n) return;
-    const FrameDesc d = descs[f];
-    const int mode = desc_mode(d.flags);
-    if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && handoff))) return;
-    celt_post(&st[d.stream], &recs[f], result[f], c, pcm + (size_t)f * pcm_stride, mode == MODE_HYBRID ? handoff[f].pcm : nullptr,
-              desc_channels(d.flags));
+    bool live = false, emit = false;
+    StreamState *ss = nullptr;
+    const i16 *silk = nullptr;
+    int silk_n = 0;
+    if (f < n) {
+        const FrameDesc d = descs[f];
+        const int mode = desc_mode(d.flags);
+        if (d.stream >= 0 && d.stream < n_streams && (mode == MODE_CELT || (mode == MODE_HYBRID && handoff)) &&
+            !(recs[f].flags & (RF_SKIP | RF_BAD_CELT))) {
+            live = true;
+            ss = &st[d.stream];
+            emit = result[f] >= 0;
+            if (mode == MODE_HYBRID) {
+                silk = handoff[f].pcm;
+                silk_n = 960 * desc_channels(d.flags);
+            }
+        }
+    }
+    i16 *out = pcm + (size_t)(f < n ? f : 0) * pcm_stride;
+    const int pos = live ? ((ss->celt.ring_pos - 960) & RING_MASK) : 0;
+    const bool fast = channels == 2 && __all(live && emit && (pos & 15) == 0);
+    if (!fast) {
+        if (live) celt_post_lane(&ss->celt, c, channels, 960, emit ? out : nullptr, silk, silk_n);
+        return;
+    }
+    rows[lane].ring = ss->celt.ring[c];
+    rows[lane].pcm = out;
+    rows[lane].silk = silk;
+    rows[lane].pos = pos;
+    rows[lane].silk_n = silk_n;
+    __syncthreads();
+    // this lane's share of the cooperative traffic: quarter q of rows r0, r0 + 16, r0 + 32, r0 + 48
+    const int q = lane & 3, r0 = lane >> 2;
+    const i32 *src[4];
+    int spos[4];
+    for (int k = 0; k < 4; k++) {
+        src[k] = rows[r0 + 16 * k].ring;
+        spos[k] = rows[r0 + 16 * k].pos + 4 * q;
+    }
+    og_v4i v[4];
+    for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const og_v4i *>(src[k] + (spos[k] & RING_MASK));
+    i32 m = ss->celt.deemph[c];
+    for (int ch = 0; ch < 60; ch++) {
+        const int b = ch & 1;
+        for (int k = 0; k < 4; k++) *reinterpret_cast<og_v4i *>(&tin[b][r0 + 16 * k][4 * q]) = v[k];
+        if (ch + 1 < 60)
+            for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const og_v4i *>(src[k] + ((spos[k] + 16 * (ch + 1)) & RING_MASK));
+        __syncthreads();
+        // the recurrence on this lane's own row (celt.cpp:1965-2055, sig2word16 celt.h:413)
+        i16 o[16];
+        for (int g4 = 0; g4 < 4; g4++) {
+            const og_v4i sv = *reinterpret_cast<const og_v4i *>(&tin[b][lane][4 * g4]);
+            const int j = 16 * ch + 4 * g4;
+            const PostAdd ad = post_addends(silk, silk_n, j, c, 2);
+            i32 tt = sv.x + m;
+            m = mul16x32_q15(27853, tt);
+            o[4 * g4 + 0] = (i16)sat16(sat16(pshr32(tt, 12)) + ad.a0);
+            tt = sv.y + m;
+            m = mul16x32_q15(27853, tt);
+            o[4 * g4 + 1] = (i16)sat16(sat16(pshr32(tt, 12)) + ad.a1);
+            tt = sv.z + m;
+            m = mul16x32_q15(27853, tt);
+            o[4 * g4 + 2] = (i16)sat16(sat16(pshr32(tt, 12)) + ad.a2);
+            tt = sv.w + m;
+            m = mul16x32_q15(27853, tt);
+            o[4 * g4 + 3] = (i16)sat16(sat16(pshr32(tt, 12)) + ad.a3);
+        }
+        for (int g8 = 0; g8 < 2; g8++) {
+            og_v4i w;
+            w.x = (i32)((u32)(u16)o[8 * g8 + 0] | (u32)(u16)o[8 * g8 + 1] << 16);
+            w.y = (i32)((u32)(u16)o[8 * g8 + 2] | (u32)(u16)o[8 * g8 + 3] << 16);
+            w.z = (i32)((u32)(u16)o[8 * g8 + 4] | (u32)(u16)o[8 * g8 + 5] << 16);
+            w.w = (i32)((u32)(u16)o[8 * g8 + 6] | (u32)(u16)o[8 * g8 + 7] << 16);
+            *reinterpret_cast<og_v4i *>(&tout[lane][8 * g8]) = w;
+        }
+        __syncthreads();
+        // PCM: frame fr's 16 samples x 2 channels = 64 contiguous bytes; this lane writes piece q (samples 4q .. 4q+3)
+        for (int k = 0; k < 2; k++) {
+            const int fr = r0 + 16 * k; // frame within the wave: rows 2 fr (left) and 2 fr + 1 (right)
+            const og_v2u L = *reinterpret_cast<const og_v2u *>(&tout[2 * fr][4 * q]);
+            const og_v2u R = *reinterpret_cast<const og_v2u *>(&tout[2 * fr + 1][4 * q]);
+            og_v4i w;
+            w.x = (i32)((L.x & 0xffffu) | R.x << 16);
+            w.y = (i32)(L.x >> 16 | (R.x & 0xffff0000u));
+            w.z = (i32)((L.y & 0xffffu) | R.y << 16);
+            w.w = (i32)(L.y >> 16 | (R.y & 0xffff0000u));
+            *reinterpret_cast<og_v4i *>(rows[2 * fr].pcm + (16 * ch + 4 * q) * 2) = w;
+        }
+    }
+    ss->celt.deemph[c] = m;
 }
 
 // ---- context ----------------------------------------------------------------------------------------
