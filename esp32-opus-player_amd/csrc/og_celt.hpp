@@ -606,6 +606,7 @@ OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, in
     // at each other's results (no barrier in between, their history loads overlap)
     int chunk = OG_MIN(T0, T1) - 2;
     int end = g1 == 0 ? overlap : N; // with g1 == 0 only the cross-fade part changes the signal
+#ifdef OG_HOST_EMUL
     for (int base = 0; base < end; base += chunk) {
         OG_SYNC();
         OG_FOR_LANES(l, chunk) {
@@ -628,6 +629,46 @@ OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, in
             syn_buf()[p] = clampsym(y, SIG_SAT);
         }
     }
+#else
+    // 64 consecutive samples per step: the five taps of lane l are elements e[l] .. e[l+4] of one 68-element window of the
+    // signal (e[j] = x[p0 - T - 2 + j]).  Lane l fetches e[l+4] only; the other four arrive by shifting that register one
+    // lane at a time (DPP wave_shr:1), with e[3] .. e[0] (fetched by lanes 0..3) fed in at lane 0.
+    for (int base = 0; base < end; base += chunk) {
+        OG_SYNC();
+        const int lim = OG_MIN(chunk, end - base);
+        for (int it = 0; it < lim; it += 64) {
+            const int i = base + it + OG_LANE, p = off + i;
+            const bool live = it + OG_LANE < lim;
+            const i32 y0 = live ? syn_buf()[p] : 0;
+            auto window = [&](int T, i32 &t4, i32 &t3, i32 &t2, i32 &t1, i32 &t0) {
+                // t0 = x[p-T+2] (e[l+4]) ... t4 = x[p-T-2] (e[l]); indices past this step's last live sample are clamped
+                const int q = OG_MIN(p, off + base + lim - 1) - T + 2;
+                t0 = syn_at(st, c, q);
+                const i32 w = OG_LANE < 4 ? syn_at(st, c, off + base + it - T - 2 + OG_LANE) : 0;
+                t1 = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(w, 3), t0, 0x138, 0xf, 0xf, false);
+                t2 = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(w, 2), t1, 0x138, 0xf, 0xf, false);
+                t3 = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(w, 1), t2, 0x138, 0xf, 0xf, false);
+                t4 = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(w, 0), t3, 0x138, 0xf, 0xf, false);
+            };
+            i32 a4, a3, a2, a1, a0;
+            window(T1, a4, a3, a2, a1, a0);
+            i32 y;
+            if (base + it < overlap) { // (the cross-fade region is a whole number of steps only up to its last step)
+                i32 b4, b3, b2, b1, b0;
+                window(T0, b4, b3, b2, b1, b0);
+                if (i < overlap) {
+                    const i32 f = tr16(mul16_q15(rom_win120[i], rom_win120[i]));
+                    y = y0 + mul16x32_q15(mul16_q15(32767 - f, g00), b2) + mul16x32_q15(mul16_q15(32767 - f, g01), b1 + b3) +
+                        mul16x32_q15(mul16_q15(32767 - f, g02), b0 + b4) + mul16x32_q15(mul16_q15(f, g10), a2) +
+                        mul16x32_q15(mul16_q15(f, g11), a1 + a3) + mul16x32_q15(mul16_q15(f, g12), a0 + a4);
+                } else
+                    y = y0 + mul16x32_q15(g10, a2) + mul16x32_q15(g11, a1 + a3) + mul16x32_q15(g12, a0 + a4);
+            } else
+                y = y0 + mul16x32_q15(g10, a2) + mul16x32_q15(g11, a1 + a3) + mul16x32_q15(g12, a0 + a4);
+            if (live) syn_buf()[p] = clampsym(y, SIG_SAT);
+        }
+    }
+#endif
     OG_SYNC();
 }
 
