@@ -633,6 +633,19 @@ OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, in
     // 64 consecutive samples per step: the five taps of lane l are elements e[l] .. e[l+4] of one 68-element window of the
     // signal (e[j] = x[p0 - T - 2 + j]).  Lane l fetches e[l+4] only; the other four arrive by shifting that register one
     // lane at a time (DPP wave_shr:1), with e[3] .. e[0] (fetched by lanes 0..3) fed in at lane 0.
+    // The ring head does not move during the filter: read it once (a reload per tap would put an HBM round trip in front of
+    // every history load).  LDS taps are plain LDS reads (index clamped), only the history taps branch to a global load --
+    // never one generic pointer for both.
+    const int ring_pos = OG_UNI(st->ring_pos);
+    // (explicit address spaces: two generic pointers would be folded back into one flat load)
+    const __attribute__((address_space(1))) i32 *ring = (const __attribute__((address_space(1))) i32 *)st->ring[c];
+    const __attribute__((address_space(3))) i32 *lds = (const __attribute__((address_space(3))) i32 *)syn_buf();
+    auto tap_at = [&](int idx) -> i32 {
+        const i32 in_lds = lds[OG_MAX(idx, 0)];
+        i32 in_ring = 0;
+        if (idx < 0) in_ring = ring[(ring_pos + idx) & RING_MASK];
+        return idx < 0 ? in_ring : in_lds;
+    };
     for (int base = 0; base < end; base += chunk) {
         OG_SYNC();
         const int lim = OG_MIN(chunk, end - base);
@@ -643,8 +656,8 @@ OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, in
             auto window = [&](int T, i32 &t4, i32 &t3, i32 &t2, i32 &t1, i32 &t0) {
                 // t0 = x[p-T+2] (e[l+4]) ... t4 = x[p-T-2] (e[l]); indices past this step's last live sample are clamped
                 const int q = OG_MIN(p, off + base + lim - 1) - T + 2;
-                t0 = syn_at(st, c, q);
-                const i32 w = OG_LANE < 4 ? syn_at(st, c, off + base + it - T - 2 + OG_LANE) : 0;
+                t0 = tap_at(q);
+                const i32 w = OG_LANE < 4 ? tap_at(off + base + it - T - 2 + OG_LANE) : 0;
                 t1 = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(w, 3), t0, 0x138, 0xf, 0xf, false);
                 t2 = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(w, 2), t1, 0x138, 0xf, 0xf, false);
                 t3 = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(w, 1), t2, 0x138, 0xf, 0xf, false);
