@@ -26,7 +26,9 @@ struct Rc {
 struct RcLane : Rc {
     const u8 *buf;
 #ifndef OG_HOST_EMUL
-    const u32 *words; // buf rounded down to a 4-byte boundary
+    // buf rounded down to a 4-byte boundary.  Explicitly a global-memory pointer: through a generic one these prefetches
+    // become flat loads, which also count against lgkmcnt -- every LDS wait would then wait for the prefetch as well.
+    const __attribute__((address_space(1))) u32 *words;
     u32 shift;        // buf - (const u8 *)words
     i32 last_word;    // index of the last word that overlaps the packet
     u32 f_cur, f_next, b_cur, b_next;
@@ -51,7 +53,7 @@ OG_DEV u32 rc_lane_word(const RcLane &rc, i32 w) { return (w >= 0 && w <= rc.las
 OG_DEV void rc_lane_attach(RcLane &rc, const u8 *buf, u32 len) { // call before rc_init
     rc.buf = buf;
     const unsigned long long a = (unsigned long long)buf;
-    rc.words = reinterpret_cast<const u32 *>(a & ~3ull);
+    rc.words = (const __attribute__((address_space(1))) u32 *)(a & ~3ull);
     rc.shift = (u32)(a & 3ull);
     rc.last_word = len ? (i32)((rc.shift + len - 1) >> 2) : -1;
     rc.f_idx = 0;
