@@ -87,12 +87,13 @@ __global__ void __launch_bounds__(64, OG_SILK_WAVES) k_silk_synth(const FrameDes
 }
 
 // SILK-only and hybrid frames, entropy half: ONE FRAME PER LANE (og_silk_parse.hpp).  Lane l of workgroup g decodes the
-// side information and pulses of frame 64 g + l into srecs[frame] and leaves the coder state in handoff[frame].
+// side information and pulses of frame OG_SP_LANES g + l (l < OG_SP_LANES = 32; the upper lanes idle) into srecs[frame] and leaves the coder state in handoff[frame].
 __global__ void __launch_bounds__(64, 2) k_silk_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
                                                       const StreamState *st, SilkRec *srecs, SilkHandoff *handoff, int n,
                                                       int n_streams) {
     silk_tables_load();
-    const int f = (int)blockIdx.x * 64 + (int)threadIdx.x;
+    if ((int)threadIdx.x >= OG_SP_LANES) return;
+    const int f = (int)blockIdx.x * OG_SP_LANES + (int)threadIdx.x;
     if (f >= n) return;
     const FrameDesc d = descs[f];
     const int mode = desc_mode(d.flags);
@@ -107,13 +108,14 @@ __global__ void __launch_bounds__(64, 2) k_silk_parse(const FrameDesc *__restric
 #endif
 }
 
-// Split CELT path, first half: ONE FRAME PER LANE.  Lane l of workgroup g parses frame 64 g + l (range decoder,
+// Split CELT path, first half: ONE FRAME PER LANE.  Lane l < OG_PL_LANES (= 32) of workgroup g parses frame OG_PL_LANES g + l (range decoder,
 // energies, allocation, band budget logic, PVQ indices) into recs[frame]; no vector work, no cross-lane traffic.
 __global__ void __launch_bounds__(64, 2) k_celt_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
                                                       const StreamState *st, ParseRec *recs, int n, int n_streams,
                                                       const SilkHandoff *handoff) {
     parse_tables_load();
-    const int f = (int)blockIdx.x * 64 + (int)threadIdx.x;
+    if ((int)threadIdx.x >= OG_PL_LANES) return;
+    const int f = (int)blockIdx.x * OG_PL_LANES + (int)threadIdx.x;
     if (f >= n) return;
     const FrameDesc d = descs[f];
     const int mode = desc_mode(d.flags);
@@ -424,7 +426,7 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
             handoff = (SilkHandoff *)ctx->d_handoff;
             srecs = (SilkRec *)ctx->d_srecs;
             // SILK-only and hybrid frames: entropy half, one frame per lane
-            hipLaunchKernelGGL(k_silk_parse, dim3((n + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
+            hipLaunchKernelGGL(k_silk_parse, dim3((n + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
                                (const StreamState *)ctx->d_streams, srecs, handoff, n, ctx->n_streams);
         }
     }
@@ -445,7 +447,7 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
     if (ctx->split_celt) {
         // CELT-only frames and the CELT half of hybrid frames: parse (one frame per lane) -> records in HBM ->
         // reconstruct (one frame per wave) -> de-emphasis, SILK mix and PCM (one (frame, channel) per lane)
-        hipLaunchKernelGGL(k_celt_parse, dim3((n + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
+        hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_LANES - 1) / OG_PL_LANES), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
                            (const StreamState *)ctx->d_streams, (ParseRec *)ctx->d_recs, n, ctx->n_streams,
                            (const SilkHandoff *)handoff);
         hipLaunchKernelGGL(k_celt_recon, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, ctx->d_streams,

@@ -94,7 +94,11 @@ static_assert(sizeof(ParseRec) % 16 == 0, "record alignment");
 // =====================================================================================================
 //  parse: one frame per lane
 // =====================================================================================================
-#define OG_PL_LANES OG_NLANES
+// Frames per parse wave (= lanes that carry a frame; the [element][lane] arrays below are that wide).  Fewer than the wave's
+// 64 lanes means more, smaller waves: less LDS per wave (more of them resident per SIMD) and a shorter divergent union.
+#ifndef OG_PL_LANES
+#define OG_PL_LANES (OG_NLANES >= 32 ? 32 : OG_NLANES) // measured: 64 / 32 / 16 frames per wave, see DESIGN.md section 6
+#endif
 struct ParseLds { // [element][lane]: lanes of a wave touch consecutive addresses, no bank conflicts
     i32 pulses[NBANDS][OG_PL_LANES];
     i16 bandE[2 * NBANDS][OG_PL_LANES];

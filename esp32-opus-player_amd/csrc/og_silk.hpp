@@ -594,14 +594,14 @@ OG_DEV void silk_decode_parameters(const i16 *prevNLSF_Q15, K &k, int fs_kHz, in
 
 // ---- lane-private parameter decoding for the parse kernel ----------------------------------------------------------
 struct SilkParLds { // [element][lane]
-    i16 nlsf[SILK_MAX_LPC][OG_NLANES], nlsf0[SILK_MAX_LPC][OG_NLANES], res_Q10[SILK_MAX_LPC][OG_NLANES];
-    i32 pred_Q8[SILK_MAX_LPC][OG_NLANES], cosLSF[SILK_MAX_LPC][OG_NLANES], P[SILK_MAX_LPC / 2 + 1][OG_NLANES],
-        Q[SILK_MAX_LPC / 2 + 1][OG_NLANES], a32[SILK_MAX_LPC][OG_NLANES], Atmp[SILK_MAX_LPC][OG_NLANES];
+    i16 nlsf[SILK_MAX_LPC][OG_SP_LANES], nlsf0[SILK_MAX_LPC][OG_SP_LANES], res_Q10[SILK_MAX_LPC][OG_SP_LANES];
+    i32 pred_Q8[SILK_MAX_LPC][OG_SP_LANES], cosLSF[SILK_MAX_LPC][OG_SP_LANES], P[SILK_MAX_LPC / 2 + 1][OG_SP_LANES],
+        Q[SILK_MAX_LPC / 2 + 1][OG_SP_LANES], a32[SILK_MAX_LPC][OG_SP_LANES], Atmp[SILK_MAX_LPC][OG_SP_LANES];
 };
 OG_LDS SilkParLds g_silk_par;
 struct SilkParLane {
-    typedef ArrV<i16, OG_NLANES> A16;
-    typedef ArrV<i32, OG_NLANES> A32;
+    typedef ArrV<i16, OG_SP_LANES> A16;
+    typedef ArrV<i32, OG_SP_LANES> A32;
     static OG_MEMBER A16 nlsf() { A16 r = {&g_silk_par.nlsf[0][OG_LANE]}; return r; }
     static OG_MEMBER A16 nlsf0() { A16 r = {&g_silk_par.nlsf0[0][OG_LANE]}; return r; }
     static OG_MEMBER A16 res_Q10() { A16 r = {&g_silk_par.res_Q10[0][OG_LANE]}; return r; }

@@ -144,8 +144,12 @@ OG_DEV void shell_split_tab(RcLane &rc, int &c1, int &c2, int p, int table) {
     }
 }
 
+// Frames per SILK parse wave (see OG_PL_LANES, og_celt_split.hpp): width of the [element][lane] arrays of k_silk_parse.
+#ifndef OG_SP_LANES
+#define OG_SP_LANES (OG_NLANES >= 32 ? 32 : OG_NLANES) // measured: 64 / 32 / 16 frames per wave, see DESIGN.md section 6
+#endif
 // per-lane block bookkeeping of the pulse decoder: sum_pulses (<= 16) | nLshifts (<= 10) << 5 per 16-sample block
-OG_LDS u16 g_silk_blk[SILK_REC_FRAME / 16][OG_NLANES];
+OG_LDS u16 g_silk_blk[SILK_REC_FRAME / 16][OG_SP_LANES];
 
 // silk_decode_pulses silk.cpp:898.  The pulses of a channel go to the record (HBM) as they are produced; the later
 // passes (LSBs, signs) re-read them, one value ahead of their use.
