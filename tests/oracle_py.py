@@ -12,6 +12,25 @@ LIB = os.path.join(ROOT, "oracle", "liboc_oracle.so")
 MODE_SILK, MODE_HYBRID, MODE_CELT = 1000, 1001, 1002
 
 
+def usable_cpus():
+    """CPUs this process can actually use: the smaller of the affinity mask and the cgroup CPU quota (a GPU box shows all
+    of the host's logical CPUs but grants a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2: "<quota> <period>" or "max <period>"
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 class Oracle:
     def __init__(self, lib):
         self.lib = lib
@@ -38,6 +57,27 @@ class Oracle:
         ok = self.lib.oc_batch_decode(channels, toc, pay.ctypes.data, ns, nf, L, s0, s1,
                                       pcm.ctypes.data if want_pcm else None)
         return pcm, ok
+
+    def batch_decode_threads(self, channels, toc, payloads, threads=None):
+        """batch_decode over all streams, the stream range split over `threads` host threads (the C call releases the GIL).
+        -> (pcm int16 [streams, frames, 960, ch], frames decoded without error)."""
+        import threading
+        nf, ns, L = payloads.shape
+        threads = max(1, min(threads or usable_cpus(), ns))
+        pay = np.ascontiguousarray(payloads)
+        pcm = np.zeros((ns, nf, 960, channels), dtype=np.int16)
+        oks = [0] * threads
+        cuts = [ns * t // threads for t in range(threads + 1)]
+
+        def work(t):
+            oks[t] = self.lib.oc_batch_decode(channels, toc, pay.ctypes.data, ns, nf, L, cuts[t], cuts[t + 1], pcm.ctypes.data)
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        return pcm, sum(oks)
 
     def decoder(self, channels):
         return OracleDecoder(self, channels)

@@ -1,59 +1,59 @@
-"""GPU parity at BASELINE.json's full batch size (65,536 streams per step), through size-independent properties:
+"""GPU parity at BASELINE.json's full batch sizes, every PCM sample of every stream of every
+step compared with the CPU oracle:
 
-  * placement independence -- the second half of the batch replays the payloads of the first half: stream i and
-    stream i + n/2 must produce identical PCM and identical final coder state, whatever wave / lane / CU decodes them;
-  * sampled oracle comparison -- a few hundred streams spread over the batch are compared with the CPU oracle, every
-    sample, every step;
-  * every frame of every step reports 960 samples.
-One test per mode (CELT-only = the bench workload, SILK-only, hybrid)."""
+  * C2  65,536 CELT-FB stereo streams (the bench workload),
+  * C3  65,536 SILK-NB stereo streams,
+  *     65,536 hybrid FB stereo streams,
+  * C4  262,144 hybrid FB stereo streams,
+
+plus: every frame of every step reports 960 samples.  The oracle side runs on the host threads this process is granted."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-N = 65536
 STEPS = 3
 
 
-def _run(pkg, oracle, ctx, toc, L, sample_every):
-    half = N // 2
-    pay_half = pkg.lcg_payloads(half, STEPS, L)
-    pay = np.concatenate([pay_half, pay_half], axis=1)  # [steps, N, L]
-    ctx.streams_alloc(N, 2)
-    d_desc = ctx.dev_alloc(16 * N)
-    d_arena = ctx.dev_alloc(N * (L + 1) + 16)
-    d_pcm = ctx.dev_alloc(N * 960 * 2 * 2)
-    d_res = ctx.dev_alloc(4 * N)
-    out = np.zeros((N, 960, 2), dtype=np.int16)
-    res = np.zeros(N, dtype=np.int32)
-    picks = np.arange(0, half, sample_every)
-    pk = [[bytes([toc]) + pay_half[f, s].tobytes() for f in range(STEPS)] for s in picks]
-    ref, rets = oracle.decode_streams(2, pk)
-    assert (rets == 960).all()
-    for f in range(STEPS):
-        arena, descs = pkg.build_step(toc, pay[f])
-        ctx.h2d(d_arena, arena)
-        ctx.h2d(d_desc, descs)
-        ctx.decode_step_device(N, d_desc, d_arena, d_pcm, d_res)
-        ctx.synchronize()
-        ctx.d2h(out, d_pcm)
-        ctx.d2h(res, d_res)
-        assert (res == 960).all(), f"step {f}: {(res != 960).sum()} frames failed"
-        twin = np.nonzero((out[:half] != out[half:]).reshape(half, -1).any(axis=1))[0]
-        assert twin.size == 0, f"step {f}: {twin.size} twin streams differ, first {twin[:5]}"
-        bad = np.nonzero((out[picks] != ref[:, f]).reshape(len(picks), -1).any(axis=1))[0]
-        assert bad.size == 0, f"step {f}: {bad.size} sampled streams differ from the oracle, first {picks[bad[:5]]}"
-    for p in (d_desc, d_arena, d_pcm, d_res):
-        ctx.dev_free(p)
+def _run(pkg, oracle, ctx, toc, L, n, steps):
+    pay = pkg.lcg_payloads(n, steps, L)  # [steps, n, L], one LCG stream per decoder stream
+    ref, ok = oracle.batch_decode_threads(2, toc, pay)  # [n, steps, 960, 2]
+    assert ok == n * steps
+    ctx.streams_alloc(n, 2)
+    d_desc = ctx.dev_alloc(16 * n)
+    d_arena = ctx.dev_alloc(n * (L + 1) + 16)
+    d_pcm = ctx.dev_alloc(n * 960 * 2 * 2)
+    d_res = ctx.dev_alloc(4 * n)
+    out = np.zeros((n, 960, 2), dtype=np.int16)
+    res = np.zeros(n, dtype=np.int32)
+    try:
+        for f in range(steps):
+            arena, descs = pkg.build_step(toc, pay[f])
+            ctx.h2d(d_arena, arena)
+            ctx.h2d(d_desc, descs)
+            ctx.decode_step_device(n, d_desc, d_arena, d_pcm, d_res)
+            ctx.synchronize()
+            ctx.d2h(out, d_pcm)
+            ctx.d2h(res, d_res)
+            assert (res == 960).all(), f"step {f}: {(res != 960).sum()} frames failed"
+            bad = np.nonzero((out != ref[:, f]).reshape(n, -1).any(axis=1))[0]
+            assert bad.size == 0, f"step {f}: {bad.size} of {n} streams differ from the oracle, first {bad[:5]}"
+    finally:
+        for p in (d_desc, d_arena, d_pcm, d_res):
+            ctx.dev_free(p)
 
 
 def test_fullsize_celt(pkg, oracle, gpu_ctx):
-    _run(pkg, oracle, gpu_ctx, pkg.TOC_CELT_FB_STEREO, 160, 127)
+    _run(pkg, oracle, gpu_ctx, pkg.TOC_CELT_FB_STEREO, 160, 65536, STEPS)
 
 
 def test_fullsize_silk(pkg, oracle, gpu_ctx):
-    _run(pkg, oracle, gpu_ctx, pkg.TOC_SILK_NB_STEREO, 40, 127)
+    _run(pkg, oracle, gpu_ctx, pkg.TOC_SILK_NB_STEREO, 40, 65536, STEPS)
 
 
 def test_fullsize_hybrid(pkg, oracle, gpu_ctx):
-    _run(pkg, oracle, gpu_ctx, pkg.TOC_HYBRID_FB_STEREO, 120, 127)
+    _run(pkg, oracle, gpu_ctx, pkg.TOC_HYBRID_FB_STEREO, 120, 65536, STEPS)
+
+
+def test_fullsize_hybrid_c4(pkg, oracle, gpu_ctx):
+    _run(pkg, oracle, gpu_ctx, pkg.TOC_HYBRID_FB_STEREO, 120, 262144, 2)

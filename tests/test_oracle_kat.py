@@ -50,3 +50,14 @@ def test_kat2_fresh_state_per_mode(oracle):
             assert r == 960
             h = fnv1a_u16(out[:960], h)
         assert h == expect[m], (m, hex(h))
+
+
+def test_threaded_batch_decode_matches_single_thread(pkg, oracle):
+    """The threaded helper the full-size GPU tests rely on returns exactly what one thread returns (streams are
+    independent; each thread owns a stream range)."""
+    for toc, L in ((pkg.TOC_CELT_FB_STEREO, 160), (pkg.TOC_SILK_NB_STEREO, 40), (pkg.TOC_HYBRID_FB_STEREO, 120)):
+        pay = pkg.lcg_payloads(37, 3, L)
+        one, ok1 = oracle.batch_decode(2, toc, pay)
+        many, okn = oracle.batch_decode_threads(2, toc, pay, threads=5)
+        assert ok1 == okn == 37 * 3
+        assert (one == many).all()
