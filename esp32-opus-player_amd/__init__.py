@@ -24,6 +24,8 @@ EXPORTS = [
     "opusgpu_dev_alloc", "opusgpu_dev_free", "opusgpu_memcpy_h2d", "opusgpu_memcpy_d2h",
     "opusgpu_decode_step_device", "opusgpu_synchronize", "opusgpu_event_create", "opusgpu_event_record",
     "opusgpu_event_elapsed_ms", "opusgpu_event_destroy", "opusgpu_stream_state_get",
+    "opusgpu_pages_demux", "opusgpu_page_batch_steps", "opusgpu_page_batch_step", "opusgpu_page_batch_arena",
+    "opusgpu_page_batch_free",
 ]
 
 
@@ -32,6 +34,11 @@ class FrameDesc(C.Structure):
 
 
 DESC_DTYPE = np.dtype([("stream", "<i4"), ("offset", "<i4"), ("len", "<i4"), ("flags", "<i4")])
+# opusgpu_page_info (include/opusgpu.h)
+PAGE_INFO_DTYPE = np.dtype([("status", "<i4"), ("packets", "<i4"), ("first_step", "<i4"), ("header_type", "<i4"),
+                            ("serial", "<u4"), ("seqno", "<u4"), ("granulepos", "<i8")])
+PAGE_BAD_CAPTURE, PAGE_BAD_CRC, PAGE_SPANS, PAGE_BAD_PACKET, PAGE_BAD_STREAM = -200, -201, -202, -203, -204
+PAGES_VERIFY_CRC, PAGES_GROUP_BY_MODE = 1, 2
 
 _lib = None
 
@@ -71,6 +78,13 @@ def load_lib():
     lib.opusgpu_event_elapsed_ms.argtypes = [vp, vp, vp, C.POINTER(C.c_float)]
     lib.opusgpu_event_destroy.argtypes = [vp, vp]
     lib.opusgpu_stream_state_get.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.opusgpu_pages_demux.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    lib.opusgpu_page_batch_steps.argtypes = [vp]
+    lib.opusgpu_page_batch_step.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
+    lib.opusgpu_page_batch_arena.argtypes = [vp, C.POINTER(C.c_size_t)]
+    lib.opusgpu_page_batch_arena.restype = vp
+    lib.opusgpu_page_batch_free.argtypes = [vp]
+    lib.opusgpu_page_batch_free.restype = None
     _lib = lib
     return lib
 
@@ -87,6 +101,60 @@ def packet_to_frames(packet: bytes, stream: int = 0):
     if n < 0:
         return n
     return [(d[i].offset, d[i].len, d[i].flags) for i in range(n)]
+
+
+class PageBatch:
+    """Decode steps made from a batch of Ogg pages by opusgpu_pages_demux (host only, include/opusgpu.h).
+    `blob` holds the pages back to back, page i = blob[offsets[i] : offsets[i] + lens[i]]; stream_ids[i] is the decoder
+    stream page i belongs to.  info: one PAGE_INFO_DTYPE record per page (status = frames contributed or PAGE_*)."""
+
+    def __init__(self, blob, offsets, lens, stream_ids, flags=PAGES_VERIFY_CRC | PAGES_GROUP_BY_MODE, threads=1):
+        lib = load_lib()
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offsets = np.asarray(offsets, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        ids = np.ascontiguousarray(stream_ids, dtype=np.int32)
+        n = len(offsets)
+        if not (len(lens) == n and len(ids) == n):
+            raise ValueError("offsets, lens and stream_ids must have one entry per page")
+        if n and (offsets.min() < 0 or (offsets + lens).max() > blob.size):
+            raise ValueError("a page lies outside the blob")
+        ptrs = (np.uint64(blob.ctypes.data) + offsets.astype(np.uint64)).astype(np.uint64)
+        self.info = np.zeros(n, dtype=PAGE_INFO_DTYPE)
+        h = C.c_void_p()
+        r = lib.opusgpu_pages_demux(n, ptrs.ctypes.data, lens.ctypes.data, ids.ctypes.data, flags, threads,
+                                    self.info.ctypes.data, C.byref(h))
+        if r != 0:
+            raise OpusGpuError(f"opusgpu_pages_demux failed: {r}")
+        self.lib, self.h = lib, h
+        self.n_steps = lib.opusgpu_page_batch_steps(h)
+        nbytes = C.c_size_t()
+        a = lib.opusgpu_page_batch_arena(h, C.byref(nbytes))
+        self.arena = np.ctypeslib.as_array((C.c_uint8 * nbytes.value).from_address(a)) if nbytes.value else np.zeros(0, np.uint8)
+
+    def step(self, k):
+        """-> (descriptors [DESC_DTYPE], page index of every slot [int32]); views into the batch, valid until close()."""
+        d, sp = C.c_void_p(), C.c_void_p()
+        n = self.lib.opusgpu_page_batch_step(self.h, k, C.byref(d), C.byref(sp))
+        if n < 0:
+            raise IndexError(k)
+        if n == 0:
+            return np.zeros(0, dtype=DESC_DTYPE), np.zeros(0, dtype=np.int32)
+        descs = np.frombuffer((C.c_uint8 * (16 * n)).from_address(d.value), dtype=DESC_DTYPE)
+        pages = np.frombuffer((C.c_uint8 * (4 * n)).from_address(sp.value), dtype=np.int32)
+        return descs, pages
+
+    def close(self):
+        if self.h:
+            self.lib.opusgpu_page_batch_free(self.h)
+            self.h = None
+            self.arena = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:
@@ -198,6 +266,47 @@ def lcg_payloads(n_streams, n_frames, payload_len, seed_base=0x9E3779B9):
                 x = x * a + c
                 out[f, :, i] = (x >> np.uint32(24)).astype(np.uint8)
     return out
+
+
+_CRC_T = None
+
+
+def ogg_crc_rows(rows):
+    """Ogg page CRC-32 (polynomial 0x04c11db7, MSB first, zero start; src/ogg.cpp:439) of every row of a uint8 matrix,
+    all rows in step: one table lookup per byte column."""
+    global _CRC_T
+    if _CRC_T is None:
+        t = np.arange(256, dtype=np.uint64) << np.uint64(24)
+        for _ in range(8):
+            t = np.where(t & np.uint64(0x80000000), (t << np.uint64(1)) ^ np.uint64(0x04C11DB7), t << np.uint64(1)) & np.uint64(0xFFFFFFFF)
+        _CRC_T = t.astype(np.uint32)
+    crc = np.zeros(rows.shape[0], dtype=np.uint32)
+    for j in range(rows.shape[1]):
+        crc = (crc << np.uint32(8)) ^ _CRC_T[(crc >> np.uint32(24)) ^ rows[:, j]]
+    return crc
+
+
+def build_pages(toc, payloads, serials, seqno=2, granule_step=960):
+    """Synthetic Ogg pages, one per stream: page s carries payloads[:, s] as code-0 packets (TOC + payload each).
+    payloads uint8 [packets, n, L] with L + 1 < 255 (one lacing value per packet).  Returns uint8 [n, page_len]:
+    "OggS", version 0, header type 0, granule position packets * granule_step, serial number, page sequence number,
+    CRC, segment table, packets (src/ogg.cpp:439-480 for the layout the reference checks)."""
+    npk, n, L = payloads.shape
+    if L + 1 >= 255 or npk > 255:
+        raise ValueError("one lacing value per packet, at most 255 packets")
+    hdr = 27 + npk
+    pages = np.zeros((n, hdr + npk * (L + 1)), dtype=np.uint8)
+    pages[:, 0:4] = np.frombuffer(b"OggS", dtype=np.uint8)
+    pages[:, 6:14] = np.frombuffer(np.int64(npk * granule_step).tobytes(), dtype=np.uint8)
+    pages[:, 14:18] = np.asarray(serials, dtype="<u4").reshape(n, 1).view(np.uint8)
+    pages[:, 18:22] = np.frombuffer(np.uint32(seqno).tobytes(), dtype=np.uint8)
+    pages[:, 26] = npk
+    pages[:, 27:hdr] = L + 1
+    body = pages[:, hdr:].reshape(n, npk, L + 1)
+    body[:, :, 0] = toc
+    body[:, :, 1:] = payloads.transpose(1, 0, 2)
+    pages[:, 22:26] = ogg_crc_rows(pages).astype("<u4").reshape(n, 1).view(np.uint8)
+    return pages
 
 
 def build_step(toc, payloads):

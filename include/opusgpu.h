@@ -100,6 +100,52 @@ int opusgpu_event_destroy(opusgpu_ctx *ctx, void *event);
 /* Copies stream `index`'s raw state record to the host (tests / checkpointing). */
 int opusgpu_stream_state_get(opusgpu_ctx *ctx, int index, void *dst, size_t bytes);
 
+/* ---- Ogg page ingest at scale (host only, no GPU involved) --------------------------------------
+ * The batched equivalent of what the reference does one page at a time: page sync + header checks
+ * (ogg_sync_pageseek src/ogg.cpp:839-923), the page CRC (ogg_page_checksum_set :439-480), lacing values -> packets
+ * (ogg_stream_pagein / ogg_stream_packetout :969-1097, :1192; op_collect_audio_packets src/opusfile.cpp:424-466) and
+ * the TOC split of every packet (opusgpu_packet_to_frames above).  Input: n complete Ogg pages, each tagged by the
+ * caller with the decoder stream it belongs to (the caller owns the serial-number -> stream mapping).  Output: decode
+ * steps.  Step k holds one descriptor per page that has a k-th 20 ms frame, ready for opusgpu_decode_step_device after
+ * the arena and the step's table are copied to the device; frames of one page land in consecutive steps, and a second
+ * page of the same stream in the same call starts where the first one ends, so a stream never appears twice in a step.
+ * A page must carry whole packets: one that starts with the tail or ends with the head of a spanning packet is
+ * reported (OPUSGPU_PAGE_SPANS) and contributes nothing; the file surface (opusfile.h) handles such streams. */
+#define OPUSGPU_PAGE_BAD_CAPTURE (-200) /* no "OggS", stream structure version != 0, or shorter than its header says */
+#define OPUSGPU_PAGE_BAD_CRC (-201)     /* only with OPUSGPU_PAGES_VERIFY_CRC */
+#define OPUSGPU_PAGE_SPANS (-202)
+#define OPUSGPU_PAGE_BAD_PACKET (-203)  /* a packet with a valid duration fails the frame split (opus_packet_parse_impl): the
+                                           reference decodes the page's earlier packets and then reports the error; here
+                                           the whole page is dropped.  Packets whose TOC sequence has no valid duration
+                                           are skipped like the reference does (src/opusfile.cpp:453-459). */
+#define OPUSGPU_PAGE_BAD_STREAM (-204)  /* negative stream id */
+
+#define OPUSGPU_PAGES_VERIFY_CRC 1
+#define OPUSGPU_PAGES_GROUP_BY_MODE 2 /* order each step's table SILK-only, hybrid, CELT-only (stable): uniform waves */
+
+typedef struct opusgpu_page_info { /* 32 bytes */
+    int32_t status;      /* >= 0: 20 ms frames the page contributes; < 0: OPUSGPU_PAGE_* */
+    int32_t packets;     /* packets on the page */
+    int32_t first_step;  /* step of the page's first frame */
+    int32_t header_type; /* bit 0 continued, bit 1 first page of the stream, bit 2 last page */
+    uint32_t serial, seqno;
+    int64_t granulepos;
+} opusgpu_page_info;
+
+typedef struct opusgpu_page_batch opusgpu_page_batch; /* owns the step tables and the packet arena of one demux call */
+
+/* threads <= 0: one.  info (n_pages entries) may be NULL.  Returns OPUSGPU_OK (bad pages are reported per page, not as
+ * a failure of the call), OPUSGPU_BAD_ARG or OPUSGPU_ALLOC_FAIL. */
+int opusgpu_pages_demux(int n_pages, const uint8_t *const *pages, const int32_t *page_lens, const int32_t *stream_ids,
+                        int flags, int threads, opusgpu_page_info *info, opusgpu_page_batch **out);
+int opusgpu_page_batch_steps(const opusgpu_page_batch *b);
+/* Step `step`: returns its descriptor count and points *descs at the table and *slot_pages (may be NULL) at the index
+ * of the input page each descriptor came from (the PCM block of slot s belongs to page (*slot_pages)[s]). */
+int opusgpu_page_batch_step(const opusgpu_page_batch *b, int step, const opusgpu_frame_desc **descs,
+                            const int32_t **slot_pages);
+const uint8_t *opusgpu_page_batch_arena(const opusgpu_page_batch *b, size_t *bytes); /* descriptor offsets index this */
+void opusgpu_page_batch_free(opusgpu_page_batch *b);
+
 #ifdef __cplusplus
 }
 #endif
