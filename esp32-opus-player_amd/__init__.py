@@ -227,6 +227,13 @@ class Context:
         self._chk(self.lib.opusgpu_decode_step_device(self.h, n, d_descs, d_arena, d_pcm, d_result, stream),
                   "opusgpu_decode_step_device")
 
+    def decode_work_step(self, base, layout, k, d_pcm, d_result):
+        """Step k of a packed work buffer (shard.pack_work / shard.WorkLayout) resident in HBM at address `base`: the
+        step's descriptor table and the arena are used where they lie."""
+        base = base.value if isinstance(base, C.c_void_p) else int(base)
+        self.decode_step_device(layout.counts[k], C.c_void_p(base + layout.desc_at[k]), C.c_void_p(base + layout.arena_at),
+                                d_pcm, d_result)
+
     def synchronize(self):
         self._chk(self.lib.opusgpu_synchronize(self.h), "opusgpu_synchronize")
 

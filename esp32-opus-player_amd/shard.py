@@ -1,16 +1,73 @@
 """Multi-GPU plumbing of the decode path: one process per GPU, streams partitioned across ranks.
 
 The Opus decode path has no cross-stream data flow: every stream's state lives on
-exactly one GPU and a decode step never exchanges payload or PCM between ranks.  The only collectives are
-the ones the benchmark contract needs -- a barrier around the timed region and a MAX over the ranks'
-elapsed times -- so this module is deliberately small.  `torch.distributed` is plumbing here: backend
-"nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+exactly one GPU and a decode step never exchanges payload or PCM between ranks.  The collectives are the
+ones the benchmark contract needs -- a barrier around the timed region and a MAX over the ranks' elapsed
+times -- plus the one exchange the path does have when work arrives at a single ingest point: the
+work-queue scatter (`pack_work` / `Ranks.scatter_bytes`), which hands every rank its decode steps (descriptor
+tables + packet arena, made from Ogg pages by opusgpu_pages_demux) in one buffer, straight into its HBM.
+`torch.distributed` is plumbing here: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 """
 import os
 
+import numpy as np
+
+# ---- work queue: one rank's decode steps in one buffer ------------------------------------------------------
+# [ header: int64 x WORK_HEADER_WORDS | descriptor tables of all steps, back to back | packet arena ], every part
+# starting on a 256-byte boundary.  header = magic, n_steps, total descriptors, arena bytes, then one count per step.
+WORK_MAGIC = 0x4F475751
+WORK_HEADER_WORDS = 1024
+WORK_HEADER_BYTES = 8 * WORK_HEADER_WORDS
+WORK_MAX_STEPS = WORK_HEADER_WORDS - 4
+
+
+def _pad256(n):
+    return (n + 255) & ~255
+
+
+def pack_work(batch):
+    """PageBatch (host) -> uint8 buffer in the layout above."""
+    n_steps = batch.n_steps
+    if n_steps > WORK_MAX_STEPS:
+        raise ValueError(f"{n_steps} steps do not fit the work header ({WORK_MAX_STEPS})")
+    tables = [batch.step(k)[0] for k in range(n_steps)]
+    counts = [len(t) for t in tables]
+    total = sum(counts)
+    arena = batch.arena if batch.arena is not None else np.zeros(0, np.uint8)
+    desc_at = WORK_HEADER_BYTES
+    arena_at = desc_at + _pad256(16 * total)
+    buf = np.zeros(arena_at + _pad256(arena.size), dtype=np.uint8)
+    hdr = buf[:WORK_HEADER_BYTES].view(np.int64)
+    hdr[0:4] = (WORK_MAGIC, n_steps, total, arena.size)
+    hdr[4:4 + n_steps] = counts
+    at = desc_at
+    for t in tables:
+        buf[at:at + 16 * len(t)] = t.view(np.uint8).reshape(-1)
+        at += 16 * len(t)
+    buf[arena_at:arena_at + arena.size] = arena
+    return buf
+
+
+class WorkLayout:
+    """Where the parts of a packed work buffer are (byte offsets from its start)."""
+
+    def __init__(self, header_bytes):
+        hdr = np.frombuffer(bytes(header_bytes[:WORK_HEADER_BYTES]), dtype=np.int64)
+        if hdr[0] != WORK_MAGIC:
+            raise ValueError("not a packed work buffer")
+        self.n_steps, self.total, self.arena_bytes = int(hdr[1]), int(hdr[2]), int(hdr[3])
+        self.counts = [int(c) for c in hdr[4:4 + self.n_steps]]
+        self.desc_at = []
+        at = WORK_HEADER_BYTES
+        for c in self.counts:
+            self.desc_at.append(at)
+            at += 16 * c
+        self.arena_at = WORK_HEADER_BYTES + _pad256(16 * self.total)
+        self.nbytes = self.arena_at + _pad256(self.arena_bytes)
+
 
 class Ranks:
-    """Rank/world bookkeeping + the two collectives the path uses."""
+    """Rank/world bookkeeping + the collectives the path uses."""
 
     def __init__(self, backend=None, device=None):
         self.rank = int(os.environ.get("RANK", "0"))
@@ -66,6 +123,37 @@ class Ranks:
         t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
+
+    def scatter_bytes(self, buffers=None, src=0):
+        """The work-queue scatter: rank `src` passes one uint8 array per rank, every rank gets its own back -- as a numpy
+        array (one rank, or a CPU backend) or as a uint8 tensor in this rank's HBM (nccl: the bytes travel GPU to GPU).
+        Two collectives: the sizes, then the buffers padded to the largest."""
+        if self.dist is None:
+            return buffers[0]
+        import torch
+        sizes = torch.zeros(1, dtype=torch.int64, device=self.device)
+        if self.rank == src:
+            if len(buffers) != self.world:
+                raise ValueError("one buffer per rank")
+            all_sizes = [torch.tensor([b.size], dtype=torch.int64, device=self.device) for b in buffers]
+            cap = torch.tensor([max(b.size for b in buffers)], dtype=torch.int64, device=self.device)
+        else:
+            all_sizes = None
+            cap = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.dist.scatter(sizes, all_sizes, src=src)
+        self.dist.broadcast(cap, src=src)
+        cap = int(cap.item())
+        recv = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        parts = None
+        if self.rank == src:
+            parts = []
+            for b in buffers:
+                t = torch.zeros(cap, dtype=torch.uint8)
+                t[:b.size] = torch.from_numpy(np.ascontiguousarray(b))
+                parts.append(t.to(self.device))
+        self.dist.scatter(recv, parts, src=src)
+        recv = recv[:int(sizes.item())]
+        return recv.numpy() if recv.device.type == "cpu" else recv
 
     def close(self):
         if self.dist is not None:

@@ -1,0 +1,84 @@
+"""BASELINE config 5 on one GPU: mixed-mode Ogg pages -> host demux (opusgpu_pages_demux) -> packed work
+(shard.pack_work, what the work-queue scatter delivers) -> HBM -> decode steps; every PCM sample of every stream and step
+compared with the CPU oracle.  Modes 1:1:1 across streams (fixed within a stream), two chained pages per stream."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _shard():
+    spec = importlib.util.spec_from_file_location("og_shard", os.path.join(ROOT, "esp32-opus-player_amd", "shard.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _run(pkg, oracle, ctx, n, pages_per_stream, packets_per_page, threads):
+    shard = _shard()
+    modes = ((pkg.TOC_SILK_NB_STEREO, 40), (pkg.TOC_HYBRID_FB_STEREO, 120), (pkg.TOC_CELT_FB_STEREO, 160))
+    frames = pages_per_stream * packets_per_page
+    ids_of = [np.arange(m, n, 3, dtype=np.int32) for m in range(3)]
+    ref = [None] * 3
+    parts = []  # (page matrix, stream ids) in the order the pages enter the queue
+    for m, (toc, L) in enumerate(modes):
+        pay = pkg.lcg_payloads(len(ids_of[m]), frames, L, seed_base=0x9E3779B9 + m)
+        ref[m], ok = oracle.batch_decode_threads(2, toc, pay)
+        assert ok == len(ids_of[m]) * frames
+        for q in range(pages_per_stream):
+            pg = pkg.build_pages(toc, pay[q * packets_per_page:(q + 1) * packets_per_page], ids_of[m].astype(np.uint32) + 77, seqno=2 + q)
+            parts.append((q, pg, ids_of[m]))
+    parts.sort(key=lambda x: x[0])  # all first pages, then all second pages ...
+    blob = np.concatenate([pg.reshape(-1) for _, pg, _ in parts])
+    lens = np.concatenate([np.full(pg.shape[0], pg.shape[1], dtype=np.int32) for _, pg, _ in parts])
+    offs = np.concatenate([[0], np.cumsum(lens.astype(np.int64))[:-1]])
+    ids = np.concatenate([i for _, _, i in parts])
+    batch = pkg.PageBatch(blob, offs, lens, ids, threads=threads)
+    assert (batch.info["status"] == packets_per_page).all()
+    assert batch.n_steps == frames
+    work = shard.pack_work(batch)
+    batch.close()
+    lay = shard.WorkLayout(work)
+    assert lay.counts == [n] * frames
+    ctx.streams_alloc(n, 2)
+    d_work = ctx.dev_alloc(work.size)
+    d_pcm = ctx.dev_alloc(n * 960 * 2 * 2)
+    d_res = ctx.dev_alloc(4 * n)
+    out = np.zeros((n, 960, 2), dtype=np.int16)
+    res = np.zeros(n, dtype=np.int32)
+    try:
+        ctx.h2d(d_work, work)
+        for k in range(frames):
+            ctx.decode_work_step(d_work, lay, k, d_pcm, d_res)
+            ctx.synchronize()
+            ctx.d2h(out, d_pcm)
+            ctx.d2h(res, d_res)
+            assert (res == 960).all(), f"step {k}: {(res != 960).sum()} frames failed"
+            descs = np.frombuffer(work[lay.desc_at[k]:lay.desc_at[k] + 16 * n].tobytes(), dtype=pkg.DESC_DTYPE)
+            stream = descs["stream"]
+            assert (np.sort(stream) == np.arange(n)).all()
+            mode = descs["flags"] & 3
+            assert (np.diff(mode) >= 0).all()  # grouped by mode
+            for m in range(3):
+                slots = np.nonzero(mode == m)[0]
+                assert (stream[slots] % 3 == m).all()
+                want = ref[m][stream[slots] // 3, k]
+                bad = np.nonzero((out[slots] != want).reshape(len(slots), -1).any(axis=1))[0]
+                assert bad.size == 0, f"step {k} mode {m}: {bad.size} streams differ from the oracle, first {stream[slots][bad[:5]]}"
+    finally:
+        for p in (d_work, d_pcm, d_res):
+            ctx.dev_free(p)
+
+
+def test_mixed_mode_pages_small(pkg, oracle, gpu_ctx):
+    _run(pkg, oracle, gpu_ctx, 3 * 1024, 2, 5, threads=2)
+
+
+def test_mixed_mode_pages_c5_share(pkg, oracle, gpu_ctx):
+    """One GPU's share of config C5 (2 M pages over 8 GPUs): 262,143 pages of 10 packets, one page per stream."""
+    _run(pkg, oracle, gpu_ctx, 262144 - 262144 % 3, 1, 10, threads=16)

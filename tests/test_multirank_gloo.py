@@ -34,3 +34,18 @@ def test_two_ranks_partition_and_aggregate(tmp_path):
         assert abs(x["dt_max"] - max(r[0]["dt"], r[1]["dt"])) < 1e-6
         assert abs(x["value"] - 36 / x["dt_max"]) < 1e-6
     assert r[1]["dt"] > r[0]["dt"]
+
+
+def test_work_queue_scatter(tmp_path):
+    """The one exchange step of the path: rank 0 ingests Ogg pages for the streams of both ranks, routes them by owner,
+    demuxes them into decode steps and scatters the packed work; each rank must receive exactly its own share."""
+    env = dict(os.environ, OG_TEST_OUT=str(tmp_path), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "multirank_pages_worker.py")]
+    subprocess.run(cmd, check=True, env=env, cwd=ROOT, timeout=300)
+    r = [json.load(open(tmp_path / f"pages_rank{k}.json")) for k in range(2)]
+    for k, x in enumerate(r):
+        assert x["rank"] == k and x["same"], x
+        assert x["n_steps"] == 4 and x["counts"] == [30] * 4  # 30 streams per rank, 4 packets per page
+        assert x["grouped"] and x["size"] == x["nbytes"]
+    assert r[0]["crc"] != r[1]["crc"]  # different streams, different work
