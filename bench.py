@@ -31,7 +31,12 @@ WORKLOADS = {
     "celt_fb_stereo_64k": (0xFC, 160, 21633, 65536),
     "silk_nb_stereo_64k": (0x0C, 40, 5953, 65536),
     "hybrid_fb_stereo_256k": (0x7C, 120, 24945, 262144),
+    # BASELINE config 5: Ogg pages of 10 packets, modes 1:1:1 across streams, 2 M pages over 8 GPUs = 262,144 per GPU.
+    # Rank 0 ingests (page demux on the host) and scatters every rank's decode steps (the one collective of the path).
+    "mixed_pages_2m": (None, None, (5953 + 24945 + 21633) / 3.0, 262144),
 }
+MIX = ((0x0C, 40), (0x7C, 120), (0xFC, 160))  # mode of local stream s = s % 3: SILK-NB, hybrid FB, CELT FB
+PACKETS_PER_PAGE = 10
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -64,7 +69,7 @@ def cpu_baseline(toc, L, seconds_target=12.0):
     import oracle_py
     o = oracle_py.load()
     pkg = load_pkg()
-    cores = oracle_py.usable_cpus()  # the CPUs granted to this process, not the host's logical CPU count
+    cores = load_shard().usable_cpus()  # the CPUs granted to this process, not the host's logical CPU count
     frames = 16
     # calibrate on one core, then size the sample to ~seconds_target of total CPU work
     pay = pkg.lcg_payloads(64, frames, L)
@@ -96,6 +101,71 @@ def cpu_baseline(toc, L, seconds_target=12.0):
     }
 
 
+def mixed_cpu_baseline():
+    """CPU oracle on the 1:1:1 mode mix: one bounded sample per mode, combined as frames / total time."""
+    parts = [cpu_baseline(toc, L, seconds_target=5.0) for toc, L in MIX]
+    value = 3.0 / sum(1.0 / p["value"] for p in parts)
+    return {"value": value, "unit": "frames/s", "cores": parts[0]["cores"], "kind": "port",
+            "sample": "equal numbers of SILK-NB, hybrid and CELT frames: 3 / sum(1 / rate) of " +
+                      " | ".join(p["sample"] for p in parts),
+            "per_mode_frames_per_s": [p["value"] for p in parts], "host_logical_cpus": parts[0]["host_logical_cpus"]}
+
+
+def prepare_pages_work(pkg, shard, ranks, ctx, n, frames):
+    """mixed_pages workload: rank 0 builds the Ogg pages of every rank's streams (`frames` packets per stream in pages of
+    PACKETS_PER_PAGE, chained), turns them into decode steps (opusgpu_pages_demux, host threads) and scatters the packed
+    work.  Returns (device address of this rank's work, its layout, ingest statistics, keep-alive object)."""
+    threads = shard.usable_cpus()
+    buffers, stats = None, None
+    if ranks.rank == 0:
+        buffers, n_pages, page_bytes, t_demux = [], 0, 0, 0.0
+        for r in range(ranks.world):
+            mats, ids = [], []
+            for m, (toc, L) in enumerate(MIX):
+                sid = np.arange(m, n, 3, dtype=np.int32)
+                seed = (0x9E3779B9 ^ (r * 0x01000193) ^ (m * 0x5bd1e995)) & 0xFFFFFFFF
+                pay = pkg.lcg_payloads(len(sid), frames, L, seed_base=seed)
+                for q, lo in enumerate(range(0, frames, PACKETS_PER_PAGE)):
+                    pg = pkg.build_pages(toc, pay[lo:lo + PACKETS_PER_PAGE], sid.astype(np.uint32) + r * n, seqno=2 + q)
+                    mats.append((q, pg))
+                    ids.append((q, sid))
+            order = sorted(range(len(mats)), key=lambda i: mats[i][0])  # a stream's pages in order
+            blob = np.concatenate([mats[i][1].reshape(-1) for i in order])
+            lens = np.concatenate([np.full(mats[i][1].shape[0], mats[i][1].shape[1], dtype=np.int32) for i in order])
+            offs = np.concatenate([[0], np.cumsum(lens.astype(np.int64))[:-1]])
+            sids = np.concatenate([ids[i][1] for i in order])
+            del mats
+            t0 = time.perf_counter()
+            batch = pkg.PageBatch(blob, offs, lens, sids, threads=threads)
+            t_demux += time.perf_counter() - t0
+            if not (batch.info["status"] > 0).all():
+                raise SystemExit("page demux rejected synthetic pages")
+            buffers.append(shard.pack_work(batch))
+            batch.close()
+            n_pages += len(lens)
+            page_bytes += int(blob.size)
+        stats = {"pages": n_pages, "page_bytes": page_bytes, "demux_s": t_demux, "demux_threads": threads,
+                 "pages_per_s": n_pages / t_demux, "demux_GB_per_s": page_bytes / t_demux / 1e9}
+    t0 = time.perf_counter()
+    mine = ranks.scatter_bytes(buffers, src=0)
+    if ranks.world > 1:
+        import torch
+        torch.cuda.synchronize()
+    t_scatter = time.perf_counter() - t0
+    if isinstance(mine, np.ndarray):  # one rank: host -> HBM directly
+        lay = shard.WorkLayout(mine)
+        base = ctx.dev_alloc(mine.size)
+        ctx.h2d(base, mine)
+        keep = None
+    else:  # the scatter delivered into this rank's HBM: only the header comes back to the host
+        lay = shard.WorkLayout(mine[:shard.WORK_HEADER_BYTES].cpu().numpy())
+        base, keep = mine.data_ptr(), mine
+    if stats is not None:
+        stats["scatter_s"] = t_scatter if ranks.world > 1 else None
+        stats["work_bytes_per_rank"] = int(lay.nbytes)
+    return base, lay, stats, keep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,19 +186,35 @@ def main():
 
     pkg = load_pkg()
     ctx = pkg.Context(local_rank)
+    mixed = args.workload == "mixed_pages_2m"
+    if mixed:
+        n -= n % 3  # equal numbers of streams per mode
     ctx.streams_alloc(n, 2)
-    # streams are sharded across ranks with no data-path exchange: each rank owns streams
-    # [rank*n, (rank+1)*n) of the global id space (seeds differ per global stream id)
-    pay = pkg.lcg_payloads(n, K + W, L, seed_base=ranks.seed_base())
-    d_arena, d_desc = [], []
-    for f in range(K + W):
-        arena, descs = pkg.build_step(toc, pay[f])
-        a = ctx.dev_alloc(arena.nbytes + 16)
-        d = ctx.dev_alloc(descs.nbytes)
-        ctx.h2d(a, arena)
-        ctx.h2d(d, descs)
-        d_arena.append(a)
-        d_desc.append(d)
+    ingest = None
+    if mixed:
+        # work arrives at rank 0 as Ogg pages and is scattered: the path's one exchange step, before the timed region
+        base, lay, ingest, _keep = prepare_pages_work(pkg, load_shard(), ranks, ctx, n, K + W)
+        if lay.counts != [n] * (K + W):
+            raise SystemExit(f"unexpected step tables: {lay.counts[:4]}...")
+
+        def step(f):
+            ctx.decode_work_step(base, lay, f, d_pcm, d_res)
+    else:
+        # streams are sharded across ranks with no data-path exchange: each rank owns streams
+        # [rank*n, (rank+1)*n) of the global id space (seeds differ per global stream id)
+        pay = pkg.lcg_payloads(n, K + W, L, seed_base=ranks.seed_base())
+        d_arena, d_desc = [], []
+        for f in range(K + W):
+            arena, descs = pkg.build_step(toc, pay[f])
+            a = ctx.dev_alloc(arena.nbytes + 16)
+            d = ctx.dev_alloc(descs.nbytes)
+            ctx.h2d(a, arena)
+            ctx.h2d(d, descs)
+            d_arena.append(a)
+            d_desc.append(d)
+
+        def step(f):
+            ctx.decode_step_device(n, d_desc[f], d_arena[f], d_pcm, d_res)
     d_pcm = ctx.dev_alloc(n * 960 * 2 * 2)
     d_res = ctx.dev_alloc(4 * n)
 
@@ -137,14 +223,14 @@ def main():
         ctx.synchronize()
 
     for f in range(W):
-        ctx.decode_step_device(n, d_desc[f], d_arena[f], d_pcm, d_res)
+        step(f)
     ctx.synchronize()
     ev = [ctx.event() for _ in range(K + 1)]
     barrier()
     t0 = time.perf_counter()
     ctx.event_record(ev[0])
     for f in range(K):
-        ctx.decode_step_device(n, d_desc[W + f], d_arena[W + f], d_pcm, d_res)
+        step(W + f)
         ctx.event_record(ev[f + 1])
     ctx.synchronize()
     barrier()
@@ -170,7 +256,9 @@ def main():
                 traffic = tj["hbm_bytes_per_step"]
         split = os.environ.get("OPUSGPU_SPLIT", "1") != "0"
         split_silk = split and os.environ.get("OPUSGPU_SPLIT_HYBRID", "1") != "0"
-        if args.workload.startswith("celt"):
+        if mixed:
+            kernels = "k_silk_parse + k_silk_synth + k_decode_step (Q4 pass) + k_celt_parse + k_celt_recon + k_celt_post"
+        elif args.workload.startswith("celt"):
             kernels = "k_celt_parse + k_celt_recon + k_celt_post" if split else "k_decode_step"
         elif args.workload.startswith("silk"):
             kernels = "k_silk_parse + k_silk_synth" if split_silk else "k_decode_step"
@@ -183,17 +271,26 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32 fixed-point (int16/int32 with 64-bit products)", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {n} streams/GPU x 20 ms frames, 48 kHz stereo, "
-                                   f"TOC 0x{toc:02X}, {L}-byte LCG payloads, state persistent across steps",
-                       "streams_per_gpu": n, "sharding": "streams partitioned across ranks, no data-path collective"},
+            "config": ({"workload": f"{args.workload}: {n} streams/GPU, one Ogg page of {PACKETS_PER_PAGE} packets per stream and "
+                                    f"10 steps, modes SILK-NB : hybrid FB : CELT FB = 1:1:1 across streams (TOC 0x0C / 0x7C / "
+                                    f"0xFC, 40 / 120 / 160-byte LCG payloads), 48 kHz stereo, step tables grouped by mode",
+                        "streams_per_gpu": n,
+                        "sharding": "rank 0 ingests the pages (host demux) and scatters every rank's decode steps "
+                                    "(torch.distributed scatter = RCCL), before the timed region; no collective inside it"}
+                       if mixed else
+                       {"workload": f"{args.workload}: {n} streams/GPU x 20 ms frames, 48 kHz stereo, "
+                                    f"TOC 0x{toc:02X}, {L}-byte LCG payloads, state persistent across steps",
+                        "streams_per_gpu": n, "sharding": "streams partitioned across ranks, no data-path collective"}),
             "x_realtime_per_gpu": value / world / 50.0,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel_name, "avg_launch_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_frame": bytes_per_frame, "frames_per_launch": n},
         }
+        if ingest is not None:
+            line["ingest"] = ingest  # host page demux + scatter, outside the timed region: never part of `value`
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(toc, L)
+            line["cpu_baseline"] = mixed_cpu_baseline() if mixed else cpu_baseline(toc, L)
         print(json.dumps(line), flush=True)
     ranks.close()
     ctx.close()

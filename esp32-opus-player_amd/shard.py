@@ -12,6 +12,26 @@ import os
 
 import numpy as np
 
+
+def usable_cpus():
+    """CPUs this process can actually use: the smaller of the affinity mask and the cgroup CPU quota (a GPU box shows all
+    of the host's logical CPUs but grants a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2: "<quota> <period>" or "max <period>"
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 # ---- work queue: one rank's decode steps in one buffer ------------------------------------------------------
 # [ header: int64 x WORK_HEADER_WORDS | descriptor tables of all steps, back to back | packet arena ], every part
 # starting on a 256-byte boundary.  header = magic, n_steps, total descriptors, arena bytes, then one count per step.

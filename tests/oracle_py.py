@@ -13,22 +13,12 @@ MODE_SILK, MODE_HYBRID, MODE_CELT = 1000, 1001, 1002
 
 
 def usable_cpus():
-    """CPUs this process can actually use: the smaller of the affinity mask and the cgroup CPU quota (a GPU box shows all
-    of the host's logical CPUs but grants a share of them)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:  # cgroup v2: "<quota> <period>" or "max <period>"
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, -(-int(quota) // int(period))))
-    except (OSError, ValueError):
-        try:  # cgroup v1
-            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if quota > 0:
-                n = min(n, max(1, -(-quota // period)))
-        except (OSError, ValueError):
-            pass
-    return n
+    """CPUs this process can actually use (esp32-opus-player_amd/shard.py: affinity mask and cgroup quota)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("og_shard_for_oracle", os.path.join(ROOT, "esp32-opus-player_amd", "shard.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.usable_cpus()
 
 
 class Oracle:
