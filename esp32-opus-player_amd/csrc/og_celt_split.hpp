@@ -580,6 +580,7 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
     //   s = (i >= U(n, k+1));  i -= s ? U(n, k+1) : 0;  k' = max { k' <= k : U(n, k') <= i };  value = +-(k - k');  i -= U(n, k')
     // One formulation matters here: the lanes of a wave decode different leaves, and a wave pays for every path any of
     // its lanes takes.  k' == k (a zero) is by far the most common outcome and is tested first; otherwise bisection.
+    OG_MARK(56);
     while (n > 2) {
         const u32 p1 = pvq_u_rom(n, k + 1), p0 = pvq_u_rom(n, k);
         const int s = -(int)(i >= p1);
@@ -624,6 +625,7 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
         yy += val * val;
     }
     // collapse mask from the pulses
+    OG_MARK(57);
     u32 cm = 1;
     if (B > 1) {
         cm = 0;
@@ -634,10 +636,12 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
         }
     }
     // scale the pulses in place
+    OG_MARK(58);
     const int kk = ilog2(yy) >> 1;
     const i32 t = vshr32(yy, 2 * (kk - 7));
     const i32 g = tr16(mul16_p15(rsqrt_norm(t), gain));
     for (int j = 0; j < N; j++) S.v[x + j] = (i16)pshr32(mul16(g, S.v[x + j]), kk + 1);
+    OG_MARK(59);
     if (2 * K < N && spread != 0) {
         const int factor = spread == 1 ? 15 : (spread == 2 ? 10 : 5);
         const i32 rg = tr16(mul32_q31(mul16(32767, N), celt_rcp(N + factor * K))); // celt_div celt.h:367
@@ -727,6 +731,9 @@ OG_DEV u32 recon_job_leaves(RecCur &cur, const LcgTab &lcg, u32 jw, u32 &seed_io
         const i32 gain = (i32)((w1 >> 11) & 0xffff);
         const u32 cm_mask = (u32)((1ull << B) - 1);
         const i32 fill = (i32)((u32)(fill_job >> off) & cm_mask);
+        OG_STAT(10, fill == 0);                     // fill leaves left zero
+        OG_STAT(11, fill != 0 && low_job < 0);      // ... noise
+        OG_STAT(12, fill != 0 && low_job >= 0);     // ... folded
         if (fill) { // (no fill: the leaf stays zero, as the spectrum was initialised)
             const u32 seed = seed_io;
             u32 cm;
@@ -786,6 +793,12 @@ OG_DEV u32 recon_band_mono(RecCur &cur, const LcgTab &lcg, int tf_change, u32 &s
     int logB = ilog2(B), time_divide = 0, recombine = 0;
     int N_B = N >> logB;
     const u32 jw = rec_word(cur);
+    OG_STAT(1, 1);                                  // jobs
+    OG_STAT(2, (jw & JW_NEED_LOW) && low >= 0);     // jobs that prepare a folding source
+    OG_STAT(3, (int)(jw & 31));                     // fill leaves
+    OG_STAT(4, (int)(jw >> JW_NPVQ_SHIFT) & 31);    // PVQ leaves
+    OG_STAT(5, tf_change != 0);                     // jobs with a tf change
+    OG_STAT(6, B > 1);                              // jobs in short-block frames
     if (!(jw & JW_NEED_LOW)) low = -1; // no leaf of this job folds: skip the whole preparation of the folding source
     if (tf_change > 0) recombine = tf_change;
     if (low_scratch >= 0 && low >= 0 && (recombine || ((N_B & 1) == 0 && tf_change < 0) || B > 1)) {
@@ -816,6 +829,9 @@ OG_DEV u32 recon_band_mono(RecCur &cur, const LcgTab &lcg, int tf_change, u32 &s
     u32 cm = recon_job_leaves(cur, lcg, jw, seed, x, low, fill);
     OG_MARK(8);
     if (B0 > 1) hadamard_p2(x, N_B >> recombine, logB0 + recombine, longBlocks, 1);
+    OG_STAT(7, B0 > 1);                             // jobs that undo a Hadamard interleave on x
+    OG_STAT(8, time_divide + recombine);            // Haar passes on x
+    OG_STAT(9, low_out >= 0);                       // jobs that write folding history
     N_B = N_B0;
     for (int k = 0; k < time_divide; k++) {
         logB--;
@@ -842,6 +858,8 @@ OG_DEV u32 recon_band_mono(RecCur &cur, const LcgTab &lcg, int tf_change, u32 &s
 OG_DEV void recon_all_bands(const u32 *words, u32 need_norm, const LcgTab &lcg, int start, int end, int C, int N_ch, int shortBlocks, int LM,
                             u32 &seed_io) {
     const int M = 1 << LM, B = shortBlocks ? M : 1;
+    OG_STAT(0, 1);                 // frames
+    OG_STAT(19, shortBlocks != 0); // transient frames
     const int norm_offset = M * rom_eband[start];
     const int norm = V_NORM, norm2 = V_NORM + M * rom_eband[NBANDS - 1] - norm_offset;
     // The reference borrows the last band's spectrum slot as scratch; here that slot already holds the band's
@@ -871,6 +889,12 @@ OG_DEV void recon_all_bands(const u32 *words, u32 need_norm, const LcgTab &lcg, 
             }
         }
         const int tf_change = (int)((w0 >> BW_TF_SHIFT) & 7) - 4;
+        OG_STAT(13, 1);                                             // bands
+        OG_STAT(14, N == 1);                                        // N == 1 bands
+        OG_STAT(15, (w0 & BW_STEREO) && N > 2);                     // bands that end in a stereo merge
+        OG_STAT(16, (w0 & BW_STEREO) && N == 2);                    // N == 2 stereo bands
+        OG_STAT(17, dual_stereo);                                   // dual-stereo bands
+        OG_STAT(18, (w0 & BW_HAS_LOW) != 0);                        // bands with a folding source available
         if (last) low_scratch = -1;
         u32 x_cm, y_cm;
         if (w0 & BW_HAS_LOW) {
@@ -1021,6 +1045,19 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         return ret;
 #endif
         // ---- all PVQ leaves of the frame, one per lane
+#if defined(OG_HOST_EMUL) && defined(OG_STATS)
+        { // the wave pays for its longest leaf: what does that leaf look like?
+            int max_n = 0, k_at_max = 0, sum_n = 0;
+            for (int t = 0; t < n_leaves; t++) {
+                const u32 g = rec->leaf_geom[t];
+                const int n = (int)(g >> 11) & 255, k = (int)(g >> 19) & 255;
+                sum_n += n;
+                if (n > max_n) { max_n = n; k_at_max = k; }
+            }
+            OG_STAT(40, max_n); OG_STAT(41, k_at_max); OG_STAT(42, sum_n); OG_STAT(44, n_leaves);
+            OG_STAT(45, max_n >= 96); OG_STAT(46, max_n >= 144);
+        }
+#endif
         OG_MARK(2);
         OG_FOR_LANES(t, n_leaves) {
             const u32 g = rec->leaf_geom[t];

@@ -104,6 +104,15 @@ __shared__ int s_prof_cur;
 #define OG_PROF_FLUSH() ((void)0)
 #endif
 
+// Event counters of the host emulation (tests/emul, -DOG_STATS): how often the band loop takes each of its paths on a
+// given workload.  Nothing in any other build.
+#if defined(OG_HOST_EMUL) && defined(OG_STATS)
+extern long long og_stats[64];
+#define OG_STAT(id, n) (og_stats[id] += (n))
+#else
+#define OG_STAT(id, n) ((void)0)
+#endif
+
 #define OG_MIN(a, b) ((a) < (b) ? (a) : (b))
 #define OG_MAX(a, b) ((a) > (b) ? (a) : (b))
 

@@ -4,6 +4,11 @@
 #define OG_HOST_EMUL 1
 #include "og_decode.hpp"
 
+#ifdef OG_STATS
+long long og_stats[64];
+extern "C" const long long *emu_stats(void) { return og_stats; }
+#endif
+
 extern "C" {
 int emu_state_size(void) { return (int)sizeof(og::StreamState); }
 void emu_stream_init(void *st, int channels) { og::stream_init((og::StreamState *)st, channels); }

@@ -18,6 +18,7 @@ NAMES = {0: "outside", 1: "stage record", 2: "leaf pass", 3: "band prologue", 4:
          12: "anti-collapse", 13: "synth prologue", 14: "imdct", 15: "comb filter", 16: "ring write", 17: "epilogue",
          20: "parse: init", 21: "parse: flags", 22: "parse: coarse energy", 23: "parse: tf/spread/dynalloc", 24: "parse: allocation",
          25: "parse: fine energy", 26: "parse: bands", 27: "parse: finalise",
+         56: "leaf: index walk (cwrsi)", 57: "leaf: collapse mask", 58: "leaf: scale", 59: "leaf: rotation",
          40: "parse: stereo theta + band words", 41: "parse: tree descend (split theta)", 42: "parse: leaf bits2pulses", 43: "parse: leaf index (rc_uint)",
          44: "parse: tree ascend",
          50: "silk parse: init + flags + LBRR + stereo", 51: "silk parse: indices", 52: "silk parse: pulses", 53: "silk parse: parameters",
