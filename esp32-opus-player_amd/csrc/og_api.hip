@@ -79,8 +79,14 @@ __global__ void __launch_bounds__(64, OG_SILK_WAVES) k_silk_synth(const FrameDes
     } else if (desc_mode(d.flags) == MODE_CELT) {
         return;
     } else {
+#ifdef OG_PROF_SSYNTH // profiling builds: time the sections of the SILK synthesis kernel
+        OG_PROF_INIT();
+#endif
         ret = decode_frame_wave<false>(&st[d.stream], arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
                                        desc_channels(d.flags), pcm + (size_t)f * pcm_stride, &handoff[f], &srecs[f]);
+#ifdef OG_PROF_SSYNTH
+        OG_PROF_FLUSH();
+#endif
         if (ret == CONTINUE_SPLIT || ret == CONTINUE_Q4) return;
     }
     if (threadIdx.x == 0) result[f] = ret;
@@ -139,12 +145,12 @@ __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDe
     const int mode = desc_mode(d.flags);
     if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && hybrid))) return;
     if (mode == MODE_HYBRID && (recs[f].flags & RF_SKIP)) return; // the single-kernel path already reported this frame
-#if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE) && !defined(OG_PROF_SPARSE)
+#if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE) && !defined(OG_PROF_SPARSE) && !defined(OG_PROF_SSYNTH)
     OG_PROF_INIT();
 #endif
     const int ret = celt_recon_wave(&st[d.stream], &recs[f], mode, desc_channels(d.flags));
     if (threadIdx.x == 0) result[f] = ret;
-#if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE) && !defined(OG_PROF_SPARSE)
+#if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE) && !defined(OG_PROF_SPARSE) && !defined(OG_PROF_SSYNTH)
     OG_PROF_FLUSH();
 #endif
 }

@@ -764,6 +764,10 @@ OG_DEV i32 row_sum16(i32 v) { // sum over the 16 lanes of a DPP row, result in e
     v += OG_DPP_ROR(v, 1);
     return v;
 }
+OG_DEV i32 row_lane0(i32 v) { // lane 0 of every 16-lane row, in all lanes of that row
+    // keep lane 0's value, zero elsewhere, then sum over the row
+    return row_sum16((OG_LANE & 15) == 0 ? v : 0);
+}
 OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels) {
     SilkLds &L = SL();
     const int row = OG_LANE >> 4, j = OG_LANE & 15;
@@ -823,38 +827,93 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels) {
                 OG_ROW_SYNC();
             }
         }
-        for (int i = 0; i < subfr; i++) {
-            // excitation (silk.cpp:1826-1835), identical in the 16 lanes of the row
-            rand_seed = (i32)(907633515u + (u32)rand_seed * 196314165u);
-            const i32 pl = pulses[pos + i];
-            i32 exc = shl32(pl, 14);
-            if (exc > 0)
-                exc -= 80 << 4;
-            else if (exc < 0)
-                exc += 80 << 4;
-            exc += offset_Q10 << 4;
-            if (rand_seed < 0) exc = -exc;
-            rand_seed = addw(rand_seed, pl);
-            i32 res = exc;
-            if (voiced) {
-                const i32 *p = &sLTP_Q15[sLTP_buf_idx - lag + 2];
-                i32 LTP_pred_Q13 = 2;
-                LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[0], B_Q14[0]);
-                LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[-1], B_Q14[1]);
-                LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[-2], B_Q14[2]);
-                LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[-3], B_Q14[3]);
-                LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[-4], B_Q14[4]);
-                res = addw(exc, shl32(LTP_pred_Q13, 1));
-                if (j == 0) sLTP_Q15[sLTP_buf_idx] = shl32(res, 1);
-                sLTP_buf_idx++;
+        // The subframe in three phases, so that only what must wait for the previous output sample does (silk.cpp:1826-1873):
+        //  1. excitation: a short serial chain (the dither seed absorbs each pulse), every lane of the row runs it and
+        //     keeps the samples it owns (i % 16 == lane); no stores inside, so the pulse reads pipeline;
+        //  2. voiced: the LTP prediction reads its own state at least lag - 2 samples back -- min(16, lag - 2) samples at a
+        //     time, one per lane;
+        //  3. the LPC recurrence.  silk_SMLAWB wraps, so the order of its additions is free: taps 2 .. order of the NEXT
+        //     sample do not involve the sample being computed and are reduced over the row beside it; one multiply-add and
+        //     the saturating update stay on the dependent chain.  The row sum leaves the same value in every lane, so each
+        //     lane again keeps the samples it owns; the output scaling happens after the loop, in parallel.
+        i32 *resb = reinterpret_cast<i32 *>(sLTP); // residuals of this subframe (the whitened history is dead by now)
+        enum { OWN = (SILK_MAX_FRAME / 4 + 15) / 16 };
+        i32 own[OWN];
+#pragma unroll
+        for (int b16 = 0; b16 < OWN; b16++) {
+            own[b16] = 0;
+            if (16 * b16 < subfr) {
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const int i = 16 * b16 + t;
+                    if (i < subfr) {
+                        rand_seed = (i32)(907633515u + (u32)rand_seed * 196314165u);
+                        const i32 pl = pulses[pos + i];
+                        i32 exc = shl32(pl, 14);
+                        if (exc > 0)
+                            exc -= 80 << 4;
+                        else if (exc < 0)
+                            exc += 80 << 4;
+                        exc += offset_Q10 << 4;
+                        if (rand_seed < 0) exc = -exc;
+                        rand_seed = addw(rand_seed, pl);
+                        if (t == j) own[b16] = exc;
+                    }
+                }
             }
-            // silk_SMLAWB wraps (ADD32_ovflw): the order of the 16 additions does not matter
-            const i32 LPC_pred_Q10 = addw(order >> 1, row_sum16(smulwb(sLPC, A_j)));
-            const i32 s = add_sat32(res, lshift_sat32(LPC_pred_Q10, 4));
-            const i32 shifted = __builtin_amdgcn_update_dpp(0, sLPC, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
-            sLPC = j == 0 ? s : shifted;
-            if (j == 0) xq[pos + i] = (i16)sat16(rshift_round(smulww(s, Gain_Q10), 8));
         }
+#pragma unroll
+        for (int b16 = 0; b16 < OWN; b16++)
+            if (16 * b16 + j < subfr) resb[16 * b16 + j] = own[b16];
+        OG_ROW_SYNC();
+        if (voiced) {
+            const int chunk = OG_MIN(16, lag - 2);
+            for (int i0 = 0; i0 < subfr; i0 += chunk) {
+                const int i = i0 + j;
+                if (j < chunk && i < subfr) {
+                    const i32 *p = &sLTP_Q15[sLTP_buf_idx + i - lag + 2];
+                    i32 LTP_pred_Q13 = 2;
+                    LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[0], B_Q14[0]);
+                    LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[-1], B_Q14[1]);
+                    LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[-2], B_Q14[2]);
+                    LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[-3], B_Q14[3]);
+                    LTP_pred_Q13 = smlawb(LTP_pred_Q13, p[-4], B_Q14[4]);
+                    const i32 res = addw(resb[i], shl32(LTP_pred_Q13, 1));
+                    sLTP_Q15[sLTP_buf_idx + i] = shl32(res, 1);
+                    resb[i] = res;
+                }
+                OG_ROW_SYNC();
+            }
+            sLTP_buf_idx += subfr;
+        }
+        {
+            const i32 A_0 = (i32)A_Q12[0];
+            const i32 A_next = j + 1 < order ? (i32)A_Q12[j + 1] : 0; // lane j: the tap its sample meets one step later
+            i32 s_last = row_lane0(sLPC); // the previous output sample, in every lane of the row
+            i32 T = addw(order >> 1, row_sum16(j >= 1 ? smulwb(sLPC, A_j) : 0)); // taps 2 .. order of the first sample
+#pragma unroll
+            for (int b16 = 0; b16 < OWN; b16++) {
+                if (16 * b16 < subfr) {
+#pragma unroll
+                    for (int t = 0; t < 16; t++) {
+                        const int i = 16 * b16 + t;
+                        if (i < subfr) {
+                            const i32 T_next = addw(order >> 1, row_sum16(smulwb(sLPC, A_next)));
+                            const i32 LPC_pred_Q10 = addw(T, smulwb(s_last, A_0));
+                            const i32 sn = __builtin_elementwise_add_sat(resb[i], lshift_sat32(LPC_pred_Q10, 4));
+                            const i32 shifted = __builtin_amdgcn_update_dpp(0, sLPC, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+                            sLPC = j == 0 ? sn : shifted;
+                            s_last = sn;
+                            T = T_next;
+                            if (t == j) own[b16] = sn;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int b16 = 0; b16 < OWN; b16++)
+            if (16 * b16 + j < subfr) xq[pos + 16 * b16 + j] = (i16)sat16(rshift_round(smulww(own[b16], Gain_Q10), 8));
         pos += subfr;
         if (voiced) OG_ROW_SYNC(); // this subframe's sLTP_Q15 / xq writes before the next subframe's reads
     }
