@@ -791,6 +791,7 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels) {
     i32 prev_gain_Q16 = c->prev_gain_Q16;
     int sLTP_buf_idx = ltp_mem, lag = 0, pos = 0;
     for (int sf = 0; sf < 4; sf++) {
+        OG_MARK(60);
         const i16 *A_Q12 = k.PredCoef_Q12[sf >> 1];
         const i16 *B_Q14 = &k.LTPCoef_Q14[sf * 5];
         const i32 A_j = j < order ? (i32)A_Q12[j] : 0;
@@ -828,44 +829,72 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels) {
             }
         }
         // The subframe in three phases, so that only what must wait for the previous output sample does (silk.cpp:1826-1873):
-        //  1. excitation: a short serial chain (the dither seed absorbs each pulse), every lane of the row runs it and
-        //     keeps the samples it owns (i % 16 == lane); no stores inside, so the pulse reads pipeline;
+        //  1. excitation: the dither seed absorbs each pulse -- a chain of affine maps, folded per lane and scanned over the row;
         //  2. voiced: the LTP prediction reads its own state at least lag - 2 samples back -- min(16, lag - 2) samples at a
         //     time, one per lane;
         //  3. the LPC recurrence.  silk_SMLAWB wraps, so the order of its additions is free: taps 2 .. order of the NEXT
         //     sample do not involve the sample being computed and are reduced over the row beside it; one multiply-add and
         //     the saturating update stay on the dependent chain.  The row sum leaves the same value in every lane, so each
         //     lane again keeps the samples it owns; the output scaling happens after the loop, in parallel.
+        OG_MARK(61);
         i32 *resb = reinterpret_cast<i32 *>(sLTP); // residuals of this subframe (the whitened history is dead by now)
         enum { OWN = (SILK_MAX_FRAME / 4 + 15) / 16 };
-        i32 own[OWN];
+        i32 own[OWN] = {};
+        {
+            // The dither seed: r <- a r + c, used for the sign, then r <- r + pulse: one affine map mod 2^32 per sample, and
+            // affine maps compose exactly.  Lane j folds its own `per` consecutive samples into one map, an inclusive scan
+            // over the row (four DPP steps) composes the maps of the lanes before it, and the lane replays only its own
+            // samples from its start seed.
+            const u32 LCG_A = 196314165u, LCG_C = 907633515u;
+            const int per = (subfr + 15) >> 4, i0 = per * j;
+            u32 M = 1u, B = 0u;
+            i32 pl_own[OWN];
 #pragma unroll
-        for (int b16 = 0; b16 < OWN; b16++) {
-            own[b16] = 0;
-            if (16 * b16 < subfr) {
+            for (int t = 0; t < OWN; t++) {
+                pl_own[t] = 0;
+                if (t < per && i0 + t < subfr) {
+                    pl_own[t] = pulses[pos + i0 + t];
+                    M *= LCG_A;
+                    B = B * LCG_A + LCG_C + (u32)pl_own[t];
+                }
+            }
+            // (M, B) <- (M, B) o (M', B') of lane j - d, d = 1, 2, 4, 8; the identity where there is no such lane
+#define OG_AFFINE_SCAN_STEP(d)                                                                                      \
+    do {                                                                                                            \
+        const u32 Mp = (u32)__builtin_amdgcn_update_dpp(1, (i32)M, 0x110 + (d) /* row_shr:d */, 0xf, 0xf, false);   \
+        const u32 Bp = (u32)__builtin_amdgcn_update_dpp(0, (i32)B, 0x110 + (d), 0xf, 0xf, false);                   \
+        B = M * Bp + B;                                                                                             \
+        M = M * Mp;                                                                                                 \
+    } while (0)
+            OG_AFFINE_SCAN_STEP(1);
+            OG_AFFINE_SCAN_STEP(2);
+            OG_AFFINE_SCAN_STEP(4);
+            OG_AFFINE_SCAN_STEP(8);
+#undef OG_AFFINE_SCAN_STEP
+            const u32 r0 = (u32)rand_seed;
+            const u32 Me = (u32)__builtin_amdgcn_update_dpp(1, (i32)M, 0x111, 0xf, 0xf, false);
+            const u32 Be = (u32)__builtin_amdgcn_update_dpp(0, (i32)B, 0x111, 0xf, 0xf, false);
+            u32 r = Me * r0 + Be;                                              // seed before the lane's first sample
+            rand_seed = row_sum16(j == 15 ? (i32)(M * r0 + B) : 0);            // seed after the subframe, in every lane
 #pragma unroll
-                for (int t = 0; t < 16; t++) {
-                    const int i = 16 * b16 + t;
-                    if (i < subfr) {
-                        rand_seed = (i32)(907633515u + (u32)rand_seed * 196314165u);
-                        const i32 pl = pulses[pos + i];
-                        i32 exc = shl32(pl, 14);
-                        if (exc > 0)
-                            exc -= 80 << 4;
-                        else if (exc < 0)
-                            exc += 80 << 4;
-                        exc += offset_Q10 << 4;
-                        if (rand_seed < 0) exc = -exc;
-                        rand_seed = addw(rand_seed, pl);
-                        if (t == j) own[b16] = exc;
-                    }
+            for (int t = 0; t < OWN; t++) {
+                if (t < per && i0 + t < subfr) {
+                    r = LCG_C + r * LCG_A;
+                    const i32 pl = pl_own[t];
+                    i32 exc = shl32(pl, 14);
+                    if (exc > 0)
+                        exc -= 80 << 4;
+                    else if (exc < 0)
+                        exc += 80 << 4;
+                    exc += offset_Q10 << 4;
+                    if ((i32)r < 0) exc = -exc;
+                    r += (u32)pl;
+                    resb[i0 + t] = exc;
                 }
             }
         }
-#pragma unroll
-        for (int b16 = 0; b16 < OWN; b16++)
-            if (16 * b16 + j < subfr) resb[16 * b16 + j] = own[b16];
         OG_ROW_SYNC();
+        OG_MARK(62);
         if (voiced) {
             const int chunk = OG_MIN(16, lag - 2);
             for (int i0 = 0; i0 < subfr; i0 += chunk) {
@@ -886,6 +915,7 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels) {
             }
             sLTP_buf_idx += subfr;
         }
+        OG_MARK(63);
         {
             const i32 A_0 = (i32)A_Q12[0];
             const i32 A_next = j + 1 < order ? (i32)A_Q12[j + 1] : 0; // lane j: the tap its sample meets one step later
@@ -917,6 +947,7 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels) {
         pos += subfr;
         if (voiced) OG_ROW_SYNC(); // this subframe's sLTP_Q15 / xq writes before the next subframe's reads
     }
+    OG_MARK(34);
     c->sLPC_Q14_buf[SILK_MAX_LPC - 1 - j] = sLPC;
     if (j == 0) {
         c->prev_gain_Q16 = prev_gain_Q16;

@@ -19,6 +19,8 @@ NAMES = {0: "outside", 1: "stage record", 2: "leaf pass", 3: "band prologue", 4:
          20: "parse: init", 21: "parse: flags", 22: "parse: coarse energy", 23: "parse: tf/spread/dynalloc", 24: "parse: allocation",
          25: "parse: fine energy", 26: "parse: bands", 27: "parse: finalise",
          56: "leaf: index walk (cwrsi)", 57: "leaf: collapse mask", 58: "leaf: scale", 59: "leaf: rotation",
+         60: "silk core: subframe setup (gains, re-whitening)", 61: "silk core: excitation", 62: "silk core: LTP prediction",
+         63: "silk core: LPC recurrence + output scaling",
          40: "parse: stereo theta + band words", 41: "parse: tree descend (split theta)", 42: "parse: leaf bits2pulses", 43: "parse: leaf index (rc_uint)",
          44: "parse: tree ascend",
          50: "silk parse: init + flags + LBRR + stereo", 51: "silk parse: indices", 52: "silk parse: pulses", 53: "silk parse: parameters",
