@@ -76,7 +76,7 @@ __shared__ unsigned long long s_prof_t;
 __shared__ int s_prof_cur;
 #define OG_PROF_INIT()                                                  \
     do {                                                                \
-        s_prof[threadIdx.x & 63] = 0;                                   \
+        if (threadIdx.x < 32) s_prof[threadIdx.x] = s_prof[threadIdx.x + 32] = 0; /* (kernels with 32 active lanes) */ \
         if (threadIdx.x == 0) {                                         \
             s_prof_cur = 0;                                             \
             s_prof_t = __builtin_amdgcn_s_memtime();                    \
@@ -96,7 +96,10 @@ __shared__ int s_prof_cur;
     do {                                                                \
         OG_MARK(0);                                                     \
         __syncthreads();                                                \
-        atomicAdd(&g_prof[threadIdx.x & 63], (unsigned long long)s_prof[threadIdx.x & 63]); \
+        if (threadIdx.x < 32) {                                         \
+            atomicAdd(&g_prof[threadIdx.x], (unsigned long long)s_prof[threadIdx.x]); \
+            atomicAdd(&g_prof[threadIdx.x + 32], (unsigned long long)s_prof[threadIdx.x + 32]); \
+        }                                                               \
     } while (0)
 #else
 #define OG_PROF_INIT() ((void)0)

@@ -139,3 +139,36 @@ def test_multiframe_packets_and_errors(pkg, oracle, gpu_ctx):
         assert res[s] == r, (s, res[s], r)
         if r > 0:
             assert np.array_equal(pcm[s, :r], out[:r])
+
+
+def test_tiny_frames(pkg, oracle, gpu_ctx):
+    """Frames of 0 .. 3 payload bytes (the reference has no special case for them: the range decoder simply runs out of
+    bytes), in every mode, stereo and mono packets, interleaved with ordinary frames so that state carries across."""
+    rng = np.random.default_rng(11)
+    for channels in (2, 1):
+        tocs = [0xFC, 0x0C, 0x7C, 0x4C, 0x2C] if channels == 2 else [0xF8, 0x08, 0x78, 0xFC, 0x0C]
+        n, frames = 120, 6
+        pk = []
+        for s in range(n):
+            toc = tocs[s % len(tocs)]  # mode fixed per stream (no Q4 transitions here; they have their own test)
+            row = []
+            for f in range(frames):
+                L = int(rng.choice([0, 1, 2, 3, 0, 1, 50]))
+                kind = rng.integers(4)
+                body = bytes(L) if kind == 0 else (b"\xff" * L if kind == 1 else rng.integers(0, 256, L, dtype=np.uint8).tobytes())
+                row.append(bytes([toc]) + body)
+            pk.append(row)
+        ref, rets = oracle.decode_streams(channels, pk)
+        gpu_ctx.streams_alloc(n, channels)
+        for f in range(frames):
+            pcm, res = gpu_ctx.decode_packets(np.arange(n), [pk[s][f] for s in range(n)], frame_capacity=1)
+            assert (res == rets[:, f]).all(), (channels, f, res[res != rets[:, f]][:5], rets[:, f][res != rets[:, f]][:5])
+            for s in range(n):
+                if res[s] <= 0:
+                    continue
+                toc = pk[s][f][0]
+                stereo_pkt = bool(toc & 4)
+                silk_only = not (toc & 0x80) and (toc & 0x60) != 0x60
+                # Q3: a mono SILK-only packet in a stereo decoder defines only the first 960 interleaved entries
+                ncmp = 960 if (silk_only and not stereo_pkt and channels == 2) else 960 * channels
+                assert (pcm[s].reshape(-1)[:ncmp] == ref[s, f].reshape(-1)[:ncmp]).all(), (channels, s, f, hex(toc), len(pk[s][f]))
