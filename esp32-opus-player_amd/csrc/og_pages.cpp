@@ -70,6 +70,28 @@ struct PageScan {
     int32_t status = 0; // frames (>= 0) or OPUSGPU_PAGE_*
     int32_t packets = 0;
     int32_t header_len = 0, body_len = 0;
+    uint64_t modes = 0; // mode (2 bits) of the page's first 32 frames: enough for the mode grouping of ordinary pages
+};
+
+// Uninitialised storage for the large outputs: a zero-filling resize would touch (page-fault) every byte on one thread
+// before the parallel pass that fills them gets to run.
+template <class T>
+struct RawBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { free(p); }
+    void alloc(size_t count) {
+        free(p);
+        n = count;
+        p = static_cast<T *>(malloc((count ? count : 1) * sizeof(T)));
+        if (!p) throw std::bad_alloc();
+    }
+    T *data() const { return p; }
+    size_t size() const { return n; }
+    T &operator[](size_t i) const { return p[i]; }
 };
 
 // Header checks, CRC, lacing walk.  With `emit`: called per frame as emit(frame k of the page, offset in body, len, flags).
@@ -134,6 +156,7 @@ PageScan scan_page(const uint8_t *pg, int32_t len, int flags, opusgpu_page_info 
         const int32_t fl = ogh::toc_flags(toc);
         for (int k = 0; k < count; k++) {
             emit(frames + k, at + off, (int32_t)size[k], fl);
+            if (frames + k < 32) r.modes |= (uint64_t)(fl & 3) << (2 * (frames + k));
             off += size[k];
         }
         frames += count;
@@ -162,10 +185,10 @@ void parallel_for(int n, int threads, F f) { // f(begin, end)
 } // namespace
 
 struct opusgpu_page_batch {
-    std::vector<opusgpu_frame_desc> descs; // all steps, step after step
-    std::vector<int32_t> slot_pages;       // parallel to descs
-    std::vector<size_t> step_begin;        // n_steps + 1
-    std::vector<uint8_t> arena;
+    RawBuf<opusgpu_frame_desc> descs; // all steps, step after step
+    RawBuf<int32_t> slot_pages;       // parallel to descs
+    std::vector<size_t> step_begin;   // n_steps + 1
+    RawBuf<uint8_t> arena;
 };
 
 int opusgpu_pages_demux(int n_pages, const uint8_t *const *pages, const int32_t *page_lens, const int32_t *stream_ids,
@@ -212,36 +235,48 @@ int opusgpu_pages_demux(int n_pages, const uint8_t *const *pages, const int32_t 
         const bool group = (flags & OPUSGPU_PAGES_GROUP_BY_MODE) != 0;
         const int G = group ? 3 : 1;
         std::vector<size_t> count((size_t)n_steps * G + 1, 0);
-        std::vector<uint8_t> mode_of; // mode (0..2) per frame of every page, only when grouping
+        RawBuf<uint8_t> mode_of; // mode (0..2) per frame of every page, only when grouping
         std::vector<size_t> frame_at((size_t)n_pages + 1, 0);
-        for (int i = 0; i < n_pages; i++) frame_at[i + 1] = frame_at[i] + (scan[i].status > 0 ? scan[i].status : 0);
+        for (int i = 0; i < n_pages; i++) {
+            frame_at[i + 1] = frame_at[i] + (scan[i].status > 0 ? scan[i].status : 0);
+        }
         const size_t total = frame_at[n_pages];
+        if (total > 0xffffffffull) { // slots are 32-bit: split the call
+            delete b;
+            return OPUSGPU_BAD_ARG;
+        }
         if (group) {
-            mode_of.resize(total);
+            mode_of.alloc(total);
             parallel_for(n_pages, threads, [&](int lo, int hi) {
-                for (int i = lo; i < hi; i++)
-                    if (scan[i].status > 0)
+                for (int i = lo; i < hi; i++) {
+                    if (scan[i].status <= 0) continue;
+                    const int nf = scan[i].status < 32 ? scan[i].status : 32;
+                    for (int k = 0; k < nf; k++) mode_of[frame_at[i] + k] = (uint8_t)((scan[i].modes >> (2 * k)) & 3);
+                    if (scan[i].status > 32) // rare: scan the page again for the rest
                         scan_page(pages[i], page_lens[i], 0, nullptr, [&](int k, int32_t, int32_t, int32_t fl) {
                             mode_of[frame_at[i] + k] = (uint8_t)(fl & 3);
                         });
+                }
             });
         }
         for (int i = 0; i < n_pages; i++)
             for (int k = 0; k < (scan[i].status > 0 ? scan[i].status : 0); k++)
                 count[(size_t)(first_step[i] + k) * G + (group ? mode_of[frame_at[i] + k] : 0) + 1]++;
         for (size_t j = 1; j < count.size(); j++) count[j] += count[j - 1]; // count[j] = first slot of (step, group) j
-        std::vector<size_t> slot_of(total);
+        RawBuf<uint32_t> slot_of;
+        slot_of.alloc(total);
         {
             std::vector<size_t> cur(count.begin(), count.end() - 1);
             for (int i = 0; i < n_pages; i++)
                 for (int k = 0; k < (scan[i].status > 0 ? scan[i].status : 0); k++)
-                    slot_of[frame_at[i] + k] = cur[(size_t)(first_step[i] + k) * G + (group ? mode_of[frame_at[i] + k] : 0)]++;
+                    slot_of[frame_at[i] + k] = (uint32_t)cur[(size_t)(first_step[i] + k) * G + (group ? mode_of[frame_at[i] + k] : 0)]++;
         }
         b->step_begin.resize((size_t)n_steps + 1);
         for (int s = 0; s <= n_steps; s++) b->step_begin[s] = count[(size_t)s * G];
-        b->descs.resize(total);
-        b->slot_pages.resize(total);
-        b->arena.resize(arena_bytes + 16); // the kernels read packets through aligned 32-bit words: keep a tail
+        b->descs.alloc(total);
+        b->slot_pages.alloc(total);
+        b->arena.alloc(arena_bytes + 16); // the kernels read packets through aligned 32-bit words: keep a tail
+        memset(b->arena.data() + arena_bytes, 0, 16);
         // pass 3: bodies and descriptors
         parallel_for(n_pages, threads, [&](int lo, int hi) {
             for (int i = lo; i < hi; i++) {

@@ -141,3 +141,28 @@ def test_empty_batch(pkg):
     with pytest.raises(IndexError):
         b.step(0)
     b.close()
+
+
+def test_page_with_more_than_32_frames_groups_correctly(pkg):
+    """The demux keeps the modes of a page's first 32 frames from its first scan and re-scans longer pages: a page of 45
+    frames with alternating modes must still come out grouped, frame k in step k."""
+    rng = random.Random(5)
+    tocs = [0x0C, 0x7C, 0xFC]
+    long_modes = [rng.randrange(3) for _ in range(45)]
+    long_page = ogg_util.page(9, 0, 0, [_packet(rng, tocs[m], 5) for m in long_modes])
+    short_modes = [[rng.randrange(3) for _ in range(3)] for _ in range(6)]
+    pages = [ogg_util.page(20 + i, 0, 0, [_packet(rng, tocs[m], 5) for m in ms]) for i, ms in enumerate(short_modes)]
+    pages.insert(3, long_page)
+    ids = list(range(len(pages)))
+    b = _batch(pkg, pages, ids)
+    assert b.info["status"][3] == 45 and b.n_steps == 45
+    for s in range(45):
+        descs, slot_pages = b.step(s)
+        got = [int(f) & 3 for f in descs["flags"]]
+        assert got == sorted(got)
+        want = {3: long_modes[s]}
+        for i, ms in enumerate(short_modes):
+            if s < 3:
+                want[i if i < 3 else i + 1] = ms[s]
+        assert {int(p): g for p, g in zip(slot_pages, got)} == want
+    b.close()
