@@ -436,14 +436,25 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
                                (const StreamState *)ctx->d_streams, srecs, handoff, n, ctx->n_streams);
         }
     }
+    // The launch order of a step on the split path, all on one stream:
+    //   k_silk_parse  k_celt_parse  k_silk_synth  k_celt_recon  k_celt_post  k_decode_step[Q4]
+    // After k_silk_parse the SILK synthesis and the CELT parse + reconstruction are independent (they share no field of
+    // the stream state: SilkRec::prev_mode, og_silk_parse.hpp); only k_celt_post needs both.  Running them on two streams
+    // was measured: next to k_celt_recon the synthesis gains nothing; next to k_celt_parse it gains
+    // 5 % on mixed-mode steps but costs 13 % on CELT-only steps -- k_celt_parse is a single round of long-running
+    // workgroups, and anything occupying slots while it starts (even 65,536 workgroups that exit at once) leaves it
+    // unevenly placed for its whole duration (0.86 -> 1.35 ms).  It therefore starts behind the tiny k_silk_parse only.
+    if (ctx->split_celt) {
+        // CELT-only frames and the CELT half of hybrid frames: parse (one frame per lane) -> records in HBM
+        hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_LANES - 1) / OG_PL_LANES), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
+                           (const StreamState *)ctx->d_streams, (ParseRec *)ctx->d_recs, n, ctx->n_streams,
+                           (const SilkHandoff *)handoff);
+    }
     if (srecs) {
         // SILK-only frames and the SILK half of hybrid frames: arithmetic half, one frame per wave (also reports
-        // stream-index errors); then the rare hybrid -> SILK-only transition frames (Q4) through the full kernel
+        // stream-index errors)
         hipLaunchKernelGGL(k_silk_synth, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams,
                            (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, handoff, (const SilkRec *)srecs);
-        hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
-                           ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, 1, handoff,
-                           (const SilkRec *)srecs, 1);
     } else {
         // every frame (OPUSGPU_SPLIT=0), or every frame that is not CELT-only (OPUSGPU_SPLIT_HYBRID=0)
         hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
@@ -451,17 +462,20 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
                            nullptr, 0);
     }
     if (ctx->split_celt) {
-        // CELT-only frames and the CELT half of hybrid frames: parse (one frame per lane) -> records in HBM ->
         // reconstruct (one frame per wave) -> de-emphasis, SILK mix and PCM (one (frame, channel) per lane)
-        hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_LANES - 1) / OG_PL_LANES), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
-                           (const StreamState *)ctx->d_streams, (ParseRec *)ctx->d_recs, n, ctx->n_streams,
-                           (const SilkHandoff *)handoff);
         hipLaunchKernelGGL(k_celt_recon, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, ctx->d_streams,
                            (const ParseRec *)ctx->d_recs, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride,
                            handoff ? 1 : 0);
         hipLaunchKernelGGL(k_celt_post, dim3((n * ctx->channels + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs,
                            ctx->d_streams, (const ParseRec *)ctx->d_recs, (const i32 *)d_result, (i16 *)d_pcm, n, ctx->n_streams,
                            ctx->channels, pcm_stride, (const SilkHandoff *)handoff);
+    }
+    if (srecs) {
+        // The rare hybrid -> SILK-only transition frames (Q4), parked by k_silk_synth, through the full kernel.  Nothing in
+        // the step waits for it and almost all of its workgroups exit at once: it goes last.
+        hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
+                           ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, 1, handoff,
+                           (const SilkRec *)srecs, 1);
     }
     HIPCHK(ctx, hipGetLastError());
     return OPUSGPU_OK;

@@ -57,7 +57,8 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
     const int audiosize = 960;
     const int CC = st->channels;
     if (len < 0 || len > 1275) return BAD_ARG;
-    const int prev_mode = st->prev_mode;
+    // (split path: the value the parse kernel saw when the step began; see SilkRec::prev_mode)
+    const int prev_mode = srec ? (int)OG_UNI(srec->prev_mode) : st->prev_mode;
     Rc rc;
     if (srec) {
         const int r0 = OG_UNI(srec->ret);

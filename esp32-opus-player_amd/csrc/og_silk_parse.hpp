@@ -38,6 +38,9 @@ struct SilkRec {
     i32 ret; // 0, or the negative code the frame ends with (then nothing else is valid)
     i32 decode_only_middle;
     i32 MS_pred_Q13[2];
+    // The stream's prev_mode when the step began.  The synthesis kernel takes it from here, not from the stream state: on
+    // a hybrid frame the CELT reconstruction kernel -- which may run concurrently -- writes the new value there.
+    i32 prev_mode, pad_[3];
     SilkRecCh ch[2];
 };
 static_assert(sizeof(SilkRec) % 16 == 0, "record alignment");
@@ -263,6 +266,7 @@ OG_DEV void silk_parse_stereo_pred(RcLane &rc, i32 pred_Q13[2]) { // silk_stereo
 OG_DEV void silk_parse_lane(const StreamState *st, const u8 *payload, int len, int mode, int bandwidth, int channels, SilkRec *rec,
                             SilkHandoff *handoff) {
     handoff->valid = 0;
+    rec->prev_mode = st->prev_mode;
     if (len < 0 || len > 1275) {
         rec->ret = BAD_ARG;
         return;
