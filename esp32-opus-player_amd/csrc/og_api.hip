@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <new>
+#include <thread>
 #include <vector>
 #include "og_decode.hpp"
 #include "og_packet.hpp"
@@ -277,6 +278,10 @@ struct opusgpu_ctx {
     // staging for the host-buffer path
     void *d_descs = nullptr, *d_arena = nullptr, *d_pcm = nullptr, *d_result = nullptr;
     size_t cap_descs = 0, cap_arena = 0, cap_pcm = 0, cap_result = 0;
+    // pinned host landing zone of the host-buffer path's PCM and result codes (DMA at full PCIe rate, no zero-filling of
+    // a fresh temporary per call); the caller's pageable buffer is filled from it by a few host threads
+    void *h_pcm = nullptr, *h_res = nullptr;
+    size_t cap_h_pcm = 0, cap_h_res = 0;
     // parse records of the split CELT path (one per frame of a step), grown on demand
     void *d_recs = nullptr, *d_handoff = nullptr, *d_srecs = nullptr;
     size_t cap_recs = 0, cap_handoff = 0, cap_srecs = 0;
@@ -338,6 +343,8 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     (void)hipFree(ctx->d_recs);
     (void)hipFree(ctx->d_handoff);
     (void)hipFree(ctx->d_srecs);
+    (void)hipHostFree(ctx->h_pcm);
+    (void)hipHostFree(ctx->h_res);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -547,6 +554,17 @@ int opusgpu_packet_to_frames(const uint8_t *packet, int32_t len, int32_t stream,
     return count;
 }
 
+static int grow_pinned(opusgpu_ctx *ctx, void **p, size_t *cap, size_t need) {
+    if (*cap >= need) return OPUSGPU_OK;
+    if (*p) HIPCHK(ctx, hipHostFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = need + need / 4;
+    if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) return OPUSGPU_ALLOC_FAIL;
+    *cap = want;
+    return OPUSGPU_OK;
+}
+
 static int grow(opusgpu_ctx *ctx, void **p, size_t *cap, size_t need) {
     if (*cap >= need) return OPUSGPU_OK;
     if (*p) HIPCHK(ctx, hipFree(*p));
@@ -609,8 +627,6 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_arena, arena.data(), arena.size(), hipMemcpyHostToDevice, ctx->stream));
     std::vector<opusgpu_frame_desc> step;
     std::vector<int> owner;
-    std::vector<int16_t> h_pcm;
-    std::vector<int32_t> h_res;
     for (int k = 0; k < max_frames; k++) {
         step.clear();
         owner.clear();
@@ -628,19 +644,33 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
                                    ctx->stream));
         rc = opusgpu_decode_step_device(ctx, m, ctx->d_descs, ctx->d_arena, ctx->d_pcm, ctx->d_result, nullptr);
         if (rc) return rc;
-        h_pcm.resize(frame_pcm * m);
-        h_res.resize(m);
-        HIPCHK(ctx, hipMemcpyAsync(h_pcm.data(), ctx->d_pcm, frame_pcm * 2 * m, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(h_res.data(), ctx->d_result, sizeof(int32_t) * m, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = grow_pinned(ctx, &ctx->h_pcm, &ctx->cap_h_pcm, frame_pcm * 2 * m))) return rc;
+        if ((rc = grow_pinned(ctx, &ctx->h_res, &ctx->cap_h_res, sizeof(int32_t) * m))) return rc;
+        const int16_t *h_pcm = (const int16_t *)ctx->h_pcm;
+        const int32_t *h_res = (const int32_t *)ctx->h_res;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pcm, ctx->d_pcm, frame_pcm * 2 * m, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_res, ctx->d_result, sizeof(int32_t) * m, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        for (int j = 0; j < m; j++) {
-            const int i = owner[j];
-            if (h_res[j] < 0) {
-                result[i] = h_res[j];
-                continue;
+        // every packet owns its own block of the caller's PCM buffer: the blocks are filled by a few threads
+        auto deliver = [&](int lo, int hi) {
+            for (int j = lo; j < hi; j++) {
+                const int i = owner[j];
+                if (h_res[j] < 0) {
+                    result[i] = h_res[j];
+                    continue;
+                }
+                memcpy(pcm + ((size_t)i * frame_capacity + k) * frame_pcm, &h_pcm[(size_t)j * frame_pcm], frame_pcm * 2);
+                result[i] += h_res[j];
             }
-            memcpy(pcm + ((size_t)i * frame_capacity + k) * frame_pcm, &h_pcm[(size_t)j * frame_pcm], frame_pcm * 2);
-            result[i] += h_res[j];
+        };
+        const int threads = m >= 4096 ? 8 : 1;
+        if (threads == 1)
+            deliver(0, m);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < threads; t++)
+                th.emplace_back(deliver, (int)((int64_t)m * t / threads), (int)((int64_t)m * (t + 1) / threads));
+            for (auto &x : th) x.join();
         }
     }
     return OPUSGPU_OK;
