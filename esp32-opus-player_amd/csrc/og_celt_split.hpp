@@ -198,6 +198,7 @@ OG_DEV int parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits,
     int depth = 0, off = 0, silent = 0, n_fill = 0;
     const int jpos = out.reserve(), first_pvq = out.nl;
     for (;;) {
+        OG_MARK(41);
         for (;;) { // descend
             if (!(LM != -1 && b > pulse_cache_max<RomLds>(band, LM) + 12 && N > 2)) break;
             const int B0 = B;
@@ -243,6 +244,7 @@ OG_DEV int parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits,
             }
         }
         { // leaf: pulse count from the remaining budget, then the codeword index (celt.cpp:1463-1480)
+            OG_MARK(42);
             int q = bits2pulses<RomLds>(band, LM, b), curr_bits = pulses2bits<RomLds>(band, LM, q);
             remaining_bits -= curr_bits;
             while (remaining_bits < 0 && q > 0) {
@@ -252,6 +254,7 @@ OG_DEV int parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits,
                 remaining_bits -= curr_bits;
             }
             const int K = q ? get_pulses(q) : 0;
+            OG_MARK(43);
             if (K)
                 out.leaf(x, N, K, B, gain, off, rc_uint(rc, pvq_u_rom(N, K) + pvq_u_rom(N, K + 1)));
             else if (!silent) { // (a silent leaf stays zero, as the spectrum was initialised: nothing to record)
@@ -260,8 +263,10 @@ OG_DEV int parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits,
                 n_fill++;
             }
         }
+        OG_MARK(44);
         for (;;) { // back to the parents
             if (depth == 0) {
+                OG_MARK(40);
                 const int need_low = has_low && n_fill > 0;
                 out.patch(jpos, (u32)n_fill | (u32)(out.nl - first_pvq) << JW_NPVQ_SHIFT | (u32)first_pvq << JW_FIRST_SHIFT |
                                     (need_low ? JW_NEED_LOW : 0));
