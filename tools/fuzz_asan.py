@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Fuzz the kernel source in host emulation under AddressSanitizer + UBSan (CPU only; GPU sanitizers are not available
+on this pool).  Every 20 ms mode / bandwidth, mono and stereo, random mode switches between frames, payloads of 0 .. 1274
+bytes incl. all-zero and all-ones.  The emulated LDS arrays are static globals, which ASan bounds-checks.
+    make -C tests/emul asan
+    LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python3 tools/fuzz_asan.py"""
+import ctypes as C, importlib.util, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("opusgpu_pkg", os.path.join(ROOT, "esp32-opus-player_amd", "__init__.py"))
+pkg = importlib.util.module_from_spec(spec); spec.loader.exec_module(pkg)
+lib = C.CDLL(os.path.join(ROOT, "tests", "emul", "libog_emul_asan.so"))
+lib.emu_state_size.restype = C.c_int
+lib.emu_decode_frame.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+lib.emu_stream_init.argtypes = [C.c_void_p, C.c_int]
+rng = np.random.default_rng(3)
+def mode_bw(toc):
+    if toc & 0x80:
+        bw = 1102 + ((toc >> 5) & 3); return 1002, (1101 if bw == 1102 else bw)
+    if (toc & 0x60) == 0x60: return 1001, (1105 if toc & 0x10 else 1104)
+    return 1000, 1101 + ((toc >> 5) & 3)
+out = np.zeros(960 * 2, dtype=np.int16)
+frames = 0
+for channels in (2, 1):
+    for s in range(150):
+        st = C.create_string_buffer(lib.emu_state_size()); lib.emu_stream_init(st, channels)
+        for f in range(6):
+            cfg = int(rng.choice([1, 5, 9, 13, 15, 19, 23, 27, 31]))   # 20 ms configurations of every mode / bandwidth
+            stereo = bool(rng.integers(2)) if channels == 2 else bool(rng.integers(4) == 0)
+            toc = (cfg << 3) | (4 if stereo else 0)
+            L = int(rng.choice([0, 1, 2, 7, 40, 120, 160, 400, 1274]))
+            kind = rng.integers(6)
+            body = bytes(L) if kind == 0 else (b"\xff" * L if kind == 1 else rng.integers(0, 256, L, dtype=np.uint8).tobytes())
+            m, bw = mode_bw(toc)
+            lib.emu_decode_frame(st, body, L, m, bw, 2 if stereo else 1, out.ctypes.data)
+            frames += 1
+print("frames decoded under ASan/UBSan:", frames)
