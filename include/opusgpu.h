@@ -88,7 +88,16 @@ int opusgpu_memcpy_h2d(opusgpu_ctx *ctx, void *dst, const void *src, size_t byte
 int opusgpu_memcpy_d2h(opusgpu_ctx *ctx, void *dst, const void *src, size_t bytes);
 /* One decode step: n frames described by d_descs (device array of opusgpu_frame_desc), payload bytes in
  * d_arena, PCM to d_pcm[n][960*channels] int16, per-frame result to d_result[n] int32.  Asynchronous on the
- * context's stream (or on `hip_stream` if not NULL: a hipStream_t). */
+ * context's stream (or on `hip_stream` if not NULL: a hipStream_t).
+ * The tables are in device memory and are NOT validated beyond what a frame's own kernel can see.  The caller guarantees:
+ *   - a stream appears at most once in a step (frames of one stream are sequential: one step each);
+ *   - 0 <= offset and offset + len lies inside the arena; d_arena is 4-byte aligned and the ALLOCATION extends at least
+ *     to the next multiple of 4 past the last frame's end (the kernels fetch packets as aligned 32-bit words; allocating
+ *     16 bytes more than the packed bytes, as every producer in this repository does, is enough);
+ *   - d_descs, d_arena, d_pcm and d_result stay valid and unmodified until the step has completed on its stream.
+ * Checked on the device, per frame, and reported in d_result: stream index out of range -> OPUSGPU_BAD_ARG; len outside
+ * 0..1275 -> OPUSGPU_BAD_ARG; every decode error the reference would return for the frame.
+ * opusgpu_packet_to_frames, opusgpu_decode_packets and opusgpu_pages_demux produce tables that satisfy all of this. */
 int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm,
                                void *d_result, void *hip_stream);
 int opusgpu_synchronize(opusgpu_ctx *ctx);
