@@ -62,3 +62,40 @@ def test_celt_host_path_mixed_lengths_and_mono(pkg, oracle, gpu_ctx):
             assert (res == rets[:, f]).all()
             ok = res > 0
             assert (pcm[ok] == ref[ok, f]).all()
+
+
+def test_device_path_reports_bad_descriptors(pkg, oracle, gpu_ctx):
+    """include/opusgpu.h, opusgpu_decode_step_device: a stream index out of range or a frame length outside 0..1275 comes
+    back as OPUSGPU_BAD_ARG in that frame's result; the other frames of the step are decoded as if it were not there."""
+    ctx = gpu_ctx
+    for toc, L in ((pkg.TOC_CELT_FB_STEREO, 160), (pkg.TOC_SILK_NB_STEREO, 40), (pkg.TOC_HYBRID_FB_STEREO, 120)):
+        n = 200
+        pay = pkg.lcg_payloads(n, 2, L, seed_base=0xBAD + L)
+        ref, ok = oracle.batch_decode(2, toc, pay)
+        assert ok == n * 2
+        ctx.streams_alloc(n, 2)
+        d_desc, d_arena = ctx.dev_alloc(16 * n), ctx.dev_alloc(n * (L + 1) + 16)
+        d_pcm, d_res = ctx.dev_alloc(n * 960 * 2 * 2), ctx.dev_alloc(4 * n)
+        out = np.zeros((n, 960, 2), dtype=np.int16)
+        res = np.zeros(n, dtype=np.int32)
+        bad = {5: ("stream", -1), 17: ("stream", n), 40: ("stream", 1 << 30), 63: ("len", 1276), 64: ("len", -1), 130: ("len", 70000)}
+        for f in range(2):
+            arena, descs = pkg.build_step(toc, pay[f])
+            descs = descs.copy()
+            if f == 0:  # the first step carries the broken descriptors; their streams simply skip that frame
+                for slot, (field, value) in bad.items():
+                    descs[field][slot] = value
+            ctx.h2d(d_arena, arena)
+            ctx.h2d(d_desc, descs)
+            ctx.decode_step_device(n, d_desc, d_arena, d_pcm, d_res)
+            ctx.synchronize()
+            ctx.d2h(out, d_pcm)
+            ctx.d2h(res, d_res)
+            good = np.ones(n, dtype=bool)
+            if f == 0:
+                good[list(bad)] = False
+                assert (res[~good] == -1).all(), (hex(toc), res[~good])
+                assert (res[good] == 960).all()
+                assert (out[good] == ref[good, 0]).all()
+        for p in (d_desc, d_arena, d_pcm, d_res):
+            ctx.dev_free(p)
