@@ -148,7 +148,7 @@ def prepare_pages_work(pkg, shard, ranks, ctx, n, frames):
                  "pages_per_s": n_pages / t_demux, "demux_GB_per_s": page_bytes / t_demux / 1e9}
     t0 = time.perf_counter()
     mine = ranks.scatter_bytes(buffers, src=0)
-    if ranks.world > 1:
+    if ranks.dist is not None:
         import torch
         torch.cuda.synchronize()
     t_scatter = time.perf_counter() - t0
@@ -161,7 +161,7 @@ def prepare_pages_work(pkg, shard, ranks, ctx, n, frames):
         lay = shard.WorkLayout(mine[:shard.WORK_HEADER_BYTES].cpu().numpy())
         base, keep = mine.data_ptr(), mine
     if stats is not None:
-        stats["scatter_s"] = t_scatter if ranks.world > 1 else None
+        stats["scatter_s"] = t_scatter if ranks.dist is not None else None
         stats["work_bytes_per_rank"] = int(lay.nbytes)
     return base, lay, stats, keep
 

@@ -95,7 +95,9 @@ class Ranks:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.device = device
-        if self.world > 1:
+        # OPUSGPU_FORCE_DIST=1: take the torch.distributed path with a single rank too (rehearsal of the N > 1 code on a
+        # one-GPU box: process-group init, barrier, all-reduce and scatter over RCCL)
+        if self.world > 1 or os.environ.get("OPUSGPU_FORCE_DIST") == "1":
             import torch
             import torch.distributed as dist
             backend = backend or "nccl"
