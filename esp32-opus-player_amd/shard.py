@@ -104,7 +104,21 @@ class Ranks:
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
                 self.device = torch.device("cuda", self.local_rank)
-                dist.init_process_group(backend="nccl", device_id=self.device)
+                # RCCL prints its version banner (NCCL_DEBUG=VERSION) straight to stdout when the first communicator is
+                # created; this process's stdout carries the result line only, so file descriptor 1 points at stderr
+                # until the group and its communicator exist.
+                import sys
+                sys.stdout.flush()
+                saved = os.dup(1)
+                os.dup2(2, 1)
+                try:
+                    dist.init_process_group(backend="nccl", device_id=self.device)
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                finally:
+                    sys.stdout.flush()
+                    os.dup2(saved, 1)
+                    os.close(saved)
             else:
                 self.device = torch.device("cpu")
                 dist.init_process_group(backend=backend)
