@@ -36,6 +36,35 @@ long oc_batch_decode(int channels, int toc, const u8 *payloads, int n_streams, i
     return ok;
 }
 
+/* Arbitrary packets: frame f of stream s is the packet arena[offs[f * n_streams + s] .. + lens[f * n_streams + s]) (TOC
+ * first, any frame count code).  Streams [s0, s1) are decoded with a fresh decoder each and carry their state across
+ * frames.  rets: [n_streams][n_frames] return value of every call; pcm: [n_streams][n_frames][960][channels], written
+ * for calls that return 960 (the first 960 * channels entries of the decoder's output).  Returns the number of calls that
+ * returned 960. */
+long oc_batch_decode_var(int channels, const u8 *arena, const long long *offs, const i32 *lens, int n_streams, int n_frames,
+                         int s0, int s1, i16 *pcm, i32 *rets) {
+    oc_decoder *d = oc_decoder_create(channels);
+    i16 *tmp = (i16 *)malloc(sizeof(i16) * 5760 * 2);
+    long ok = 0;
+    int s, f;
+    if (!d || !tmp) return -1;
+    for (s = s0; s < s1; s++) {
+        oc_decoder_init(d, channels);
+        for (f = 0; f < n_frames; f++) {
+            const size_t k = (size_t)f * n_streams + s;
+            const int r = oc_decode(d, arena + offs[k], lens[k], tmp, 5760);
+            rets[(size_t)s * n_frames + f] = r;
+            if (r == 960) {
+                ok++;
+                memcpy(pcm + (((size_t)s * n_frames + f) * 960) * channels, tmp, sizeof(i16) * 960 * channels);
+            }
+        }
+    }
+    free(tmp);
+    oc_decoder_destroy(d);
+    return ok;
+}
+
 /* stage taps for parity tests of the HIP kernels: enable once, then copy after each oc_decode() call */
 int oc_taps_enable(oc_decoder *d) {
     if (!d->taps) d->taps = (oc_celt_taps *)calloc(1, sizeof(oc_celt_taps));

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on the GPU (device-resident path), far larger than the test suite: every stream gets its own
+random sequence of 20 ms packets -- mode / bandwidth / mono-stereo switches between frames, payloads of 0 .. 1275 bytes incl.
+all-zero and all-ones -- and every PCM sample and return code is compared with the CPU oracle.
+usage (GPU box): python3 tools/soak_parity.py [streams] [frames] [rounds] [seed]"""
+import importlib.util
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_py  # noqa: E402
+
+spec = importlib.util.spec_from_file_location("opusgpu_pkg", os.path.join(ROOT, "esp32-opus-player_amd", "__init__.py"))
+pkg = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(pkg)
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+seed = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+CONFIGS = np.array([1, 5, 9, 13, 15, 19, 23, 27, 31])  # the 20 ms configuration of every mode / bandwidth
+LENS = np.array([0, 1, 2, 3, 5, 8, 13, 20, 30, 40, 60, 80, 100, 120, 160, 200, 320, 500, 800, 1275])
+oracle = oracle_py.load()
+ctx = pkg.Context(0)
+total = bad_total = errs = 0
+t_start = time.time()
+for rnd in range(rounds):
+    for channels in (2, 1):
+        rng = np.random.default_rng(seed * 1000 + rnd * 2 + channels)
+        # per stream a "home" configuration; each frame keeps it with probability 0.8, else any configuration
+        home = rng.choice(CONFIGS, n)
+        cfg = np.where(rng.random((frames, n)) < 0.8, home[None, :], rng.choice(CONFIGS, (frames, n)))
+        stereo = (rng.random((frames, n)) < (0.85 if channels == 2 else 0.15))
+        toc = (cfg << 3 | np.where(stereo, 4, 0)).astype(np.uint8)
+        lens = rng.choice(LENS, (frames, n), p=np.r_[np.full(4, 0.02), np.full(15, 0.06), 0.02])
+        plen = (lens + 1).astype(np.int64)                      # packet = TOC + payload
+        offs = np.concatenate([[0], np.cumsum(plen.reshape(-1))[:-1]]).reshape(frames, n)
+        arena = rng.integers(0, 256, int(plen.sum()) + 16, dtype=np.uint8)
+        kind = rng.integers(0, 10, (frames, n))
+        for f, s in zip(*np.nonzero(kind == 0)):                # some all-zero / all-ones payloads
+            arena[offs[f, s] + 1: offs[f, s] + plen[f, s]] = 0
+        for f, s in zip(*np.nonzero(kind == 1)):
+            arena[offs[f, s] + 1: offs[f, s] + plen[f, s]] = 255
+        arena[offs.reshape(-1)] = toc.reshape(-1)
+        ref, rets = oracle.batch_decode_var(channels, arena, offs, plen.astype(np.int32))
+        # device path: one step per frame index
+        mode = np.where(toc & 0x80, 2, np.where((toc & 0x60) == 0x60, 1, 0)).astype(np.int32)
+        bw_c = ((toc >> 5) & 3).astype(np.int32)
+        bw = np.where(mode == 2, np.where(bw_c == 0, 0, bw_c + 1), np.where(mode == 1, np.where(toc & 0x10, 4, 3), bw_c))
+        flags = (mode | bw << 2 | np.where(toc & 4, 32, 0)).astype(np.int32)
+        ctx.streams_alloc(n, channels)
+        d_arena = ctx.dev_alloc(arena.size)
+        ctx.h2d(d_arena, arena)
+        d_desc, d_pcm, d_res = ctx.dev_alloc(16 * n), ctx.dev_alloc(n * 960 * channels * 2), ctx.dev_alloc(4 * n)
+        out = np.zeros((n, 960, channels), dtype=np.int16)
+        res = np.zeros(n, dtype=np.int32)
+        descs = np.zeros(n, dtype=pkg.DESC_DTYPE)
+        descs["stream"] = np.arange(n, dtype=np.int32)
+        for f in range(frames):
+            descs["offset"] = (offs[f] + 1).astype(np.int32)
+            descs["len"] = lens[f].astype(np.int32)
+            descs["flags"] = flags[f]
+            ctx.h2d(d_desc, descs)
+            ctx.decode_step_device(n, d_desc, d_arena, d_pcm, d_res)
+            ctx.synchronize()
+            ctx.d2h(out, d_pcm)
+            ctx.d2h(res, d_res)
+            code_bad = np.nonzero(res != rets[:, f])[0]
+            ok = rets[:, f] == 960
+            # Q3: a mono SILK-only packet in a stereo decoder defines only the first 960 interleaved entries
+            half = ok & (mode[f] == 0) & ((toc[f] & 4) == 0) & (channels == 2)
+            full = ok & ~half
+            a, b = out.reshape(n, -1), ref[:, f].reshape(n, -1)
+            pcm_bad = np.nonzero((a[full] != b[full]).any(axis=1))[0]
+            pcm_bad_h = np.nonzero((a[half][:, :960] != b[half][:, :960]).any(axis=1))[0] if half.any() else np.zeros(0, int)
+            nb = code_bad.size + pcm_bad.size + pcm_bad_h.size
+            if nb:
+                print(f"round {rnd} channels {channels} frame {f}: {code_bad.size} return codes, {pcm_bad.size + pcm_bad_h.size} PCM blocks differ"
+                      f" (first code diff stream {code_bad[:3]}, gpu {res[code_bad[:3]]}, oracle {rets[code_bad[:3], f]})", flush=True)
+            bad_total += nb
+            total += n
+            errs += int((rets[:, f] != 960).sum())
+        for p in (d_arena, d_desc, d_pcm, d_res):
+            ctx.dev_free(p)
+        print(f"round {rnd} channels {channels}: {n * frames} frames done, {bad_total} mismatches so far, {time.time() - t_start:.0f} s", flush=True)
+print(f"SOAK: {total} frames compared ({errs} of them error returns, compared as codes), {bad_total} mismatches")
+sys.exit(1 if bad_total else 0)
