@@ -72,6 +72,10 @@ size_t opusgpu_stream_state_bytes(void);
  * at most once per call.  pcm receives n blocks of `frame_capacity` * 960 * channels interleaved int16;
  * result[i] = samples per channel decoded for packet i (frames * 960) or a negative OPUS_* code.
  * Packets with several frames (codes 1-3) are decoded frame after frame like opus_decode_native.
+ * One deliberate difference from the reference: it checks the room as frames * (frame duration from the TOC) but
+ * decodes every frame as 960 samples (src/opus_decoder.cpp:161, :323), so a packet of more short frames than
+ * `frame_capacity` passes its check and overruns the caller's buffer.  Here such a packet gets
+ * OPUSGPU_BUFFER_TOO_SMALL and nothing is written.
  * Returns OPUSGPU_OK or a context-level error. */
 int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, const uint8_t *const *packets,
                            const int32_t *lens, int16_t *pcm, int frame_capacity, int32_t *result);

@@ -41,22 +41,33 @@ long oc_batch_decode(int channels, int toc, const u8 *payloads, int n_streams, i
  * frames.  rets: [n_streams][n_frames] return value of every call; pcm: [n_streams][n_frames][960][channels], written
  * for calls that return 960 (the first 960 * channels entries of the decoder's output).  Returns the number of calls that
  * returned 960. */
+long oc_batch_decode_var_cap(int channels, const u8 *arena, const long long *offs, const i32 *lens, int n_streams, int n_frames,
+                             int s0, int s1, i16 *pcm, i32 *rets, int cap_frames);
 long oc_batch_decode_var(int channels, const u8 *arena, const long long *offs, const i32 *lens, int n_streams, int n_frames,
                          int s0, int s1, i16 *pcm, i32 *rets) {
+    return oc_batch_decode_var_cap(channels, arena, offs, lens, n_streams, n_frames, s0, s1, pcm, rets, 1);
+}
+/* The same with room for cap_frames 20 ms frames per call (multi-frame packets): the decoder is called with
+ * frame_size = 960 * cap_frames like opus_multistream_decode's caller would; pcm: [n_streams][n_frames][960 * cap_frames]
+ * [channels], the first r samples written when the call returns r > 0.  Returns the number of calls with r > 0. */
+long oc_batch_decode_var_cap(int channels, const u8 *arena, const long long *offs, const i32 *lens, int n_streams, int n_frames,
+                             int s0, int s1, i16 *pcm, i32 *rets, int cap_frames) {
     oc_decoder *d = oc_decoder_create(channels);
-    i16 *tmp = (i16 *)malloc(sizeof(i16) * 5760 * 2);
+    /* Q6: the reference checks count * (samples per frame from the TOC) against frame_size but decodes EVERY frame as 960
+     * samples: a packet of many short frames passes the check and writes up to 48 * 960 samples.  Room for that. */
+    i16 *tmp = (i16 *)malloc(sizeof(i16) * 48 * 960 * 2);
     long ok = 0;
     int s, f;
-    if (!d || !tmp) return -1;
+    if (!d || !tmp || cap_frames < 1 || cap_frames > 6) return -1;
     for (s = s0; s < s1; s++) {
         oc_decoder_init(d, channels);
         for (f = 0; f < n_frames; f++) {
             const size_t k = (size_t)f * n_streams + s;
-            const int r = oc_decode(d, arena + offs[k], lens[k], tmp, 5760);
+            const int r = oc_decode(d, arena + offs[k], lens[k], tmp, 960 * cap_frames);
             rets[(size_t)s * n_frames + f] = r;
-            if (r == 960) {
+            if (r > 0 && r <= 960 * cap_frames) {
                 ok++;
-                memcpy(pcm + (((size_t)s * n_frames + f) * 960) * channels, tmp, sizeof(i16) * 960 * channels);
+                memcpy(pcm + (((size_t)s * n_frames + f) * 960 * cap_frames) * channels, tmp, sizeof(i16) * (size_t)r * channels);
             }
         }
     }

@@ -69,26 +69,26 @@ class Oracle:
             x.join()
         return pcm, sum(oks)
 
-    def batch_decode_var(self, channels, arena, offs, lens, threads=None):
+    def batch_decode_var(self, channels, arena, offs, lens, threads=None, cap_frames=1):
         """Arbitrary packets: frame f of stream s = arena[offs[f, s] : offs[f, s] + lens[f, s]] (TOC first).  offs / lens:
-        [frames, streams].  -> (pcm int16 [streams, frames, 960, ch], return codes int32 [streams, frames]); streams are
-        split over host threads."""
+        [frames, streams].  -> (pcm int16 [streams, frames, 960 * cap_frames, ch], return codes int32 [streams, frames]);
+        cap_frames: room (and frame_size) for that many 20 ms frames per call.  Streams are split over host threads."""
         import threading
         nf, ns = offs.shape
         threads = max(1, min(threads or usable_cpus(), ns))
         arena = np.ascontiguousarray(arena, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.int64)
         lens = np.ascontiguousarray(lens, dtype=np.int32)
-        pcm = np.zeros((ns, nf, 960, channels), dtype=np.int16)
+        pcm = np.zeros((ns, nf, 960 * cap_frames, channels), dtype=np.int16)
         rets = np.zeros((ns, nf), dtype=np.int32)
-        self.lib.oc_batch_decode_var.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                                 C.c_void_p, C.c_void_p]
-        self.lib.oc_batch_decode_var.restype = C.c_long
+        self.lib.oc_batch_decode_var_cap.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                     C.c_void_p, C.c_void_p, C.c_int]
+        self.lib.oc_batch_decode_var_cap.restype = C.c_long
         cuts = [ns * t // threads for t in range(threads + 1)]
 
         def work(t):
-            self.lib.oc_batch_decode_var(channels, arena.ctypes.data, offs.ctypes.data, lens.ctypes.data, ns, nf, cuts[t], cuts[t + 1],
-                                         pcm.ctypes.data, rets.ctypes.data)
+            self.lib.oc_batch_decode_var_cap(channels, arena.ctypes.data, offs.ctypes.data, lens.ctypes.data, ns, nf, cuts[t], cuts[t + 1],
+                                             pcm.ctypes.data, rets.ctypes.data, cap_frames)
 
         th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
         for x in th:
