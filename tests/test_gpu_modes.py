@@ -172,3 +172,28 @@ def test_tiny_frames(pkg, oracle, gpu_ctx):
                 # Q3: a mono SILK-only packet in a stereo decoder defines only the first 960 interleaved entries
                 ncmp = 960 if (silk_only and not stereo_pkt and channels == 2) else 960 * channels
                 assert (pcm[s].reshape(-1)[:ncmp] == ref[s, f].reshape(-1)[:ncmp]).all(), (channels, s, f, hex(toc), len(pk[s][f]))
+
+
+def test_more_short_frames_than_room_is_refused(pkg, gpu_ctx):
+    """include/opusgpu.h, opusgpu_decode_packets: four 2.5 ms CELT frames are 480 samples by the TOC, which passes the
+    reference's size check against one 960-sample frame of room -- and the reference then writes 4 x 960 samples (Q6).  The
+    library returns OPUSGPU_BUFFER_TOO_SMALL and writes nothing; the stream's state is untouched (the next frame decodes as
+    if the packet had not been there)."""
+    rng = np.random.default_rng(21)
+    n = 8
+    gpu_ctx.streams_alloc(n, 2)
+    first = [bytes([0xFC]) + rng.integers(0, 256, 100, dtype=np.uint8).tobytes() for _ in range(n)]
+    follow = [bytes([0xFC]) + rng.integers(0, 256, 100, dtype=np.uint8).tobytes() for _ in range(n)]
+    cfg_celt_fb_2_5ms = 28
+    short4 = bytes([cfg_celt_fb_2_5ms << 3 | 4 | 3, 4]) + rng.integers(0, 256, 4 * 20, dtype=np.uint8).tobytes()  # code 3, CBR, 4 frames
+    assert len(pkg.packet_to_frames(short4)) == 4
+    pcm0, res0 = gpu_ctx.decode_packets(np.arange(n), first)
+    assert (res0 == 960).all()
+    pcm1, res1 = gpu_ctx.decode_packets(np.arange(n), [short4] * n, frame_capacity=1)
+    assert (res1 == -2).all() and not pcm1.any()
+    pcm2, res2 = gpu_ctx.decode_packets(np.arange(n), follow)
+    # the same two good packets on fresh streams, without the refused one in between
+    gpu_ctx.streams_alloc(n, 2)
+    gpu_ctx.decode_packets(np.arange(n), first)
+    pcm3, res3 = gpu_ctx.decode_packets(np.arange(n), follow)
+    assert (res2 == 960).all() and (res3 == 960).all() and (pcm2 == pcm3).all()
