@@ -97,6 +97,40 @@ inline int packet_duration(const uint8_t *p, int32_t len) {
     return samples * 25 > 48000 * 3 ? -4 : samples;
 }
 
+// Granule positions (op_granpos_add / _diff / _cmp, opusfile.cpp:299-400).  A granule position is a 64-bit counter whose
+// negative values come AFTER the positive ones, with -1 (= 2^64 - 1) meaning "none": stated here in unsigned arithmetic,
+// which has no undefined overflow.  All three tolerate -1 as an operand (the reference asserts against it) so that a
+// hostile file cannot reach undefined behaviour.
+inline bool gp_add(int64_t *dst, int64_t src, int32_t delta) { // false: the result would cross -1 or drop below 0
+    const uint64_t u = (uint64_t)src;
+    if (delta >= 0) {
+        if (u > UINT64_MAX - 1 - (uint64_t)delta) return false;
+        *dst = (int64_t)(u + (uint64_t)delta);
+    } else {
+        const uint64_t m = (uint64_t)(-(int64_t)delta);
+        if (u < m) return false;
+        *dst = (int64_t)(u - m);
+    }
+    return true;
+}
+inline bool gp_diff(int64_t *delta, int64_t a, int64_t b) { // a - b in counter order; false: it does not fit 64 signed bits
+    const uint64_t ua = (uint64_t)a, ub = (uint64_t)b;
+    if (ua >= ub) {
+        const uint64_t d = ua - ub;
+        if (d > (uint64_t)INT64_MAX) return false;
+        *delta = (int64_t)d;
+    } else {
+        const uint64_t d = ub - ua;
+        if (d > (uint64_t)INT64_MAX + 1) return false;
+        *delta = d == (uint64_t)INT64_MAX + 1 ? INT64_MIN : -(int64_t)d;
+    }
+    return true;
+}
+inline int gp_cmp(int64_t a, int64_t b) { return ((uint64_t)a > (uint64_t)b) - ((uint64_t)b > (uint64_t)a); }
+// samples still to trim from a packet of `dur` samples when `diff` samples remain before the page's granule position
+// (the overflow guard of opusfile.cpp:1066-1070: a hugely negative diff means "far too many")
+inline int64_t gp_trim(int dur, int64_t diff) { return diff < 0 && INT64_MAX + diff < dur ? (int64_t)dur + 1 : dur - diff; }
+
 struct Page {
     int header_type = 0;
     int64_t granulepos = -1;
@@ -197,7 +231,7 @@ class OpusFile {
     std::vector<Packet> op_;
     size_t op_pos_ = 0;
     int32_t cur_discard_ = 0;
-    int64_t prev_packet_gp_ = -1;
+    int64_t prev_packet_gp_ = -1, pcm_start_ = 0;
     std::vector<int16_t> od_;
     int od_pos_ = 0, od_size_ = 0;
 
@@ -354,17 +388,19 @@ class OpusFile {
         const int64_t cur_page_gp = pk.back().granulepos;
         if (cur_page_gp == -1) return OP_EBADTIMESTAMP;
         const bool eos = pk.back().e_o_s;
-        int64_t pcm_start = cur_page_gp - total;
-        if (pcm_start < 0) {
+        int64_t pcm_start;
+        if (!gp_add(&pcm_start, cur_page_gp, -total)) { // less audio before the granule position than the page carries
             if (!eos) return OP_EBADTIMESTAMP;
-            pcm_start = 0;
-            if (cur_page_gp < (int64_t)head_.pre_skip) return OP_EBADTIMESTAMP;
+            pcm_start = 0; // end trimming: the stream starts at zero by definition
+            if (gp_cmp(cur_page_gp, (int64_t)head_.pre_skip) < 0) return OP_EBADTIMESTAMP;
         }
         int64_t prev = pcm_start;
         size_t pi;
         for (pi = 0; pi < pk.size(); pi++) {
             if (eos) {
-                int64_t diff = dur[pi] - (cur_page_gp - prev);
+                int64_t diff;
+                if (!gp_diff(&diff, cur_page_gp, prev)) return OP_EBADTIMESTAMP; // (the reference reads an unset variable here)
+                diff = gp_trim(dur[pi], diff);
                 if (diff > 0) {
                     if (diff > dur[pi]) break;
                     pk[pi].granulepos = prev = cur_page_gp;
@@ -372,13 +408,15 @@ class OpusFile {
                     continue;
                 }
             }
-            pk[pi].granulepos = prev = prev + dur[pi];
+            int64_t g;
+            if (gp_add(&g, prev, dur[pi])) pk[pi].granulepos = g; // (on overflow the packet keeps what the page gave it)
+            prev = pk[pi].granulepos;
         }
         pk.resize(pi);
         op_.swap(pk);
         op_pos_ = 0;
         cur_discard_ = (int32_t)head_.pre_skip;
-        prev_packet_gp_ = pcm_start;
+        prev_packet_gp_ = pcm_start_ = pcm_start;
         return 0;
     }
 
@@ -407,34 +445,36 @@ class OpusFile {
                         if (hole) return OP_HOLE;
                         continue;
                     }
-                    prev = cur_page_gp != -1 ? cur_page_gp - total : 0;
-                    if (prev < 0) prev = 0;
+                    prev = pcm_start_; // an unusable granule position: count on from the start of the stream
+                    if (cur_page_gp != -1) (void)gp_add(&prev, cur_page_gp, -total);
                     cur_discard_ = 80 * 48;
                 }
-                if (cur_page_gp == -1) cur_page_gp = prev + total;
+                // completed packets but no granule position on the page (illegal): count forwards from the previous page
+                if (cur_page_gp == -1 && !gp_add(&cur_page_gp, prev, total)) return OP_EBADTIMESTAMP; // timeline exhausted
                 size_t pi;
-                if (eos && cur_page_gp - prev < total) { // end trimming
-                    int64_t diff = cur_page_gp - prev, cur = prev;
+                int64_t diff;
+                if (eos && gp_diff(&diff, cur_page_gp, prev) && diff < total) { // end trimming
+                    int64_t cur = prev;
                     for (pi = 0; pi < pk.size(); pi++) {
-                        diff = dur[pi] - diff;
+                        diff = gp_trim(dur[pi], diff);
                         if (diff > 0) {
                             if (diff > dur[pi]) break;
                             cur = cur_page_gp;
                             pk[pi].e_o_s = true;
                         } else
-                            cur += dur[pi];
+                            (void)gp_add(&cur, cur, dur[pi]);
                         pk[pi].granulepos = cur;
-                        diff = cur_page_gp - cur;
+                        (void)gp_diff(&diff, cur_page_gp, cur);
                     }
-                } else {
-                    prev = cur_page_gp - total;
-                    if (prev < 0) prev = 0;
+                } else { // timestamps backwards from the page's granule position; an underflowing start counts as 0
+                    if (!gp_add(&prev, cur_page_gp, -total)) prev = 0;
                     int32_t left = total;
                     for (pi = 0; pi < pk.size(); pi++) {
-                        int64_t cur = cur_page_gp - left;
-                        if (cur < 0) cur = 0;
+                        int64_t cur;
+                        if (!gp_add(&cur, cur_page_gp, -left)) cur = 0;
                         left -= dur[pi];
-                        pk[pi].granulepos = cur + dur[pi];
+                        (void)gp_add(&cur, cur, dur[pi]);
+                        pk[pi].granulepos = cur;
                     }
                 }
                 prev_packet_gp_ = prev;
@@ -457,12 +497,10 @@ class OpusFile {
                 const int nch = head_.channel_count;
                 const int duration = packet_duration(pop.data.data(), (int32_t)pop.data.size());
                 int trimmed = duration;
-                if (pop.e_o_s) {
-                    if (pop.granulepos <= prev_packet_gp_) trimmed = 0;
-                    else {
-                        int64_t diff = pop.granulepos - prev_packet_gp_;
-                        if (diff < trimmed) trimmed = (int)diff;
-                    }
+                if (pop.e_o_s) { // end trimming (opusfile.cpp:1220-1227)
+                    int64_t diff;
+                    if (gp_cmp(pop.granulepos, prev_packet_gp_) <= 0) trimmed = 0;
+                    else if (gp_diff(&diff, pop.granulepos, prev_packet_gp_) && diff < trimmed) trimmed = (int)diff;
                 }
                 prev_packet_gp_ = pop.granulepos;
                 if (od_.size() < (size_t)nch * 5760) od_.resize((size_t)nch * 5760); // 120 ms at 48 kHz
