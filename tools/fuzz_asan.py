@@ -9,7 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("opusgpu_pkg", os.path.join(ROOT, "esp32-opus-player_amd", "__init__.py"))
 pkg = importlib.util.module_from_spec(spec); spec.loader.exec_module(pkg)
-lib = C.CDLL(os.path.join(ROOT, "tests", "emul", "libog_emul_asan.so"))
+lib = C.CDLL(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "emul", "libog_emul_asan.so"))
 lib.emu_state_size.restype = C.c_int
 lib.emu_decode_frame.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
 lib.emu_stream_init.argtypes = [C.c_void_p, C.c_int]
