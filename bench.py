@@ -111,11 +111,14 @@ def mixed_cpu_baseline():
             "per_mode_frames_per_s": [p["value"] for p in parts], "host_logical_cpus": parts[0]["host_logical_cpus"]}
 
 
-def prepare_pages_work(pkg, shard, ranks, ctx, n, frames):
+def prepare_pages_work(pkg, shard, ranks, ctx, n, frames, ingest="rank0"):
     """mixed_pages workload: rank 0 builds the Ogg pages of every rank's streams (`frames` packets per stream in pages of
-    PACKETS_PER_PAGE, chained), turns them into decode steps (opusgpu_pages_demux, host threads) and scatters the packed
-    work.  Returns (device address of this rank's work, its layout, ingest statistics, keep-alive object)."""
+    PACKETS_PER_PAGE, chained) and routes them by owner.  ingest = "rank0": it also turns them into decode steps
+    (opusgpu_pages_demux, host threads) and scatters the packed work -- one demux for the whole job.  ingest = "per-rank":
+    it scatters the raw pages and every rank demuxes its own share on its own host CPUs -- demux capacity grows with the
+    rank count.  Returns (device address of this rank's work, its layout, ingest statistics, keep-alive object)."""
     threads = shard.usable_cpus()
+    per_rank = ingest == "per-rank"
     buffers, stats = None, None
     if ranks.rank == 0:
         buffers, n_pages, page_bytes, t_demux = [], 0, 0, 0.0
@@ -135,6 +138,11 @@ def prepare_pages_work(pkg, shard, ranks, ctx, n, frames):
             offs = np.concatenate([[0], np.cumsum(lens.astype(np.int64))[:-1]])
             sids = np.concatenate([ids[i][1] for i in order])
             del mats
+            n_pages += len(lens)
+            page_bytes += int(blob.size)
+            if per_rank:
+                buffers.append(shard.pack_pages(blob, lens, sids))
+                continue
             t0 = time.perf_counter()
             batch = pkg.PageBatch(blob, offs, lens, sids, threads=threads)
             t_demux += time.perf_counter() - t0
@@ -142,16 +150,30 @@ def prepare_pages_work(pkg, shard, ranks, ctx, n, frames):
                 raise SystemExit("page demux rejected synthetic pages")
             buffers.append(shard.pack_work(batch))
             batch.close()
-            n_pages += len(lens)
-            page_bytes += int(blob.size)
-        stats = {"pages": n_pages, "page_bytes": page_bytes, "demux_s": t_demux, "demux_threads": threads,
-                 "pages_per_s": n_pages / t_demux, "demux_GB_per_s": page_bytes / t_demux / 1e9}
+        stats = {"mode": ingest, "pages": n_pages, "page_bytes": page_bytes, "demux_threads": threads}
+        if not per_rank:
+            stats.update({"demux_s": t_demux, "pages_per_s": n_pages / t_demux, "demux_GB_per_s": page_bytes / t_demux / 1e9})
     t0 = time.perf_counter()
     mine = ranks.scatter_bytes(buffers, src=0)
     if ranks.dist is not None:
         import torch
         torch.cuda.synchronize()
     t_scatter = time.perf_counter() - t0
+    if per_rank:
+        # this rank's raw pages -> host (they may have arrived in HBM), demux here, steps -> HBM
+        raw = mine if isinstance(mine, np.ndarray) else mine.cpu().numpy()
+        blob, offs, lens, sids = shard.unpack_pages(raw)
+        t0 = time.perf_counter()
+        batch = pkg.PageBatch(blob, offs, lens, sids, threads=threads)
+        t_local = time.perf_counter() - t0
+        if not (batch.info["status"] > 0).all():
+            raise SystemExit("page demux rejected synthetic pages")
+        mine = shard.pack_work(batch)
+        batch.close()
+        # the job's demux rate: all pages over the slowest rank's demux time
+        t_max = ranks.max_over_ranks(t_local)
+        if stats is not None:
+            stats.update({"demux_s": t_max, "pages_per_s": stats["pages"] / t_max, "demux_GB_per_s": stats["page_bytes"] / t_max / 1e9})
     if isinstance(mine, np.ndarray):  # one rank: host -> HBM directly
         lay = shard.WorkLayout(mine)
         base = ctx.dev_alloc(mine.size)
@@ -173,6 +195,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="celt_fb_stereo_64k", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
+    ap.add_argument("--ingest", default="rank0", choices=["rank0", "per-rank"],
+                    help="mixed_pages_2m: who demuxes the Ogg pages (rank 0 for all, or every rank its own share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -193,7 +217,7 @@ def main():
     ingest = None
     if mixed:
         # work arrives at rank 0 as Ogg pages and is scattered: the path's one exchange step, before the timed region
-        base, lay, ingest, _keep = prepare_pages_work(pkg, load_shard(), ranks, ctx, n, K + W)
+        base, lay, ingest, _keep = prepare_pages_work(pkg, load_shard(), ranks, ctx, n, K + W, args.ingest)
         if lay.counts != [n] * (K + W):
             raise SystemExit(f"unexpected step tables: {lay.counts[:4]}...")
 
@@ -275,8 +299,10 @@ def main():
                                     f"10 steps, modes SILK-NB : hybrid FB : CELT FB = 1:1:1 across streams (TOC 0x0C / 0x7C / "
                                     f"0xFC, 40 / 120 / 160-byte LCG payloads), 48 kHz stereo, step tables grouped by mode",
                         "streams_per_gpu": n,
-                        "sharding": "rank 0 ingests the pages (host demux) and scatters every rank's decode steps "
-                                    "(torch.distributed scatter = RCCL), before the timed region; no collective inside it"}
+                        "sharding": ("rank 0 ingests the pages (host demux) and scatters every rank's decode steps "
+                                     if args.ingest == "rank0" else
+                                     "rank 0 routes the raw pages and scatters them, every rank demuxes its own share "
+                                     ) + "(torch.distributed scatter = RCCL), before the timed region; no collective inside it"}
                        if mixed else
                        {"workload": f"{args.workload}: {n} streams/GPU x 20 ms frames, 48 kHz stereo, "
                                     f"TOC 0x{toc:02X}, {L}-byte LCG payloads, state persistent across steps",

@@ -86,6 +86,45 @@ class WorkLayout:
         self.nbytes = self.arena_at + _pad256(self.arena_bytes)
 
 
+# ---- raw pages for one rank in one buffer (the scalable ingest: the receiving rank demuxes its own share) ---------------
+# [ int64: magic, n_pages, blob bytes | int32 lens[n_pages] | int32 stream_ids[n_pages] | page bytes ], parts 256-aligned
+PAGES_MAGIC = 0x4F475047
+
+
+def pack_pages(blob, lens, stream_ids):
+    """Pages back to back in `blob` (page i is lens[i] bytes long), their decoder streams -> one uint8 buffer."""
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    ids = np.ascontiguousarray(stream_ids, dtype=np.int32)
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    n = len(lens)
+    if len(ids) != n or int(lens.sum()) != blob.size:
+        raise ValueError("lens / stream_ids / blob do not describe the same pages")
+    lens_at = 256
+    ids_at = lens_at + _pad256(4 * n)
+    blob_at = ids_at + _pad256(4 * n)
+    buf = np.zeros(blob_at + _pad256(blob.size), dtype=np.uint8)
+    buf[:24].view(np.int64)[:] = (PAGES_MAGIC, n, blob.size)
+    buf[lens_at:lens_at + 4 * n] = lens.view(np.uint8)
+    buf[ids_at:ids_at + 4 * n] = ids.view(np.uint8)
+    buf[blob_at:blob_at + blob.size] = blob
+    return buf
+
+
+def unpack_pages(buf):
+    """-> (blob, offsets, lens, stream_ids) views into a pack_pages buffer (host memory)."""
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    magic, n, nbytes = (int(x) for x in buf[:24].view(np.int64))
+    if magic != PAGES_MAGIC:
+        raise ValueError("not a packed page buffer")
+    lens_at = 256
+    ids_at = lens_at + _pad256(4 * n)
+    blob_at = ids_at + _pad256(4 * n)
+    lens = buf[lens_at:lens_at + 4 * n].view(np.int32)
+    ids = buf[ids_at:ids_at + 4 * n].view(np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens.astype(np.int64))[:-1]]) if n else np.zeros(0, np.int64)
+    return buf[blob_at:blob_at + nbytes], offs, lens, ids
+
+
 class Ranks:
     """Rank/world bookkeeping + the collectives the path uses."""
 

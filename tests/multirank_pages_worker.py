@@ -50,6 +50,20 @@ def work_for(rank):
     return buf
 
 
+def raw_for(rank):
+    items = pages_of(range(rank * m, (rank + 1) * m))
+    blob = np.frombuffer(b"".join(p for p, _ in items), dtype=np.uint8)
+    lens = np.array([len(p) for p, _ in items], dtype=np.int32)
+    return shard.pack_pages(blob, lens, np.array([g - rank * m for _, g in items], dtype=np.int32))
+
+
+# second ingest mode: raw pages are scattered and every rank demuxes its own share; the result must be the same work
+raw = ranks.scatter_bytes([raw_for(r) for r in range(ranks.world)] if ranks.rank == 0 else None, src=0)
+blob, offs, lens, local = shard.unpack_pages(raw)
+b2 = pkg.PageBatch(blob, offs, lens, local)
+per_rank_work = shard.pack_work(b2)
+b2.close()
+
 buffers = [work_for(r) for r in range(ranks.world)] if ranks.rank == 0 else None
 mine = ranks.scatter_bytes(buffers, src=0)
 want = work_for(ranks.rank)
@@ -60,7 +74,8 @@ for k in range(lay.n_steps):
     modes.append([int(f) & 3 for f in d["flags"]])
 out = {"rank": ranks.rank, "same": bool(mine.size == want.size and (mine == want).all()), "size": int(mine.size),
        "n_steps": lay.n_steps, "counts": lay.counts, "grouped": all(x == sorted(x) for x in modes),
-       "crc": zlib.crc32(mine.tobytes()), "nbytes": lay.nbytes}
+       "crc": zlib.crc32(mine.tobytes()), "nbytes": lay.nbytes,
+       "per_rank_same": bool(per_rank_work.size == want.size and (per_rank_work == want).all())}
 with open(os.path.join(os.environ["OG_TEST_OUT"], f"pages_rank{ranks.rank}.json"), "w") as fh:
     json.dump(out, fh)
 ranks.close()

@@ -46,6 +46,7 @@ def test_work_queue_scatter(tmp_path):
     r = [json.load(open(tmp_path / f"pages_rank{k}.json")) for k in range(2)]
     for k, x in enumerate(r):
         assert x["rank"] == k and x["same"], x
+        assert x["per_rank_same"], x  # raw pages scattered, demuxed by the receiving rank: the same work
         assert x["n_steps"] == 4 and x["counts"] == [30] * 4  # 30 streams per rank, 4 packets per page
         assert x["grouped"] and x["size"] == x["nbytes"]
     assert r[0]["crc"] != r[1]["crc"]  # different streams, different work
