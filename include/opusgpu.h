@@ -123,7 +123,10 @@ int opusgpu_stream_state_get(opusgpu_ctx *ctx, int index, void *dst, size_t byte
  * the arena and the step's table are copied to the device; frames of one page land in consecutive steps, and a second
  * page of the same stream in the same call starts where the first one ends, so a stream never appears twice in a step.
  * A page must carry whole packets: one that starts with the tail or ends with the head of a spanning packet is
- * reported (OPUSGPU_PAGE_SPANS) and contributes nothing; the file surface (opusfile.h) handles such streams. */
+ * reported (OPUSGPU_PAGE_SPANS) and contributes nothing; the file surface (opusfile.h) handles such streams.
+ * Every frame becomes its own step entry: if a frame of a multi-frame packet fails on the device (in practice a CELT or
+ * hybrid frame of at most one byte, which the reference's CELT decoder rejects), the later frames of that packet are
+ * still decoded.  opus_decode_native -- and opusgpu_decode_packets -- stop at a packet's first failing frame. */
 #define OPUSGPU_PAGE_BAD_CAPTURE (-200) /* no "OggS", stream structure version != 0, or shorter than its header says */
 #define OPUSGPU_PAGE_BAD_CRC (-201)     /* only with OPUSGPU_PAGES_VERIFY_CRC */
 #define OPUSGPU_PAGE_SPANS (-202)
