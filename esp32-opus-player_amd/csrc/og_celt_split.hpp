@@ -685,6 +685,25 @@ OG_DEV u32 rec_word(RecCur &cur) {
     return w;
 }
 
+// Four consecutive words (a band's header): when they lie inside the current window -- 15 times out of 16 -- the four LDS
+// reads have no refill check between them and issue together (one latency instead of four).
+OG_DEV void rec_word4(RecCur &cur, u32 &w0, u32 &w1, u32 &w2, u32 &w3) {
+    const int at = cur.w & 63;
+    if (at != 0 && at <= 60) {
+        const u32 a = S.win[at], b = S.win[at + 1], c = S.win[at + 2], d = S.win[at + 3];
+        w0 = (u32)OG_UNI(a);
+        w1 = (u32)OG_UNI(b);
+        w2 = (u32)OG_UNI(c);
+        w3 = (u32)OG_UNI(d);
+        cur.w += 4;
+        return;
+    }
+    w0 = rec_word(cur);
+    w1 = rec_word(cur);
+    w2 = rec_word(cur);
+    w3 = rec_word(cur);
+}
+
 // The noise generator jumped ahead (lcg_skip) by n = lane + 1, lane + 65, lane + 129 steps: s -> a s + c.  Computed
 // once per frame; every noise / dither pass then costs one multiply-add per coefficient.
 struct LcgTab {
@@ -878,7 +897,8 @@ OG_DEV void recon_all_bands(const u32 *words, u32 need_norm, const LcgTab &lcg, 
     for (int i = start; i < end; i++) {
         OG_MARK(3);
         const int last = i == end - 1;
-        const u32 w0 = rec_word(cur), w1 = rec_word(cur), w2 = rec_word(cur), w3 = rec_word(cur);
+        u32 w0, w1, w2, w3;
+        rec_word4(cur, w0, w1, w2, w3);
         const int eb0 = (int)(w1 >> 11) & 2047, N = (int)(w1 >> 22) & 255;
         const int x = V_X + eb0, y = C == 2 ? V_X + N_ch + eb0 : -1;
         const int dual_stereo = (w0 & BW_DUAL) != 0;
