@@ -7,8 +7,12 @@ Two kinds of fixture:
                         the oracle still reproduces them.  They are the parity pin of the oracle.
   oracle_vectors.*   -- vectors produced by the oracle (NOT by the reference) for regression and for checking the
                         GPU path on machines where the oracle library is not built: per-frame FNV-1a hashes of
-                        48 streams x 6 frames per mode, and full PCM of 2 streams x 2 frames per mode.
-Inputs are the LCG payloads of SURVEY.md section 8d (seed 0x9E3779B9 ^ stream id)."""
+                        64 streams x 16 frames per mode, and full PCM of 2 streams x 4 frames per mode.
+                        Inputs are the LCG payloads of SURVEY.md section 8d (seed 0x9E3779B9 ^ stream id).
+  oracle_sequences.json -- explicit packet sequences (hex) for the quirk cases, with the oracle's return code and PCM hash
+                        per call: mono decoders, a mono packet in a stereo decoder (Q3: only the defined half is
+                        hashed), multi-frame packets of every frame-count code with room for three frames (Q6), and a
+                        mode-switch sequence incl. hybrid -> SILK-only (Q4) and CELT <-> SILK."""
 import json
 import os
 import sys
@@ -24,21 +28,79 @@ from conftest import load_pkg  # noqa: E402
 MODES = {"celt_fb_stereo": (0xFC, 160), "silk_nb_stereo": (0x0C, 40), "hybrid_fb_stereo": (0x7C, 120)}
 
 
+CAP = 3  # room for three 20 ms frames per call in the sequences
+
+
+def _bytes(rng, n):
+    return rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+
+
+def _size(a):  # frame length field of code 2 / VBR code 3 (RFC 6716 section 3.2.1)
+    return bytes([a]) if a < 252 else bytes([252 + (a & 3), (a - 252 - (a & 3)) >> 2])
+
+
+def sequence_packets():
+    """name -> (decoder channels, [packets])."""
+    rng = np.random.default_rng(20260401)
+    seqs = {}
+    for name, toc, L in (("mono_celt_fb", 0xF8, 80), ("mono_silk_nb", 0x08, 30), ("mono_hybrid_fb", 0x78, 70)):
+        seqs[name] = (1, [bytes([toc]) + _bytes(rng, L) for _ in range(6)])
+    # Q3: mono packets in a stereo decoder, all three modes, between stereo packets
+    seqs["mono_packets_in_stereo_decoder"] = (2, [bytes([t]) + _bytes(rng, 60) for t in (0xFC, 0xF8, 0x0C, 0x08, 0x0C, 0x7C, 0x78, 0xFC)])
+    # Q6: every frame-count code; CELT, SILK and hybrid; a 10 ms configuration that the reference decodes as 20 ms
+    mf = []
+    for toc in (0xFC, 0x0C, 0x7C):
+        mf.append(bytes([toc | 1]) + _bytes(rng, 2 * 50))                                   # code 1: two equal frames
+        mf.append(bytes([toc | 2]) + _size(40) + _bytes(rng, 40 + 70))                      # code 2: 40 + 70
+        mf.append(bytes([toc | 3, 3]) + _bytes(rng, 3 * 45))                                # code 3 CBR, 3 frames
+        mf.append(bytes([toc | 3, 0x80 | 2]) + _size(30) + _bytes(rng, 30 + 55))            # code 3 VBR, 2 frames
+        mf.append(bytes([toc | 3, 0x40 | 2, 5]) + _bytes(rng, 2 * 35) + bytes(5))           # code 3 CBR, padding
+        mf.append(bytes([toc]) + _bytes(rng, 90))                                           # back to one frame
+    mf.append(bytes([(30 << 3) | 4 | 1]) + _bytes(rng, 2 * 40))                             # CELT FB 10 ms x 2 (Q6)
+    mf.append(bytes([0xFC | 3, 4]) + _bytes(rng, 4 * 30))                                   # four 20 ms frames: too many for the room
+    mf.append(bytes([0xFC | 3, 0]) + _bytes(rng, 10))                                       # code 3 with 0 frames: invalid
+    mf.append(bytes([0xFC]) + _bytes(rng, 100))
+    seqs["multiframe_packets"] = (2, mf)
+    # Q4 and friends: CELT -> hybrid -> SILK-only (the transition frame) -> hybrid -> CELT -> SILK -> CELT, varying bandwidth
+    order = (0xFC, 0x7C, 0x0C, 0x0C, 0x6C, 0x2C, 0x7C, 0xFC, 0xDC, 0x4C, 0xFC, 0x7C, 0x4C, 0x0C)
+    seqs["mode_switches"] = (2, [bytes([t]) + _bytes(rng, 50 + 7 * i) for i, t in enumerate(order)])
+    return seqs
+
+
+def sequences(o):
+    out = {"generator": "oracle (oracle/liboc_oracle.so), NOT the reference", "frame_capacity": CAP, "sequences": {}}
+    for name, (channels, packets) in sequence_packets().items():
+        d = o.decoder(channels)
+        d.init()
+        calls = []
+        for p in packets:
+            pcm, r = d.decode_cap(p, CAP)
+            toc = p[0]
+            silk_mono_in_stereo = channels == 2 and not (toc & 0x80) and (toc & 0x60) != 0x60 and not (toc & 4)
+            h = None
+            if r > 0 and not silk_mono_in_stereo:
+                h = oracle_py.fnv1a_u16(pcm[:r])
+            calls.append({"packet": p.hex(), "ret": int(r), "fnv1a_u16": h})
+        out["sequences"][name] = {"channels": channels, "calls": calls}
+    return out
+
+
 def main():
     o = oracle_py.load()
     pkg = load_pkg()
     hashes, pcm = {}, {}
     for name, (toc, L) in MODES.items():
-        pay = pkg.lcg_payloads(48, 6, L)
+        pay = pkg.lcg_payloads(64, 16, L)
         ref, ok = o.batch_decode(2, toc, pay)
-        assert ok == 48 * 6
-        hashes[name] = {"toc": toc, "payload_len": L, "streams": 48, "frames": 6,
-                        "fnv1a_u16": [[oracle_py.fnv1a_u16(ref[s, f]) for f in range(6)] for s in range(48)]}
-        pcm[name] = ref[:2, :2].copy()
+        assert ok == 64 * 16
+        hashes[name] = {"toc": toc, "payload_len": L, "streams": 64, "frames": 16,
+                        "fnv1a_u16": [[oracle_py.fnv1a_u16(ref[s, f]) for f in range(16)] for s in range(64)]}
+        pcm[name] = ref[:2, :4].copy()
     json.dump({"generator": "oracle (oracle/liboc_oracle.so), NOT the reference", "payloads": "lcg_payloads(seed 0x9E3779B9 ^ stream)",
                "modes": hashes}, open(os.path.join(HERE, "oracle_vectors.json"), "w"), indent=0)
     np.savez_compressed(os.path.join(HERE, "oracle_vectors_pcm.npz"), **pcm)
-    print("wrote oracle_vectors.json / oracle_vectors_pcm.npz")
+    json.dump(sequences(o), open(os.path.join(HERE, "oracle_sequences.json"), "w"), indent=0)
+    print("wrote oracle_vectors.json / oracle_vectors_pcm.npz / oracle_sequences.json")
 
 
 if __name__ == "__main__":

@@ -134,6 +134,11 @@ class OracleDecoder:
         r = self.o.lib.oc_decode(self.h, bytes(packet), len(packet), self.buf.ctypes.data, 5760)
         return self.buf, r
 
+    def decode_cap(self, packet: bytes, cap_frames):
+        """Like a caller with room for cap_frames 20 ms frames (frame_size = 960 * cap_frames)."""
+        r = self.o.lib.oc_decode(self.h, bytes(packet), len(packet), self.buf.ctypes.data, 960 * cap_frames)
+        return self.buf, r
+
     def __del__(self):
         try:
             self.o.lib.oc_decoder_destroy(self.h)
