@@ -408,6 +408,32 @@ static u32 alg_unquant(bandctx *cx, i16 *X, int N, int K, int spread, int B, i16
     return mask;
 }
 
+/* TEST ENTRY (unit known-answer tests of the HIP kernels' leaf decode): alg_unquant with the codeword index given instead of
+ * read from the range decoder.  Returns the collapse mask; X receives N values. */
+u32 oc_test_pvq_leaf(int N, int K, u32 index, int spread, int B, int gain, i16 *X) {
+    i32 iy[176 + 4], Ryy, t;
+    u32 mask;
+    int i, k;
+    i16 g;
+    Ryy = oc_cwrsi(N, K, index, iy);
+    k = ilog2p(Ryy) >> 1;
+    t = vshr32(Ryy, 2 * (k - 7));
+    g = (i16)m16_p15(oc_rsqrt_norm(t), (i16)gain);
+    for (i = 0; i < N; i++) X[i] = (i16)pshr32(m16(g, iy[i]), k + 1);
+    oc_exp_rotation(X, N, -1, B, K, spread);
+    if (B <= 1) return 1;
+    {
+        int N0 = (int)((u32)N / (u32)B), j;
+        mask = 0;
+        for (i = 0; i < B; i++) {
+            u32 tmp = 0;
+            for (j = 0; j < N0; j++) tmp |= iy[i * N0 + j];
+            mask |= (u32)(tmp != 0) << i;
+        }
+    }
+    return mask;
+}
+
 /* celt.cpp:1113 */
 static void stereo_merge(i16 *X, i16 *Y, i16 mid, int N) {
     i32 xp = 0, side = 0, El, Er, t, lgain, rgain;

@@ -1,0 +1,84 @@
+"""Unit known-answer test ("cwrsi over all (N,K) reachable"): the kernels' PVQ leaf decode -- codeword index ->
+pulses -> scaled to the leaf gain -> spreading rotation undone -> collapse mask -- in host emulation against the oracle's
+alg_unquant, for every (N, K) the pulse cache of the 48 kHz mode can produce, over several indices (first, last, random),
+block counts, spread settings and gains.  CPU only."""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tables():
+    spec = importlib.util.spec_from_file_location("gen_rom", os.path.join(ROOT, "tools", "gen_rom_tables.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _get_pulses(q):
+    return q if q < 8 else (8 + (q & 7)) << ((q >> 3) - 1)
+
+
+def reachable_nk():
+    """(N, K) pairs of the pulse cache (compute_pulse_cache layout: index[(LM + 1) * nbEBands + band], LM = -1 .. 3)."""
+    t = _tables()
+    nb = 21
+    out = set()
+    for lm in range(-1, 4):
+        for i in range(nb):
+            width = t.EBAND[i + 1] - t.EBAND[i]
+            n = width << lm if lm >= 0 else width >> 1
+            if n < 1 or (lm < 0 and width & 1):
+                continue
+            idx = t.PULSE_IDX[(lm + 1) * nb + i]
+            if idx < 0:
+                continue
+            for q in range(1, t.PULSE_BITS[idx] + 1):
+                out.add((n, _get_pulses(q)))
+    return sorted(out)
+
+
+def _v(n, k, memo={}):  # V(n, k) = number of PVQ codewords = U(n, k) + U(n, k + 1)
+    def u(a, b):
+        if (a, b) in memo:
+            return memo[(a, b)]
+        if a == 0 or b == 0:
+            r = 1 if (a == 0 and b == 0) else 0
+        else:
+            r = u(a - 1, b) + u(a, b - 1) + u(a - 1, b - 1)
+        memo[(a, b)] = r
+        return r
+    import sys
+    sys.setrecursionlimit(10000)
+    return u(n, k) + u(n, k + 1)
+
+
+def test_pvq_leaf_over_all_reachable_n_k(oracle):
+    emu = C.CDLL(os.path.join(ROOT, "tests", "emul", "libog_emul.so"))
+    emu.emu_pvq_leaf.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    emu.emu_pvq_leaf.restype = C.c_uint
+    oracle.lib.oc_test_pvq_leaf.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    oracle.lib.oc_test_pvq_leaf.restype = C.c_uint
+    rng = np.random.default_rng(8)
+    pairs = [(n, k) for n, k in reachable_nk() if n >= 2]  # N = 1 bands carry a sign bit, not a PVQ codeword
+    assert len(pairs) > 300 and max(n for n, _ in pairs) == 176
+    a, b = np.zeros(176, dtype=np.int16), np.zeros(176, dtype=np.int16)
+    checked = 0
+    for n, k in pairs:
+        v = _v(n, k)
+        assert 0 < v <= 0xFFFFFFFF, (n, k, v)  # a legal (N, K) has a 32-bit codebook
+        idxs = {0, v - 1, v // 2} | {int(x) for x in rng.integers(0, v, 4)}
+        blocks = [bb for bb in (1, 2, 4, 8, 16) if n % bb == 0 and n // bb >= 1]
+        for index in idxs:
+            for B in blocks:
+                for spread in (0, 1, 2, 3):
+                    gain = int(rng.choice([32767, 16384, 23170, 1, 12345]))
+                    ma = emu.emu_pvq_leaf(n, k, index, B, gain, spread, a.ctypes.data)
+                    mb = oracle.lib.oc_test_pvq_leaf(n, k, index, spread, B, gain, b.ctypes.data)
+                    assert ma == mb, ("mask", n, k, index, B, spread, gain, ma, mb)
+                    assert (a[:n] == b[:n]).all(), ("X", n, k, index, B, spread, gain)
+                    checked += 1
+    assert checked > 20000
