@@ -595,6 +595,10 @@ OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, in
     // gains[tapset][0..2] Q15 (celt.cpp:854)
     T0 = OG_MAX(T0, 15);
     T1 = OG_MAX(T1, 15);
+    OG_STAT(50, 1);                                   // comb filter calls that filter
+    OG_STAT(51, T1 == 15 || T0 == 15);                // ... at the shortest lag
+    OG_STAT(52, T1 >= 1020 || T0 >= 1020);            // ... at (almost) the longest: 1020 .. 1022
+    OG_STAT(53, T1 == 1022 || T0 == 1022);
     i32 ga0 = tap0 == 0 ? 10048 : tap0 == 1 ? 15200 : 26208, ga1 = tap0 == 0 ? 7112 : tap0 == 1 ? 8784 : 3280,
         ga2 = tap0 == 0 ? 4248 : 0;
     i32 gb0 = tap1 == 0 ? 10048 : tap1 == 1 ? 15200 : 26208, gb1 = tap1 == 0 ? 7112 : tap1 == 1 ? 8784 : 3280,
