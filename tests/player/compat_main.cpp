@@ -1,0 +1,72 @@
+// TEST PROGRAM for the reference-compatible decoder surface (include/opus_decoder.h over libopusgpu.so): what a caller of
+// opus_decode / opus_multistream_decode / the ctls / the packet helpers would do, driven by a script file so that the
+// Python test can compare every result with the CPU oracle.
+//   script:  records  'D' u32 frame_size u32 len bytes   decode (single-stream decoder and multistream wrapper, both)
+//                     'R'                                 OPUS_RESET_STATE on both
+//                     'Q'                                 ctl queries + packet helpers of the last packet
+//   output:  per 'D': i32 ret_single, i32 ret_ms, then min(ret, frame_size) * 2 int16 of the single-stream PCM if ret > 0
+//            per 'Q': 8 x i32
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "opus_decoder.h"
+
+static const int16_t GUARD = 0x7A7A;
+
+int main(int argc, char **argv) {
+    if (argc < 3) return 2;
+    FILE *in = fopen(argv[1], "rb"), *out = fopen(argv[2], "wb");
+    if (!in || !out) return 2;
+    OpusDecoder *st = (OpusDecoder *)malloc((size_t)opus_decoder_get_size(2));
+    if (!st || opus_decoder_init(st, 48000, 2) != OPUS_OK) { fprintf(stderr, "opus_decoder_init failed\n"); return 1; }
+    int err = 1;
+    const uint8_t mapping[2] = {0, 1};
+    OpusMSDecoder_t *ms = opus_multistream_decoder_create(48000, 2, 1, 1, mapping, &err);
+    if (!ms || err != OPUS_OK) { fprintf(stderr, "opus_multistream_decoder_create failed (%d)\n", err); return 1; }
+    std::vector<uint8_t> last;
+    int cmd, guards_ok = 1, decodes = 0;
+    while ((cmd = fgetc(in)) != EOF) {
+        if (cmd == 'D') {
+            uint32_t fs = 0, len = 0;
+            if (fread(&fs, 4, 1, in) != 1 || fread(&len, 4, 1, in) != 1) return 2;
+            last.resize(len);
+            if (len && fread(last.data(), 1, len, in) != len) return 2;
+            const size_t room = (size_t)fs * 2, guard = 4096;
+            std::vector<int16_t> a(room + guard, GUARD), b(room + guard, GUARD);
+            const int32_t ra = opus_decode(st, last.data(), (int32_t)len, a.data(), (int)fs);
+            const int32_t rb = opus_multistream_decode(ms, last.data(), (int32_t)len, b.data(), (int)fs);
+            for (size_t i = room; i < room + guard; i++) guards_ok &= a[i] == GUARD && b[i] == GUARD;
+            fwrite(&ra, 4, 1, out);
+            fwrite(&rb, 4, 1, out);
+            if (ra > 0) {
+                const size_t n = (size_t)(ra < (int32_t)fs ? ra : (int32_t)fs) * 2;
+                fwrite(a.data(), 2, n, out);
+                if (rb != ra || memcmp(a.data(), b.data(), n * 2) != 0) { fprintf(stderr, "single-stream and multistream disagree\n"); return 1; }
+            }
+            decodes++;
+        } else if (cmd == 'R') {
+            if (opus_decoder_ctl(st, OPUS_RESET_STATE) != OPUS_OK || opus_multistream_decoder_ctl(ms, OPUS_RESET_STATE) != OPUS_OK) return 1;
+        } else if (cmd == 'Q') {
+            int32_t v[8] = {0};
+            opus_decoder_ctl(st, OPUS_GET_SAMPLE_RATE_REQUEST, &v[0]);
+            opus_decoder_ctl(st, OPUS_GET_BANDWIDTH_REQUEST, &v[1]);
+            opus_decoder_ctl(st, OPUS_GET_LAST_PACKET_DURATION_REQUEST, &v[2]);
+            if (!last.empty()) {
+                v[3] = opus_packet_get_nb_frames(last.data(), (int32_t)last.size());
+                v[4] = opus_packet_get_nb_samples(last.data(), (int32_t)last.size(), 48000);
+                v[5] = opus_packet_get_nb_channels(last.data());
+                v[6] = opus_packet_get_bandwidth(last.data());
+                v[7] = opus_packet_get_samples_per_frame(last.data(), 48000);
+            }
+            fwrite(v, 4, 8, out);
+        } else
+            return 2;
+    }
+    printf("decodes=%d guards=%s\n", decodes, guards_ok ? "intact" : "OVERRUN");
+    opus_multistream_decoder_destroy(ms);
+    opus_decoder_destroy(st);
+    fclose(out);
+    return guards_ok ? 0 : 1;
+}

@@ -88,3 +88,65 @@ def test_main_like_player_on_gpu(tmp_path):
     assert "calls=100" in log and "final=-128" in log, log
     assert pcm.size // 2 == 95688
     assert fnv1a_u16(pcm) == 0xA6FEB1E8
+
+
+@pytest.mark.gpu
+def test_opus_decoder_h_surface_on_gpu(tmp_path, oracle):
+    """include/opus_decoder.h (the operator boundary the container layer calls): opus_decode and opus_multistream_decode on
+    single- and multi-frame packets in all modes, OPUS_RESET_STATE (the reference's partial reset, Q5), the ctl queries and
+    the packet helpers, against the oracle; and the over-long packet (Q6) -- more short frames than the caller's frame_size
+    has room for at 960 samples each: the reference's return value, only frame_size samples written, guard region intact."""
+    import struct
+    src = os.path.join(ROOT, "tests", "player", "compat_main.cpp")
+    exe = str(tmp_path / "compat")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), src,
+                           "-L", os.path.join(ROOT, "esp32-opus-player_amd"), "-lopusgpu",
+                           "-Wl,-rpath," + os.path.join(ROOT, "esp32-opus-player_amd"), "-o", exe])
+    rng = np.random.default_rng(31)
+    body = lambda n: rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    steps = []  # ('D', frame_size, packet) | ('R',) | ('Q',)
+    for toc in (0xFC, 0x0C, 0x7C, 0xFC):
+        steps += [("D", 2880, bytes([toc]) + body(80)), ("Q",), ("D", 960, bytes([toc]) + body(60)),
+                  ("D", 2880, bytes([toc | 1]) + body(2 * 40)), ("Q",), ("D", 2880, bytes([toc | 3, 3]) + body(3 * 30)),
+                  ("D", 960, bytes([toc | 1]) + body(2 * 40)),      # two 20 ms frames, room for one: BUFFER_TOO_SMALL
+                  ("R",), ("D", 5760, bytes([toc]) + body(100)), ("Q",)]
+    over_long = bytes([(28 << 3) | 4 | 3, 4]) + body(4 * 20)        # CELT FB 2.5 ms x 4: 480 samples by the TOC
+    steps += [("D", 960, over_long), ("Q",), ("D", 960, bytes([0xFC]) + body(90))]
+    script = b""
+    for s in steps:
+        script += s[0].encode() + (struct.pack("<II", s[1], len(s[2])) + s[2] if s[0] == "D" else b"")
+    (tmp_path / "script.bin").write_bytes(script)
+    log = subprocess.check_output([exe, str(tmp_path / "script.bin"), str(tmp_path / "out.bin")], text=True)
+    assert "guards=intact" in log, log
+    got = (tmp_path / "out.bin").read_bytes()
+    d = oracle.decoder(2)
+    d.init()
+    at, last, last_ret = 0, None, 0
+    for s in steps:
+        if s[0] == "R":
+            d.reset()
+        elif s[0] == "D":
+            fs, pkt = s[1], s[2]
+            ra, rb = struct.unpack_from("<ii", got, at)
+            at += 8
+            # the oracle with generous room decodes every frame (Q6: 960 samples each); with the caller's room it applies
+            # the reference's size check
+            pcm, r = d.decode_cap(pkt, 6) if pkt is over_long else d.decode_cap(pkt, fs // 960)
+            assert ra == rb == r, (hex(pkt[0]), fs, ra, rb, r)
+            if r > 0:
+                n = min(r, fs)
+                out = np.frombuffer(got, dtype=np.int16, count=2 * n, offset=at).reshape(n, 2)
+                at += 4 * n
+                assert (out == pcm[:n]).all(), (hex(pkt[0]), fs)
+                last_ret = r
+            last = pkt
+        else:
+            v = struct.unpack_from("<8i", got, at)
+            at += 32
+            toc = last[0]
+            bw = 1101 + ((toc >> 5) & 3) if not toc & 0x80 and (toc & 0x60) != 0x60 else (
+                (1105 if toc & 0x10 else 1104) if not toc & 0x80 else {0: 1101, 1: 1103, 2: 1104, 3: 1105}[(toc >> 5) & 3])
+            assert v[0] == 48000 and v[2] == last_ret
+            assert v[5] == (2 if toc & 4 else 1) and v[6] == bw
+            assert v[3] == (1 if toc & 3 == 0 else 2 if toc & 3 != 3 else last[1] & 63) and v[4] == v[3] * v[7]
+    assert at == len(got)
