@@ -202,9 +202,12 @@ int opus_multistream_decode(OpusMSDecoder_t *st, uint8_t *data, int32_t len, int
     if (!buf) return OPUS_ALLOC_FAIL;
     int ret = dec_decode(&m->dec, data, len, buf, frame_size);
     if (ret > 0) { // opus_copy_channel_out_short by mapping (src/opus_decoder.cpp:881-910)
+        // A packet of more short frames than frame_size has room for at 960 samples each returns more than frame_size
+        // (Q6): only what the caller has room for -- and what `buf` holds -- is handed out (dec_decode did the same).
+        const int n = ret < frame_size ? ret : frame_size;
         for (int c = 0; c < st->nb_channels; c++) {
             const int mp = st->mapping[c];
-            for (int i = 0; i < ret; i++) {
+            for (int i = 0; i < n; i++) {
                 int16_t v = 0;
                 if (mp != 255) v = (dch == 2) ? buf[2 * i + (mp & 1)] : buf[i];
                 pcm[i * st->nb_channels + c] = v;
