@@ -3,8 +3,7 @@
 bookkeeping; untrusted input) under AddressSanitizer + UBSan, with a stub decode callback so that only container logic
 runs.  Files are built page by page with structural mutations and, mostly, recomputed CRCs (so the damage gets past the
 CRC check), then bit-flipped / truncated.
-    g++ -std=c++17 -O1 -g -fPIC -shared -fsanitize=address,undefined -DCT_STUB_DECODE -Iesp32-opus-player_amd/csrc -Ioracle \\
-        tests/emul/og_container_test.cpp -Loracle -loc_oracle -Wl,-rpath,$PWD/oracle -o /tmp/libct_asan.so
+    make -C tests/emul container_asan
     LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=halt_on_error=1:abort_on_error=1 \
         python3 tools/fuzz_container_asan.py
 (UBSan only prints by default: with halt_on_error the process dies at the first report, so reaching the last line means none.)"""
@@ -20,9 +19,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ogg_util  # noqa: E402
 
-lib = C.CDLL(sys.argv[1] if len(sys.argv) > 1 else "/tmp/libct_asan.so")
-lib.ct_open.argtypes = [C.c_char_p, C.c_size_t, C.c_int]
-lib.ct_read_stereo.argtypes = [C.c_void_p, C.c_int]
 rng = random.Random(2024)
 TOCS = [0xFC, 0xFD, 0xFF, 0x0C, 0x7C, 0x08, 0x00, 0x4B, 0xF8, 0xE3]
 
@@ -103,19 +99,27 @@ def make_file():
     return bytes(data)
 
 
-buf = np.zeros(2048 * 2, dtype=np.int16)
-opened = reads = samples = 0
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
-for it in range(N):
-    data = make_file()
-    if lib.ct_open(data, len(data), rng.choice([-1, 0])) != 0:
-        continue
-    opened += 1
-    for _ in range(300):
-        r = lib.ct_read_stereo(buf.ctypes.data, rng.choice([2048, 2048, 960, 100, 2]))
-        if r <= 0:
-            break
-        assert r <= 1024
-        reads += 1
-        samples += r
-print(f"{N} files, {opened} opened, {reads} successful reads, {samples} samples per channel delivered; reached the end (run with UBSAN_OPTIONS=halt_on_error=1 for that to mean: no report)")
+def main():
+    lib = C.CDLL(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "emul", "libct_asan.so"))
+    lib.ct_open.argtypes = [C.c_char_p, C.c_size_t, C.c_int]
+    lib.ct_read_stereo.argtypes = [C.c_void_p, C.c_int]
+    buf = np.zeros(2048 * 2, dtype=np.int16)
+    opened = reads = samples = 0
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
+    for it in range(N):
+        data = make_file()
+        if lib.ct_open(data, len(data), rng.choice([-1, 0])) != 0:
+            continue
+        opened += 1
+        for _ in range(300):
+            r = lib.ct_read_stereo(buf.ctypes.data, rng.choice([2048, 2048, 960, 100, 2]))
+            if r <= 0:
+                break
+            assert r <= 1024
+            reads += 1
+            samples += r
+    print(f"{N} files, {opened} opened, {reads} successful reads, {samples} samples per channel delivered; reached the end (run with UBSAN_OPTIONS=halt_on_error=1 for that to mean: no report)")
+
+
+if __name__ == "__main__":
+    main()
