@@ -82,3 +82,80 @@ def test_mixed_mode_pages_small(pkg, oracle, gpu_ctx):
 def test_mixed_mode_pages_c5_share(pkg, oracle, gpu_ctx):
     """One GPU's share of config C5 (2 M pages over 8 GPUs): 262,143 pages of 10 packets, one page per stream."""
     _run(pkg, oracle, gpu_ctx, 262144 - 262144 % 3, 1, 10, threads=16)
+
+
+def test_ragged_pages_random_modes(pkg, oracle, gpu_ctx):
+    """Ragged input on the page path: every stream has its own number of pages (1 - 3, chained) and packets per page (1 - 8),
+    its own mode / bandwidth / mono-stereo per packet and payload lengths from 2 to 400 bytes, so later steps are only
+    partly filled, groups differ from step to step and chained pages start at different steps.  Every frame against the
+    oracle (frames of a stream in order: page by page, packet by packet)."""
+    import random
+    import ogg_util
+    shard = _shard()
+    rng = random.Random(77)
+    n = 1500
+    cfgs = [1, 5, 9, 13, 15, 19, 23, 27, 31]
+    streams = []  # per stream: list of packets in decode order
+    pages, ids = [], []
+    for s in range(n):
+        home = rng.choice(cfgs)
+        pk = []
+        for q in range(rng.randrange(1, 4)):
+            page_pk = []
+            for _ in range(rng.randrange(1, 9)):
+                cfg = home if rng.random() < 0.8 else rng.choice(cfgs)
+                toc = cfg << 3 | (4 if rng.random() < 0.8 else 0)
+                page_pk.append(bytes([toc]) + bytes(rng.getrandbits(8) for _ in range(rng.choice([2, 3, 10, 40, 120, 160, 400]))))
+            pages.append((q, s, ogg_util.page(1000 + s, 2 + q, 0, page_pk)))
+            pk += page_pk
+        streams.append(pk)
+    pages.sort(key=lambda x: (x[0], rng.random()))  # a stream's pages in order, streams shuffled within each wave of pages
+    blob = np.frombuffer(b"".join(p for _, _, p in pages), dtype=np.uint8)
+    lens = np.array([len(p) for _, _, p in pages], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens.astype(np.int64))[:-1]])
+    sids = np.array([s for _, s, _ in pages], dtype=np.int32)
+    batch = pkg.PageBatch(blob, offs, lens, sids, threads=4)
+    assert (batch.info["status"] > 0).all()  # all pages accepted
+    frames = max(len(pk) for pk in streams)
+    assert batch.n_steps == frames
+    work = shard.pack_work(batch)
+    batch.close()
+    lay = shard.WorkLayout(work)
+    assert lay.counts == [sum(1 for pk in streams if len(pk) > k) for k in range(frames)]
+    # oracle: every stream's packets in order
+    plen = np.zeros((frames, n), dtype=np.int64)
+    for s, pk in enumerate(streams):
+        plen[:len(pk), s] = [len(p) for p in pk]
+    aoffs = np.concatenate([[0], np.cumsum(plen.reshape(-1))[:-1]]).reshape(frames, n)
+    arena = np.zeros(int(plen.sum()) + 16, dtype=np.uint8)
+    for s, pk in enumerate(streams):
+        for f, p in enumerate(pk):
+            arena[aoffs[f, s]:aoffs[f, s] + len(p)] = np.frombuffer(p, dtype=np.uint8)
+    # (streams that have run out contribute zero-length "packets": the oracle returns an error for those and they are skipped)
+    ref, rets = oracle.batch_decode_var(2, arena, aoffs, plen.astype(np.int32))
+    gpu_ctx.streams_alloc(n, 2)
+    d_work = gpu_ctx.dev_alloc(work.size)
+    d_pcm, d_res = gpu_ctx.dev_alloc(n * 960 * 2 * 2), gpu_ctx.dev_alloc(4 * n)
+    try:
+        gpu_ctx.h2d(d_work, work)
+        for k in range(frames):
+            m = lay.counts[k]
+            out = np.zeros((m, 960, 2), dtype=np.int16)
+            res = np.zeros(m, dtype=np.int32)
+            gpu_ctx.decode_work_step(d_work, lay, k, d_pcm, d_res)
+            gpu_ctx.synchronize()
+            gpu_ctx.d2h(out, d_pcm)
+            gpu_ctx.d2h(res, d_res)
+            descs = np.frombuffer(work[lay.desc_at[k]:lay.desc_at[k] + 16 * m].tobytes(), dtype=pkg.DESC_DTYPE)
+            stream = descs["stream"]
+            assert len(set(stream.tolist())) == m and (np.diff(descs["flags"] & 3) >= 0).all()
+            assert sorted(stream.tolist()) == [s for s, pk in enumerate(streams) if len(pk) > k]
+            assert (res == rets[stream, k]).all(), (k, res[res != rets[stream, k]][:4])
+            for j in np.nonzero(res == 960)[0]:
+                s = stream[j]
+                toc = streams[s][k][0]
+                ncmp = 960 if (not toc & 0x80 and (toc & 0x60) != 0x60 and not toc & 4) else 1920  # Q3
+                assert (out[j].reshape(-1)[:ncmp] == ref[s, k].reshape(-1)[:ncmp]).all(), (k, s, hex(toc))
+    finally:
+        for p in (d_work, d_pcm, d_res):
+            gpu_ctx.dev_free(p)
