@@ -1208,6 +1208,7 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz,
     silk_decode_core_rows(s, fs_kHz, channels);
 #endif
     OG_SYNC();
+    OG_TAP(40); // decoder control + core output of every coded channel (host emulation only)
     OG_MARK(35);
     // outBuf update (silk.cpp:2031-2034): ltp_mem_length == frame_length, so the history is exactly this frame
     for (int n = 0; n < channels; n++)

@@ -62,6 +62,35 @@ struct oc_silk {
 
 int oc_silk_sizeof(void) { return (int)sizeof(struct oc_silk); }
 
+/* TEST ENTRY: stage taps of the last SILK frame decoded (single-threaded tests only): per coded channel the decoder
+ * control (gains, pitch lags, both sets of LPC coefficients, LTP taps and scale), the signal type and the internal-rate
+ * output of the synthesis core, taken before stereo un-mixing rewrites it in place. */
+static struct {
+    int on;
+    i32 valid[2], signalType[2], quantOffsetType[2], frame_length[2], lpc_order[2];
+    ctrl_t ctrl[2];
+    i16 xq[2][MAX_FRAME];
+} g_silk_taps;
+void oc_silk_taps_enable(int on) { g_silk_taps.on = on; }
+/* what: 0 = {valid, signalType, quantOffsetType, frame_length, LPC order, LTP_scale_Q14} (i32 x 6), 1 = pitchL + Gains_Q16
+ * (i32 x 8), 2 = PredCoef_Q12 (i16 x 2 x 16), 3 = LTPCoef_Q14 (i16 x 20), 4 = xq (i16 x frame_length).  Returns bytes. */
+int oc_silk_taps_copy(int what, int ch, void *dst) {
+    if (ch < 0 || ch > 1) return -1;
+    switch (what) {
+        case 0: {
+            i32 v[6] = {g_silk_taps.valid[ch], g_silk_taps.signalType[ch], g_silk_taps.quantOffsetType[ch],
+                        g_silk_taps.frame_length[ch], g_silk_taps.lpc_order[ch], g_silk_taps.ctrl[ch].LTP_scale_Q14};
+            memcpy(dst, v, sizeof(v));
+            return (int)sizeof(v);
+        }
+        case 1: memcpy(dst, g_silk_taps.ctrl[ch].pitchL, 8 * sizeof(i32)); return 8 * (int)sizeof(i32);
+        case 2: memcpy(dst, g_silk_taps.ctrl[ch].PredCoef_Q12, sizeof(g_silk_taps.ctrl[ch].PredCoef_Q12)); return (int)sizeof(g_silk_taps.ctrl[ch].PredCoef_Q12);
+        case 3: memcpy(dst, g_silk_taps.ctrl[ch].LTPCoef_Q14, sizeof(g_silk_taps.ctrl[ch].LTPCoef_Q14)); return (int)sizeof(g_silk_taps.ctrl[ch].LTPCoef_Q14);
+        case 4: memcpy(dst, g_silk_taps.xq[ch], sizeof(i16) * (size_t)g_silk_taps.frame_length[ch]); return (int)sizeof(i16) * g_silk_taps.frame_length[ch];
+    }
+    return -1;
+}
+
 /* silk_init_decoder silk.cpp:2192 */
 static void chan_init(chan_t *c) {
     memset(c, 0, sizeof(*c));
@@ -931,6 +960,7 @@ int oc_silk_decode(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int fir
     }
     memset(tmp, 0, sizeof(tmp));
     has_side = !decode_only_middle;
+    if (g_silk_taps.on) g_silk_taps.valid[0] = g_silk_taps.valid[1] = 0;
     for (n = 0; n < channels; n++) {
         if (n == 0 || has_side) {
             int FrameIndex = s->ch[0].nFramesDecoded - n, condCoding;
@@ -941,6 +971,15 @@ int oc_silk_decode(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int fir
             else
                 condCoding = 2;
             decode_frame(&s->ch[n], &s->ctrl, rc, &tmp[n][2], &nSamplesOutDec, condCoding);
+            if (g_silk_taps.on) {
+                g_silk_taps.valid[n] = 1;
+                g_silk_taps.signalType[n] = s->ch[n].idx.signalType;
+                g_silk_taps.quantOffsetType[n] = s->ch[n].idx.quantOffsetType;
+                g_silk_taps.frame_length[n] = s->ch[n].frame_length;
+                g_silk_taps.lpc_order[n] = s->ch[n].LPC_order;
+                g_silk_taps.ctrl[n] = s->ctrl;
+                memcpy(g_silk_taps.xq[n], &tmp[n][2], sizeof(i16) * (size_t)s->ch[n].frame_length);
+            }
         } else
             memset(&tmp[n][2], 0, nSamplesOutDec * sizeof(i16));
         s->ch[n].nFramesDecoded++;

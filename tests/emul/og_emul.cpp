@@ -54,13 +54,35 @@ extern "C" unsigned emu_pvq_leaf(int n, int k, unsigned index, int B, int gain, 
 // ---- stage taps -------------------------------------------------------------------------------
 static int16_t tap_X[1920], tap_bandE[42];
 static int32_t tap_syn_pre[2][1080], tap_syn_post[2][1080];
+static og::SilkCtrl tap_silk_ctrl[2];
+static int16_t tap_silk_xq[2][og::SILK_MAX_FRAME];
 extern "C" void og_emul_tap(int id) {
+    if (id == 40) { // SILK: decoder control and core output, before stereo un-mixing rewrites xq
+        for (int c = 0; c < 2; c++) {
+            tap_silk_ctrl[c] = og::SL().ctrl[c];
+            memcpy(tap_silk_xq[c], &og::SL().xq[c][2], sizeof(tap_silk_xq[c]));
+        }
+        return;
+    }
     if (id == 1) { memcpy(tap_X, &og::S.v[og::V_X], sizeof(tap_X)); memcpy(tap_bandE, og::S.bandE, sizeof(tap_bandE)); }
     // synthesis taps come once per channel: id = 2 (IMDCT output) or 3 (comb filter output), + 16 * channel
     if ((id & 15) == 2) memcpy(tap_syn_pre[id >> 4], og::syn_buf(), 1080 * 4);
     if ((id & 15) == 3) memcpy(tap_syn_post[id >> 4], og::syn_buf(), 1080 * 4);
 }
 extern "C" {
+// what as in the oracle's oc_silk_taps_copy: 0 = {coded, signalType, quantOffsetType, -, -, LTP_scale_Q14}, 1 = pitchL + Gains_Q16,
+// 2 = PredCoef_Q12, 3 = LTPCoef_Q14, 4 = xq (SILK_MAX_FRAME values)
+int emu_tap_silk(int what, int ch, void *dst) {
+    const og::SilkCtrl &k = tap_silk_ctrl[ch];
+    switch (what) {
+        case 0: { int32_t v[6] = {k.coded, k.signalType, k.quantOffsetType, 0, 0, k.LTP_scale_Q14}; memcpy(dst, v, sizeof v); return sizeof v; }
+        case 1: memcpy(dst, k.pitchL, 8 * sizeof(int32_t)); return 8 * sizeof(int32_t);
+        case 2: memcpy(dst, k.PredCoef_Q12, sizeof k.PredCoef_Q12); return sizeof k.PredCoef_Q12;
+        case 3: memcpy(dst, k.LTPCoef_Q14, sizeof k.LTPCoef_Q14); return sizeof k.LTPCoef_Q14;
+        case 4: memcpy(dst, tap_silk_xq[ch], sizeof tap_silk_xq[ch]); return sizeof tap_silk_xq[ch];
+    }
+    return -1;
+}
 const int16_t *emu_tap_X(void) { return tap_X; }
 const int16_t *emu_tap_bandE(void) { return tap_bandE; }
 const int32_t *emu_tap_syn_pre(int c) { return tap_syn_pre[c]; }
