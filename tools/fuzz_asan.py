@@ -3,7 +3,7 @@
 on this pool).  Every 20 ms mode / bandwidth, mono and stereo, random mode switches between frames, payloads of 0 .. 1274
 bytes incl. all-zero and all-ones.  The emulated LDS arrays are static globals, which ASan bounds-checks.
     make -C tests/emul asan
-    LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python3 tools/fuzz_asan.py"""
+    LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python3 tools/fuzz_asan.py [lib.so [streams [seed]]]"""
 import ctypes as C, importlib.util, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +13,8 @@ lib = C.CDLL(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "
 lib.emu_state_size.restype = C.c_int
 lib.emu_decode_frame.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
 lib.emu_stream_init.argtypes = [C.c_void_p, C.c_int]
-rng = np.random.default_rng(3)
+STREAMS = int(sys.argv[2]) if len(sys.argv) > 2 else 150   # per decoder configuration (stereo, mono); 6 frames each
+rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 3)
 def mode_bw(toc):
     if toc & 0x80:
         bw = 1102 + ((toc >> 5) & 3); return 1002, (1101 if bw == 1102 else bw)
@@ -22,7 +23,7 @@ def mode_bw(toc):
 out = np.zeros(960 * 2, dtype=np.int16)
 frames = 0
 for channels in (2, 1):
-    for s in range(150):
+    for s in range(STREAMS):
         st = C.create_string_buffer(lib.emu_state_size()); lib.emu_stream_init(st, channels)
         for f in range(6):
             cfg = int(rng.choice([1, 5, 9, 13, 15, 19, 23, 27, 31]))   # 20 ms configurations of every mode / bandwidth
