@@ -25,7 +25,7 @@ EXPORTS = [
     "opusgpu_decode_step_device", "opusgpu_synchronize", "opusgpu_event_create", "opusgpu_event_record",
     "opusgpu_event_elapsed_ms", "opusgpu_event_destroy", "opusgpu_stream_state_get",
     "opusgpu_pages_demux", "opusgpu_page_batch_steps", "opusgpu_page_batch_step", "opusgpu_page_batch_arena",
-    "opusgpu_page_batch_free",
+    "opusgpu_page_batch_free", "opusgpu_pages_crc_device",
 ]
 
 
@@ -85,6 +85,7 @@ def load_lib():
     lib.opusgpu_page_batch_arena.restype = vp
     lib.opusgpu_page_batch_free.argtypes = [vp]
     lib.opusgpu_page_batch_free.restype = None
+    lib.opusgpu_pages_crc_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -131,6 +132,38 @@ class PageBatch:
         nbytes = C.c_size_t()
         a = lib.opusgpu_page_batch_arena(h, C.byref(nbytes))
         self.arena = np.ctypeslib.as_array((C.c_uint8 * nbytes.value).from_address(a)) if nbytes.value else np.zeros(0, np.uint8)
+
+    @classmethod
+    def with_gpu_crc(cls, ctx, d_blob, blob, offsets, lens, stream_ids, flags=PAGES_GROUP_BY_MODE, threads=1):
+        """The steps PageBatch(..., flags | PAGES_VERIFY_CRC) makes, with the checksums computed on the GPU
+        (opusgpu_pages_crc_device) from the copy of the pages that lies in HBM at `d_blob` (same offsets as in `blob`,
+        e.g. raw pages delivered by the work-queue scatter); the host demux then skips its own CRC pass.  Pages whose
+        checksum does not match are kept out of the demux and reported as PAGE_BAD_CRC."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        n = len(offsets)
+        st = np.zeros(n, dtype=np.int32)
+        if n:
+            bufs = [ctx.dev_alloc(8 * n), ctx.dev_alloc(4 * n), ctx.dev_alloc(4 * n)]
+            try:
+                ctx.h2d(bufs[0], offsets)
+                ctx.h2d(bufs[1], lens)
+                ctx.pages_crc_device(n, d_blob, bufs[0], bufs[1], bufs[2])
+                ctx.synchronize()
+                ctx.d2h(st, bufs[2])
+            finally:
+                for b in bufs:
+                    ctx.dev_free(b)
+        batch = cls(blob, offsets, np.where(st == 1, lens, 0), stream_ids, flags & ~PAGES_VERIFY_CRC, threads)
+        bad_crc = (st == 0) & (batch.info["status"] != PAGE_BAD_STREAM)  # (the demux looks at the stream id first)
+        batch.info["status"][bad_crc] = PAGE_BAD_CRC
+        hdr = np.ascontiguousarray(blob, dtype=np.uint8)
+        for i in np.nonzero(bad_crc)[0]:  # the header fields the demux reports for such a page
+            h = hdr[offsets[i]:offsets[i] + 27]
+            batch.info[i]["header_type"] = h[5]
+            batch.info[i]["granulepos"] = h[6:14].view("<i8")[0]
+            batch.info[i]["serial"], batch.info[i]["seqno"] = h[14:18].view("<u4")[0], h[18:22].view("<u4")[0]
+        return batch
 
     def step(self, k):
         """-> (descriptors [DESC_DTYPE], page index of every slot [int32]); views into the batch, valid until close()."""
@@ -226,6 +259,11 @@ class Context:
     def decode_step_device(self, n, d_descs, d_arena, d_pcm, d_result, stream=None):
         self._chk(self.lib.opusgpu_decode_step_device(self.h, n, d_descs, d_arena, d_pcm, d_result, stream),
                   "opusgpu_decode_step_device")
+
+    def pages_crc_device(self, n_pages, d_blob, d_offsets, d_lens, d_status, stream=None):
+        """Page checksums on the GPU (include/opusgpu.h): d_status[i] = 1 match, 0 mismatch, PAGE_BAD_CAPTURE malformed."""
+        self._chk(self.lib.opusgpu_pages_crc_device(self.h, n_pages, d_blob, d_offsets, d_lens, d_status, stream),
+                  "opusgpu_pages_crc_device")
 
     def decode_work_step(self, base, layout, k, d_pcm, d_result):
         """Step k of a packed work buffer (shard.pack_work / shard.WorkLayout) resident in HBM at address `base`: the

@@ -162,6 +162,16 @@ int opusgpu_page_batch_step(const opusgpu_page_batch *b, int step, const opusgpu
 const uint8_t *opusgpu_page_batch_arena(const opusgpu_page_batch *b, size_t *bytes); /* descriptor offsets index this */
 void opusgpu_page_batch_free(opusgpu_page_batch *b);
 
+/* Page checksums on the GPU ("optional GPU CRC"): for pages that are already in HBM -- e.g. raw pages
+ * delivered by the work-queue scatter -- the page CRC of ogg_page_checksum_set (src/ogg.cpp:439-480) is recomputed by a
+ * kernel, one page per lane, and compared with the stored one.  d_blob: the pages' bytes; d_offsets (int64[n_pages]) and
+ * d_lens (int32[n_pages]): where page i lies in d_blob; d_status (int32[n_pages]) receives 1 = checksum matches,
+ * 0 = mismatch, OPUSGPU_PAGE_BAD_CAPTURE = not a complete Ogg page (capture pattern, version, lengths: the checks of
+ * opusgpu_pages_demux).  The caller guarantees that every [offset, offset + len) lies inside d_blob.  A host demux of
+ * pages verified this way can drop OPUSGPU_PAGES_VERIFY_CRC.  Asynchronous on the context's stream (or `hip_stream`). */
+int opusgpu_pages_crc_device(opusgpu_ctx *ctx, int n_pages, const void *d_blob, const void *d_offsets, const void *d_lens,
+                             void *d_status, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,7 @@
 """BASELINE config 5 on one GPU: mixed-mode Ogg pages -> host demux (opusgpu_pages_demux) -> packed work
 (shard.pack_work, what the work-queue scatter delivers) -> HBM -> decode steps; every PCM sample of every stream and step
 compared with the CPU oracle.  Modes 1:1:1 across streams (fixed within a stream), two chained pages per stream."""
+import ctypes
 import importlib.util
 import os
 
@@ -159,3 +160,120 @@ def test_ragged_pages_random_modes(pkg, oracle, gpu_ctx):
     finally:
         for p in (d_work, d_pcm, d_res):
             gpu_ctx.dev_free(p)
+
+
+def test_page_crc_on_the_gpu(pkg, gpu_ctx):
+    """opusgpu_pages_crc_device against the independent pure-Python CRC of tests/ogg_util.py: pages at arbitrary byte
+    alignment (junk between them), empty and tiny pages, a maximum-size page (255 segments of 255 bytes), bit flips in the
+    header, the body and the checksum field, truncated pages, wrong capture pattern / version."""
+    import random
+    import ogg_util
+    rng = random.Random(123)
+
+    def expect(pg):
+        if len(pg) < 27 or pg[:4] != b"OggS" or pg[4] != 0:
+            return pkg.PAGE_BAD_CAPTURE
+        total = 27 + pg[26] + sum(pg[27:27 + pg[26]]) if len(pg) >= 27 + pg[26] else None
+        if total is None or len(pg) < total:
+            return pkg.PAGE_BAD_CAPTURE
+        want = int.from_bytes(pg[22:26], "little")
+        return int(ogg_util.ogg_crc(pg[:22] + bytes(4) + pg[26:total]) == want)
+
+    pages = []
+    for i in range(2500):
+        packets = [bytes(rng.getrandbits(8) for _ in range(rng.choice([0, 1, 7, 30, 161, 254, 255, 256, 700]))) for _ in range(rng.randrange(0, 9))]
+        pg = bytearray(ogg_util.page(rng.getrandbits(32), i, rng.getrandbits(40), packets))
+        how = rng.random()
+        if how < 0.15:
+            pg[rng.randrange(len(pg))] ^= 1 << rng.randrange(8)          # anywhere, incl. capture pattern and checksum
+        elif how < 0.2:
+            pg = pg[:rng.randrange(0, len(pg))]                           # truncated
+        elif how < 0.23:
+            pg[4] = 1                                                     # stream structure version
+        elif how < 0.3:
+            pg += bytes(rng.getrandbits(8) for _ in range(rng.randrange(1, 50)))  # trailing bytes beyond the page: ignored
+        pages.append(bytes(pg))
+    pages.append(ogg_util.page(7, 7, 7, [bytes(rng.getrandbits(8) for _ in range(255 * 254 + 200))]))  # 255 lacing values: the largest page
+    assert len(pages[-1]) > 65000
+    blob = bytearray()
+    offs, lens = [], []
+    for pg in pages:
+        blob += bytes(rng.getrandbits(8) for _ in range(rng.randrange(0, 9)))  # arbitrary alignment
+        offs.append(len(blob))
+        lens.append(len(pg))
+        blob += pg
+    want = np.array([expect(pg) for pg in pages], dtype=np.int32)
+    assert (want == 1).sum() > 1000 and (want == 0).sum() > 100 and (want == pkg.PAGE_BAD_CAPTURE).sum() > 50
+    n = len(pages)
+    ctx = gpu_ctx
+    d_blob, d_offs, d_lens, d_st = ctx.dev_alloc(len(blob) + 64), ctx.dev_alloc(8 * n), ctx.dev_alloc(4 * n), ctx.dev_alloc(4 * n)
+    try:
+        ctx.h2d(d_offs, np.array(offs, dtype=np.int64))
+        ctx.h2d(d_lens, np.array(lens, dtype=np.int32))
+        # the blob may start at any address (a view into a larger buffer), and nothing follows its last page
+        for shift in (0, 1, 13, 16, 63):
+            base = ctypes.c_void_p(d_blob.value + shift)
+            ctx.h2d(base, np.frombuffer(bytes(blob), dtype=np.uint8))
+            got = np.full(n, 99, dtype=np.int32)
+            ctx.h2d(d_st, got)
+            ctx.pages_crc_device(n, base, d_offs, d_lens, d_st)
+            ctx.synchronize()
+            ctx.d2h(got, d_st)
+            bad = np.nonzero(got != want)[0]
+            assert bad.size == 0, (shift, bad[:5], got[bad[:5]], want[bad[:5]], [lens[i] for i in bad[:5]])
+    finally:
+        for p in (d_blob, d_offs, d_lens, d_st):
+            ctx.dev_free(p)
+
+
+def test_demux_with_gpu_checksums_equals_demux_with_host_checksums(pkg, gpu_ctx):
+    """PageBatch.with_gpu_crc (checksums by opusgpu_pages_crc_device, host demux without its CRC pass) makes the same
+    decode steps, arena and page reports as the host demux with OPUSGPU_PAGES_VERIFY_CRC -- on pages some of which are
+    damaged (body, header, checksum field, capture pattern, truncation) or carry a bad stream id."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    modes = ((pkg.TOC_SILK_NB_STEREO, 40), (pkg.TOC_HYBRID_FB_STEREO, 120), (pkg.TOC_CELT_FB_STEREO, 160))
+    mats, ids = [], []
+    for m, (toc, L) in enumerate(modes):
+        sid = np.arange(m, n, 3, dtype=np.int32)
+        pay = pkg.lcg_payloads(len(sid), 4, L, seed_base=31 + m)
+        mats.append(pkg.build_pages(toc, pay, sid.astype(np.uint32), seqno=2))
+        ids.append(sid)
+    blob = np.concatenate([x.reshape(-1) for x in mats]).copy()
+    lens = np.concatenate([np.full(x.shape[0], x.shape[1], dtype=np.int32) for x in mats])
+    offs = np.concatenate([[0], np.cumsum(lens.astype(np.int64))[:-1]])
+    sids = np.concatenate(ids).copy()
+    hit = rng.choice(n, size=600, replace=False)
+    for j, i in enumerate(hit):
+        kind = j % 6
+        if kind == 0:
+            blob[offs[i] + rng.integers(27 + 4, lens[i])] ^= 1 << rng.integers(8)   # body (or lacing table)
+        elif kind == 1:
+            blob[offs[i] + rng.integers(5, 22)] ^= 1 << rng.integers(8)           # header fields
+        elif kind == 2:
+            blob[offs[i] + rng.integers(22, 26)] ^= 1 << rng.integers(8)          # the checksum itself
+        elif kind == 3:
+            blob[offs[i] + rng.integers(0, 5)] ^= 1 << rng.integers(8)            # capture pattern / version
+        elif kind == 4:
+            lens[i] = rng.integers(0, lens[i])                                     # truncated
+        else:
+            sids[i] = -1                                                           # no decoder stream
+    ctx = gpu_ctx
+    d_blob = ctx.dev_alloc(blob.size)
+    try:
+        ctx.h2d(d_blob, blob)
+        a = pkg.PageBatch(blob, offs, lens, sids, flags=pkg.PAGES_VERIFY_CRC | pkg.PAGES_GROUP_BY_MODE, threads=4)
+        b = pkg.PageBatch.with_gpu_crc(ctx, d_blob, blob, offs, lens, sids, flags=pkg.PAGES_GROUP_BY_MODE, threads=4)
+        st = a.info["status"]
+        assert (st == pkg.PAGE_BAD_CRC).sum() >= 250 and (st == pkg.PAGE_BAD_CAPTURE).sum() >= 100 and (st == 4).sum() >= n - 600
+        for name in a.info.dtype.names:
+            assert np.array_equal(a.info[name], b.info[name]), name
+        assert a.n_steps == b.n_steps == 4
+        assert np.array_equal(a.arena, b.arena)
+        for k in range(a.n_steps):
+            (da, pa), (db, pb) = a.step(k), b.step(k)
+            assert np.array_equal(da, db) and np.array_equal(pa, pb)
+        a.close()
+        b.close()
+    finally:
+        ctx.dev_free(d_blob)
