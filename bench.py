@@ -111,12 +111,14 @@ def mixed_cpu_baseline():
             "per_mode_frames_per_s": [p["value"] for p in parts], "host_logical_cpus": parts[0]["host_logical_cpus"]}
 
 
-def prepare_pages_work(pkg, shard, ranks, ctx, n, frames, ingest="rank0"):
+def prepare_pages_work(pkg, shard, ranks, ctx, n, frames, ingest="rank0", page_crc="host"):
     """mixed_pages workload: rank 0 builds the Ogg pages of every rank's streams (`frames` packets per stream in pages of
     PACKETS_PER_PAGE, chained) and routes them by owner.  ingest = "rank0": it also turns them into decode steps
     (opusgpu_pages_demux, host threads) and scatters the packed work -- one demux for the whole job.  ingest = "per-rank":
     it scatters the raw pages and every rank demuxes its own share on its own host CPUs -- demux capacity grows with the
-    rank count.  Returns (device address of this rank's work, its layout, ingest statistics, keep-alive object)."""
+    rank count; with page_crc = "gpu" the checksums of the raw pages are verified where they arrived, in HBM
+    (opusgpu_pages_crc_device), and the host demux skips its CRC pass.
+    Returns (device address of this rank's work, its layout, ingest statistics, keep-alive object)."""
     threads = shard.usable_cpus()
     per_rank = ingest == "per-rank"
     buffers, stats = None, None
@@ -150,7 +152,8 @@ def prepare_pages_work(pkg, shard, ranks, ctx, n, frames, ingest="rank0"):
                 raise SystemExit("page demux rejected synthetic pages")
             buffers.append(shard.pack_work(batch))
             batch.close()
-        stats = {"mode": ingest, "pages": n_pages, "page_bytes": page_bytes, "demux_threads": threads}
+        stats = {"mode": ingest, "pages": n_pages, "page_bytes": page_bytes, "demux_threads": threads,
+                 "page_crc": page_crc if per_rank else "host"}
         if not per_rank:
             stats.update({"demux_s": t_demux, "pages_per_s": n_pages / t_demux, "demux_GB_per_s": page_bytes / t_demux / 1e9})
     t0 = time.perf_counter()
@@ -163,9 +166,26 @@ def prepare_pages_work(pkg, shard, ranks, ctx, n, frames, ingest="rank0"):
         # this rank's raw pages -> host (they may have arrived in HBM), demux here, steps -> HBM
         raw = mine if isinstance(mine, np.ndarray) else mine.cpu().numpy()
         blob, offs, lens, sids = shard.unpack_pages(raw)
-        t0 = time.perf_counter()
-        batch = pkg.PageBatch(blob, offs, lens, sids, threads=threads)
-        t_local = time.perf_counter() - t0
+        if page_crc == "gpu":
+            import ctypes
+            if isinstance(mine, np.ndarray):  # one rank, no scatter: put the raw pages where a scatter would have put them
+                d_raw = ctx.dev_alloc(raw.size)
+                ctx.h2d(d_raw, raw)
+                d_raw_at = d_raw.value
+            else:
+                d_raw, d_raw_at = None, mine.data_ptr()
+            d_blob = ctypes.c_void_p(d_raw_at + (blob.ctypes.data - raw.ctypes.data))
+            # one page first: the checksum tables and the kernel's code are set up once per context, not per batch
+            pkg.PageBatch.with_gpu_crc(ctx, d_blob, blob, offs[:1], lens[:1], sids[:1]).close()
+            t0 = time.perf_counter()
+            batch = pkg.PageBatch.with_gpu_crc(ctx, d_blob, blob, offs, lens, sids, threads=threads)
+            t_local = time.perf_counter() - t0
+            if d_raw is not None:
+                ctx.dev_free(d_raw)
+        else:
+            t0 = time.perf_counter()
+            batch = pkg.PageBatch(blob, offs, lens, sids, threads=threads)
+            t_local = time.perf_counter() - t0
         if not (batch.info["status"] > 0).all():
             raise SystemExit("page demux rejected synthetic pages")
         mine = shard.pack_work(batch)
@@ -195,6 +215,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="celt_fb_stereo_64k", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
+    ap.add_argument("--page-crc", default="host", choices=["host", "gpu"],
+                    help="mixed_pages_2m with --ingest per-rank: who verifies the page checksums")
     ap.add_argument("--ingest", default="rank0", choices=["rank0", "per-rank"],
                     help="mixed_pages_2m: who demuxes the Ogg pages (rank 0 for all, or every rank its own share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -217,7 +239,7 @@ def main():
     ingest = None
     if mixed:
         # work arrives at rank 0 as Ogg pages and is scattered: the path's one exchange step, before the timed region
-        base, lay, ingest, _keep = prepare_pages_work(pkg, load_shard(), ranks, ctx, n, K + W, args.ingest)
+        base, lay, ingest, _keep = prepare_pages_work(pkg, load_shard(), ranks, ctx, n, K + W, args.ingest, args.page_crc)
         if lay.counts != [n] * (K + W):
             raise SystemExit(f"unexpected step tables: {lay.counts[:4]}...")
 

@@ -11,7 +11,11 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <new>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -85,8 +89,18 @@ struct RawBuf {
     ~RawBuf() { free(p); }
     void alloc(size_t count) {
         free(p);
+        p = nullptr;
         n = count;
-        p = static_cast<T *>(malloc((count ? count : 1) * sizeof(T)));
+        const size_t bytes = (count ? count : 1) * sizeof(T), huge = (size_t)2 << 20;
+        if (bytes >= 4 * huge) { // first touch of a large buffer is mostly page faults: ask for 2 MB pages where the host allows
+            void *q = nullptr;
+            const size_t rounded = (bytes + huge - 1) / huge * huge;
+            if (posix_memalign(&q, huge, rounded) == 0) {
+                (void)madvise(q, rounded, MADV_HUGEPAGE);
+                p = static_cast<T *>(q);
+            }
+        }
+        if (!p) p = static_cast<T *>(malloc(bytes));
         if (!p) throw std::bad_alloc();
     }
     T *data() const { return p; }
@@ -166,10 +180,23 @@ PageScan scan_page(const uint8_t *pg, int32_t len, int flags, opusgpu_page_info 
     return r;
 }
 
+// OPUSGPU_PAGES_TIMING=1: wall time of every phase of a demux call on stderr (for tuning; off by default)
+struct PhaseTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    PhaseTimer() : on(getenv("OPUSGPU_PAGES_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[opusgpu_pages_demux] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 template <class F>
-void parallel_for(int n, int threads, F f) { // f(begin, end)
+void parallel_for(int n, int threads, F f, int grain = 256) { // f(begin, end); at least `grain` items per thread
     threads = threads < 1 ? 1 : threads;
-    if (threads > n / 256 + 1) threads = n / 256 + 1;
+    if (threads > n / grain + 1) threads = n / grain + 1;
     if (threads <= 1) {
         f(0, n);
         return;
@@ -198,7 +225,9 @@ int opusgpu_pages_demux(int n_pages, const uint8_t *const *pages, const int32_t 
     if (n_pages < 0 || (n_pages > 0 && (!pages || !page_lens || !stream_ids))) return OPUSGPU_BAD_ARG;
     try {
         opusgpu_page_batch *b = new opusgpu_page_batch;
+        PhaseTimer timer;
         std::vector<PageScan> scan((size_t)n_pages);
+        timer.mark("allocate page scans");
         // pass 1: validate and count
         parallel_for(n_pages, threads, [&](int lo, int hi) {
             for (int i = lo; i < hi; i++) {
@@ -214,16 +243,25 @@ int opusgpu_pages_demux(int n_pages, const uint8_t *const *pages, const int32_t 
                 }
             }
         });
+        timer.mark("pass 1: validate");
         // pass 2: chain the pages of one stream, size the steps, place every page's body in the arena
         std::vector<int32_t> first_step((size_t)n_pages, 0);
         std::vector<size_t> arena_at((size_t)n_pages, 0);
-        std::unordered_map<int32_t, int32_t> next_step;
-        next_step.reserve((size_t)n_pages);
+        // a stream's running step count: a table indexed by stream id when the ids are dense enough for one (the usual
+        // case: ids 0 .. n_streams - 1), a hash map otherwise -- at a quarter of a million pages the map alone took
+        // longer than the parallel passes
+        int32_t max_id = -1;
+        for (int i = 0; i < n_pages; i++)
+            if (scan[i].status > 0 && stream_ids[i] > max_id) max_id = stream_ids[i];
+        const bool dense = (int64_t)max_id < 16 * (int64_t)n_pages + 4096;
+        std::vector<int32_t> next_dense(dense ? (size_t)max_id + 1 : 0, 0);
+        std::unordered_map<int32_t, int32_t> next_sparse;
+        if (!dense) next_sparse.reserve((size_t)n_pages);
         int32_t n_steps = 0;
         size_t arena_bytes = 0;
         for (int i = 0; i < n_pages; i++) {
             if (scan[i].status <= 0) continue;
-            int32_t &ns = next_step[stream_ids[i]];
+            int32_t &ns = dense ? next_dense[(size_t)stream_ids[i]] : next_sparse[stream_ids[i]];
             first_step[i] = ns;
             ns += scan[i].status;
             if (ns > n_steps) n_steps = ns;
@@ -231,10 +269,10 @@ int opusgpu_pages_demux(int n_pages, const uint8_t *const *pages, const int32_t 
             arena_bytes += (size_t)scan[i].body_len;
             if (info) info[i].first_step = first_step[i];
         }
+        timer.mark("pass 2: chain streams");
         // slots: per step, pages in input order -- or grouped by mode first (three stable groups)
         const bool group = (flags & OPUSGPU_PAGES_GROUP_BY_MODE) != 0;
         const int G = group ? 3 : 1;
-        std::vector<size_t> count((size_t)n_steps * G + 1, 0);
         RawBuf<uint8_t> mode_of; // mode (0..2) per frame of every page, only when grouping
         std::vector<size_t> frame_at((size_t)n_pages + 1, 0);
         for (int i = 0; i < n_pages; i++) {
@@ -259,24 +297,54 @@ int opusgpu_pages_demux(int n_pages, const uint8_t *const *pages, const int32_t 
                 }
             });
         }
-        for (int i = 0; i < n_pages; i++)
-            for (int k = 0; k < (scan[i].status > 0 ? scan[i].status : 0); k++)
-                count[(size_t)(first_step[i] + k) * G + (group ? mode_of[frame_at[i] + k] : 0) + 1]++;
-        for (size_t j = 1; j < count.size(); j++) count[j] += count[j - 1]; // count[j] = first slot of (step, group) j
+        timer.mark("frame index + modes");
+        // A counting sort of the frames by (step, group), stable in input order, done by page ranges: every range counts
+        // its frames per key, the ranges' counts are chained per key, and every range then numbers its own frames.
+        const size_t keys = (size_t)n_steps * G;
+        int chunks = threads < 1 ? 1 : threads;
+        if (chunks > n_pages / 256 + 1) chunks = n_pages / 256 + 1;
+        if (keys * (size_t)chunks > ((size_t)1 << 22)) chunks = 1; // (very many steps: not worth a table per range)
+        auto chunk_lo = [&](int c) { return (int)((int64_t)n_pages * c / chunks); };
+        auto key_of = [&](int i, int k) { return (size_t)(first_step[i] + k) * G + (group ? mode_of[frame_at[i] + k] : 0); };
+        std::vector<size_t> cur((size_t)chunks * keys, 0); // [range][key]: frames counted, then the next free slot
+        parallel_for(chunks, chunks, [&](int lo, int hi) {
+            for (int c = lo; c < hi; c++) {
+                size_t *h = cur.data() + (size_t)c * keys;
+                for (int i = chunk_lo(c); i < chunk_lo(c + 1); i++)
+                    for (int k = 0; k < (scan[i].status > 0 ? scan[i].status : 0); k++) h[key_of(i, k)]++;
+            }
+        }, 1);
+        std::vector<size_t> count(keys + 1, 0); // count[j] = first slot of (step, group) j
+        {
+            size_t at = 0;
+            for (size_t j = 0; j < keys; j++) {
+                count[j] = at;
+                for (int c = 0; c < chunks; c++) {
+                    const size_t mine = cur[(size_t)c * keys + j];
+                    cur[(size_t)c * keys + j] = at;
+                    at += mine;
+                }
+            }
+            count[keys] = at;
+        }
         RawBuf<uint32_t> slot_of;
         slot_of.alloc(total);
-        {
-            std::vector<size_t> cur(count.begin(), count.end() - 1);
-            for (int i = 0; i < n_pages; i++)
-                for (int k = 0; k < (scan[i].status > 0 ? scan[i].status : 0); k++)
-                    slot_of[frame_at[i] + k] = (uint32_t)cur[(size_t)(first_step[i] + k) * G + (group ? mode_of[frame_at[i] + k] : 0)]++;
-        }
+        parallel_for(chunks, chunks, [&](int lo, int hi) {
+            for (int c = lo; c < hi; c++) {
+                size_t *h = cur.data() + (size_t)c * keys;
+                for (int i = chunk_lo(c); i < chunk_lo(c + 1); i++)
+                    for (int k = 0; k < (scan[i].status > 0 ? scan[i].status : 0); k++)
+                        slot_of[frame_at[i] + k] = (uint32_t)h[key_of(i, k)]++;
+            }
+        }, 1);
+        timer.mark("slot numbering");
         b->step_begin.resize((size_t)n_steps + 1);
         for (int s = 0; s <= n_steps; s++) b->step_begin[s] = count[(size_t)s * G];
         b->descs.alloc(total);
         b->slot_pages.alloc(total);
         b->arena.alloc(arena_bytes + 16); // the kernels read packets through aligned 32-bit words: keep a tail
         memset(b->arena.data() + arena_bytes, 0, 16);
+        timer.mark("allocate outputs");
         // pass 3: bodies and descriptors
         parallel_for(n_pages, threads, [&](int lo, int hi) {
             for (int i = lo; i < hi; i++) {
@@ -293,6 +361,7 @@ int opusgpu_pages_demux(int n_pages, const uint8_t *const *pages, const int32_t 
                 });
             }
         });
+        timer.mark("pass 3: bodies + descriptors");
         if (arena_bytes > 0x7fffffffu) { // descriptor offsets are 32-bit: split the call
             delete b;
             return OPUSGPU_BAD_ARG;

@@ -166,3 +166,44 @@ def test_page_with_more_than_32_frames_groups_correctly(pkg):
                 want[i if i < 3 else i + 1] = ms[s]
         assert {int(p): g for p, g in zip(slot_pages, got)} == want
     b.close()
+
+
+@pytest.mark.parametrize("id_scale", [1, 100003])  # dense stream ids (table) and sparse ones (hash map)
+def test_slot_order_is_the_stable_order_for_any_thread_count(pkg, id_scale):
+    """Mixed modes, 0 - 6 packets per page, up to three pages per stream, some pages damaged: slot s of step k is what a
+    stable sort of the frames by (step, mode) gives, whatever the number of threads (the slot numbering is done by
+    page ranges in parallel)."""
+    rng = random.Random(11)
+    tocs = {0: 0x0C, 1: 0x7C, 2: 0xFC}
+    n_streams = 1200
+    mode_of_stream = [rng.randrange(3) for _ in range(n_streams)]
+    pages, ids = [], []
+    for rnd in range(3):
+        for s in rng.sample(range(n_streams), n_streams - 200 * rnd):
+            pg = bytearray(ogg_util.page(s, rnd, 0, [_packet(rng, tocs[mode_of_stream[s]], rng.randrange(2, 60)) for _ in range(rng.randrange(0, 7))]))
+            if rng.random() < 0.05:
+                pg[rng.randrange(len(pg))] ^= 0x10
+            pages.append(bytes(pg))
+            ids.append(s * id_scale)
+    b1 = _batch(pkg, pages, ids, threads=1)
+    nxt, want = {}, {}
+    for i, st in enumerate(b1.info["status"]):
+        if st <= 0:
+            continue
+        at = nxt.get(ids[i], 0)
+        assert b1.info["first_step"][i] == at
+        for k in range(st):
+            want.setdefault((at + k, mode_of_stream[ids[i] // id_scale]), []).append(i)
+        nxt[ids[i]] = at + st
+    assert (b1.info["status"] < 0).sum() > 50 and b1.n_steps == max(k for k, _ in want) + 1 and b1.n_steps > 10
+    for threads in (1, 3, 7):
+        b = b1 if threads == 1 else _batch(pkg, pages, ids, threads=threads)
+        assert (b.info == b1.info).all() and b.n_steps == b1.n_steps and (b.arena == b1.arena).all()
+        for k in range(b.n_steps):
+            descs, slot_pages = b.step(k)
+            assert list(slot_pages) == [i for m in range(3) for i in want.get((k, m), [])]
+            d1, _ = b1.step(k)
+            assert (descs == d1).all()
+        if b is not b1:
+            b.close()
+    b1.close()

@@ -34,9 +34,10 @@ def packet():
 
 
 calls = pages_seen = accepted = 0
-for it in range(400):
+for it in range(412):
     pages = []
-    for _ in range(rng.randrange(1, 40)):
+    big = it >= 400  # a few large batches: the slot numbering runs by page ranges in parallel from 256 pages per thread on
+    for _ in range(rng.randrange(1500, 2500) if big else rng.randrange(1, 40)):
         pg = bytearray(ogg_util.page(rng.getrandbits(32), rng.getrandbits(16), rng.getrandbits(40), [packet() for _ in range(rng.randrange(0, 12))],
                                      bos=rng.random() < 0.1, eos=rng.random() < 0.1, continued=rng.random() < 0.1))
         how = rng.randrange(8)
@@ -55,10 +56,12 @@ for it in range(400):
     offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
     ptrs = (np.uint64(blob.ctypes.data) + offs).astype(np.uint64)
     ids = np.array([rng.choice([-1, 0, 1, 2, 3, 7, 1000000]) for _ in pages], dtype=np.int32)
+    if big:
+        ids = np.array([rng.randrange(-1, 400) * (1 if it % 2 else 7919) for _ in pages], dtype=np.int32)
     info = np.zeros(len(pages) * 8, dtype=np.int32)
     for flags in (0, 1, 2, 3):
         h = vp()
-        rc = lib.opusgpu_pages_demux(len(pages), ptrs.ctypes.data, lens.ctypes.data, ids.ctypes.data, flags, rng.choice([0, 1, 3]),
+        rc = lib.opusgpu_pages_demux(len(pages), ptrs.ctypes.data, lens.ctypes.data, ids.ctypes.data, flags, rng.choice([2, 5, 8]) if big else rng.choice([0, 1, 3]),
                                      info.ctypes.data, C.byref(h))
         assert rc == 0, rc
         nbytes = C.c_size_t()
