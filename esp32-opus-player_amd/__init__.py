@@ -25,8 +25,17 @@ EXPORTS = [
     "opusgpu_decode_step_device", "opusgpu_synchronize", "opusgpu_event_create", "opusgpu_event_record",
     "opusgpu_event_elapsed_ms", "opusgpu_event_destroy", "opusgpu_stream_state_get",
     "opusgpu_pages_demux", "opusgpu_page_batch_steps", "opusgpu_page_batch_step", "opusgpu_page_batch_arena",
-    "opusgpu_page_batch_free", "opusgpu_pages_crc_device",
+    "opusgpu_page_batch_free", "opusgpu_pages_crc_device", "opusgpu_output_stage_device",
 ]
+
+
+class OutputCfg(C.Structure):
+    """opusgpu_output_cfg (include/opusgpu.h): the player's output settings, src/main.cpp m_vol / m_f_forceMono /
+    m_bitsPerSample / m_channels."""
+    _fields_ = [("volume", C.c_uint8), ("force_mono", C.c_uint8), ("bits", C.c_uint8), ("channels", C.c_uint8)]
+
+
+OUTPUT_CFG_DTYPE = np.dtype([("volume", "u1"), ("force_mono", "u1"), ("bits", "u1"), ("channels", "u1")])
 
 
 class FrameDesc(C.Structure):
@@ -86,6 +95,8 @@ def load_lib():
     lib.opusgpu_page_batch_free.argtypes = [vp]
     lib.opusgpu_page_batch_free.restype = None
     lib.opusgpu_pages_crc_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    lib.opusgpu_output_stage_device.argtypes = [vp, C.c_int, C.c_int, vp, C.c_longlong, vp, C.c_int, vp, OutputCfg, vp,
+                                                C.c_longlong, vp]
     _lib = lib
     return lib
 
@@ -264,6 +275,13 @@ class Context:
         """Page checksums on the GPU (include/opusgpu.h): d_status[i] = 1 match, 0 mismatch, PAGE_BAD_CAPTURE malformed."""
         self._chk(self.lib.opusgpu_pages_crc_device(self.h, n_pages, d_blob, d_offsets, d_lens, d_status, stream),
                   "opusgpu_pages_crc_device")
+
+    def output_stage_device(self, n_blocks, block_samples, d_pcm, pcm_stride, d_i2s, i2s_stride, d_valid=None, valid_all=0,
+                            d_cfgs=None, volume=64, force_mono=False, bits=16, channels=2, stream=None):
+        """The player's output stage on the GPU (include/opusgpu.h): PCM blocks -> 32-bit I2S words."""
+        cfg = OutputCfg(volume, 1 if force_mono else 0, bits, channels)
+        self._chk(self.lib.opusgpu_output_stage_device(self.h, n_blocks, block_samples, d_pcm, pcm_stride, d_valid, valid_all,
+                                                       d_cfgs, cfg, d_i2s, i2s_stride, stream), "opusgpu_output_stage_device")
 
     def decode_work_step(self, base, layout, k, d_pcm, d_result):
         """Step k of a packed work buffer (shard.pack_work / shard.WorkLayout) resident in HBM at address `base`: the

@@ -13,6 +13,7 @@
 #include <vector>
 #include "og_decode.hpp"
 #include "og_packet.hpp"
+#include "og_output.hpp"
 
 using namespace og;
 
@@ -172,6 +173,39 @@ __global__ void __launch_bounds__(256) k_pages_crc(const u8 *__restrict__ blob, 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (p < n) status[p] = st < 0 ? st : (i32)(crc == want);
+}
+
+// Output stage (og_output.hpp): a thread makes four consecutive I2S words of one block.  Plain streaming work: 4 bytes in,
+// 4 bytes out per word in the usual 16-bit stereo case, which takes the 16-byte path when the caller's layout allows it.
+static_assert(sizeof(opusgpu_output_cfg) == sizeof(OutputCfg) && sizeof(OutputCfg) == 4, "output cfg layout");
+__global__ void __launch_bounds__(256) k_output_stage(const i16 *__restrict__ pcm, long long pcm_stride, const i32 *__restrict__ valid_of,
+                                                       int valid_all, int block_samples, const OutputCfg *__restrict__ cfg_of,
+                                                       OutputCfg cfg_all, u32 *__restrict__ out, long long out_stride,
+                                                       int units_per_block, long long n_units, int vec_ok) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_units) return;
+    const int b = (int)(t / units_per_block), w0 = 4 * (int)(t - (long long)b * units_per_block);
+    const OutputCfg c = cfg_of ? cfg_of[b] : cfg_all;
+    int valid = valid_of ? valid_of[b] : valid_all; // a decode result: negative = the frame failed, nothing to play
+    valid = valid > block_samples ? block_samples : valid;
+    const int count = output_words(c, valid);
+    if (w0 >= count) return;
+    const i16 *blk = pcm + (size_t)b * pcm_stride;
+    u32 *dst = out + (size_t)b * out_stride + w0;
+    if (vec_ok && c.bits == 16 && c.channels == 2 && w0 + 4 <= count) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(blk + 2 * w0); // four stereo samples
+        const u32 in[4] = {v.x, v.y, v.z, v.w};
+        u32 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            i32 l = (i32)(i16)(in[j] & 0xffffu), r = (i32)(i16)(in[j] >> 16);
+            if (c.force_mono) l = r = (i32)(i16)((l + r) / 2);
+            o[j] = output_pack(l, r, false, (i32)c.volume);
+        }
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+        for (int j = 0; j < 4 && w0 + j < count; j++) dst[j] = output_word(blk, w0 + j, c);
+    }
 }
 
 #ifndef OG_WAVES_PER_SIMD
@@ -669,6 +703,31 @@ int opusgpu_pages_crc_device(opusgpu_ctx *ctx, int n_pages, const void *d_blob, 
     }
     hipLaunchKernelGGL(k_pages_crc, dim3((n_pages + 255) / 256), dim3(256), 0, s, (const u8 *)d_blob, (const long long *)d_offsets,
                        (const i32 *)d_lens, (i32 *)d_status, n_pages, (const u32 *)ctx->d_crc_tables);
+    HIPCHK(ctx, hipGetLastError());
+    return OPUSGPU_OK;
+}
+
+int opusgpu_output_stage_device(opusgpu_ctx *ctx, int n_blocks, int block_samples, const void *d_pcm, long long pcm_stride,
+                                const void *d_valid, int valid_all, const void *d_cfgs, opusgpu_output_cfg cfg, void *d_i2s,
+                                long long i2s_stride, void *hip_stream) {
+    if (!ctx || n_blocks < 0 || block_samples < 0) return OPUSGPU_BAD_ARG;
+    if (n_blocks == 0 || block_samples == 0) return OPUSGPU_OK;
+    if (!d_pcm || !d_i2s || pcm_stride < 0 || i2s_stride < 0) return OPUSGPU_BAD_ARG;
+    if (!d_valid && (valid_all < 0 || valid_all > block_samples)) return OPUSGPU_BAD_ARG;
+    // the reference's setters refuse anything else (setBitsPerSample / setChannels, src/main.cpp:119-132)
+    if (!d_cfgs && ((cfg.bits != 8 && cfg.bits != 16) || (cfg.channels != 1 && cfg.channels != 2))) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    // words a block can make: 8-bit mono plays two per sample; with per-block settings any block might
+    const int max_words = (d_cfgs || (cfg.bits == 8 && cfg.channels == 1)) ? 2 * block_samples : block_samples;
+    const int units = (max_words + 3) / 4;
+    const long long n_units = (long long)units * n_blocks;
+    const int vec_ok = ((uintptr_t)d_pcm % 16 == 0 && pcm_stride % 8 == 0 && (uintptr_t)d_i2s % 16 == 0 && i2s_stride % 4 == 0) ? 1 : 0;
+    OutputCfg c;
+    memcpy(&c, &cfg, sizeof c);
+    hipLaunchKernelGGL(k_output_stage, dim3((unsigned)((n_units + 255) / 256)), dim3(256), 0, s, (const i16 *)d_pcm, pcm_stride,
+                       (const i32 *)d_valid, valid_all, block_samples, (const OutputCfg *)d_cfgs, c, (u32 *)d_i2s, i2s_stride, units,
+                       n_units, vec_ok);
     HIPCHK(ctx, hipGetLastError());
     return OPUSGPU_OK;
 }

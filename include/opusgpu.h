@@ -172,6 +172,31 @@ void opusgpu_page_batch_free(opusgpu_page_batch *b);
 int opusgpu_pages_crc_device(opusgpu_ctx *ctx, int n_pages, const void *d_blob, const void *d_offsets, const void *d_lens,
                              void *d_status, void *hip_stream);
 
+/* Output stage of the player: decoded PCM -> the 32-bit words src/main.cpp hands to the I2S peripheral.
+ * Replaces playChunk (src/main.cpp:148-224), playSample (:226-256) and Gain (:137-146) for a whole step at once: every
+ * block of d_pcm is one m_outBuff.  Per output frame: the two samples are picked by bit depth / channel count /
+ * force-mono, 8-bit samples are expanded ((x - 128) << 8), both are halved for headroom (>> 1), scaled
+ * ((s * volume) >> 6) and packed as (right << 16) | (left & 0xffff).  The OpusHead output gain is NOT applied -- the
+ * reference does not apply it either (op_update_gain is commented out, src/opusfile.cpp:704). */
+typedef struct opusgpu_output_cfg {
+    uint8_t volume;     /* m_vol (src/main.cpp:39): 64 = unity; above 127 the 16-bit halves wrap as they do there */
+    uint8_t force_mono; /* m_f_forceMono: both channels play (left + right) / 2 */
+    uint8_t bits;       /* setBitsPerSample: 16, or 8 (every int16 of the block holds two unsigned 8-bit samples) */
+    uint8_t channels;   /* setChannels: 2 (interleaved), or 1 */
+} opusgpu_output_cfg;
+
+/* Block b: int16 samples at d_pcm + b * pcm_stride (stride in int16 units; a decode step's PCM has stride
+ * 2 * 960 * frame_capacity), m_validSamples = d_valid[b] (int32; e.g. the step's result array: a negative entry plays
+ * nothing) or valid_all when d_valid is NULL, at most block_samples.  Settings: d_cfgs[b] (device array) or `cfg` when
+ * d_cfgs is NULL; `cfg` with other bits / channels than the setters accept is OPUSGPU_BAD_ARG, such a d_cfgs entry makes
+ * its block play nothing (as playChunk does).  Output: uint32 words at d_i2s + b * i2s_stride, `valid` of them -- 2 * valid
+ * for 8-bit mono, so i2s_stride must hold 2 * block_samples there; words past a block's count are left untouched.
+ * 16-byte aligned bases with pcm_stride % 8 == 0 and i2s_stride % 4 == 0 take the fast path; anything else works too.
+ * Asynchronous on the context's stream (or `hip_stream`). */
+int opusgpu_output_stage_device(opusgpu_ctx *ctx, int n_blocks, int block_samples, const void *d_pcm, long long pcm_stride,
+                                const void *d_valid, int valid_all, const void *d_cfgs, opusgpu_output_cfg cfg, void *d_i2s,
+                                long long i2s_stride, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

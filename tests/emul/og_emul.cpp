@@ -3,6 +3,7 @@
 // against the oracle and run under ASan/UBSan without a GPU.  Never linked into libopusgpu.so.
 #define OG_HOST_EMUL 1
 #include "og_decode.hpp"
+#include "og_output.hpp"
 
 #ifdef OG_STATS
 long long og_stats[64];
@@ -87,4 +88,13 @@ const int16_t *emu_tap_X(void) { return tap_X; }
 const int16_t *emu_tap_bandE(void) { return tap_bandE; }
 const int32_t *emu_tap_syn_pre(int c) { return tap_syn_pre[c]; }
 const int32_t *emu_tap_syn_post(int c) { return tap_syn_post[c]; }
+}
+
+// output stage (og_output.hpp): all words of one block, as the kernel computes them
+extern "C" int emu_output_block(const int16_t *blk, int valid, int volume, int force_mono, int bits, int channels, uint32_t *out) {
+    og::OutputCfg c;
+    c.volume = (uint8_t)volume; c.force_mono = (uint8_t)force_mono; c.bits = (uint8_t)bits; c.channels = (uint8_t)channels;
+    const int n = og::output_words(c, valid);
+    for (int w = 0; w < n; w++) out[w] = og::output_word(blk, w, c);
+    return n;
 }
