@@ -7,7 +7,10 @@
 // affinity is not a concern either.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <chrono>
+#include <memory>
 #include <new>
 #include <thread>
 #include <vector>
@@ -18,6 +21,7 @@
 using namespace og;
 
 static_assert(sizeof(opusgpu_frame_desc) == sizeof(FrameDesc), "descriptor layout");
+enum { OPUSGPU_COPY_PIECES = 16, OPUSGPU_COPY_THREADS = 8 };
 
 // ---- kernels --------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_stream_init(StreamState *st, int first, int count, int channels, int full) {
@@ -463,6 +467,7 @@ struct opusgpu_ctx {
     void *h_pcm = nullptr, *h_res = nullptr;
     size_t cap_h_pcm = 0, cap_h_res = 0;
     u32 *d_crc_tables = nullptr; // 8 x 256 words, made on first use (opusgpu_pages_crc_device)
+    hipEvent_t ev_piece[OPUSGPU_COPY_PIECES] = {}; // one per piece of the PCM's way back to the host (opusgpu_decode_packets)
     // parse records of the split CELT path (one per frame of a step), grown on demand
     void *d_recs = nullptr, *d_handoff = nullptr, *d_srecs = nullptr;
     size_t cap_recs = 0, cap_handoff = 0, cap_srecs = 0;
@@ -480,6 +485,20 @@ static int fail(opusgpu_ctx *ctx, int code, const char *what, hipError_t e) {
         hipError_t e_ = (call);                                          \
         if (e_ != hipSuccess) return fail(ctx, OPUSGPU_ERR_HIP, #call, e_); \
     } while (0)
+
+// OPUSGPU_HOST_TIMING=1: wall time of the phases of opusgpu_decode_packets on stderr (adds a stream synchronise after the
+// kernels so that decode and copy-back can be told apart; for tuning only)
+struct HostPhaseTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    HostPhaseTimer() : on(getenv("OPUSGPU_HOST_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[opusgpu_decode_packets] %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
 
 extern "C" {
 
@@ -527,6 +546,8 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     (void)hipHostFree(ctx->h_pcm);
     (void)hipHostFree(ctx->h_res);
     (void)hipFree(ctx->d_crc_tables);
+    for (hipEvent_t e : ctx->ev_piece)
+        if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -817,46 +838,74 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int CC = ctx->channels;
     const size_t frame_pcm = (size_t)OPUSGPU_FRAME_SAMPLES * CC;
-    // 1. frame the packets on the host (opus_decode_native, src/opus_decoder.cpp:280-348)
-    std::vector<opusgpu_frame_desc> all;   // frames in (packet, frame) order
+    // 1. frame the packets on the host (opus_decode_native, src/opus_decoder.cpp:280-348).  Large batches by ranges of
+    //    packets on a few threads, in two passes: frame counts and sizes, then (after the prefix sums that place every
+    //    packet) descriptors and packet bytes.
+    HostPhaseTimer timer;
+    const int host_threads = n >= 4096 ? 8 : 1;
+    auto on_ranges = [&](auto &&f) { // f(lo, hi) over [0, n)
+        if (host_threads == 1) {
+            f(0, n);
+            return;
+        }
+        std::vector<std::thread> th;
+        for (int t = 0; t < host_threads; t++)
+            th.emplace_back(f, (int)((int64_t)n * t / host_threads), (int)((int64_t)n * (t + 1) / host_threads));
+        for (auto &x : th) x.join();
+    };
     std::vector<int> first(n + 1, 0), nframes(n, 0);
-    std::vector<uint8_t> arena;
-    all.reserve(n);
+    on_ranges([&](int lo, int hi) {
+        for (int i = lo; i < hi; i++) {
+            result[i] = 0;
+            if (stream_ids[i] < 0 || stream_ids[i] >= ctx->n_streams || !packets[i] || lens[i] <= 0) {
+                result[i] = OPUSGPU_BAD_ARG; // no PLC in the reference: data==NULL/len==0 ends in an error (Q8)
+                continue;
+            }
+            opusgpu_frame_desc d[48];
+            const int count = opusgpu_packet_to_frames(packets[i], lens[i], stream_ids[i], d);
+            if (count < 0) {
+                result[i] = count;
+                continue;
+            }
+            // count * packet_frame_size > frame_size -> OPUS_BUFFER_TOO_SMALL (src/opus_decoder.cpp:323)
+            const int pfs = ogh::toc_samples_per_frame(packets[i][0], 48000);
+            if ((int64_t)count * pfs > (int64_t)frame_capacity * OPUSGPU_FRAME_SAMPLES || count > frame_capacity) {
+                result[i] = OPUSGPU_BUFFER_TOO_SMALL;
+                continue;
+            }
+            nframes[i] = count;
+        }
+    });
+    timer.mark("framing pass 1 (counts)");
+    std::vector<size_t> base(n + 1, 0); // where packet i lies in the arena
     int max_frames = 0;
     for (int i = 0; i < n; i++) {
-        first[i] = (int)all.size();
-        result[i] = 0;
-        if (stream_ids[i] < 0 || stream_ids[i] >= ctx->n_streams || !packets[i] || lens[i] <= 0) {
-            result[i] = OPUSGPU_BAD_ARG; // no PLC in the reference: data==NULL/len==0 ends in an error (Q8)
-            continue;
-        }
-        opusgpu_frame_desc d[48];
-        const int count = opusgpu_packet_to_frames(packets[i], lens[i], stream_ids[i], d);
-        if (count < 0) {
-            result[i] = count;
-            continue;
-        }
-        // count * packet_frame_size > frame_size -> OPUS_BUFFER_TOO_SMALL (src/opus_decoder.cpp:323)
-        const int pfs = ogh::toc_samples_per_frame(packets[i][0], 48000);
-        if ((int64_t)count * pfs > (int64_t)frame_capacity * OPUSGPU_FRAME_SAMPLES || count > frame_capacity) {
-            result[i] = OPUSGPU_BUFFER_TOO_SMALL;
-            continue;
-        }
-        const size_t base = arena.size();
-        arena.insert(arena.end(), packets[i], packets[i] + lens[i]);
-        for (int k = 0; k < count; k++) {
-            d[k].offset += (int32_t)base;
-            all.push_back(d[k]);
-        }
-        nframes[i] = count;
-        if (count > max_frames) max_frames = count;
+        first[i + 1] = first[i] + nframes[i];
+        base[i + 1] = base[i] + (nframes[i] ? (size_t)lens[i] : 0);
+        if (nframes[i] > max_frames) max_frames = nframes[i];
     }
-    first[n] = (int)all.size();
-    if (all.empty()) return OPUSGPU_OK;
+    if (first[n] == 0) return OPUSGPU_OK;
+    if (base[n] > 0x7fffffffu) return OPUSGPU_BAD_ARG; // descriptor offsets are 32-bit: split the call
+    std::unique_ptr<opusgpu_frame_desc[]> all(new opusgpu_frame_desc[first[n]]); // frames in (packet, frame) order
+    std::unique_ptr<uint8_t[]> arena(new uint8_t[base[n]]);
+    on_ranges([&](int lo, int hi) {
+        for (int i = lo; i < hi; i++) {
+            if (!nframes[i]) continue;
+            opusgpu_frame_desc d[48];
+            (void)opusgpu_packet_to_frames(packets[i], lens[i], stream_ids[i], d);
+            memcpy(arena.get() + base[i], packets[i], (size_t)lens[i]);
+            for (int k = 0; k < nframes[i]; k++) {
+                d[k].offset += (int32_t)base[i];
+                all[first[i] + k] = d[k];
+            }
+        }
+    });
+    timer.mark("prefix + framing pass 2 (place)");
     // 2. upload the arena once; run one step per frame index (frames of one packet are sequential)
-    int rc = grow(ctx, &ctx->d_arena, &ctx->cap_arena, arena.size() + 16);
+    int rc = grow(ctx, &ctx->d_arena, &ctx->cap_arena, base[n] + 16);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_arena, arena.data(), arena.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_arena, arena.get(), base[n], hipMemcpyHostToDevice, ctx->stream));
+    timer.mark("arena upload (enqueue)");
     std::vector<opusgpu_frame_desc> step;
     std::vector<int> owner;
     for (int k = 0; k < max_frames; k++) {
@@ -869,6 +918,7 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
             }
         const int m = (int)step.size();
         if (m == 0) break;
+        timer.mark("step table");
         if ((rc = grow(ctx, &ctx->d_descs, &ctx->cap_descs, sizeof(opusgpu_frame_desc) * m))) return rc;
         if ((rc = grow(ctx, &ctx->d_pcm, &ctx->cap_pcm, frame_pcm * 2 * m))) return rc;
         if ((rc = grow(ctx, &ctx->d_result, &ctx->cap_result, sizeof(int32_t) * m))) return rc;
@@ -876,34 +926,60 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
                                    ctx->stream));
         rc = opusgpu_decode_step_device(ctx, m, ctx->d_descs, ctx->d_arena, ctx->d_pcm, ctx->d_result, nullptr);
         if (rc) return rc;
+        timer.mark("table upload + kernels (enqueue)");
+        if (timer.on) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            timer.mark("kernels (wait)");
+        }
         if ((rc = grow_pinned(ctx, &ctx->h_pcm, &ctx->cap_h_pcm, frame_pcm * 2 * m))) return rc;
         if ((rc = grow_pinned(ctx, &ctx->h_res, &ctx->cap_h_res, sizeof(int32_t) * m))) return rc;
         const int16_t *h_pcm = (const int16_t *)ctx->h_pcm;
         const int32_t *h_res = (const int32_t *)ctx->h_res;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pcm, ctx->d_pcm, frame_pcm * 2 * m, hipMemcpyDeviceToHost, ctx->stream));
+        // 3. results and PCM back to the host.  The PCM comes in pieces, each followed by an event: every packet owns
+        //    its own block of the caller's buffer, and the threads that fill the blocks start on a piece as soon as it has
+        //    landed, while the later pieces are still on their way.
+        const int pieces = m >= 4096 ? OPUSGPU_COPY_PIECES : 1;
+        for (int t = 0; t < pieces; t++)
+            if (!ctx->ev_piece[t]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_piece[t], hipEventDisableTiming));
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_res, ctx->d_result, sizeof(int32_t) * m, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        // every packet owns its own block of the caller's PCM buffer: the blocks are filled by a few threads
-        auto deliver = [&](int lo, int hi) {
-            for (int j = lo; j < hi; j++) {
-                const int i = owner[j];
-                if (h_res[j] < 0) {
-                    result[i] = h_res[j];
-                    continue;
+        for (int t = 0; t < pieces; t++) {
+            const size_t lo = (size_t)((int64_t)m * t / pieces), hi = (size_t)((int64_t)m * (t + 1) / pieces);
+            HIPCHK(ctx, hipMemcpyAsync((uint8_t *)ctx->h_pcm + lo * frame_pcm * 2, (const uint8_t *)ctx->d_pcm + lo * frame_pcm * 2,
+                                       (hi - lo) * frame_pcm * 2, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipEventRecord(ctx->ev_piece[t], ctx->stream));
+        }
+        timer.mark("copy-back (enqueue)");
+        // every thread takes its share of every piece: the work left when the last piece lands is 1 / pieces of the PCM,
+        // spread over all threads
+        const int threads = pieces == 1 ? 1 : OPUSGPU_COPY_THREADS;
+        hipError_t thread_err[OPUSGPU_COPY_THREADS];
+        auto deliver = [&](int t) {
+            thread_err[t] = hipSuccess;
+            for (int p = 0; p < pieces; p++) {
+                if ((thread_err[t] = hipEventSynchronize(ctx->ev_piece[p])) != hipSuccess) return;
+                const int64_t plo = (int64_t)m * p / pieces, phi = (int64_t)m * (p + 1) / pieces;
+                const int lo = (int)(plo + (phi - plo) * t / threads), hi = (int)(plo + (phi - plo) * (t + 1) / threads);
+                for (int j = lo; j < hi; j++) {
+                    const int i = owner[j];
+                    if (h_res[j] < 0) {
+                        result[i] = h_res[j];
+                        continue;
+                    }
+                    memcpy(pcm + ((size_t)i * frame_capacity + k) * frame_pcm, &h_pcm[(size_t)j * frame_pcm], frame_pcm * 2);
+                    result[i] += h_res[j];
                 }
-                memcpy(pcm + ((size_t)i * frame_capacity + k) * frame_pcm, &h_pcm[(size_t)j * frame_pcm], frame_pcm * 2);
-                result[i] += h_res[j];
             }
         };
-        const int threads = m >= 4096 ? 8 : 1;
         if (threads == 1)
-            deliver(0, m);
+            deliver(0);
         else {
             std::vector<std::thread> th;
-            for (int t = 0; t < threads; t++)
-                th.emplace_back(deliver, (int)((int64_t)m * t / threads), (int)((int64_t)m * (t + 1) / threads));
+            for (int t = 0; t < threads; t++) th.emplace_back(deliver, t);
             for (auto &x : th) x.join();
         }
+        for (int t = 0; t < threads; t++)
+            if (thread_err[t] != hipSuccess) return fail(ctx, OPUSGPU_ERR_HIP, "hipEventSynchronize (PCM piece)", thread_err[t]);
+        timer.mark("copy-back + delivery (wait)");
     }
     return OPUSGPU_OK;
 }
