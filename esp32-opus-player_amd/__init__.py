@@ -251,6 +251,33 @@ class Context:
                   "opusgpu_decode_packets")
         return pcm, res
 
+    def decode_packets_arena(self, stream_ids, arena, offsets, lens, frame_capacity=1, pcm=None):
+        """opusgpu_decode_packets for packets that lie in one uint8 array (packet i = arena[offsets[i] : offsets[i] +
+        lens[i]]): the pointer table is made by numpy, not packet by packet -- at 65,536 packets per call the Python-side
+        marshalling of decode_packets costs several times the call itself.  `pcm`: an int16 array to decode into
+        (n, frame_capacity * 960, channels), reused between calls; a fresh one otherwise."""
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        offsets = np.asarray(offsets, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        ids = np.ascontiguousarray(stream_ids, dtype=np.int32)
+        n = len(lens)
+        if len(offsets) != n or len(ids) != n:
+            raise ValueError("stream_ids, offsets and lens must have one entry per packet")
+        if n and (offsets.min() < 0 or (offsets + lens).max() > arena.size):
+            raise ValueError("a packet lies outside the arena")
+        ptrs = (np.uint64(arena.ctypes.data) + offsets.astype(np.uint64)).astype(np.uint64)
+        shape = (n, frame_capacity * FRAME, self.channels)
+        if pcm is None:
+            pcm = np.empty(shape, dtype=np.int16)
+            pcm[...] = 0
+        elif pcm.shape != shape or pcm.dtype != np.int16 or not pcm.flags.c_contiguous:
+            raise ValueError(f"pcm must be a C-contiguous int16 array of shape {shape}")
+        res = np.zeros(n, dtype=np.int32)
+        self._chk(self.lib.opusgpu_decode_packets(self.h, n, ids.ctypes.data, ptrs.ctypes.data, lens.ctypes.data,
+                                                  pcm.ctypes.data, frame_capacity, res.ctypes.data),
+                  "opusgpu_decode_packets")
+        return pcm, res
+
     # ---- device-resident path -------------------------------------------------------------------
     def dev_alloc(self, nbytes):
         p = C.c_void_p()

@@ -197,3 +197,42 @@ def test_more_short_frames_than_room_is_refused(pkg, gpu_ctx):
     gpu_ctx.decode_packets(np.arange(n), first)
     pcm3, res3 = gpu_ctx.decode_packets(np.arange(n), follow)
     assert (res2 == 960).all() and (res3 == 960).all() and (pcm2 == pcm3).all()
+
+
+def test_packets_in_one_array_decode_like_a_list_of_packets(pkg, gpu_ctx):
+    """Context.decode_packets_arena (pointer table made by numpy) against Context.decode_packets (one buffer per packet):
+    ragged packets of all three modes, multi-frame packets, an empty and a malformed packet, a reused PCM array."""
+    rng = np.random.default_rng(17)
+    n, cap = 500, 3
+    tocs = [pkg.TOC_SILK_NB_STEREO, pkg.TOC_HYBRID_FB_STEREO, pkg.TOC_CELT_FB_STEREO]
+    packets = []
+    for i in range(n):
+        toc = tocs[i % 3]
+        L = int(rng.integers(1, 300))
+        body = rng.integers(0, 256, size=L, dtype=np.uint8).tobytes()
+        kind = i % 11
+        if kind == 0:
+            packets.append(bytes([toc | 1]) + body + body)          # two equal-size frames
+        elif kind == 1:
+            packets.append(b"")                                      # no data: an error in the reference (Q8)
+        elif kind == 2:
+            packets.append(bytes([toc | 3, 0]))                      # code 3 with zero frames: invalid
+        else:
+            packets.append(bytes([toc]) + body)
+    lens = np.array([len(p) for p in packets], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens.astype(np.int64))[:-1]])
+    arena = np.frombuffer(b"".join(packets) + b"\0", dtype=np.uint8)
+    ids = np.arange(n, dtype=np.int32)
+    gpu_ctx.streams_alloc(n, 2)
+    want = [gpu_ctx.decode_packets(ids, packets, frame_capacity=cap) for _ in range(2)]
+    gpu_ctx.streams_alloc(n, 2)
+    out = None
+    for rnd in range(2):
+        out, res = gpu_ctx.decode_packets_arena(ids, arena, offs, lens, frame_capacity=cap, pcm=out)
+        assert np.array_equal(res, want[rnd][1])
+        ok = res > 0
+        assert ok.sum() > 300 and (res < 0).sum() >= 80 and (res == 1920).sum() >= 30
+        for i in np.nonzero(ok)[0]:
+            assert np.array_equal(out[i, :res[i]], want[rnd][0][i, :res[i]]), (rnd, i)
+    with pytest.raises(ValueError):
+        gpu_ctx.decode_packets_arena(ids, arena, offs + 10**9, lens)

@@ -27,5 +27,19 @@ for s in range(1, steps + 1):
     pcm, res = ctx.decode_packets(ids, pk[s])
 dt = time.perf_counter() - t0
 assert (np.asarray(res) == 960).all()
-print("host-buffer path: %d streams x %d steps in %.3f s = %.0f frames/s (%.1f ms/step), PCM D2H %.1f MB/step"
+print("host-buffer path, a list of bytes objects (decode_packets): %d streams x %d steps in %.3f s = %.0f frames/s (%.1f ms/step), PCM D2H %.1f MB/step"
       % (n, steps, dt, n * steps / dt, dt / steps * 1e3, n * 3840 / 1e6))
+# the same packets in one array (decode_packets_arena): no per-packet Python work
+ctx.streams_alloc(n, 2)
+arenas = [np.concatenate([np.full((n, 1), pkg.TOC_CELT_FB_STEREO, dtype=np.uint8), pay[s]], axis=1).reshape(-1) for s in range(steps + 1)]
+offs = np.arange(n, dtype=np.int64) * 161
+lens = np.full(n, 161, dtype=np.int32)
+idv = np.arange(n, dtype=np.int32)
+out, res0 = ctx.decode_packets_arena(idv, arenas[0], offs, lens)
+t0 = time.perf_counter()
+for s in range(1, steps + 1):
+    out, res2 = ctx.decode_packets_arena(idv, arenas[s], offs, lens, pcm=out)
+dt = time.perf_counter() - t0
+assert (res2 == 960).all() and np.array_equal(out, pcm), "the two entries decode the same packets differently"
+print("host-buffer path, packets in one array (decode_packets_arena): %d streams x %d steps in %.3f s = %.0f frames/s (%.1f ms/step)"
+      % (n, steps, dt, n * steps / dt, dt / steps * 1e3))
