@@ -37,14 +37,29 @@ __global__ void __launch_bounds__(64) k_stream_init(StreamState *st, int first, 
 // no final inversion, the four checksum bytes taken as zero), ONE PAGE PER LANE, eight 256-entry tables in LDS.
 // A lane walking its own page with its own loads would make every wave-level load touch 64 cache lines and come back to
 // each line eight times, long after L1 has dropped it (measured: 0.55 TB/s).  Instead the wave moves whole 64-byte lines:
-// per step, 16 lanes fetch one line of one page (a load instruction covers four pages) into an LDS tile, then every lane
+// per step, four lanes fetch one line of one page (a load instruction covers 16 pages) into an LDS tile, then every lane
 // consumes its own 64-byte row eight bytes at a time.  The chunks are the MEMORY's 64-byte lines, not the page's: a
 // zero-start CRC ignores leading zero bytes, so a page that starts z bytes into a line is taken as z zeros followed by the
 // page; every 16-byte load is aligned (pages ending on line boundaries measured 18-25 % faster than pages at arbitrary
 // offsets when the chunks were counted from the page's end instead), no load passes the 16-byte block that holds the
 // page's last byte, and only the last chunk of a page is partial (eight-byte steps, then at most seven single bytes).
 // status: 1 match, 0 mismatch, OPUSGPU_PAGE_BAD_CAPTURE malformed.
-enum { CRC_ROW = 17 }; // tile row stride in words (64 bytes + 1 word: conflict-free column walks)
+// Chunk size and prefetch depth were measured (786,432 pages, shuffled / grouped sizes; the same
+// build varies by up to 10 % between runs on the grouped input, so only the last line is a real difference):
+//   64-byte chunks, one chunk ahead   2.70 - 2.72 / 3.08 - 3.45 TB/s   HBM traffic (FETCH_SIZE) 1.53 / 1.69 x the page bytes
+//   64-byte chunks, two chunks ahead  2.60 / 3.19
+//   128-byte chunks, two ahead        2.40 / 2.93        traffic 1.18 x (the second half of a 128-byte line is no longer
+//                                                        fetched again after the L2 dropped it), but 12 instead of 20
+//                                                        waves per CU, and the table lookups in LDS are what binds
+enum {
+    CRC_CHUNK = 64,               // bytes of a page per step
+    CRC_DEPTH = 1,                // chunks requested ahead of the one being worked on (1 or 2)
+    CRC_LPL = CRC_CHUNK / 16,     // lanes per line: each fetches 16 bytes
+    CRC_PPI = 64 / CRC_LPL,       // pages covered by one load instruction of the wave
+    CRC_NL = 64 / CRC_PPI,        // load instructions per chunk of the wave's 64 pages
+    CRC_ROW = CRC_CHUNK / 4 + 1,  // tile row stride in words (+ 1 word: conflict-free column walks)
+    CRC_STEPS = CRC_CHUNK / 8     // slice-by-8 steps per full chunk
+};
 __global__ void __launch_bounds__(256) k_pages_crc(const u8 *__restrict__ blob, const long long *__restrict__ offs,
                                                     const i32 *__restrict__ lens, i32 *__restrict__ status, int n,
                                                     const u32 *__restrict__ tables) {
@@ -103,26 +118,26 @@ __global__ void __launch_bounds__(256) k_pages_crc(const u8 *__restrict__ blob, 
         at0 = offs[p];
     }
     // z: where in its 64-byte line the page starts (by ADDRESS: the blob itself may start anywhere)
-    const int z = st < 0 ? 0 : (int)((reinterpret_cast<unsigned long long>(blob) + (unsigned long long)at0) & 63ull);
-    const int nfull = (z + total) >> 6, tail = (z + total) & 63, chunks = nfull + (tail != 0);
+    const int z = st < 0 ? 0 : (int)((reinterpret_cast<unsigned long long>(blob) + (unsigned long long)at0) & (unsigned long long)(CRC_CHUNK - 1));
+    const int nfull = (z + total) / CRC_CHUNK, tail = (z + total) % CRC_CHUNK, chunks = nfull + (tail != 0);
     pg_start[wv][lane] = at0 - z;
     pg_meta[wv][lane] = z | total << 8; // total <= 27 + 255 + 255 * 255
     __syncthreads();
     int max_chunks = chunks;
     for (int d = 32; d; d >>= 1) max_chunks = max(max_chunks, __shfl_xor(max_chunks, d, 64));
     u32 crc = 0;
-    const int grp = lane >> 2, quarter = lane & 3; // this lane fetches 16-byte quarter `quarter` of the line of page 16 i + grp
-    // chunk k of the wave's 64 pages into registers: four lanes per 64-byte line, four lines per lane
-    auto fetch = [&](int k, u32 (&w)[4][4]) {
+    const int grp = lane / CRC_LPL, quarter = lane % CRC_LPL; // this lane fetches 16-byte part `quarter` of the line of page CRC_PPI i + grp
+    // chunk k of the wave's 64 pages into registers: CRC_LPL lanes per line, CRC_NL lines per lane
+    auto fetch = [&](int k, u32 (&w)[CRC_NL][4]) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int q = 16 * i + grp;
+        for (int i = 0; i < CRC_NL; i++) {
+            const int q = CRC_PPI * i + grp;
             const i32 meta = pg_meta[wv][q];
-            const int idx = 64 * k + 16 * quarter - (meta & 255); // page byte index of the quarter's first byte
+            const int idx = CRC_CHUNK * k + 16 * quarter - (meta & 255); // page byte index of the quarter's first byte
             w[i][0] = w[i][1] = w[i][2] = w[i][3] = 0u;
             if (idx > -16 && idx < (meta >> 8)) { // the quarter holds at least one byte of the page
                 const uint4 v = *reinterpret_cast<const uint4 *>(
-                    __builtin_assume_aligned(blob + (pg_start[wv][q] + 64 * k + 16 * quarter), 16));
+                    __builtin_assume_aligned(blob + (pg_start[wv][q] + CRC_CHUNK * k + 16 * quarter), 16));
                 w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
                 if (idx < 26) { // near the page start: what precedes the page counts as zeros; so do bytes 22 .. 25 (the checksum)
 #pragma unroll
@@ -139,25 +154,24 @@ __global__ void __launch_bounds__(256) k_pages_crc(const u8 *__restrict__ blob, 
             }
         }
     };
-    u32 w[4][4];
-    if (max_chunks > 0) fetch(0, w);
-    for (int k = 0; k < max_chunks; k++) {
-        // ---- the fetched chunk into the tile; the next one is requested before this one is consumed, so that its memory
-        //      latency runs under the CRC work
+    // one chunk of the wave's pages from registers through the tile into the lanes' checksums
+    auto consume = [&](int k, u32 (&w)[CRC_NL][4]) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            u32 *dst = &tile[wv][(16 * i + grp) * CRC_ROW + 4 * quarter];
+        for (int i = 0; i < CRC_NL; i++) {
+            u32 *dst = &tile[wv][(CRC_PPI * i + grp) * CRC_ROW + 4 * quarter];
             dst[0] = w[i][0]; dst[1] = w[i][1]; dst[2] = w[i][2]; dst[3] = w[i][3];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (k + 1 < max_chunks) fetch(k + 1, w);
+        // the registers are free again: request a later chunk before this one is worked on, so that its memory latency
+        // runs under the CRC work
+        if (k + CRC_DEPTH < max_chunks) fetch(k + CRC_DEPTH, w);
         // ---- every lane consumes its own row: all of it, or (last chunk) the bytes up to the page's end
         const u32 *rowp = &tile[wv][lane * CRC_ROW];
-        const int steps = k < nfull ? 8 : k == nfull ? tail >> 3 : 0;
+        const int steps = k < nfull ? CRC_STEPS : k == nfull ? tail >> 3 : 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < CRC_STEPS; j++) {
             if (j < steps) {
                 const u32 lo = rowp[2 * j], hi = rowp[2 * j + 1]; // message bytes b0 .. b3 | b4 .. b7, first byte lowest
                 const u32 a = crc ^ ((lo & 0xffu) << 24 | (lo & 0xff00u) << 8 | (lo >> 8 & 0xff00u) | lo >> 24);
@@ -175,6 +189,17 @@ __global__ void __launch_bounds__(256) k_pages_crc(const u8 *__restrict__ blob, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    u32 wa[CRC_NL][4], wb[CRC_NL][4]; // chunks on their way (wb: only with CRC_DEPTH == 2)
+    if (max_chunks > 0) fetch(0, wa);
+    if (CRC_DEPTH == 2) {
+        if (max_chunks > 1) fetch(1, wb);
+        for (int k = 0; k < max_chunks; k += 2) {
+            consume(k, wa);
+            if (k + 1 < max_chunks) consume(k + 1, wb);
+        }
+    } else {
+        for (int k = 0; k < max_chunks; k++) consume(k, wa);
     }
     if (p < n) status[p] = st < 0 ? st : (i32)(crc == want);
 }
