@@ -28,8 +28,6 @@ struct WaveArr {
     OG_MEMBER i32 &offsets(int i) const { return S.offsets[i]; }
     OG_MEMBER i32 &bits1(int i) const { return S.bits1[i]; }
     OG_MEMBER i32 &bits2(int i) const { return S.bits2[i]; }
-    OG_MEMBER i32 &thresh(int i) const { return S.thresh[i]; }
-    OG_MEMBER i32 &trim_off(int i) const { return S.trim_off[i]; }
     OG_MEMBER i16 &bandE(int i) const { return S.bandE[i]; }
 };
 
@@ -161,13 +159,19 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
             total -= dual_stereo_rsv;
         }
     }
-    for (int j = start; j < end; j++) {
-        int w = T::eband(j + 1) - T::eband(j);
-        a.thresh(j) = OG_MAX(C << BITRES, (3 * w << LM << BITRES) >> 4);
+    // thresh[j] and trim_offset[j] of the reference (celt.cpp:3545-3554) are a few multiplies of per-band constants:
+    // computed where they are used instead of being kept in two per-band arrays (2.7 KB of the lane-per-frame parse
+    // kernel's LDS per wave, which decides how many of its waves fit a CU)
+    auto thresh_of = [&](int j) -> i32 {
+        const int w = T::eband(j + 1) - T::eband(j);
+        return OG_MAX(C << BITRES, (3 * w << LM << BITRES) >> 4);
+    };
+    auto trim_off_of = [&](int j) -> i32 {
+        const int w = T::eband(j + 1) - T::eband(j);
         i32 to = C * w * (alloc_trim - 5 - LM) * (end - j - 1) * (1 << (LM + BITRES)) >> 6;
         if (w << LM == 1) to -= C << BITRES;
-        a.trim_off(j) = to;
-    }
+        return to;
+    };
     int lo = 1, hi = 10;
     do {
         int done = 0, mid = (lo + hi) >> 1;
@@ -175,9 +179,9 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
         for (int j = end; j-- > start;) {
             int w = T::eband(j + 1) - T::eband(j);
             i32 bitsj = C * w * T::band_alloc(mid * NBANDS + j) << LM >> 2;
-            if (bitsj > 0) bitsj = OG_MAX(0, bitsj + a.trim_off(j));
+            if (bitsj > 0) bitsj = OG_MAX(0, bitsj + trim_off_of(j));
             bitsj += a.offsets(j);
-            if (bitsj >= a.thresh(j) || done) {
+            if (bitsj >= thresh_of(j) || done) {
                 done = 1;
                 psum += OG_MIN(bitsj, a.cap(j));
             } else if (bitsj >= C << BITRES)
@@ -190,8 +194,8 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
         int w = T::eband(j + 1) - T::eband(j);
         i32 b1 = C * w * T::band_alloc(lo * NBANDS + j) << LM >> 2;
         i32 b2 = hi >= 11 ? a.cap(j) : C * w * T::band_alloc(hi * NBANDS + j) << LM >> 2;
-        if (b1 > 0) b1 = OG_MAX(0, b1 + a.trim_off(j));
-        if (b2 > 0) b2 = OG_MAX(0, b2 + a.trim_off(j));
+        if (b1 > 0) b1 = OG_MAX(0, b1 + trim_off_of(j));
+        if (b2 > 0) b2 = OG_MAX(0, b2 + trim_off_of(j));
         if (lo > 0) b1 += a.offsets(j);
         b2 += a.offsets(j);
         if (a.offsets(j) > 0) skip_start = j;
@@ -209,7 +213,7 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
         psum = 0;
         for (int j = end; j-- > start;) {
             i32 tmp = a.bits1(j) + (mid * a.bits2(j) >> 6);
-            if (tmp >= a.thresh(j) || done) {
+            if (tmp >= thresh_of(j) || done) {
                 done = 1;
                 psum += OG_MIN(tmp, a.cap(j));
             } else if (tmp >= alloc_floor)
@@ -222,7 +226,7 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
         int done = 0;
         for (int j = end; j-- > start;) {
             i32 tmp = a.bits1(j) + (lo * a.bits2(j) >> 6);
-            if (tmp < a.thresh(j) && !done)
+            if (tmp < thresh_of(j) && !done)
                 tmp = tmp >= alloc_floor ? alloc_floor : 0;
             else
                 done = 1;
@@ -244,7 +248,7 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
         i32 rem = OG_MAX(left - (T::eband(j) - T::eband(start)), 0);
         i32 band_width = T::eband(codedBands) - T::eband(j);
         i32 band_bits = a.pulses(j) + percoeff * band_width + rem;
-        if (band_bits >= OG_MAX(a.thresh(j), alloc_floor + (1 << BITRES))) {
+        if (band_bits >= OG_MAX(thresh_of(j), alloc_floor + (1 << BITRES))) {
             if (rc_bit_logp(rc, 1)) break;
             psum += 1 << BITRES;
             band_bits -= 1 << BITRES;

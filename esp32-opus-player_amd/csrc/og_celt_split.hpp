@@ -102,11 +102,11 @@ static_assert(sizeof(ParseRec) % 16 == 0, "record alignment");
 struct ParseLds { // [element][lane]: lanes of a wave touch consecutive addresses, no bank conflicts
     i32 pulses[NBANDS][OG_PL_LANES];
     i16 bandE[2 * NBANDS][OG_PL_LANES];
-    i16 cap[NBANDS][OG_PL_LANES], offsets[NBANDS][OG_PL_LANES];
     i8 fine_quant[NBANDS][OG_PL_LANES], fine_prio[NBANDS][OG_PL_LANES], tf_res[NBANDS][OG_PL_LANES];
     union {
-        struct { // live during compute_allocation only
-            i16 thresh[NBANDS][OG_PL_LANES], trim_off[NBANDS][OG_PL_LANES];
+        struct { // live until compute_allocation returns (caps and dynalloc boosts are made just before it), i.e. before
+                 // the first band is parsed: 14.5 KB per wave in all, 11 parse waves per CU
+            i16 cap[NBANDS][OG_PL_LANES], offsets[NBANDS][OG_PL_LANES];
             u16 bits1[NBANDS][OG_PL_LANES], bits2[NBANDS][OG_PL_LANES];
         } al;
         i32 stack[5][6][OG_PL_LANES]; // split frames of the partition walk: [depth][word][lane]
@@ -149,12 +149,10 @@ struct LaneArr {
     OG_MEMBER i8 &fine_quant(int i) const { return PL.fine_quant[i][OG_LANE]; }
     OG_MEMBER i8 &fine_prio(int i) const { return PL.fine_prio[i][OG_LANE]; }
     OG_MEMBER i8 &tf_res(int i) const { return PL.tf_res[i][OG_LANE]; }
-    OG_MEMBER i16 &cap(int i) const { return PL.cap[i][OG_LANE]; }
-    OG_MEMBER i16 &offsets(int i) const { return PL.offsets[i][OG_LANE]; }
+    OG_MEMBER i16 &cap(int i) const { return PL.u.al.cap[i][OG_LANE]; }
+    OG_MEMBER i16 &offsets(int i) const { return PL.u.al.offsets[i][OG_LANE]; }
     OG_MEMBER u16 &bits1(int i) const { return PL.u.al.bits1[i][OG_LANE]; }
     OG_MEMBER u16 &bits2(int i) const { return PL.u.al.bits2[i][OG_LANE]; }
-    OG_MEMBER i16 &thresh(int i) const { return PL.u.al.thresh[i][OG_LANE]; }
-    OG_MEMBER i16 &trim_off(int i) const { return PL.u.al.trim_off[i][OG_LANE]; }
     OG_MEMBER i16 &bandE(int i) const { return PL.bandE[i][OG_LANE]; }
 };
 

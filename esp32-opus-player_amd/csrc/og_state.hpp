@@ -99,7 +99,7 @@ struct FrameLds {
     u8 pkt[1344];              // packet bytes (<= 1275); the split path keeps its per-leaf collapse masks here
     u32 win[64];               // split path: window of the parse record's word stream
     i32 pulses[NBANDS], fine_quant[NBANDS], fine_prio[NBANDS], tf_res[NBANDS], cap[NBANDS], offsets[NBANDS];
-    i32 bits1[NBANDS], bits2[NBANDS], thresh[NBANDS], trim_off[NBANDS];
+    i32 bits1[NBANDS], bits2[NBANDS];
     i16 bandE[2 * NBANDS], logE1[2 * NBANDS], logE2[2 * NBANDS];
     i16 dn_g[2 * NBANDS], dn_shift[2 * NBANDS];
     u8 cmask[2 * NBANDS];
