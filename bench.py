@@ -6,7 +6,12 @@ frame (stream state persists in HBM from step to step).  Workload at N=1 = BASEL
 65,536 synthetic CELT-only fullband stereo streams, 160-byte LCG payloads.
 All packets of all timed steps are resident in HBM before the timed region starts.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU under torch.distributed.run (RCCL).  When the driver has already started the ranks
+(WORLD_SIZE in the environment) this process is one of them and WORLD_SIZE must equal --gpus; when it has not,
+this process -- before it touches HIP or torch.cuda -- starts `python -m torch.distributed.run --nproc-per-node N
+bench.py ...` as a CHILD process, relays rank 0's JSON line and exits with the child's status.
 
 Prints ONE JSON line on rank 0.  `value` = frames decoded by all ranks / max-over-ranks wall time.
 `roofline` prices the decode kernel against HBM peak using the ALGORITHMIC bytes per frame
@@ -208,40 +213,106 @@ def prepare_pages_work(pkg, shard, ranks, ctx, n, frames, ingest="rank0", page_c
     return base, lay, stats, keep
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="celt_fb_stereo_64k", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
-    ap.add_argument("--page-crc", default="host", choices=["host", "gpu"],
-                    help="mixed_pages_2m with --ingest per-rank: who verifies the page checksums")
-    ap.add_argument("--ingest", default="rank0", choices=["rank0", "per-rank"],
-                    help="mixed_pages_2m: who demuxes the Ogg pages (rank 0 for all, or every rank its own share)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def launch_ranks(args, argv):
+    """--gpus N > 1 and no rank environment: start the N ranks as a child job (torch.distributed.run, one process per
+    GPU) and relay its output.  Nothing in THIS process has touched HIP / torch.cuda: it only waits for the child."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
 
-    # one process per GPU; streams are partitioned across the ranks (esp32-opus-player_amd/shard.py): RCCL carries
-    # nothing but the barrier around the timed region and the MAX / SUM of the per-rank figures
-    ranks = load_shard().Ranks(backend="nccl")
-    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
-    toc, L, bytes_per_frame, default_streams = WORKLOADS[args.workload]
-    n = args.streams or default_streams
+
+def check_against_oracle(pkg, ctx, name, n, frames, d_pcm, pay=None, pages_seed=None, slot_stream=None):
+    """After the timed region: the last step's PCM of >= 256 streams spread over the batch against the CPU oracle (which
+    decodes those streams' whole history: warm-up + timed steps).  Raises on a mismatch.
+    slot_stream: stream id of every PCM slot of the last step (step tables grouped by mode are not in stream order)."""
+    import zlib
+    import oracle_py
+    o = oracle_py.load()
+    pick = np.unique(np.concatenate([np.arange(0, n, max(1, n // 320)), [n - 1]])).astype(np.int64)
+    out = np.zeros((n, 960, 2), dtype=np.int16)
+    ctx.d2h(out, d_pcm)
+    slot_of = np.arange(n) if slot_stream is None else np.argsort(slot_stream)
+    refs = {}
+    if pay is not None:
+        toc = WORKLOADS[name][0]
+        ref, _ = o.batch_decode(2, toc, np.ascontiguousarray(pay[:frames][:, pick]))
+        refs = {int(s): ref[i, frames - 1] for i, s in enumerate(pick)}
+    else:  # mixed pages: stream s has mode s % 3 and payload row s // 3 of that mode's generator
+        for m, (toc, L) in enumerate(MIX):
+            sel = pick[pick % 3 == m]
+            if len(sel):
+                full = pkg.lcg_payloads(int(sel.max()) // 3 + 1, frames, L, seed_base=pages_seed(m))
+                ref, _ = o.batch_decode(2, toc, np.ascontiguousarray(full[:, sel // 3]))
+                refs.update({int(s): ref[i, frames - 1] for i, s in enumerate(sel)})
+    bad = [s for s in sorted(refs) if not (out[slot_of[s]] == refs[s]).all()]
+    if bad:
+        raise SystemExit(f"{name}: GPU PCM of the last timed step differs from the CPU oracle for streams {bad[:8]} "
+                         f"({len(bad)} of {len(refs)} checked)")
+    crc = 0
+    for s in sorted(refs):
+        crc = zlib.crc32(out[slot_of[s]].tobytes(), crc)
+    return {"streams_checked": len(refs), "frames_of_history": frames, "result": "last timed step bit-exact vs the CPU oracle",
+            "pcm_crc32": f"{crc:08x}"}
+
+
+def traffic_for(name, n):
+    """HBM bytes per step from the committed PMC passes of THIS round's build (tools/prof_pmc.sh -> profiles/r02/), taken
+    at this batch size; null when no such file exists.  The file names the build it was measured on."""
+    for rnd in ("r02",):
+        tpath = os.path.join(ROOT, "profiles", rnd, f"traffic_{name}.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            if tj.get("frames_per_launch") == n:
+                return tj["hbm_bytes_per_step"], tj.get("measured_on", f"profiles/{rnd}")
+    return None, None
+
+
+def kernels_of(name):
+    split = os.environ.get("OPUSGPU_SPLIT", "1") != "0"
+    split_silk = split and os.environ.get("OPUSGPU_SPLIT_HYBRID", "1") != "0"
+    if name == "mixed_pages_2m":
+        return "k_silk_parse + k_celt_parse + k_silk_synth + k_celt_recon + k_celt_post + k_decode_step (Q4 pass)"
+    if name.startswith("celt"):
+        return "k_celt_parse + k_celt_recon + k_celt_post" if split else "k_decode_step"
+    if name.startswith("silk"):
+        return "k_silk_parse + k_silk_synth" if split_silk else "k_decode_step"
+    return "k_silk_parse + k_silk_synth + k_celt_parse + k_celt_recon + k_celt_post" if split_silk else "k_decode_step"
+
+
+def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
+    """One workload: W warm-up steps, K timed steps between barriers, PCM check, roofline, CPU baseline.  -> dict (rank 0)."""
+    shard = load_shard()
+    rank, world = ranks.rank, ranks.world
+    toc, L, bytes_per_frame, default_streams = WORKLOADS[name]
+    n = n_override or default_streams
     K, W = args.steps, args.warmup
-
-    pkg = load_pkg()
-    ctx = pkg.Context(local_rank)
-    mixed = args.workload == "mixed_pages_2m"
+    mixed = name == "mixed_pages_2m"
     if mixed:
         n -= n % 3  # equal numbers of streams per mode
     ctx.streams_alloc(n, 2)
-    ingest = None
+    ingest, pay, e2e = None, None, None
+    frees = []
+    d_pcm = ctx.dev_alloc(n * 960 * 2 * 2)
+    d_res = ctx.dev_alloc(4 * n)
+    frees += [d_pcm, d_res]
     if mixed:
         # work arrives at rank 0 as Ogg pages and is scattered: the path's one exchange step, before the timed region
-        base, lay, ingest, _keep = prepare_pages_work(pkg, load_shard(), ranks, ctx, n, K + W, args.ingest, args.page_crc)
+        t_in0 = time.perf_counter()
+        base, lay, ingest, _keep = prepare_pages_work(pkg, shard, ranks, ctx, n, K + W, args.ingest, args.page_crc)
+        t_ingest = ranks.max_over_ranks(time.perf_counter() - t_in0)
         if lay.counts != [n] * (K + W):
             raise SystemExit(f"unexpected step tables: {lay.counts[:4]}...")
+        if _keep is None:
+            frees.append(base)
 
         def step(f):
             ctx.decode_work_step(base, lay, f, d_pcm, d_res)
@@ -258,11 +329,10 @@ def main():
             ctx.h2d(d, descs)
             d_arena.append(a)
             d_desc.append(d)
+        frees += d_arena + d_desc
 
         def step(f):
             ctx.decode_step_device(n, d_desc[f], d_arena[f], d_pcm, d_res)
-    d_pcm = ctx.dev_alloc(n * 960 * 2 * 2)
-    d_res = ctx.dev_alloc(4 * n)
 
     def barrier():
         ranks.barrier()
@@ -282,63 +352,141 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms = [ctx.event_elapsed_ms(ev[f], ev[f + 1]) for f in range(K)]
+    for e in ev:
+        ctx.event_destroy(e)
     res = np.zeros(n, dtype=np.int32)
     ctx.d2h(res, d_res)
     if not (res == 960).all():
-        raise SystemExit(f"decode failed for {(res != 960).sum()} frames in the last step")
+        raise SystemExit(f"{name}: decode failed for {(res != 960).sum()} frames in the last step")
+    # parity of what was just timed: last step's PCM of >= 256 streams vs the CPU oracle (every rank checks its own)
+    if mixed:
+        r = rank
+        last = np.zeros(n, dtype=pkg.DESC_DTYPE)
+        import ctypes
+        at = base.value if isinstance(base, ctypes.c_void_p) else int(base)
+        ctx.d2h(last, ctypes.c_void_p(at + lay.desc_at[K + W - 1]))
+        parity = check_against_oracle(pkg, ctx, name, n, K + W, d_pcm, slot_stream=last["stream"].astype(np.int64),
+                                      pages_seed=lambda m: (0x9E3779B9 ^ (r * 0x01000193) ^ (m * 0x5bd1e995)) & 0xFFFFFFFF)
+    else:
+        parity = check_against_oracle(pkg, ctx, name, n, K + W, d_pcm, pay=pay)
 
-    value, dt, total_frames = load_shard().aggregate_throughput(ranks, n * K, dt)
+    value, dt, total_frames = shard.aggregate_throughput(ranks, n * K, dt)
+    for p in frees:
+        ctx.dev_free(p)
+    if rank != 0:
+        return None
+    avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
+    achieved = bytes_per_frame * n / avg_kernel_s / 1e9
+    traffic, traffic_src = traffic_for(name, n)
+    out = {
+        "value": value, "unit": "frames/s", "ms_per_step": dt / K * 1e3,
+        "config": ({"workload": f"{name}: {n} streams/GPU, one Ogg page of {PACKETS_PER_PAGE} packets per stream and "
+                                f"10 steps, modes SILK-NB : hybrid FB : CELT FB = 1:1:1 across streams (TOC 0x0C / 0x7C / "
+                                f"0xFC, 40 / 120 / 160-byte LCG payloads), 48 kHz stereo, step tables grouped by mode",
+                    "streams_per_gpu": n,
+                    "sharding": ("rank 0 ingests the pages (host demux) and scatters every rank's decode steps "
+                                 if args.ingest == "rank0" else
+                                 "rank 0 routes the raw pages and scatters them, every rank demuxes its own share "
+                                 ) + "(torch.distributed scatter = RCCL), before the timed region; no collective inside it"}
+                   if mixed else
+                   {"workload": f"{name}: {n} streams/GPU x 20 ms frames, 48 kHz stereo, "
+                                f"TOC 0x{toc:02X}, {L}-byte LCG payloads, state persistent across steps",
+                    "streams_per_gpu": n, "sharding": "streams partitioned across ranks, no data-path collective"}),
+        "x_realtime_per_gpu": value / world / 50.0,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": f"decode step = {kernels_of(name)} (launched back to back)", "avg_launch_ms": avg_kernel_s * 1e3,
+                     "algorithmic_bytes_per_frame": bytes_per_frame, "frames_per_launch": n},
+        "parity_check": parity,
+    }
+    if ingest is not None:
+        # host page demux + scatter happen before the timed region and are never part of `value`; the end-to-end figure
+        # prices them in: all pages of the job / (ingest wall time + the decode steps those pages make)
+        ingest["ingest_wall_s"] = t_ingest
+        pages = ingest["pages"]
+        decode_s = (dt / K) * (K + W)
+        ingest["end_to_end_pages_per_s"] = pages / (t_ingest + decode_s)
+        ingest["end_to_end_note"] = ("pages of all ranks / (page generation excluded; routing + scatter + demux + upload wall time, "
+                                     "max over ranks) + (warm-up + timed decode steps at the measured step time)")
+        out["ingest"] = ingest
+    if cpu and not args.no_cpu_baseline:
+        out["cpu_baseline"] = mixed_cpu_baseline() if mixed else cpu_baseline(toc, L, seconds_target=args.cpu_seconds)
+        out["cpu_baseline"]["calibration"] = ("oracle only (a bit-identical C restatement of the reference path); the reference "
+                                              "itself is not buildable in this image (needs <Arduino.h>), so no oracle/reference "
+                                              "speed ratio exists")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="celt_fb_stereo_64k", choices=sorted(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
+    ap.add_argument("--page-crc", default="gpu", choices=["host", "gpu"],
+                    help="mixed_pages_2m with --ingest per-rank: who verifies the page checksums")
+    ap.add_argument("--ingest", default="per-rank", choices=["rank0", "per-rank"],
+                    help="mixed_pages_2m: who demuxes the Ogg pages (rank 0 for all, or every rank its own share)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work of the headline workload's cpu_baseline sample")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start / join the ranks, check the rank count, print a line and stop: no GPU work (the CPU test of "
+                         "the launcher path runs this with OPUSGPU_DIST_BACKEND=gloo)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="only the selected workload (default: the other BASELINE configs follow as other_configs)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not started by a launcher: start the ranks ourselves, as a child job, before anything here touches the GPU
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+
+    # one process per GPU; streams are partitioned across the ranks (esp32-opus-player_amd/shard.py): RCCL carries
+    # nothing but the barrier around the timed region and the MAX / SUM of the per-rank figures
+    ranks = load_shard().Ranks(backend=os.environ.get("OPUSGPU_DIST_BACKEND", "nccl"))
+    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to report a "
+                         f"{world}-GPU figure as a {args.gpus}-GPU one")
+    if world > 1 and rank == 0:
+        print(f"[bench] {world} ranks over RCCL (torch.distributed backend nccl), one process per GPU", file=sys.stderr, flush=True)
+    K, W = args.steps, args.warmup
+    if args.rendezvous_only:
+        total = ranks.sum_over_ranks(1)
+        ranks.barrier()
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": world, "ranks_counted": int(total)}), flush=True)
+        ranks.close()
+        return
+
+    pkg = load_pkg()
+    ctx = pkg.Context(local_rank)
+    main_out = run_workload(args.workload, args, ranks, pkg, ctx, n_override=args.streams)
+    others = []
+    if not args.no_other_configs and args.workload == "celt_fb_stereo_64k" and not args.streams:
+        # the other BASELINE configs (3, 4, and one GPU's share of 5), timed the same way in the same run; their CPU
+        # baselines get a smaller sample so that the default run stays within a few minutes
+        saved = args.cpu_seconds
+        args.cpu_seconds = 5.0
+        for name in ("silk_nb_stereo_64k", "hybrid_fb_stereo_256k", "mixed_pages_2m"):
+            o = run_workload(name, args, ranks, pkg, ctx)
+            if o is not None:
+                o["name"] = name
+                others.append(o)
+        args.cpu_seconds = saved
     if rank == 0:
-        avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
-        achieved = bytes_per_frame * n / avg_kernel_s / 1e9
-        # HBM traffic of one step from the committed PMC profile of this workload (tools/prof_pmc.sh), if it was taken
-        # at this batch size; null otherwise
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01", f"traffic_{args.workload}.json")
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                tj = json.load(fh)
-            if tj.get("frames_per_launch") == n:
-                traffic = tj["hbm_bytes_per_step"]
-        split = os.environ.get("OPUSGPU_SPLIT", "1") != "0"
-        split_silk = split and os.environ.get("OPUSGPU_SPLIT_HYBRID", "1") != "0"
-        if mixed:
-            kernels = "k_silk_parse + k_silk_synth + k_decode_step (Q4 pass) + k_celt_parse + k_celt_recon + k_celt_post"
-        elif args.workload.startswith("celt"):
-            kernels = "k_celt_parse + k_celt_recon + k_celt_post" if split else "k_decode_step"
-        elif args.workload.startswith("silk"):
-            kernels = "k_silk_parse + k_silk_synth" if split_silk else "k_decode_step"
-        else:
-            kernels = ("k_silk_parse + k_silk_synth + k_celt_parse + k_celt_recon + k_celt_post" if split_silk
-                       else "k_decode_step")
-        kernel_name = f"decode step = {kernels} (launched back to back)"
         line = {
             "metric": "decoded 48 kHz stereo frames/sec/GPU (x real-time); HBM GB/s vs roofline",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": main_out["value"], "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": main_out["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32 fixed-point (int16/int32 with 64-bit products)", "data": "synthetic",
-            "config": ({"workload": f"{args.workload}: {n} streams/GPU, one Ogg page of {PACKETS_PER_PAGE} packets per stream and "
-                                    f"10 steps, modes SILK-NB : hybrid FB : CELT FB = 1:1:1 across streams (TOC 0x0C / 0x7C / "
-                                    f"0xFC, 40 / 120 / 160-byte LCG payloads), 48 kHz stereo, step tables grouped by mode",
-                        "streams_per_gpu": n,
-                        "sharding": ("rank 0 ingests the pages (host demux) and scatters every rank's decode steps "
-                                     if args.ingest == "rank0" else
-                                     "rank 0 routes the raw pages and scatters them, every rank demuxes its own share "
-                                     ) + "(torch.distributed scatter = RCCL), before the timed region; no collective inside it"}
-                       if mixed else
-                       {"workload": f"{args.workload}: {n} streams/GPU x 20 ms frames, 48 kHz stereo, "
-                                    f"TOC 0x{toc:02X}, {L}-byte LCG payloads, state persistent across steps",
-                        "streams_per_gpu": n, "sharding": "streams partitioned across ranks, no data-path collective"}),
-            "x_realtime_per_gpu": value / world / 50.0,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel_name, "avg_launch_ms": avg_kernel_s * 1e3,
-                         "algorithmic_bytes_per_frame": bytes_per_frame, "frames_per_launch": n},
         }
-        if ingest is not None:
-            line["ingest"] = ingest  # host page demux + scatter, outside the timed region: never part of `value`
-        if not args.no_cpu_baseline:
-            line["cpu_baseline"] = mixed_cpu_baseline() if mixed else cpu_baseline(toc, L)
+        for k in ("config", "x_realtime_per_gpu", "roofline", "parity_check", "ingest", "cpu_baseline"):
+            if k in main_out:
+                line[k] = main_out[k]
+        if others:
+            line["other_configs"] = others
         print(json.dumps(line), flush=True)
     ranks.close()
     ctx.close()

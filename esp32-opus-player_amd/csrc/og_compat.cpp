@@ -125,6 +125,10 @@ int opus_decoder_init(OpusDecoder *st, int32_t Fs, int channels) { return st ? d
 int opus_decode(OpusDecoder *st, uint8_t *data, int32_t len, int16_t *pcm, int frame_size) {
     return dec_decode(st, data, len, pcm, frame_size);
 }
+// opus_decoder_get_nb_samples src/opus_decoder.cpp:507: the packet's sample count at the decoder's rate
+int opus_decoder_get_nb_samples(const OpusDecoder *dec, uint8_t packet[], int32_t len) {
+    return opus_packet_get_nb_samples(packet, len, dec->Fs);
+}
 int opus_decoder_ctl(OpusDecoder *st, int request, ...) {
     if (!st) return OPUS_BAD_ARG;
     va_list ap;

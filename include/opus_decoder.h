@@ -54,6 +54,7 @@ int opus_packet_get_samples_per_frame(uint8_t *data, int32_t Fs);
 int opus_packet_get_nb_channels(uint8_t *data);
 int opus_packet_get_nb_frames(uint8_t packet[], int32_t len);
 int opus_packet_get_nb_samples(uint8_t packet[], int32_t len, int32_t Fs);
+int opus_decoder_get_nb_samples(const OpusDecoder *dec, uint8_t packet[], int32_t len); // reference src/opus_decoder.h:175
 
 // ---- single-stream decoder (reference :66-118, :351-457) ---------------------------------------------------
 int opus_decoder_get_size(int channels);

@@ -22,6 +22,22 @@ def test_library_exports_every_declared_symbol(pkg):
     assert lib.opusgpu_stream_state_bytes() > 16384
 
 
+def test_library_exports_the_reference_surface(pkg):
+    """Every function include/opus_decoder.h and include/opusfile.h declare (the reference's own C++ prototypes,
+    src/opus_decoder.h:165-218, src/opusfile.h:144-156) is defined in libopusgpu.so."""
+    import subprocess
+    pkg.load_lib()
+    syms = subprocess.run(["nm", "-DC", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    have = set(re.findall(r"\b([a-z_0-9]+)\(", syms))
+    want = set()
+    for h in ("opus_decoder.h", "opusfile.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        want |= set(re.findall(r"^\s*(?:[A-Za-z_0-9]+[ \*]+)+((?:opus|op)_[a-z_0-9]+)\s*\(", text, flags=re.M))
+    assert {"opus_decoder_get_nb_samples", "opus_multistream_decode", "op_read_stereo", "opus_init_decoder"} <= want
+    missing = sorted(want - have)
+    assert not missing, f"declared but not exported: {missing}"
+
+
 def test_no_gpu_means_loud_failure_not_fallback(pkg):
     import torch
     if torch.cuda.is_available():

@@ -50,3 +50,25 @@ def test_work_queue_scatter(tmp_path):
         assert x["n_steps"] == 4 and x["counts"] == [30] * 4  # 30 streams per rank, 4 packets per page
         assert x["grouped"] and x["size"] == x["nbytes"]
     assert r[0]["crc"] != r[1]["crc"]  # different streams, different work
+
+
+def test_bench_launcher_starts_the_ranks():
+    """`python bench.py --gpus 2` without a launcher: the parent starts two ranks as a child job (before touching any GPU)
+    and relays rank 0's line.  Run here with the gloo backend and no GPU work (--rendezvous-only)."""
+    env = dict(os.environ, OPUSGPU_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(x) for x in p.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["ranks_counted"] == 2
+
+
+def test_bench_refuses_a_rank_count_that_is_not_gpus():
+    """A launcher that started one rank for --gpus 2 must not yield an `n_gpus: 1` line: the run fails loudly."""
+    env = dict(os.environ, OPUSGPU_DIST_BACKEND="gloo", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "refusing" in p.stderr
+    assert not [x for x in p.stdout.splitlines() if x.startswith("{")]
