@@ -82,12 +82,13 @@ struct ParseRec {
     i32 reserved[5];
     i16 bandE[2 * NBANDS]; // final band energies (coarse + fine + finalise)
     i16 pulses[NBANDS];
+    u16 band_w[NBANDS];    // where each band's four header words start in words[] (its job words follow them)
     i8 tf_res[NBANDS];
-    i8 pad[256 - 64 - 4 * NBANDS - 2 * NBANDS - NBANDS];
+    i8 pad[256 - 64 - 4 * NBANDS - 2 * NBANDS - 2 * NBANDS - NBANDS];
     u32 leaf_idx[REC_MAX_LEAVES];  // PVQ codeword index
     u32 leaf_geom[REC_MAX_LEAVES]; // x | N << 11 | K << 19 | (B - 1) << 27   (x: offset into S.v[V_X..])
     u32 leaf_aux[REC_MAX_LEAVES];  // gain (product of the split gains above the leaf, Q15) | mask offset << 16
-    u32 words[(REC_MAX_WORDS + 64) / 64 * 64]; // read in windows of 64
+    u32 words[(REC_MAX_WORDS + 64) / 64 * 64]; // read in windows of 64 (REC_WORDS_CAP)
 };
 static_assert(sizeof(ParseRec) % 16 == 0, "record alignment");
 
@@ -311,6 +312,7 @@ OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C
     for (int i = start; i < end; i++) {
         const int eb0 = M * RomLds::eband(i), N = M * RomLds::eband(i + 1) - eb0;
         const int x = eb0, y = C == 2 ? N_ch + eb0 : -1;
+        out.rec->band_w[i] = (u16)OG_MIN(out.nw, REC_MAX_WORDS);
         const i32 tell = (i32)rc_tell_frac(rc);
         if (i != start) balance -= tell;
         i32 remaining_bits = total_bits - tell - 1, b;
@@ -668,17 +670,19 @@ OG_DEV u16 *leaf_masks() { return reinterpret_cast<u16 *>(&S.pkt[0]); }
 static_assert(sizeof(FrameLds::pkt) >= sizeof(u16) * REC_MAX_LEAVES, "leaf masks must fit the packet buffer");
 
 // The record's word stream is consumed strictly in order: a 64-word window in LDS, refilled by one coalesced load.
-struct RecCur { // read positions in the record: next word, next PVQ leaf
+constexpr int REC_WORDS_CAP = (REC_MAX_WORDS + 64) / 64 * 64; // size of ParseRec::words
+struct RecCur { // read positions in the record: next word, first word of the window in LDS (-64: none), next PVQ leaf
     const u32 *words;
-    int w, leaf;
+    int w, base, leaf;
 };
 OG_DEV u32 rec_word(RecCur &cur) {
-    if ((cur.w & 63) == 0) {
+    if ((unsigned)(cur.w - cur.base) >= 64u) { // the window moves to the word wanted (the sequential walk: every 64 words)
         OG_SYNC();
-        OG_FOR_LANES(l, 64) S.win[l] = cur.words[cur.w + l];
+        OG_FOR_LANES(l, 64) S.win[l] = cur.words[OG_MIN(cur.w + l, REC_WORDS_CAP - 1)];
         OG_SYNC();
+        cur.base = cur.w;
     }
-    const u32 w = (u32)OG_UNI(S.win[cur.w & 63]);
+    const u32 w = (u32)OG_UNI(S.win[cur.w - cur.base]);
     cur.w++;
     return w;
 }
@@ -686,8 +690,8 @@ OG_DEV u32 rec_word(RecCur &cur) {
 // Four consecutive words (a band's header): when they lie inside the current window -- 15 times out of 16 -- the four LDS
 // reads have no refill check between them and issue together (one latency instead of four).
 OG_DEV void rec_word4(RecCur &cur, u32 &w0, u32 &w1, u32 &w2, u32 &w3) {
-    const int at = cur.w & 63;
-    if (at != 0 && at <= 60) {
+    const int at = cur.w - cur.base;
+    if (at >= 0 && at <= 60) {
         const u32 a = S.win[at], b = S.win[at + 1], c = S.win[at + 2], d = S.win[at + 3];
         w0 = (u32)OG_UNI(a);
         w1 = (u32)OG_UNI(b);
@@ -809,12 +813,11 @@ OG_DEV void hadamard_p2(int x, int N0, int log_stride, int hadamard, int dir) {
 }
 
 // quant_band celt.cpp:1526, vector half; N > 1.  `scale`: sqrt(N) for the folding history (from the record).
-OG_DEV u32 recon_band_mono(RecCur &cur, const LcgTab &lcg, int tf_change, u32 &seed, int x, int N, int B, int low, int low_out,
+OG_DEV u32 recon_band_mono(RecCur &cur, u32 jw, const LcgTab &lcg, int tf_change, u32 &seed, int x, int N, int B, int low, int low_out,
                            i32 scale, int low_scratch, i32 fill) {
     const int N0 = N, longBlocks = B == 1;
     int logB = ilog2(B), time_divide = 0, recombine = 0;
     int N_B = N >> logB;
-    const u32 jw = rec_word(cur);
     OG_STAT(1, 1);                                  // jobs
     OG_STAT(2, (jw & JW_NEED_LOW) && low >= 0);     // jobs that prepare a folding source
     OG_STAT(3, (int)(jw & 31));                     // fill leaves
@@ -890,6 +893,7 @@ OG_DEV void recon_all_bands(const u32 *words, u32 need_norm, const LcgTab &lcg, 
     RecCur cur;
     cur.words = words;
     cur.w = 0;
+    cur.base = -64;
     cur.leaf = 0;
     u32 seed = seed_io;
     for (int i = start; i < end; i++) {
@@ -985,7 +989,8 @@ OG_DEV void recon_all_bands(const u32 *words, u32 need_norm, const LcgTab &lcg, 
                     jx = y; jlow = -1; jout = -1; jscr = -1; jfill = fill0 >> B;
                 }
                 OG_MARK(5);
-                const u32 cmj = recon_band_mono(cur, lcg, tf_change, seed, jx, N, B, jlow, jout, scale, jscr, jfill);
+                const u32 jw = rec_word(cur);
+                const u32 cmj = recon_band_mono(cur, jw, lcg, tf_change, seed, jx, N, B, jlow, jout, scale, jscr, jfill);
                 if (jb == 0) cm0 = cmj; else cm1 = cmj;
             }
             OG_MARK(10);
@@ -1026,6 +1031,449 @@ OG_DEV void recon_all_bands(const u32 *words, u32 need_norm, const LcgTab &lcg, 
     seed_io = seed;
 }
 
+// =====================================================================================================
+//  recon, phase-major band loop (20 ms frames from band 0: every CELT-only frame of the BASELINE workloads)
+// =====================================================================================================
+// recon_all_bands above walks the bands one after another because the reference does; but once the leaf pass has run,
+// what a band still needs is local to it -- undoing its time-frequency change (Haar / Hadamard), its stereo merge --
+// except for two things that look back: a leaf WITHOUT pulses is filled from earlier bands (their collapse masks, their
+// spectrum as the folding source, the noise seed), and anti-collapse needs every band's mask.  Measured on the bench
+// payloads 3 of a frame's 42 jobs have such a leaf; the per-band walk nevertheless paid ~20 dependent LDS round trips and
+// ~700 scalar instructions per band for control (half of k_celt_recon's time, 15 k SALU instructions per frame).  Here:
+//   B  one LANE per job (band x decode slot) reads the job's words, derives its time-frequency steps and -- for jobs
+//      whose leaves all carry pulses -- its collapse mask;
+//   C  those jobs' time-frequency changes are undone for the whole spectrum at once, a lane per group of 8 coefficients
+//      (every band of a 20 ms frame is a multiple of 8 wide and 16-byte aligned): the interleave as a gather, Haar steps
+//      of stride 1 / 2 / 4 in registers;
+//   D  the jobs that do fill a leaf run one after another in decode order through the same code as the band walk
+//      (recon_band_mono); their folding source is made on demand from the spectrum (the band walk's `norm` rows are
+//      exactly scale(band) * X of earlier bands, taken before the stereo merge -- which is why the merge waits for E);
+//   E  all stereo merges: partial sums per group of 8, one lane per band for the gains, one apply pass;
+//   F  collapse masks per band (anti-collapse reads them).
+// Same arithmetic per coefficient as the band walk (src/celt.cpp:1526-1741, :1113-1213), reordered only where the
+// reference's order carries no dependency.
+struct PmLds { // overlays the folding-history rows S.v[V_NORM ..], which this path never materialises
+    u32 jdesc[2 * NBANDS];  // per (band, channel): JD_*
+    u32 jaux[2 * NBANDS];   // per (band, decode slot): word position of the job header | channel << 16 | exists << 17 | fills << 18
+    u32 bw0[NBANDS], bw1[NBANDS], bw2[NBANDS];
+    i32 scale[NBANDS];
+    i32 mpar[NBANDS][4];    // stereo merge of the band: mode | kl << 8 | kr << 16, lgain, rgain, mid
+    i32 part[100][2];       // per group of 8 coefficients: sum y*x, sum y*y
+    u16 jcm[2 * NBANDS];    // per (band, channel): the job's collapse mask
+    u8 binband[100], binoff[100]; // 5 ms bin (= group of 8 coefficients; 100 of them are coded) -> band, group index within the band
+};
+static_assert(sizeof(PmLds) <= sizeof(i16) * 1248, "the phase-major tables overlay the folding-history rows");
+OG_DEV PmLds &PM() { return *reinterpret_cast<PmLds *>(&S.v[V_NORM]); }
+
+enum { // PmLds::jdesc
+    JD_VALID = 1, JD_FILL = 2,          // the job exists / has a leaf without pulses (phase D does everything for it)
+    JD_PERM_SHIFT = 2 /* 3 bits: log2 of the interleave stride, 0 = none */, JD_HAD = 1 << 5,
+    JD_STEP_SHIFT = 8 /* 3 Haar steps x 4 bits: 0 none, else log2(stride) + 1 */
+};
+
+struct V8 { i32 v[8]; };
+OG_DEV V8 ld8(int pos) { // eight consecutive coefficients, pos a multiple of 8
+    V8 r;
+#ifdef OG_HOST_EMUL
+    for (int k = 0; k < 8; k++) r.v[k] = S.v[pos + k];
+#else
+    const og_v4i p = *reinterpret_cast<const og_v4i *>(&S.v[pos]);
+    r.v[0] = (i32)(i16)p.x; r.v[1] = p.x >> 16; r.v[2] = (i32)(i16)p.y; r.v[3] = p.y >> 16;
+    r.v[4] = (i32)(i16)p.z; r.v[5] = p.z >> 16; r.v[6] = (i32)(i16)p.w; r.v[7] = p.w >> 16;
+#endif
+    return r;
+}
+OG_DEV void st8(int pos, const V8 &r) {
+#ifdef OG_HOST_EMUL
+    for (int k = 0; k < 8; k++) S.v[pos + k] = (i16)r.v[k];
+#else
+    og_v4i p;
+    p.x = (i32)(((u32)r.v[0] & 0xffffu) | (u32)r.v[1] << 16); p.y = (i32)(((u32)r.v[2] & 0xffffu) | (u32)r.v[3] << 16);
+    p.z = (i32)(((u32)r.v[4] & 0xffffu) | (u32)r.v[5] << 16); p.w = (i32)(((u32)r.v[6] & 0xffffu) | (u32)r.v[7] << 16);
+    *reinterpret_cast<og_v4i *>(&S.v[pos]) = p;
+#endif
+}
+OG_DEV void haar_pair(i32 &a, i32 &b) { // one butterfly of haar1 celt.cpp:1202
+    const i32 t1 = mul16(23170, a), t2 = mul16(23170, b);
+    a = tr16(pshr32(t1 + t2, 15));
+    b = tr16(pshr32(t1 - t2, 15));
+}
+template <int S_>
+OG_DEV void haar8(V8 &r) { // the Haar step of stride S_ (1, 2, 4) inside one group of 8
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (!(i & S_)) haar_pair(r.v[i], r.v[i + S_]);
+}
+
+struct PmGrp { int band, job, x, gj, N; u32 jd; };
+constexpr int PM_GROUPS = 100; // coded groups of 8 per channel (eband5ms[21] = 100)
+OG_DEV PmGrp pm_group(int g) { // group g of the coded spectrum: 0..99 first channel, 100..199 second
+    const PmLds &P = PM();
+    PmGrp r;
+    const int ch = g >= PM_GROUPS, bin = g - PM_GROUPS * ch;
+    r.band = P.binband[bin];
+    r.gj = P.binoff[bin];
+    r.job = 2 * r.band + ch;
+    r.jd = P.jdesc[r.job];
+    r.x = V_X + 960 * ch + 8 * (bin - r.gj);
+    r.N = (int)(P.bw1[r.band] >> 22) & 255;
+    return r;
+}
+
+// B: one lane per (band, decode slot).  Returns (wave-uniform) which time-frequency passes some job needs: bit 0 the
+// interleave, bit 1 + 4 k + c the Haar stride 1 << c at step k; fill_lo / fill_hi: the jobs phase D has to run.
+OG_DEV u32 pm_setup_jobs(const ParseRec *rec, int C, int B, u32 &fill_lo, u32 &fill_hi, int &dual_end) {
+    PmLds &P = PM();
+    OG_SYNC();
+    OG_FOR_LANES(bin, PM_GROUPS) {
+        int b = 0;
+        while (rom_eband[b + 1] <= bin) b++;
+        P.binband[bin] = (u8)b;
+        P.binoff[bin] = (u8)(bin - rom_eband[b]);
+    }
+    OG_FOR_LANES(i, 2 * NBANDS) {
+        P.jdesc[i] = 0;
+        P.jcm[i] = 0;
+    }
+    OG_SYNC();
+    u32 tfm = 0, flo = 0, fhi = 0, de = 0;
+    const int logBf = ilog2(B);
+    OG_FOR_LANES(l, 2 * NBANDS) {
+        const int band = l >> 1, jb = l & 1;
+        const u32 *wp = rec->words + rec->band_w[band];
+        const u32 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3], jw0 = wp[4];
+        const int N = (int)(w1 >> 22) & 255;
+        const int stereo = (w0 & BW_STEREO) != 0, dual = (w0 & BW_DUAL) != 0, mid_first = (w0 & BW_MID_FIRST) != 0;
+        const int njobs = (stereo || dual) ? 2 : 1;
+        if (jb == 0) {
+            P.bw0[band] = w0;
+            P.bw1[band] = w1;
+            P.bw2[band] = w2;
+            P.scale[band] = (i32)(i16)(w3 & 0xffff);
+            if (w0 & BW_DUAL_END) de |= 1u << band;
+        }
+        const int exists = jb < njobs;
+        const int ch = dual ? jb : stereo ? (((jb == 0) == mid_first) ? 0 : 1) : 0;
+        const int jpos = rec->band_w[band] + 4 + (jb ? 1 + 2 * (int)(jw0 & 31) : 0);
+        u32 jw = jw0;
+        if (jb && exists) jw = rec->words[OG_MIN(jpos, REC_WORDS_CAP - 1)];
+        const int n_fill = (int)(jw & 31), n_pvq = (int)(jw >> JW_NPVQ_SHIFT) & 31, first = (int)(jw >> JW_FIRST_SHIFT) & 1023;
+        P.jaux[l] = (u32)jpos | (u32)ch << 16 | (u32)exists << 17 | (u32)(exists && n_fill > 0) << 18;
+        if (exists) {
+            // the job's time-frequency bookkeeping (quant_band celt.cpp:1548-1580), as in recon_band_mono
+            int tf_change = (int)((w0 >> BW_TF_SHIFT) & 7) - 4;
+            int recombine = tf_change > 0 ? tf_change : 0, time_divide = 0;
+            int logB = logBf - recombine, N_B = (N >> logBf) << recombine;
+            while ((N_B & 1) == 0 && tf_change < 0) {
+                logB++;
+                N_B >>= 1;
+                time_divide++;
+                tf_change++;
+            }
+            const int logB0 = logB;
+            u32 jd = JD_VALID;
+            if (logB0 > 0) jd |= (u32)(logB0 + recombine) << JD_PERM_SHIFT | (B == 1 ? JD_HAD : 0);
+            int step = 0;
+            for (int k = 0; k < time_divide; k++, step++) jd |= (u32)(logB0 - 1 - k + 1) << (JD_STEP_SHIFT + 4 * step);
+            for (int k = 0; k < recombine; k++, step++) jd |= (u32)(k + 1) << (JD_STEP_SHIFT + 4 * step);
+            if (n_fill > 0) {
+                jd |= JD_FILL;
+                if (l < 32) flo |= 1u << l; else fhi |= 1u << (l - 32);
+            } else {
+                if (logB0 > 0) tfm |= 1u;
+                for (int k = 0; k < 3; k++) {
+                    const int c = (int)(jd >> (JD_STEP_SHIFT + 4 * k)) & 15;
+                    if (c) tfm |= 1u << (1 + 4 * k + (c - 1));
+                }
+                // the collapse mask of a job whose leaves all carry pulses: the leaves' masks, then what the way back
+                // up does to a mask (celt.cpp:1596-1611)
+                u32 cm = 0;
+                for (int t = 0; t < n_pvq; t++) cm |= leaf_masks()[first + t];
+                for (int k = 0; k < time_divide; k++) {
+                    logB--;
+                    cm |= cm >> (1 << logB);
+                }
+                for (int k = 0; k < recombine; k++) {
+                    const u32 c4 = cm & 0xF; // bit_deinterleave_table celt.cpp:1606
+                    cm = ((c4 & 1) * 0x03) | ((c4 >> 1 & 1) * 0x0C) | ((c4 >> 2 & 1) * 0x30) | ((c4 >> 3 & 1) * 0xC0);
+                }
+                logB += recombine;
+                P.jcm[2 * band + ch] = (u16)(cm & ((1u << (1 << logB)) - 1));
+            }
+            P.jdesc[2 * band + ch] = jd;
+        }
+    }
+    tfm = wave_or(tfm);
+    fill_lo = wave_or(flo);
+    fill_hi = wave_or(fhi);
+    de = wave_or(de);
+    dual_end = de ? ilog2((i32)de) : NBANDS + 1; // (at most one band ends dual stereo)
+    OG_SYNC();
+    return tfm;
+}
+
+// C: undo the time-frequency changes of every job without fill leaves, a lane per group of 8 coefficients.
+OG_DEV void pm_tf_undo(u32 tfm) {
+    constexpr int NG = (2 * PM_GROUPS + OG_NLANES - 1) / OG_NLANES;
+    if (tfm & 1u) { // interleave_hadamard celt.cpp:1183 as a gather: all groups read, then all write
+        V8 hold[NG];
+        u8 mark[NG];
+#pragma unroll
+        for (int it = 0; it < NG; it++) {
+            const int g = OG_LANE + it * OG_NLANES;
+            mark[it] = 0;
+            if (g < 2 * PM_GROUPS) {
+                const PmGrp q = pm_group(g);
+                const int ls = (int)(q.jd >> JD_PERM_SHIFT) & 7;
+                if ((q.jd & JD_VALID) && !(q.jd & JD_FILL) && ls) {
+                    const int stride = 1 << ls, n0 = q.N >> ls, had = (q.jd & JD_HAD) != 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int inter = 8 * q.gj + k, j = inter >> ls, i = inter & (stride - 1);
+                        hold[it].v[k] = S.v[q.x + (had ? ordery(stride, i) : i) * n0 + j];
+                    }
+                    mark[it] = 1;
+                }
+            }
+        }
+        OG_SYNC();
+#pragma unroll
+        for (int it = 0; it < NG; it++) {
+            const int g = OG_LANE + it * OG_NLANES;
+            if (mark[it]) {
+                const PmGrp q = pm_group(g);
+                st8(q.x + 8 * q.gj, hold[it]);
+            }
+        }
+        OG_SYNC();
+    }
+    if (tfm & (1u << (1 + 3))) { // a first Haar step of stride 8 (short blocks divided once more): pairs of groups
+#pragma unroll
+        for (int it = 0; it < NG; it++) {
+            const int g = OG_LANE + it * OG_NLANES;
+            if (g < 2 * PM_GROUPS) {
+                const PmGrp q = pm_group(g);
+                if ((q.jd & JD_VALID) && !(q.jd & JD_FILL) && ((q.jd >> JD_STEP_SHIFT) & 15) == 4 && !(q.gj & 1)) {
+                    V8 a = ld8(q.x + 8 * q.gj), b = ld8(q.x + 8 * q.gj + 8);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) haar_pair(a.v[k], b.v[k]);
+                    st8(q.x + 8 * q.gj, a);
+                    st8(q.x + 8 * q.gj + 8, b);
+                }
+            }
+        }
+        OG_SYNC();
+    }
+    if (tfm & 0x0eeeu) { // Haar steps of stride 1 / 2 / 4: inside a group, in registers, up to three in a row
+#pragma unroll
+        for (int it = 0; it < NG; it++) {
+            const int g = OG_LANE + it * OG_NLANES;
+            if (g < 2 * PM_GROUPS) {
+                const PmGrp q = pm_group(g);
+                const u32 steps = (q.jd & JD_VALID) && !(q.jd & JD_FILL) ? (q.jd >> JD_STEP_SHIFT) & 0xfffu : 0u;
+                if (steps & 0x777u) { // (a step of stride 8 has code 4: bit 3 of its nibble only)
+                    V8 r = ld8(q.x + 8 * q.gj);
+                    for (int k = 0; k < 3; k++) {
+                        const int c = (int)(steps >> (4 * k)) & 15;
+                        if (c == 1) haar8<1>(r);
+                        else if (c == 2) haar8<2>(r);
+                        else if (c == 3) haar8<4>(r);
+                    }
+                    st8(q.x + 8 * q.gj, r);
+                }
+            }
+        }
+        OG_SYNC();
+    }
+}
+
+// the folding source of job (band i, channel ch) made on demand: `n` entries from position p0 of the folding history as the
+// band walk would hold it when band i starts (lowband_out of the earlier bands, celt.cpp:1617; the two channels' histories
+// averaged once dual stereo has ended, celt.cpp:1856-1860)
+OG_DEV void pm_make_lowband(int dst, int p0, int n, int i, int use_y, int dual_end) {
+    const PmLds &P = PM();
+    OG_SYNC();
+    OG_FOR_LANES(j, n) {
+        const int p = p0 + j, sb = P.binband[p >> 3];
+        const i32 sc = P.scale[sb];
+        i32 v;
+        if (i >= dual_end && sb < dual_end)
+            v = ((i32)(i16)mul16_q15(sc, S.v[V_X + p]) + (i32)(i16)mul16_q15(sc, S.v[V_X + 960 + p])) >> 1;
+        else
+            v = mul16_q15(sc, S.v[V_X + (use_y ? 960 : 0) + p]);
+        S.v[dst + j] = (i16)v;
+    }
+    OG_SYNC();
+}
+
+// collapse mask of band b, channel c (what the band walk keeps in S.cmask)
+OG_DEV u32 pm_band_cm(int b, int c) {
+    const PmLds &P = PM();
+    const u32 w0 = (u32)OG_UNI(P.bw0[b]);
+    if (w0 & BW_STEREO) return (u32)OG_UNI(P.jcm[2 * b]) | (u32)OG_UNI(P.jcm[2 * b + 1]);
+    return (u32)OG_UNI(P.jcm[2 * b + ((w0 & BW_DUAL) ? c : 0)]);
+}
+
+// D: the jobs with leaves without pulses, in decode order
+OG_DEV void pm_fill_jobs(const u32 *words, const LcgTab &lcg, u32 fill_lo, u32 fill_hi, int C, int B, int dual_end, u32 &seed) {
+    PmLds &P = PM();
+    RecCur cur;
+    cur.words = words;
+    cur.w = 0;
+    cur.base = -64;
+    cur.leaf = 0;
+    for (int l = 0; l < 2 * NBANDS; l++) {
+        if (!((l < 32 ? fill_lo >> l : fill_hi >> (l - 32)) & 1u)) continue;
+        OG_MARK(5);
+        const int i = l >> 1, jb = l & 1;
+        const u32 aux = (u32)OG_UNI(P.jaux[l]), w0 = (u32)OG_UNI(P.bw0[i]), w1 = (u32)OG_UNI(P.bw1[i]);
+        const int ch = (int)(aux >> 16) & 1;
+        const int eb0 = (int)(w1 >> 11) & 2047, N = (int)(w1 >> 22) & 255;
+        const int tf_change = (int)((w0 >> BW_TF_SHIFT) & 7) - 4;
+        const int stereo = (w0 & BW_STEREO) != 0, dual = (w0 & BW_DUAL) != 0;
+        u32 x_cm, y_cm;
+        if (w0 & BW_HAS_LOW) {
+            const int fold_end = (int)(w0 >> BW_FOLD1_SHIFT) & 31;
+            int fold_i = (int)(w0 >> BW_FOLD0_SHIFT) & 31;
+            x_cm = y_cm = 0;
+            do {
+                x_cm |= pm_band_cm(fold_i, 0);
+                y_cm |= pm_band_cm(fold_i, C - 1);
+            } while (++fold_i < fold_end);
+        } else
+            x_cm = y_cm = (1u << B) - 1;
+        i32 jfill;
+        int want_low;
+        if (dual) {
+            jfill = (i32)(jb ? y_cm : x_cm);
+            want_low = 1;
+        } else {
+            i32 fill0 = (i32)(x_cm | y_cm);
+            if (stereo) {
+                if (w0 & BW_THETA0) fill0 &= (1 << B) - 1;
+                if (w0 & BW_THETA1) fill0 &= ((1 << B) - 1) << B;
+            }
+            jfill = ch ? fill0 >> B : fill0; // (channel 1 of a stereo band is the side)
+            want_low = !ch;                  // the side never folds (celt.cpp:1709)
+        }
+        cur.w = (int)(aux & 0xffff);
+        const u32 jw = rec_word(cur);
+        int low = -1;
+        if ((w0 & BW_HAS_LOW) && want_low && (jw & JW_NEED_LOW)) {
+            pm_make_lowband(V_IY, (int)(w1 & 2047), N, i, dual && ch, dual_end);
+            low = V_IY;
+        }
+        const u32 cm = recon_band_mono(cur, jw, lcg, tf_change, seed, V_X + 960 * ch + eb0, N, B, low, -1, 0, -1, jfill);
+        if (OG_LANE == 0) P.jcm[2 * i + ch] = (u16)cm;
+        OG_SYNC();
+    }
+}
+
+// E: every stereo merge of the frame (stereo_merge celt.cpp:1113, the sign flip of celt.cpp:1731)
+OG_DEV void pm_stereo_merge(int C) {
+    PmLds &P = PM();
+    if (C != 2) return;
+    OG_SYNC();
+    OG_FOR_LANES(g, PM_GROUPS) { // partial sums of a group of 8
+        const int band = P.binband[g];
+        if (P.bw0[band] & BW_STEREO) {
+            const V8 a = ld8(V_X + 8 * g), b = ld8(V_X + 960 + 8 * g);
+            i32 xp = 0, side = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                xp += mul16(b.v[k], a.v[k]);
+                side += mul16(b.v[k], b.v[k]);
+            }
+            P.part[g][0] = xp;
+            P.part[g][1] = side;
+        }
+    }
+    OG_SYNC();
+    OG_FOR_LANES(band, NBANDS) { // the band's two gains
+        const u32 w0 = P.bw0[band];
+        if (w0 & BW_STEREO) {
+            const int g0 = rom_eband[band], g1 = rom_eband[band + 1];
+            i32 xp = 0, side = 0;
+            for (int g = g0; g < g1; g++) {
+                xp += P.part[g][0];
+                side += P.part[g][1];
+            }
+            const i32 mid = (i32)(i16)(P.bw2[band] & 0xffff);
+            xp = mul16x32_q15(mid, xp);
+            const i32 mid2 = tr16(mid >> 1);
+            const i32 El = mul16(mid2, mid2) + side - 2 * xp, Er = mul16(mid2, mid2) + side + 2 * xp;
+            i32 mode = 1, lgain = 0, rgain = 0;
+            int kl = 0, kr = 0;
+            if (Er < 161061 || El < 161061) // QCONST32(6e-4f, 28): the right channel becomes a copy of the left
+                mode = 2;
+            else {
+                kl = ilog2(El) >> 1;
+                kr = ilog2(Er) >> 1;
+                lgain = rsqrt_norm(vshr32(El, (kl - 7) << 1));
+                rgain = rsqrt_norm(vshr32(Er, (kr - 7) << 1));
+                if (kl < 7) kl = 7;
+                if (kr < 7) kr = 7;
+            }
+            if (w0 & BW_INV) mode |= 4;
+            P.mpar[band][0] = mode | kl << 8 | kr << 16;
+            P.mpar[band][1] = lgain;
+            P.mpar[band][2] = rgain;
+            P.mpar[band][3] = mid;
+        } else
+            P.mpar[band][0] = 0;
+    }
+    OG_SYNC();
+    OG_FOR_LANES(g, PM_GROUPS) {
+        const int band = P.binband[g];
+        const i32 m0 = P.mpar[band][0];
+        if (m0 & 3) {
+            const i32 lgain = P.mpar[band][1], rgain = P.mpar[band][2], mid = P.mpar[band][3];
+            const int kl = (m0 >> 8) & 255, kr = (m0 >> 16) & 255;
+            V8 a = ld8(V_X + 8 * g), b = ld8(V_X + 960 + 8 * g);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                i32 xo, yo;
+                if (m0 & 2) {
+                    xo = a.v[k];
+                    yo = a.v[k];
+                } else {
+                    const i32 l = tr16(mul16_p15(mid, a.v[k])), r = b.v[k];
+                    xo = tr16(pshr32(mul16(lgain, sub16(l, r)), kl + 1));
+                    yo = tr16(pshr32(mul16(rgain, add16(l, r)), kr + 1));
+                }
+                a.v[k] = xo;
+                b.v[k] = (m0 & 4) ? tr16(-yo) : yo;
+            }
+            if (!(m0 & 2)) st8(V_X + 8 * g, a);
+            st8(V_X + 960 + 8 * g, b);
+        }
+    }
+    OG_SYNC();
+}
+
+OG_DEV void recon_all_bands_pm(const ParseRec *rec, const LcgTab &lcg, int C, int shortBlocks, u32 &seed_io) {
+    const int B = shortBlocks ? 8 : 1;
+    u32 fill_lo, fill_hi, seed = seed_io;
+    int dual_end;
+    OG_MARK(3);
+    const u32 tfm = pm_setup_jobs(rec, C, B, fill_lo, fill_hi, dual_end);
+    OG_MARK(8);
+    if (tfm) pm_tf_undo(tfm);
+    if (fill_lo | fill_hi) pm_fill_jobs(rec->words, lcg, fill_lo, fill_hi, C, B, dual_end, seed);
+    OG_MARK(10);
+    pm_stereo_merge(C);
+    OG_MARK(4);
+    OG_FOR_LANES(t, NBANDS * C) { // F: the bands' collapse masks where anti-collapse looks for them
+        const PmLds &P = PM();
+        const int b = t / C, c = t - b * C;
+        const u32 w0 = P.bw0[b];
+        const u32 cm = (w0 & BW_STEREO) ? (u32)P.jcm[2 * b] | (u32)P.jcm[2 * b + 1] : (u32)P.jcm[2 * b + ((w0 & BW_DUAL) ? c : 0)];
+        S.cmask[t] = (u8)cm;
+    }
+    OG_SYNC();
+    seed_io = seed;
+}
+
 // One CELT-only frame, vector half + synthesis + stream bookkeeping (decode_frame_wave's CELT branch).
 // Returns the frame's result code (wave-uniform).  The comb-filtered output goes to the stream's history ring; the
 // last, strictly serial step -- de-emphasis to int16 PCM -- is celt_post_lane's, one (frame, channel) per lane.
@@ -1059,8 +1507,15 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
             S.pulses[i] = rec->pulses[i];
             S.tf_res[i] = rec->tf_res[i];
         }
+        // the phase-major band loop takes every 20 ms frame that starts at band 0 (and whose record did not overflow)
+        const int n_words = OG_UNI(rec->n_words);
+#ifdef OG_NO_PM
+        const bool pm = false;
+#else
+        const bool pm = LM == 3 && start == 0 && n_words < REC_MAX_WORDS && n_leaves < REC_MAX_LEAVES;
+#endif
         OG_FOR_LANES(i, 2 * N) S.v[V_X + i] = 0;
-        OG_FOR_LANES(i, 1248) S.v[V_NORM + i] = 0;
+        if (!pm) OG_FOR_LANES(i, 1248) S.v[V_NORM + i] = 0;
         LcgTab lcg;
         lcg.init();
         OG_SYNC();
@@ -1094,7 +1549,10 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         return ret;
 #endif
         u32 seed = cs->rng;
-        recon_all_bands(rec->words, (u32)OG_UNI(rec->need_norm), lcg, start, end, C, N, transient ? M : 0, LM, seed);
+        if (pm)
+            recon_all_bands_pm(rec, lcg, C, transient ? M : 0, seed);
+        else
+            recon_all_bands(rec->words, (u32)OG_UNI(rec->need_norm), lcg, start, end, C, N, transient ? M : 0, LM, seed);
         OG_MARK(12);
         if (flags & RF_ANTI_COLLAPSE) anti_collapse(LM, C, N, start, end, seed);
         if (silence) {

@@ -3,7 +3,7 @@
 tag=${1:-chk}
 timeout -k 10 600 python -m pytest tests -x -q -m gpu > gpurun_out/t_$tag.log 2>&1; tail -3 gpurun_out/t_$tag.log
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/tr_$tag -o t -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/b_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/tr_$tag -o t -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs > gpurun_out/b_$tag.log 2>&1
 grep "^{" gpurun_out/b_$tag.log | python3 -c "
 import sys, json
 for l in sys.stdin:

@@ -6,7 +6,7 @@ tag=$1; shift
 out=$PWD/gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-args="--steps 3 --warmup 1 --no-cpu-baseline $*"
+args="--steps 3 --warmup 1 --no-cpu-baseline --no-other-configs $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py $args > $out/trace.log 2>&1 || exit 1
 i=0
 for set in \
