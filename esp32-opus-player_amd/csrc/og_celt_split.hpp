@@ -192,9 +192,12 @@ struct RecWriter {
 // In the word stream a job is one header word (JW_*: how many leaves without pulses follow, which PVQ leaves are its
 // own, whether it needs its folding source at all) followed by two words per non-silent leaf without pulses; leaves
 // with pulses only exist in the leaf arrays.  Returns 1 when the job needs the folding source.
+// `silent`: the whole job's fill mask is known to be empty (the mid of a stereo band split at angle 16384, the side of one
+// split at angle 0 -- every band from the intensity band on: celt.cpp:1320-1353 clear that half of the mask), so none of
+// its leaves without pulses is ever filled and none is recorded.
 OG_DEV int parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits, int x, int N, i32 b, int B, int LM, i32 gain,
-                      int has_low) {
-    int depth = 0, off = 0, silent = 0, n_fill = 0;
+                      int has_low, int silent) {
+    int depth = 0, off = 0, n_fill = 0;
     const int jpos = out.reserve(), first_pvq = out.nl;
     for (;;) {
         OG_MARK(41);
@@ -397,7 +400,7 @@ OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C
             out.word(w2);
             out.word((u32)(u16)tr16(celt_sqrt(shl32(N, 22)))); // scale of the folding history (celt.cpp:1617)
             for (int jb = 0; jb < njobs; jb++) {
-                int jx, jlow = has_low;
+                int jx, jlow = has_low, jsilent = 0;
                 i32 jbits, jgain = 32767;
                 if (dual_stereo) {
                     jx = jb ? y : x;
@@ -420,6 +423,7 @@ OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C
                     }
                     jx = is_mid ? x : y;
                     jbits = is_mid ? mbits : sbits;
+                    jsilent = is_mid ? sc.itheta == 16384 : sc.itheta == 0;
                     if (!is_mid) {
                         jgain = sc.iside;
                         jlow = 0; // the side never folds (celt.cpp:1709)
@@ -435,7 +439,7 @@ OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C
                     N_B >>= 1;
                     tfc++;
                 }
-                if (parse_tree(rc, out, i, remaining_bits, jx, N, jbits, Bj, LM, jgain, jlow)) need_norm |= fold_bands;
+                if (parse_tree(rc, out, i, remaining_bits, jx, N, jbits, Bj, LM, jgain, jlow, jsilent)) need_norm |= fold_bands;
             }
         }
         balance += pulses_i + tell;
@@ -1054,7 +1058,7 @@ OG_DEV void recon_all_bands(const u32 *words, u32 need_norm, const LcgTab &lcg, 
 // reference's order carries no dependency.
 struct PmLds { // overlays the folding-history rows S.v[V_NORM ..], which this path never materialises
     u32 jdesc[2 * NBANDS];  // per (band, channel): JD_*
-    u32 jaux[2 * NBANDS];   // per (band, decode slot): word position of the job header | channel << 16 | exists << 17 | fills << 18
+    u32 jaux[2 * NBANDS];   // per (band, decode slot): word position of the job header | channel << 16 | exists << 17 | fills << 18 | has pulses << 19
     u32 bw0[NBANDS], bw1[NBANDS], bw2[NBANDS];
     i32 scale[NBANDS];
     i32 mpar[NBANDS][4];    // stereo merge of the band: mode | kl << 8 | kr << 16, lgain, rgain, mid
@@ -1158,7 +1162,7 @@ OG_DEV u32 pm_setup_jobs(const ParseRec *rec, int C, int B, u32 &fill_lo, u32 &f
         u32 jw = jw0;
         if (jb && exists) jw = rec->words[OG_MIN(jpos, REC_WORDS_CAP - 1)];
         const int n_fill = (int)(jw & 31), n_pvq = (int)(jw >> JW_NPVQ_SHIFT) & 31, first = (int)(jw >> JW_FIRST_SHIFT) & 1023;
-        P.jaux[l] = (u32)jpos | (u32)ch << 16 | (u32)exists << 17 | (u32)(exists && n_fill > 0) << 18;
+        P.jaux[l] = (u32)jpos | (u32)ch << 16 | (u32)exists << 17 | (u32)(exists && n_fill > 0) << 18 | (u32)(n_pvq > 0) << 19;
         if (exists) {
             // the job's time-frequency bookkeeping (quant_band celt.cpp:1548-1580), as in recon_band_mono
             int tf_change = (int)((w0 >> BW_TF_SHIFT) & 7) - 4;
@@ -1325,6 +1329,7 @@ OG_DEV void pm_fill_jobs(const u32 *words, const LcgTab &lcg, u32 fill_lo, u32 f
     for (int l = 0; l < 2 * NBANDS; l++) {
         if (!((l < 32 ? fill_lo >> l : fill_hi >> (l - 32)) & 1u)) continue;
         OG_MARK(5);
+        OG_STAT(20, 1);                             // fill jobs
         const int i = l >> 1, jb = l & 1;
         const u32 aux = (u32)OG_UNI(P.jaux[l]), w0 = (u32)OG_UNI(P.bw0[i]), w1 = (u32)OG_UNI(P.bw1[i]);
         const int ch = (int)(aux >> 16) & 1;
@@ -1355,6 +1360,10 @@ OG_DEV void pm_fill_jobs(const u32 *words, const LcgTab &lcg, u32 fill_lo, u32 f
             }
             jfill = ch ? fill0 >> B : fill0; // (channel 1 of a stereo band is the side)
             want_low = !ch;                  // the side never folds (celt.cpp:1709)
+        }
+        if (jfill == 0 && !(OG_UNI(P.jaux[l]) >> 19 & 1)) { // nothing to fill with and no pulses: the job's spectrum stays zero
+            OG_STAT(24, 1);
+            continue; // (its mask P.jcm is zero from the set-up, the seed does not move: celt.cpp:1481-1520 under `if (fill)`)
         }
         cur.w = (int)(aux & 0xffff);
         const u32 jw = rec_word(cur);
@@ -1457,6 +1466,11 @@ OG_DEV void recon_all_bands_pm(const ParseRec *rec, const LcgTab &lcg, int C, in
     int dual_end;
     OG_MARK(3);
     const u32 tfm = pm_setup_jobs(rec, C, B, fill_lo, fill_hi, dual_end);
+    OG_STAT(0, 1);                                  // frames
+    OG_STAT(19, shortBlocks != 0);                  // transient frames
+    OG_STAT(21, tfm != 0);                          // frames with a time-frequency change to undo in the parallel pass
+    OG_STAT(22, (tfm & 1u) != 0);                   // ... with an interleave among them
+    OG_STAT(23, (fill_lo | fill_hi) != 0);          // frames with fill jobs
     OG_MARK(8);
     if (tfm) pm_tf_undo(tfm);
     if (fill_lo | fill_hi) pm_fill_jobs(rec->words, lcg, fill_lo, fill_hi, C, B, dual_end, seed);

@@ -21,7 +21,7 @@ NAMES = {0: "frames", 19: "transient frames", 13: "bands", 14: "N == 1 bands", 1
          4: "PVQ leaves", 3: "fill leaves", 40: "longest PVQ leaf: coefficients", 41: "longest PVQ leaf: pulses",
          42: "coefficients in PVQ leaves", 44: "PVQ leaves (leaf pass)",
          45: "frames whose longest leaf has >= 96 coefficients", 46: "frames whose longest leaf has >= 144 coefficients",
-         50: "comb filter calls that filter", 51: "... with lag 15", 52: "... with lag 1020..1022", 53: "... with lag 1022", 10: "fill leaves left zero", 11: "fill leaves: noise", 12: "fill leaves: folded"}
+         50: "comb filter calls that filter", 51: "... with lag 15", 52: "... with lag 1020..1022", 53: "... with lag 1022", 20: "fill jobs (phase D)", 24: "... skipped: empty mask, no pulses", 21: "frames with tf work in the parallel pass", 22: "... incl. an interleave", 23: "frames with fill jobs", 10: "fill leaves left zero", 11: "fill leaves: noise", 12: "fill leaves: folded"}
 lib = C.CDLL(sys.argv[1] if len(sys.argv) > 1 else "/tmp/libog_emul_stats.so")
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 8
@@ -40,5 +40,5 @@ for s in range(n):
 st = lib.emu_stats()
 fr = st[0]
 print(f"{fr} CELT-FB stereo frames, 160-byte LCG payloads; per frame:")
-for k in (19, 13, 14, 15, 16, 17, 18, 1, 2, 5, 6, 7, 8, 9, 4, 3, 10, 11, 12, 44, 42, 40, 41, 45, 46, 50, 51, 52, 53):
+for k in (19, 21, 22, 23, 20, 24, 13, 14, 15, 16, 17, 18, 1, 2, 5, 6, 7, 8, 9, 4, 3, 10, 11, 12, 44, 42, 40, 41, 45, 46, 50, 51, 52, 53):
     print(f"  {NAMES[k]:42s} {st[k] / fr:8.2f}")
