@@ -610,12 +610,17 @@ OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, in
     i32 g00 = tr16(mul16_p15(g0, ga0)), g01 = tr16(mul16_p15(g0, ga1)), g02 = tr16(mul16_p15(g0, ga2));
     i32 g10 = tr16(mul16_p15(g1, gb0)), g11 = tr16(mul16_p15(g1, gb1)), g12 = tr16(mul16_p15(g1, gb2));
     int overlap = (g0 == g1 && T0 == T1 && tap0 == tap1) ? 0 : OVERLAP;
-    // every tap of a sample lies >= min(T0, T1) - 2 samples back: that many samples can be filtered without looking
-    // at each other's results (no barrier in between, their history loads overlap)
-    int chunk = OG_MIN(T0, T1) - 2;
+    // Every tap that COUNTS lies >= T - 2 samples back: that many samples can be filtered without looking at each
+    // other's results (no barrier in between, their history loads overlap).  A filter whose gain is zero contributes
+    // exactly zero (its tap gains g?0..g?2 are zero, so is every product), so its lag does not limit the chunk and its
+    // taps are not fetched -- a frame that switches the post-filter on cross-fades from "off" at the minimum lag 15, which
+    // used to cut all 840 samples of the call into chunks of 13.  Past the cross-fade only T1 counts.
+    const bool use0 = g0 != 0, use1 = g1 != 0;
+    const int chunk_fade = OG_MIN(use0 ? T0 : 1 << 20, use1 ? T1 : 1 << 20) - 2, chunk_rest = T1 - 2;
     int end = g1 == 0 ? overlap : N; // with g1 == 0 only the cross-fade part changes the signal
 #ifdef OG_HOST_EMUL
-    for (int base = 0; base < end; base += chunk) {
+    for (int base = 0, chunk; base < end; base += chunk) {
+        chunk = base < overlap ? chunk_fade : chunk_rest;
         OG_SYNC();
         OG_FOR_LANES(l, chunk) {
             const int i = base + l;
@@ -654,7 +659,8 @@ OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, in
         if (idx < 0) in_ring = ring[(ring_pos + idx) & RING_MASK];
         return idx < 0 ? in_ring : in_lds;
     };
-    for (int base = 0; base < end; base += chunk) {
+    for (int base = 0, chunk; base < end; base += chunk) {
+        chunk = base < overlap ? chunk_fade : chunk_rest;
         OG_SYNC();
         const int lim = OG_MIN(chunk, end - base);
         for (int it = 0; it < lim; it += 64) {
@@ -671,12 +677,12 @@ OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, in
                 t3 = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(w, 1), t2, 0x138, 0xf, 0xf, false);
                 t4 = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(w, 0), t3, 0x138, 0xf, 0xf, false);
             };
-            i32 a4, a3, a2, a1, a0;
-            window(T1, a4, a3, a2, a1, a0);
+            i32 a4 = 0, a3 = 0, a2 = 0, a1 = 0, a0 = 0;
+            if (use1) window(T1, a4, a3, a2, a1, a0);
             i32 y;
             if (base + it < overlap) { // (the cross-fade region is a whole number of steps only up to its last step)
-                i32 b4, b3, b2, b1, b0;
-                window(T0, b4, b3, b2, b1, b0);
+                i32 b4 = 0, b3 = 0, b2 = 0, b1 = 0, b0 = 0;
+                if (use0) window(T0, b4, b3, b2, b1, b0);
                 if (i < overlap) {
                     const i32 f = tr16(mul16_q15(rom_win120[i], rom_win120[i]));
                     y = y0 + mul16x32_q15(mul16_q15(32767 - f, g00), b2) + mul16x32_q15(mul16_q15(32767 - f, g01), b1 + b3) +

@@ -580,6 +580,26 @@ OG_DEV void rotate1_lane(int x, int len, int stride, i32 c, i32 s) { // exp_rota
 }
 #endif
 
+// U(a, b) for the leaf pass.  64 lanes walking 64 different leaves ask for 64 unrelated entries per step: from global
+// memory that is one cache line per lane and the texture path serialises them (measured: a third of the walk at best, with
+// the dense table evicted from L1 by the streaming traffic all the time).  Here rows 0..3 are closed forms and rows 4..14
+// sit in LDS in compact form (2.4 KB, rom_pvq_uc; the folding-history rows are not in use during the leaf pass).
+OG_DEV u32 *pvq_tab_lds() { return reinterpret_cast<u32 *>(&S.v[V_NORM]); }
+static_assert(ROM_PVQ_UC_LEN * 4 <= 1248 * 2, "the compact PVQ table overlays the folding-history rows");
+OG_DEV void pvq_tab_load() { // (the caller synchronises)
+    OG_FOR_LANES(t, ROM_PVQ_UC_LEN) pvq_tab_lds()[t] = rom_pvq_uc[t];
+}
+OG_DEV u32 pvq_u_lds(int a, int b) {
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    const int f = lo - 4;
+    const u64 packed = f < 6 ? ROM_PVQ_UC_RB0 : ROM_PVQ_UC_RB1;
+    const int rb = (int)(packed >> (10 * (f < 6 ? (f < 0 ? 0 : f) : f - 6))) & 1023;
+    const u32 tab = pvq_tab_lds()[lo >= 4 ? rb + hi : 0];
+    const u32 h = (u32)hi;
+    const u32 low = lo == 0 ? (u32)(hi == 0) : lo == 1 ? 1u : lo == 2 ? 2u * h - 1u : 2u * h * (h - 1u) + 1u;
+    return lo >= 4 ? tab : low;
+}
+
 OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spread) {
     const int N = n, K = k, x = pos;
     const int logB = ilog2(B), blen = N >> logB; // B is a power of two
@@ -591,7 +611,7 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
     // its lanes takes.  k' == k (a zero) is by far the most common outcome and is tested first; otherwise bisection.
     OG_MARK(56);
     while (n > 2) {
-        const u32 p1 = pvq_u_rom(n, k + 1), p0 = pvq_u_rom(n, k);
+        const u32 p1 = pvq_u_lds(n, k + 1), p0 = pvq_u_lds(n, k);
         const int s = -(int)(i >= p1);
         i -= p1 & (u32)s;
         int val = 0;
@@ -603,7 +623,7 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
             u32 plo = 0;
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
-                const u32 pm = pvq_u_rom(n, mid);
+                const u32 pm = pvq_u_lds(n, mid);
                 if (pm <= i) {
                     lo = mid;
                     plo = pm;
@@ -1528,8 +1548,12 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
 #else
         const bool pm = LM == 3 && start == 0 && n_words < REC_MAX_WORDS && n_leaves < REC_MAX_LEAVES;
 #endif
+#ifdef OG_HOST_EMUL
         OG_FOR_LANES(i, 2 * N) S.v[V_X + i] = 0;
-        if (!pm) OG_FOR_LANES(i, 1248) S.v[V_NORM + i] = 0;
+#else
+        OG_FOR_LANES(i, 2 * N / 8) *reinterpret_cast<og_v4i *>(&S.v[V_X + 8 * i]) = og_v4i{0, 0, 0, 0}; // 16 bytes per lane and store
+#endif
+        pvq_tab_load();
         LcgTab lcg;
         lcg.init();
         OG_SYNC();
@@ -1559,6 +1583,10 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
                                     << (aux >> 16));
         }
         OG_SYNC();
+        if (!pm) { // the band walk starts from an empty folding history (the table above is no longer needed)
+            OG_FOR_LANES(i, 1248) S.v[V_NORM + i] = 0;
+            OG_SYNC();
+        }
 #if defined(OG_RABL) && OG_RABL == 2
         return ret;
 #endif

@@ -95,7 +95,7 @@ constexpr int SYN_LEN = 1088;  // 960 + 120 (+8 pad)
 // i32 IMDCT / output buffer of ONE channel at a time (syn_buf(), og_celt.hpp).  After a channel's synthesis its PCM
 // goes to a half of the (by then dead) X region as a plane of 960 samples.
 struct FrameLds {
-    i16 v[V_TOTAL];
+    alignas(16) i16 v[V_TOTAL];
     u8 pkt[1344];              // packet bytes (<= 1275); the split path keeps its per-leaf collapse masks here
     u32 win[64];               // split path: window of the parse record's word stream
     i32 pulses[NBANDS], fine_quant[NBANDS], fine_prio[NBANDS], tf_res[NBANDS], cap[NBANDS], offsets[NBANDS];
