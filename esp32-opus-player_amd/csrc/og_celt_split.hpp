@@ -583,22 +583,31 @@ OG_DEV void rotate1_lane(int x, int len, int stride, i32 c, i32 s) { // exp_rota
 // U(a, b) for the leaf pass.  64 lanes walking 64 different leaves ask for 64 unrelated entries per step: from global
 // memory that is one cache line per lane and the texture path serialises them (measured: a third of the walk at best, with
 // the dense table evicted from L1 by the streaming traffic all the time).  Here rows 0..3 are closed forms and rows 4..14
-// sit in LDS in compact form (2.4 KB, rom_pvq_uc; the folding-history rows are not in use during the leaf pass).
-OG_DEV u32 *pvq_tab_lds() { return reinterpret_cast<u32 *>(&S.v[V_NORM]); }
-static_assert(ROM_PVQ_UC_LEN * 4 <= 1248 * 2, "the compact PVQ table overlays the folding-history rows");
+// sit in LDS, stored by COLUMN (rom_pvq_cc / rom_pvq_cb, 2.7 KB over the folding-history, pulse and scratch rows, none of
+// which is in use during the leaf pass): cwrsi keeps the dimension n for a whole step and counts it down by one, so the
+// column base of the next step is fetched a step ahead and every candidate of a step lies next to the others.
+struct PvqLds {
+    u32 cc[ROM_PVQ_CC_LEN];
+    u16 cb[177 + 3];
+};
+static_assert(sizeof(PvqLds) <= (V_TOTAL - V_NORM) * 2, "the PVQ table overlays the folding-history, pulse and scratch rows");
+OG_DEV PvqLds &pvq_lds() { return *reinterpret_cast<PvqLds *>(&S.v[V_NORM]); }
 OG_DEV void pvq_tab_load() { // (the caller synchronises)
-    OG_FOR_LANES(t, ROM_PVQ_UC_LEN) pvq_tab_lds()[t] = rom_pvq_uc[t];
+    OG_FOR_LANES(t, ROM_PVQ_CC_LEN) pvq_lds().cc[t] = rom_pvq_cc[t];
+    OG_FOR_LANES(t, 177) pvq_lds().cb[t] = rom_pvq_cb[t];
 }
-OG_DEV u32 pvq_u_lds(int a, int b) {
-    const int lo = a < b ? a : b, hi = a < b ? b : a;
-    const int f = lo - 4;
-    const u64 packed = f < 6 ? ROM_PVQ_UC_RB0 : ROM_PVQ_UC_RB1;
-    const int rb = (int)(packed >> (10 * (f < 6 ? (f < 0 ? 0 : f) : f - 6))) & 1023;
-    const u32 tab = pvq_tab_lds()[lo >= 4 ? rb + hi : 0];
-    const u32 h = (u32)hi;
-    const u32 low = lo == 0 ? (u32)(hi == 0) : lo == 1 ? 1u : lo == 2 ? 2u * h - 1u : 2u * h * (h - 1u) + 1u;
-    return lo >= 4 ? tab : low;
+// U(r, h) for a row r <= 3 (<= h), given U(2, h) and U(3, h); written without branches on purpose: the lanes of a wave
+// ask for different rows, and as control flow every row would cost the wave a pass of its own
+OG_DEV u32 pvq_row_sel(int r, u32 v2, u32 v3) {
+    u32 v = (u32)(r >= 1);
+    v = r == 2 ? v2 : v;
+    return r == 3 ? v3 : v;
 }
+#ifdef OG_HOST_EMUL
+OG_DEV u32 pvq_mul(u32 a, u32 b) { return a * b; }
+#else
+OG_DEV u32 pvq_mul(u32 a, u32 b) { return __umul24(a, b); } // both below 256
+#endif
 
 OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spread) {
     const int N = n, K = k, x = pos;
@@ -607,36 +616,110 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
     // cwrsi celt.cpp:2545.  The reference has two code paths (k >= n: "lots of pulses", k < n: "lots of dimensions")
     // that differ only in how they walk its triangular table; with U(a, b) available for any pair both are
     //   s = (i >= U(n, k+1));  i -= s ? U(n, k+1) : 0;  k' = max { k' <= k : U(n, k') <= i };  value = +-(k - k');  i -= U(n, k')
-    // One formulation matters here: the lanes of a wave decode different leaves, and a wave pays for every path any of
-    // its lanes takes.  k' == k (a zero) is by far the most common outcome and is tested first; otherwise bisection.
+    // The lanes of a wave decode different leaves and the wave waits for its longest one -- a leaf of many dimensions and
+    // few pulses, so what counts is the step that decodes a zero while n > k: there U(n, k) and U(n, k + 1) sit side by side
+    // in column n, the column's base was fetched two steps ago and the two entries one step ago (on the guess that k stays),
+    // so the step is a handful of register operations.  A pulse (k changes) refetches.  Steps with n <= k take the general
+    // form below it.  The spectrum was cleared before the leaf pass: zeros are not stored.
     OG_MARK(56);
+    const PvqLds &T = pvq_lds();
+    int cb_n = T.cb[n], cb_n1 = T.cb[n - 1]; // column bases of n and n - 1
+    u32 t0 = T.cc[k >= 4 ? cb_n + k : 0], t1 = T.cc[k >= 3 ? cb_n + k + 1 : 0]; // U(n, k), U(n, k + 1) where they are table rows
     while (n > 2) {
-        const u32 p1 = pvq_u_lds(n, k + 1), p0 = pvq_u_lds(n, k);
-        const int s = -(int)(i >= p1);
-        i -= p1 & (u32)s;
-        int val = 0;
-        if (p0 <= i && s == 0) {
-            i -= p0;
-        } else {
-            const int k0 = k;
-            int lo = 0, hi = k - 1; // U(n, 0) = 0 <= i; U(n, k) > i here
-            u32 plo = 0;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                const u32 pm = pvq_u_lds(n, mid);
-                if (pm <= i) {
-                    lo = mid;
-                    plo = pm;
-                } else
-                    hi = mid - 1;
+        const int cb_n2 = T.cb[n - 2];
+        const u32 h = (u32)n, v2 = 2u * h - 1u, v3 = 2u * pvq_mul(h, h - 1u) + 1u; // U(2, n), U(3, n)
+#if defined(OG_WALK_ABL) && OG_WALK_ABL >= 3
+        if (true) { S.v[pos] = (i16)(i & 1); yy += 1; } else
+#endif
+        if (n > k) {
+            const u32 nx0 = T.cc[k >= 4 ? cb_n1 + k : 0], nx1 = T.cc[k >= 3 ? cb_n1 + k + 1 : 0]; // the next step's, if k stays
+            const u32 p0 = k >= 4 ? t0 : pvq_row_sel(k, v2, v3), p1 = k >= 3 ? t1 : pvq_row_sel(k + 1, v2, v3);
+            const int s = -(int)(i >= p1);
+            i -= p1 & (u32)s;
+            if (p0 <= i && s == 0) {
+                i -= p0;
+                t0 = nx0;
+                t1 = nx1;
+            } else {
+                // the largest k' < k with U(k', n) <= i: rows k' < k <= n of column n
+                const int k0 = k;
+                u32 plo = 0;
+                int kk = 0;
+#if defined(OG_WALK_ABL) && OG_WALK_ABL >= 2
+                if (true) { kk = k - 1; } else
+#endif
+                if (k <= 8) { // all candidates at once (rows 1..3 computed, rows 4..7 side by side in the column)
+                    const u32 c4 = T.cc[cb_n + 4], c5 = T.cc[cb_n + 5], c6 = T.cc[cb_n + 6], c7 = T.cc[cb_n + 7];
+                    const u32 cand[7] = {1u, v2, v3, c4, c5, c6, c7};
+#pragma unroll
+                    for (int r = 1; r <= 7; r++) {
+                        const bool ok = r < k && cand[r - 1] <= i; // (U(., n) grows with the row: the last `ok` is k')
+                        kk = ok ? r : kk;
+                        plo = ok ? cand[r - 1] : plo;
+                    }
+                } else {
+                    int lo = 0, hi = k - 1; // U(0, n) = 0 <= i; U(k, n) > i here
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        const u32 tm = T.cc[mid >= 4 ? cb_n + mid : 0];
+                        const u32 pm = mid >= 4 ? tm : pvq_row_sel(mid, v2, v3);
+                        if (pm <= i) {
+                            lo = mid;
+                            plo = pm;
+                        } else
+                            hi = mid - 1;
+                    }
+                    kk = lo;
+                }
+                k = kk;
+                i -= plo;
+                const int val = (k0 - k + s) ^ s;
+                S.v[pos] = (i16)val;
+                yy += val * val;
+                t0 = T.cc[k >= 4 ? cb_n1 + k : 0];
+                t1 = T.cc[k >= 3 ? cb_n1 + k + 1 : 0];
             }
-            k = lo;
-            i -= plo;
-            val = (k0 - k + s) ^ s;
+        } else { // n <= k: row n of columns k, k + 1 (and of the columns below them in the search)
+            const u32 hk = (u32)k;
+            const u32 a0 = T.cc[n >= 4 ? T.cb[k] + n : 0], a1 = T.cc[n >= 4 ? T.cb[k + 1] + n : 0];
+            const u32 p0 = n >= 4 ? a0 : pvq_row_sel(n, 2u * hk - 1u, 2u * pvq_mul(hk, hk - 1u) + 1u);
+            const u32 p1 = n >= 4 ? a1 : pvq_row_sel(n, 2u * hk + 1u, 2u * pvq_mul(hk + 1u, hk) + 1u);
+            const int s = -(int)(i >= p1);
+            i -= p1 & (u32)s;
+            if (p0 <= i && s == 0) {
+                i -= p0;
+            } else {
+                const int k0 = k;
+                int lo = 0, hi = k - 1; // U(n, 0) = 0 <= i; U(n, k) > i here
+                u32 plo = 0;
+#if defined(OG_WALK_ABL) && OG_WALK_ABL >= 1 /* timing experiment only (wrong output) */
+                hi = lo = k - 1;
+#endif
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    const int r = n < mid ? n : mid;
+                    const u32 hm = (u32)mid;
+                    const u32 tm = T.cc[r >= 4 ? (n < mid ? T.cb[mid] + n : cb_n + mid) : 0];
+                    const u32 pm = r >= 4 ? tm : (n < mid ? pvq_row_sel(n, 2u * hm - 1u, 2u * pvq_mul(hm, hm - 1u) + 1u) : pvq_row_sel(mid, v2, v3));
+                    if (pm <= i) {
+                        lo = mid;
+                        plo = pm;
+                    } else
+                        hi = mid - 1;
+                }
+                k = lo;
+                i -= plo;
+                const int val = (k0 - k + s) ^ s;
+                S.v[pos] = (i16)val;
+                yy += val * val;
+            }
+            t0 = T.cc[k >= 4 ? cb_n1 + k : 0]; // in case the next step has n - 1 > k
+            t1 = T.cc[k >= 3 ? cb_n1 + k + 1 : 0];
         }
-        S.v[pos++] = (i16)val;
-        yy += val * val;
+        pos++;
         n--;
+        cb_n = cb_n1;
+        cb_n1 = cb_n2;
     }
     {
         const u32 p = 2 * (u32)k + 1;

@@ -68,23 +68,23 @@ def pvq_u_table(rows=15, cols=177):
             U[n][k] = U[n - 1][k] + U[n][k - 1] + U[n - 1][k - 1]
     return [U[n][k] & 0xFFFFFFFF for n in range(rows) for k in range(cols)]
 
-def pvq_u_compact():
-    """Rows 4..14 of U(n,k) (row = min(n,k), entries for max(n,k) from the row number up to the last one that fits 32
-    bits), back to back behind 4 unused words: entry (lo, hi) is at RB(lo) + hi with RB(lo) = offset(lo) - lo + 4 >= 0.
-    Rows 0..3 have closed forms (1 / 2h-1 / 2h(h-1)+1).  Returns (table, [RB(4) .. RB(14)])."""
+def pvq_u_columns():
+    """U(lo, hi) for lo = 4 .. 14 stored by COLUMN hi (lo <= hi <= 176; entries that fit 32 bits), columns back to back behind
+    4 unused words: entry (lo, hi) is at CB[hi] + lo.  A walk that keeps one of its arguments fixed for a step (cwrsi: the
+    dimension n) then needs one base per step, known a step ahead, and finds all its candidates next to each other.
+    Rows 0..3 have closed forms (0 / 1 / 2h-1 / 2h(h-1)+1).  Returns (table, CB[0..176])."""
     cols = 177
     U = [[0] * cols for _ in range(cols)]
     U[0][0] = 1
     for n in range(1, cols):
         for k in range(1, cols):
             U[n][k] = U[n - 1][k] + U[n][k - 1] + U[n - 1][k - 1]
-    tab, rb = [0, 0, 0, 0], []
-    for lo in range(4, 15):
-        mh = max(h for h in range(lo, cols) if U[lo][h] < 2 ** 32)
-        rb.append(len(tab) - lo)
-        tab += [U[lo][h] for h in range(lo, mh + 1)]
-    assert all(0 <= r < 1024 for r in rb)
-    return tab, rb
+    tab, cb = [0, 0, 0, 0], [0] * cols
+    for hi in range(4, cols):
+        cb[hi] = len(tab) - 4
+        tab += [U[lo][hi] for lo in range(4, min(14, hi) + 1) if U[lo][hi] < 2 ** 32]
+    assert max(cb) < 65536
+    return tab, cb
 
 def mdct_trig():
     """cos(2*pi*(i+1/8)/N) in Q15 for N = 1920, 960, 480, 240 (N/2 entries each), concatenated."""
@@ -261,12 +261,11 @@ def build_text():
         for c in range(192):
             u192.append(u[r * 177 + c] if (r < 15 and c < 177) else 0)
     t += emit("rom_pvq_u192", "uint32_t", u192, 8)
-    # compact rows 4..14 for an LDS copy (the split path's leaf pass); row bases packed in 10-bit fields
-    uc, rb = pvq_u_compact()
-    t += "#define ROM_PVQ_UC_LEN %d\n" % len(uc)
-    t += "#define ROM_PVQ_UC_RB0 0x%xULL /* RB(4) .. RB(9), 10 bits each */\n" % sum(v << (10 * i) for i, v in enumerate(rb[:6]))
-    t += "#define ROM_PVQ_UC_RB1 0x%xULL /* RB(10) .. RB(14) */\n" % sum(v << (10 * i) for i, v in enumerate(rb[6:]))
-    t += emit("rom_pvq_uc", "uint32_t", uc, 8)
+    # rows 4..14 by column for an LDS copy (the split path's leaf pass)
+    uc, cb = pvq_u_columns()
+    t += "#define ROM_PVQ_CC_LEN %d\n" % len(uc)
+    t += emit("rom_pvq_cc", "uint32_t", uc, 8)
+    t += emit("rom_pvq_cb", "uint16_t", cb, 16)
     t += emit("rom_band_alloc", "uint8_t", BAND_ALLOC, 21)
     t += emit("rom_eband", "int16_t", EBAND, 22)
     t += emit("rom_logn", "int16_t", LOGN, 21)
