@@ -346,9 +346,12 @@ __global__ void __launch_bounds__(64, 2) k_celt_parse(const FrameDesc *__restric
 }
 
 // Split CELT path, second half: one frame per wave, driven by the parse record.
+// (20 ms CELT-only frames are reconstructed by k_celt_recon_fb, og_recon.hip; `rest_only`: skip what that kernel took)
+extern "C" void og_launch_celt_recon_fb(hipStream_t s, const void *descs, void *streams, const void *recs, void *result, int n,
+                                        int n_streams);
 __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDesc *__restrict__ descs, StreamState *st,
                                                                       const ParseRec *recs, i16 *pcm, i32 *result, int n,
-                                                                      int n_streams, int pcm_stride, int hybrid) {
+                                                                      int n_streams, int pcm_stride, int hybrid, int rest_only) {
     const int f = (int)blockIdx.x;
     if (f >= n) return;
     const FrameDesc d = descs[f];
@@ -358,8 +361,8 @@ __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDe
 #if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE) && !defined(OG_PROF_SPARSE) && !defined(OG_PROF_SSYNTH)
     OG_PROF_INIT();
 #endif
-    const int ret = celt_recon_wave(&st[d.stream], &recs[f], mode, desc_channels(d.flags));
-    if (threadIdx.x == 0) result[f] = ret;
+    const int ret = celt_recon_wave(&st[d.stream], &recs[f], mode, desc_channels(d.flags), rest_only ? RECON_REST_ONLY : RECON_ALL);
+    if (ret != RECON_NOT_MINE && threadIdx.x == 0) result[f] = ret;
 #if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE) && !defined(OG_PROF_SPARSE) && !defined(OG_PROF_SSYNTH)
     OG_PROF_FLUSH();
 #endif
@@ -498,6 +501,7 @@ struct opusgpu_ctx {
     size_t cap_recs = 0, cap_handoff = 0, cap_srecs = 0;
     int split_celt = 1;   // OPUSGPU_SPLIT=0 forces the single-kernel path for every mode (A/B measurements)
     int split_hybrid = 1; // OPUSGPU_SPLIT_HYBRID=0 keeps SILK-only and hybrid frames entirely on the single-kernel path
+    int fast_recon = 1;   // OPUSGPU_FAST_RECON=0: every CELT frame through the general reconstruction kernel (A/B measurements)
     char err[256] = {0};
 };
 
@@ -548,6 +552,7 @@ int opusgpu_ctx_create(int device, opusgpu_ctx **out) {
     ctx->device = device;
     if (const char *e = getenv("OPUSGPU_SPLIT")) ctx->split_celt = e[0] != '0';
     if (const char *e = getenv("OPUSGPU_SPLIT_HYBRID")) ctx->split_hybrid = e[0] != '0';
+    if (const char *e = getenv("OPUSGPU_FAST_RECON")) ctx->fast_recon = e[0] != '0';
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return OPUSGPU_ERR_HIP;
@@ -698,9 +703,11 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
     }
     if (ctx->split_celt) {
         // reconstruct (one frame per wave) -> de-emphasis, SILK mix and PCM (one (frame, channel) per lane)
+        if (ctx->fast_recon)
+            og_launch_celt_recon_fb(s, d_descs, ctx->d_streams, ctx->d_recs, d_result, n, ctx->n_streams);
         hipLaunchKernelGGL(k_celt_recon, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, ctx->d_streams,
                            (const ParseRec *)ctx->d_recs, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride,
-                           handoff ? 1 : 0);
+                           handoff ? 1 : 0, ctx->fast_recon);
         hipLaunchKernelGGL(k_celt_post, dim3((n * ctx->channels + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs,
                            ctx->d_streams, (const ParseRec *)ctx->d_recs, (const i32 *)d_result, (i16 *)d_pcm, n, ctx->n_streams,
                            ctx->channels, pcm_stride, (const SilkHandoff *)handoff);
@@ -718,8 +725,12 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
 
 #ifdef OG_PROF
 // profiling builds only: per-section wave-cycle totals of k_celt_recon (see OG_MARK), optionally cleared after the read
+extern "C" int og_recon_fb_prof(unsigned long long *out64, int reset);
 int opusgpu_debug_prof(unsigned long long *out64, int reset) {
+    unsigned long long fb[64];
+    if (og_recon_fb_prof(fb, reset) != 0) return -1;
     if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    for (int i = 0; i < 64; i++) out64[i] += fb[i];
     if (reset) {
         unsigned long long z[64] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -1;

@@ -20,7 +20,7 @@ namespace og {
 // lane-private (one frame per LANE in the parse kernel, og_celt_parse.hpp).
 struct WaveArr {
     typedef RomGlobal Rom;
-    OG_MEMBER i32 &pulses(int i) const { return S.pulses[i]; }
+    OG_MEMBER i32 &pulses(int i) const { return S.pulses_row()[i]; }
     OG_MEMBER i32 &fine_quant(int i) const { return S.fine_quant[i]; }
     OG_MEMBER i32 &fine_prio(int i) const { return S.fine_prio[i]; }
     OG_MEMBER i32 &tf_res(int i) const { return S.tf_res[i]; }
@@ -28,7 +28,7 @@ struct WaveArr {
     OG_MEMBER i32 &offsets(int i) const { return S.offsets[i]; }
     OG_MEMBER i32 &bits1(int i) const { return S.bits1[i]; }
     OG_MEMBER i32 &bits2(int i) const { return S.bits2[i]; }
-    OG_MEMBER i16 &bandE(int i) const { return S.bandE[i]; }
+    OG_MEMBER i16 &bandE(int i) const { return S.bandE_row()[i]; }
 };
 
 // ---- energies (src/celt.cpp:3613-3700) ------------------------------------------------------------
@@ -339,7 +339,7 @@ OG_DEV void denorm_gains(int start, int end, int C, int silence) {
         int c = id / NBANDS, i = id - c * NBANDS;
         i32 g = 0, shift = 0;
         if (!silence && i >= start && i < end) {
-            i32 lg = sat16((i32)S.bandE[c * NBANDS + i] + shl32((i32)rom_emeans[i], 6));
+            i32 lg = sat16((i32)S.bandE_row()[c * NBANDS + i] + shl32((i32)rom_emeans[i], 6));
             shift = 16 - (lg >> 10);
             if (shift > 31) {
                 shift = 0;
@@ -351,13 +351,13 @@ OG_DEV void denorm_gains(int start, int end, int C, int silence) {
                 shift = -2;
             }
         }
-        S.dn_g[id] = (i16)g;
-        S.dn_shift[id] = (i16)shift;
+        S.dn_g_row()[id] = (i16)g;
+        S.dn_shift_row()[id] = (i16)shift;
     }
     OG_FOR_LANES(bin, 100) { // 5 ms bin -> band
         int b = 0;
         while (rom_eband[b + 1] <= bin) b++;
-        S.bin2band[bin] = (u8)b;
+        S.bin2band_row()[bin] = (u8)b;
     }
     OG_SYNC();
 }
@@ -366,8 +366,8 @@ OG_DEV void denorm_gains(int start, int end, int C, int silence) {
 OG_DEV i32 freq_coded(int c, int j, int N, int LM) {
     int bin = j >> LM;
     if (bin >= 100) return 0;
-    int band = S.bin2band[bin];
-    i32 g = S.dn_g[c * NBANDS + band], sh = S.dn_shift[c * NBANDS + band];
+    int band = S.bin2band_row()[bin];
+    i32 g = S.dn_g_row()[c * NBANDS + band], sh = S.dn_shift_row()[c * NBANDS + band];
     i32 p = mul16(S.v[V_X + c * N + j], g);
     return sh < 0 ? shl32(p, -sh) : p >> sh;
 }
@@ -513,8 +513,9 @@ OG_DEV const i16 *bitrev_for(int shift) {
     return shift == 0 ? rom_bitrev480 : shift == 1 ? rom_bitrev240 : shift == 2 ? rom_bitrev120 : rom_bitrev60;
 }
 
-// The i32 synthesis buffer of the channel being synthesised (overlays norm | iy | tmp | pkt, see og_state.hpp).
-OG_DEV i32 *syn_buf() { return reinterpret_cast<i32 *>(&S.v[V_NORM]); }
+// The i32 synthesis buffer of the channel being synthesised (overlays norm | iy | tmp | pkt -- in the reconstruction
+// kernel's 8 KB layout the second channel's spectrum and what follows X; see og_state.hpp).
+OG_DEV i32 *syn_buf() { return reinterpret_cast<i32 *>(&S.v[V_SYN]); }
 // Where channel co's PCM plane (960 x i16) goes inside the dead X region: the half this and later channels no longer read.
 OG_DEV int pcm_plane(int co, int C, int CC) { return V_X + 960 * ((C == 1 && CC == 2) ? 1 - co : co); }
 
@@ -532,13 +533,64 @@ OG_DEV void pcm_store(i16 *pcm, int n, int C, int CC) {
 
 // Inverse MDCT of every block of one output channel (clt_mdct_backward celt.cpp:3204), reading
 // the denormalised coefficients on the fly.  B blocks of NBk = N/B outputs, transform size 2*NBk.
-OG_DEVN void imdct_channel(int co, int N, int LM, int B, int shift, int C, int CC) {
+OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int shift, int C, int CC) {
     const int NBk = N / B, N2 = NBk, N4 = N2 >> 1;
     const i16 *trig = rom_mdct_trig + (shift == 0 ? 0 : shift == 1 ? 960 : shift == 2 ? 1440 : 1680);
     const i16 *br = bitrev_for(shift);
     i32 *const SY = syn_buf();
     {
         OG_SYNC();
+#ifdef OG_RECON_TIGHT
+        // The buffer starts inside X, over the second channel's spectrum (og_state.hpp).  A channel that reads that spectrum
+        // has every coefficient read, and rotated, before the first word of the buffer is written: 480 rotations, 8 per lane,
+        // held in registers across the barrier.  The other channel (synthesised second) reads what the buffer does not touch.
+        const bool reads_buffer = (C == 2 && (co == 1 || CC == 1));
+        if (!reads_buffer) {
+            OG_FOR_LANES(id, B * N4) {
+                int b = id / N4, i = id - b * N4;
+                i32 x1 = freq_out(co, b + B * (2 * i), N, LM, C, CC);
+                i32 x2 = freq_out(co, b + B * (N2 - 1 - 2 * i), N, LM, C, CC);
+                i32 t0 = trig[i], t1 = trig[N4 + i];
+                i32 yr = addw(OG_SMUL(x2, t0), OG_SMUL(x1, t1));
+                i32 yi = subw(OG_SMUL(x1, t0), OG_SMUL(x2, t1));
+                i32 *yp = &SY[NBk * b + (OVERLAP >> 1)];
+                int rev = br[i];
+                yp[2 * rev + 1] = yr;
+                yp[2 * rev] = yi;
+            }
+            OG_FOR_LANES(i, OVERLAP / 2) SY[i] = tail[i];
+        } else {
+        constexpr int NR = (480 + OG_NLANES - 1) / OG_NLANES;
+        i32 hr[NR], hi[NR];
+#pragma unroll
+        for (int it = 0; it < NR; it++) {
+            const int id = OG_LANE + it * OG_NLANES;
+            hr[it] = hi[it] = 0;
+            if (id < B * N4) {
+                int b = id / N4, i = id - b * N4;
+                i32 x1 = freq_out(co, b + B * (2 * i), N, LM, C, CC);
+                i32 x2 = freq_out(co, b + B * (N2 - 1 - 2 * i), N, LM, C, CC);
+                i32 t0 = trig[i], t1 = trig[N4 + i];
+                hr[it] = addw(OG_SMUL(x2, t0), OG_SMUL(x1, t1));
+                hi[it] = subw(OG_SMUL(x1, t0), OG_SMUL(x2, t1));
+            }
+        }
+        OG_SYNC();
+#pragma unroll
+        for (int it = 0; it < NR; it++) {
+            const int id = OG_LANE + it * OG_NLANES;
+            if (id < B * N4) {
+                int b = id / N4, i = id - b * N4;
+                i32 *yp = &SY[NBk * b + (OVERLAP >> 1)];
+                int rev = br[i];
+                yp[2 * rev + 1] = hr[it];
+                yp[2 * rev] = hi[it];
+            }
+        }
+        OG_FOR_LANES(i, OVERLAP / 2) SY[i] = tail[i];
+        }
+#else
+        OG_FOR_LANES(i, OVERLAP / 2) SY[i] = tail[i];
         OG_FOR_LANES(id, B * N4) { // pre-rotation into digit-reversed order
             int b = id / N4, i = id - b * N4;
             i32 x1 = freq_out(co, b + B * (2 * i), N, LM, C, CC);
@@ -551,6 +603,7 @@ OG_DEVN void imdct_channel(int co, int N, int LM, int B, int shift, int C, int C
             yp[2 * rev + 1] = yr;
             yp[2 * rev] = yi;
         }
+#endif
         fft_blocks(&SY[OVERLAP >> 1], B, NBk, shift);
         OG_FOR_LANES(id, B * (N4 >> 1)) { // post-rotation, pairs (i, N4-1-i)
             int b = id / (N4 >> 1), i = id - b * (N4 >> 1);
@@ -981,12 +1034,12 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
     // ---- energy history (celt.cpp:2404-2436)
     OG_SYNC();
     if (C == 1) {
-        OG_FOR_LANES(i, NBANDS) S.bandE[NBANDS + i] = S.bandE[i];
+        OG_FOR_LANES(i, NBANDS) S.bandE_row()[NBANDS + i] = S.bandE_row()[i];
         OG_SYNC();
     }
     OG_FOR_LANES(i, 2 * NBANDS) {
         int band = i >= NBANDS ? i - NBANDS : i;
-        i32 e = S.bandE[i], l1 = S.logE1[i], l2 = S.logE2[i];
+        i32 e = S.bandE_row()[i], l1 = S.logE1_row()[i], l2 = S.logE2_row()[i];
         if (!transient) {
             l2 = l1;
             l1 = e;
@@ -1007,11 +1060,15 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
     const int pos = st->ring_pos;
     i32 *const SY = syn_buf();
     // ---- one output channel at a time through the single synthesis buffer
+    // (the 8 KB layout synthesises the second channel first: its spectrum lies where the buffer starts)
+#ifdef OG_RECON_TIGHT
+    for (int c = CC - 1; c >= 0; c--) {
+#else
     for (int c = 0; c < CC; c++) {
+#endif
         OG_SYNC();
         OG_MARK(14);
-        OG_FOR_LANES(i, OVERLAP / 2) SY[i] = st->tail[c][i];
-        imdct_channel(c, N, LM, B, shift, C, CC);
+        imdct_channel(st->tail[c], c, N, LM, B, shift, C, CC);
         OG_MARK(15);
         OG_TAP(2 + 16 * c); // IMDCT output
 #if !(defined(OG_ABLATE) && OG_ABLATE == 3)
@@ -1076,13 +1133,13 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
     // ---- stage persistent scalars in LDS
     OG_SYNC();
     OG_FOR_LANES(i, 2 * NBANDS) {
-        S.bandE[i] = st->bandE[i];
-        S.logE1[i] = st->logE1[i];
-        S.logE2[i] = st->logE2[i];
+        S.bandE_row()[i] = st->bandE[i];
+        S.logE1_row()[i] = st->logE1[i];
+        S.logE2_row()[i] = st->logE2[i];
     }
-    OG_FOR_LANES(i, 2 * NBANDS) S.cmask[i] = 0;
+    OG_FOR_LANES(i, 2 * NBANDS) S.cmask_row()[i] = 0;
     OG_FOR_LANES(i, NBANDS) {
-        S.pulses[i] = 0;
+        S.pulses_row()[i] = 0;
         S.fine_quant[i] = 0;
         S.fine_prio[i] = 0;
         S.offsets[i] = 0;
@@ -1091,7 +1148,7 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
     OG_FOR_LANES(i, 1248) S.v[V_NORM + i] = 0;
     OG_SYNC();
     if (C == 1) {
-        OG_FOR_LANES(i, NBANDS) S.bandE[i] = OG_MAX(S.bandE[i], S.bandE[NBANDS + i]);
+        OG_FOR_LANES(i, NBANDS) S.bandE_row()[i] = OG_MAX(S.bandE_row()[i], S.bandE_row()[NBANDS + i]);
         OG_SYNC();
     }
 
@@ -1112,7 +1169,7 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
     energy_finalise(WaveArr(), rc, start, end, (i32)rc.storage * 8 - rc_tell(rc), C);
     if (anti_collapse_on) anti_collapse(LM, C, N, start, end, seed);
     if (silence)
-        for (int i = 0; i < C * NBANDS; i++) S.bandE[i] = (i16)(-28 * 1024);
+        for (int i = 0; i < C * NBANDS; i++) S.bandE_row()[i] = (i16)(-28 * 1024);
 
     OG_TAP(1); // X and bandE final
 #if defined(OG_ABLATE) && OG_ABLATE == 2

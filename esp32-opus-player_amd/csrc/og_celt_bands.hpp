@@ -628,7 +628,7 @@ OG_DEV void decode_all_bands(Rc &rc, int start, int end, int C, int N_ch, int sh
         i32 tell = (i32)rc_tell_frac(rc);
         if (i != start) balance -= tell;
         i32 remaining_bits = total_bits - tell - 1, b;
-        const i32 pulses_i = OG_UNI(S.pulses[i]);
+        const i32 pulses_i = OG_UNI(S.pulses_row()[i]);
         if (i <= codedBands - 1) {
             i32 curr_balance = balance / OG_MIN(3, codedBands - i);
             b = OG_MAX(0, OG_MIN(16383, OG_MIN(remaining_bits + 1, pulses_i + curr_balance)));
@@ -660,8 +660,8 @@ OG_DEV void decode_all_bands(Rc &rc, int start, int end, int C, int N_ch, int sh
             x_cm = y_cm = 0;
             int fold_i = fold_start;
             do {
-                x_cm |= (u32)OG_UNI(S.cmask[fold_i * C + 0]);
-                y_cm |= (u32)OG_UNI(S.cmask[fold_i * C + C - 1]);
+                x_cm |= (u32)OG_UNI(S.cmask_row()[fold_i * C + 0]);
+                y_cm |= (u32)OG_UNI(S.cmask_row()[fold_i * C + C - 1]);
             } while (++fold_i < fold_end);
         } else
             x_cm = y_cm = (1u << B) - 1;
@@ -782,8 +782,8 @@ OG_DEV void decode_all_bands(Rc &rc, int start, int end, int C, int N_ch, int sh
             } else
                 x_cm = y_cm = cm0;
         }
-        S.cmask[i * C + 0] = (u8)x_cm;
-        S.cmask[i * C + C - 1] = (u8)y_cm;
+        S.cmask_row()[i * C + 0] = (u8)x_cm;
+        S.cmask_row()[i * C + C - 1] = (u8)y_cm;
         balance += pulses_i + tell;
         update_lowband = b > (N << BITRES);
     }
@@ -795,7 +795,7 @@ OG_DEV void decode_all_bands(Rc &rc, int start, int end, int C, int N_ch, int sh
 OG_DEV void anti_collapse(int LM, int C, int size, int start, int end, u32 seed) {
     for (int i = start; i < end; i++) {
         int N0 = rom_eband[i + 1] - rom_eband[i];
-        int depth = (int)(udiv((u32)(1 + S.pulses[i]), (u32)N0) >> LM);
+        int depth = (int)(udiv((u32)(1 + S.pulses_row()[i]), (u32)N0) >> LM);
         i32 thresh32 = celt_exp2(-shl16(depth, 10 - BITRES)) >> 1;
         i32 thresh = tr16(mul16x32_q15(16384, OG_MIN(32767, thresh32)));
         i32 t = N0 << LM;
@@ -803,12 +803,12 @@ OG_DEV void anti_collapse(int LM, int C, int size, int start, int end, u32 seed)
         t = shl32(t, (7 - shift) << 1);
         i32 sqrt_1 = rsqrt_norm(t);
         for (int c = 0; c < C; c++) {
-            i32 prev1 = S.logE1[c * NBANDS + i], prev2 = S.logE2[c * NBANDS + i];
+            i32 prev1 = S.logE1_row()[c * NBANDS + i], prev2 = S.logE2_row()[c * NBANDS + i];
             if (C == 1) {
-                prev1 = OG_MAX(prev1, (i32)S.logE1[NBANDS + i]);
-                prev2 = OG_MAX(prev2, (i32)S.logE2[NBANDS + i]);
+                prev1 = OG_MAX(prev1, (i32)S.logE1_row()[NBANDS + i]);
+                prev2 = OG_MAX(prev2, (i32)S.logE2_row()[NBANDS + i]);
             }
-            i32 Ediff = (i32)S.bandE[c * NBANDS + i] - OG_MIN(prev1, prev2);
+            i32 Ediff = (i32)S.bandE_row()[c * NBANDS + i] - OG_MIN(prev1, prev2);
             Ediff = OG_MAX(0, Ediff);
             i32 r;
             if (Ediff < 16384) {
@@ -821,7 +821,7 @@ OG_DEV void anti_collapse(int LM, int C, int size, int start, int end, u32 seed)
             r = tr16(mul16_q15(sqrt_1, r) >> shift);
             int x = V_X + c * size + (rom_eband[i] << LM);
             int renorm = 0;
-            u32 mask = S.cmask[i * C + c];
+            u32 mask = S.cmask_row()[i * C + c];
             for (int k = 0; k < 1 << LM; k++) {
                 if (!(mask & (1u << k))) {
                     OG_SYNC();

@@ -588,9 +588,13 @@ OG_DEV void rotate1_lane(int x, int len, int stride, i32 c, i32 s) { // exp_rota
 // column base of the next step is fetched a step ahead and every candidate of a step lies next to the others.
 struct PvqLds {
     u32 cc[ROM_PVQ_CC_LEN];
-    u16 cb[177 + 3];
+    u16 cb[177 + 1];
 };
+#ifdef OG_RECON_TIGHT
+static_assert(sizeof(PvqLds) <= (V_MASK - V_NORM) * 2, "the PVQ table overlays the band loop's tables and scratch rows");
+#else
 static_assert(sizeof(PvqLds) <= (V_TOTAL - V_NORM) * 2, "the PVQ table overlays the folding-history, pulse and scratch rows");
+#endif
 OG_DEV PvqLds &pvq_lds() { return *reinterpret_cast<PvqLds *>(&S.v[V_NORM]); }
 OG_DEV void pvq_tab_load() { // (the caller synchronises)
     OG_FOR_LANES(t, ROM_PVQ_CC_LEN) pvq_lds().cc[t] = rom_pvq_cc[t];
@@ -773,8 +777,8 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
 }
 
 // Collapse masks of the frame's PVQ leaves, in decode order (LDS: the packet staging area is unused on this path).
-OG_DEV u16 *leaf_masks() { return reinterpret_cast<u16 *>(&S.pkt[0]); }
-static_assert(sizeof(FrameLds::pkt) >= sizeof(u16) * REC_MAX_LEAVES, "leaf masks must fit the packet buffer");
+OG_DEV u16 *leaf_masks() { return S.leaf_mask_row(); } // room for MAX_LEAF_MASKS (og_state.hpp)
+static_assert(MAX_LEAF_MASKS <= REC_MAX_LEAVES, "leaf mask row");
 
 // The record's word stream is consumed strictly in order: a 64-word window in LDS, refilled by one coalesced load.
 constexpr int REC_WORDS_CAP = (REC_MAX_WORDS + 64) / 64 * 64; // size of ParseRec::words
@@ -785,11 +789,11 @@ struct RecCur { // read positions in the record: next word, first word of the wi
 OG_DEV u32 rec_word(RecCur &cur) {
     if ((unsigned)(cur.w - cur.base) >= 64u) { // the window moves to the word wanted (the sequential walk: every 64 words)
         OG_SYNC();
-        OG_FOR_LANES(l, 64) S.win[l] = cur.words[OG_MIN(cur.w + l, REC_WORDS_CAP - 1)];
+        OG_FOR_LANES(l, 64) S.word_window()[l] = cur.words[OG_MIN(cur.w + l, REC_WORDS_CAP - 1)];
         OG_SYNC();
         cur.base = cur.w;
     }
-    const u32 w = (u32)OG_UNI(S.win[cur.w - cur.base]);
+    const u32 w = (u32)OG_UNI(S.word_window()[cur.w - cur.base]);
     cur.w++;
     return w;
 }
@@ -799,7 +803,8 @@ OG_DEV u32 rec_word(RecCur &cur) {
 OG_DEV void rec_word4(RecCur &cur, u32 &w0, u32 &w1, u32 &w2, u32 &w3) {
     const int at = cur.w - cur.base;
     if (at >= 0 && at <= 60) {
-        const u32 a = S.win[at], b = S.win[at + 1], c = S.win[at + 2], d = S.win[at + 3];
+        const u32 *win = S.word_window();
+        const u32 a = win[at], b = win[at + 1], c = win[at + 2], d = win[at + 3];
         w0 = (u32)OG_UNI(a);
         w1 = (u32)OG_UNI(b);
         w2 = (u32)OG_UNI(c);
@@ -1036,8 +1041,8 @@ OG_DEV void recon_all_bands(const u32 *words, u32 need_norm, const LcgTab &lcg, 
             int fold_i = (int)(w0 >> BW_FOLD0_SHIFT) & 31;
             x_cm = y_cm = 0;
             do {
-                x_cm |= (u32)OG_UNI(S.cmask[fold_i * C + 0]);
-                y_cm |= (u32)OG_UNI(S.cmask[fold_i * C + C - 1]);
+                x_cm |= (u32)OG_UNI(S.cmask_row()[fold_i * C + 0]);
+                y_cm |= (u32)OG_UNI(S.cmask_row()[fold_i * C + C - 1]);
             } while (++fold_i < fold_end);
         } else
             x_cm = y_cm = (1u << B) - 1;
@@ -1132,8 +1137,8 @@ OG_DEV void recon_all_bands(const u32 *words, u32 need_norm, const LcgTab &lcg, 
             } else
                 x_cm = y_cm = cm0;
         }
-        S.cmask[i * C + 0] = (u8)x_cm;
-        S.cmask[i * C + C - 1] = (u8)y_cm;
+        S.cmask_row()[i * C + 0] = (u8)x_cm;
+        S.cmask_row()[i * C + C - 1] = (u8)y_cm;
     }
     seed_io = seed;
 }
@@ -1164,13 +1169,20 @@ struct PmLds { // overlays the folding-history rows S.v[V_NORM ..], which this p
     u32 jaux[2 * NBANDS];   // per (band, decode slot): word position of the job header | channel << 16 | exists << 17 | fills << 18 | has pulses << 19
     u32 bw0[NBANDS], bw1[NBANDS], bw2[NBANDS];
     i32 scale[NBANDS];
-    i32 mpar[NBANDS][4];    // stereo merge of the band: mode | kl << 8 | kr << 16, lgain, rgain, mid
-    i32 part[100][2];       // per group of 8 coefficients: sum y*x, sum y*y
+    u32 mpar[NBANDS][2];    // stereo merge of the band: mode | kl << 8 | kr << 16, lgain | rgain << 16 (the mid gain is in bw2)
     u16 jcm[2 * NBANDS];    // per (band, channel): the job's collapse mask
     u8 binband[100], binoff[100]; // 5 ms bin (= group of 8 coefficients; 100 of them are coded) -> band, group index within the band
 };
-static_assert(sizeof(PmLds) <= sizeof(i16) * 1248, "the phase-major tables overlay the folding-history rows");
+#ifdef OG_RECON_TIGHT
+constexpr int V_PART = V_IY; // the stereo merges' partial sums take the two scratch rows (the fill jobs are done by then)
+static_assert(sizeof(PmLds) <= sizeof(i16) * (V_IY - V_NORM) && 800 <= sizeof(i16) * (V_MASK - V_IY), "the phase-major tables");
+#else
+constexpr int V_PART = V_NORM + 600;
+static_assert(sizeof(PmLds) <= sizeof(i16) * 600 && 600 + 400 <= 1248, "the phase-major tables overlay the folding-history rows");
+#endif
 OG_DEV PmLds &PM() { return *reinterpret_cast<PmLds *>(&S.v[V_NORM]); }
+typedef i32 PmPart[2]; // per group of 8 coefficients: sum y*x, sum y*y
+OG_DEV PmPart *pm_part() { return reinterpret_cast<PmPart *>(&S.v[V_PART]); }
 
 enum { // PmLds::jdesc
     JD_VALID = 1, JD_FILL = 2,          // the job exists / has a leaf without pulses (phase D does everything for it)
@@ -1496,8 +1508,8 @@ OG_DEV void pm_stereo_merge(int C) {
                 xp += mul16(b.v[k], a.v[k]);
                 side += mul16(b.v[k], b.v[k]);
             }
-            P.part[g][0] = xp;
-            P.part[g][1] = side;
+            pm_part()[g][0] = xp;
+            pm_part()[g][1] = side;
         }
     }
     OG_SYNC();
@@ -1507,8 +1519,8 @@ OG_DEV void pm_stereo_merge(int C) {
             const int g0 = rom_eband[band], g1 = rom_eband[band + 1];
             i32 xp = 0, side = 0;
             for (int g = g0; g < g1; g++) {
-                xp += P.part[g][0];
-                side += P.part[g][1];
+                xp += pm_part()[g][0];
+                side += pm_part()[g][1];
             }
             const i32 mid = (i32)(i16)(P.bw2[band] & 0xffff);
             xp = mul16x32_q15(mid, xp);
@@ -1527,19 +1539,18 @@ OG_DEV void pm_stereo_merge(int C) {
                 if (kr < 7) kr = 7;
             }
             if (w0 & BW_INV) mode |= 4;
-            P.mpar[band][0] = mode | kl << 8 | kr << 16;
-            P.mpar[band][1] = lgain;
-            P.mpar[band][2] = rgain;
-            P.mpar[band][3] = mid;
+            P.mpar[band][0] = (u32)(mode | kl << 8 | kr << 16);
+            P.mpar[band][1] = ((u32)lgain & 0xffffu) | (u32)rgain << 16;
         } else
-            P.mpar[band][0] = 0;
+            P.mpar[band][0] = 0u;
     }
     OG_SYNC();
     OG_FOR_LANES(g, PM_GROUPS) {
         const int band = P.binband[g];
-        const i32 m0 = P.mpar[band][0];
+        const i32 m0 = (i32)P.mpar[band][0];
         if (m0 & 3) {
-            const i32 lgain = P.mpar[band][1], rgain = P.mpar[band][2], mid = P.mpar[band][3];
+            const u32 m1 = P.mpar[band][1];
+            const i32 lgain = (i32)(i16)(m1 & 0xffff), rgain = (i32)m1 >> 16, mid = (i32)(i16)(P.bw2[band] & 0xffff);
             const int kl = (m0 >> 8) & 255, kr = (m0 >> 16) & 255;
             V8 a = ld8(V_X + 8 * g), b = ld8(V_X + 960 + 8 * g);
 #pragma unroll
@@ -1585,7 +1596,7 @@ OG_DEV void recon_all_bands_pm(const ParseRec *rec, const LcgTab &lcg, int C, in
         const int b = t / C, c = t - b * C;
         const u32 w0 = P.bw0[b];
         const u32 cm = (w0 & BW_STEREO) ? (u32)P.jcm[2 * b] | (u32)P.jcm[2 * b + 1] : (u32)P.jcm[2 * b + ((w0 & BW_DUAL) ? c : 0)];
-        S.cmask[t] = (u8)cm;
+        S.cmask_row()[t] = (u8)cm;
     }
     OG_SYNC();
     seed_io = seed;
@@ -1594,10 +1605,24 @@ OG_DEV void recon_all_bands_pm(const ParseRec *rec, const LcgTab &lcg, int C, in
 // One CELT-only frame, vector half + synthesis + stream bookkeeping (decode_frame_wave's CELT branch).
 // Returns the frame's result code (wave-uniform).  The comb-filtered output goes to the stream's history ring; the
 // last, strictly serial step -- de-emphasis to int16 PCM -- is celt_post_lane's, one (frame, channel) per lane.
-OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int ch) {
+// Which reconstruction kernel takes a frame: 20 ms frames that start at band 0 and whose record is complete go to the
+// kernel with the 8 KB working set (og_recon.hip, phase-major band loop only), everything else -- the CELT half of hybrid
+// frames, the 2.5 ms transition frame, records that overflowed -- to the general one.
+constexpr int FAST_MAX_LEAVES = 416; // (og_state.hpp: the most a 20 ms frame can have)
+enum { RECON_ALL = 0, RECON_FAST_ONLY = 1, RECON_REST_ONLY = 2, RECON_NOT_MINE = -1000 };
+OG_DEV bool recon_fast_eligible(const ParseRec *rec) {
+    const u32 flags = (u32)OG_UNI(rec->flags);
+    if (flags & (RF_SKIP | RF_BAD_CELT)) return false;
+    return ((flags >> RF_LM_SHIFT) & 3) == 3 && OG_UNI(rec->start) == 0 && OG_UNI(rec->n_words) < REC_MAX_WORDS &&
+           OG_UNI(rec->n_leaves) <= FAST_MAX_LEAVES;
+}
+
+OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int ch, int role = RECON_ALL) {
     const u32 flags = (u32)OG_UNI(rec->flags);
     const int ret = OG_UNI(rec->ret);
-    if (flags & RF_SKIP) return ret;
+    if (flags & RF_SKIP) return role == RECON_FAST_ONLY ? (int)RECON_NOT_MINE : ret;
+    const bool fast = recon_fast_eligible(rec);
+    if ((role == RECON_FAST_ONLY && !fast) || (role == RECON_REST_ONLY && fast)) return RECON_NOT_MINE;
     const int CC = st->channels, C = ch, prev_mode = st->prev_mode;
     if (mode != prev_mode && prev_mode > 0) {
         celt_reset_state(&st->celt);
@@ -1614,22 +1639,23 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         // ---- stage the record's header arrays and the persistent scalars
         OG_MARK(1);
         OG_SYNC();
+#ifndef OG_RECON_TIGHT
         OG_FOR_LANES(i, 2 * NBANDS) {
-            S.bandE[i] = rec->bandE[i];
-            S.logE1[i] = cs->logE1[i];
-            S.logE2[i] = cs->logE2[i];
-            S.cmask[i] = 0;
+            S.bandE_row()[i] = rec->bandE[i];
+            S.logE1_row()[i] = cs->logE1[i];
+            S.logE2_row()[i] = cs->logE2[i];
+            S.cmask_row()[i] = 0;
         }
         OG_FOR_LANES(i, NBANDS) {
-            S.pulses[i] = rec->pulses[i];
+            S.pulses_row()[i] = rec->pulses[i];
             S.tf_res[i] = rec->tf_res[i];
         }
+#endif
         // the phase-major band loop takes every 20 ms frame that starts at band 0 (and whose record did not overflow)
-        const int n_words = OG_UNI(rec->n_words);
-#ifdef OG_NO_PM
+#if defined(OG_NO_PM) && !defined(OG_RECON_TIGHT)
         const bool pm = false;
 #else
-        const bool pm = LM == 3 && start == 0 && n_words < REC_MAX_WORDS && n_leaves < REC_MAX_LEAVES;
+        const bool pm = fast;
 #endif
 #ifdef OG_HOST_EMUL
         OG_FOR_LANES(i, 2 * N) S.v[V_X + i] = 0;
@@ -1666,23 +1692,38 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
                                     << (aux >> 16));
         }
         OG_SYNC();
+#ifndef OG_RECON_TIGHT
         if (!pm) { // the band walk starts from an empty folding history (the table above is no longer needed)
             OG_FOR_LANES(i, 1248) S.v[V_NORM + i] = 0;
             OG_SYNC();
         }
+#endif
 #if defined(OG_RABL) && OG_RABL == 2
         return ret;
 #endif
         u32 seed = cs->rng;
+#ifdef OG_RECON_TIGHT
+        recon_all_bands_pm(rec, lcg, C, transient ? M : 0, seed);
+        // what anti-collapse and the synthesis read besides the spectrum, staged only now (og_state.hpp, V_LATE: the rows
+        // were the band loop's scratch until here; the bands' collapse masks are there already)
+        OG_FOR_LANES(i, 2 * NBANDS) {
+            S.bandE_row()[i] = rec->bandE[i];
+            S.logE1_row()[i] = cs->logE1[i];
+            S.logE2_row()[i] = cs->logE2[i];
+        }
+        OG_FOR_LANES(i, NBANDS) S.pulses_row()[i] = rec->pulses[i];
+        OG_SYNC();
+#else
         if (pm)
             recon_all_bands_pm(rec, lcg, C, transient ? M : 0, seed);
         else
             recon_all_bands(rec->words, (u32)OG_UNI(rec->need_norm), lcg, start, end, C, N, transient ? M : 0, LM, seed);
+#endif
         OG_MARK(12);
         if (flags & RF_ANTI_COLLAPSE) anti_collapse(LM, C, N, start, end, seed);
         if (silence) {
             OG_SYNC();
-            OG_FOR_LANES(i, C * NBANDS) S.bandE[i] = (i16)(-28 * 1024);
+            OG_FOR_LANES(i, C * NBANDS) S.bandE_row()[i] = (i16)(-28 * 1024);
         }
         OG_TAP(1);
 #if defined(OG_RABL) && OG_RABL == 3

@@ -82,12 +82,14 @@ OG_DEV int desc_bandwidth(i32 f) { return BW_NB + ((f >> 2) & 7); }
 OG_DEV int desc_channels(i32 f) { return (f & 32) ? 2 : 1; }
 
 // ---- per-wave LDS working set ---------------------------------------------------------------------
+#ifndef OG_RECON_TIGHT
 // i16 vector arena: [X (2 x 960)] [norm (2 x 624)] [iy (192)] [tmp (192)]
 constexpr int V_X = 0;
 constexpr int V_NORM = 1920;
 constexpr int V_IY = V_NORM + 1248;
 constexpr int V_TMP = V_IY + 192;
 constexpr int V_TOTAL = V_TMP + 192;
+constexpr int V_SYN = V_NORM;  // the i32 synthesis buffer of one channel starts here
 constexpr int SYN_LEN = 1088;  // 960 + 120 (+8 pad)
 
 // Two phases share the bytes behind X: while the bands are decoded they hold the folding history, the pulse /
@@ -104,7 +106,71 @@ struct FrameLds {
     i16 dn_g[2 * NBANDS], dn_shift[2 * NBANDS];
     u8 cmask[2 * NBANDS];
     u8 bin2band[120];
+#ifdef OG_LDS_PAD /* occupancy experiments only: make the wave's LDS footprint larger */
+    u8 pad_experiment[OG_LDS_PAD];
+#endif
+    OG_MEMBER i16 *bandE_row() { return bandE; }
+    OG_MEMBER i16 *logE1_row() { return logE1; }
+    OG_MEMBER i16 *logE2_row() { return logE2; }
+    OG_MEMBER u8 *cmask_row() { return cmask; }
+    OG_MEMBER i32 *pulses_row() { return pulses; }
+    OG_MEMBER u16 *leaf_mask_row() { return reinterpret_cast<u16 *>(&pkt[0]); }
+    OG_MEMBER u32 *word_window() { return win; }
+    OG_MEMBER i16 *dn_g_row() { return dn_g; }
+    OG_MEMBER i16 *dn_shift_row() { return dn_shift; }
+    OG_MEMBER u8 *bin2band_row() { return bin2band; }
 };
+constexpr int MAX_LEAF_MASKS = 672;
 static_assert((V_TOTAL - V_NORM) * 2 + 1344 >= SYN_LEN * 4, "the synthesis buffer overlays norm | iy | tmp | pkt");
+#else
+// The working set of the reconstruction kernel of 20 ms CELT-only frames (og_recon.hip), cut to 7.5 KB so that FIVE waves
+// fit a SIMD: LDS is handed out in granules of 1280 bytes (measured with a residency census: 9968 B -> 16 workgroups per
+// CU, 8080 B -> 18, 6000 B -> 25), so 7680 B = 6 granules is the step that gives 21.  On the 10 KB layout above
+// k_celt_recon's time goes with 1 / (waves per SIMD): 2.69 ms at three, 2.09 ms at four.  What makes it fit:
+//   * the folding history is made on demand (phase-major band loop), so the bytes behind X hold, one after the other, the
+//     PVQ table (leaf pass), the band loop's tables + two 200-entry scratch rows, the synthesis buffer;
+//   * the synthesis buffer of a channel starts INSIDE X, over the second channel's spectrum: that channel is synthesised
+//     first, its spectrum read into registers before the buffer is written (og_celt.hpp), and the first channel's
+//     spectrum is still in place when its turn comes;
+//   * a 20 ms frame has at most 416 PVQ leaves (a band of N coefficients splits into at most min(16, N / 2) leaves);
+//   * arrays only the entropy-decoding half needs are gone (zero-length here: the code that names them is never run from
+//     this layout, see og_recon.hip).
+constexpr int V_X = 0;
+constexpr int V_NORM = 1920;            // the band loop's tables (PmLds) -- or the PVQ table during the leaf pass
+constexpr int V_IY = V_NORM + 576;      // scratch row (folding source), 200 entries
+constexpr int V_TMP = V_IY + 200;       // scratch row (Hadamard), 200 entries
+// Once the stereo merges are done the two scratch rows hold the frame's small arrays: the bands' collapse masks, and --
+// staged from the record and the stream state only now -- pulses, band energies and the two energy histories, which
+// anti-collapse and the start of the synthesis read.  (The synthesis buffer later runs over them: they are dead by then.)
+constexpr int V_LATE = V_IY;
+constexpr int V_WIN = V_TMP + 200;      // window of the record's word stream (64 x u32; fill jobs), where the PVQ table's end was
+constexpr int V_MASK = V_NORM + 1380;   // per-leaf collapse masks (416 x u16: jobs with both kinds of leaves read them while they
+                                        // fill); later the synthesis gains
+constexpr int V_TOTAL = V_MASK + 416;
+constexpr int V_SYN = 960;              // the synthesis buffer: second channel's spectrum + 2432 bytes behind X
+constexpr int SYN_LEN = 1088;
+struct FrameLds {
+    alignas(16) i16 v[V_TOTAL];
+    // (named by code that this layout never runs)
+    u8 pkt[0];
+    i32 fine_quant[0], fine_prio[0], tf_res[0], cap[0], offsets[0], bits1[0], bits2[0];
+    OG_MEMBER u8 *cmask_row() { return reinterpret_cast<u8 *>(&v[V_LATE]); }                 // 42 bytes
+    OG_MEMBER i32 *pulses_row() { return reinterpret_cast<i32 *>(&v[V_LATE + 24]); }          // 21 words
+    OG_MEMBER i16 *bandE_row() { return &v[V_LATE + 24 + 2 * NBANDS]; }
+    OG_MEMBER i16 *logE1_row() { return &v[V_LATE + 24 + 4 * NBANDS]; }
+    OG_MEMBER i16 *logE2_row() { return &v[V_LATE + 24 + 6 * NBANDS]; }
+    OG_MEMBER u16 *leaf_mask_row() { return reinterpret_cast<u16 *>(&v[V_MASK]); }
+    OG_MEMBER u32 *word_window() { return reinterpret_cast<u32 *>(&v[V_WIN]); }
+    OG_MEMBER i16 *dn_g_row() { return &v[V_MASK]; }                               // synthesis only
+    OG_MEMBER i16 *dn_shift_row() { return &v[V_MASK + 2 * NBANDS]; }
+    OG_MEMBER u8 *bin2band_row() { return reinterpret_cast<u8 *>(&v[V_MASK + 4 * NBANDS]); }
+};
+constexpr int MAX_LEAF_MASKS = 416;
+static_assert(V_SYN * 2 + SYN_LEN * 4 <= V_MASK * 2, "the synthesis buffer ends before the synthesis gains");
+static_assert((V_MASK + 4 * NBANDS) * 2 + 120 <= V_TOTAL * 2, "synthesis tables fit behind the buffer");
+static_assert(V_LATE + 24 + 8 * NBANDS <= V_MASK && (V_LATE + 24) % 2 == 0, "the late-staged arrays fit the scratch rows");
+static_assert(V_MASK % 2 == 0 && V_NORM % 8 == 0 && V_IY % 8 == 0 && V_WIN % 2 == 0 && V_WIN + 128 <= V_MASK, "alignment of the overlays");
+static_assert(sizeof(FrameLds) <= 7680, "six 1280-byte LDS granules: 21 workgroups per CU");
+#endif
 
 } // namespace og
