@@ -93,7 +93,7 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
         if (prev_mode == MODE_CELT) silk_init_state(&st->silk);
         int internal_hz = 16000;
         if (mode == MODE_SILK) internal_hz = bandwidth == BW_NB ? 8000 : (bandwidth == BW_MB ? 12000 : 16000);
-        int ret = silk_decode_20ms(&st->silk, rc, ch, internal_hz, srec); // fills g_pcm_silk (48 kHz, interleaved)
+        int ret = silk_decode_20ms<!WITH_CELT>(&st->silk, rc, ch, internal_hz, srec); // fills g_pcm_silk (48 kHz, interleaved)
         if (ret) return INTERNAL_ERROR;
     }
 #else

@@ -35,7 +35,6 @@ struct SilkCtrl { // silk_decoder_control_t (src/silk.h:747) + the frame's side 
 };
 
 struct SilkLds {
-    i16 pulses[2][SILK_MAX_FRAME + 16];
     i16 xq[2][SILK_MAX_FRAME + 8];      // [0..2) look-back slots, frame at +2 (samplesOut1_tmp, silk.cpp:1657)
     // Two phases share these bytes: the synthesis recurrence (LTP state, whitened history, staged outBuf) and, once
     // that is done, the resampler (48 kHz PCM of both channels, 2x up-sampled signals).  The up-sampler's staged
@@ -52,15 +51,24 @@ struct SilkLds {
         } out;
     } u;
     SilkCtrl ctrl[2];
+};
+// SILK's working set is its own LDS object: only the kernels that run SILK pay for it.
+OG_LDS SilkLds g_silk_lds;
+OG_DEV SilkLds &SL() { return g_silk_lds; }
+// What only the wave-uniform ENTROPY half needs -- the pulse row it decodes into, the scratch of the pulse decoder and of
+// the NLSF -> LPC conversion -- is an object of its own: the synthesis kernel of the split path (silk_decode_20ms<true>:
+// everything from the parse kernel's record, pulses read where they lie in HBM) never names it, and its LDS footprint
+// drops from 12,160 to 10,152 bytes = 8 instead of 10 LDS granules of 1280 bytes: 16 instead of 12 workgroups per CU.
+struct SilkWaveParseLds {
+    i16 pulses[2][SILK_MAX_FRAME + 16];
     i32 sum_pulses[20], nLshifts[20];
     i32 VAD_flags[2], LBRR_flag[2];
     i16 nlsf[SILK_MAX_LPC], nlsf0[SILK_MAX_LPC], ec_ix[SILK_MAX_LPC], res_Q10[SILK_MAX_LPC];
     i32 pred_Q8[SILK_MAX_LPC];
     i32 cosLSF[SILK_MAX_LPC], P[SILK_MAX_LPC / 2 + 1], Q[SILK_MAX_LPC / 2 + 1], a32[SILK_MAX_LPC], Atmp[SILK_MAX_LPC];
 };
-// SILK's working set is its own LDS object: only the single-kernel path (which runs SILK) pays for it.
-OG_LDS SilkLds g_silk_lds;
-OG_DEV SilkLds &SL() { return g_silk_lds; }
+OG_LDS SilkWaveParseLds g_silk_wp;
+OG_DEV SilkWaveParseLds &PW() { return g_silk_wp; }
 
 // ---- state ------------------------------------------------------------------------------------------
 OG_DEV void silk_chan_init(SilkChannel *c) { // silk_init_decoder silk.cpp:2192
@@ -157,8 +165,8 @@ OG_DEV NlsfCb nlsf_cb(int wb) {
     return cb;
 }
 
-OG_DEV void nlsf_unpack(const NlsfCb &cb, int CB1_index) { // silk_NLSF_unpack silk.cpp:2762 -> SL().ec_ix / pred_Q8
-    SilkLds &L = SL();
+OG_DEV void nlsf_unpack(const NlsfCb &cb, int CB1_index) { // silk_NLSF_unpack silk.cpp:2762 -> PW().ec_ix / pred_Q8
+    SilkWaveParseLds &L = PW();
     const u8 *sel = &cb.ec_sel[CB1_index * cb.order / 2];
     for (int i = 0; i < cb.order; i += 2) {
         int entry = *sel++;
@@ -172,7 +180,7 @@ OG_DEV void nlsf_unpack(const NlsfCb &cb, int CB1_index) { // silk_NLSF_unpack s
 // ---- side information (silk_decode_indices silk.cpp:708) --------------------------------------------------
 OG_DEV void silk_decode_indices(SilkChannel *c, SilkCtrl &k, Rc &rc, int fs_kHz, int vad, int decode_LBRR, int condCoding,
                                  i32 &ec_prevSignalType, i32 &ec_prevLagIndex) {
-    SilkLds &L = SL();
+    SilkWaveParseLds &L = PW();
     (void)c;
     const NlsfCb cb = nlsf_cb(fs_kHz == 16);
     int Ix;
@@ -239,7 +247,7 @@ OG_DEV void shell_split(Rc &rc, int &c1, int &c2, int p, const u8 *table) {
 }
 
 OG_DEV void silk_decode_pulses(Rc &rc, int ch, int signalType, int quantOffsetType, int frame_length) {
-    SilkLds &L = SL();
+    SilkWaveParseLds &L = PW();
     i16 *pulses = L.pulses[ch];
     int iter = frame_length >> 4;
     if (iter * 16 < frame_length) iter++;
@@ -334,15 +342,15 @@ struct ArrV {
 struct SilkParWave {
     typedef ArrV<i16, 1> A16;
     typedef ArrV<i32, 1> A32;
-    static OG_MEMBER A16 nlsf() { A16 r = {SL().nlsf}; return r; }
-    static OG_MEMBER A16 nlsf0() { A16 r = {SL().nlsf0}; return r; }
-    static OG_MEMBER A16 res_Q10() { A16 r = {SL().res_Q10}; return r; }
-    static OG_MEMBER A32 pred_Q8() { A32 r = {SL().pred_Q8}; return r; }
-    static OG_MEMBER A32 cosLSF() { A32 r = {SL().cosLSF}; return r; }
-    static OG_MEMBER A32 P() { A32 r = {SL().P}; return r; }
-    static OG_MEMBER A32 Q() { A32 r = {SL().Q}; return r; }
-    static OG_MEMBER A32 a32() { A32 r = {SL().a32}; return r; }
-    static OG_MEMBER A32 Atmp() { A32 r = {SL().Atmp}; return r; }
+    static OG_MEMBER A16 nlsf() { A16 r = {PW().nlsf}; return r; }
+    static OG_MEMBER A16 nlsf0() { A16 r = {PW().nlsf0}; return r; }
+    static OG_MEMBER A16 res_Q10() { A16 r = {PW().res_Q10}; return r; }
+    static OG_MEMBER A32 pred_Q8() { A32 r = {PW().pred_Q8}; return r; }
+    static OG_MEMBER A32 cosLSF() { A32 r = {PW().cosLSF}; return r; }
+    static OG_MEMBER A32 P() { A32 r = {PW().P}; return r; }
+    static OG_MEMBER A32 Q() { A32 r = {PW().Q}; return r; }
+    static OG_MEMBER A32 a32() { A32 r = {PW().a32}; return r; }
+    static OG_MEMBER A32 Atmp() { A32 r = {PW().Atmp}; return r; }
 };
 
 template <class A16>
@@ -661,11 +669,11 @@ OG_DEV void silk_params_lane(const StreamState *st, int mode, int bandwidth, int
 }
 
 // ---- synthesis: one lane per channel (silk_decode_core silk.cpp:1806, LPC analysis filter :2268) --------------
-OG_DEVN void silk_decode_core_lane(SilkChannel *c, int ch, int fs_kHz) {
+// `pulses`: the channel's excitation pulses -- in the parse record in HBM (split path) or in PW().pulses
+OG_DEVN void silk_decode_core_lane(SilkChannel *c, int ch, int fs_kHz, const i16 *pulses) {
     SilkLds &L = SL();
     const SilkCtrl &k = L.ctrl[ch];
     const int order = fs_kHz == 16 ? 16 : 10, subfr = 5 * fs_kHz, frame_length = 4 * subfr, ltp_mem = 20 * fs_kHz;
-    const i16 *pulses = L.pulses[ch];
     i16 *xq = &L.xq[ch][2];
     i32 *sLTP_Q15 = L.u.core.sLTP_Q15[ch];
     i16 *sLTP = L.u.core.sLTP[ch];
@@ -781,7 +789,7 @@ OG_DEV i32 row_lane0(i32 v) { // lane 0 of every 16-lane row, in all lanes of th
     // keep lane 0's value, zero elsewhere, then sum over the row
     return row_sum16((OG_LANE & 15) == 0 ? v : 0);
 }
-OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels) {
+OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const i16 *pulses0, const i16 *pulses1) {
     SilkLds &L = SL();
     const int row = OG_LANE >> 4, j = OG_LANE & 15;
     if (row >= channels) return;
@@ -794,7 +802,7 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels) {
     }
     SilkChannel *c = &st->ch[ch];
     const SilkCtrl &k = L.ctrl[ch];
-    const i16 *pulses = L.pulses[ch];
+    const i16 *pulses = ch ? pulses1 : pulses0;
     i32 *sLTP_Q15 = L.u.core.sLTP_Q15[ch];
     i16 *sLTP = L.u.core.sLTP[ch];
     const i32 offset_Q10 = rom_silk_quant_offsets_q10[(k.signalType >> 1) * 2 + k.quantOffsetType];
@@ -1093,6 +1101,9 @@ OG_DEV void silk_stereo_decode_pred(Rc &rc, i32 pred_Q13[2]) { // silk.cpp:592
 // Decode one 20 ms SILK frame (mid + side / mono) into S.pcm_silk (48 kHz, interleaved when stereo).
 // Returns 0 or a non-zero error (wave-uniform).
 // `rec` != null: the frame's entropy half comes from the parse kernel's record and `rc` is not touched.
+// REC_ONLY: the instantiation of the split path's synthesis kernel -- `rec` is always there, none of the wave-uniform
+// entropy decoding is compiled in, and neither is its LDS object (PW()).
+template <bool REC_ONLY = false>
 OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz, const SilkRec *rec = nullptr) {
     SilkLds &L = SL();
     const int fs_kHz = (internal_hz >> 10) + 1;
@@ -1122,7 +1133,7 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz,
     OG_MARK(30);
     i32 MS_pred_Q13[2] = {0, 0};
     int decode_only_middle = 0;
-    if (rec) { // the entropy half was done by the lane-per-frame parse kernel (og_silk_parse.hpp)
+    if (REC_ONLY || rec) { // the entropy half was done by the lane-per-frame parse kernel (og_silk_parse.hpp)
         MS_pred_Q13[0] = OG_UNI(rec->MS_pred_Q13[0]);
         MS_pred_Q13[1] = OG_UNI(rec->MS_pred_Q13[1]);
         decode_only_middle = OG_UNI(rec->decode_only_middle);
@@ -1130,7 +1141,7 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz,
             ecType[n] = OG_UNI(rec->ch[n].ec_prevSignalType);
             ecLag[n] = OG_UNI(rec->ch[n].ec_prevLagIndex);
         }
-    } else {
+    } else if constexpr (!REC_ONLY) {
     for (int n = 0; n < channels; n++) {
         vad[n] = rc_bit_logp(rc, 1);
         lbrr[n] = rc_bit_logp(rc, 1);
@@ -1171,27 +1182,24 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz,
             // FrameIndex = nFramesDecoded - n = -n <= 0 -> independent coding (silk.cpp:1678-1681)
             const int condCoding = 0;
             OG_MARK(30);
-            if (rec) { // parameters + indices (68 words laid out like SilkCtrl) and pulses from the record
+            if (REC_ONLY || rec) { // parameters + indices (68 words laid out like SilkCtrl) from the record
                 OG_SYNC();
                 const i32 *src = rec->ch[n].pitchL;
                 i32 *dst = L.ctrl[n].pitchL;
                 OG_FOR_LANES(i, SILK_REC_CTRL_WORDS) dst[i] = src[i];
-                OG_FOR_LANES(i, SILK_MAX_LPC) L.nlsf[i] = rec->ch[n].nlsf[i];
                 lastGain[n] = OG_UNI(rec->ch[n].LastGainIndex);
-                const u32 *ps = reinterpret_cast<const u32 *>(rec->ch[n].pulses);
-                u32 *pd = reinterpret_cast<u32 *>(L.pulses[n]);
-                OG_FOR_LANES(i, (frame_length + 16) / 2) pd[i] = ps[i];
+                OG_FOR_LANES(i, fs_kHz == 16 ? 16 : 10) s->ch[n].prevNLSF_Q15[i] = rec->ch[n].nlsf[i];
                 OG_SYNC();
-            } else {
-            silk_decode_indices(&s->ch[n], L.ctrl[n], rc, fs_kHz, vad[n], 0, condCoding, ecType[n], ecLag[n]);
-            OG_MARK(31);
-            silk_decode_pulses(rc, n, L.ctrl[n].signalType, L.ctrl[n].quantOffsetType, frame_length);
+            } else if constexpr (!REC_ONLY) {
+                silk_decode_indices(&s->ch[n], L.ctrl[n], rc, fs_kHz, vad[n], 0, condCoding, ecType[n], ecLag[n]);
+                OG_MARK(31);
+                silk_decode_pulses(rc, n, L.ctrl[n].signalType, L.ctrl[n].quantOffsetType, frame_length);
+                OG_MARK(32);
+                silk_decode_parameters<SilkParWave>(s->ch[n].prevNLSF_Q15, L.ctrl[n], fs_kHz, condCoding, lastGain[n], ffar[n]);
+                OG_SYNC();
+                OG_FOR_LANES(i, fs_kHz == 16 ? 16 : 10) s->ch[n].prevNLSF_Q15[i] = PW().nlsf[i];
+                OG_SYNC();
             }
-            OG_MARK(32);
-            if (!rec) silk_decode_parameters<SilkParWave>(s->ch[n].prevNLSF_Q15, L.ctrl[n], fs_kHz, condCoding, lastGain[n], ffar[n]);
-            OG_SYNC();
-            OG_FOR_LANES(i, fs_kHz == 16 ? 16 : 10) s->ch[n].prevNLSF_Q15[i] = L.nlsf[i];
-            OG_SYNC();
             OG_MARK(33);
         }
     }
@@ -1207,18 +1215,27 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz,
     OG_SYNC();
     // ---- synthesis: stage the output history, then lane n = channel n
     OG_MARK(34);
+    // where the channels' pulses are: in the parse record (read where they lie, in HBM) or in the row they were decoded into
+    const i16 *pulse_row[2];
+    if constexpr (REC_ONLY) {
+        pulse_row[0] = rec->ch[0].pulses;
+        pulse_row[1] = rec->ch[1].pulses;
+    } else {
+        pulse_row[0] = rec ? rec->ch[0].pulses : PW().pulses[0];
+        pulse_row[1] = rec ? rec->ch[1].pulses : PW().pulses[1];
+    }
     for (int n = 0; n < channels; n++)
         if (L.ctrl[n].coded) OG_FOR_LANES(i, frame_length) L.u.core.hist[n][i] = s->ch[n].outBuf[i];
     OG_SYNC();
 #ifdef OG_HOST_EMUL
     OG_FOR_LANES(n, channels) {
         if (L.ctrl[n].coded)
-            silk_decode_core_lane(&s->ch[n], n, fs_kHz);
+            silk_decode_core_lane(&s->ch[n], n, fs_kHz, pulse_row[n]);
         else
             for (int i = 0; i < frame_length; i++) L.xq[n][2 + i] = 0;
     }
 #else
-    silk_decode_core_rows(s, fs_kHz, channels);
+    silk_decode_core_rows(s, fs_kHz, channels, pulse_row[0], pulse_row[1]);
 #endif
     OG_SYNC();
     OG_TAP(40); // decoder control + core output of every coded channel (host emulation only)
