@@ -26,6 +26,7 @@ EXPORTS = [
     "opusgpu_event_elapsed_ms", "opusgpu_event_destroy", "opusgpu_stream_state_get",
     "opusgpu_pages_demux", "opusgpu_page_batch_steps", "opusgpu_page_batch_step", "opusgpu_page_batch_arena",
     "opusgpu_page_batch_free", "opusgpu_pages_crc_device", "opusgpu_output_stage_device",
+    "opusgpu_set_mode", "opusgpu_get_mode", "opusgpu_packet_to_frames_mode",
 ]
 
 
@@ -76,6 +77,9 @@ def load_lib():
     lib.opusgpu_stream_state_bytes.restype = C.c_size_t
     lib.opusgpu_decode_packets.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]
     lib.opusgpu_packet_to_frames.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(FrameDesc)]
+    lib.opusgpu_packet_to_frames_mode.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int, C.POINTER(FrameDesc)]
+    lib.opusgpu_set_mode.argtypes = [vp, C.c_int]
+    lib.opusgpu_get_mode.argtypes = [vp]
     lib.opusgpu_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.opusgpu_dev_free.argtypes = [vp, vp]
     lib.opusgpu_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
@@ -233,6 +237,10 @@ class Context:
     def streams_alloc(self, n, channels):
         self._chk(self.lib.opusgpu_streams_alloc(self.h, n, channels), "opusgpu_streams_alloc")
         self.n_streams, self.channels = n, channels
+
+    def set_mode(self, rfc):
+        """RFC mode on / off (include/opusgpu.h, OPUSGPU_MODE_RFC): frames at the durations their TOC names."""
+        self._chk(self.lib.opusgpu_set_mode(self.h, 1 if rfc else 0), "opusgpu_set_mode")
 
     def streams_reset(self, first, count, full=True):
         self._chk(self.lib.opusgpu_streams_reset(self.h, first, count, 1 if full else 0), "opusgpu_streams_reset")

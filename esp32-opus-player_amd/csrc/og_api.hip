@@ -256,6 +256,9 @@ __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const Fra
     int ret;
     if (d.stream < 0 || d.stream >= n_streams) {
         ret = BAD_ARG;
+    } else if (desc_rfc(d.flags)) { // RFC mode (opt-in): the frame at its true duration, on this kernel only
+        ret = decode_frame_rfc(&st[d.stream], arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
+                               desc_channels(d.flags), pcm + (size_t)f * pcm_stride, desc_frame_size(d.flags));
     } else if (skip_celt && desc_mode(d.flags) == MODE_CELT) {
         return; // CELT-only frames take the split path (k_celt_parse + k_celt_recon)
     } else if (q4_only && !(desc_mode(d.flags) == MODE_SILK && handoff[f].valid == 2)) {
@@ -286,7 +289,7 @@ __global__ void __launch_bounds__(64, OG_SILK_WAVES) k_silk_synth(const FrameDes
     int ret;
     if (d.stream < 0 || d.stream >= n_streams) {
         ret = BAD_ARG;
-    } else if (desc_mode(d.flags) == MODE_CELT) {
+    } else if (desc_mode(d.flags) == MODE_CELT || desc_rfc(d.flags)) {
         return;
     } else {
 #ifdef OG_PROF_SSYNTH // profiling builds: time the sections of the SILK synthesis kernel
@@ -313,7 +316,7 @@ __global__ void __launch_bounds__(64, 2) k_silk_parse(const FrameDesc *__restric
     if (f >= n) return;
     const FrameDesc d = descs[f];
     const int mode = desc_mode(d.flags);
-    if (d.stream < 0 || d.stream >= n_streams || mode == MODE_CELT) return;
+    if (d.stream < 0 || d.stream >= n_streams || mode == MODE_CELT || desc_rfc(d.flags)) return;
 #ifdef OG_PROF_SPARSE // profiling builds: time the sections of the SILK parse kernel (full batches only)
     OG_PROF_INIT();
 #endif
@@ -335,7 +338,7 @@ __global__ void __launch_bounds__(64, 2) k_celt_parse(const FrameDesc *__restric
     if (f >= n) return;
     const FrameDesc d = descs[f];
     const int mode = desc_mode(d.flags);
-    if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && handoff))) return;
+    if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && handoff)) || desc_rfc(d.flags)) return;
 #ifdef OG_PROF_PARSE // profiling builds: time the sections of the parse kernel instead of the recon kernel (full batches only)
     OG_PROF_INIT();
 #endif
@@ -356,7 +359,7 @@ __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDe
     if (f >= n) return;
     const FrameDesc d = descs[f];
     const int mode = desc_mode(d.flags);
-    if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && hybrid))) return;
+    if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && hybrid)) || desc_rfc(d.flags)) return;
     if (mode == MODE_HYBRID && (recs[f].flags & RF_SKIP)) return; // the single-kernel path already reported this frame
 #if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE) && !defined(OG_PROF_SPARSE) && !defined(OG_PROF_SSYNTH)
     OG_PROF_INIT();
@@ -396,7 +399,7 @@ __global__ void __launch_bounds__(64) k_celt_post(const FrameDesc *__restrict__ 
     if (f < n) {
         const FrameDesc d = descs[f];
         const int mode = desc_mode(d.flags);
-        if (d.stream >= 0 && d.stream < n_streams && (mode == MODE_CELT || (mode == MODE_HYBRID && handoff)) &&
+        if (d.stream >= 0 && d.stream < n_streams && (mode == MODE_CELT || (mode == MODE_HYBRID && handoff)) && !desc_rfc(d.flags) &&
             !(recs[f].flags & (RF_SKIP | RF_BAD_CELT))) {
             live = true;
             ss = &st[d.stream];
@@ -502,6 +505,7 @@ struct opusgpu_ctx {
     int split_celt = 1;   // OPUSGPU_SPLIT=0 forces the single-kernel path for every mode (A/B measurements)
     int split_hybrid = 1; // OPUSGPU_SPLIT_HYBRID=0 keeps SILK-only and hybrid frames entirely on the single-kernel path
     int fast_recon = 1;   // OPUSGPU_FAST_RECON=0: every CELT frame through the general reconstruction kernel (A/B measurements)
+    int mode = OPUSGPU_MODE_REFERENCE; // opusgpu_set_mode
     char err[256] = {0};
 };
 
@@ -583,6 +587,12 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
 }
 
 const char *opusgpu_last_error(const opusgpu_ctx *ctx) { return ctx ? ctx->err : "no context"; }
+int opusgpu_set_mode(opusgpu_ctx *ctx, int mode) {
+    if (!ctx || (mode != OPUSGPU_MODE_REFERENCE && mode != OPUSGPU_MODE_RFC)) return OPUSGPU_BAD_ARG;
+    ctx->mode = mode;
+    return OPUSGPU_OK;
+}
+int opusgpu_get_mode(const opusgpu_ctx *ctx) { return ctx ? ctx->mode : OPUSGPU_MODE_REFERENCE; }
 size_t opusgpu_stream_state_bytes(void) { return sizeof(StreamState); }
 int opusgpu_stream_count(const opusgpu_ctx *ctx) { return ctx ? ctx->n_streams : 0; }
 int opusgpu_stream_channels(const opusgpu_ctx *ctx) { return ctx ? ctx->channels : 0; }
@@ -648,7 +658,7 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
     if (n == 0) return OPUSGPU_OK;
     if (!d_descs || !d_arena || !d_pcm || !d_result) return OPUSGPU_BAD_ARG;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-    const int pcm_stride = OPUSGPU_FRAME_SAMPLES * ctx->channels;
+    const int pcm_stride = (ctx->mode == OPUSGPU_MODE_RFC ? OPUSGPU_RFC_FRAME_SAMPLES : OPUSGPU_FRAME_SAMPLES) * ctx->channels;
     SilkHandoff *handoff = nullptr;
     SilkRec *srecs = nullptr;
     if (ctx->split_celt) {
@@ -825,6 +835,10 @@ int opusgpu_stream_state_get(opusgpu_ctx *ctx, int index, void *dst, size_t byte
 }
 
 int opusgpu_packet_to_frames(const uint8_t *packet, int32_t len, int32_t stream, opusgpu_frame_desc descs[48]) {
+    return opusgpu_packet_to_frames_mode(packet, len, stream, OPUSGPU_MODE_REFERENCE, descs);
+}
+
+int opusgpu_packet_to_frames_mode(const uint8_t *packet, int32_t len, int32_t stream, int mode, opusgpu_frame_desc descs[48]) {
     if (!packet || !descs) return OPUSGPU_BAD_ARG;
     if (len <= 0) return len == 0 ? OPUSGPU_INVALID_PACKET : OPUSGPU_BAD_ARG;
     int16_t size[48];
@@ -832,7 +846,7 @@ int opusgpu_packet_to_frames(const uint8_t *packet, int32_t len, int32_t stream,
     int offset = 0;
     const int count = ogh::parse_packet(packet, len, 0, &toc, size, &offset, nullptr);
     if (count < 0) return count;
-    const int32_t flags = ogh::toc_flags(toc);
+    const int32_t flags = mode == OPUSGPU_MODE_RFC ? ogh::toc_flags_rfc(toc) : ogh::toc_flags(toc);
     for (int i = 0; i < count; i++) {
         descs[i].stream = stream;
         descs[i].offset = offset;
@@ -873,7 +887,10 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
     if (!stream_ids || !packets || !lens || !pcm || !result || frame_capacity <= 0) return OPUSGPU_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int CC = ctx->channels;
-    const size_t frame_pcm = (size_t)OPUSGPU_FRAME_SAMPLES * CC;
+    const bool rfc = ctx->mode == OPUSGPU_MODE_RFC;
+    // one frame's block in the device PCM buffer: 20 ms, or room for a 60 ms frame in RFC mode
+    const size_t frame_pcm = (size_t)(rfc ? OPUSGPU_RFC_FRAME_SAMPLES : OPUSGPU_FRAME_SAMPLES) * CC;
+    const size_t cap_pcm = (size_t)frame_capacity * OPUSGPU_FRAME_SAMPLES * CC; // the caller's block per packet
     // 1. frame the packets on the host (opus_decode_native, src/opus_decoder.cpp:280-348).  Large batches by ranges of
     //    packets on a few threads, in two passes: frame counts and sizes, then (after the prefix sums that place every
     //    packet) descriptors and packet bytes.
@@ -898,14 +915,15 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
                 continue;
             }
             opusgpu_frame_desc d[48];
-            const int count = opusgpu_packet_to_frames(packets[i], lens[i], stream_ids[i], d);
+            const int count = opusgpu_packet_to_frames_mode(packets[i], lens[i], stream_ids[i], ctx->mode, d);
             if (count < 0) {
                 result[i] = count;
                 continue;
             }
             // count * packet_frame_size > frame_size -> OPUS_BUFFER_TOO_SMALL (src/opus_decoder.cpp:323)
             const int pfs = ogh::toc_samples_per_frame(packets[i][0], 48000);
-            if ((int64_t)count * pfs > (int64_t)frame_capacity * OPUSGPU_FRAME_SAMPLES || count > frame_capacity) {
+            // (RFC mode decodes the durations the check is about: no second condition)
+            if ((int64_t)count * pfs > (int64_t)frame_capacity * OPUSGPU_FRAME_SAMPLES || (!rfc && count > frame_capacity)) {
                 result[i] = OPUSGPU_BUFFER_TOO_SMALL;
                 continue;
             }
@@ -928,7 +946,7 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
         for (int i = lo; i < hi; i++) {
             if (!nframes[i]) continue;
             opusgpu_frame_desc d[48];
-            (void)opusgpu_packet_to_frames(packets[i], lens[i], stream_ids[i], d);
+            (void)opusgpu_packet_to_frames_mode(packets[i], lens[i], stream_ids[i], ctx->mode, d);
             memcpy(arena.get() + base[i], packets[i], (size_t)lens[i]);
             for (int k = 0; k < nframes[i]; k++) {
                 d[k].offset += (int32_t)base[i];
@@ -1001,7 +1019,10 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
                         result[i] = h_res[j];
                         continue;
                     }
-                    memcpy(pcm + ((size_t)i * frame_capacity + k) * frame_pcm, &h_pcm[(size_t)j * frame_pcm], frame_pcm * 2);
+                    if (rfc) // frames of a packet share their duration: frame k starts k frames into the packet's block
+                        memcpy(pcm + (size_t)i * cap_pcm + (size_t)k * h_res[j] * CC, &h_pcm[(size_t)j * frame_pcm], (size_t)h_res[j] * CC * 2);
+                    else
+                        memcpy(pcm + (size_t)i * cap_pcm + (size_t)k * frame_pcm, &h_pcm[(size_t)j * frame_pcm], frame_pcm * 2);
                     result[i] += h_res[j];
                 }
             }

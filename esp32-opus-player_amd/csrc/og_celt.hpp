@@ -1120,9 +1120,9 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
 // Decode one CELT frame of `frame_size` samples (120 << LM) from the live range decoder.
 // pcm_out: LDS i16 buffer (interleaved, CC channels) -- S.v[V_X..] is reused for it after synthesis.
 // Returns frame_size or a negative code (wave-uniform).
-OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int CC, int start, int disable_inv) {
+// `end`: one past the last band decoded -- 21 always in reference mode (Q1), by bandwidth in RFC mode
+OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int CC, int start, int disable_inv, int end = NBANDS) {
     const i32 *eb = rom_eband;
-    const int end = NBANDS;
     int LM;
     for (LM = 0; LM <= 3; LM++)
         if (120 << LM == frame_size) break;

@@ -203,4 +203,111 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
         return INTERNAL_ERROR;
 }
 
+// RFC mode (opt-in; the oracle's oc_decoder_set_rfc): one Opus frame at the duration its TOC names -- CELT 2.5 /
+// 5 / 10 / 20 ms, SILK 10 / 20 / 40 / 60 ms, hybrid 10 / 20 ms -- CELT's last band by bandwidth, and the two-byte silence frame
+// instead of Q4's stale-coder frame when SILK-only follows hybrid.  Everything else as decode_frame_wave has it (Q2, Q3, Q5).
+// Runs on the single-kernel path only (wave-uniform entropy decoding): the mode exists for completeness, the lane-per-frame
+// parse kernels and the 8 KB reconstruction kernel stay 20 ms.  `pcm`: audiosize * channels int16 in HBM.
+// Returns audiosize or a negative code (wave-uniform).
+OG_DEV int rfc_end_band(int bandwidth) { // RFC 6716 section 4.3: NB 13, WB 17, SWB 19, FB 21 bands
+    return bandwidth == BW_NB ? 13 : (bandwidth == BW_MB || bandwidth == BW_WB) ? 17 : bandwidth == BW_SWB ? 19 : NBANDS;
+}
+OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mode, int bandwidth, int ch, i16 *pcm, int audiosize) {
+    const int CC = st->channels;
+    if (len < 0 || len > 1275) return BAD_ARG;
+    const int prev_mode = st->prev_mode;
+    // the reference's mix loop runs over audiosize * stream_channels LINEAR entries of the interleaved output (Q3); the oracle's
+    // RFC mode keeps that and stops at the frame's own end
+    const int nmix = audiosize * (ch < CC ? ch : CC);
+    const bool flush = mode == MODE_SILK && prev_mode == MODE_HYBRID;
+    const int disable_inv = CC == 1;
+#ifndef OG_NO_SILK
+    if (flush) {
+        // RFC 6716 section 4.5.2: the MDCT fades out through a silence frame of 2.5 ms, start band 0 (its return value is not
+        // looked at).  It shares nothing with the SILK data, so it runs first: its 120 samples per channel then wait in the
+        // CELT working set, which the SILK decoder does not touch, until the first internal frame's PCM is added to them.
+        OG_SYNC();
+        OG_FOR_LANES(i, 2) S.pkt[i] = 0xFF;
+        OG_SYNC();
+        Rc rs;
+        rc_init(rs, 2u);
+        (void)celt_decode_frame(&st->celt, rs, 120, ch, CC, 0, disable_inv, NBANDS);
+        OG_SYNC();
+    }
+#endif
+    OG_SYNC();
+    OG_FOR_LANES(i, len) S.pkt[i] = payload[i];
+    OG_SYNC();
+    Rc rc;
+    rc_init(rc, (u32)len);
+    int celt_ret = 0;
+#ifndef OG_NO_SILK
+    if (mode != MODE_CELT) {
+        if (prev_mode == MODE_CELT) silk_init_state(&st->silk);
+        int internal_hz = 16000;
+        if (mode == MODE_SILK) internal_hz = bandwidth == BW_NB ? 8000 : (bandwidth == BW_MB ? 12000 : 16000);
+        int base = 0; // linear position of the internal frame in the packet's SILK PCM
+        const int ret = silk_decode_packet<false>(&st->silk, rc, ch, internal_hz, audiosize / 48, nullptr, [&](int, int n48) {
+            if (mode == MODE_SILK) { // PCM = SAT16(outbuf + pcm_silk), outbuf zero but for the fade-out: straight to HBM
+                OG_FOR_LANES(i, n48 * ch) {
+                    const int at = base + i;
+                    if (at < nmix) {
+                        i32 v = SL().u.out.pcm[i];
+                        if (flush && at < 120 * CC) {
+                            const int c = CC == 2 ? (at & 1) : 0, j = CC == 2 ? (at >> 1) : at;
+                            v = sat16(v + (i32)S.v[pcm_plane(c, ch, CC) + j]);
+                        }
+                        pcm[at] = (i16)v;
+                    }
+                }
+                base += n48 * ch;
+            }
+        });
+        if (ret) return INTERNAL_ERROR;
+    }
+    if (mode != MODE_CELT && rc_tell(rc) + 17 + 20 * (mode == MODE_HYBRID) <= 8 * len) {
+        if (mode == MODE_HYBRID) (void)rc_bit_logp(rc, 12); // redundancy flag read and ignored (Q2)
+    }
+#else
+    if (mode != MODE_CELT) return INTERNAL_ERROR;
+#endif
+    if (mode != MODE_SILK) {
+        if (mode != prev_mode && prev_mode > 0) {
+            celt_reset_state(&st->celt);
+            OG_SYNC();
+        }
+        celt_ret = celt_decode_frame(&st->celt, rc, audiosize, ch, CC, mode == MODE_CELT ? 0 : 17, disable_inv, rfc_end_band(bandwidth));
+#ifndef OG_NO_SILK
+        if (mode == MODE_HYBRID && celt_ret >= 0) {
+            OG_SYNC();
+            OG_FOR_LANES(i, nmix) { // i indexes the interleaved PCM; sample j of channel c lives in plane c
+                const int c = CC == 2 ? (i & 1) : 0, j = CC == 2 ? (i >> 1) : i, at = pcm_plane(c, ch, CC) + j;
+                S.v[at] = (i16)sat16((i32)S.v[at] + (i32)SL().u.out.pcm[i]);
+            }
+            OG_SYNC();
+        }
+#endif
+        if (celt_ret >= 0) {
+            OG_SYNC();
+            pcm_store(pcm, audiosize, ch, CC);
+            OG_SYNC();
+        }
+    }
+#ifndef OG_NO_SILK
+    else if (flush && nmix < 120 * CC) { // (never: SILK frames are at least 10 ms) entries only the fade-out reaches
+        OG_FOR_LANES(i, 120 * CC) {
+            const int c = CC == 2 ? (i & 1) : 0, j = CC == 2 ? (i >> 1) : i;
+            if (i >= nmix) pcm[i] = S.v[pcm_plane(c, ch, CC) + j];
+        }
+    }
+#endif
+    if (OG_LANE == 0) {
+        st->prev_mode = mode;
+        st->frames_decoded += 1;
+        st->range_final = rc.rng;
+    }
+    OG_SYNC();
+    return celt_ret < 0 ? celt_ret : audiosize;
+}
+
 } // namespace og

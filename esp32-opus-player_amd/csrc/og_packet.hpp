@@ -33,6 +33,12 @@ inline int toc_samples_per_frame(uint8_t toc, int32_t Fs) {
 inline int32_t toc_flags(uint8_t toc) {
     return (toc_mode(toc) - MODE_SILK) | ((toc_bandwidth(toc) - BW_NB) << 2) | ((toc & 4) ? 32 : 0);
 }
+// RFC mode: the frame's duration (bits 6-8) and the mode bit (bit 9) on top of toc_flags
+inline int32_t toc_flags_rfc(uint8_t toc) {
+    const int n = toc_samples_per_frame(toc, 48000);
+    const int code = n == 120 ? 1 : n == 240 ? 2 : n == 480 ? 3 : n == 1920 ? 4 : n == 2880 ? 5 : 0;
+    return toc_flags(toc) | code << 6 | 1 << 9;
+}
 
 inline int read_size(const uint8_t *d, int32_t len, int16_t *size) {
     if (len < 1) { *size = -1; return -1; }

@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(64, OG_FAST_WAVES) k_celt_recon_fb(const Frame
     const int f = (int)blockIdx.x;
     if (f >= n) return;
     const FrameDesc d = descs[f];
-    if (d.stream < 0 || d.stream >= n_streams || desc_mode(d.flags) != MODE_CELT) return;
+    if (d.stream < 0 || d.stream >= n_streams || desc_mode(d.flags) != MODE_CELT || desc_rfc(d.flags)) return;
     OG_PROF_INIT();
     const int ret = celt_recon_wave(&st[d.stream], &recs[f], MODE_CELT, desc_channels(d.flags), RECON_FAST_ONLY);
     if (ret != RECON_NOT_MINE && threadIdx.x == 0) result[f] = ret;

@@ -178,8 +178,9 @@ OG_DEV void nlsf_unpack(const NlsfCb &cb, int CB1_index) { // silk_NLSF_unpack s
 }
 
 // ---- side information (silk_decode_indices silk.cpp:708) --------------------------------------------------
+// nb_subfr: 4 (20 ms frames: all the reference decodes, Q6) or 2 (10 ms frames, RFC mode)
 OG_DEV void silk_decode_indices(SilkChannel *c, SilkCtrl &k, Rc &rc, int fs_kHz, int vad, int decode_LBRR, int condCoding,
-                                 i32 &ec_prevSignalType, i32 &ec_prevLagIndex) {
+                                 i32 &ec_prevSignalType, i32 &ec_prevLagIndex, int nb_subfr = 4) {
     SilkWaveParseLds &L = PW();
     (void)c;
     const NlsfCb cb = nlsf_cb(fs_kHz == 16);
@@ -196,7 +197,7 @@ OG_DEV void silk_decode_indices(SilkChannel *c, SilkCtrl &k, Rc &rc, int fs_kHz,
         k.GainsIndices[0] = rc_icdf(rc, rom_silk_gain_icdf + 8 * k.signalType, 8) << 3;
         k.GainsIndices[0] += rc_icdf(rc, rom_silk_uniform8_icdf, 8);
     }
-    for (int i = 1; i < 4; i++) k.GainsIndices[i] = rc_icdf(rc, rom_silk_delta_gain_icdf, 8);
+    for (int i = 1; i < nb_subfr; i++) k.GainsIndices[i] = rc_icdf(rc, rom_silk_delta_gain_icdf, 8);
     k.NLSFIndices[0] = rc_icdf(rc, &cb.CB1_iCDF[(k.signalType >> 1) * 32], 8);
     nlsf_unpack(cb, k.NLSFIndices[0]);
     for (int i = 0; i < cb.order; i++) {
@@ -207,11 +208,12 @@ OG_DEV void silk_decode_indices(SilkChannel *c, SilkCtrl &k, Rc &rc, int fs_kHz,
             Ix += rc_icdf(rc, rom_silk_nlsf_ext_icdf, 8);
         k.NLSFIndices[i + 1] = Ix - 4;
     }
-    k.NLSFInterpCoef_Q2 = rc_icdf(rc, rom_silk_nlsf_interp_icdf, 8); // nb_subfr == 4
+    k.NLSFInterpCoef_Q2 = nb_subfr == 4 ? rc_icdf(rc, rom_silk_nlsf_interp_icdf, 8) : 4; // silk.cpp:771-776
     if (k.signalType == 2) {
         int decode_abs = 1;
         const u8 *lowbits = fs_kHz == 16 ? rom_silk_uniform8_icdf : (fs_kHz == 12 ? rom_silk_uniform6_icdf : rom_silk_uniform4_icdf);
-        const u8 *contour = fs_kHz == 8 ? rom_silk_pitch_contour_nb_icdf : rom_silk_pitch_contour_icdf;
+        const u8 *contour = fs_kHz == 8 ? (nb_subfr == 4 ? rom_silk_pitch_contour_nb_icdf : rom_silk_pitch_contour_10ms_nb_icdf)
+                                         : (nb_subfr == 4 ? rom_silk_pitch_contour_icdf : rom_silk_pitch_contour_10ms_icdf);
         if (condCoding == 2 && ec_prevSignalType == 2) {
             int delta = rc_icdf(rc, rom_silk_pitch_delta_icdf, 8);
             if (delta > 0) {
@@ -228,7 +230,7 @@ OG_DEV void silk_decode_indices(SilkChannel *c, SilkCtrl &k, Rc &rc, int fs_kHz,
         k.contourIndex = rc_icdf(rc, contour, 8);
         k.PERIndex = rc_icdf(rc, rom_silk_ltp_per_icdf, 8);
         const u8 *t = k.PERIndex == 0 ? rom_silk_ltp_gain_icdf0 : (k.PERIndex == 1 ? rom_silk_ltp_gain_icdf1 : rom_silk_ltp_gain_icdf2);
-        for (int j = 0; j < 4; j++) k.LTPIndex[j] = rc_icdf(rc, t, 8);
+        for (int j = 0; j < nb_subfr; j++) k.LTPIndex[j] = rc_icdf(rc, t, 8);
         k.LTP_scaleIndex = condCoding == 0 ? rc_icdf(rc, rom_silk_ltpscale_icdf, 8) : 0;
     }
     ec_prevSignalType = k.signalType;
@@ -551,12 +553,12 @@ OG_DEV void silk_nlsf2a(AQ a_Q12, typename W::A16 NLSF, int d) { // silk.cpp:642
 // stabilised NLSFs are left in W::nlsf() for the caller to store as the next frame's prevNLSF.
 template <class W, class K>
 OG_DEV void silk_decode_parameters(const i16 *prevNLSF_Q15, K &k, int fs_kHz, int condCoding, i32 &LastGainIndex,
-                                   int first_frame_after_reset) {
+                                   int first_frame_after_reset, int nb_subfr = 4) {
     typedef ArrV<i16, 1> AQ;
     struct { typename W::A16 nlsf, nlsf0; } L = {W::nlsf(), W::nlsf0()};
     const int order = fs_kHz == 16 ? 16 : 10;
     const NlsfCb cb = nlsf_cb(fs_kHz == 16);
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < nb_subfr; j++) {
         const int ind = k.GainsIndices[j];
         i32 prev = LastGainIndex;
         if (j == 0 && condCoding != 2)
@@ -584,17 +586,19 @@ OG_DEV void silk_decode_parameters(const i16 *prevNLSF_Q15, K &k, int fs_kHz, in
     }
     if (k.signalType == 2) {
         const i8 *cbk = k.PERIndex == 0 ? rom_silk_ltp_vq0 : (k.PERIndex == 1 ? rom_silk_ltp_vq1 : rom_silk_ltp_vq2);
-        const i8 *lagcb = fs_kHz == 8 ? rom_silk_lags_stage2 : rom_silk_lags_stage3;
-        const int cbk_size = fs_kHz == 8 ? 11 : 34;
+        // silk_decode_pitch silk.cpp:2055: the 10 ms frames have codebooks of their own
+        const i8 *lagcb = fs_kHz == 8 ? (nb_subfr == 4 ? rom_silk_lags_stage2 : rom_silk_lags_stage2_10ms)
+                                      : (nb_subfr == 4 ? rom_silk_lags_stage3 : rom_silk_lags_stage3_10ms);
+        const int cbk_size = fs_kHz == 8 ? (nb_subfr == 4 ? 11 : 3) : (nb_subfr == 4 ? 34 : 12);
         const int min_lag = 2 * fs_kHz, max_lag = 18 * fs_kHz, lag = min_lag + k.lagIndex;
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < nb_subfr; j++) {
             k.pitchL[j] = limit32(lag + lagcb[j * cbk_size + k.contourIndex], min_lag, max_lag);
             for (int i = 0; i < 5; i++) k.LTPCoef_Q14[j * 5 + i] = (i16)shl32((i32)cbk[k.LTPIndex[j] * 5 + i], 7);
         }
         k.LTP_scale_Q14 = rom_silk_ltp_scales_q14[k.LTP_scaleIndex];
     } else {
-        for (int j = 0; j < 4; j++) k.pitchL[j] = 0;
-        for (int j = 0; j < 20; j++) k.LTPCoef_Q14[j] = 0;
+        for (int j = 0; j < nb_subfr; j++) k.pitchL[j] = 0;
+        for (int j = 0; j < 5 * nb_subfr; j++) k.LTPCoef_Q14[j] = 0;
         k.PERIndex = 0;
         k.LTP_scale_Q14 = 0;
     }
@@ -670,10 +674,10 @@ OG_DEV void silk_params_lane(const StreamState *st, int mode, int bandwidth, int
 
 // ---- synthesis: one lane per channel (silk_decode_core silk.cpp:1806, LPC analysis filter :2268) --------------
 // `pulses`: the channel's excitation pulses -- in the parse record in HBM (split path) or in PW().pulses
-OG_DEVN void silk_decode_core_lane(SilkChannel *c, int ch, int fs_kHz, const i16 *pulses) {
+OG_DEVN void silk_decode_core_lane(SilkChannel *c, int ch, int fs_kHz, const i16 *pulses, int nb_subfr = 4) {
     SilkLds &L = SL();
     const SilkCtrl &k = L.ctrl[ch];
-    const int order = fs_kHz == 16 ? 16 : 10, subfr = 5 * fs_kHz, frame_length = 4 * subfr, ltp_mem = 20 * fs_kHz;
+    const int order = fs_kHz == 16 ? 16 : 10, subfr = 5 * fs_kHz, frame_length = nb_subfr * subfr, ltp_mem = 20 * fs_kHz;
     i16 *xq = &L.xq[ch][2];
     i32 *sLTP_Q15 = L.u.core.sLTP_Q15[ch];
     i16 *sLTP = L.u.core.sLTP[ch];
@@ -684,7 +688,7 @@ OG_DEVN void silk_decode_core_lane(SilkChannel *c, int ch, int fs_kHz, const i16
     i32 rand_seed = k.Seed;
     i32 prev_gain_Q16 = c->prev_gain_Q16;
     int sLTP_buf_idx = ltp_mem, lag = 0, pos = 0;
-    for (int sf = 0; sf < 4; sf++) {
+    for (int sf = 0; sf < nb_subfr; sf++) {
         const i16 *A_Q12 = k.PredCoef_Q12[sf >> 1];
         const i16 *B_Q14 = &k.LTPCoef_Q14[sf * 5];
         const i32 Gain_Q16 = k.Gains_Q16[sf], Gain_Q10 = Gain_Q16 >> 6;
@@ -760,7 +764,7 @@ OG_DEVN void silk_decode_core_lane(SilkChannel *c, int ch, int fs_kHz, const i16
     for (int j = 0; j < SILK_MAX_LPC; j++) c->sLPC_Q14_buf[SILK_MAX_LPC - 1 - j] = sLPC[j];
     c->prev_gain_Q16 = prev_gain_Q16;
     (void)frame_length; // outBuf update happens lane-parallel in the caller
-    c->lagPrev = k.pitchL[3];
+    c->lagPrev = k.pitchL[nb_subfr - 1];
     c->prevSignalType = k.signalType;
     c->first_frame_after_reset = 0;
 }
@@ -1101,16 +1105,26 @@ OG_DEV void silk_stereo_decode_pred(Rc &rc, i32 pred_Q13[2]) { // silk.cpp:592
 // Decode one 20 ms SILK frame (mid + side / mono) into S.pcm_silk (48 kHz, interleaved when stereo).
 // Returns 0 or a non-zero error (wave-uniform).
 // `rec` != null: the frame's entropy half comes from the parse kernel's record and `rc` is not touched.
-// REC_ONLY: the instantiation of the split path's synthesis kernel -- `rec` is always there, none of the wave-uniform
-// entropy decoding is compiled in, and neither is its LDS object (PW()).
-template <bool REC_ONLY = false>
-OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz, const SilkRec *rec = nullptr) {
+// silk_Decode silk.cpp:1481 for one Opus frame: the packet header, then its internal SILK frames one after the other.
+// payload_ms: 20 in reference mode (the reference pins it, Q6); RFC mode also 10 (two subframes), 40 and 60 (two / three
+// internal frames of 20 ms; silk.cpp:1522-1540 derives both from payloadSize_ms).  After every internal frame its 48 kHz PCM
+// (interleaved over `channels`) is in SL().u.out.pcm and `emit(frame index, samples per channel)` is called.
+// REC_ONLY: the instantiation of the split path's synthesis kernel -- `rec` is always there (one 20 ms frame), none of the
+// wave-uniform entropy decoding is compiled in, and neither is its LDS object (PW()).
+// silk_LBRR_flags_2_iCDF / _3_iCDF (RFC 6716 table 4); only packets of two / three internal frames read them
+OPUS_ROM uint8_t rom_silk_lbrr_flags_2_icdf[3] = {203, 150, 0};
+OPUS_ROM uint8_t rom_silk_lbrr_flags_3_icdf[7] = {215, 195, 166, 125, 110, 82, 0};
+
+template <bool REC_ONLY, class Emit>
+OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_hz, int payload_ms, const SilkRec *rec, Emit &&emit) {
     SilkLds &L = SL();
     const int fs_kHz = (internal_hz >> 10) + 1;
     if (fs_kHz != 8 && fs_kHz != 12 && fs_kHz != 16) return -200;
-    const int frame_length = 20 * fs_kHz;
+    const int nF = (REC_ONLY || rec) ? 1 : payload_ms == 40 ? 2 : payload_ms == 60 ? 3 : 1;
+    const int nb_subfr = (REC_ONLY || rec) ? 4 : payload_ms == 10 ? 2 : 4;
+    const int frame_length = nb_subfr * 5 * fs_kHz, ltp_mem = 20 * fs_kHz;
     OG_SYNC();
-    // first (and only) frame of the packet: nFramesDecoded = 0 for the coded channels
+    // first frame of the packet: nFramesDecoded = 0 for the coded channels
     if (channels > s->nChannelsInternal) silk_chan_init(&s->ch[1]);
     for (int n = 0; n < channels; n++) silk_set_fs(&s->ch[n], fs_kHz);
     if (channels == 2 && (s->nChannelsAPI == 1 || s->nChannelsInternal == 1)) {
@@ -1129,7 +1143,7 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz,
         lastGain[n] = s->ch[n].LastGainIndex;
         ffar[n] = s->ch[n].first_frame_after_reset;
     }
-    int vad[2] = {0, 0}, lbrr[2] = {0, 0};
+    int vad[2][3] = {{0, 0, 0}, {0, 0, 0}}, lbrr[2][3] = {{0, 0, 0}, {0, 0, 0}};
     OG_MARK(30);
     i32 MS_pred_Q13[2] = {0, 0};
     int decode_only_middle = 0;
@@ -1142,198 +1156,242 @@ OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz,
             ecLag[n] = OG_UNI(rec->ch[n].ec_prevLagIndex);
         }
     } else if constexpr (!REC_ONLY) {
-    for (int n = 0; n < channels; n++) {
-        vad[n] = rc_bit_logp(rc, 1);
-        lbrr[n] = rc_bit_logp(rc, 1);
+        int lbrr_flag[2] = {0, 0};
+        for (int n = 0; n < channels; n++) { // silk.cpp:1568-1573: every channel's VAD flags and LBRR flag first
+            for (int i = 0; i < nF; i++) vad[n][i] = rc_bit_logp(rc, 1);
+            lbrr_flag[n] = rc_bit_logp(rc, 1);
+        }
+        for (int n = 0; n < channels; n++) // then, per channel, which of its frames carry LBRR data (silk.cpp:1576-1586)
+            if (lbrr_flag[n]) {
+                if (nF == 1)
+                    lbrr[n][0] = 1;
+                else {
+                    const int sym = rc_icdf(rc, nF == 2 ? rom_silk_lbrr_flags_2_icdf : rom_silk_lbrr_flags_3_icdf, 8) + 1;
+                    for (int i = 0; i < nF; i++) lbrr[n][i] = (sym >> i) & 1;
+                }
+            }
+        for (int i = 0; i < nF; i++) // regular decoding reads past the LBRR frames (silk.cpp:1590-1616)
+            for (int n = 0; n < channels; n++)
+                if (lbrr[n][i]) {
+                    if (channels == 2 && n == 0) {
+                        silk_stereo_decode_pred(rc, MS_pred_Q13);
+                        if (lbrr[1][i] == 0) decode_only_middle = rc_icdf(rc, rom_silk_mid_only_icdf, 8);
+                    }
+                    const int condCoding = (i > 0 && lbrr[n][i - 1]) ? 2 : 0;
+                    silk_decode_indices(&s->ch[n], L.ctrl[n], rc, fs_kHz, vad[n][i], 1, condCoding, ecType[n], ecLag[n], nb_subfr);
+                    silk_decode_pulses(rc, n, L.ctrl[n].signalType, L.ctrl[n].quantOffsetType, frame_length);
+                }
     }
-    for (int n = 0; n < channels; n++) { // regular decoding reads past the LBRR frame (silk.cpp:1590-1616)
-        if (lbrr[n]) {
-            if (channels == 2 && n == 0) {
+    int prev_dom = s->prev_decode_only_middle;
+    for (int fi = 0; fi < nF; fi++) {
+        if constexpr (!REC_ONLY) {
+            if (!rec && channels == 2) {
                 silk_stereo_decode_pred(rc, MS_pred_Q13);
-                if (lbrr[1] == 0) decode_only_middle = rc_icdf(rc, rom_silk_mid_only_icdf, 8);
+                decode_only_middle = vad[1][fi] == 0 ? rc_icdf(rc, rom_silk_mid_only_icdf, 8) : 0;
             }
-            silk_decode_indices(&s->ch[n], L.ctrl[n], rc, fs_kHz, vad[n], 1, 0, ecType[n], ecLag[n]);
-            silk_decode_pulses(rc, n, L.ctrl[n].signalType, L.ctrl[n].quantOffsetType, frame_length);
         }
-    }
-    if (channels == 2) {
-        silk_stereo_decode_pred(rc, MS_pred_Q13);
-        decode_only_middle = vad[1] == 0 ? rc_icdf(rc, rom_silk_mid_only_icdf, 8) : 0;
-    }
-    }
-    const int prev_dom = s->prev_decode_only_middle;
-    if (channels == 2 && decode_only_middle == 0 && prev_dom == 1) { // side channel restarts (silk.cpp:1639)
-        SilkChannel *c1 = &s->ch[1];
+        const int restart_side = channels == 2 && decode_only_middle == 0 && prev_dom == 1;
+        if (restart_side) { // side channel restarts (silk.cpp:1639)
+            SilkChannel *c1 = &s->ch[1];
+            OG_SYNC();
+            OG_FOR_LANES(i, 320) c1->outBuf[i] = 0;
+            OG_FOR_LANES(i, 16) c1->sLPC_Q14_buf[i] = 0;
+            if (OG_LANE == 0) {
+                c1->lagPrev = 100;
+                c1->prevSignalType = 0;
+            }
+            OG_SYNC();
+            lastGain[1] = 10;
+            ffar[1] = 1;
+        }
+        const int has_side = !decode_only_middle;
+        for (int n = 0; n < channels; n++) {
+            L.ctrl[n].coded = (n == 0 || has_side);
+            if (L.ctrl[n].coded) {
+                // FrameIndex = channel 0's nFramesDecoded - n, and channel 0's count has been stepped by the time channel 1
+                // gets here (silk.cpp:1676-1700): the frame's index for both; <= 0 -> independent coding
+                const int FrameIndex = fi;
+                const int condCoding = FrameIndex <= 0 ? 0 : (n > 0 && prev_dom) ? 1 : 2;
+                OG_MARK(30);
+                if (REC_ONLY || rec) { // parameters + indices (68 words laid out like SilkCtrl) from the record
+                    OG_SYNC();
+                    const i32 *src = rec->ch[n].pitchL;
+                    i32 *dst = L.ctrl[n].pitchL;
+                    OG_FOR_LANES(i, SILK_REC_CTRL_WORDS) dst[i] = src[i];
+                    lastGain[n] = OG_UNI(rec->ch[n].LastGainIndex);
+                    OG_FOR_LANES(i, fs_kHz == 16 ? 16 : 10) s->ch[n].prevNLSF_Q15[i] = rec->ch[n].nlsf[i];
+                    OG_SYNC();
+                } else if constexpr (!REC_ONLY) {
+                    silk_decode_indices(&s->ch[n], L.ctrl[n], rc, fs_kHz, vad[n][fi], 0, condCoding, ecType[n], ecLag[n], nb_subfr);
+                    OG_MARK(31);
+                    silk_decode_pulses(rc, n, L.ctrl[n].signalType, L.ctrl[n].quantOffsetType, frame_length);
+                    OG_MARK(32);
+                    silk_decode_parameters<SilkParWave>(s->ch[n].prevNLSF_Q15, L.ctrl[n], fs_kHz, condCoding, lastGain[n], ffar[n],
+                                                        nb_subfr);
+                    OG_SYNC();
+                    OG_FOR_LANES(i, fs_kHz == 16 ? 16 : 10) s->ch[n].prevNLSF_Q15[i] = PW().nlsf[i];
+                    OG_SYNC();
+                }
+                ffar[n] = 0; // (the synthesis below clears it in the state)
+                OG_MARK(33);
+            }
+        }
         OG_SYNC();
-        OG_FOR_LANES(i, 320) c1->outBuf[i] = 0;
-        OG_FOR_LANES(i, 16) c1->sLPC_Q14_buf[i] = 0;
         if (OG_LANE == 0) {
-            c1->lagPrev = 100;
-            c1->prevSignalType = 0;
+            for (int n = 0; n < 2; n++) {
+                s->ch[n].ec_prevSignalType = ecType[n];
+                s->ch[n].ec_prevLagIndex = ecLag[n];
+                s->ch[n].LastGainIndex = lastGain[n];
+            }
+            if (restart_side) s->ch[1].first_frame_after_reset = 1;
         }
         OG_SYNC();
-        lastGain[1] = 10;
-        ffar[1] = 1;
-    }
-    const int has_side = !decode_only_middle;
-    for (int n = 0; n < channels; n++) {
-        L.ctrl[n].coded = (n == 0 || has_side);
-        if (L.ctrl[n].coded) {
-            // FrameIndex = nFramesDecoded - n = -n <= 0 -> independent coding (silk.cpp:1678-1681)
-            const int condCoding = 0;
-            OG_MARK(30);
-            if (REC_ONLY || rec) { // parameters + indices (68 words laid out like SilkCtrl) from the record
-                OG_SYNC();
-                const i32 *src = rec->ch[n].pitchL;
-                i32 *dst = L.ctrl[n].pitchL;
-                OG_FOR_LANES(i, SILK_REC_CTRL_WORDS) dst[i] = src[i];
-                lastGain[n] = OG_UNI(rec->ch[n].LastGainIndex);
-                OG_FOR_LANES(i, fs_kHz == 16 ? 16 : 10) s->ch[n].prevNLSF_Q15[i] = rec->ch[n].nlsf[i];
-                OG_SYNC();
-            } else if constexpr (!REC_ONLY) {
-                silk_decode_indices(&s->ch[n], L.ctrl[n], rc, fs_kHz, vad[n], 0, condCoding, ecType[n], ecLag[n]);
-                OG_MARK(31);
-                silk_decode_pulses(rc, n, L.ctrl[n].signalType, L.ctrl[n].quantOffsetType, frame_length);
-                OG_MARK(32);
-                silk_decode_parameters<SilkParWave>(s->ch[n].prevNLSF_Q15, L.ctrl[n], fs_kHz, condCoding, lastGain[n], ffar[n]);
-                OG_SYNC();
-                OG_FOR_LANES(i, fs_kHz == 16 ? 16 : 10) s->ch[n].prevNLSF_Q15[i] = PW().nlsf[i];
-                OG_SYNC();
-            }
-            OG_MARK(33);
+        // ---- synthesis: stage the output history, then lane n = channel n
+        OG_MARK(34);
+        // where the channels' pulses are: in the parse record (read where they lie, in HBM) or in the row they were decoded into
+        const i16 *pulse_row[2];
+        if constexpr (REC_ONLY) {
+            pulse_row[0] = rec->ch[0].pulses;
+            pulse_row[1] = rec->ch[1].pulses;
+        } else {
+            pulse_row[0] = rec ? rec->ch[0].pulses : PW().pulses[0];
+            pulse_row[1] = rec ? rec->ch[1].pulses : PW().pulses[1];
         }
-    }
-    OG_SYNC();
-    if (OG_LANE == 0) {
-        for (int n = 0; n < 2; n++) {
-            s->ch[n].ec_prevSignalType = ecType[n];
-            s->ch[n].ec_prevLagIndex = ecLag[n];
-            s->ch[n].LastGainIndex = lastGain[n];
-        }
-        if (channels == 2 && decode_only_middle == 0 && prev_dom == 1) s->ch[1].first_frame_after_reset = 1;
-    }
-    OG_SYNC();
-    // ---- synthesis: stage the output history, then lane n = channel n
-    OG_MARK(34);
-    // where the channels' pulses are: in the parse record (read where they lie, in HBM) or in the row they were decoded into
-    const i16 *pulse_row[2];
-    if constexpr (REC_ONLY) {
-        pulse_row[0] = rec->ch[0].pulses;
-        pulse_row[1] = rec->ch[1].pulses;
-    } else {
-        pulse_row[0] = rec ? rec->ch[0].pulses : PW().pulses[0];
-        pulse_row[1] = rec ? rec->ch[1].pulses : PW().pulses[1];
-    }
-    for (int n = 0; n < channels; n++)
-        if (L.ctrl[n].coded) OG_FOR_LANES(i, frame_length) L.u.core.hist[n][i] = s->ch[n].outBuf[i];
-    OG_SYNC();
+        for (int n = 0; n < channels; n++)
+            if (L.ctrl[n].coded) OG_FOR_LANES(i, ltp_mem) L.u.core.hist[n][i] = s->ch[n].outBuf[i];
+        OG_SYNC();
 #ifdef OG_HOST_EMUL
-    OG_FOR_LANES(n, channels) {
-        if (L.ctrl[n].coded)
-            silk_decode_core_lane(&s->ch[n], n, fs_kHz, pulse_row[n]);
-        else
-            for (int i = 0; i < frame_length; i++) L.xq[n][2 + i] = 0;
-    }
+        OG_FOR_LANES(n, channels) {
+            if (L.ctrl[n].coded)
+                silk_decode_core_lane(&s->ch[n], n, fs_kHz, pulse_row[n], nb_subfr);
+            else
+                for (int i = 0; i < frame_length; i++) L.xq[n][2 + i] = 0;
+        }
 #else
-    silk_decode_core_rows(s, fs_kHz, channels, pulse_row[0], pulse_row[1]);
-#endif
-    OG_SYNC();
-    OG_TAP(40); // decoder control + core output of every coded channel (host emulation only)
-    OG_MARK(35);
-    // outBuf update (silk.cpp:2031-2034): ltp_mem_length == frame_length, so the history is exactly this frame
-    for (int n = 0; n < channels; n++)
-        if (L.ctrl[n].coded) OG_FOR_LANES(i, frame_length) s->ch[n].outBuf[i] = L.xq[n][2 + i];
-    OG_SYNC();
-    // ---- stereo un-mixing (silk_stereo_MS_to_LR silk.cpp:4028) or mono look-back buffering (:1705)
-    if (channels == 2) {
-        i16 *x1 = L.xq[0], *x2 = L.xq[1];
-        if (OG_LANE == 0) {
-            x1[0] = s->sMid[0]; x1[1] = s->sMid[1];
-            x2[0] = s->sSide[0]; x2[1] = s->sSide[1];
-            s->sMid[0] = x1[frame_length]; s->sMid[1] = x1[frame_length + 1];
-            s->sSide[0] = x2[frame_length]; s->sSide[1] = x2[frame_length + 1];
-        }
-        const i32 pp0 = s->pred_prev_Q13[0], pp1 = s->pred_prev_Q13[1];
-        const i32 denom_Q16 = (1 << 16) / (8 * fs_kHz);
-        const i32 delta0 = rshift_round(smulbb(MS_pred_Q13[0] - pp0, denom_Q16), 16);
-        const i32 delta1 = rshift_round(smulbb(MS_pred_Q13[1] - pp1, denom_Q16), 16);
-        OG_SYNC();
-        i32 side_new[(SILK_MAX_FRAME + OG_NLANES - 1) / OG_NLANES]; // each lane holds its own results until every lane has read the old side signal
-        int cnt = 0;
-        OG_FOR_LANES(n, frame_length) {
-            const i32 p0 = n < 8 * fs_kHz ? pp0 + (n + 1) * delta0 : MS_pred_Q13[0];
-            const i32 p1 = n < 8 * fs_kHz ? pp1 + (n + 1) * delta1 : MS_pred_Q13[1];
-            i32 sum = shl32(((i32)x1[n] + (i32)x1[n + 2]) + shl32((i32)x1[n + 1], 1), 9);
-            sum = smlawb(shl32((i32)x2[n + 1], 8), sum, p0);
-            sum = smlawb(sum, shl32((i32)x1[n + 1], 11), p1);
-            side_new[cnt++] = sat16(rshift_round(sum, 8));
-        }
-        OG_SYNC();
-        cnt = 0;
-        OG_FOR_LANES(n, frame_length) {
-            const i32 m = x1[n + 1], sd = side_new[cnt++];
-            x1[n + 1] = (i16)sat16(m + sd);
-            x2[n + 1] = (i16)sat16(m - sd);
-        }
-        if (OG_LANE == 0) {
-            s->pred_prev_Q13[0] = tr16(MS_pred_Q13[0]);
-            s->pred_prev_Q13[1] = tr16(MS_pred_Q13[1]);
-        }
-        OG_SYNC();
-    } else {
-        if (OG_LANE == 0) {
-            i16 *x1 = L.xq[0];
-            x1[0] = s->sMid[0]; x1[1] = s->sMid[1];
-            s->sMid[0] = x1[frame_length]; s->sMid[1] = x1[frame_length + 1];
-        }
-        OG_SYNC();
-    }
-    // ---- resample to 48 kHz: 2x all-pass per channel (serial in time), then lane-parallel FIR interpolation
-    OG_MARK(36);
-#ifdef OG_HOST_EMUL
-    OG_FOR_LANES(n, channels) silk_up2_lane(&s->ch[n], n, frame_length);
-#else
-    silk_up2_rows(s, channels, frame_length);
-#endif
-    OG_SYNC();
-    OG_MARK(37);
-    {
-        const i32 inv = s->ch[0].rs_invRatio_Q16; // both channels run at the same rate
-        // batches of the reference: [0, fs_kHz), then chunks of 10*fs_kHz (silk.cpp:3676, :3475)
-        int t0 = 0, out0 = 0;
-        while (t0 < frame_length) {
-            const int nIn = t0 == 0 ? fs_kHz : OG_MIN(frame_length - t0, 10 * fs_kHz);
-            const i32 max_index_Q16 = shl32(nIn, 17);
-            const int count = (int)udiv((u32)max_index_Q16 + (u32)inv - 1u, (u32)inv);
-            OG_FOR_LANES(id, count * channels) {
-                const int n = id / count, m = id - n * count;
-                const i32 index_Q16 = m * inv;
-                const int t = smulwb(index_Q16 & 0xFFFF, 12);
-                const i16 *b = &L.u.out.up[n][2 * t0 + (index_Q16 >> 16)];
-                const i16 *f0 = &rom_silk_frac_fir12[4 * t], *f1 = &rom_silk_frac_fir12[4 * (11 - t)];
-                i32 res = smulbb(b[0], f0[0]);
-                res = smlabb(res, b[1], f0[1]);
-                res = smlabb(res, b[2], f0[2]);
-                res = smlabb(res, b[3], f0[3]);
-                res = smlabb(res, b[4], f1[3]);
-                res = smlabb(res, b[5], f1[2]);
-                res = smlabb(res, b[6], f1[1]);
-                res = smlabb(res, b[7], f1[0]);
-                SL().u.out.pcm[(out0 + m) * channels + n] = (i16)sat16(rshift_round(res, 15));
+        if (nb_subfr == 4)
+            silk_decode_core_rows(s, fs_kHz, channels, pulse_row[0], pulse_row[1]);
+        else { // 10 ms frames (RFC mode only): the one-lane-per-channel form of the core
+            OG_FOR_LANES(n, channels) {
+                if (L.ctrl[n].coded)
+                    silk_decode_core_lane(&s->ch[n], n, fs_kHz, pulse_row[n], nb_subfr);
+                else
+                    for (int i = 0; i < frame_length; i++) L.xq[n][2 + i] = 0;
             }
-            t0 += nIn;
-            out0 += count;
         }
+#endif
+        OG_SYNC();
+        OG_TAP(40); // decoder control + core output of every coded channel (host emulation only)
+        OG_MARK(35);
+        // outBuf update (silk.cpp:2031-2034): the last ltp_mem_length samples -- for 20 ms frames exactly this frame, for 10 ms
+        // frames the second half of the old history (still staged in LDS) followed by this frame
+        for (int n = 0; n < channels; n++)
+            if (L.ctrl[n].coded) {
+                const int keep = ltp_mem - frame_length;
+                OG_FOR_LANES(i, ltp_mem) s->ch[n].outBuf[i] = i < keep ? L.u.core.hist[n][frame_length + i] : L.xq[n][2 + i - keep];
+            }
+        OG_SYNC();
+        // ---- stereo un-mixing (silk_stereo_MS_to_LR silk.cpp:4028) or mono look-back buffering (:1705)
+        if (channels == 2) {
+            i16 *x1 = L.xq[0], *x2 = L.xq[1];
+            if (OG_LANE == 0) {
+                x1[0] = s->sMid[0]; x1[1] = s->sMid[1];
+                x2[0] = s->sSide[0]; x2[1] = s->sSide[1];
+                s->sMid[0] = x1[frame_length]; s->sMid[1] = x1[frame_length + 1];
+                s->sSide[0] = x2[frame_length]; s->sSide[1] = x2[frame_length + 1];
+            }
+            const i32 pp0 = s->pred_prev_Q13[0], pp1 = s->pred_prev_Q13[1];
+            const i32 denom_Q16 = (1 << 16) / (8 * fs_kHz);
+            const i32 delta0 = rshift_round(smulbb(MS_pred_Q13[0] - pp0, denom_Q16), 16);
+            const i32 delta1 = rshift_round(smulbb(MS_pred_Q13[1] - pp1, denom_Q16), 16);
+            OG_SYNC();
+            i32 side_new[(SILK_MAX_FRAME + OG_NLANES - 1) / OG_NLANES]; // each lane holds its own results until every lane has read the old side signal
+            int cnt = 0;
+            OG_FOR_LANES(n, frame_length) {
+                const i32 p0 = n < 8 * fs_kHz ? pp0 + (n + 1) * delta0 : MS_pred_Q13[0];
+                const i32 p1 = n < 8 * fs_kHz ? pp1 + (n + 1) * delta1 : MS_pred_Q13[1];
+                i32 sum = shl32(((i32)x1[n] + (i32)x1[n + 2]) + shl32((i32)x1[n + 1], 1), 9);
+                sum = smlawb(shl32((i32)x2[n + 1], 8), sum, p0);
+                sum = smlawb(sum, shl32((i32)x1[n + 1], 11), p1);
+                side_new[cnt++] = sat16(rshift_round(sum, 8));
+            }
+            OG_SYNC();
+            cnt = 0;
+            OG_FOR_LANES(n, frame_length) {
+                const i32 m = x1[n + 1], sd = side_new[cnt++];
+                x1[n + 1] = (i16)sat16(m + sd);
+                x2[n + 1] = (i16)sat16(m - sd);
+            }
+            if (OG_LANE == 0) {
+                s->pred_prev_Q13[0] = tr16(MS_pred_Q13[0]);
+                s->pred_prev_Q13[1] = tr16(MS_pred_Q13[1]);
+            }
+            OG_SYNC();
+        } else {
+            if (OG_LANE == 0) {
+                i16 *x1 = L.xq[0];
+                x1[0] = s->sMid[0]; x1[1] = s->sMid[1];
+                s->sMid[0] = x1[frame_length]; s->sMid[1] = x1[frame_length + 1];
+            }
+            OG_SYNC();
+        }
+        // ---- resample to 48 kHz: 2x all-pass per channel (serial in time), then lane-parallel FIR interpolation
+        OG_MARK(36);
+#ifdef OG_HOST_EMUL
+        OG_FOR_LANES(n, channels) silk_up2_lane(&s->ch[n], n, frame_length);
+#else
+        silk_up2_rows(s, channels, frame_length);
+#endif
+        OG_SYNC();
+        OG_MARK(37);
+        int out_total = 0;
+        {
+            const i32 inv = s->ch[0].rs_invRatio_Q16; // both channels run at the same rate
+            // batches of the reference: [0, fs_kHz), then chunks of 10*fs_kHz (silk.cpp:3676, :3475)
+            int t0 = 0, out0 = 0;
+            while (t0 < frame_length) {
+                const int nIn = t0 == 0 ? fs_kHz : OG_MIN(frame_length - t0, 10 * fs_kHz);
+                const i32 max_index_Q16 = shl32(nIn, 17);
+                const int count = (int)udiv((u32)max_index_Q16 + (u32)inv - 1u, (u32)inv);
+                OG_FOR_LANES(id, count * channels) {
+                    const int n = id / count, m = id - n * count;
+                    const i32 index_Q16 = m * inv;
+                    const int t = smulwb(index_Q16 & 0xFFFF, 12);
+                    const i16 *b = &L.u.out.up[n][2 * t0 + (index_Q16 >> 16)];
+                    const i16 *f0 = &rom_silk_frac_fir12[4 * t], *f1 = &rom_silk_frac_fir12[4 * (11 - t)];
+                    i32 res = smulbb(b[0], f0[0]);
+                    res = smlabb(res, b[1], f0[1]);
+                    res = smlabb(res, b[2], f0[2]);
+                    res = smlabb(res, b[3], f0[3]);
+                    res = smlabb(res, b[4], f1[3]);
+                    res = smlabb(res, b[5], f1[2]);
+                    res = smlabb(res, b[6], f1[1]);
+                    res = smlabb(res, b[7], f1[0]);
+                    SL().u.out.pcm[(out0 + m) * channels + n] = (i16)sat16(rshift_round(res, 15));
+                }
+                t0 += nIn;
+                out0 += count;
+            }
+            out_total = out0;
+        }
+        OG_SYNC();
+        OG_MARK(38);
+        prev_dom = decode_only_middle;
+        if (OG_LANE == 0) s->prev_decode_only_middle = decode_only_middle;
+        emit(fi, out_total);
+        OG_SYNC();
     }
-    OG_SYNC();
-    OG_MARK(38);
     if (OG_LANE == 0) {
         s->nChannelsAPI = channels;
         s->nChannelsInternal = channels;
-        s->prev_decode_only_middle = decode_only_middle;
     }
     OG_SYNC();
     return 0;
+}
+
+// one 20 ms frame per packet: what the reference decodes (Q6)
+template <bool REC_ONLY = false>
+OG_DEV int silk_decode_20ms(SilkState *s, Rc &rc, int channels, int internal_hz, const SilkRec *rec = nullptr) {
+    return silk_decode_packet<REC_ONLY>(s, rc, channels, internal_hz, 20, rec, [](int, int) {});
 }
 
 } // namespace og

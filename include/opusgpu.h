@@ -38,7 +38,8 @@ extern "C" {
 typedef struct opusgpu_ctx opusgpu_ctx;
 
 /* One frame of work for one stream in one decode step (16 bytes, device layout).
- * flags: bits 0-1 mode (0 SILK-only, 1 hybrid, 2 CELT-only); bits 2-4 bandwidth (0 NB .. 4 FB); bit 5 stereo.
+ * flags: bits 0-1 mode (0 SILK-only, 1 hybrid, 2 CELT-only); bits 2-4 bandwidth (0 NB .. 4 FB); bit 5 stereo;
+ * bits 6-9: frame duration and the RFC bit, zero in reference mode (see OPUSGPU_MODE_RFC).
  * These are the TOC fields opus_decode_native derives (src/opus_decoder.cpp:312-315). */
 typedef struct opusgpu_frame_desc {
     int32_t stream;  /* stream index in the context */
@@ -53,6 +54,26 @@ int opusgpu_version(void);
 int opusgpu_ctx_create(int device, opusgpu_ctx **out);
 void opusgpu_ctx_destroy(opusgpu_ctx *ctx);
 const char *opusgpu_last_error(const opusgpu_ctx *ctx);
+
+/* ---- RFC mode (opt-in, off by default) ---------------------------------------------------------
+ * The reference decodes every frame as 20 ms whatever its TOC says (src/opus_decoder.cpp:161, :186, :341; Q6).  With
+ * OPUSGPU_MODE_RFC set, frames decode at the duration the TOC names -- CELT 2.5 / 5 / 10 / 20 ms, SILK 10 / 20 / 40 / 60 ms
+ * (src/silk.cpp:1522-1540 with the real payload duration), hybrid 10 / 20 ms -- multi-frame packets (codes 1 - 3) accordingly;
+ * CELT's last band follows the bandwidth (Q1 fixed) and a SILK-only frame after a hybrid one fades the CELT layer out with the
+ * two-byte silence frame of RFC 6716 section 4.5.2 instead of Q4's frame off the stale coder.  Everything else stays as the
+ * reference has it (redundancy ignored: Q2; no loss concealment: Q8).  The reference cannot produce these outputs and no
+ * libopus exists in the image: this mode is bit-exact to oracle/'s RFC mode (oc_decoder_set_rfc), which is PARITY-UNPINNED.
+ * RFC-mode frames run on the single-kernel path (wave-uniform entropy decoding): the mode is for completeness, not speed.
+ * Applies to opusgpu_packet_to_frames_mode / opusgpu_decode_packets / opusgpu_decode_step_device calls made after it is set:
+ *   - descriptors carry the duration and the mode bit (frame_desc.flags bits 6 - 9);
+ *   - opusgpu_decode_packets: result[i] and the PCM block of packet i hold the packet's true sample count (<= 5760);
+ *   - opusgpu_decode_step_device: d_pcm is [n][OPUSGPU_RFC_FRAME_SAMPLES * channels] (room for a 60 ms frame), d_result[f]
+ *     the frame's sample count. */
+#define OPUSGPU_MODE_REFERENCE 0
+#define OPUSGPU_MODE_RFC 1
+#define OPUSGPU_RFC_FRAME_SAMPLES 2880
+int opusgpu_set_mode(opusgpu_ctx *ctx, int mode);
+int opusgpu_get_mode(const opusgpu_ctx *ctx);
 
 /* ---- streams -------------------------------------------------------------------------------- */
 /* Allocates `n_streams` per-stream state records in HBM (replacing any previous set) and gives each
@@ -84,6 +105,9 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
  * (src/opus_decoder.cpp:559, :135, :460, :474).  descs[k].offset is relative to the packet start.
  * Returns the frame count (1..48) or a negative OPUS_* code.  Pure host code. */
 int opusgpu_packet_to_frames(const uint8_t *packet, int32_t len, int32_t stream, opusgpu_frame_desc descs[48]);
+/* The same for a given mode (OPUSGPU_MODE_*): in RFC mode the descriptors carry the frames' duration (flags bits 6 - 8: 0 20 ms,
+ * 1 2.5, 2 5, 3 10, 4 40, 5 60) and the RFC bit (bit 9). */
+int opusgpu_packet_to_frames_mode(const uint8_t *packet, int32_t len, int32_t stream, int mode, opusgpu_frame_desc descs[48]);
 
 /* ---- device-resident path (inputs and outputs stay in HBM; used by bench.py and on-device consumers) -- */
 int opusgpu_dev_alloc(opusgpu_ctx *ctx, size_t bytes, void **dptr);

@@ -38,6 +38,7 @@ void oc_celt_init(oc_celt *st, int channels) { /* celt.cpp:1933: clear everythin
     st->channels = channels;
     st->stream_channels = channels;
     st->disable_inv = channels == 1;
+    st->end_band = NB;
     oc_celt_reset(st);
 }
 
@@ -1082,7 +1083,8 @@ int oc_celt_decode(oc_celt *st, oc_rc *rc, i16 *pcm, int frame_size, oc_celt_tap
     i32 tf_res[NB], cap[NB], offsets[NB], fine_quant[NB], pulses[NB], fine_priority[NB];
     u8 collapse_masks[2 * NB];
     i16 *bandE = st->bandE, *logE1 = st->logE1, *logE2 = st->logE2;
-    int c, i, N, LM, M, start = st->start_band, end = NB, effEnd = NB;
+    /* the reference ignores its END_BAND request and always decodes 21 bands (Q1); RFC mode sets end_band by bandwidth */
+    int c, i, N, LM, M, start = st->start_band, end = (st->end_band > 0 && st->end_band <= NB) ? st->end_band : NB, effEnd = end;
     int spread, shortBlocks, transient, intra, codedBands, alloc_trim, pf_pitch = 0, pf_tapset = 0;
     i16 pf_gain = 0;
     i32 intensity = 0, dual_stereo = 0, total_bits, balance, tell, bits;

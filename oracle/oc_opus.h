@@ -70,6 +70,7 @@ typedef struct {
     i32 channels;          /* CC: output channels of the decoder */
     i32 stream_channels;   /* C : channels coded in the packet */
     i32 start_band;
+    i32 end_band;          /* 21 in reference mode (Q1); by bandwidth in RFC mode */
     i32 disable_inv;
     u32 rng;
     i32 error;
@@ -113,10 +114,15 @@ int oc_silk_sizeof(void);
 void oc_silk_init(oc_silk *s);                           /* silk_InitDecoder silk.cpp:1792 */
 /* silk_Decode silk.cpp:1481 with lostFlag=0, API rate 48 kHz, 20 ms payload; first = first frame in packet */
 int oc_silk_decode(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int first, i16 *out, i32 *n_out);
+/* the same with the packet's true payload duration (RFC mode): 10 ms -> two subframes, 40 / 60 ms -> two / three internal
+ * frames per packet, one call each (silk.cpp:1522-1540 sets nFramesPerPacket / nb_subfr from payloadSize_ms; the reference
+ * pins that to 20).  NOT pinned by any reference output: written from RFC 6716 section 4.2. */
+int oc_silk_decode_ms(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int first, int payload_ms, i16 *out, i32 *n_out);
 
 /* ---- packet layer (opus_decoder.cpp) ------------------------------------------------------ */
 typedef struct oc_decoder {
     i32 channels;
+    i32 rfc;               /* 0: reference-exact (every frame decodes as 20 ms, Q6); 1: RFC mode, see oc_decoder_set_rfc */
     i32 stream_channels, bandwidth, mode, prev_mode, frame_size, last_packet_duration;
     u32 range_final;
     oc_rc rc;              /* the reference's global s_ec: survives between frames (Q4) */
@@ -129,6 +135,12 @@ oc_decoder *oc_decoder_create(int channels);             /* fresh state == opus_
 void oc_decoder_destroy(oc_decoder *d);
 void oc_decoder_init(oc_decoder *d, int channels);       /* opus_decoder_init opus_decoder.cpp:82 */
 void oc_decoder_reset(oc_decoder *d);                    /* OPUS_RESET_STATE  opus_decoder.cpp:382 */
+/* RFC mode (PARITY UNPINNED -- the reference cannot do this and no libopus exists in the image): frames decode
+ * at the duration their TOC names (CELT 2.5 / 5 / 10 / 20 ms, SILK 10 / 20 / 40 / 60 ms, hybrid 10 / 20 ms), multi-frame
+ * packets accordingly; CELT's last band follows the bandwidth (13 / 17 / 19 / 21: Q1 fixed); a SILK-only frame after a hybrid
+ * one fades the CELT layer out with the two-byte silence frame (RFC 6716 section 4.5.2) instead of Q4's stale-coder frame.
+ * Everything else stays as the reference has it (Q2, Q3, Q5, Q7).  Survives oc_decoder_init / _reset. */
+void oc_decoder_set_rfc(oc_decoder *d, int on);
 /* opus_decode_native (opus_decoder.cpp:280) for one elementary stream; returns samples/channel or <0 */
 int oc_decode(oc_decoder *d, const u8 *data, i32 len, i16 *pcm, int frame_size);
 int oc_packet_parse(const u8 *data, i32 len, int self_delimited, u8 *out_toc, i16 size[48],

@@ -149,10 +149,14 @@ int oc_packet_parse(const u8 *data, i32 len, int self_delimited, u8 *out_toc, i1
 }
 
 /* ---- decoder object ----------------------------------------------------------------------- */
+void oc_decoder_set_rfc(oc_decoder *d, int on) { d->rfc = on ? 1 : 0; }
+
 void oc_decoder_init(oc_decoder *d, int channels) { /* opus_decoder.cpp:82 */
     oc_silk *silk = d->silk;
     oc_celt_taps *taps = d->taps;
+    const i32 rfc = d->rfc;
     memset(d, 0, sizeof(*d));
+    d->rfc = rfc;
     d->silk = silk;
     d->taps = taps;
     d->channels = d->stream_channels = channels;
@@ -190,11 +194,28 @@ void oc_decoder_destroy(oc_decoder *d) {
     free(d);
 }
 
-/* opus_decoder.cpp:154 */
+/* RFC mode: CELT's last band by audio bandwidth (RFC 6716 section 4.3: NB 13, WB 17, SWB 19, FB 21 bands; the CELT-only
+ * "medium band" code point does not exist, and hybrid is SWB or FB) */
+static int rfc_end_band(int bandwidth) {
+    switch (bandwidth) {
+        case OC_BW_NB: return 13;
+        case OC_BW_MB:
+        case OC_BW_WB: return 17;
+        case OC_BW_SWB: return 19;
+        default: return 21;
+    }
+}
+
+/* opus_decoder.cpp:154.  Reference mode: audiosize is 960 whatever the TOC says (Q6).  RFC mode: the TOC's duration. */
 static int decode_frame(oc_decoder *d, const u8 *inbuf, i32 len, i16 *out) {
-    const int mode = d->mode, ch = d->stream_channels, audiosize = 960;
+    const int mode = d->mode, ch = d->stream_channels, audiosize = d->rfc ? d->frame_size : 960;
+    const int payload_ms = d->rfc ? audiosize / 48 : 20;
+    /* The reference zeroes / mixes 960 * stream_channels entries of `out` even when the decoder has fewer channels (Q3): what
+     * lies beyond the frame's own 960 * channels entries is the next frame's space or past the caller's buffer.  RFC mode
+     * keeps the arithmetic and stays inside the frame (packets of 120 ms fill the buffer to its last entry). */
+    const int nmix = d->rfc ? audiosize * (ch < d->channels ? ch : d->channels) : audiosize * ch;
     int i, celt_ret = 0, start_band;
-    i16 pcm_silk[960 * 2];
+    i16 pcm_silk[2880 * 2];
     oc_rc *rc = &d->rc;
 
     oc_rc_init(rc, inbuf, len);
@@ -210,7 +231,7 @@ static int decode_frame(oc_decoder *d, const u8 *inbuf, i32 len, i16 *out) {
             internal_hz = 16000;
         do {
             i32 n = 0;
-            int ret = oc_silk_decode(d->silk, rc, ch, internal_hz, decoded == 0, p, &n);
+            int ret = oc_silk_decode_ms(d->silk, rc, ch, internal_hz, decoded == 0, payload_ms, p, &n);
             if (ret) return OC_INTERNAL_ERROR;
             p += n * ch;
             decoded += n;
@@ -223,19 +244,27 @@ static int decode_frame(oc_decoder *d, const u8 *inbuf, i32 len, i16 *out) {
     if (mode != OC_MODE_CELT) start_band = 17;
     if (d->bandwidth) d->celt.stream_channels = ch; /* END_BAND request has no effect (Q1) */
     d->celt.start_band = start_band;
+    d->celt.end_band = d->rfc ? rfc_end_band(d->bandwidth) : OC_NBANDS;
 
     if (mode != OC_MODE_SILK) {
         if (mode != d->prev_mode && d->prev_mode > 0) oc_celt_reset(&d->celt);
-        celt_ret = oc_celt_decode(&d->celt, rc, out, audiosize, d->taps);
+        celt_ret = oc_celt_decode(&d->celt, rc, out, audiosize, d->taps); /* (CELT frames are 2.5 - 20 ms) */
     } else {
-        for (i = 0; i < audiosize * ch; i++) out[i] = 0;
-        if (d->prev_mode == OC_MODE_HYBRID) { /* Q4 */
+        for (i = 0; i < nmix; i++) out[i] = 0;
+        if (d->prev_mode == OC_MODE_HYBRID) {
             d->celt.start_band = 0;
-            (void)oc_celt_decode(&d->celt, rc, out, 120, NULL);
+            if (d->rfc) { /* RFC 6716 section 4.5.2: let the MDCT fade out by decoding a silence frame */
+                static const u8 silence[2] = {0xFF, 0xFF};
+                oc_rc rs;
+                oc_rc_init(&rs, silence, 2);
+                d->celt.end_band = OC_NBANDS;
+                (void)oc_celt_decode(&d->celt, &rs, out, 120, NULL);
+            } else /* Q4: the reference runs the 2.5 ms frame off the coder SILK has just used */
+                (void)oc_celt_decode(&d->celt, rc, out, 120, NULL);
         }
     }
     if (mode != OC_MODE_CELT)
-        for (i = 0; i < audiosize * ch; i++) out[i] = sat16((i32)out[i] + pcm_silk[i]);
+        for (i = 0; i < nmix; i++) out[i] = sat16((i32)out[i] + pcm_silk[i]);
     d->prev_mode = mode;
     return celt_ret < 0 ? celt_ret : audiosize;
 }

@@ -893,7 +893,16 @@ static void ms_to_lr(oc_silk *s, i16 x1[], i16 x2[], const i32 pred_Q13[], int f
 
 /* silk_Decode silk.cpp:1481 with lostFlag = FLAG_DECODE_NORMAL, payloadSize_ms = 20, API 48 kHz,
  * nChannelsAPI = nChannelsInternal = channels (src/opus_decoder.cpp:167-169, :203) */
+/* silk_LBRR_flags_2_iCDF / _3_iCDF (RFC 6716 table 4: PDFs {0,53,53,150} and {0,41,20,29,41,15,28,82}) -- only packets of
+ * two / three internal frames read them, which the reference never decodes as such */
+static const u8 lbrr_flags_2_icdf[3] = {203, 150, 0};
+static const u8 lbrr_flags_3_icdf[7] = {215, 195, 166, 125, 110, 82, 0};
+
 int oc_silk_decode(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int first, i16 *out, i32 *n_out) {
+    return oc_silk_decode_ms(s, rc, channels, internal_hz, first, 20, out, n_out);
+}
+
+int oc_silk_decode_ms(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int first, int payload_ms, i16 *out, i32 *n_out) {
     i16 tmp[2][MAX_FRAME + 2 + 16], rs_out[960];
     i32 MS_pred_Q13[2] = {0, 0}, nSamplesOutDec = 0;
     int n, i, decode_only_middle = 0, has_side;
@@ -903,8 +912,9 @@ int oc_silk_decode(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int fir
     if (s->ch[0].nFramesDecoded == 0) {
         for (n = 0; n < channels; n++) {
             int fs_kHz_dec = (internal_hz >> 10) + 1;
-            s->ch[n].nFramesPerPacket = 1;
-            s->ch[n].nb_subfr = 4;
+            /* silk.cpp:1522-1540 with the payload duration the reference pins to 20 ms */
+            s->ch[n].nFramesPerPacket = payload_ms == 40 ? 2 : payload_ms == 60 ? 3 : 1;
+            s->ch[n].nb_subfr = payload_ms == 10 ? 2 : 4;
             if (fs_kHz_dec != 8 && fs_kHz_dec != 12 && fs_kHz_dec != 16) return -200;
             set_fs(&s->ch[n], &s->rs[n], fs_kHz_dec);
         }
@@ -924,7 +934,14 @@ int oc_silk_decode(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int fir
         }
         for (n = 0; n < channels; n++) {
             memset(s->ch[n].LBRR_flags, 0, sizeof(s->ch[n].LBRR_flags));
-            if (s->ch[n].LBRR_flag) s->ch[n].LBRR_flags[0] = 1; /* one frame per packet */
+            if (s->ch[n].LBRR_flag) {
+                if (s->ch[n].nFramesPerPacket == 1)
+                    s->ch[n].LBRR_flags[0] = 1;
+                else { /* silk.cpp:1580-1586 */
+                    int sym = oc_rc_icdf(rc, s->ch[n].nFramesPerPacket == 2 ? lbrr_flags_2_icdf : lbrr_flags_3_icdf, 8) + 1;
+                    for (i = 0; i < s->ch[n].nFramesPerPacket; i++) s->ch[n].LBRR_flags[i] = (sym >> i) & 1;
+                }
+            }
         }
         /* regular decoding: read past the LBRR data (it still updates the entropy-coding context) */
         for (i = 0; i < s->ch[0].nFramesPerPacket; i++) {

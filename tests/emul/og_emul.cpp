@@ -41,6 +41,10 @@ int emu_decode_frame(void *stv, const uint8_t *payload, int len, int mode, int b
     for (int c = 0; c < st->channels; c++) og::celt_post(st, &rec, ret, c, pcm, h ? h->pcm : nullptr, ch);
     return ret;
 }
+// RFC mode (opt-in): one Opus frame at its true duration through the single-kernel code (og_decode.hpp, decode_frame_rfc)
+int emu_decode_frame_rfc(void *st, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm, int frame_size) {
+    return og::decode_frame_rfc((og::StreamState *)st, payload, len, mode, bw, ch, pcm, frame_size);
+}
 int emu_last_record_words(void) { return 0; }
 }
 

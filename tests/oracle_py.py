@@ -35,6 +35,8 @@ class Oracle:
         lib.oc_decoder_reset.restype = None
         lib.oc_decode.argtypes = [vp, C.c_char_p, C.c_int32, vp, C.c_int]
         lib.oc_decode.restype = C.c_int
+        lib.oc_decoder_set_rfc.argtypes = [vp, C.c_int]
+        lib.oc_decoder_set_rfc.restype = None
         lib.oc_batch_decode.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
         lib.oc_batch_decode.restype = C.c_long
 
@@ -129,6 +131,10 @@ class OracleDecoder:
 
     def reset(self):
         self.o.lib.oc_decoder_reset(self.h)
+
+    def set_rfc(self, on=True):
+        """RFC mode (oracle/oc_opus.h: frames at the durations their TOC names; parity-unpinned)."""
+        self.o.lib.oc_decoder_set_rfc(self.h, 1 if on else 0)
 
     def decode(self, packet: bytes):
         r = self.o.lib.oc_decode(self.h, bytes(packet), len(packet), self.buf.ctypes.data, 5760)
