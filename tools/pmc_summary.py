@@ -9,7 +9,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
-kernels = ["k_celt_parse", "k_celt_recon", "k_celt_post", "k_decode_step"]
+kernels = ["k_celt_parse", "k_celt_recon_fb", "k_celt_recon", "k_celt_post", "k_decode_step", "k_silk_parse", "k_silk_synth"]
 for f in sorted(glob.glob(root + "/trace/**/*kernel_stats.csv", recursive=True)):
     with open(f) as fh:
         for row in csv.DictReader(fh):
@@ -27,7 +27,7 @@ for kern in kernels:
         per_dispatch = defaultdict(float)
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if kern not in row["Kernel_Name"]:
+                if row["Kernel_Name"].split("(")[0].strip() != kern:
                     continue
                 per_dispatch[(row["Dispatch_Id"], row["Counter_Name"])] += float(row["Counter_Value"])
         for (_, name), v in per_dispatch.items():
