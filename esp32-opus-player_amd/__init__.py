@@ -246,7 +246,9 @@ class Context:
         self._chk(self.lib.opusgpu_streams_reset(self.h, first, count, 1 if full else 0), "opusgpu_streams_reset")
 
     def decode_packets(self, stream_ids, packets, frame_capacity=1):
-        """Batched opus_multistream_decode: returns (pcm[n, cap*960, ch] int16, result[n] int32)."""
+        """Batched opus_multistream_decode: returns (pcm[n, cap*960, ch] int16, result[n] int32).
+        RFC mode: an empty (or None) packet is a LOST packet, concealed for as long as the stream's last packet was."""
+        packets = [b"" if p is None else p for p in packets]
         n = len(packets)
         ids = np.ascontiguousarray(stream_ids, dtype=np.int32)
         lens = np.array([len(p) for p in packets], dtype=np.int32)

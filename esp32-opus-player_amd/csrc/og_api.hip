@@ -256,9 +256,8 @@ __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const Fra
     int ret;
     if (d.stream < 0 || d.stream >= n_streams) {
         ret = BAD_ARG;
-    } else if (desc_rfc(d.flags)) { // RFC mode (opt-in): the frame at its true duration, on this kernel only
-        ret = decode_frame_rfc(&st[d.stream], arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
-                               desc_channels(d.flags), pcm + (size_t)f * pcm_stride, desc_frame_size(d.flags));
+    } else if (desc_rfc(d.flags)) {
+        return; // RFC-mode frames belong to k_decode_rfc (og_rfc.hip)
     } else if (skip_celt && desc_mode(d.flags) == MODE_CELT) {
         return; // CELT-only frames take the split path (k_celt_parse + k_celt_recon)
     } else if (q4_only && !(desc_mode(d.flags) == MODE_SILK && handoff[f].valid == 2)) {
@@ -352,6 +351,9 @@ __global__ void __launch_bounds__(64, 2) k_celt_parse(const FrameDesc *__restric
 // (20 ms CELT-only frames are reconstructed by k_celt_recon_fb, og_recon.hip; `rest_only`: skip what that kernel took)
 extern "C" void og_launch_celt_recon_fb(hipStream_t s, const void *descs, void *streams, const void *recs, void *result, int n,
                                         int n_streams);
+// RFC mode (opt-in): every frame of a step, at its true duration, incl. the loss path (og_rfc.hip)
+extern "C" void og_launch_decode_rfc(hipStream_t s, const void *descs, const void *arena, void *streams, void *pcm, void *result, int n,
+                                     int n_streams, int pcm_stride);
 __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDesc *__restrict__ descs, StreamState *st,
                                                                       const ParseRec *recs, i16 *pcm, i32 *result, int n,
                                                                       int n_streams, int pcm_stride, int hybrid, int rest_only) {
@@ -506,6 +508,9 @@ struct opusgpu_ctx {
     int split_hybrid = 1; // OPUSGPU_SPLIT_HYBRID=0 keeps SILK-only and hybrid frames entirely on the single-kernel path
     int fast_recon = 1;   // OPUSGPU_FAST_RECON=0: every CELT frame through the general reconstruction kernel (A/B measurements)
     int mode = OPUSGPU_MODE_REFERENCE; // opusgpu_set_mode
+    // RFC mode, host side of the loss path: per stream, the frame count and descriptor flags of the last packet framed by
+    // opusgpu_decode_packets -- what a lost packet of that stream is concealed as (0 frames: nothing framed yet)
+    std::vector<int32_t> last_count, last_flags;
     char err[256] = {0};
 };
 
@@ -605,6 +610,9 @@ int opusgpu_streams_reset(opusgpu_ctx *ctx, int first, int count, int full) {
                        full ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // (both kinds of reset forget the last packet -- src/opus_decoder.cpp:382-390 clears frame_size and the like -- a loss right
+    // after one conceals 20 ms, of zeros)
+    for (int i = first; i < first + count; i++) ctx->last_count[i] = ctx->last_flags[i] = 0;
     return OPUSGPU_OK;
 }
 
@@ -621,6 +629,8 @@ int opusgpu_streams_alloc(opusgpu_ctx *ctx, int n_streams, int channels) {
     if (e != hipSuccess) return fail(ctx, OPUSGPU_ALLOC_FAIL, "hipMalloc(streams)", e);
     ctx->n_streams = n_streams;
     ctx->channels = channels;
+    ctx->last_count.assign((size_t)n_streams, 0);
+    ctx->last_flags.assign((size_t)n_streams, 0);
     return opusgpu_streams_reset(ctx, 0, n_streams, 1);
 }
 
@@ -659,6 +669,12 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
     if (!d_descs || !d_arena || !d_pcm || !d_result) return OPUSGPU_BAD_ARG;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
     const int pcm_stride = (ctx->mode == OPUSGPU_MODE_RFC ? OPUSGPU_RFC_FRAME_SAMPLES : OPUSGPU_FRAME_SAMPLES) * ctx->channels;
+    if (ctx->mode == OPUSGPU_MODE_RFC) { // every frame on the one kernel of that mode (og_rfc.hip)
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        og_launch_decode_rfc(s, d_descs, d_arena, ctx->d_streams, d_pcm, d_result, n, ctx->n_streams, pcm_stride);
+        HIPCHK(ctx, hipGetLastError());
+        return OPUSGPU_OK;
+    }
     SilkHandoff *handoff = nullptr;
     SilkRec *srecs = nullptr;
     if (ctx->split_celt) {
@@ -907,11 +923,28 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
         for (auto &x : th) x.join();
     };
     std::vector<int> first(n + 1, 0), nframes(n, 0);
+    std::vector<uint8_t> is_lost(rfc ? n : 0, 0);
     on_ranges([&](int lo, int hi) {
         for (int i = lo; i < hi; i++) {
             result[i] = 0;
-            if (stream_ids[i] < 0 || stream_ids[i] >= ctx->n_streams || !packets[i] || lens[i] <= 0) {
-                result[i] = OPUSGPU_BAD_ARG; // no PLC in the reference: data==NULL/len==0 ends in an error (Q8)
+            if (stream_ids[i] < 0 || stream_ids[i] >= ctx->n_streams || lens[i] < 0) {
+                result[i] = OPUSGPU_BAD_ARG;
+                continue;
+            }
+            if (!packets[i] || lens[i] == 0) {
+                if (!rfc) {
+                    result[i] = OPUSGPU_BAD_ARG; // no PLC in the reference: data==NULL/len==0 ends in an error (Q8)
+                    continue;
+                }
+                // RFC mode: a lost packet is concealed as long as the stream's last packet was (one 20 ms frame if there was none)
+                const int count = ctx->last_count[stream_ids[i]] ? ctx->last_count[stream_ids[i]] : 1;
+                const int fs = ogh::flags_frame_size(ctx->last_flags[stream_ids[i]]);
+                if ((int64_t)count * fs > (int64_t)frame_capacity * OPUSGPU_FRAME_SAMPLES) {
+                    result[i] = OPUSGPU_BUFFER_TOO_SMALL;
+                    continue;
+                }
+                nframes[i] = count;
+                is_lost[i] = 1;
                 continue;
             }
             opusgpu_frame_desc d[48];
@@ -928,6 +961,10 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
                 continue;
             }
             nframes[i] = count;
+            if (rfc) { // (a stream appears at most once per call: no two threads write the same entry)
+                ctx->last_count[stream_ids[i]] = count;
+                ctx->last_flags[stream_ids[i]] = d[0].flags;
+            }
         }
     });
     timer.mark("framing pass 1 (counts)");
@@ -935,16 +972,22 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
     int max_frames = 0;
     for (int i = 0; i < n; i++) {
         first[i + 1] = first[i] + nframes[i];
-        base[i + 1] = base[i] + (nframes[i] ? (size_t)lens[i] : 0);
+        base[i + 1] = base[i] + (nframes[i] && !(rfc && is_lost[i]) ? (size_t)lens[i] : 0);
         if (nframes[i] > max_frames) max_frames = nframes[i];
     }
     if (first[n] == 0) return OPUSGPU_OK;
     if (base[n] > 0x7fffffffu) return OPUSGPU_BAD_ARG; // descriptor offsets are 32-bit: split the call
     std::unique_ptr<opusgpu_frame_desc[]> all(new opusgpu_frame_desc[first[n]]); // frames in (packet, frame) order
-    std::unique_ptr<uint8_t[]> arena(new uint8_t[base[n]]);
+    std::unique_ptr<uint8_t[]> arena(new uint8_t[base[n] + 1]);
     on_ranges([&](int lo, int hi) {
         for (int i = lo; i < hi; i++) {
             if (!nframes[i]) continue;
+            if (rfc && is_lost[i]) { // nothing to read: len 0, the flags of the stream's last packet (RFC bit and duration included)
+                const int32_t fl = ctx->last_count[stream_ids[i]] ? ctx->last_flags[stream_ids[i]]
+                                                                   : (int32_t)((ogh::MODE_CELT - ogh::MODE_SILK) | 4 << 2 | (CC == 2 ? 32 : 0) | 1 << 9);
+                for (int k = 0; k < nframes[i]; k++) all[first[i] + k] = opusgpu_frame_desc{stream_ids[i], 0, 0, fl};
+                continue;
+            }
             opusgpu_frame_desc d[48];
             (void)opusgpu_packet_to_frames_mode(packets[i], lens[i], stream_ids[i], ctx->mode, d);
             memcpy(arena.get() + base[i], packets[i], (size_t)lens[i]);

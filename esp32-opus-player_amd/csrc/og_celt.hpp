@@ -909,6 +909,8 @@ struct CeltSynth {
     u32 rng_final;
     int rc_error;
     int inline_deemph; // 1: de-emphasis + PCM planes here (single-kernel path); 0: left to celt_post_lane (split path)
+    LossState *loss;   // RFC mode: the noise floor follows the decoded energies and the loss counter restarts (celt.cpp:2411-2440)
+    int lost;          // a concealed frame (celt_decode_lost): the energy histories, the post-filter and its state stay as they are
 };
 
 // De-emphasis and float-to-int16 of one channel of one frame, lane-private (celt.cpp:1965-2055, sig2word16 celt.h:413):
@@ -1037,7 +1039,7 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
         OG_FOR_LANES(i, NBANDS) S.bandE_row()[NBANDS + i] = S.bandE_row()[i];
         OG_SYNC();
     }
-    OG_FOR_LANES(i, 2 * NBANDS) {
+    if (!p.lost) OG_FOR_LANES(i, 2 * NBANDS) {
         int band = i >= NBANDS ? i - NBANDS : i;
         i32 e = S.bandE_row()[i], l1 = S.logE1_row()[i], l2 = S.logE2_row()[i];
         if (!transient) {
@@ -1045,6 +1047,10 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
             l1 = e;
         } else
             l1 = OG_MIN(l1, e);
+        if (p.loss && !transient) { // the noise floor rises by at most 2.4 dB/s; 1 dB per update after a long loss
+            const i32 inc = p.loss->celt_loss_count < 10 ? M : 1024; // M * QCONST16(0.001f, DB_SHIFT); QCONST16(1.f, DB_SHIFT)
+            p.loss->backgroundLogE[i] = (i16)OG_MIN((i32)(i16)(p.loss->backgroundLogE[i] + inc), e);
+        }
         if (band < start || band >= end) {
             e = 0;
             l1 = l2 = -28 * 1024;
@@ -1072,8 +1078,10 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
         OG_MARK(15);
         OG_TAP(2 + 16 * c); // IMDCT output
 #if !(defined(OG_ABLATE) && OG_ABLATE == 3)
-        comb_filter(st, c, 0, ppo, pp, 120, pgo, pg, pto, pt);
-        if (LM != 0) comb_filter(st, c, 120, pp, pf_pitch, N - 120, pg, pf_gain, pt, pf_tapset);
+        if (!p.lost) {
+            comb_filter(st, c, 0, ppo, pp, 120, pgo, pg, pto, pt);
+            if (LM != 0) comb_filter(st, c, 120, pp, pf_pitch, N - 120, pg, pf_gain, pt, pf_tapset);
+        }
         OG_TAP(3 + 16 * c); // comb filter output
 #if !(defined(OG_ABLATE) && OG_ABLATE == 4)
         // de-emphasis (celt.cpp:1965-2055): a rounding IIR, serial; the PCM plane replaces a dead half of X
@@ -1097,7 +1105,12 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
 #endif
     }
     OG_SYNC();
-    if (OG_LANE == 0) {
+    if (OG_LANE == 0 && p.lost) {
+        st->ring_pos = (pos + N) & RING_MASK;
+        st->rng = p.rng_final;
+        p.loss->celt_loss_count += 1;
+    } else if (OG_LANE == 0) {
+        if (p.loss) p.loss->celt_loss_count = 0;
         st->ring_pos = (pos + N) & RING_MASK;
         st->rng = p.rng_final;
         int new_old_period = pp, new_old_tapset = pt;
@@ -1121,7 +1134,8 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
 // pcm_out: LDS i16 buffer (interleaved, CC channels) -- S.v[V_X..] is reused for it after synthesis.
 // Returns frame_size or a negative code (wave-uniform).
 // `end`: one past the last band decoded -- 21 always in reference mode (Q1), by bandwidth in RFC mode
-OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int CC, int start, int disable_inv, int end = NBANDS) {
+OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int CC, int start, int disable_inv, int end = NBANDS,
+                             LossState *loss = nullptr) {
     const i32 *eb = rom_eband;
     int LM;
     for (LM = 0; LM <= 3; LM++)
@@ -1178,8 +1192,50 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
     CeltSynth sp;
     sp.N = N; sp.LM = LM; sp.C = C; sp.CC = CC; sp.start = start; sp.end = end; sp.silence = silence; sp.transient = transient;
     sp.pf_pitch = pf_pitch; sp.pf_tapset = pf_tapset; sp.pf_gain = pf_gain; sp.rng_final = rc.rng; sp.rc_error = rc.error; sp.inline_deemph = 1;
+    sp.loss = loss; sp.lost = 0;
     celt_synthesis(st, sp);
     if (rc_tell(rc) > 8 * (i32)rc.storage) return INTERNAL_ERROR;
+    return frame_size;
+}
+
+// Concealment of a lost CELT frame (RFC mode only; the reference has none, Q8): the noise-based branch of RFC 6716's
+// celt_decode_lost, as the oracle restates it (oc_celt_decode_lost).  The band energies decay towards the noise floor
+// (1.5 dB for the first lost frame, 0.5 dB after), every band from `start` to `end` of every DECODER channel is filled with LCG
+// noise and renormalised, then one long MDCT, no post-filter, de-emphasis.  The pitch-based branch is in neither the reference's
+// source nor normative and is not built.  PCM planes as after celt_decode_frame with C == CC.
+OG_DEV int celt_decode_lost(CeltState *st, LossState *loss, int frame_size, int CC, int start, int end) {
+    const i32 *eb = rom_eband;
+    int LM;
+    for (LM = 0; LM <= 3; LM++)
+        if (120 << LM == frame_size) break;
+    if (LM > 3) return BAD_ARG;
+    const int N = 120 << LM, effEnd = OG_MAX(start, OG_MIN(end, NBANDS));
+    const i32 decay = loss->celt_loss_count == 0 ? 1536 : 512; // QCONST16(1.5f, DB_SHIFT) : QCONST16(.5f, DB_SHIFT)
+    OG_SYNC();
+    OG_FOR_LANES(i, 2 * NBANDS) {
+        const int c = i >= NBANDS, band = i - c * NBANDS;
+        i32 e = st->bandE[i];
+        if (c < CC && band >= start && band < end) {
+            e = OG_MAX((i32)loss->backgroundLogE[i], (i32)(i16)(e - decay));
+            st->bandE[i] = (i16)e;
+        }
+        S.bandE_row()[i] = (i16)e;
+    }
+    OG_FOR_LANES(i, 2 * N) S.v[V_X + i] = 0;
+    OG_SYNC();
+    // noise: the LCG runs once per coefficient in (channel, band, bin) order; the bins of a channel's bands are contiguous
+    u32 seed = st->rng;
+    const int lo = eb[start] << LM, width = (eb[effEnd] << LM) - lo;
+    for (int c = 0; c < CC; c++) {
+        OG_FOR_LANES(j, width) S.v[V_X + c * N + lo + j] = (i16)((i32)lcg_skip(seed, (u32)j + 1) >> 20);
+        seed = lcg_skip(seed, (u32)width);
+        for (int i = start; i < effEnd; i++) renormalise(V_X + c * N + (eb[i] << LM), (eb[i + 1] - eb[i]) << LM, 32767);
+    }
+    CeltSynth sp;
+    sp.N = N; sp.LM = LM; sp.C = CC; sp.CC = CC; sp.start = start; sp.end = effEnd; sp.silence = 0; sp.transient = 0;
+    sp.pf_pitch = 0; sp.pf_tapset = 0; sp.pf_gain = 0; sp.rng_final = seed; sp.rc_error = 0; sp.inline_deemph = 1;
+    sp.loss = loss; sp.lost = 1;
+    celt_synthesis(st, sp);
     return frame_size;
 }
 

@@ -1733,6 +1733,7 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         sp.N = N; sp.LM = LM; sp.C = C; sp.CC = CC; sp.start = start; sp.end = end; sp.silence = silence; sp.transient = transient;
         sp.pf_pitch = OG_UNI(rec->pf_pitch); sp.pf_tapset = OG_UNI(rec->pf_tapset); sp.pf_gain = OG_UNI(rec->pf_gain);
         sp.rng_final = rng_final; sp.rc_error = (flags & RF_RC_ERROR) != 0; sp.inline_deemph = 0;
+        sp.loss = nullptr; sp.lost = 0;
         OG_MARK(13);
         celt_synthesis(cs, sp);
         OG_MARK(17);

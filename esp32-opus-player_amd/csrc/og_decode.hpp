@@ -212,9 +212,75 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
 OG_DEV int rfc_end_band(int bandwidth) { // RFC 6716 section 4.3: NB 13, WB 17, SWB 19, FB 21 bands
     return bandwidth == BW_NB ? 13 : (bandwidth == BW_MB || bandwidth == BW_WB) ? 17 : bandwidth == BW_SWB ? 19 : NBANDS;
 }
+// A frame with nothing to decode (RFC mode): the packet was lost (len == 0) or the frame is a DTX frame of at
+// most one byte.  RFC 6716's opus_decode_frame with data == NULL as the oracle restates it (conceal_frame, oracle/oc_packet.c):
+// the mode is the previous frame's; more than 20 ms goes in chunks of 20 ms; SILK conceals 10 or 20 ms (a 2.5 / 5 ms request takes
+// the head of a 10 ms concealment); CELT -- and hybrid's CELT layer from band 17 -- conceals with celt_decode_lost, its last band
+// what the last decoded frame made it.  `ch`: the channel count of the last packet (the descriptor's).
+OG_DEV int conceal_chunk_rfc(StreamState *st, int ch, i16 *pcm, int audiosize) { // at most 20 ms
+    const int CC = st->channels, mode = st->prev_mode;
+    if (mode == 0) { // nothing decoded yet: zeros
+        OG_FOR_LANES(i, audiosize * CC) pcm[i] = 0;
+        OG_SYNC();
+        return audiosize;
+    }
+    const int nmix = audiosize * (ch < CC ? ch : CC);
+#ifndef OG_NO_SILK
+    if (mode != MODE_CELT) {
+        Rc none;
+        rc_init(none, 0u);
+        int taken = 0; // the SILK PCM of the frame, kept in SL().u.out.pcm (one internal frame: the first call's output is what counts)
+        const int ret = silk_decode_packet<false>(&st->silk, none, ch, 0, audiosize >= 960 ? 20 : 10, nullptr,
+                                                  [&](int, int n48) { taken += n48; }, &st->loss, 1);
+        if (ret) return INTERNAL_ERROR;
+        if (mode == MODE_SILK) { // PCM = SAT16(0 + pcm_silk) over the frame's first nmix linear entries
+            OG_SYNC();
+            OG_FOR_LANES(i, nmix) pcm[i] = SL().u.out.pcm[i];
+            OG_SYNC();
+        }
+    }
+#else
+    if (mode != MODE_CELT) return INTERNAL_ERROR;
+#endif
+    int celt_ret = 0;
+    if (mode != MODE_SILK) {
+        celt_ret = celt_decode_lost(&st->celt, &st->loss, audiosize, CC, mode == MODE_CELT ? 0 : 17, st->loss.celt_end_band);
+#ifndef OG_NO_SILK
+        if (mode == MODE_HYBRID && celt_ret >= 0) {
+            OG_SYNC();
+            OG_FOR_LANES(i, nmix) {
+                const int c = CC == 2 ? (i & 1) : 0, j = CC == 2 ? (i >> 1) : i, at = pcm_plane(c, CC, CC) + j;
+                S.v[at] = (i16)sat16((i32)S.v[at] + (i32)SL().u.out.pcm[i]);
+            }
+            OG_SYNC();
+        }
+#endif
+        if (celt_ret >= 0) {
+            OG_SYNC();
+            pcm_store(pcm, audiosize, CC, CC);
+            OG_SYNC();
+        }
+    }
+    if (OG_LANE == 0) {
+        st->frames_decoded += 1;
+        st->range_final = 0;
+    }
+    OG_SYNC();
+    return celt_ret < 0 ? celt_ret : audiosize;
+}
+OG_DEV int conceal_frame_rfc(StreamState *st, int ch, i16 *pcm, int audiosize) {
+    const int CC = st->channels;
+    for (int done = 0; done < audiosize; done += 960) {
+        const int r = conceal_chunk_rfc(st, ch, pcm + done * CC, OG_MIN(audiosize - done, 960));
+        if (r < 0) return r;
+    }
+    return audiosize;
+}
+
 OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mode, int bandwidth, int ch, i16 *pcm, int audiosize) {
     const int CC = st->channels;
     if (len < 0 || len > 1275) return BAD_ARG;
+    if (len <= 1) return conceal_frame_rfc(st, ch, pcm, audiosize);
     const int prev_mode = st->prev_mode;
     // the reference's mix loop runs over audiosize * stream_channels LINEAR entries of the interleaved output (Q3); the oracle's
     // RFC mode keeps that and stops at the frame's own end
@@ -231,7 +297,7 @@ OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mod
         OG_SYNC();
         Rc rs;
         rc_init(rs, 2u);
-        (void)celt_decode_frame(&st->celt, rs, 120, ch, CC, 0, disable_inv, NBANDS);
+        (void)celt_decode_frame(&st->celt, rs, 120, ch, CC, 0, disable_inv, NBANDS, &st->loss);
         OG_SYNC();
     }
 #endif
@@ -243,7 +309,7 @@ OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mod
     int celt_ret = 0;
 #ifndef OG_NO_SILK
     if (mode != MODE_CELT) {
-        if (prev_mode == MODE_CELT) silk_init_state(&st->silk);
+        if (prev_mode == MODE_CELT) silk_init_state(&st->silk, &st->loss);
         int internal_hz = 16000;
         if (mode == MODE_SILK) internal_hz = bandwidth == BW_NB ? 8000 : (bandwidth == BW_MB ? 12000 : 16000);
         int base = 0; // linear position of the internal frame in the packet's SILK PCM
@@ -262,7 +328,7 @@ OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mod
                 }
                 base += n48 * ch;
             }
-        });
+        }, &st->loss, 0);
         if (ret) return INTERNAL_ERROR;
     }
     if (mode != MODE_CELT && rc_tell(rc) + 17 + 20 * (mode == MODE_HYBRID) <= 8 * len) {
@@ -276,7 +342,9 @@ OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mod
             celt_reset_state(&st->celt);
             OG_SYNC();
         }
-        celt_ret = celt_decode_frame(&st->celt, rc, audiosize, ch, CC, mode == MODE_CELT ? 0 : 17, disable_inv, rfc_end_band(bandwidth));
+        if (OG_LANE == 0) st->loss.celt_end_band = rfc_end_band(bandwidth); // (what a later concealment's last band is)
+        celt_ret = celt_decode_frame(&st->celt, rc, audiosize, ch, CC, mode == MODE_CELT ? 0 : 17, disable_inv, rfc_end_band(bandwidth),
+                                     &st->loss);
 #ifndef OG_NO_SILK
         if (mode == MODE_HYBRID && celt_ret >= 0) {
             OG_SYNC();

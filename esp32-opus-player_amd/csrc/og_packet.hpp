@@ -40,6 +40,12 @@ inline int32_t toc_flags_rfc(uint8_t toc) {
     return toc_flags(toc) | code << 6 | 1 << 9;
 }
 
+// the frame duration a descriptor's flags name, in samples at 48 kHz (bits 6 - 8; 960 in reference mode)
+inline int flags_frame_size(int32_t f) {
+    const int d = (f >> 6) & 7;
+    return d == 1 ? 120 : d == 2 ? 240 : d == 3 ? 480 : d == 4 ? 1920 : d == 5 ? 2880 : 960;
+}
+
 inline int read_size(const uint8_t *d, int32_t len, int16_t *size) {
     if (len < 1) { *size = -1; return -1; }
     if (d[0] < 252) { *size = d[0]; return 1; }

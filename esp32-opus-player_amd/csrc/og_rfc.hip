@@ -1,0 +1,31 @@
+// og_rfc.hip -- RFC mode (opt-in): one Opus frame per wave at the duration its TOC names, and the loss path
+// (lost packets, DTX frames) -- decode_frame_rfc / conceal_frame_rfc, og_decode.hpp.
+//
+// A translation unit and a kernel of its own so that nothing of this mode is compiled into the reference-mode kernels of
+// og_api.hip: their register allocation, LDS footprint and timings stay what the profiles under profiles/ were taken from.  The
+// mode exists for completeness, not speed: entropy decoding is wave-uniform, the synthesis of loss-aware SILK frames runs one
+// lane per channel.
+#include <hip/hip_runtime.h>
+#include "og_decode.hpp"
+
+using namespace og;
+
+__global__ void __launch_bounds__(64, 1) k_decode_rfc(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena, StreamState *st,
+                                                      i16 *pcm, i32 *result, int n, int n_streams, int pcm_stride) {
+    const int f = (int)blockIdx.x;
+    if (f >= n) return;
+    const FrameDesc d = descs[f];
+    int ret;
+    if (d.stream < 0 || d.stream >= n_streams || !desc_rfc(d.flags))
+        ret = BAD_ARG; // (in RFC mode every descriptor carries the mode bit: opusgpu_packet_to_frames_mode)
+    else
+        ret = decode_frame_rfc(&st[d.stream], arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
+                               desc_channels(d.flags), pcm + (size_t)f * pcm_stride, desc_frame_size(d.flags));
+    if (threadIdx.x == 0) result[f] = ret;
+}
+
+extern "C" void og_launch_decode_rfc(hipStream_t s, const void *descs, const void *arena, void *streams, void *pcm, void *result, int n,
+                                     int n_streams, int pcm_stride) {
+    hipLaunchKernelGGL(k_decode_rfc, dim3(n), dim3(64), 0, s, (const FrameDesc *)descs, (const u8 *)arena, (StreamState *)streams,
+                       (i16 *)pcm, (i32 *)result, n, n_streams, pcm_stride);
+}

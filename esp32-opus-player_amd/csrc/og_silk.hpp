@@ -71,9 +71,14 @@ OG_LDS SilkWaveParseLds g_silk_wp;
 OG_DEV SilkWaveParseLds &PW() { return g_silk_wp; }
 
 // ---- state ------------------------------------------------------------------------------------------
-OG_DEV void silk_chan_init(SilkChannel *c) { // silk_init_decoder silk.cpp:2192
+// `lc`: the channel's loss-concealment state (RFC mode; reference-mode callers pass none and never look at it)
+OG_DEV void silk_chan_init(SilkChannel *c, SilkLossChannel *lc = nullptr) { // silk_init_decoder silk.cpp:2192
     u32 *w = reinterpret_cast<u32 *>(c);
     OG_FOR_LANES(i, (int)(sizeof(SilkChannel) / 4)) w[i] = 0;
+    if (lc) { // silk_CNG_Reset / silk_PLC_Reset run again, with the real rate, before anything reads what they set
+        u32 *wl = reinterpret_cast<u32 *>(lc);
+        OG_FOR_LANES(i, (int)(sizeof(SilkLossChannel) / 4)) wl[i] = 0;
+    }
     OG_SYNC();
     if (OG_LANE == 0) {
         c->first_frame_after_reset = 1;
@@ -84,9 +89,9 @@ OG_DEV void silk_chan_init(SilkChannel *c) { // silk_init_decoder silk.cpp:2192
 
 // silk_InitDecoder silk.cpp:1792.  The channel init clears fs_kHz, so the resampler part of the record is
 // re-initialised by the next frame exactly when the reference re-initialises its (separate) resampler state.
-OG_DEV void silk_init_state(SilkState *s) {
-    silk_chan_init(&s->ch[0]);
-    silk_chan_init(&s->ch[1]);
+OG_DEV void silk_init_state(SilkState *s, LossState *loss = nullptr) {
+    silk_chan_init(&s->ch[0], loss ? &loss->silk[0] : nullptr);
+    silk_chan_init(&s->ch[1], loss ? &loss->silk[1] : nullptr);
     if (OG_LANE == 0) {
         s->pred_prev_Q13[0] = s->pred_prev_Q13[1] = 0;
         s->sMid[0] = s->sMid[1] = 0;
@@ -674,9 +679,12 @@ OG_DEV void silk_params_lane(const StreamState *st, int mode, int bandwidth, int
 
 // ---- synthesis: one lane per channel (silk_decode_core silk.cpp:1806, LPC analysis filter :2268) --------------
 // `pulses`: the channel's excitation pulses -- in the parse record in HBM (split path) or in PW().pulses
-OG_DEVN void silk_decode_core_lane(SilkChannel *c, int ch, int fs_kHz, const i16 *pulses, int nb_subfr = 4) {
+// `lc` (RFC mode): the excitation is kept for a later concealment, and the first decoded frame after a loss is smoothed
+OG_DEVN void silk_decode_core_lane(SilkChannel *c, int ch, int fs_kHz, const i16 *pulses, int nb_subfr = 4,
+                                   SilkLossChannel *lc = nullptr) {
     SilkLds &L = SL();
-    const SilkCtrl &k = L.ctrl[ch];
+    SilkCtrl &k = L.ctrl[ch];
+    const int after_loss = lc && lc->lossCnt && c->prevSignalType == 2 && k.signalType != 2; // silk.cpp:1869
     const int order = fs_kHz == 16 ? 16 : 10, subfr = 5 * fs_kHz, frame_length = nb_subfr * subfr, ltp_mem = 20 * fs_kHz;
     i16 *xq = &L.xq[ch][2];
     i32 *sLTP_Q15 = L.u.core.sLTP_Q15[ch];
@@ -699,7 +707,13 @@ OG_DEVN void silk_decode_core_lane(SilkChannel *c, int ch, int fs_kHz, const i16
         } else
             gain_adj_Q16 = 1 << 16;
         prev_gain_Q16 = Gain_Q16;
-        const int voiced = k.signalType == 2;
+        int voiced = k.signalType == 2;
+        i16 B_smooth[5] = {0, 0, 4096, 0, 0}; // SILK_FIX_CONST(0.25, 14) on the centre tap
+        if (after_loss && sf < 2) { // avoid an abrupt transition from voiced concealment to unvoiced decoding (silk.cpp:1869-1876)
+            for (int i = 0; i < 5; i++) k.LTPCoef_Q14[sf * 5 + i] = B_smooth[i];
+            voiced = 1;
+            k.pitchL[sf] = c->lagPrev;
+        }
         if (voiced) {
             lag = k.pitchL[sf];
             if (sf == 0 || (sf == 2 && interp_flag)) { // re-whitening
@@ -733,6 +747,7 @@ OG_DEVN void silk_decode_core_lane(SilkChannel *c, int ch, int fs_kHz, const i16
             exc += offset_Q10 << 4;
             if (rand_seed < 0) exc = -exc;
             rand_seed = addw(rand_seed, pl);
+            if (lc) lc->exc_Q14[pos + i] = exc;
             i32 res = exc;
             if (voiced) {
                 const i32 *p = &sLTP_Q15[sLTP_buf_idx - lag + 2];
@@ -1084,6 +1099,8 @@ OG_DEV void silk_up2_rows(SilkState *st, int channels, int inLen) {
 }
 #endif
 
+#include "og_silk_loss.hpp"
+
 OG_DEV void silk_stereo_decode_pred(Rc &rc, i32 pred_Q13[2]) { // silk.cpp:592
     int ix[2][3];
     int n = rc_icdf(rc, rom_silk_stereo_joint_icdf, 8);
@@ -1115,17 +1132,22 @@ OG_DEV void silk_stereo_decode_pred(Rc &rc, i32 pred_Q13[2]) { // silk.cpp:592
 OPUS_ROM uint8_t rom_silk_lbrr_flags_2_icdf[3] = {203, 150, 0};
 OPUS_ROM uint8_t rom_silk_lbrr_flags_3_icdf[7] = {215, 195, 166, 125, 110, 82, 0};
 
+// `loss` (RFC mode): the stream's loss-concealment state.  With it every decoded frame also leaves what a later
+// concealment starts from (silk_PLC_update, the comfort-noise estimate) and is smoothed when it follows a loss; `lost` = 1 is
+// silk_Decode's lostFlag == FLAG_PACKET_LOST (silk.cpp:1481-1779): nothing is read from `rc`, one frame of payload_ms (10 or
+// 20) is concealed at the rate of the last decoded frame (internal_hz == 0).  The synthesis then runs one lane per channel.
 template <bool REC_ONLY, class Emit>
-OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_hz, int payload_ms, const SilkRec *rec, Emit &&emit) {
+OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_hz, int payload_ms, const SilkRec *rec, Emit &&emit,
+                              LossState *loss = nullptr, int lost = 0) {
     SilkLds &L = SL();
-    const int fs_kHz = (internal_hz >> 10) + 1;
+    const int fs_kHz = internal_hz ? (internal_hz >> 10) + 1 : (int)OG_UNI(s->ch[0].fs_kHz);
     if (fs_kHz != 8 && fs_kHz != 12 && fs_kHz != 16) return -200;
     const int nF = (REC_ONLY || rec) ? 1 : payload_ms == 40 ? 2 : payload_ms == 60 ? 3 : 1;
     const int nb_subfr = (REC_ONLY || rec) ? 4 : payload_ms == 10 ? 2 : 4;
     const int frame_length = nb_subfr * 5 * fs_kHz, ltp_mem = 20 * fs_kHz;
     OG_SYNC();
     // first frame of the packet: nFramesDecoded = 0 for the coded channels
-    if (channels > s->nChannelsInternal) silk_chan_init(&s->ch[1]);
+    if (channels > s->nChannelsInternal) silk_chan_init(&s->ch[1], loss ? &loss->silk[1] : nullptr);
     for (int n = 0; n < channels; n++) silk_set_fs(&s->ch[n], fs_kHz);
     if (channels == 2 && (s->nChannelsAPI == 1 || s->nChannelsInternal == 1)) {
         OG_SYNC();
@@ -1155,6 +1177,9 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
             ecType[n] = OG_UNI(rec->ch[n].ec_prevSignalType);
             ecLag[n] = OG_UNI(rec->ch[n].ec_prevLagIndex);
         }
+    } else if (lost) { // silk.cpp:1632-1635: the predictors stay; decode_only_middle is silk_Decode's local, zero
+        MS_pred_Q13[0] = s->pred_prev_Q13[0];
+        MS_pred_Q13[1] = s->pred_prev_Q13[1];
     } else if constexpr (!REC_ONLY) {
         int lbrr_flag[2] = {0, 0};
         for (int n = 0; n < channels; n++) { // silk.cpp:1568-1573: every channel's VAD flags and LBRR flag first
@@ -1185,7 +1210,7 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
     int prev_dom = s->prev_decode_only_middle;
     for (int fi = 0; fi < nF; fi++) {
         if constexpr (!REC_ONLY) {
-            if (!rec && channels == 2) {
+            if (!rec && !lost && channels == 2) {
                 silk_stereo_decode_pred(rc, MS_pred_Q13);
                 decode_only_middle = vad[1][fi] == 0 ? rc_icdf(rc, rom_silk_mid_only_icdf, 8) : 0;
             }
@@ -1204,10 +1229,33 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
             lastGain[1] = 10;
             ffar[1] = 1;
         }
-        const int has_side = !decode_only_middle;
+        const int has_side = lost ? !prev_dom : !decode_only_middle; // silk.cpp:1664-1671
+        i32 plc_invGain_Q30[2] = {0, 0};
         for (int n = 0; n < channels; n++) {
             L.ctrl[n].coded = (n == 0 || has_side);
-            if (L.ctrl[n].coded) {
+            if (L.ctrl[n].coded && lost) {
+                if constexpr (!REC_ONLY) {
+                    // a concealed frame: the serial part runs one lane per channel below; what needs the wave's scratch runs here
+                    // (silk_PLC silk.cpp:2871-2877; silk_PLC_conceal :2992, :3015-3039)
+                    SilkLossChannel *lc = &loss->silk[n];
+                    const int order = fs_kHz == 16 ? 16 : 10;
+                    OG_SYNC();
+                    if (OG_LANE == 0) {
+                        silk_plc_rate_check(lc, fs_kHz, frame_length);
+                        if (ffar[n])
+                            for (int i = 0; i < SILK_MAX_LPC; i++) lc->plc_prevLPC_Q12[i] = 0;
+                        ArrV<i16, 1> a = {lc->plc_prevLPC_Q12};
+                        silk_bwexpander16(a, order, 64881); // SILK_FIX_CONST(BWE_COEF = 0.99, 16)
+                        L.ctrl[n].signalType = s->ch[n].prevSignalType;
+                    }
+                    OG_SYNC();
+                    if (OG_UNI(lc->lossCnt) == 0 && OG_UNI(s->ch[n].prevSignalType) != 2) {
+                        ArrV<i16, 1> a = {lc->plc_prevLPC_Q12};
+                        plc_invGain_Q30[n] = silk_inverse_pred_gain<SilkParWave>(a, order);
+                    }
+                    OG_SYNC();
+                }
+            } else if (L.ctrl[n].coded) {
                 // FrameIndex = channel 0's nFramesDecoded - n, and channel 0's count has been stepped by the time channel 1
                 // gets here (silk.cpp:1676-1700): the frame's index for both; <= 0 -> independent coding
                 const int FrameIndex = fi;
@@ -1230,6 +1278,11 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
                                                         nb_subfr);
                     OG_SYNC();
                     OG_FOR_LANES(i, fs_kHz == 16 ? 16 : 10) s->ch[n].prevNLSF_Q15[i] = PW().nlsf[i];
+                    if (loss && OG_UNI(loss->silk[n].lossCnt) && OG_LANE == 0) { // silk.cpp:860-864: BWE_AFTER_LOSS_Q16
+                        ArrV<i16, 1> a0 = {L.ctrl[n].PredCoef_Q12[0]}, a1 = {L.ctrl[n].PredCoef_Q12[1]};
+                        silk_bwexpander16(a0, fs_kHz == 16 ? 16 : 10, 63570);
+                        silk_bwexpander16(a1, fs_kHz == 16 ? 16 : 10, 63570);
+                    }
                     OG_SYNC();
                 }
                 ffar[n] = 0; // (the synthesis below clears it in the state)
@@ -1260,24 +1313,35 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
         for (int n = 0; n < channels; n++)
             if (L.ctrl[n].coded) OG_FOR_LANES(i, ltp_mem) L.u.core.hist[n][i] = s->ch[n].outBuf[i];
         OG_SYNC();
-#ifdef OG_HOST_EMUL
-        OG_FOR_LANES(n, channels) {
-            if (L.ctrl[n].coded)
-                silk_decode_core_lane(&s->ch[n], n, fs_kHz, pulse_row[n], nb_subfr);
-            else
+        // one lane per channel: the decoded frame's synthesis, or a lost frame's concealment
+        auto lane_synth = [&](int n) {
+            if (!L.ctrl[n].coded) {
                 for (int i = 0; i < frame_length; i++) L.xq[n][2 + i] = 0;
-        }
-#else
-        if (nb_subfr == 4)
-            silk_decode_core_rows(s, fs_kHz, channels, pulse_row[0], pulse_row[1]);
-        else { // 10 ms frames (RFC mode only): the one-lane-per-channel form of the core
-            OG_FOR_LANES(n, channels) {
-                if (L.ctrl[n].coded)
-                    silk_decode_core_lane(&s->ch[n], n, fs_kHz, pulse_row[n], nb_subfr);
-                else
-                    for (int i = 0; i < frame_length; i++) L.xq[n][2 + i] = 0;
+                return;
             }
-        }
+            if constexpr (!REC_ONLY) {
+                if (loss) {
+                    SilkLossChannel *lc = &loss->silk[n];
+                    if (lost)
+                        silk_plc_conceal_lane(&s->ch[n], lc, n, fs_kHz, nb_subfr, plc_invGain_Q30[n]);
+                    else { // silk_decode_frame silk.cpp:2008-2015: the core, then silk_PLC(lost = 0), then lossCnt = 0
+                        silk_decode_core_lane(&s->ch[n], n, fs_kHz, pulse_row[n], nb_subfr, lc);
+                        silk_plc_rate_check(lc, fs_kHz, frame_length);
+                        silk_plc_update_lane(lc, L.ctrl[n], fs_kHz, nb_subfr);
+                        lc->lossCnt = 0;
+                    }
+                    return;
+                }
+            }
+            silk_decode_core_lane(&s->ch[n], n, fs_kHz, pulse_row[n], nb_subfr);
+        };
+#ifdef OG_HOST_EMUL
+        OG_FOR_LANES(n, channels) lane_synth(n);
+#else
+        if (nb_subfr == 4 && !loss)
+            silk_decode_core_rows(s, fs_kHz, channels, pulse_row[0], pulse_row[1]);
+        else // 10 ms frames and everything loss-aware (RFC mode only): the one-lane-per-channel form
+            OG_FOR_LANES(n, channels) lane_synth(n);
 #endif
         OG_SYNC();
         OG_TAP(40); // decoder control + core output of every coded channel (host emulation only)
@@ -1290,6 +1354,37 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
                 OG_FOR_LANES(i, ltp_mem) s->ch[n].outBuf[i] = i < keep ? L.u.core.hist[n][frame_length + i] : L.xq[n][2 + i - keep];
             }
         OG_SYNC();
+        if constexpr (!REC_ONLY) {
+            if (loss) { // silk_decode_frame silk.cpp:2036-2044: comfort noise estimate / generation, then the glue to the last frame
+                const int order = fs_kHz == 16 ? 16 : 10;
+                for (int n = 0; n < channels; n++) {
+                    if (!L.ctrl[n].coded) continue;
+                    SilkLossChannel *lc = &loss->silk[n];
+                    if (OG_LANE == 0 && lc->cng_fs_kHz != fs_kHz) { // silk_CNG_Reset silk.cpp:1327
+                        const i32 step = 32767 / (order + 1);
+                        for (int i = 0; i < order; i++) lc->cng_smth_NLSF_Q15[i] = (i16)((i + 1) * step);
+                        lc->cng_smth_Gain_Q16 = 0;
+                        lc->cng_rand_seed = 3176576;
+                        lc->cng_fs_kHz = fs_kHz;
+                    }
+                    OG_SYNC();
+                    if (OG_UNI(lc->lossCnt)) { // the smoothed NLSFs as a filter, into the (free) whitening row of the channel
+                        OG_FOR_LANES(i, order) PW().nlsf[i] = lc->cng_smth_NLSF_Q15[i];
+                        OG_SYNC();
+                        ArrV<i16, 1> a = {L.u.core.sLTP[n]};
+                        silk_nlsf2a<SilkParWave>(a, SilkParWave::nlsf(), order);
+                        OG_SYNC();
+                    }
+                }
+                OG_FOR_LANES(n, channels) {
+                    if (L.ctrl[n].coded) {
+                        silk_cng_lane(&s->ch[n], &loss->silk[n], n, fs_kHz, nb_subfr, L.u.core.sLTP[n]);
+                        silk_glue_lane(&loss->silk[n], n, frame_length);
+                    }
+                }
+                OG_SYNC();
+            }
+        }
         // ---- stereo un-mixing (silk_stereo_MS_to_LR silk.cpp:4028) or mono look-back buffering (:1705)
         if (channels == 2) {
             i16 *x1 = L.xq[0], *x2 = L.xq[1];
@@ -1375,14 +1470,18 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
         }
         OG_SYNC();
         OG_MARK(38);
-        prev_dom = decode_only_middle;
-        if (OG_LANE == 0) s->prev_decode_only_middle = decode_only_middle;
+        if (!lost) { // silk.cpp:1772-1778
+            prev_dom = decode_only_middle;
+            if (OG_LANE == 0) s->prev_decode_only_middle = decode_only_middle;
+        }
         emit(fi, out_total);
         OG_SYNC();
     }
     if (OG_LANE == 0) {
         s->nChannelsAPI = channels;
         s->nChannelsInternal = channels;
+        if (lost) // no gain clamping across a loss (silk.cpp:1772-1776)
+            for (int n = 0; n < channels; n++) s->ch[n].LastGainIndex = 10;
     }
     OG_SYNC();
     return 0;

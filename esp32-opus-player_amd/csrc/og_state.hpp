@@ -61,6 +61,32 @@ struct SilkState {              // silk_decoder_t (src/silk.h:758-764) incl. ste
     i32 reserved;
 };
 
+// RFC mode only (loss concealment): what the reference keeps for a path it never takes (lostFlag == 0, Q8) --
+// a channel's last excitation, silk_PLC_struct and silk_CNG_struct (src/silk.h:680-703, :716, :738), and CELT's noise floor
+// and loss counter (src/celt.h:161, src/celt.cpp:2206).  Reference-mode kernels never touch these bytes: they sit at the END
+// of the record, and the record's hot part keeps its layout.
+struct SilkLossChannel {
+    i32 exc_Q14[320];
+    i32 cng_exc_buf_Q14[320];
+    i32 cng_synth_state[16];
+    i32 lossCnt;
+    i32 plc_pitchL_Q8, plc_last_frame_lost, plc_rand_seed, plc_randScale_Q14, plc_conc_energy, plc_conc_energy_shift;
+    i32 plc_prevLTP_scale_Q14, plc_prevGain_Q16[2], plc_fs_kHz, plc_nb_subfr, plc_subfr_length;
+    i32 cng_smth_Gain_Q16, cng_rand_seed, cng_fs_kHz;
+    i16 plc_LTPCoef_Q14[6];    // 5 taps
+    i16 plc_prevLPC_Q12[16];
+    i16 cng_smth_NLSF_Q15[16];
+    i32 reserved;
+};
+struct LossState {
+    SilkLossChannel silk[2];
+    i16 backgroundLogE[2 * NBANDS];
+    i16 pad[2];
+    i32 celt_loss_count;
+    i32 celt_end_band;         // last band of the last decoded CELT / hybrid frame (what a concealment fills up to)
+    i32 reserved[2];
+};
+
 struct StreamState {
     i32 channels;              // decoder channels (OpusHead)
     i32 prev_mode;             // OpusDecoder.prev_mode (src/opus_decoder.cpp:54)
@@ -68,6 +94,7 @@ struct StreamState {
     u32 range_final;
     CeltState celt;
     SilkState silk;
+    LossState loss;            // RFC mode only
 };
 
 // One frame of work for one stream in one decode step (host-built, SoA-free: 16 bytes).

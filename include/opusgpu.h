@@ -61,11 +61,21 @@ const char *opusgpu_last_error(const opusgpu_ctx *ctx);
  * (src/silk.cpp:1522-1540 with the real payload duration), hybrid 10 / 20 ms -- multi-frame packets (codes 1 - 3) accordingly;
  * CELT's last band follows the bandwidth (Q1 fixed) and a SILK-only frame after a hybrid one fades the CELT layer out with the
  * two-byte silence frame of RFC 6716 section 4.5.2 instead of Q4's frame off the stale coder.  Everything else stays as the
- * reference has it (redundancy ignored: Q2; no loss concealment: Q8).  The reference cannot produce these outputs and no
- * libopus exists in the image: this mode is bit-exact to oracle/'s RFC mode (oc_decoder_set_rfc), which is PARITY-UNPINNED.
- * RFC-mode frames run on the single-kernel path (wave-uniform entropy decoding): the mode is for completeness, not speed.
+ * reference has it (redundancy ignored: Q2).  The reference cannot produce these outputs and no libopus exists in the image:
+ * this mode is bit-exact to oracle/'s RFC mode (oc_decoder_set_rfc), which is PARITY-UNPINNED.
+ * RFC-mode frames run on a kernel of their own (wave-uniform entropy decoding): the mode is for completeness, not speed.
+ * LOSS PATH (the reference has none, Q8 -- in reference mode an empty packet stays OPUSGPU_BAD_ARG):
+ *   - opusgpu_decode_packets: packets[i] == NULL or lens[i] == 0 is a LOST packet: it is concealed for as long as the stream's
+ *     last packet was (frame count x frame duration; 20 ms of zeros before the stream's first packet or after a reset), what
+ *     opus_decode(data = NULL, frame_size = last duration) gives; result[i] = the samples concealed;
+ *   - a frame of at most one payload byte (DTX) is concealed for its TOC's duration;
+ *   - opusgpu_decode_step_device: a descriptor with len <= 1 conceals the duration in its flags; mode and bandwidth come from
+ *     the stream's state, the stereo bit should be that of the stream's last packet.
+ *   SILK conceals with the reference's own (unreachable) silk_PLC / silk_CNG code restated (src/silk.cpp:2862-3185, :1305-1432),
+ *   CELT with the noise-based concealment of RFC 6716's decoder; hybrid with both.  Use one mode per stream from its (re)set on:
+ *   the state the concealment needs is only kept by RFC-mode frames.
  * Applies to opusgpu_packet_to_frames_mode / opusgpu_decode_packets / opusgpu_decode_step_device calls made after it is set:
- *   - descriptors carry the duration and the mode bit (frame_desc.flags bits 6 - 9);
+ *   - descriptors carry the duration and the mode bit (frame_desc.flags bits 6 - 9); one without the bit is OPUSGPU_BAD_ARG;
  *   - opusgpu_decode_packets: result[i] and the PCM block of packet i hold the packet's true sample count (<= 5760);
  *   - opusgpu_decode_step_device: d_pcm is [n][OPUSGPU_RFC_FRAME_SAMPLES * channels] (room for a 60 ms frame), d_result[f]
  *     the frame's sample count. */

@@ -93,3 +93,6 @@ int oc_taps_copy(const oc_decoder *d, int what, int c, void *dst) {
     }
     return -1;
 }
+
+/* TEST ENTRY: the mode of the last frame (0 before the first one): what a concealment would run in */
+int oc_decoder_prev_mode(const oc_decoder *d) { return d->prev_mode; }

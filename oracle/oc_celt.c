@@ -1230,7 +1230,10 @@ int oc_celt_decode(oc_celt *st, oc_rc *rc, i16 *pcm, int frame_size, oc_celt_tap
     if (!transient) {
         memcpy(logE2, logE1, 2 * NB * sizeof(*logE2));
         memcpy(logE1, bandE, 2 * NB * sizeof(*logE1));
-        /* backgroundLogE (celt.cpp:2413-2418) only feeds the absent PLC: not kept */
+        { /* celt.cpp:2411-2418: the noise floor rises by at most 2.4 dB/s, or 1 dB per update after a long loss */
+            const i16 inc = st->loss_count < 10 ? (i16)(M * 1) : 1024; /* M * QCONST16(0.001f, DB_SHIFT), QCONST16(1.f, DB_SHIFT) */
+            for (i = 0; i < 2 * NB; i++) st->backgroundLogE[i] = OC_MIN((i16)(st->backgroundLogE[i] + inc), bandE[i]);
+        }
     } else {
         for (i = 0; i < 2 * NB; i++) logE1[i] = OC_MIN(logE1[i], bandE[i]);
     }
@@ -1249,9 +1252,48 @@ int oc_celt_decode(oc_celt *st, oc_rc *rc, i16 *pcm, int frame_size, oc_celt_tap
     if (taps) taps->rc_rng_end = rc->rng;
 
     deemphasis(out_syn, pcm, N, CC, st->deemph_mem);
+    st->loss_count = 0;
     for (c = 0; c < CC; c++) /* keep OC_HIST samples of history + the 60-sample overlap tail at out_syn[0..60) */
         memmove(st->syn[c], st->syn[c] + N, (OC_HIST + OC_OVERLAP / 2) * sizeof(i32));
     if (oc_rc_tell(rc) > 8 * (i32)rc->storage) return OC_INTERNAL_ERROR;
     if (rc->error) st->error = 1;
+    return frame_size;
+}
+
+/* RFC 6716's celt_decode_lost, noise-based branch, then the tail of celt_decode_with_ec for a lost frame (de-emphasis only) */
+int oc_celt_decode_lost(oc_celt *st, i16 *pcm, int frame_size) {
+    const i32 *eb = rom_eband;
+    const int C = st->channels; /* the concealment runs over the decoder's channels, not the last packet's */
+    const int start = st->start_band, end = (st->end_band > 0 && st->end_band <= NB) ? st->end_band : NB;
+    const int effEnd = OC_MAX(start, OC_MIN(end, NB));
+    const i16 decay = st->loss_count == 0 ? 1536 : 512; /* QCONST16(1.5f, DB_SHIFT) : QCONST16(.5f, DB_SHIFT) */
+    i32 *out_syn[2];
+    i16 X[2 * 960];
+    int c, i, j, LM, N;
+    u32 seed;
+    for (LM = 0; LM <= 3; LM++)
+        if (120 << LM == frame_size) break;
+    if (LM > 3 || pcm == NULL) return OC_BAD_ARG;
+    N = 120 << LM;
+    for (c = 0; c < C; c++) out_syn[c] = st->syn[c] + OC_HIST;
+    for (c = 0; c < C; c++)
+        for (i = start; i < end; i++)
+            st->bandE[c * NB + i] = OC_MAX(st->backgroundLogE[c * NB + i], (i16)(st->bandE[c * NB + i] - decay));
+    memset(X, 0, sizeof(X));
+    seed = st->rng;
+    for (c = 0; c < C; c++)
+        for (i = start; i < effEnd; i++) {
+            const int boffs = N * c + (eb[i] << LM), blen = (eb[i + 1] - eb[i]) << LM;
+            for (j = 0; j < blen; j++) {
+                seed = lcg(seed);
+                X[boffs + j] = (i16)((i32)seed >> 20);
+            }
+            renormalise(X + boffs, blen, 32767);
+        }
+    st->rng = seed;
+    synthesis(st, X, out_syn, st->bandE, start, effEnd, C, C, 0, LM, 0, NULL);
+    deemphasis(out_syn, pcm, N, C, st->deemph_mem);
+    st->loss_count++;
+    for (c = 0; c < C; c++) memmove(st->syn[c], st->syn[c] + N, (OC_HIST + OC_OVERLAP / 2) * sizeof(i32));
     return frame_size;
 }

@@ -80,6 +80,8 @@ typedef struct {
     i32 deemph_mem[2];
     i32 syn[2][OC_SYNLEN]; /* [0,OC_HIST) = history, out_syn starts at OC_HIST */
     i16 bandE[2 * OC_NBANDS], logE1[2 * OC_NBANDS], logE2[2 * OC_NBANDS];
+    i16 backgroundLogE[2 * OC_NBANDS]; /* celt.cpp:2206, :2413-2418: the noise floor the concealment decays to */
+    i32 loss_count;                    /* celt.h:161 */
 } oc_celt;
 
 /* optional stage taps for parity tests of the HIP kernels (filled when non-NULL) */
@@ -99,6 +101,10 @@ typedef struct {
 void oc_celt_init(oc_celt *st, int channels);           /* celt_decoder_init  celt.cpp:1933 */
 void oc_celt_reset(oc_celt *st);                        /* OPUS_RESET_STATE   celt.cpp:2479 (partial, Q5) */
 int oc_celt_decode(oc_celt *st, oc_rc *rc, i16 *pcm, int frame_size, oc_celt_taps *taps); /* celt.cpp:2162 */
+/* Concealment of a lost CELT frame (RFC mode only; the reference has none, Q8): the noise-based branch of RFC 6716's decoder
+ * (celt_decode_lost): band energies decay towards backgroundLogE, every band is filled with renormalised LCG noise, one long
+ * MDCT, no post-filter.  The pitch-based branch is in neither the reference nor normative and is not restated. */
+int oc_celt_decode_lost(oc_celt *st, i16 *pcm, int frame_size);
 
 /* stage functions exported for unit tests of the HIP kernels */
 void oc_imdct(const i32 *in, i32 *out, int overlap, int shift, int stride);     /* celt.cpp:3204 */
@@ -118,6 +124,11 @@ int oc_silk_decode(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int fir
  * frames per packet, one call each (silk.cpp:1522-1540 sets nFramesPerPacket / nb_subfr from payloadSize_ms; the reference
  * pins that to 20).  NOT pinned by any reference output: written from RFC 6716 section 4.2. */
 int oc_silk_decode_ms(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int first, int payload_ms, i16 *out, i32 *n_out);
+/* ... and with the reference's lostFlag (silk.cpp:1483): 0 normal, 1 packet lost (conceal payload_ms = 10 or 20; rc unused;
+ * internal_hz 0 keeps the rate of the last frame), 2 decode the LBRR (FEC) copy.  The reference never calls with 1 or 2 (Q8):
+ * the code is its silk_PLC / silk_CNG (:2862-3185, :1305-1432), reachable only in RFC mode; NOT pinned by any reference output. */
+int oc_silk_decode_ex(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int first, int payload_ms, int lostFlag, i16 *out,
+                      i32 *n_out);
 
 /* ---- packet layer (opus_decoder.cpp) ------------------------------------------------------ */
 typedef struct oc_decoder {

@@ -206,6 +206,52 @@ static int rfc_end_band(int bandwidth) {
     }
 }
 
+/* RFC mode, a frame with nothing to decode (the packet was lost: inbuf NULL; or a DTX frame: at most one payload byte):
+ * RFC 6716's opus_decode_frame with data == NULL.  The mode is the previous frame's; `frame_size` is what is to be concealed
+ * (120 << k, or a multiple of 960): more than 20 ms goes in chunks of 20 ms; SILK conceals 10 or 20 ms (2.5 / 5 ms requests take
+ * the head of a 10 ms concealment); CELT (and hybrid's CELT layer, from band 17) conceals with oc_celt_decode_lost.  No
+ * transition smoothing and no redundancy, like the rest of this decoder (Q7, Q2). */
+static int conceal_frame(oc_decoder *d, i16 *out, int frame_size) {
+    const int mode = d->prev_mode, ch = d->stream_channels, CC = d->channels;
+    int audiosize = frame_size, i, nmix, celt_ret = 0;
+    i16 pcm_silk[960 * 2];
+    if (mode == 0) { /* nothing decoded yet: all we can do is return zeros */
+        for (i = 0; i < audiosize * CC; i++) out[i] = 0;
+        return audiosize;
+    }
+    if (audiosize > 960) {
+        int done = 0;
+        do {
+            int ret = conceal_frame(d, out + done * CC, OC_MIN(audiosize - done, 960));
+            if (ret < 0) return ret;
+            done += ret;
+        } while (done < audiosize);
+        return frame_size;
+    }
+    nmix = audiosize * (ch < CC ? ch : CC);
+    if (mode != OC_MODE_CELT) {
+        int decoded = 0;
+        i16 *p = pcm_silk;
+        const int payload_ms = OC_MAX(10, audiosize / 48);
+        do {
+            i32 n = 0;
+            if (oc_silk_decode_ex(d->silk, &d->rc, ch, 0, decoded == 0, payload_ms, 1, p, &n)) return OC_INTERNAL_ERROR;
+            p += n * ch;
+            decoded += n;
+        } while (decoded < audiosize);
+    }
+    d->celt.start_band = mode != OC_MODE_CELT ? 17 : 0; /* the last band stays what the last frame made it */
+    if (mode != OC_MODE_SILK)
+        celt_ret = oc_celt_decode_lost(&d->celt, out, audiosize);
+    else
+        for (i = 0; i < nmix; i++) out[i] = 0;
+    if (mode != OC_MODE_CELT)
+        for (i = 0; i < nmix; i++) out[i] = sat16((i32)out[i] + pcm_silk[i]);
+    d->prev_mode = mode;
+    d->range_final = 0;
+    return celt_ret < 0 ? celt_ret : audiosize;
+}
+
 /* opus_decoder.cpp:154.  Reference mode: audiosize is 960 whatever the TOC says (Q6).  RFC mode: the TOC's duration. */
 static int decode_frame(oc_decoder *d, const u8 *inbuf, i32 len, i16 *out) {
     const int mode = d->mode, ch = d->stream_channels, audiosize = d->rfc ? d->frame_size : 960;
@@ -218,6 +264,7 @@ static int decode_frame(oc_decoder *d, const u8 *inbuf, i32 len, i16 *out) {
     i16 pcm_silk[2880 * 2];
     oc_rc *rc = &d->rc;
 
+    if (d->rfc && (inbuf == NULL || len <= 1)) return conceal_frame(d, out, d->frame_size);
     oc_rc_init(rc, inbuf, len);
     if (mode != OC_MODE_CELT) {
         int decoded = 0, internal_hz;
@@ -275,6 +322,18 @@ int oc_decode(oc_decoder *d, const u8 *data, i32 len, i16 *pcm, int frame_size) 
     i16 size[48];
     u8 toc;
     if (frame_size <= 0) return OC_BAD_ARG;
+    if (d->rfc && (len == 0 || data == NULL)) { /* a lost packet: conceal frame_size samples, a frame of the last size at a time */
+        int done = 0;
+        if (frame_size % 120) return OC_BAD_ARG;
+        while (done < frame_size) {
+            const int want = OC_MIN(frame_size - done, d->frame_size);
+            int ret = conceal_frame(d, pcm + done * d->channels, want);
+            if (ret < 0) return ret;
+            done += ret;
+        }
+        d->last_packet_duration = done;
+        return done;
+    }
     if (len <= 0 || data == NULL) return OC_BAD_ARG; /* no PLC in the reference (Q8) */
     pmode = oc_packet_mode(data);
     pbw = oc_packet_bandwidth(data);

@@ -6,7 +6,10 @@
  * silk_NLSF_decode / _stabilize / _unpack (:2466, :2676, :2762), silk_NLSF2A (:642),
  * silk_LPC_fit (:2314), silk_LPC_inverse_pred_gain (:2359-2443), silk_decode_core (:1806),
  * silk_stereo_* (:592-623, :4028), silk_resampler* (:3451-3713), with the state in oc_silk.
- * PLC/CNG state updates are not kept: with lostFlag == 0 they never reach the PCM.
+ * The loss path -- silk_PLC (:2862-3185), silk_CNG (:1305-1432), the lostFlag branches of silk_Decode / silk_decode_frame
+ * and LBRR (FEC) decoding -- is restated too.  The reference never reaches it (lostFlag == 0 always, Q8): with lossCnt == 0
+ * the per-frame state updates (silk_PLC_update, the CNG smoothing, glue_frames) do not touch the PCM, so
+ * reference-mode output is unchanged; only the oracle's RFC mode (oc_decoder_set_rfc) calls with lostFlag != 0.
  */
 #include "oc_celt_priv.h"
 
@@ -36,6 +39,20 @@ typedef struct {
     i32 VAD_flags[3], LBRR_flag, LBRR_flags[3];
     side_info idx;
     i32 lossCnt, prevSignalType;
+    struct { /* silk_PLC_struct silk.h:680 */
+        i32 pitchL_Q8;
+        i16 LTPCoef_Q14[LTP_ORDER], prevLPC_Q12[MAX_LPC];
+        i32 last_frame_lost, rand_seed;
+        i16 randScale_Q14;
+        i32 conc_energy, conc_energy_shift;
+        i16 prevLTP_scale_Q14;
+        i32 prevGain_Q16[2], fs_kHz, nb_subfr, subfr_length;
+    } plc;
+    struct { /* silk_CNG_struct silk.h:696 */
+        i32 exc_buf_Q14[MAX_FRAME];
+        i16 smth_NLSF_Q15[MAX_LPC];
+        i32 synth_state[MAX_LPC], smth_Gain_Q16, rand_seed, fs_kHz;
+    } cng;
 } chan_t;
 
 typedef struct {
@@ -91,11 +108,33 @@ int oc_silk_taps_copy(int what, int ch, void *dst) {
     return -1;
 }
 
+/* silk_CNG_Reset silk.cpp:1327 */
+static void cng_reset(chan_t *c) {
+    int i;
+    i32 step = 32767 / (c->LPC_order + 1), acc = 0;
+    for (i = 0; i < c->LPC_order; i++) {
+        acc += step;
+        c->cng.smth_NLSF_Q15[i] = (i16)acc;
+    }
+    c->cng.smth_Gain_Q16 = 0;
+    c->cng.rand_seed = 3176576;
+}
+
+/* silk_PLC_Reset silk.cpp:2862 */
+static void plc_reset(chan_t *c) {
+    c->plc.pitchL_Q8 = shl32(c->frame_length, 8 - 1);
+    c->plc.prevGain_Q16[0] = c->plc.prevGain_Q16[1] = 1 << 16;
+    c->plc.subfr_length = 20;
+    c->plc.nb_subfr = 2;
+}
+
 /* silk_init_decoder silk.cpp:2192 */
 static void chan_init(chan_t *c) {
     memset(c, 0, sizeof(*c));
     c->first_frame_after_reset = 1;
     c->prev_gain_Q16 = 65536;
+    cng_reset(c);
+    plc_reset(c);
 }
 
 /* silk_InitDecoder silk.cpp:1792: the channel states and the stereo state; NOT the resamplers nor the
@@ -440,6 +479,17 @@ static void bwexpander_32(i32 *ar, int d, i32 chirp_Q16) {
     ar[d - 1] = smulww(chirp_Q16, ar[d - 1]);
 }
 
+/* silk_bwexpander silk.cpp:576 (16-bit coefficients) */
+static void bwexpander(i16 *ar, int d, i32 chirp_Q16) {
+    i32 chirp_minus_one_Q16 = chirp_Q16 - 65536;
+    int i;
+    for (i = 0; i < d - 1; i++) {
+        ar[i] = (i16)rshift_round(chirp_Q16 * ar[i], 16);
+        chirp_Q16 += rshift_round(chirp_Q16 * chirp_minus_one_Q16, 16);
+    }
+    ar[d - 1] = (i16)rshift_round(chirp_Q16 * ar[d - 1], 16);
+}
+
 /* silk_LPC_fit silk.cpp:2314 */
 static void lpc_fit(i16 *a_QOUT, i32 *a_QIN, int QOUT, int QIN, int d) {
     int i, k, idx = 0;
@@ -597,7 +647,10 @@ static void decode_parameters(chan_t *c, ctrl_t *ct, int condCoding) {
     } else
         memcpy(ct->PredCoef_Q12[0], ct->PredCoef_Q12[1], c->LPC_order * sizeof(i16));
     memcpy(c->prevNLSF_Q15, pNLSF_Q15, c->LPC_order * sizeof(i16));
-    /* lossCnt is always 0: no bandwidth expansion after loss */
+    if (c->lossCnt) { /* silk.cpp:860-864: after a packet loss do BWE of the LPC coefficients (BWE_AFTER_LOSS_Q16) */
+        bwexpander(ct->PredCoef_Q12[0], c->LPC_order, 63570);
+        bwexpander(ct->PredCoef_Q12[1], c->LPC_order, 63570);
+    }
     if (c->idx.signalType == 2) {
         const signed char *cbk = (const signed char *)(c->idx.PERIndex == 0 ? rom_silk_ltp_vq0
                                                        : (c->idx.PERIndex == 1 ? rom_silk_ltp_vq1 : rom_silk_ltp_vq2));
@@ -670,7 +723,13 @@ static void decode_core(chan_t *c, ctrl_t *ct, i16 xq[], const i16 pulses[]) {
         } else
             gain_adj_Q16 = 1 << 16;
         c->prev_gain_Q16 = ct->Gains_Q16[k];
-        /* lossCnt == 0: no PLC->unvoiced smoothing */
+        /* silk.cpp:1869-1876: avoid an abrupt transition from voiced PLC to unvoiced normal decoding */
+        if (c->lossCnt && c->prevSignalType == 2 && c->idx.signalType != 2 && k < 2) {
+            memset(B_Q14, 0, LTP_ORDER * sizeof(i16));
+            B_Q14[LTP_ORDER / 2] = 4096; /* SILK_FIX_CONST(0.25, 14) */
+            signalType = 2;
+            ct->pitchL[k] = c->lagPrev;
+        }
         if (signalType == 2) {
             lag = ct->pitchL[k];
             if (k == 0 || (k == 2 && NLSF_interpolation_flag)) {
@@ -717,21 +776,292 @@ static void decode_core(chan_t *c, ctrl_t *ct, i16 xq[], const i16 pulses[]) {
     memcpy(c->sLPC_Q14_buf, sLPC_Q14, MAX_LPC * sizeof(i32));
 }
 
-/* silk_decode_frame silk.cpp:1974 (normal decoding only) */
-static void decode_frame(chan_t *c, ctrl_t *ct, oc_rc *rc, i16 pOut[], i32 *pN, int condCoding) {
+/* ---- loss concealment and comfort noise (silk.cpp:2862-3185, :1305-1432) -------------------------------- */
+/* silk_sum_sqr_shift silk.cpp:3839 */
+static void sum_sqr_shift(i32 *energy, i32 *shift, const i16 *x, int len) {
+    int i, shft = 31 - clz32(len);
+    i32 nrg = len;
+    u32 t;
+    for (i = 0; i < len - 1; i += 2) {
+        t = (u32)smulbb(x[i], x[i]);
+        t += (u32)smulbb(x[i + 1], x[i + 1]);
+        nrg = (i32)((u32)nrg + (t >> shft));
+    }
+    if (i < len) {
+        t = (u32)smulbb(x[i], x[i]);
+        nrg = (i32)((u32)nrg + (t >> shft));
+    }
+    shft = OC_MAX(0, shft + 3 - clz32(nrg));
+    nrg = 0;
+    for (i = 0; i < len - 1; i += 2) {
+        t = (u32)smulbb(x[i], x[i]);
+        t += (u32)smulbb(x[i + 1], x[i + 1]);
+        nrg = (i32)((u32)nrg + (t >> shft));
+    }
+    if (i < len) {
+        t = (u32)smulbb(x[i], x[i]);
+        nrg = (i32)((u32)nrg + (t >> shft));
+    }
+    *shift = shft;
+    *energy = nrg;
+}
+
+/* silk_SQRT_APPROX silk.h:888 */
+static i32 sqrt_approx(i32 x) {
+    i32 y, lz, frac_Q7;
+    if (x <= 0) return 0;
+    lz = clz32(x);
+    frac_Q7 = ror32(x, 24 - lz) & 0x7f;
+    y = (lz & 1) ? 32768 : 46214;
+    y >>= lz >> 1;
+    return smlawb(y, y, smulbb(213, frac_Q7));
+}
+
+/* silk_PLC_update silk.cpp:2895 */
+static void plc_update(chan_t *c, const ctrl_t *ct) {
+    i32 LTP_Gain_Q14 = 0, temp;
+    int i, j;
+    c->prevSignalType = c->idx.signalType;
+    if (c->idx.signalType == 2) {
+        for (j = 0; j * c->subfr_length < ct->pitchL[c->nb_subfr - 1]; j++) {
+            if (j == c->nb_subfr) break;
+            temp = 0;
+            for (i = 0; i < LTP_ORDER; i++) temp += ct->LTPCoef_Q14[(c->nb_subfr - 1 - j) * LTP_ORDER + i];
+            if (temp > LTP_Gain_Q14) {
+                LTP_Gain_Q14 = temp;
+                memcpy(c->plc.LTPCoef_Q14, &ct->LTPCoef_Q14[smulbb(c->nb_subfr - 1 - j, LTP_ORDER)], LTP_ORDER * sizeof(i16));
+                c->plc.pitchL_Q8 = shl32(ct->pitchL[c->nb_subfr - 1 - j], 8);
+            }
+        }
+        memset(c->plc.LTPCoef_Q14, 0, LTP_ORDER * sizeof(i16));
+        c->plc.LTPCoef_Q14[LTP_ORDER / 2] = (i16)LTP_Gain_Q14;
+        if (LTP_Gain_Q14 < 11469) { /* V_PITCH_GAIN_START_MIN_Q14 */
+            i32 scale_Q10 = shl32(11469, 10) / OC_MAX(LTP_Gain_Q14, 1);
+            for (i = 0; i < LTP_ORDER; i++) c->plc.LTPCoef_Q14[i] = (i16)(smulbb(c->plc.LTPCoef_Q14[i], scale_Q10) >> 10);
+        } else if (LTP_Gain_Q14 > 15565) { /* V_PITCH_GAIN_START_MAX_Q14 */
+            i32 scale_Q14 = shl32(15565, 14) / OC_MAX(LTP_Gain_Q14, 1);
+            for (i = 0; i < LTP_ORDER; i++) c->plc.LTPCoef_Q14[i] = (i16)(smulbb(c->plc.LTPCoef_Q14[i], scale_Q14) >> 14);
+        }
+    } else {
+        c->plc.pitchL_Q8 = shl32(smulbb(c->fs_kHz, 18), 8);
+        memset(c->plc.LTPCoef_Q14, 0, LTP_ORDER * sizeof(i16));
+    }
+    memcpy(c->plc.prevLPC_Q12, ct->PredCoef_Q12[1], c->LPC_order * sizeof(i16));
+    c->plc.prevLTP_scale_Q14 = (i16)ct->LTP_scale_Q14;
+    memcpy(c->plc.prevGain_Q16, &ct->Gains_Q16[c->nb_subfr - 2], 2 * sizeof(i32));
+    c->plc.subfr_length = c->subfr_length;
+    c->plc.nb_subfr = c->nb_subfr;
+}
+
+/* silk_PLC_conceal silk.cpp:2973 (with silk_PLC_energy :2956) */
+static void plc_conceal(chan_t *c, ctrl_t *ct, i16 frame[]) {
+    static const i16 HARM_ATT_Q15[2] = {32440, 31130}, RAND_ATT_V_Q15[2] = {31130, 26214}, RAND_ATT_UV_Q15[2] = {32440, 29491};
+    i32 sLTP_Q14[2 * MAX_FRAME + MAX_LPC], prevGain_Q10[2], energy1, energy2, shift1, shift2, *rand_ptr, *pred_lag_ptr, *sLPC;
+    i32 rand_seed, harm_Gain_Q15, rand_Gain_Q15, inv_gain_Q30, lag, idx, sLTP_buf_idx;
+    i16 sLTP[MAX_FRAME], exc_buf[2 * 80], A_Q12[MAX_LPC], rand_scale_Q14, *B_Q14 = c->plc.LTPCoef_Q14;
+    int i, j, k, att = OC_MIN(1, c->lossCnt);
+    memset(sLTP_Q14, 0, sizeof(sLTP_Q14));
+    memset(sLTP, 0, sizeof(sLTP));
+    prevGain_Q10[0] = c->plc.prevGain_Q16[0] >> 6;
+    prevGain_Q10[1] = c->plc.prevGain_Q16[1] >> 6;
+    if (c->first_frame_after_reset) memset(c->plc.prevLPC_Q12, 0, sizeof(c->plc.prevLPC_Q12));
+    for (k = 0; k < 2; k++)
+        for (i = 0; i < c->subfr_length; i++)
+            exc_buf[k * c->subfr_length + i] =
+                sat16(smulww(c->exc_Q14[i + (k + c->nb_subfr - 2) * c->subfr_length], prevGain_Q10[k]) >> 8);
+    sum_sqr_shift(&energy1, &shift1, exc_buf, c->subfr_length);
+    sum_sqr_shift(&energy2, &shift2, &exc_buf[c->subfr_length], c->subfr_length);
+    if ((energy1 >> shift2) < (energy2 >> shift1))
+        rand_ptr = &c->exc_Q14[OC_MAX(0, (c->plc.nb_subfr - 1) * c->plc.subfr_length - 128)];
+    else
+        rand_ptr = &c->exc_Q14[OC_MAX(0, c->plc.nb_subfr * c->plc.subfr_length - 128)];
+    rand_scale_Q14 = c->plc.randScale_Q14;
+    harm_Gain_Q15 = HARM_ATT_Q15[att];
+    rand_Gain_Q15 = c->prevSignalType == 2 ? RAND_ATT_V_Q15[att] : RAND_ATT_UV_Q15[att];
+    bwexpander(c->plc.prevLPC_Q12, c->LPC_order, 64881); /* SILK_FIX_CONST(BWE_COEF = 0.99, 16) */
+    memcpy(A_Q12, c->plc.prevLPC_Q12, c->LPC_order * sizeof(i16));
+    if (c->lossCnt == 0) { /* first lost frame */
+        rand_scale_Q14 = 1 << 14;
+        if (c->prevSignalType == 2) {
+            for (i = 0; i < LTP_ORDER; i++) rand_scale_Q14 = (i16)(rand_scale_Q14 - B_Q14[i]);
+            rand_scale_Q14 = OC_MAX(3277, rand_scale_Q14);
+            rand_scale_Q14 = (i16)(smulbb(rand_scale_Q14, c->plc.prevLTP_scale_Q14) >> 14);
+        } else {
+            i32 invGain_Q30 = inverse_pred_gain(c->plc.prevLPC_Q12, c->LPC_order), down_scale_Q30;
+            down_scale_Q30 = OC_MIN((1 << 30) >> 3, invGain_Q30); /* LOG2_INV_LPC_GAIN_HIGH_THRES */
+            down_scale_Q30 = OC_MAX((1 << 30) >> 8, down_scale_Q30); /* LOG2_INV_LPC_GAIN_LOW_THRES */
+            down_scale_Q30 = shl32(down_scale_Q30, 3);
+            rand_Gain_Q15 = smulwb(down_scale_Q30, rand_Gain_Q15) >> 14;
+        }
+    }
+    rand_seed = c->plc.rand_seed;
+    lag = rshift_round(c->plc.pitchL_Q8, 8);
+    sLTP_buf_idx = c->ltp_mem_length;
+    idx = c->ltp_mem_length - lag - c->LPC_order - LTP_ORDER / 2;
+    lpc_analysis_filter(&sLTP[idx], &c->outBuf[idx], A_Q12, c->ltp_mem_length - idx, c->LPC_order);
+    inv_gain_Q30 = inverse32_varQ(c->plc.prevGain_Q16[1], 46);
+    inv_gain_Q30 = OC_MIN(inv_gain_Q30, INT32_MAX >> 1);
+    for (i = idx + c->LPC_order; i < c->ltp_mem_length; i++) sLTP_Q14[i] = smulwb(inv_gain_Q30, sLTP[i]);
+    for (k = 0; k < c->nb_subfr; k++) {
+        pred_lag_ptr = &sLTP_Q14[sLTP_buf_idx - lag + LTP_ORDER / 2];
+        for (i = 0; i < c->subfr_length; i++) {
+            i32 LTP_pred_Q12 = 2;
+            LTP_pred_Q12 = smlawb(LTP_pred_Q12, pred_lag_ptr[0], B_Q14[0]);
+            LTP_pred_Q12 = smlawb(LTP_pred_Q12, pred_lag_ptr[-1], B_Q14[1]);
+            LTP_pred_Q12 = smlawb(LTP_pred_Q12, pred_lag_ptr[-2], B_Q14[2]);
+            LTP_pred_Q12 = smlawb(LTP_pred_Q12, pred_lag_ptr[-3], B_Q14[3]);
+            LTP_pred_Q12 = smlawb(LTP_pred_Q12, pred_lag_ptr[-4], B_Q14[4]);
+            pred_lag_ptr++;
+            rand_seed = silk_rand(rand_seed);
+            idx = (rand_seed >> 25) & 127; /* RAND_BUF_MASK */
+            sLTP_Q14[sLTP_buf_idx] = shl32(smlawb(LTP_pred_Q12, rand_ptr[idx], rand_scale_Q14), 2);
+            sLTP_buf_idx++;
+        }
+        for (j = 0; j < LTP_ORDER; j++) B_Q14[j] = (i16)(smulbb(harm_Gain_Q15, B_Q14[j]) >> 15);
+        if (c->idx.signalType != 0) rand_scale_Q14 = (i16)(smulbb(rand_scale_Q14, rand_Gain_Q15) >> 15);
+        c->plc.pitchL_Q8 = smlawb(c->plc.pitchL_Q8, c->plc.pitchL_Q8, 655); /* PITCH_DRIFT_FAC_Q16 */
+        c->plc.pitchL_Q8 = OC_MIN(c->plc.pitchL_Q8, shl32(smulbb(18, c->fs_kHz), 8)); /* MAX_PITCH_LAG_MS */
+        lag = rshift_round(c->plc.pitchL_Q8, 8);
+    }
+    sLPC = &sLTP_Q14[c->ltp_mem_length - MAX_LPC];
+    memcpy(sLPC, c->sLPC_Q14_buf, MAX_LPC * sizeof(i32));
+    for (i = 0; i < c->frame_length; i++) {
+        i32 LPC_pred_Q10 = c->LPC_order >> 1;
+        for (j = 0; j < c->LPC_order; j++) LPC_pred_Q10 = smlawb(LPC_pred_Q10, sLPC[MAX_LPC + i - j - 1], A_Q12[j]);
+        sLPC[MAX_LPC + i] = add_sat32(sLPC[MAX_LPC + i], lshift_sat32(LPC_pred_Q10, 4));
+        frame[i] = sat16(rshift_round(smulww(sLPC[MAX_LPC + i], prevGain_Q10[1]), 8));
+    }
+    memcpy(c->sLPC_Q14_buf, &sLPC[c->frame_length], MAX_LPC * sizeof(i32));
+    c->plc.rand_seed = rand_seed;
+    c->plc.randScale_Q14 = rand_scale_Q14;
+    for (i = 0; i < 4; i++) ct->pitchL[i] = lag;
+}
+
+/* silk_PLC silk.cpp:2871 */
+static void plc(chan_t *c, ctrl_t *ct, i16 frame[], int lost) {
+    if (c->fs_kHz != c->plc.fs_kHz) {
+        plc_reset(c);
+        c->plc.fs_kHz = c->fs_kHz;
+    }
+    if (lost) {
+        plc_conceal(c, ct, frame);
+        c->lossCnt++;
+    } else
+        plc_update(c, ct);
+}
+
+/* silk_PLC_glue_frames silk.cpp:3138 */
+static void plc_glue_frames(chan_t *c, i16 frame[], int length) {
+    i32 energy, energy_shift;
+    int i;
+    if (c->lossCnt) {
+        sum_sqr_shift(&c->plc.conc_energy, &c->plc.conc_energy_shift, frame, length);
+        c->plc.last_frame_lost = 1;
+        return;
+    }
+    if (c->plc.last_frame_lost) {
+        sum_sqr_shift(&energy, &energy_shift, frame, length);
+        if (energy_shift > c->plc.conc_energy_shift)
+            c->plc.conc_energy >>= energy_shift - c->plc.conc_energy_shift;
+        else if (energy_shift < c->plc.conc_energy_shift)
+            energy >>= c->plc.conc_energy_shift - energy_shift;
+        if (energy > c->plc.conc_energy) {
+            i32 frac_Q24, gain_Q16, slope_Q16;
+            int LZ = clz32(c->plc.conc_energy) - 1;
+            c->plc.conc_energy = shl32(c->plc.conc_energy, LZ);
+            energy >>= OC_MAX(24 - LZ, 0);
+            frac_Q24 = c->plc.conc_energy / OC_MAX(energy, 1);
+            gain_Q16 = shl32(sqrt_approx(frac_Q24), 4);
+            slope_Q16 = ((1 << 16) - gain_Q16) / length;
+            slope_Q16 = shl32(slope_Q16, 2);
+            for (i = 0; i < length; i++) {
+                frame[i] = (i16)smulwb(gain_Q16, frame[i]);
+                gain_Q16 += slope_Q16;
+                if (gain_Q16 > 1 << 16) break;
+            }
+        }
+    }
+    c->plc.last_frame_lost = 0;
+}
+
+/* silk_CNG silk.cpp:1342 (with silk_CNG_exc :1305) */
+static void cng(chan_t *c, const ctrl_t *ct, i16 frame[], int length) {
+    int i, j, subfr;
+    if (c->fs_kHz != c->cng.fs_kHz) {
+        cng_reset(c);
+        c->cng.fs_kHz = c->fs_kHz;
+    }
+    if (c->lossCnt == 0 && c->prevSignalType == 0) {
+        i32 max_Gain_Q16 = 0;
+        for (i = 0; i < c->LPC_order; i++)
+            c->cng.smth_NLSF_Q15[i] = (i16)(c->cng.smth_NLSF_Q15[i] + smulwb((i32)c->prevNLSF_Q15[i] - (i32)c->cng.smth_NLSF_Q15[i], 16348));
+        subfr = 0;
+        for (i = 0; i < c->nb_subfr; i++)
+            if (ct->Gains_Q16[i] > max_Gain_Q16) {
+                max_Gain_Q16 = ct->Gains_Q16[i];
+                subfr = i;
+            }
+        memmove(&c->cng.exc_buf_Q14[c->subfr_length], c->cng.exc_buf_Q14, (c->nb_subfr - 1) * c->subfr_length * sizeof(i32));
+        memcpy(c->cng.exc_buf_Q14, &c->exc_Q14[subfr * c->subfr_length], c->subfr_length * sizeof(i32));
+        for (i = 0; i < c->nb_subfr; i++) c->cng.smth_Gain_Q16 += smulwb(ct->Gains_Q16[i] - c->cng.smth_Gain_Q16, 4634);
+    }
+    if (c->lossCnt) {
+        i32 sig_Q14[MAX_FRAME + MAX_LPC], gain_Q16, gain_Q10, seed, exc_mask = 255; /* CNG_BUF_MASK_MAX */
+        i16 A_Q12[MAX_LPC];
+        gain_Q16 = smulww(c->plc.randScale_Q14, c->plc.prevGain_Q16[1]);
+        if (gain_Q16 >= (1 << 21) || c->cng.smth_Gain_Q16 > (1 << 23)) {
+            gain_Q16 = (gain_Q16 >> 16) * (gain_Q16 >> 16);
+            gain_Q16 = subw((c->cng.smth_Gain_Q16 >> 16) * (c->cng.smth_Gain_Q16 >> 16), shl32(gain_Q16, 5));
+            gain_Q16 = shl32(sqrt_approx(gain_Q16), 16);
+        } else {
+            gain_Q16 = smulww(gain_Q16, gain_Q16);
+            gain_Q16 = subw(smulww(c->cng.smth_Gain_Q16, c->cng.smth_Gain_Q16), shl32(gain_Q16, 5));
+            gain_Q16 = shl32(sqrt_approx(gain_Q16), 8);
+        }
+        gain_Q10 = gain_Q16 >> 6;
+        while (exc_mask > length) exc_mask >>= 1;
+        seed = c->cng.rand_seed;
+        for (i = 0; i < length; i++) {
+            seed = silk_rand(seed);
+            sig_Q14[MAX_LPC + i] = c->cng.exc_buf_Q14[(seed >> 24) & exc_mask];
+        }
+        c->cng.rand_seed = seed;
+        nlsf2a(A_Q12, c->cng.smth_NLSF_Q15, c->LPC_order);
+        memcpy(sig_Q14, c->cng.synth_state, MAX_LPC * sizeof(i32));
+        for (i = 0; i < length; i++) {
+            i32 LPC_pred_Q10 = c->LPC_order >> 1;
+            for (j = 0; j < c->LPC_order; j++) LPC_pred_Q10 = smlawb(LPC_pred_Q10, sig_Q14[MAX_LPC + i - j - 1], A_Q12[j]);
+            sig_Q14[MAX_LPC + i] = add_sat32(sig_Q14[MAX_LPC + i], lshift_sat32(LPC_pred_Q10, 4));
+            frame[i] = sat16((i32)frame[i] + sat16(rshift_round(smulww(sig_Q14[MAX_LPC + i], gain_Q10), 8)));
+        }
+        memcpy(c->cng.synth_state, &sig_Q14[length], MAX_LPC * sizeof(i32));
+    } else
+        memset(c->cng.synth_state, 0, c->LPC_order * sizeof(i32));
+}
+
+/* silk_decode_frame silk.cpp:1974.  lostFlag: 0 normal, 1 packet lost, 2 decode the LBRR (FEC) copy */
+static void decode_frame(chan_t *c, ctrl_t *ct, oc_rc *rc, i16 pOut[], i32 *pN, int lostFlag, int condCoding) {
     i16 pulses[MAX_FRAME + 16];
     int L = c->frame_length, mv_len;
     ct->LTP_scale_Q14 = 0;
-    decode_indices(c, rc, c->nFramesDecoded, 0, condCoding);
-    decode_pulses(rc, pulses, c->idx.signalType, c->idx.quantOffsetType, c->frame_length);
-    decode_parameters(c, ct, condCoding);
-    decode_core(c, ct, pOut, pulses);
-    c->lossCnt = 0;
-    c->prevSignalType = c->idx.signalType;
-    c->first_frame_after_reset = 0;
+    if (lostFlag == 0 || (lostFlag == 2 && c->LBRR_flags[c->nFramesDecoded] == 1)) {
+        decode_indices(c, rc, c->nFramesDecoded, lostFlag, condCoding);
+        decode_pulses(rc, pulses, c->idx.signalType, c->idx.quantOffsetType, c->frame_length);
+        decode_parameters(c, ct, condCoding);
+        decode_core(c, ct, pOut, pulses);
+        plc(c, ct, pOut, 0);
+        c->lossCnt = 0;
+        c->prevSignalType = c->idx.signalType;
+        c->first_frame_after_reset = 0;
+    } else {
+        c->idx.signalType = (signed char)c->prevSignalType;
+        plc(c, ct, pOut, 1);
+    }
     mv_len = c->ltp_mem_length - c->frame_length;
     memmove(c->outBuf, &c->outBuf[c->frame_length], mv_len * sizeof(i16));
     memcpy(&c->outBuf[mv_len], pOut, c->frame_length * sizeof(i16));
+    cng(c, ct, pOut, L);
+    plc_glue_frames(c, pOut, L);
     c->lagPrev = ct->pitchL[c->nb_subfr - 1];
     *pN = L;
 }
@@ -903,6 +1233,13 @@ int oc_silk_decode(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int fir
 }
 
 int oc_silk_decode_ms(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int first, int payload_ms, i16 *out, i32 *n_out) {
+    return oc_silk_decode_ex(s, rc, channels, internal_hz, first, payload_ms, 0, out, n_out);
+}
+
+/* lostFlag 1 (packet lost: conceal one frame of payload_ms = 10 or 20; the internal rate stays what it is when internal_hz
+ * is 0) and 2 (decode the LBRR copy of the frame where there is one, conceal otherwise) follow silk.cpp:1481-1779 */
+int oc_silk_decode_ex(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int first, int payload_ms, int lostFlag, i16 *out,
+                      i32 *n_out) {
     i16 tmp[2][MAX_FRAME + 2 + 16], rs_out[960];
     i32 MS_pred_Q13[2] = {0, 0}, nSamplesOutDec = 0;
     int n, i, decode_only_middle = 0, has_side;
@@ -911,7 +1248,7 @@ int oc_silk_decode_ms(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int 
     if (channels > s->nChannelsInternal) chan_init(&s->ch[1]);
     if (s->ch[0].nFramesDecoded == 0) {
         for (n = 0; n < channels; n++) {
-            int fs_kHz_dec = (internal_hz >> 10) + 1;
+            int fs_kHz_dec = internal_hz ? (internal_hz >> 10) + 1 : s->ch[0].fs_kHz;
             /* silk.cpp:1522-1540 with the payload duration the reference pins to 20 ms */
             s->ch[n].nFramesPerPacket = payload_ms == 40 ? 2 : payload_ms == 60 ? 3 : 1;
             s->ch[n].nb_subfr = payload_ms == 10 ? 2 : 4;
@@ -927,7 +1264,7 @@ int oc_silk_decode_ms(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int 
     s->nChannelsAPI = channels;
     s->nChannelsInternal = channels;
 
-    if (s->ch[0].nFramesDecoded == 0) {
+    if (lostFlag != 1 && s->ch[0].nFramesDecoded == 0) {
         for (n = 0; n < channels; n++) {
             for (i = 0; i < s->ch[n].nFramesPerPacket; i++) s->ch[n].VAD_flags[i] = oc_rc_bit_logp(rc, 1);
             s->ch[n].LBRR_flag = oc_rc_bit_logp(rc, 1);
@@ -944,28 +1281,33 @@ int oc_silk_decode_ms(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int 
             }
         }
         /* regular decoding: read past the LBRR data (it still updates the entropy-coding context) */
-        for (i = 0; i < s->ch[0].nFramesPerPacket; i++) {
-            for (n = 0; n < channels; n++) {
-                if (s->ch[n].LBRR_flags[i]) {
-                    i16 pulses[MAX_FRAME + 16];
-                    int condCoding;
-                    if (channels == 2 && n == 0) {
-                        stereo_decode_pred(rc, MS_pred_Q13);
-                        if (s->ch[1].LBRR_flags[i] == 0) decode_only_middle = oc_rc_icdf(rc, rom_silk_mid_only_icdf, 8);
+        if (lostFlag == 0)
+            for (i = 0; i < s->ch[0].nFramesPerPacket; i++) {
+                for (n = 0; n < channels; n++) {
+                    if (s->ch[n].LBRR_flags[i]) {
+                        i16 pulses[MAX_FRAME + 16];
+                        int condCoding;
+                        if (channels == 2 && n == 0) {
+                            stereo_decode_pred(rc, MS_pred_Q13);
+                            if (s->ch[1].LBRR_flags[i] == 0) decode_only_middle = oc_rc_icdf(rc, rom_silk_mid_only_icdf, 8);
+                        }
+                        condCoding = (i > 0 && s->ch[n].LBRR_flags[i - 1]) ? 2 : 0;
+                        decode_indices(&s->ch[n], rc, i, 1, condCoding);
+                        decode_pulses(rc, pulses, s->ch[n].idx.signalType, s->ch[n].idx.quantOffsetType, s->ch[n].frame_length);
                     }
-                    condCoding = (i > 0 && s->ch[n].LBRR_flags[i - 1]) ? 2 : 0;
-                    decode_indices(&s->ch[n], rc, i, 1, condCoding);
-                    decode_pulses(rc, pulses, s->ch[n].idx.signalType, s->ch[n].idx.quantOffsetType, s->ch[n].frame_length);
                 }
             }
-        }
     }
-    if (channels == 2) {
-        stereo_decode_pred(rc, MS_pred_Q13);
-        if (s->ch[1].VAD_flags[s->ch[0].nFramesDecoded] == 0)
-            decode_only_middle = oc_rc_icdf(rc, rom_silk_mid_only_icdf, 8);
-        else
-            decode_only_middle = 0;
+    if (channels == 2) { /* silk.cpp:1620-1637 */
+        if (lostFlag == 0 || (lostFlag == 2 && s->ch[0].LBRR_flags[s->ch[0].nFramesDecoded] == 1)) {
+            stereo_decode_pred(rc, MS_pred_Q13);
+            if ((lostFlag == 0 && s->ch[1].VAD_flags[s->ch[0].nFramesDecoded] == 0) ||
+                (lostFlag == 2 && s->ch[1].LBRR_flags[s->ch[0].nFramesDecoded] == 0))
+                decode_only_middle = oc_rc_icdf(rc, rom_silk_mid_only_icdf, 8);
+            else
+                decode_only_middle = 0;
+        } else
+            for (n = 0; n < 2; n++) MS_pred_Q13[n] = s->pred_prev_Q13[n];
     }
     if (channels == 2 && decode_only_middle == 0 && s->prev_decode_only_middle == 1) {
         memset(s->ch[1].outBuf, 0, sizeof(s->ch[1].outBuf));
@@ -976,18 +1318,23 @@ int oc_silk_decode_ms(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int 
         s->ch[1].first_frame_after_reset = 1;
     }
     memset(tmp, 0, sizeof(tmp));
-    has_side = !decode_only_middle;
+    if (lostFlag == 0)
+        has_side = !decode_only_middle;
+    else /* silk.cpp:1667-1671 */
+        has_side = !s->prev_decode_only_middle || (channels == 2 && lostFlag == 2 && s->ch[1].LBRR_flags[s->ch[1].nFramesDecoded] == 1);
     if (g_silk_taps.on) g_silk_taps.valid[0] = g_silk_taps.valid[1] = 0;
     for (n = 0; n < channels; n++) {
         if (n == 0 || has_side) {
             int FrameIndex = s->ch[0].nFramesDecoded - n, condCoding;
             if (FrameIndex <= 0)
                 condCoding = 0;
+            else if (lostFlag == 2)
+                condCoding = s->ch[n].LBRR_flags[FrameIndex - 1] ? 2 : 0;
             else if (n > 0 && s->prev_decode_only_middle)
                 condCoding = 1;
             else
                 condCoding = 2;
-            decode_frame(&s->ch[n], &s->ctrl, rc, &tmp[n][2], &nSamplesOutDec, condCoding);
+            decode_frame(&s->ch[n], &s->ctrl, rc, &tmp[n][2], &nSamplesOutDec, lostFlag, condCoding);
             if (g_silk_taps.on) {
                 g_silk_taps.valid[n] = 1;
                 g_silk_taps.signalType[n] = s->ch[n].idx.signalType;
@@ -1015,6 +1362,9 @@ int oc_silk_decode_ms(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int 
         else
             memcpy(out, rs_out, *n_out * sizeof(i16));
     }
-    s->prev_decode_only_middle = decode_only_middle;
+    if (lostFlag == 1) /* silk.cpp:1772-1776: no gain clamping across a loss */
+        for (i = 0; i < s->nChannelsInternal; i++) s->ch[i].LastGainIndex = 10;
+    else
+        s->prev_decode_only_middle = decode_only_middle;
     return 0;
 }

@@ -140,6 +140,16 @@ class OracleDecoder:
         r = self.o.lib.oc_decode(self.h, bytes(packet), len(packet), self.buf.ctypes.data, 5760)
         return self.buf, r
 
+    def prev_mode(self):
+        """Mode of the last frame decoded or concealed (0 before the first): the mode a concealment runs in."""
+        self.o.lib.oc_decoder_prev_mode.argtypes = [C.c_void_p]
+        return int(self.o.lib.oc_decoder_prev_mode(self.h))
+
+    def conceal(self, samples):
+        """A lost packet (RFC mode only): conceal `samples` per channel, as opus_decode(data = NULL) would."""
+        r = self.o.lib.oc_decode(self.h, None, 0, self.buf.ctypes.data, samples)
+        return self.buf, r
+
     def decode_cap(self, packet: bytes, cap_frames):
         """Like a caller with room for cap_frames 20 ms frames (frame_size = 960 * cap_frames)."""
         r = self.o.lib.oc_decode(self.h, bytes(packet), len(packet), self.buf.ctypes.data, 960 * cap_frames)

@@ -1,6 +1,7 @@
 """CPU: RFC mode of the kernel source (host emulation of decode_frame_rfc) against the oracle's RFC mode, all 32 TOC
-configurations x codes 0..3 with configuration switches (tools/fuzz_emul_rfc.py at a small size); and the oracle's RFC
-mode against what is defined independently of it: the sample count of every packet."""
+configurations x codes 0..3 with configuration switches, lost packets and DTX frames (tools/fuzz_emul_rfc.py at a small size);
+and the oracle's RFC mode against what is defined independently of it: the sample count of every packet, and how a
+concealment behaves (its length, silence before the first packet, the decay over a burst of losses)."""
 import os
 import subprocess
 import sys
@@ -41,3 +42,52 @@ def test_oracle_rfc_mode_returns_true_durations(oracle):
         d.set_rfc(False)
         _, r = d.decode(bytes([0xE0]) + bytes(60))  # reference mode again: a 2.5 ms TOC decodes as 20 ms (Q6)
         assert r == 960
+
+
+def test_oracle_conceals_the_duration_asked_for(oracle):
+    rng = np.random.default_rng(8)
+    for channels in (1, 2):
+        d = oracle.decoder(channels)
+        d.init()
+        d.set_rfc(True)
+        buf, r = d.conceal(960)  # nothing decoded yet: zeros
+        assert r == 960 and not buf[:960].any()
+        for cfg in (1, 9, 11, 13, 15, 17, 23, 29, 31):  # SILK NB 20, WB 20, WB 60, hybrid SWB 20, FB 20, CELT NB 5, WB 20, FB 5, FB 20
+            toc = (cfg << 3) | (4 if channels == 2 else 0)
+            fs = __import__("rfc_common").dur(toc)
+            for _ in range(3):
+                _, r = d.decode(bytes([toc]) + rng.integers(0, 256, 70, dtype=np.uint8).tobytes())
+                assert r == fs
+            for want in (fs, 2 * fs, fs):
+                if want > 5760:
+                    continue
+                _, r = d.conceal(want)
+                assert r == want, (cfg, want, r)
+            _, r = d.decode(bytes([toc]) + rng.integers(0, 256, 70, dtype=np.uint8).tobytes())  # and decoding goes on
+            assert r == fs
+        assert d.conceal(100)[1] < 0  # not a multiple of 2.5 ms
+        d.set_rfc(False)
+        assert d.conceal(960)[1] < 0  # reference mode: no concealment (Q8)
+
+
+def test_oracle_celt_concealment_decays(oracle):
+    """a burst of lost CELT frames fades towards the noise floor (1.5 dB for the first frame, 0.5 dB per frame after, never below
+    the floor the decoded frames left): over a burst the level never grows, and where the last decoded frame was well above
+    the floor it falls"""
+    fell = 0
+    for seed in range(12):
+        rng = np.random.default_rng(seed)
+        d = oracle.decoder(2)
+        d.init()
+        d.set_rfc(True)
+        for _ in range(6):
+            d.decode(bytes([0xFC]) + rng.integers(0, 256, 120, dtype=np.uint8).tobytes())
+        rms = []
+        for _ in range(16):
+            buf, r = d.conceal(960)
+            assert r == 960
+            rms.append(float(np.sqrt(np.mean(buf[:960].astype(np.float64) ** 2))))
+        early, late = np.mean(rms[1:5]), np.mean(rms[-4:])  # (the first frame still carries the overlap of the last decoded one)
+        assert early > 0 and late <= 1.15 * early, (seed, rms)
+        fell += late < 0.5 * early
+    assert fell >= 3, fell

@@ -6,36 +6,15 @@ configuration switches (incl. hybrid -> SILK-only: the silence-frame fade-out). 
 import numpy as np
 import pytest
 
+from rfc_common import dur, make_packet, mode_bw, frame_payloads, same_pcm
+
 pytestmark = pytest.mark.gpu
 
 
-def dur(toc):
-    if toc & 0x80:
-        return (48000 << ((toc >> 3) & 3)) // 400
-    if (toc & 0x60) == 0x60:
-        return 960 if toc & 8 else 480
-    a = (toc >> 3) & 3
-    return 2880 if a == 3 else (48000 << a) // 100
-
-
-def make_packet(rng, cfg, stereo, code, L):
-    toc = (cfg << 3) | (4 if stereo else 0) | code
-    body = lambda k: rng.integers(0, 256, k, dtype=np.uint8).tobytes()
-    if code == 0:
-        return bytes([toc]) + body(L)
-    if code == 1:
-        return bytes([toc]) + body(2 * L)
-    if code == 2:
-        L = min(L, 250)
-        return bytes([toc, L]) + body(L + int(rng.integers(2, 120)))
-    cnt = int(rng.integers(1, 5))
-    while dur(toc) * cnt > 5760:
-        cnt -= 1
-    return bytes([toc, cnt]) + body(cnt * L)
-
-
-def _run(pkg, oracle, ctx, channels, plan, seed):
-    """plan(stream, step, rng) -> (cfg, code); every stream decodes len-of-plan packets, one per step."""
+def _run(pkg, oracle, ctx, channels, plan, seed, p_loss=0.0, p_dtx=0.0):
+    """plan["pick"](stream, step, rng) -> (cfg, code); every stream decodes plan["steps"] packets, one per step.  p_loss: the
+    share of packets that are lost (empty: concealed for as long as the stream's last packet was); p_dtx: the share of packets
+    whose frames carry 0 or 1 bytes.  -> packets compared."""
     rng = np.random.default_rng(seed)
     n, steps = plan["streams"], plan["steps"]
     ctx.set_mode(True)
@@ -47,30 +26,38 @@ def _run(pkg, oracle, ctx, channels, plan, seed):
             d.init()
             d.set_rfc(True)
             decs.append(d)
+        last = [None] * n  # (frame count, frame duration, packet channels) of the stream's last packet that framed
         checked = 0
         for f in range(steps):
             pk = []
             for s in range(n):
+                if rng.random() < p_loss:
+                    pk.append(b"")
+                    continue
                 cfg, code = plan["pick"](s, f, rng)
                 stereo = (channels == 2) if rng.random() < 0.85 else bool(rng.integers(2))
-                pk.append(make_packet(rng, cfg, stereo, code, int(rng.choice([3, 8, 20, 40, 80, 120, 160, 300]))))
+                L = int(rng.integers(0, 2)) if rng.random() < p_dtx else int(rng.choice([3, 8, 20, 40, 80, 120, 160, 300]))
+                pk.append(make_packet(rng, cfg, stereo, code, L))
             pcm, res = ctx.decode_packets(np.arange(n), pk, frame_capacity=6)
             for s in range(n):
-                ref, r = decs[s].decode(pk[s])
-                assert res[s] == r, (f, s, hex(pk[s][0]), int(res[s]), r)
+                before = decs[s].prev_mode()
+                if len(pk[s]) == 0:
+                    cnt, fs, pch = last[s] if last[s] else (1, 960, channels)
+                    ref, r = decs[s].conceal(cnt * fs)
+                    lens, toc_mode, label = [0] * cnt, before, "lost"
+                else:
+                    ref, r = decs[s].decode(pk[s])
+                    pays = frame_payloads(oracle, pk[s])
+                    toc = pk[s][0]
+                    fs, pch, toc_mode, label = dur(toc), (2 if toc & 4 else 1), mode_bw(toc)[0], hex(toc)
+                    if pays is not None:
+                        last[s] = (len(pays), fs, pch)
+                        lens = [len(p) for p in pays]
+                assert res[s] == r, (f, s, label, int(res[s]), r)
                 if r <= 0:
                     continue
-                toc = pk[s][0]
-                fs, pch = dur(toc), (2 if toc & 4 else 1)
-                got, want = pcm[s][:r], ref[:r]
-                if not (toc & 0x80) and (toc & 0x60) != 0x60 and pch < channels:
-                    # Q3: a mono SILK-only packet in a stereo decoder defines only the first fs * pch linear entries of a frame
-                    for k in range(r // fs):
-                        a = got[k * fs:(k + 1) * fs].reshape(-1)[:fs * pch]
-                        b = want[k * fs:(k + 1) * fs].reshape(-1)[:fs * pch]
-                        assert np.array_equal(a, b), (f, s, hex(toc), k)
-                else:
-                    assert np.array_equal(got, want), (f, s, hex(toc), int(np.argmax((got != want).any(axis=1))))
+                ok, k = same_pcm(pcm[s][:r], ref[:r], fs, lens, before, toc_mode, pch, channels)
+                assert ok, (f, s, label, "frame", k)
                 checked += 1
         return checked
     finally:
@@ -97,6 +84,51 @@ def test_rfc_configuration_switches(pkg, oracle, gpu_ctx, channels):
 
     plan = {"streams": 384, "steps": 8, "pick": pick}
     assert _run(pkg, oracle, gpu_ctx, channels, plan, 77 + channels) > 384 * 5
+
+
+@pytest.mark.parametrize("channels", [2, 1])
+def test_rfc_loss_path(pkg, oracle, gpu_ctx, channels):
+    """lost packets (len == 0) and DTX frames conceal on the GPU, bit-exact to the oracle's RFC mode -- SILK PLC +
+    comfort noise + the glue to the next decoded frame, CELT's noise-based concealment, hybrid both; random configuration
+    walks so that losses follow (and are followed by) every mode, bandwidth and frame duration; several losses in a row."""
+    state = {}
+
+    def pick(s, f, rng):
+        if s not in state or rng.random() < 0.3:
+            state[s] = int(rng.integers(32))
+        return state[s], int(rng.choice([0, 0, 0, 1, 2, 3]))
+
+    plan = {"streams": 512, "steps": 10, "pick": pick}
+    assert _run(pkg, oracle, gpu_ctx, channels, plan, 501 + channels, p_loss=0.3, p_dtx=0.06) > 512 * 7
+
+
+def test_rfc_loss_before_any_packet_and_after_reset(pkg, oracle, gpu_ctx):
+    """a loss with nothing decoded yet is 20 ms of zeros; after a stream reset the same"""
+    ctx = gpu_ctx
+    ctx.set_mode(True)
+    try:
+        ctx.streams_alloc(4, 2)
+        pcm, res = ctx.decode_packets(np.arange(4), [b""] * 4, frame_capacity=6)
+        assert (res == 960).all() and not pcm.any()
+        rng = np.random.default_rng(9)
+        pk = [make_packet(rng, 31, True, 0, 80) for _ in range(4)]
+        pcm, res = ctx.decode_packets(np.arange(4), pk, frame_capacity=6)
+        assert (res == 960).all() and pcm.any()
+        pcm, res = ctx.decode_packets(np.arange(4), [None] * 4, frame_capacity=6)
+        assert (res == 960).all() and pcm[:, :960].any()  # concealed from the CELT state
+        ctx.streams_reset(0, 4, True)
+        pcm, res = ctx.decode_packets(np.arange(4), [b""] * 4, frame_capacity=6)
+        assert (res == 960).all() and not pcm.any()
+    finally:
+        ctx.set_mode(False)
+
+
+def test_loss_is_an_error_in_reference_mode(pkg, gpu_ctx):
+    """the reference has no concealment: data == NULL / len == 0 ends in an error (Q8)"""
+    ctx = gpu_ctx
+    ctx.streams_alloc(2, 2)
+    pcm, res = ctx.decode_packets(np.arange(2), [b"", None])
+    assert (res == -1).all()  # OPUS_BAD_ARG
 
 
 def test_reference_mode_unchanged_after_rfc(pkg, oracle, gpu_ctx):
