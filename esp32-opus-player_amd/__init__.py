@@ -20,7 +20,7 @@ FRAME = 960
 EXPORTS = [
     "opusgpu_version", "opusgpu_ctx_create", "opusgpu_ctx_destroy", "opusgpu_last_error",
     "opusgpu_streams_alloc", "opusgpu_streams_reset", "opusgpu_stream_count", "opusgpu_stream_channels",
-    "opusgpu_stream_state_bytes", "opusgpu_decode_packets", "opusgpu_packet_to_frames",
+    "opusgpu_stream_state_bytes", "opusgpu_decode_packets", "opusgpu_decode_packets_fec", "opusgpu_packet_to_frames",
     "opusgpu_dev_alloc", "opusgpu_dev_free", "opusgpu_memcpy_h2d", "opusgpu_memcpy_d2h",
     "opusgpu_decode_step_device", "opusgpu_synchronize", "opusgpu_event_create", "opusgpu_event_record",
     "opusgpu_event_elapsed_ms", "opusgpu_event_destroy", "opusgpu_stream_state_get",
@@ -76,6 +76,7 @@ def load_lib():
     lib.opusgpu_stream_channels.argtypes = [vp]
     lib.opusgpu_stream_state_bytes.restype = C.c_size_t
     lib.opusgpu_decode_packets.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]
+    lib.opusgpu_decode_packets_fec.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]
     lib.opusgpu_packet_to_frames.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(FrameDesc)]
     lib.opusgpu_packet_to_frames_mode.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int, C.POINTER(FrameDesc)]
     lib.opusgpu_set_mode.argtypes = [vp, C.c_int]
@@ -245,7 +246,13 @@ class Context:
     def streams_reset(self, first, count, full=True):
         self._chk(self.lib.opusgpu_streams_reset(self.h, first, count, 1 if full else 0), "opusgpu_streams_reset")
 
-    def decode_packets(self, stream_ids, packets, frame_capacity=1):
+    def decode_packets_fec(self, stream_ids, packets, frame_capacity=1):
+        """RFC mode: packets[i] FOLLOWS a lost packet of its stream; produces the lost packet's audio from packets[i]'s forward
+        error correction data where it has any, by concealment otherwise (opusgpu_decode_packets_fec).  Decode the packets
+        themselves with decode_packets afterwards."""
+        return self.decode_packets(stream_ids, packets, frame_capacity, _fn="opusgpu_decode_packets_fec")
+
+    def decode_packets(self, stream_ids, packets, frame_capacity=1, _fn="opusgpu_decode_packets"):
         """Batched opus_multistream_decode: returns (pcm[n, cap*960, ch] int16, result[n] int32).
         RFC mode: an empty (or None) packet is a LOST packet, concealed for as long as the stream's last packet was."""
         packets = [b"" if p is None else p for p in packets]
@@ -256,9 +263,8 @@ class Context:
         ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
         pcm = np.zeros((n, frame_capacity * FRAME, self.channels), dtype=np.int16)
         res = np.zeros(n, dtype=np.int32)
-        self._chk(self.lib.opusgpu_decode_packets(self.h, n, ids.ctypes.data, C.addressof(ptrs), lens.ctypes.data,
-                                                  pcm.ctypes.data, frame_capacity, res.ctypes.data),
-                  "opusgpu_decode_packets")
+        self._chk(getattr(self.lib, _fn)(self.h, n, ids.ctypes.data, C.addressof(ptrs), lens.ctypes.data,
+                                         pcm.ctypes.data, frame_capacity, res.ctypes.data), _fn)
         return pcm, res
 
     def decode_packets_arena(self, stream_ids, arena, offsets, lens, frame_capacity=1, pcm=None):

@@ -896,14 +896,34 @@ static int grow(opusgpu_ctx *ctx, void **p, size_t *cap, size_t need) {
     return OPUSGPU_OK;
 }
 
-int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, const uint8_t *const *packets,
-                           const int32_t *lens, int16_t *pcm, int frame_capacity, int32_t *result) {
+// How a concealment of `total` samples is cut into device frames (valid duration codes): a frame of the last packet's size at a
+// time like opus_decode(NULL) (src/opus_decoder.cpp:294-308 has the loop), what is left over (30 / 50 ms) as 20 / 40 ms + 10 ms.
+static int conceal_pieces(int total, int last_fs, int32_t base_flags, int32_t out_flags[48]) {
+    static const int kDur[6] = {2880, 1920, 960, 480, 240, 120}, kCode[6] = {5, 4, 0, 3, 2, 1};
+    int n = 0;
+    while (total > 0) {
+        int w = total < last_fs ? total : last_fs;
+        total -= w;
+        while (w > 0) {
+            int j = 0;
+            while (kDur[j] > w) j++;
+            if (n == 48) return -1;
+            out_flags[n++] = (base_flags & ~(7 << 6) & ~(1 << 10)) | kCode[j] << 6 | 1 << 9;
+            w -= kDur[j];
+        }
+    }
+    return n;
+}
+
+static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, const uint8_t *const *packets,
+                               const int32_t *lens, int16_t *pcm, int frame_capacity, int32_t *result, const bool fec) {
     if (!ctx || n < 0 || !ctx->d_streams) return OPUSGPU_BAD_ARG;
     if (n == 0) return OPUSGPU_OK;
     if (!stream_ids || !packets || !lens || !pcm || !result || frame_capacity <= 0) return OPUSGPU_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int CC = ctx->channels;
     const bool rfc = ctx->mode == OPUSGPU_MODE_RFC;
+    if (fec && !rfc) return OPUSGPU_BAD_ARG;
     // one frame's block in the device PCM buffer: 20 ms, or room for a 60 ms frame in RFC mode
     const size_t frame_pcm = (size_t)(rfc ? OPUSGPU_RFC_FRAME_SAMPLES : OPUSGPU_FRAME_SAMPLES) * CC;
     const size_t cap_pcm = (size_t)frame_capacity * OPUSGPU_FRAME_SAMPLES * CC; // the caller's block per packet
@@ -953,6 +973,28 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
                 result[i] = count;
                 continue;
             }
+            if (fec) { // the packet BEFORE this one was lost (opus_decode with decode_fec = 1): its duration is concealed, the last
+                       // frame's worth of it from this packet's first frame where SILK data is there to carry LBRR frames
+                const int sid = stream_ids[i], lc = ctx->last_count[sid];
+                const int last_fs = lc ? ogh::flags_frame_size(ctx->last_flags[sid]) : 120;
+                const int lost_dur = lc ? lc * last_fs : OPUSGPU_FRAME_SAMPLES;
+                const int pfs = ogh::toc_samples_per_frame(packets[i][0], 48000);
+                const bool celt = (d[0].flags & 3) == 2 || (lc && (ctx->last_flags[sid] & 3) == 2);
+                if (lost_dur > frame_capacity * OPUSGPU_FRAME_SAMPLES) {
+                    result[i] = OPUSGPU_BUFFER_TOO_SMALL;
+                    continue;
+                }
+                int32_t fl[48];
+                const bool use = !(lost_dur < pfs || celt);
+                const int np = conceal_pieces(use ? lost_dur - pfs : lost_dur, last_fs, lc ? ctx->last_flags[sid] : d[0].flags, fl);
+                if (np < 0 || np + (use ? 1 : 0) > 48) {
+                    result[i] = OPUSGPU_BAD_ARG;
+                    continue;
+                }
+                nframes[i] = np + (use ? 1 : 0);
+                is_lost[i] = use ? 2 : 3; // 2: concealment + the FEC frame, 3: concealment only
+                continue;
+            }
             // count * packet_frame_size > frame_size -> OPUS_BUFFER_TOO_SMALL (src/opus_decoder.cpp:323)
             const int pfs = ogh::toc_samples_per_frame(packets[i][0], 48000);
             // (RFC mode decodes the durations the check is about: no second condition)
@@ -972,7 +1014,7 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
     int max_frames = 0;
     for (int i = 0; i < n; i++) {
         first[i + 1] = first[i] + nframes[i];
-        base[i + 1] = base[i] + (nframes[i] && !(rfc && is_lost[i]) ? (size_t)lens[i] : 0);
+        base[i + 1] = base[i] + (nframes[i] && !(rfc && (is_lost[i] == 1 || is_lost[i] == 3)) ? (size_t)lens[i] : 0);
         if (nframes[i] > max_frames) max_frames = nframes[i];
     }
     if (first[n] == 0) return OPUSGPU_OK;
@@ -982,10 +1024,29 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
     on_ranges([&](int lo, int hi) {
         for (int i = lo; i < hi; i++) {
             if (!nframes[i]) continue;
-            if (rfc && is_lost[i]) { // nothing to read: len 0, the flags of the stream's last packet (RFC bit and duration included)
+            if (rfc && is_lost[i] == 1) { // nothing to read: len 0, the flags of the stream's last packet (RFC bit and duration included)
                 const int32_t fl = ctx->last_count[stream_ids[i]] ? ctx->last_flags[stream_ids[i]]
                                                                    : (int32_t)((ogh::MODE_CELT - ogh::MODE_SILK) | 4 << 2 | (CC == 2 ? 32 : 0) | 1 << 9);
                 for (int k = 0; k < nframes[i]; k++) all[first[i] + k] = opusgpu_frame_desc{stream_ids[i], 0, 0, fl};
+                continue;
+            }
+            if (rfc && is_lost[i] >= 2) { // decode_fec: the concealment frames, then (2) the packet's first frame with the FEC bit
+                const int sid = stream_ids[i], lc = ctx->last_count[sid];
+                opusgpu_frame_desc d0[48];
+                (void)opusgpu_packet_to_frames_mode(packets[i], lens[i], sid, ctx->mode, d0);
+                int32_t fl[48];
+                const int np = nframes[i] - (is_lost[i] == 2 ? 1 : 0);
+                const int last_fs = lc ? ogh::flags_frame_size(ctx->last_flags[sid]) : 120;
+                const int lost_dur = lc ? lc * last_fs : OPUSGPU_FRAME_SAMPLES;
+                (void)conceal_pieces(is_lost[i] == 2 ? lost_dur - ogh::flags_frame_size(d0[0].flags) : lost_dur, last_fs,
+                                     lc ? ctx->last_flags[sid] : d0[0].flags, fl);
+                for (int k = 0; k < np; k++) all[first[i] + k] = opusgpu_frame_desc{sid, 0, 0, fl[k]};
+                if (is_lost[i] == 2) {
+                    memcpy(arena.get() + base[i], packets[i], (size_t)lens[i]);
+                    d0[0].offset += (int32_t)base[i];
+                    d0[0].flags |= 1 << 10;
+                    all[first[i] + np] = d0[0];
+                }
                 continue;
             }
             opusgpu_frame_desc d[48];
@@ -1005,6 +1066,7 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
     timer.mark("arena upload (enqueue)");
     std::vector<opusgpu_frame_desc> step;
     std::vector<int> owner;
+    std::vector<int32_t> placed(rfc ? n : 0, 0); // RFC mode: samples of packet i delivered so far (frames may differ in duration)
     for (int k = 0; k < max_frames; k++) {
         step.clear();
         owner.clear();
@@ -1062,9 +1124,10 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
                         result[i] = h_res[j];
                         continue;
                     }
-                    if (rfc) // frames of a packet share their duration: frame k starts k frames into the packet's block
-                        memcpy(pcm + (size_t)i * cap_pcm + (size_t)k * h_res[j] * CC, &h_pcm[(size_t)j * frame_pcm], (size_t)h_res[j] * CC * 2);
-                    else
+                    if (rfc) { // a packet appears once per step: nobody else touches placed[i]
+                        memcpy(pcm + (size_t)i * cap_pcm + (size_t)placed[i] * CC, &h_pcm[(size_t)j * frame_pcm], (size_t)h_res[j] * CC * 2);
+                        placed[i] += h_res[j];
+                    } else
                         memcpy(pcm + (size_t)i * cap_pcm + (size_t)k * frame_pcm, &h_pcm[(size_t)j * frame_pcm], frame_pcm * 2);
                     result[i] += h_res[j];
                 }
@@ -1082,6 +1145,15 @@ int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, c
         timer.mark("copy-back + delivery (wait)");
     }
     return OPUSGPU_OK;
+}
+
+int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, const uint8_t *const *packets,
+                           const int32_t *lens, int16_t *pcm, int frame_capacity, int32_t *result) {
+    return decode_packets_impl(ctx, n, stream_ids, packets, lens, pcm, frame_capacity, result, false);
+}
+int opusgpu_decode_packets_fec(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, const uint8_t *const *packets,
+                               const int32_t *lens, int16_t *pcm, int frame_capacity, int32_t *result) {
+    return decode_packets_impl(ctx, n, stream_ids, packets, lens, pcm, frame_capacity, result, true);
 }
 
 } // extern "C"

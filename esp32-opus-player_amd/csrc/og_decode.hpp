@@ -277,7 +277,11 @@ OG_DEV int conceal_frame_rfc(StreamState *st, int ch, i16 *pcm, int audiosize) {
     return audiosize;
 }
 
-OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mode, int bandwidth, int ch, i16 *pcm, int audiosize) {
+// `fec` (descriptor flag bit 10): RFC 6716's decode_fec -- the frame is the first one of the packet AFTER a lost packet: SILK
+// decodes its LBRR copies (the lost frame's audio) where the packet carries them and conceals where not, CELT has no FEC and
+// conceals (hybrid: its layer from band 17).  The host never sets it for CELT-only frames (plain concealment instead).
+OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mode, int bandwidth, int ch, i16 *pcm, int audiosize,
+                            int fec = 0) {
     const int CC = st->channels;
     if (len < 0 || len > 1275) return BAD_ARG;
     if (len <= 1) return conceal_frame_rfc(st, ch, pcm, audiosize);
@@ -328,10 +332,10 @@ OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mod
                 }
                 base += n48 * ch;
             }
-        }, &st->loss, 0);
+        }, &st->loss, fec ? 2 : 0);
         if (ret) return INTERNAL_ERROR;
     }
-    if (mode != MODE_CELT && rc_tell(rc) + 17 + 20 * (mode == MODE_HYBRID) <= 8 * len) {
+    if (!fec && mode != MODE_CELT && rc_tell(rc) + 17 + 20 * (mode == MODE_HYBRID) <= 8 * len) {
         if (mode == MODE_HYBRID) (void)rc_bit_logp(rc, 12); // redundancy flag read and ignored (Q2)
     }
 #else
@@ -343,13 +347,18 @@ OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mod
             OG_SYNC();
         }
         if (OG_LANE == 0) st->loss.celt_end_band = rfc_end_band(bandwidth); // (what a later concealment's last band is)
-        celt_ret = celt_decode_frame(&st->celt, rc, audiosize, ch, CC, mode == MODE_CELT ? 0 : 17, disable_inv, rfc_end_band(bandwidth),
-                                     &st->loss);
+        OG_SYNC();
+        const int Cp = fec ? CC : ch; // (a concealment runs over the decoder's channels: its PCM planes are laid out for C == CC)
+        if (fec)
+            celt_ret = celt_decode_lost(&st->celt, &st->loss, audiosize, CC, mode == MODE_CELT ? 0 : 17, rfc_end_band(bandwidth));
+        else
+            celt_ret = celt_decode_frame(&st->celt, rc, audiosize, ch, CC, mode == MODE_CELT ? 0 : 17, disable_inv,
+                                         rfc_end_band(bandwidth), &st->loss);
 #ifndef OG_NO_SILK
         if (mode == MODE_HYBRID && celt_ret >= 0) {
             OG_SYNC();
             OG_FOR_LANES(i, nmix) { // i indexes the interleaved PCM; sample j of channel c lives in plane c
-                const int c = CC == 2 ? (i & 1) : 0, j = CC == 2 ? (i >> 1) : i, at = pcm_plane(c, ch, CC) + j;
+                const int c = CC == 2 ? (i & 1) : 0, j = CC == 2 ? (i >> 1) : i, at = pcm_plane(c, Cp, CC) + j;
                 S.v[at] = (i16)sat16((i32)S.v[at] + (i32)SL().u.out.pcm[i]);
             }
             OG_SYNC();
@@ -357,7 +366,7 @@ OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mod
 #endif
         if (celt_ret >= 0) {
             OG_SYNC();
-            pcm_store(pcm, audiosize, ch, CC);
+            pcm_store(pcm, audiosize, Cp, CC);
             OG_SYNC();
         }
     }

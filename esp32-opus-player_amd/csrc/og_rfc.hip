@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(64, 1) k_decode_rfc(const FrameDesc *__restric
         ret = BAD_ARG; // (in RFC mode every descriptor carries the mode bit: opusgpu_packet_to_frames_mode)
     else
         ret = decode_frame_rfc(&st[d.stream], arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
-                               desc_channels(d.flags), pcm + (size_t)f * pcm_stride, desc_frame_size(d.flags));
+                               desc_channels(d.flags), pcm + (size_t)f * pcm_stride, desc_frame_size(d.flags), desc_fec(d.flags));
     if (threadIdx.x == 0) result[f] = ret;
 }
 

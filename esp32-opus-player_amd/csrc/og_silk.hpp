@@ -1135,7 +1135,9 @@ OPUS_ROM uint8_t rom_silk_lbrr_flags_3_icdf[7] = {215, 195, 166, 125, 110, 82, 0
 // `loss` (RFC mode): the stream's loss-concealment state.  With it every decoded frame also leaves what a later
 // concealment starts from (silk_PLC_update, the comfort-noise estimate) and is smoothed when it follows a loss; `lost` = 1 is
 // silk_Decode's lostFlag == FLAG_PACKET_LOST (silk.cpp:1481-1779): nothing is read from `rc`, one frame of payload_ms (10 or
-// 20) is concealed at the rate of the last decoded frame (internal_hz == 0).  The synthesis then runs one lane per channel.
+// 20) is concealed at the rate of the last decoded frame (internal_hz == 0); `lost` = 2 is FLAG_DECODE_LBRR: the packet's
+// forward error correction data -- every internal frame's LBRR copy where the packet carries one, a concealment where not.
+// The synthesis then runs one lane per channel.
 template <bool REC_ONLY, class Emit>
 OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_hz, int payload_ms, const SilkRec *rec, Emit &&emit,
                               LossState *loss = nullptr, int lost = 0) {
@@ -1177,7 +1179,7 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
             ecType[n] = OG_UNI(rec->ch[n].ec_prevSignalType);
             ecLag[n] = OG_UNI(rec->ch[n].ec_prevLagIndex);
         }
-    } else if (lost) { // silk.cpp:1632-1635: the predictors stay; decode_only_middle is silk_Decode's local, zero
+    } else if (lost == 1) { // silk.cpp:1632-1635: the predictors stay; decode_only_middle is silk_Decode's local, zero
         MS_pred_Q13[0] = s->pred_prev_Q13[0];
         MS_pred_Q13[1] = s->pred_prev_Q13[1];
     } else if constexpr (!REC_ONLY) {
@@ -1195,7 +1197,7 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
                     for (int i = 0; i < nF; i++) lbrr[n][i] = (sym >> i) & 1;
                 }
             }
-        for (int i = 0; i < nF; i++) // regular decoding reads past the LBRR frames (silk.cpp:1590-1616)
+        for (int i = 0; i < nF && !lost; i++) // regular decoding reads past the LBRR frames (silk.cpp:1590-1616)
             for (int n = 0; n < channels; n++)
                 if (lbrr[n][i]) {
                     if (channels == 2 && n == 0) {
@@ -1213,6 +1215,15 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
             if (!rec && !lost && channels == 2) {
                 silk_stereo_decode_pred(rc, MS_pred_Q13);
                 decode_only_middle = vad[1][fi] == 0 ? rc_icdf(rc, rom_silk_mid_only_icdf, 8) : 0;
+            } else if (lost == 2) { // silk.cpp:1620-1637 with FLAG_DECODE_LBRR (decode_only_middle is a local of the call: zero)
+                decode_only_middle = 0;
+                if (channels == 2 && lbrr[0][fi]) {
+                    silk_stereo_decode_pred(rc, MS_pred_Q13);
+                    if (lbrr[1][fi] == 0) decode_only_middle = rc_icdf(rc, rom_silk_mid_only_icdf, 8);
+                } else {
+                    MS_pred_Q13[0] = s->pred_prev_Q13[0];
+                    MS_pred_Q13[1] = s->pred_prev_Q13[1];
+                }
             }
         }
         const int restart_side = channels == 2 && decode_only_middle == 0 && prev_dom == 1;
@@ -1229,11 +1240,13 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
             lastGain[1] = 10;
             ffar[1] = 1;
         }
-        const int has_side = lost ? !prev_dom : !decode_only_middle; // silk.cpp:1664-1671
+        const int has_side = lost ? (!prev_dom || (channels == 2 && lost == 2 && lbrr[1][fi])) : !decode_only_middle; // silk.cpp:1664-1671
         i32 plc_invGain_Q30[2] = {0, 0};
+        int conceal[2] = {0, 0}; // the channel has no data to decode for this frame (silk_decode_frame silk.cpp:1987, :2021)
         for (int n = 0; n < channels; n++) {
             L.ctrl[n].coded = (n == 0 || has_side);
-            if (L.ctrl[n].coded && lost) {
+            conceal[n] = lost == 1 || (lost == 2 && !lbrr[n][fi]);
+            if (L.ctrl[n].coded && conceal[n]) {
                 if constexpr (!REC_ONLY) {
                     // a concealed frame: the serial part runs one lane per channel below; what needs the wave's scratch runs here
                     // (silk_PLC silk.cpp:2871-2877; silk_PLC_conceal :2992, :3015-3039)
@@ -1259,7 +1272,7 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
                 // FrameIndex = channel 0's nFramesDecoded - n, and channel 0's count has been stepped by the time channel 1
                 // gets here (silk.cpp:1676-1700): the frame's index for both; <= 0 -> independent coding
                 const int FrameIndex = fi;
-                const int condCoding = FrameIndex <= 0 ? 0 : (n > 0 && prev_dom) ? 1 : 2;
+                const int condCoding = FrameIndex <= 0 ? 0 : lost == 2 ? (lbrr[n][fi - 1] ? 2 : 0) : (n > 0 && prev_dom) ? 1 : 2;
                 OG_MARK(30);
                 if (REC_ONLY || rec) { // parameters + indices (68 words laid out like SilkCtrl) from the record
                     OG_SYNC();
@@ -1270,7 +1283,7 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
                     OG_FOR_LANES(i, fs_kHz == 16 ? 16 : 10) s->ch[n].prevNLSF_Q15[i] = rec->ch[n].nlsf[i];
                     OG_SYNC();
                 } else if constexpr (!REC_ONLY) {
-                    silk_decode_indices(&s->ch[n], L.ctrl[n], rc, fs_kHz, vad[n][fi], 0, condCoding, ecType[n], ecLag[n], nb_subfr);
+                    silk_decode_indices(&s->ch[n], L.ctrl[n], rc, fs_kHz, vad[n][fi], lost == 2, condCoding, ecType[n], ecLag[n], nb_subfr);
                     OG_MARK(31);
                     silk_decode_pulses(rc, n, L.ctrl[n].signalType, L.ctrl[n].quantOffsetType, frame_length);
                     OG_MARK(32);
@@ -1322,7 +1335,7 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
             if constexpr (!REC_ONLY) {
                 if (loss) {
                     SilkLossChannel *lc = &loss->silk[n];
-                    if (lost)
+                    if (conceal[n])
                         silk_plc_conceal_lane(&s->ch[n], lc, n, fs_kHz, nb_subfr, plc_invGain_Q30[n]);
                     else { // silk_decode_frame silk.cpp:2008-2015: the core, then silk_PLC(lost = 0), then lossCnt = 0
                         silk_decode_core_lane(&s->ch[n], n, fs_kHz, pulse_row[n], nb_subfr, lc);
@@ -1470,7 +1483,7 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
         }
         OG_SYNC();
         OG_MARK(38);
-        if (!lost) { // silk.cpp:1772-1778
+        if (lost != 1) { // silk.cpp:1772-1778
             prev_dom = decode_only_middle;
             if (OG_LANE == 0) s->prev_decode_only_middle = decode_only_middle;
         }
@@ -1480,7 +1493,7 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
     if (OG_LANE == 0) {
         s->nChannelsAPI = channels;
         s->nChannelsInternal = channels;
-        if (lost) // no gain clamping across a loss (silk.cpp:1772-1776)
+        if (lost == 1) // no gain clamping across a loss (silk.cpp:1772-1776)
             for (int n = 0; n < channels; n++) s->ch[n].LastGainIndex = 10;
     }
     OG_SYNC();

@@ -103,13 +103,15 @@ struct FrameDesc {
     i32 offset;                // byte offset of the frame payload (after TOC/size bytes) in the arena
     i32 len;                   // payload bytes (<= 1275)
     i32 flags;                 // bits 0-1: 0 SILK, 1 hybrid, 2 CELT; bits 2-4: bandwidth - 1101; bit 5: stereo;
-                               // bits 6-8: frame duration (0: 20 ms, 1: 2.5, 2: 5, 3: 10, 4: 40, 5: 60); bit 9: RFC mode
+                               // bits 6-8: frame duration (0: 20 ms, 1: 2.5, 2: 5, 3: 10, 4: 40, 5: 60); bit 9: RFC mode;
+                               // bit 10 (RFC mode): decode the frame's forward error correction data (the frame before it)
 };
 OG_DEV int desc_mode(i32 f) { return MODE_SILK + (f & 3); }
 OG_DEV int desc_bandwidth(i32 f) { return BW_NB + ((f >> 2) & 7); }
 OG_DEV int desc_channels(i32 f) { return (f & 32) ? 2 : 1; }
 // RFC mode (opt-in, opusgpu_set_mode): the frame decodes at the duration its TOC names; reference mode: always 960 (Q6)
 OG_DEV int desc_rfc(i32 f) { return (f >> 9) & 1; }
+OG_DEV int desc_fec(i32 f) { return (f >> 10) & 1; }
 OG_DEV int desc_frame_size(i32 f) {
     const int d = (f >> 6) & 7;
     return d == 1 ? 120 : d == 2 ? 240 : d == 3 ? 480 : d == 4 ? 1920 : d == 5 ? 2880 : 960;

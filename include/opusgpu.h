@@ -39,7 +39,7 @@ typedef struct opusgpu_ctx opusgpu_ctx;
 
 /* One frame of work for one stream in one decode step (16 bytes, device layout).
  * flags: bits 0-1 mode (0 SILK-only, 1 hybrid, 2 CELT-only); bits 2-4 bandwidth (0 NB .. 4 FB); bit 5 stereo;
- * bits 6-9: frame duration and the RFC bit, zero in reference mode (see OPUSGPU_MODE_RFC).
+ * bits 6-10: frame duration, the RFC bit and the FEC bit, zero in reference mode (see OPUSGPU_MODE_RFC).
  * These are the TOC fields opus_decode_native derives (src/opus_decoder.cpp:312-315). */
 typedef struct opusgpu_frame_desc {
     int32_t stream;  /* stream index in the context */
@@ -110,6 +110,16 @@ size_t opusgpu_stream_state_bytes(void);
  * Returns OPUSGPU_OK or a context-level error. */
 int opusgpu_decode_packets(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, const uint8_t *const *packets,
                            const int32_t *lens, int16_t *pcm, int frame_capacity, int32_t *result);
+
+/* RFC mode only (OPUSGPU_BAD_ARG otherwise): forward error correction, opus_decode(decode_fec = 1) of RFC 6716's decoder -- the
+ * reference has neither the flag nor the path.  packets[i] is the packet that FOLLOWS a lost packet of stream stream_ids[i]: the
+ * lost packet's duration (that of the stream's last packet) is produced -- the last frame's worth of it from the LBRR frames in
+ * packets[i]'s first frame where it is a SILK-only or hybrid packet (SILK conceals the channels / internal frames without an LBRR
+ * copy, hybrid's CELT layer conceals), everything before that by concealment; a CELT-only packet or predecessor carries no such
+ * data: plain concealment.  result[i] = samples produced.  Call opusgpu_decode_packets with the same packets afterwards: the
+ * packet itself is not decoded here.  On the device path: descriptor flags bit 10 on the packet's first frame. */
+int opusgpu_decode_packets_fec(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, const uint8_t *const *packets,
+                               const int32_t *lens, int16_t *pcm, int frame_capacity, int32_t *result);
 
 /* Splits one packet into frame descriptors exactly as opus_packet_parse_impl + the TOC helpers do
  * (src/opus_decoder.cpp:559, :135, :460, :474).  descs[k].offset is relative to the packet start.

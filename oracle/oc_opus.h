@@ -154,6 +154,10 @@ void oc_decoder_reset(oc_decoder *d);                    /* OPUS_RESET_STATE  op
 void oc_decoder_set_rfc(oc_decoder *d, int on);
 /* opus_decode_native (opus_decoder.cpp:280) for one elementary stream; returns samples/channel or <0 */
 int oc_decode(oc_decoder *d, const u8 *data, i32 len, i16 *pcm, int frame_size);
+/* RFC mode only, PARITY UNPINNED: opus_decode(decode_fec = 1) as RFC 6716's decoder has it (the reference has neither the flag
+ * nor the path, Q8).  `data` is the packet AFTER a lost one; frame_size samples are concealed, the last frame's worth of them from
+ * the LBRR frames in `data` where it carries any (SILK / hybrid). */
+int oc_decode_fec(oc_decoder *d, const u8 *data, i32 len, i16 *pcm, int frame_size);
 int oc_packet_parse(const u8 *data, i32 len, int self_delimited, u8 *out_toc, i16 size[48],
                     int *payload_offset, i32 *packet_offset);               /* opus_decoder.cpp:559 */
 int oc_packet_mode(const u8 *data);

@@ -228,6 +228,13 @@ static int conceal_frame(oc_decoder *d, i16 *out, int frame_size) {
         } while (done < audiosize);
         return frame_size;
     }
+    /* no concealment of sizes other than 2.5 (CELT), 5 (CELT), 10 or 20 ms: e.g. 12.5 ms conceals 10 and the caller comes back */
+    if (audiosize < 960) {
+        if (audiosize > 480)
+            audiosize = 480;
+        else if (mode != OC_MODE_SILK && audiosize > 240 && audiosize < 480)
+            audiosize = 240;
+    }
     nmix = audiosize * (ch < CC ? ch : CC);
     if (mode != OC_MODE_CELT) {
         int decoded = 0;
@@ -253,7 +260,9 @@ static int conceal_frame(oc_decoder *d, i16 *out, int frame_size) {
 }
 
 /* opus_decoder.cpp:154.  Reference mode: audiosize is 960 whatever the TOC says (Q6).  RFC mode: the TOC's duration. */
-static int decode_frame(oc_decoder *d, const u8 *inbuf, i32 len, i16 *out) {
+/* fec (RFC mode only): RFC 6716's decode_fec -- SILK decodes the LBRR copy of the frame BEFORE this packet where the packet
+ * carries one (lostFlag 2), conceals otherwise; CELT has no FEC and conceals (hybrid: its layer from band 17). */
+static int decode_frame(oc_decoder *d, const u8 *inbuf, i32 len, i16 *out, int fec) {
     const int mode = d->mode, ch = d->stream_channels, audiosize = d->rfc ? d->frame_size : 960;
     const int payload_ms = d->rfc ? audiosize / 48 : 20;
     /* The reference zeroes / mixes 960 * stream_channels entries of `out` even when the decoder has fewer channels (Q3): what
@@ -278,14 +287,14 @@ static int decode_frame(oc_decoder *d, const u8 *inbuf, i32 len, i16 *out) {
             internal_hz = 16000;
         do {
             i32 n = 0;
-            int ret = oc_silk_decode_ms(d->silk, rc, ch, internal_hz, decoded == 0, payload_ms, p, &n);
+            int ret = oc_silk_decode_ex(d->silk, rc, ch, internal_hz, decoded == 0, payload_ms, fec ? 2 : 0, p, &n);
             if (ret) return OC_INTERNAL_ERROR;
             p += n * ch;
             decoded += n;
         } while (decoded < audiosize);
     }
     start_band = 0;
-    if (mode != OC_MODE_CELT && oc_rc_tell(rc) + 17 + 20 * (mode == OC_MODE_HYBRID) <= 8 * len) {
+    if (!fec && mode != OC_MODE_CELT && oc_rc_tell(rc) + 17 + 20 * (mode == OC_MODE_HYBRID) <= 8 * len) {
         if (mode == OC_MODE_HYBRID) (void)oc_rc_bit_logp(rc, 12); /* redundancy flag: ignored (Q2) */
     }
     if (mode != OC_MODE_CELT) start_band = 17;
@@ -295,7 +304,10 @@ static int decode_frame(oc_decoder *d, const u8 *inbuf, i32 len, i16 *out) {
 
     if (mode != OC_MODE_SILK) {
         if (mode != d->prev_mode && d->prev_mode > 0) oc_celt_reset(&d->celt);
-        celt_ret = oc_celt_decode(&d->celt, rc, out, audiosize, d->taps); /* (CELT frames are 2.5 - 20 ms) */
+        if (fec)
+            celt_ret = oc_celt_decode_lost(&d->celt, out, audiosize);
+        else
+            celt_ret = oc_celt_decode(&d->celt, rc, out, audiosize, d->taps); /* (CELT frames are 2.5 - 20 ms) */
     } else {
         for (i = 0; i < nmix; i++) out[i] = 0;
         if (d->prev_mode == OC_MODE_HYBRID) {
@@ -348,11 +360,47 @@ int oc_decode(oc_decoder *d, const u8 *data, i32 len, i16 *pcm, int frame_size) 
     d->frame_size = pfs;
     d->stream_channels = pch;
     for (i = 0; i < count; i++) {
-        int ret = decode_frame(d, data, size[i], pcm + nb_samples * d->channels);
+        int ret = decode_frame(d, data, size[i], pcm + nb_samples * d->channels, 0);
         if (ret < 0) return ret;
         data += size[i];
         nb_samples += ret;
     }
     d->last_packet_duration = nb_samples;
     return nb_samples;
+}
+
+/* RFC mode: opus_decode(decode_fec = 1) of RFC 6716's decoder -- the packet BEFORE `data` was lost; conceal frame_size samples
+ * (what the lost packet carried), the last packet_frame_size of them from the forward error correction data (SILK's LBRR
+ * frames) in the first frame of `data`, where there is any.  A CELT-only packet (or predecessor) has none: plain concealment.
+ * The caller decodes `data` itself afterwards, normally. */
+int oc_decode_fec(oc_decoder *d, const u8 *data, i32 len, i16 *pcm, int frame_size) {
+    int count, offset, pfs, pbw, pmode, pch, ret, dur;
+    i16 size[48];
+    u8 toc;
+    if (!d->rfc || frame_size <= 0 || frame_size % 120) return OC_BAD_ARG;
+    if (len <= 0 || data == NULL) return oc_decode(d, NULL, 0, pcm, frame_size);
+    pmode = oc_packet_mode(data);
+    pbw = oc_packet_bandwidth(data);
+    pfs = oc_packet_samples_per_frame(data, 48000);
+    pch = oc_packet_channels(data);
+    count = oc_packet_parse(data, len, 0, &toc, size, &offset, NULL);
+    if (count < 0) return count;
+    data += offset;
+    if (frame_size < pfs || pmode == OC_MODE_CELT || d->mode == OC_MODE_CELT) return oc_decode(d, NULL, 0, pcm, frame_size);
+    dur = d->last_packet_duration;
+    if (frame_size - pfs != 0) {
+        ret = oc_decode(d, NULL, 0, pcm, frame_size - pfs);
+        if (ret < 0) {
+            d->last_packet_duration = dur;
+            return ret;
+        }
+    }
+    d->mode = pmode;
+    d->bandwidth = pbw;
+    d->frame_size = pfs;
+    d->stream_channels = pch;
+    ret = decode_frame(d, data, size[0], pcm + d->channels * (frame_size - pfs), 1);
+    if (ret < 0) return ret;
+    d->last_packet_duration = frame_size;
+    return frame_size;
 }

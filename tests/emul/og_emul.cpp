@@ -45,6 +45,10 @@ int emu_decode_frame(void *stv, const uint8_t *payload, int len, int mode, int b
 int emu_decode_frame_rfc(void *st, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm, int frame_size) {
     return og::decode_frame_rfc((og::StreamState *)st, payload, len, mode, bw, ch, pcm, frame_size);
 }
+// ... its forward error correction data instead (RFC 6716's decode_fec; descriptor flag bit 10)
+int emu_decode_frame_rfc_fec(void *st, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm, int frame_size) {
+    return og::decode_frame_rfc((og::StreamState *)st, payload, len, mode, bw, ch, pcm, frame_size, 1);
+}
 int emu_last_record_words(void) { return 0; }
 }
 

@@ -79,3 +79,27 @@ def same_pcm(got, want, fs, frame_lens, prev_mode, toc_mode, pch, channels):
         if not np.array_equal(a, b):
             return False, k
     return True, -1
+
+
+def conceal_pieces(lost_dur, last_fs):
+    """How a concealment of lost_dur samples is cut into device frames (valid duration codes): a frame of the last packet's size
+    at a time like opus_decode(NULL), what is left over (30 / 50 ms) as 20 / 40 ms + 10 ms."""
+    out, rem = [], lost_dur
+    while rem > 0:
+        w = min(rem, last_fs)
+        rem -= w
+        while w > 0:
+            piece = next(v for v in (2880, 1920, 960, 480, 240, 120) if v <= w)
+            out.append(piece)
+            w -= piece
+    return out
+
+
+def fec_plan(last, toc, channels):
+    """RFC 6716's opus_decode(decode_fec = 1) for the packet with this TOC after a lost packet; last = (frames, frame duration,
+    mode) of the stream's last packet or None.  -> (samples to produce, [concealment frame durations], use the FEC frame?)"""
+    lost_dur, last_fs, last_mode = (last[0] * last[1], last[1], last[2]) if last else (960, 120, 0)
+    pfs, pmode = dur(toc), mode_bw(toc)[0]
+    if lost_dur < pfs or pmode == MODE_CELT or last_mode == MODE_CELT:
+        return lost_dur, conceal_pieces(lost_dur, last_fs), False
+    return lost_dur, conceal_pieces(lost_dur - pfs, last_fs), True

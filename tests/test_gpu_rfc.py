@@ -6,15 +6,19 @@ configuration switches (incl. hybrid -> SILK-only: the silence-frame fade-out). 
 import numpy as np
 import pytest
 
-from rfc_common import dur, make_packet, mode_bw, frame_payloads, same_pcm
+import ctypes as C
+
+from rfc_common import dur, make_packet, mode_bw, frame_payloads, same_pcm, fec_plan
 
 pytestmark = pytest.mark.gpu
 
 
-def _run(pkg, oracle, ctx, channels, plan, seed, p_loss=0.0, p_dtx=0.0):
+def _run(pkg, oracle, ctx, channels, plan, seed, p_loss=0.0, p_dtx=0.0, p_fec=0.0):
     """plan["pick"](stream, step, rng) -> (cfg, code); every stream decodes plan["steps"] packets, one per step.  p_loss: the
     share of packets that are lost (empty: concealed for as long as the stream's last packet was); p_dtx: the share of packets
-    whose frames carry 0 or 1 bytes.  -> packets compared."""
+    whose frames carry 0 or 1 bytes; p_fec: the share of packets before which a packet was lost and is recovered from the
+    packet's forward error correction data (decode_packets_fec), after which the packet is decoded normally.
+    -> packets compared."""
     rng = np.random.default_rng(seed)
     n, steps = plan["streams"], plan["steps"]
     ctx.set_mode(True)
@@ -26,8 +30,9 @@ def _run(pkg, oracle, ctx, channels, plan, seed, p_loss=0.0, p_dtx=0.0):
             d.init()
             d.set_rfc(True)
             decs.append(d)
-        last = [None] * n  # (frame count, frame duration, packet channels) of the stream's last packet that framed
+        last = [None] * n  # (frame count, frame duration, packet channels, mode) of the stream's last packet that framed
         checked = 0
+        oracle.lib.oc_decode_fec.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_int]
         for f in range(steps):
             pk = []
             for s in range(n):
@@ -38,11 +43,35 @@ def _run(pkg, oracle, ctx, channels, plan, seed, p_loss=0.0, p_dtx=0.0):
                 stereo = (channels == 2) if rng.random() < 0.85 else bool(rng.integers(2))
                 L = int(rng.integers(0, 2)) if rng.random() < p_dtx else int(rng.choice([3, 8, 20, 40, 80, 120, 160, 300]))
                 pk.append(make_packet(rng, cfg, stereo, code, L))
+            who = [s for s in range(n) if len(pk[s]) and rng.random() < p_fec and frame_payloads(oracle, pk[s]) is not None]
+            if who:  # the packet before pk[s] was lost: recover it from pk[s]
+                pcm, res = ctx.decode_packets_fec(np.array(who), [pk[s] for s in who], frame_capacity=6)
+                for j, s in enumerate(who):
+                    toc = pk[s][0]
+                    total, pieces, use = fec_plan((last[s][0], last[s][1], last[s][3]) if last[s] else None, toc, channels)
+                    before = decs[s].prev_mode()
+                    ref = np.zeros((5760, channels), dtype=np.int16)
+                    r = oracle.lib.oc_decode_fec(decs[s].h, pk[s], len(pk[s]), ref.ctypes.data, total)
+                    assert res[j] == r, (f, s, "fec", hex(toc), int(res[j]), r)
+                    if r <= 0:
+                        continue
+                    lpch = last[s][2] if last[s] else channels
+                    at, mode_now = 0, before
+                    for w in pieces:  # concealed in the mode of the frame before, over the last packet's channels
+                        ok, _ = same_pcm(pcm[j][at:at + w], ref[at:at + w], w, [0], mode_now, mode_now, lpch, channels)
+                        assert ok, (f, s, "fec: concealment piece at", at)
+                        at += w
+                    if use:
+                        fs, pch, m = dur(toc), (2 if toc & 4 else 1), mode_bw(toc)[0]
+                        ln = len(frame_payloads(oracle, pk[s])[0])
+                        ok, _ = same_pcm(pcm[j][at:at + fs], ref[at:at + fs], fs, [ln], mode_now, m, pch, channels)
+                        assert ok, (f, s, "fec frame", hex(toc))
+                    checked += 1
             pcm, res = ctx.decode_packets(np.arange(n), pk, frame_capacity=6)
             for s in range(n):
                 before = decs[s].prev_mode()
                 if len(pk[s]) == 0:
-                    cnt, fs, pch = last[s] if last[s] else (1, 960, channels)
+                    cnt, fs, pch = last[s][:3] if last[s] else (1, 960, channels)
                     ref, r = decs[s].conceal(cnt * fs)
                     lens, toc_mode, label = [0] * cnt, before, "lost"
                 else:
@@ -51,7 +80,7 @@ def _run(pkg, oracle, ctx, channels, plan, seed, p_loss=0.0, p_dtx=0.0):
                     toc = pk[s][0]
                     fs, pch, toc_mode, label = dur(toc), (2 if toc & 4 else 1), mode_bw(toc)[0], hex(toc)
                     if pays is not None:
-                        last[s] = (len(pays), fs, pch)
+                        last[s] = (len(pays), fs, pch, toc_mode)
                         lens = [len(p) for p in pays]
                 assert res[s] == r, (f, s, label, int(res[s]), r)
                 if r <= 0:
@@ -100,6 +129,22 @@ def test_rfc_loss_path(pkg, oracle, gpu_ctx, channels):
 
     plan = {"streams": 512, "steps": 10, "pick": pick}
     assert _run(pkg, oracle, gpu_ctx, channels, plan, 501 + channels, p_loss=0.3, p_dtx=0.06) > 512 * 7
+
+
+@pytest.mark.parametrize("channels", [2, 1])
+def test_rfc_forward_error_correction(pkg, oracle, gpu_ctx, channels):
+    """opus_decode(decode_fec = 1): a lost packet recovered from the NEXT packet's LBRR frames (SILK-only and hybrid; per channel
+    and internal frame a concealment where the packet carries no copy; hybrid's CELT layer concealed), plain concealment
+    around CELT-only packets; mixed with ordinary losses and DTX frames"""
+    state = {}
+
+    def pick(s, f, rng):
+        if s not in state or rng.random() < 0.25:
+            state[s] = int(rng.integers(32)) if rng.random() < 0.3 else int(rng.integers(16))  # (mostly SILK-only / hybrid)
+        return state[s], int(rng.choice([0, 0, 0, 1, 2, 3]))
+
+    plan = {"streams": 384, "steps": 10, "pick": pick}
+    assert _run(pkg, oracle, gpu_ctx, channels, plan, 801 + channels, p_loss=0.15, p_dtx=0.04, p_fec=0.3) > 384 * 9
 
 
 def test_rfc_loss_before_any_packet_and_after_reset(pkg, oracle, gpu_ctx):

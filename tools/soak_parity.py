@@ -4,7 +4,9 @@ random sequence of 20 ms packets -- mode / bandwidth / mono-stereo switches betw
 all-zero and all-ones -- and every PCM sample and return code is compared with the CPU oracle.
 usage (GPU box): python3 tools/soak_parity.py [streams] [frames] [rounds] [seed]
        --host: through opusgpu_decode_packets instead, packets of every frame-count code (1 - 48 frames, padding, VBR / CBR,
-       some malformed), every configuration incl. the non-20 ms ones, room for three frames per call"""
+       some malformed), every configuration incl. the non-20 ms ones, room for three frames per call
+       --rfc: RFC mode (true frame durations, all 32 configurations x codes 0..3) with 25 % lost packets, 6 % DTX packets and 10 % of the packets preceded by a recovery from their FEC data,
+       through opusgpu_decode_packets against one oracle decoder per stream (tests/test_gpu_rfc.py's comparison, larger)"""
 import importlib.util
 import os
 import sys
@@ -23,6 +25,9 @@ spec.loader.exec_module(pkg)
 HOST = "--host" in sys.argv
 if HOST:
     sys.argv.remove("--host")
+RFC = "--rfc" in sys.argv
+if RFC:
+    sys.argv.remove("--rfc")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
@@ -71,6 +76,24 @@ def random_packet(rng, cfg, stereo):
         out += body(max(m, 1) * fl())
     return out + bytes(padlen)
 
+
+if RFC:
+    import test_gpu_rfc  # noqa: E402  (tests/ is on the path)
+    for rnd in range(rounds):
+        for channels in (2, 1):
+            state = {}
+
+            def pick(s, f, rng):
+                if s not in state or rng.random() < 0.3:
+                    state[s] = int(rng.integers(32))
+                return state[s], int(rng.choice([0, 0, 0, 1, 2, 3]))
+
+            got = test_gpu_rfc._run(pkg, oracle, ctx, channels, {"streams": n, "steps": frames, "pick": pick},
+                                    seed * 1000 + 900 + rnd * 2 + channels, p_loss=0.25, p_dtx=0.06, p_fec=0.1)  # asserts on any mismatch
+            total += got
+            print(f"rfc round {rnd} channels {channels}: {got} packets with PCM compared (of {n * frames}), 0 mismatches, {time.time() - t_start:.0f} s", flush=True)
+    print(f"SOAK (RFC mode with lost packets and DTX frames): {total} packets compared sample by sample, 0 mismatches")
+    sys.exit(0)
 
 if HOST:
     ALLCFG = list(range(32))
