@@ -218,7 +218,8 @@ OG_DEV int rfc_end_band(int bandwidth) { // RFC 6716 section 4.3: NB 13, WB 17, 
 // the head of a 10 ms concealment); CELT -- and hybrid's CELT layer from band 17 -- conceals with celt_decode_lost, its last band
 // what the last decoded frame made it.  `ch`: the channel count of the last packet (the descriptor's).
 OG_DEV int conceal_chunk_rfc(StreamState *st, int ch, i16 *pcm, int audiosize) { // at most 20 ms
-    const int CC = st->channels, mode = st->prev_mode;
+    // the last used mode: CELT if the last frame ended with CELT redundancy
+    const int CC = st->channels, mode = st->loss.prev_redundancy ? (int)MODE_CELT : st->prev_mode;
     if (mode == 0) { // nothing decoded yet: zeros
         OG_FOR_LANES(i, audiosize * CC) pcm[i] = 0;
         OG_SYNC();
@@ -261,7 +262,10 @@ OG_DEV int conceal_chunk_rfc(StreamState *st, int ch, i16 *pcm, int audiosize) {
             OG_SYNC();
         }
     }
+    OG_SYNC();
     if (OG_LANE == 0) {
+        st->prev_mode = mode;
+        st->loss.prev_redundancy = 0;
         st->frames_decoded += 1;
         st->range_final = 0;
     }
@@ -280,37 +284,39 @@ OG_DEV int conceal_frame_rfc(StreamState *st, int ch, i16 *pcm, int audiosize) {
 // `fec` (descriptor flag bit 10): RFC 6716's decode_fec -- the frame is the first one of the packet AFTER a lost packet: SILK
 // decodes its LBRR copies (the lost frame's audio) where the packet carries them and conceals where not, CELT has no FEC and
 // conceals (hybrid: its layer from band 17).  The host never sets it for CELT-only frames (plain concealment instead).
+// Redundancy (RFC 6716 section 4.5.1; the reference reads the flag and ignores it, Q2): a hybrid frame may flag, and a SILK-only
+// frame carries in whatever follows its SILK data, a redundant 5 ms CELT frame for a mode transition.  CELT -> SILK: it is
+// decoded first, from the running CELT state; its first 2.5 ms replace the frame's start, the rest fades out into the frame.
+// SILK -> CELT: it is decoded last, from a reset CELT state, and its second half fades in over the frame's last 2.5 ms (the CELT
+// frame that follows then continues from that state instead of a reset one).  The fades weigh with the squared CELT window.
+OG_DEV void rfc_smooth_fade(i16 *pcm, int at, const i16 *red, int red_at, int CC, bool into_pcm) {
+    // out = (w * in2 + (Q15ONE - w) * in1) >> 15 over 120 samples per channel; in1 fades out, in2 fades in.
+    // into_pcm: in1 = the frame (pcm[at..]), in2 = the redundant audio (red[red_at..]); otherwise the other way round.
+    OG_FOR_LANES(i, 120 * CC) {
+        const int j = CC == 2 ? (i >> 1) : i;
+        const i32 w = mul16_q15(rom_win120[j], rom_win120[j]);
+        const i32 p = pcm[at + i], r = red[red_at + i];
+        const i32 in1 = into_pcm ? p : r, in2 = into_pcm ? r : p;
+        pcm[at + i] = (i16)((mul16(w, in2) + mul16(32767 - w, in1)) >> 15);
+    }
+}
 OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mode, int bandwidth, int ch, i16 *pcm, int audiosize,
                             int fec = 0) {
     const int CC = st->channels;
     if (len < 0 || len > 1275) return BAD_ARG;
     if (len <= 1) return conceal_frame_rfc(st, ch, pcm, audiosize);
-    const int prev_mode = st->prev_mode;
+    const int prev_mode = st->prev_mode, prev_redundancy = st->loss.prev_redundancy;
     // the reference's mix loop runs over audiosize * stream_channels LINEAR entries of the interleaved output (Q3); the oracle's
     // RFC mode keeps that and stops at the frame's own end
     const int nmix = audiosize * (ch < CC ? ch : CC);
-    const bool flush = mode == MODE_SILK && prev_mode == MODE_HYBRID;
-    const int disable_inv = CC == 1;
-#ifndef OG_NO_SILK
-    if (flush) {
-        // RFC 6716 section 4.5.2: the MDCT fades out through a silence frame of 2.5 ms, start band 0 (its return value is not
-        // looked at).  It shares nothing with the SILK data, so it runs first: its 120 samples per channel then wait in the
-        // CELT working set, which the SILK decoder does not touch, until the first internal frame's PCM is added to them.
-        OG_SYNC();
-        OG_FOR_LANES(i, 2) S.pkt[i] = 0xFF;
-        OG_SYNC();
-        Rc rs;
-        rc_init(rs, 2u);
-        (void)celt_decode_frame(&st->celt, rs, 120, ch, CC, 0, disable_inv, NBANDS, &st->loss);
-        OG_SYNC();
-    }
-#endif
+    const int disable_inv = CC == 1, end_band = rfc_end_band(bandwidth);
     OG_SYNC();
     OG_FOR_LANES(i, len) S.pkt[i] = payload[i];
     OG_SYNC();
     Rc rc;
     rc_init(rc, (u32)len);
-    int celt_ret = 0;
+    int celt_ret = 0, redundancy = 0, celt_to_silk = 0, redundancy_bytes = 0, celt_lost = 0, main_len = len;
+    u32 redundant_rng = 0;
 #ifndef OG_NO_SILK
     if (mode != MODE_CELT) {
         if (prev_mode == MODE_CELT) silk_init_state(&st->silk, &st->loss);
@@ -318,17 +324,10 @@ OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mod
         if (mode == MODE_SILK) internal_hz = bandwidth == BW_NB ? 8000 : (bandwidth == BW_MB ? 12000 : 16000);
         int base = 0; // linear position of the internal frame in the packet's SILK PCM
         const int ret = silk_decode_packet<false>(&st->silk, rc, ch, internal_hz, audiosize / 48, nullptr, [&](int, int n48) {
-            if (mode == MODE_SILK) { // PCM = SAT16(outbuf + pcm_silk), outbuf zero but for the fade-out: straight to HBM
+            if (mode == MODE_SILK) { // PCM = SAT16(outbuf + pcm_silk), outbuf zero but for the fade-out added below: straight to HBM
                 OG_FOR_LANES(i, n48 * ch) {
                     const int at = base + i;
-                    if (at < nmix) {
-                        i32 v = SL().u.out.pcm[i];
-                        if (flush && at < 120 * CC) {
-                            const int c = CC == 2 ? (at & 1) : 0, j = CC == 2 ? (at >> 1) : at;
-                            v = sat16(v + (i32)S.v[pcm_plane(c, ch, CC) + j]);
-                        }
-                        pcm[at] = (i16)v;
-                    }
+                    if (at < nmix) pcm[at] = SL().u.out.pcm[i];
                 }
                 base += n48 * ch;
             }
@@ -336,24 +335,61 @@ OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mod
         if (ret) return INTERNAL_ERROR;
     }
     if (!fec && mode != MODE_CELT && rc_tell(rc) + 17 + 20 * (mode == MODE_HYBRID) <= 8 * len) {
-        if (mode == MODE_HYBRID) (void)rc_bit_logp(rc, 12); // redundancy flag read and ignored (Q2)
+        redundancy = mode == MODE_HYBRID ? rc_bit_logp(rc, 12) : 1;
+        if (redundancy) {
+            celt_to_silk = rc_bit_logp(rc, 1);
+            redundancy_bytes = mode == MODE_HYBRID ? (int)rc_uint(rc, 256) + 2 : len - ((rc_tell(rc) + 7) >> 3);
+            main_len = len - redundancy_bytes;
+            if (main_len * 8 < rc_tell(rc)) { // (never for a valid packet; what happens then is not normative)
+                main_len = 0;
+                redundancy_bytes = 0;
+                redundancy = 0;
+                celt_lost = 1; // RFC 6716's decoder: a CELT frame of len <= 1 is a lost one
+            }
+            rc.storage -= (u32)redundancy_bytes; // the raw bits end where the redundant frame starts
+        }
     }
+    i16 *const red_hold = &SL().u.out.up[0][0]; // 240 * CC samples: the 2x up-sampler's buffers are dead once SILK's PCM is out
 #else
     if (mode != MODE_CELT) return INTERNAL_ERROR;
+    i16 *const red_hold = nullptr;
 #endif
+    if (OG_LANE == 0) st->loss.celt_end_band = end_band; // (what a later concealment's last band is)
+    // the redundant frame: its bytes to the front of the packet buffer, a range decoder of its own, 5 ms from band 0
+    auto decode_redundant = [&]() {
+        OG_SYNC();
+        OG_FOR_LANES(i, redundancy_bytes) S.pkt[i] = payload[main_len + i];
+        OG_SYNC();
+        Rc rr;
+        rc_init(rr, (u32)redundancy_bytes);
+        (void)celt_decode_frame(&st->celt, rr, 240, ch, CC, 0, disable_inv, end_band, &st->loss);
+        OG_SYNC();
+        redundant_rng = (u32)OG_UNI(st->celt.rng);
+    };
+    if (redundancy && celt_to_silk) {
+        decode_redundant();
+        OG_FOR_LANES(i, 240 * CC) {
+            const int c = CC == 2 ? (i & 1) : 0, j = CC == 2 ? (i >> 1) : i;
+            red_hold[i] = S.v[pcm_plane(c, ch, CC) + j];
+        }
+        OG_SYNC();
+        if (mode == MODE_HYBRID) { // the main frame's bytes again: its coder is still running
+            OG_FOR_LANES(i, main_len) S.pkt[i] = payload[i];
+            OG_SYNC();
+        }
+    }
     if (mode != MODE_SILK) {
-        if (mode != prev_mode && prev_mode > 0) {
+        if (mode != prev_mode && prev_mode > 0 && !prev_redundancy) {
             celt_reset_state(&st->celt);
             OG_SYNC();
         }
-        if (OG_LANE == 0) st->loss.celt_end_band = rfc_end_band(bandwidth); // (what a later concealment's last band is)
         OG_SYNC();
-        const int Cp = fec ? CC : ch; // (a concealment runs over the decoder's channels: its PCM planes are laid out for C == CC)
-        if (fec)
-            celt_ret = celt_decode_lost(&st->celt, &st->loss, audiosize, CC, mode == MODE_CELT ? 0 : 17, rfc_end_band(bandwidth));
+        const int lost = fec || celt_lost;
+        const int Cp = lost ? CC : ch; // (a concealment runs over the decoder's channels: its PCM planes are laid out for C == CC)
+        if (lost)
+            celt_ret = celt_decode_lost(&st->celt, &st->loss, audiosize, CC, mode == MODE_CELT ? 0 : 17, end_band);
         else
-            celt_ret = celt_decode_frame(&st->celt, rc, audiosize, ch, CC, mode == MODE_CELT ? 0 : 17, disable_inv,
-                                         rfc_end_band(bandwidth), &st->loss);
+            celt_ret = celt_decode_frame(&st->celt, rc, audiosize, ch, CC, mode == MODE_CELT ? 0 : 17, disable_inv, end_band, &st->loss);
 #ifndef OG_NO_SILK
         if (mode == MODE_HYBRID && celt_ret >= 0) {
             OG_SYNC();
@@ -371,17 +407,47 @@ OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mod
         }
     }
 #ifndef OG_NO_SILK
-    else if (flush && nmix < 120 * CC) { // (never: SILK frames are at least 10 ms) entries only the fade-out reaches
+    else if (prev_mode == MODE_HYBRID && !(redundancy && celt_to_silk && prev_redundancy)) {
+        // RFC 6716 section 4.5.2: the MDCT fades out through a silence frame of 2.5 ms from band 0 (its return value is not looked
+        // at); its 120 samples per channel are added to the SILK PCM already in HBM
+        OG_SYNC();
+        OG_FOR_LANES(i, 2) S.pkt[i] = 0xFF;
+        OG_SYNC();
+        Rc rs;
+        rc_init(rs, 2u);
+        (void)celt_decode_frame(&st->celt, rs, 120, ch, CC, 0, disable_inv, end_band, &st->loss);
+        OG_SYNC();
         OG_FOR_LANES(i, 120 * CC) {
             const int c = CC == 2 ? (i & 1) : 0, j = CC == 2 ? (i >> 1) : i;
-            if (i >= nmix) pcm[i] = S.v[pcm_plane(c, ch, CC) + j];
+            const i32 v = S.v[pcm_plane(c, ch, CC) + j];
+            pcm[i] = (i16)(i < nmix ? sat16(v + (i32)pcm[i]) : v);
         }
+        OG_SYNC();
+    }
+    if (redundancy && !celt_to_silk) { // SILK -> CELT: a fresh CELT state, the redundant frame, its second half over the frame's end
+        celt_reset_state(&st->celt);
+        OG_SYNC();
+        decode_redundant();
+        if (celt_ret >= 0) {
+            OG_FOR_LANES(i, 120 * CC) { // (the redundant audio still lies in the PCM planes: interleave its second half first)
+                const int c = CC == 2 ? (i & 1) : 0, j = CC == 2 ? (i >> 1) : i;
+                red_hold[i] = S.v[pcm_plane(c, ch, CC) + 120 + j];
+            }
+            OG_SYNC();
+            rfc_smooth_fade(pcm, CC * (audiosize - 120), red_hold, 0, CC, true);
+        }
+    } else if (redundancy && celt_ret >= 0) { // CELT -> SILK
+        OG_SYNC();
+        OG_FOR_LANES(i, 120 * CC) pcm[i] = red_hold[i];
+        rfc_smooth_fade(pcm, CC * 120, red_hold, CC * 120, CC, false);
     }
 #endif
+    OG_SYNC();
     if (OG_LANE == 0) {
         st->prev_mode = mode;
+        st->loss.prev_redundancy = redundancy && !celt_to_silk;
         st->frames_decoded += 1;
-        st->range_final = rc.rng;
+        st->range_final = main_len <= 1 ? 0u : rc.rng ^ redundant_rng;
     }
     OG_SYNC();
     return celt_ret < 0 ? celt_ret : audiosize;

@@ -83,8 +83,9 @@ struct LossState {
     i16 backgroundLogE[2 * NBANDS];
     i16 pad[2];
     i32 celt_loss_count;
-    i32 celt_end_band;         // last band of the last decoded CELT / hybrid frame (what a concealment fills up to)
-    i32 reserved[2];
+    i32 celt_end_band;         // last band by the bandwidth of the last decoded frame (what a concealment fills up to)
+    i32 prev_redundancy;       // the last frame ended with a redundant CELT frame: a SILK -> CELT transition is under way
+    i32 reserved[1];
 };
 
 struct StreamState {

@@ -95,4 +95,6 @@ int oc_taps_copy(const oc_decoder *d, int what, int c, void *dst) {
 }
 
 /* TEST ENTRY: the mode of the last frame (0 before the first one): what a concealment would run in */
-int oc_decoder_prev_mode(const oc_decoder *d) { return d->prev_mode; }
+int oc_decoder_prev_mode(const oc_decoder *d) { return d->prev_redundancy ? OC_MODE_CELT : d->prev_mode; }
+/* TEST ENTRY: 0 none, 1 SILK -> CELT, 3 CELT -> SILK: the redundancy of the last frame decoded (RFC mode) */
+int oc_decoder_last_redundancy(const oc_decoder *d) { return d->last_redundancy; }

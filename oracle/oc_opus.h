@@ -135,6 +135,8 @@ typedef struct oc_decoder {
     i32 channels;
     i32 rfc;               /* 0: reference-exact (every frame decodes as 20 ms, Q6); 1: RFC mode, see oc_decoder_set_rfc */
     i32 stream_channels, bandwidth, mode, prev_mode, frame_size, last_packet_duration;
+    i32 prev_redundancy;   /* RFC mode: the last frame ended with a redundant CELT frame (a SILK -> CELT transition is under way) */
+    i32 last_redundancy;   /* test hook: what the last decoded frame carried -- 0 none, 1 SILK -> CELT, 3 CELT -> SILK redundancy */
     u32 range_final;
     oc_rc rc;              /* the reference's global s_ec: survives between frames (Q4) */
     oc_celt celt;
@@ -149,8 +151,10 @@ void oc_decoder_reset(oc_decoder *d);                    /* OPUS_RESET_STATE  op
 /* RFC mode (PARITY UNPINNED -- the reference cannot do this and no libopus exists in the image): frames decode
  * at the duration their TOC names (CELT 2.5 / 5 / 10 / 20 ms, SILK 10 / 20 / 40 / 60 ms, hybrid 10 / 20 ms), multi-frame
  * packets accordingly; CELT's last band follows the bandwidth (13 / 17 / 19 / 21: Q1 fixed); a SILK-only frame after a hybrid
- * one fades the CELT layer out with the two-byte silence frame (RFC 6716 section 4.5.2) instead of Q4's stale-coder frame.
- * Everything else stays as the reference has it (Q2, Q3, Q5, Q7).  Survives oc_decoder_init / _reset. */
+ * one fades the CELT layer out with the two-byte silence frame (RFC 6716 section 4.5.2) instead of Q4's stale-coder frame;
+ * the redundant 5 ms CELT frames of mode transitions are decoded and cross-faded in (section 4.5.1; Q2 fixed); lost packets,
+ * DTX frames and forward error correction as in RFC 6716's decoder (oc_decode with data == NULL, oc_decode_fec; Q8 fixed).
+ * Everything else stays as the reference has it (Q3, Q5, Q7).  Survives oc_decoder_init / _reset. */
 void oc_decoder_set_rfc(oc_decoder *d, int on);
 /* opus_decode_native (opus_decoder.cpp:280) for one elementary stream; returns samples/channel or <0 */
 int oc_decode(oc_decoder *d, const u8 *data, i32 len, i16 *pcm, int frame_size);

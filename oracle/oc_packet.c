@@ -6,7 +6,7 @@
  * decoded and ignored (Q2), hybrid->SILK transition decodes CELT from the live range coder (Q4).
  */
 #include <stdlib.h>
-#include "oc_opus.h"
+#include "oc_celt_priv.h"
 
 int oc_packet_mode(const u8 *d) { /* opus_decoder.cpp:135 */
     if (d[0] & 0x80) return OC_MODE_CELT;
@@ -168,6 +168,7 @@ void oc_decoder_init(oc_decoder *d, int channels) { /* opus_decoder.cpp:82 */
 
 void oc_decoder_reset(oc_decoder *d) { /* opus_decoder.cpp:382 */
     d->stream_channels = d->bandwidth = d->mode = d->prev_mode = d->frame_size = 0;
+    d->prev_redundancy = 0;
     d->last_packet_duration = 0;
     d->range_final = 0;
     oc_celt_reset(&d->celt);
@@ -212,7 +213,8 @@ static int rfc_end_band(int bandwidth) {
  * the head of a 10 ms concealment); CELT (and hybrid's CELT layer, from band 17) conceals with oc_celt_decode_lost.  No
  * transition smoothing and no redundancy, like the rest of this decoder (Q7, Q2). */
 static int conceal_frame(oc_decoder *d, i16 *out, int frame_size) {
-    const int mode = d->prev_mode, ch = d->stream_channels, CC = d->channels;
+    /* the last used mode: CELT if the last frame ended with CELT redundancy */
+    const int mode = d->prev_redundancy ? OC_MODE_CELT : d->prev_mode, ch = d->stream_channels, CC = d->channels;
     int audiosize = frame_size, i, nmix, celt_ret = 0;
     i16 pcm_silk[960 * 2];
     if (mode == 0) { /* nothing decoded yet: all we can do is return zeros */
@@ -255,6 +257,7 @@ static int conceal_frame(oc_decoder *d, i16 *out, int frame_size) {
     if (mode != OC_MODE_CELT)
         for (i = 0; i < nmix; i++) out[i] = sat16((i32)out[i] + pcm_silk[i]);
     d->prev_mode = mode;
+    d->prev_redundancy = 0;
     d->range_final = 0;
     return celt_ret < 0 ? celt_ret : audiosize;
 }
@@ -269,8 +272,10 @@ static int decode_frame(oc_decoder *d, const u8 *inbuf, i32 len, i16 *out, int f
      * lies beyond the frame's own 960 * channels entries is the next frame's space or past the caller's buffer.  RFC mode
      * keeps the arithmetic and stays inside the frame (packets of 120 ms fill the buffer to its last entry). */
     const int nmix = d->rfc ? audiosize * (ch < d->channels ? ch : d->channels) : audiosize * ch;
-    int i, celt_ret = 0, start_band;
-    i16 pcm_silk[2880 * 2];
+    int i, c, celt_ret = 0, start_band, redundancy = 0, celt_to_silk = 0, celt_lost = 0;
+    i32 redundancy_bytes = 0;
+    u32 redundant_rng = 0;
+    i16 pcm_silk[2880 * 2], redundant_audio[240 * 2];
     oc_rc *rc = &d->rc;
 
     if (d->rfc && (inbuf == NULL || len <= 1)) return conceal_frame(d, out, d->frame_size);
@@ -295,28 +300,53 @@ static int decode_frame(oc_decoder *d, const u8 *inbuf, i32 len, i16 *out, int f
     }
     start_band = 0;
     if (!fec && mode != OC_MODE_CELT && oc_rc_tell(rc) + 17 + 20 * (mode == OC_MODE_HYBRID) <= 8 * len) {
-        if (mode == OC_MODE_HYBRID) (void)oc_rc_bit_logp(rc, 12); /* redundancy flag: ignored (Q2) */
+        if (!d->rfc) {
+            if (mode == OC_MODE_HYBRID) (void)oc_rc_bit_logp(rc, 12); /* redundancy flag: ignored (Q2) */
+        } else {
+            /* RFC 6716 section 4.5.1: a redundant 5 ms CELT frame for the mode transitions.  Hybrid frames flag it; in a SILK-only
+             * frame whatever follows the SILK data is one.  Then: which side of the frame it belongs to, and its size. */
+            redundancy = mode == OC_MODE_HYBRID ? oc_rc_bit_logp(rc, 12) : 1;
+            if (redundancy) {
+                celt_to_silk = oc_rc_bit_logp(rc, 1);
+                redundancy_bytes = mode == OC_MODE_HYBRID ? (i32)oc_rc_uint(rc, 256) + 2 : len - ((oc_rc_tell(rc) + 7) >> 3);
+                len -= redundancy_bytes;
+                if (len * 8 < oc_rc_tell(rc)) { /* (never for a valid packet; what happens then is not normative) */
+                    len = 0;
+                    redundancy_bytes = 0;
+                    redundancy = 0;
+                    celt_lost = 1; /* RFC 6716's decoder: a CELT frame of len <= 1 is a lost one */
+                }
+                rc->storage -= redundancy_bytes; /* the raw bits end where the redundant frame starts */
+            }
+        }
     }
     if (mode != OC_MODE_CELT) start_band = 17;
     if (d->bandwidth) d->celt.stream_channels = ch; /* END_BAND request has no effect (Q1) */
-    d->celt.start_band = start_band;
     d->celt.end_band = d->rfc ? rfc_end_band(d->bandwidth) : OC_NBANDS;
 
+    if (redundancy && celt_to_silk) { /* the 5 ms redundant frame of a CELT -> SILK transition: decoded first, heard first */
+        oc_rc rr;
+        d->celt.start_band = 0;
+        oc_rc_init(&rr, inbuf + len, redundancy_bytes);
+        (void)oc_celt_decode(&d->celt, &rr, redundant_audio, 240, NULL);
+        redundant_rng = d->celt.rng;
+    }
+    d->celt.start_band = start_band;
+
     if (mode != OC_MODE_SILK) {
-        if (mode != d->prev_mode && d->prev_mode > 0) oc_celt_reset(&d->celt);
-        if (fec)
+        if (mode != d->prev_mode && d->prev_mode > 0 && !d->prev_redundancy) oc_celt_reset(&d->celt);
+        if (fec || celt_lost)
             celt_ret = oc_celt_decode_lost(&d->celt, out, audiosize);
         else
             celt_ret = oc_celt_decode(&d->celt, rc, out, audiosize, d->taps); /* (CELT frames are 2.5 - 20 ms) */
     } else {
         for (i = 0; i < nmix; i++) out[i] = 0;
-        if (d->prev_mode == OC_MODE_HYBRID) {
+        if (d->prev_mode == OC_MODE_HYBRID && !(redundancy && celt_to_silk && d->prev_redundancy)) {
             d->celt.start_band = 0;
             if (d->rfc) { /* RFC 6716 section 4.5.2: let the MDCT fade out by decoding a silence frame */
                 static const u8 silence[2] = {0xFF, 0xFF};
                 oc_rc rs;
                 oc_rc_init(&rs, silence, 2);
-                d->celt.end_band = OC_NBANDS;
                 (void)oc_celt_decode(&d->celt, &rs, out, 120, NULL);
             } else /* Q4: the reference runs the 2.5 ms frame off the coder SILK has just used */
                 (void)oc_celt_decode(&d->celt, rc, out, 120, NULL);
@@ -324,7 +354,35 @@ static int decode_frame(oc_decoder *d, const u8 *inbuf, i32 len, i16 *out, int f
     }
     if (mode != OC_MODE_CELT)
         for (i = 0; i < nmix; i++) out[i] = sat16((i32)out[i] + pcm_silk[i]);
+    if (redundancy) { /* RFC 6716 section 4.5.1.4 (smooth_fade: the squared CELT window over 2.5 ms) */
+        const int CC = d->channels;
+        i16 *a, *b, *o;
+        if (!celt_to_silk) { /* SILK -> CELT: the redundant frame starts a fresh CELT state; its second half fades in at the end */
+            oc_rc rr;
+            oc_celt_reset(&d->celt);
+            d->celt.start_band = 0;
+            oc_rc_init(&rr, inbuf + len, redundancy_bytes);
+            (void)oc_celt_decode(&d->celt, &rr, redundant_audio, 240, NULL);
+            redundant_rng = d->celt.rng;
+            a = out + CC * (audiosize - 120);
+            b = redundant_audio + CC * 120;
+            o = a;
+        } else { /* CELT -> SILK: its first half replaces the frame's start, its second half fades out into the frame */
+            for (i = 0; i < 120 * CC; i++) out[i] = redundant_audio[i];
+            a = redundant_audio + CC * 120;
+            b = out + CC * 120;
+            o = b;
+        }
+        for (c = 0; c < CC; c++)
+            for (i = 0; i < 120; i++) {
+                const i32 w = m16_q15(rom_win120[i], rom_win120[i]);
+                o[i * CC + c] = (i16)((m16(w, b[i * CC + c]) + m16(32767 - w, a[i * CC + c])) >> 15);
+            }
+    }
+    d->range_final = len <= 1 ? 0 : rc->rng ^ redundant_rng;
     d->prev_mode = mode;
+    d->prev_redundancy = redundancy && !celt_to_silk;
+    d->last_redundancy = redundancy | celt_to_silk << 1;
     return celt_ret < 0 ? celt_ret : audiosize;
 }
 

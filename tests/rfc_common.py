@@ -1,6 +1,8 @@
 """Shared by the RFC-mode parity tests (tests/test_emul_rfc.py via tools/fuzz_emul_rfc.py, tests/test_gpu_rfc.py): packet
 generation over all TOC configurations, framing, and WHICH output entries a packet defines -- the comparison domain."""
 import ctypes as C
+import json
+import os
 
 import numpy as np
 
@@ -103,3 +105,20 @@ def fec_plan(last, toc, channels):
     if lost_dur < pfs or pmode == MODE_CELT or last_mode == MODE_CELT:
         return lost_dur, conceal_pieces(lost_dur, last_fs), False
     return lost_dur, conceal_pieces(lost_dur - pfs, last_fs), True
+
+
+_REDUNDANT = None
+
+
+def redundancy_packet(rng, channels_pref=None):
+    """A hybrid packet whose redundancy flag is set (tests/golden/rfc_hybrid_redundancy_seeds.json, found by
+    tools/find_redundancy_seeds.py: the flag is one range-coded bit of probability 2^-12, random payloads almost never set it).
+    -> (packet bytes, kind)"""
+    global _REDUNDANT
+    if _REDUNDANT is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rfc_hybrid_redundancy_seeds.json")
+        _REDUNDANT = json.load(open(path))
+    pool = [e for e in _REDUNDANT if channels_pref is None or bool(e["toc"] & 4) == (channels_pref == 2)] or _REDUNDANT
+    e = pool[int(rng.integers(len(pool)))]
+    pay = np.random.default_rng(e["seed"]).integers(0, 256, e["len"], dtype=np.uint8).tobytes()
+    return bytes([e["toc"]]) + pay, e["kind"]

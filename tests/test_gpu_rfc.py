@@ -8,7 +8,7 @@ import pytest
 
 import ctypes as C
 
-from rfc_common import dur, make_packet, mode_bw, frame_payloads, same_pcm, fec_plan
+from rfc_common import dur, make_packet, mode_bw, frame_payloads, same_pcm, fec_plan, redundancy_packet
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +42,10 @@ def _run(pkg, oracle, ctx, channels, plan, seed, p_loss=0.0, p_dtx=0.0, p_fec=0.
                 cfg, code = plan["pick"](s, f, rng)
                 stereo = (channels == 2) if rng.random() < 0.85 else bool(rng.integers(2))
                 L = int(rng.integers(0, 2)) if rng.random() < p_dtx else int(rng.choice([3, 8, 20, 40, 80, 120, 160, 300]))
-                pk.append(make_packet(rng, cfg, stereo, code, L))
+                if rng.random() < plan.get("p_redundant", 0.0):  # a hybrid packet with its redundancy flag set
+                    pk.append(redundancy_packet(rng, channels if rng.random() < 0.85 else None)[0])
+                else:
+                    pk.append(make_packet(rng, cfg, stereo, code, L))
             who = [s for s in range(n) if len(pk[s]) and rng.random() < p_fec and frame_payloads(oracle, pk[s]) is not None]
             if who:  # the packet before pk[s] was lost: recover it from pk[s]
                 pcm, res = ctx.decode_packets_fec(np.array(who), [pk[s] for s in who], frame_capacity=6)
@@ -103,7 +106,8 @@ def test_rfc_all_configs_and_codes(pkg, oracle, gpu_ctx, channels):
 @pytest.mark.parametrize("channels", [2, 1])
 def test_rfc_configuration_switches(pkg, oracle, gpu_ctx, channels):
     """every stream walks its own random sequence of configurations and codes (mode, bandwidth and duration switches,
-    hybrid -> SILK-only among them)"""
+    hybrid -> SILK-only among them); redundant CELT frames (RFC 6716 section 4.5.1): SILK-only frames with random payloads
+    carry one almost always, hybrid packets with the flag set are mixed in from tests/golden/rfc_hybrid_redundancy_seeds.json"""
     state = {}
 
     def pick(s, f, rng):
@@ -111,7 +115,7 @@ def test_rfc_configuration_switches(pkg, oracle, gpu_ctx, channels):
             state[s] = int(rng.integers(32))
         return state[s], int(rng.choice([0, 0, 0, 1, 2, 3]))
 
-    plan = {"streams": 384, "steps": 8, "pick": pick}
+    plan = {"streams": 384, "steps": 8, "pick": pick, "p_redundant": 0.06}
     assert _run(pkg, oracle, gpu_ctx, channels, plan, 77 + channels) > 384 * 5
 
 
@@ -127,7 +131,7 @@ def test_rfc_loss_path(pkg, oracle, gpu_ctx, channels):
             state[s] = int(rng.integers(32))
         return state[s], int(rng.choice([0, 0, 0, 1, 2, 3]))
 
-    plan = {"streams": 512, "steps": 10, "pick": pick}
+    plan = {"streams": 512, "steps": 10, "pick": pick, "p_redundant": 0.05}
     assert _run(pkg, oracle, gpu_ctx, channels, plan, 501 + channels, p_loss=0.3, p_dtx=0.06) > 512 * 7
 
 

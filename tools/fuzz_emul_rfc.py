@@ -4,14 +4,15 @@ mode (oc_decoder_set_rfc) -- all 32 TOC configurations, mono and stereo packets 
 0..3, configuration switches inside a stream (incl. hybrid -> SILK-only: the silence-frame fade-out), and the loss path: lost
 packets (concealed for the duration of the stream's last packet, like a caller of opus_decode(NULL) would ask) and DTX frames
 (at most one payload byte), and forward error correction: a third of the losses are not concealed when they happen but
-recovered from the NEXT packet's LBRR data (opus_decode(decode_fec = 1)), which is then decoded normally.
+recovered from the NEXT packet's LBRR data (opus_decode(decode_fec = 1)), which is then decoded normally.  Redundant CELT frames (RFC 6716 section 4.5.1): SILK-only frames with
+random payloads carry one almost always; hybrid packets with the flag set come from tests/golden/rfc_hybrid_redundancy_seeds.json.
     python3 tools/fuzz_emul_rfc.py [streams [packets per stream [seed [loss probability]]]]"""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_py
-from rfc_common import dur, mode_bw, make_packet, frame_payloads, same_pcm, fec_plan
+from rfc_common import dur, mode_bw, make_packet, frame_payloads, same_pcm, fec_plan, redundancy_packet
 o = oracle_py.load()
 lib = C.CDLL(os.environ.get("OG_EMUL_LIB", os.path.join(ROOT, "tests", "emul", "libog_emul.so")))
 lib.emu_state_size.restype = C.c_int
@@ -24,7 +25,7 @@ STREAMS = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 PACKETS = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 5)
 P_LOSS = float(sys.argv[4]) if len(sys.argv) > 4 else 0.2
-n = bad = frames = lost = fec_calls = fec_used = 0
+n = bad = frames = lost = fec_calls = fec_used = redundant = 0
 
 
 def run_frames(st, channels, payloads, fs, m, bw, pch):
@@ -64,6 +65,10 @@ for s in range(STREAMS):
             L = int(rng.choice([3, 8, 20, 40, 80, 120, 160, 300])) if rng.random() >= 0.08 else int(rng.integers(0, 2))  # (DTX frames)
             pkt = make_packet(rng, cfg, stereo, int(rng.choice([0, 0, 0, 1, 2, 3])), L)
             label = hex(pkt[0]) + ("/%d" % L if L < 2 else "")
+            if rng.random() < 0.06:  # a hybrid packet that carries a redundant CELT frame (random payloads almost never do)
+                pkt, kind = redundancy_packet(rng, channels if rng.random() < 0.85 else None)
+                stereo, label, L = bool(pkt[0] & 4), hex(pkt[0]) + ":" + kind, 99
+                redundant += 1
             if rng.random() < P_LOSS / 2 and frame_payloads(o, pkt) is not None:
                 # the packet before this one was lost and is recovered from this one's forward error correction data
                 fec_calls += 1
@@ -131,5 +136,5 @@ for s in range(STREAMS):
             if not stream_bad and bad <= 40:
                 print("MISMATCH stream", s, "packet", f, label, "channels", channels, r, r2, "last", last, "history", history)
             stream_bad = True
-print(f"{n} packets ({lost} lost, {fec_calls} recovered with decode_fec: {fec_used} from LBRR data), {frames} frames, {bad} mismatches")
+print(f"{n} packets ({lost} lost, {fec_calls} recovered with decode_fec: {fec_used} from LBRR data; {redundant} hybrid packets with redundancy), {frames} frames, {bad} mismatches")
 sys.exit(1 if bad else 0)

@@ -88,7 +88,7 @@ if RFC:
                     state[s] = int(rng.integers(32))
                 return state[s], int(rng.choice([0, 0, 0, 1, 2, 3]))
 
-            got = test_gpu_rfc._run(pkg, oracle, ctx, channels, {"streams": n, "steps": frames, "pick": pick},
+            got = test_gpu_rfc._run(pkg, oracle, ctx, channels, {"streams": n, "steps": frames, "pick": pick, "p_redundant": 0.04},
                                     seed * 1000 + 900 + rnd * 2 + channels, p_loss=0.25, p_dtx=0.06, p_fec=0.1)  # asserts on any mismatch
             total += got
             print(f"rfc round {rnd} channels {channels}: {got} packets with PCM compared (of {n * frames}), 0 mismatches, {time.time() - t_start:.0f} s", flush=True)
