@@ -202,7 +202,9 @@ class Ranks:
     def scatter_bytes(self, buffers=None, src=0):
         """The work-queue scatter: rank `src` passes one uint8 array per rank, every rank gets its own back -- as a numpy
         array (one rank, or a CPU backend) or as a uint8 tensor in this rank's HBM (nccl: the bytes travel GPU to GPU).
-        Two collectives: the sizes, then the buffers padded to the largest."""
+        One small collective for the sizes, then one point-to-point send per destination, each of the destination's exact
+        size: on the source's device only the buffer in flight and the next one (being copied up from pinned host memory)
+        exist at any time -- not one padded copy per rank, as a scatter collective of device tensors needs."""
         if self.dist is None:
             return buffers[0]
         import torch
@@ -211,23 +213,32 @@ class Ranks:
             if len(buffers) != self.world:
                 raise ValueError("one buffer per rank")
             all_sizes = [torch.tensor([b.size], dtype=torch.int64, device=self.device) for b in buffers]
-            cap = torch.tensor([max(b.size for b in buffers)], dtype=torch.int64, device=self.device)
         else:
             all_sizes = None
-            cap = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.dist.scatter(sizes, all_sizes, src=src)
-        self.dist.broadcast(cap, src=src)
-        cap = int(cap.item())
-        recv = torch.empty(cap, dtype=torch.uint8, device=self.device)
-        parts = None
+        n = int(sizes.item())
+        on_gpu = self.device is not None and self.device.type == "cuda"
+
+        def staged(b):  # the source's copy of one destination's buffer, where the backend can send it from
+            t = torch.from_numpy(np.ascontiguousarray(b, dtype=np.uint8))
+            return t.pin_memory().to(self.device, non_blocking=True) if on_gpu else t
+
         if self.rank == src:
-            parts = []
-            for b in buffers:
-                t = torch.zeros(cap, dtype=torch.uint8)
-                t[:b.size] = torch.from_numpy(np.ascontiguousarray(b))
-                parts.append(t.to(self.device))
-        self.dist.scatter(recv, parts, src=src)
-        recv = recv[:int(sizes.item())]
+            in_flight = []
+            for dst, b in enumerate(buffers):
+                if dst == src or b.size == 0:
+                    continue
+                t = staged(b)
+                in_flight.append((self.dist.isend(t, dst), t))
+                if len(in_flight) > 1:  # at most two destinations' buffers on the device
+                    in_flight.pop(0)[0].wait()
+            for w, _ in in_flight:
+                w.wait()
+            recv = staged(buffers[src])
+        else:
+            recv = torch.empty(n, dtype=torch.uint8, device=self.device)
+            if n:
+                self.dist.recv(recv, src=src)
         return recv.numpy() if recv.device.type == "cpu" else recv
 
     def close(self):
