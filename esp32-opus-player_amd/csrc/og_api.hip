@@ -501,6 +501,11 @@ struct opusgpu_ctx {
     size_t cap_h_pcm = 0, cap_h_res = 0;
     u32 *d_crc_tables = nullptr; // 8 x 256 words, made on first use (opusgpu_pages_crc_device)
     hipEvent_t ev_piece[OPUSGPU_COPY_PIECES] = {}; // one per piece of the PCM's way back to the host (opusgpu_decode_packets)
+    // large batches on the host-buffer path run in parts: a part's PCM travels back (on a stream of its own) while the next
+    // part's kernels run
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_part[OPUSGPU_COPY_PIECES] = {};
+    int host_parts = 2; // OPUSGPU_HOST_PARTS=1: one batch, copy after the kernels (A/B measurements); 2, 4, 8, 16
     // parse records of the split CELT path (one per frame of a step), grown on demand
     void *d_recs = nullptr, *d_handoff = nullptr, *d_srecs = nullptr;
     size_t cap_recs = 0, cap_handoff = 0, cap_srecs = 0;
@@ -562,6 +567,10 @@ int opusgpu_ctx_create(int device, opusgpu_ctx **out) {
     if (const char *e = getenv("OPUSGPU_SPLIT")) ctx->split_celt = e[0] != '0';
     if (const char *e = getenv("OPUSGPU_SPLIT_HYBRID")) ctx->split_hybrid = e[0] != '0';
     if (const char *e = getenv("OPUSGPU_FAST_RECON")) ctx->fast_recon = e[0] != '0';
+    if (const char *e = getenv("OPUSGPU_HOST_PARTS")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ctx->host_parts = v;
+    }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return OPUSGPU_ERR_HIP;
@@ -587,6 +596,9 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     (void)hipFree(ctx->d_crc_tables);
     for (hipEvent_t e : ctx->ev_piece)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_part)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -932,16 +944,18 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
     //    packet) descriptors and packet bytes.
     HostPhaseTimer timer;
     const int host_threads = n >= 4096 ? 8 : 1;
-    auto on_ranges = [&](auto &&f) { // f(lo, hi) over [0, n)
-        if (host_threads == 1) {
-            f(0, n);
+    auto on_subranges = [&](int from, int to, auto &&f) { // f(lo, hi) over [from, to), on the host threads
+        if (host_threads == 1 || to - from < 1024) {
+            f(from, to);
             return;
         }
         std::vector<std::thread> th;
+        const int64_t w = to - from;
         for (int t = 0; t < host_threads; t++)
-            th.emplace_back(f, (int)((int64_t)n * t / host_threads), (int)((int64_t)n * (t + 1) / host_threads));
+            th.emplace_back(f, from + (int)(w * t / host_threads), from + (int)(w * (t + 1) / host_threads));
         for (auto &x : th) x.join();
     };
+    auto on_ranges = [&](auto &&f) { on_subranges(0, n, f); };
     std::vector<int> first(n + 1, 0), nframes(n, 0);
     std::vector<uint8_t> is_lost(rfc ? n : 0, 0);
     on_ranges([&](int lo, int hi) {
@@ -1021,7 +1035,7 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
     if (base[n] > 0x7fffffffu) return OPUSGPU_BAD_ARG; // descriptor offsets are 32-bit: split the call
     std::unique_ptr<opusgpu_frame_desc[]> all(new opusgpu_frame_desc[first[n]]); // frames in (packet, frame) order
     std::unique_ptr<uint8_t[]> arena(new uint8_t[base[n] + 1]);
-    on_ranges([&](int lo, int hi) {
+    auto place = [&](int lo, int hi) { // framing pass 2: descriptors and packet bytes of packets [lo, hi) to their places
         for (int i = lo; i < hi; i++) {
             if (!nframes[i]) continue;
             if (rfc && is_lost[i] == 1) { // nothing to read: len 0, the flags of the stream's last packet (RFC bit and duration included)
@@ -1057,55 +1071,114 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
                 all[first[i] + k] = d[k];
             }
         }
-    });
-    timer.mark("prefix + framing pass 2 (place)");
-    // 2. upload the arena once; run one step per frame index (frames of one packet are sequential)
+    };
+    // The common large call -- one frame per packet -- is pipelined: the frames in packet order ARE the step table, so the call
+    // goes in parts of packets, each placed (pass 2), uploaded and launched while the device works on the part before it and that
+    // part's PCM travels back.  Anything else: everything placed and uploaded first, then one step per frame index.
+    const bool pipelined = max_frames == 1 && first[n] >= 4096 && ctx->host_parts > 1 && !timer.on;
     int rc = grow(ctx, &ctx->d_arena, &ctx->cap_arena, base[n] + 16);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_arena, arena.get(), base[n], hipMemcpyHostToDevice, ctx->stream));
-    timer.mark("arena upload (enqueue)");
+    if (!pipelined) {
+        on_ranges(place);
+        timer.mark("prefix + framing pass 2 (place)");
+        // 2. upload the arena once; run one step per frame index (frames of one packet are sequential)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_arena, arena.get(), base[n], hipMemcpyHostToDevice, ctx->stream));
+        timer.mark("arena upload (enqueue)");
+    }
     std::vector<opusgpu_frame_desc> step;
     std::vector<int> owner;
     std::vector<int32_t> placed(rfc ? n : 0, 0); // RFC mode: samples of packet i delivered so far (frames may differ in duration)
     for (int k = 0; k < max_frames; k++) {
         step.clear();
         owner.clear();
-        for (int i = 0; i < n; i++)
-            if (nframes[i] > k && result[i] >= 0) {
-                step.push_back(all[first[i] + k]);
-                owner.push_back(i);
-            }
-        const int m = (int)step.size();
+        if (pipelined) {
+            owner.reserve(first[n]);
+            for (int i = 0; i < n; i++)
+                if (nframes[i]) owner.push_back(i);
+        } else
+            for (int i = 0; i < n; i++)
+                if (nframes[i] > k && result[i] >= 0) {
+                    step.push_back(all[first[i] + k]);
+                    owner.push_back(i);
+                }
+        const int m = (int)owner.size();
         if (m == 0) break;
         timer.mark("step table");
         if ((rc = grow(ctx, &ctx->d_descs, &ctx->cap_descs, sizeof(opusgpu_frame_desc) * m))) return rc;
         if ((rc = grow(ctx, &ctx->d_pcm, &ctx->cap_pcm, frame_pcm * 2 * m))) return rc;
         if ((rc = grow(ctx, &ctx->d_result, &ctx->cap_result, sizeof(int32_t) * m))) return rc;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_descs, step.data(), sizeof(opusgpu_frame_desc) * m, hipMemcpyHostToDevice,
-                                   ctx->stream));
-        rc = opusgpu_decode_step_device(ctx, m, ctx->d_descs, ctx->d_arena, ctx->d_pcm, ctx->d_result, nullptr);
-        if (rc) return rc;
-        timer.mark("table upload + kernels (enqueue)");
-        if (timer.on) {
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            timer.mark("kernels (wait)");
-        }
+        if (!pipelined)
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_descs, step.data(), sizeof(opusgpu_frame_desc) * m, hipMemcpyHostToDevice,
+                                       ctx->stream));
         if ((rc = grow_pinned(ctx, &ctx->h_pcm, &ctx->cap_h_pcm, frame_pcm * 2 * m))) return rc;
         if ((rc = grow_pinned(ctx, &ctx->h_res, &ctx->cap_h_res, sizeof(int32_t) * m))) return rc;
         const int16_t *h_pcm = (const int16_t *)ctx->h_pcm;
         const int32_t *h_res = (const int32_t *)ctx->h_res;
-        // 3. results and PCM back to the host.  The PCM comes in pieces, each followed by an event: every packet owns
-        //    its own block of the caller's buffer, and the threads that fill the blocks start on a piece as soon as it has
-        //    landed, while the later pieces are still on their way.
+        // 3. kernels, then results and PCM back to the host.  The PCM comes in pieces, each followed by an event: every packet
+        //    owns its own block of the caller's buffer, and the threads that fill the blocks start on a piece as soon as it has
+        //    landed, while the later pieces are still on their way.  A large batch goes in parts: a part's pieces travel (on the
+        //    copy stream) while the next part's kernels run.  More parts start the copy earlier but pay the parse kernels' fixed
+        //    latency once per part: two is the measured optimum at 65,536 frames (9.5 ms; one 11.8, four 10.7, eight 13.2).
         const int pieces = m >= 4096 ? OPUSGPU_COPY_PIECES : 1;
+        const int parts = (pieces > 1 && !timer.on) ? ctx->host_parts : 1;
         for (int t = 0; t < pieces; t++)
             if (!ctx->ev_piece[t]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_piece[t], hipEventDisableTiming));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_res, ctx->d_result, sizeof(int32_t) * m, hipMemcpyDeviceToHost, ctx->stream));
-        for (int t = 0; t < pieces; t++) {
-            const size_t lo = (size_t)((int64_t)m * t / pieces), hi = (size_t)((int64_t)m * (t + 1) / pieces);
-            HIPCHK(ctx, hipMemcpyAsync((uint8_t *)ctx->h_pcm + lo * frame_pcm * 2, (const uint8_t *)ctx->d_pcm + lo * frame_pcm * 2,
-                                       (hi - lo) * frame_pcm * 2, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipEventRecord(ctx->ev_piece[t], ctx->stream));
+        // frames [bound[t], bound[t + 1]) make piece t; a part is pieces / parts consecutive pieces.  Pipelined: a part is a range
+        // of PACKETS (its frames: first[] of the range's ends), cut evenly into its pieces.
+        size_t bound[OPUSGPU_COPY_PIECES + 1];
+        for (int h = 0; h < parts; h++) {
+            const int t0 = h * pieces / parts, t1 = (h + 1) * pieces / parts;
+            const size_t flo = pipelined ? (size_t)first[(int64_t)n * h / parts] : (size_t)((int64_t)m * t0 / pieces);
+            const size_t fhi = pipelined ? (size_t)first[(int64_t)n * (h + 1) / parts] : (size_t)((int64_t)m * t1 / pieces);
+            for (int t = t0; t <= t1; t++) bound[t] = flo + (size_t)((int64_t)(fhi - flo) * (t - t0) / (t1 - t0));
+        }
+        auto piece_lo = [&](int t) { return bound[t]; };
+        auto copy_pieces = [&](hipStream_t cs, int t0, int t1) -> int { // results of the pieces' frames first, then the pieces
+            const size_t flo = piece_lo(t0), fhi = piece_lo(t1);
+            HIPCHK(ctx, hipMemcpyAsync((int32_t *)ctx->h_res + flo, (const int32_t *)ctx->d_result + flo, sizeof(int32_t) * (fhi - flo),
+                                       hipMemcpyDeviceToHost, cs));
+            for (int t = t0; t < t1; t++) {
+                const size_t lo = piece_lo(t), hi = piece_lo(t + 1);
+                HIPCHK(ctx, hipMemcpyAsync((uint8_t *)ctx->h_pcm + lo * frame_pcm * 2, (const uint8_t *)ctx->d_pcm + lo * frame_pcm * 2,
+                                           (hi - lo) * frame_pcm * 2, hipMemcpyDeviceToHost, cs));
+                HIPCHK(ctx, hipEventRecord(ctx->ev_piece[t], cs));
+            }
+            return OPUSGPU_OK;
+        };
+        if (parts > 1) {
+            if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            for (int h = 0; h < parts; h++)
+                if (!ctx->ev_part[h]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_part[h], hipEventDisableTiming));
+            for (int h = 0; h < parts; h++) {
+                const int t0 = h * pieces / parts, t1 = (h + 1) * pieces / parts;
+                const size_t flo = piece_lo(t0), fhi = piece_lo(t1);
+                if (pipelined) { // this part's packets: place, upload
+                    const int plo = (int)((int64_t)n * h / parts), phi = (int)((int64_t)n * (h + 1) / parts);
+                    on_subranges(plo, phi, place);
+                    if (base[phi] > base[plo])
+                        HIPCHK(ctx, hipMemcpyAsync((uint8_t *)ctx->d_arena + base[plo], arena.get() + base[plo], base[phi] - base[plo],
+                                                   hipMemcpyHostToDevice, ctx->stream));
+                    if (fhi > flo)
+                        HIPCHK(ctx, hipMemcpyAsync((opusgpu_frame_desc *)ctx->d_descs + flo, all.get() + flo,
+                                                   sizeof(opusgpu_frame_desc) * (fhi - flo), hipMemcpyHostToDevice, ctx->stream));
+                }
+                rc = opusgpu_decode_step_device(ctx, (int)(fhi - flo), (const opusgpu_frame_desc *)ctx->d_descs + flo, ctx->d_arena,
+                                                (uint8_t *)ctx->d_pcm + flo * frame_pcm * 2, (int32_t *)ctx->d_result + flo, nullptr);
+                if (rc) return rc; // (an empty part launches nothing; its pieces' events are still recorded below)
+                HIPCHK(ctx, hipEventRecord(ctx->ev_part[h], ctx->stream));
+                HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_part[h], 0));
+                if ((rc = copy_pieces(ctx->copy_stream, t0, t1))) return rc;
+            }
+            timer.mark("table upload + kernels + copy-back in parts (enqueue)");
+        } else {
+            rc = opusgpu_decode_step_device(ctx, m, ctx->d_descs, ctx->d_arena, ctx->d_pcm, ctx->d_result, nullptr);
+            if (rc) return rc;
+            timer.mark("table upload + kernels (enqueue)");
+            if (timer.on) {
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                timer.mark("kernels (wait)");
+            }
+            if ((rc = copy_pieces(ctx->stream, 0, pieces))) return rc;
         }
         timer.mark("copy-back (enqueue)");
         // every thread takes its share of every piece: the work left when the last piece lands is 1 / pieces of the PCM,
@@ -1116,7 +1189,7 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
             thread_err[t] = hipSuccess;
             for (int p = 0; p < pieces; p++) {
                 if ((thread_err[t] = hipEventSynchronize(ctx->ev_piece[p])) != hipSuccess) return;
-                const int64_t plo = (int64_t)m * p / pieces, phi = (int64_t)m * (p + 1) / pieces;
+                const int64_t plo = (int64_t)bound[p], phi = (int64_t)bound[p + 1];
                 const int lo = (int)(plo + (phi - plo) * t / threads), hi = (int)(plo + (phi - plo) * (t + 1) / threads);
                 for (int j = lo; j < hi; j++) {
                     const int i = owner[j];
