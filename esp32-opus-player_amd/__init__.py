@@ -20,7 +20,7 @@ FRAME = 960
 EXPORTS = [
     "opusgpu_version", "opusgpu_ctx_create", "opusgpu_ctx_destroy", "opusgpu_last_error",
     "opusgpu_streams_alloc", "opusgpu_streams_reset", "opusgpu_stream_count", "opusgpu_stream_channels",
-    "opusgpu_stream_state_bytes", "opusgpu_decode_packets", "opusgpu_decode_packets_fec", "opusgpu_packet_to_frames",
+    "opusgpu_stream_state_bytes", "opusgpu_debug_stage_taps", "opusgpu_decode_packets", "opusgpu_decode_packets_fec", "opusgpu_packet_to_frames",
     "opusgpu_dev_alloc", "opusgpu_dev_free", "opusgpu_memcpy_h2d", "opusgpu_memcpy_d2h",
     "opusgpu_decode_step_device", "opusgpu_synchronize", "opusgpu_event_create", "opusgpu_event_record",
     "opusgpu_event_elapsed_ms", "opusgpu_event_destroy", "opusgpu_stream_state_get",
@@ -37,6 +37,25 @@ class OutputCfg(C.Structure):
 
 
 OUTPUT_CFG_DTYPE = np.dtype([("volume", "u1"), ("force_mono", "u1"), ("bits", "u1"), ("channels", "u1")])
+
+
+class _SilkChTaps(C.Structure):
+    _fields_ = [("pitchL", C.c_int32 * 4), ("Gains_Q16", C.c_int32 * 4), ("PredCoef_Q12", (C.c_int16 * 16) * 2),
+                ("LTPCoef_Q14", C.c_int16 * 20), ("LTP_scale_Q14", C.c_int32), ("signalType", C.c_int32), ("quantOffsetType", C.c_int32)]
+
+
+class StageTaps(C.Structure):
+    """opusgpu_stage_taps (include/opusgpu.h): what the kernels of the last decode step left between the stages."""
+    _fields_ = [("celt_valid", C.c_int32), ("celt_ret", C.c_int32), ("silence", C.c_int32), ("transient", C.c_int32), ("lm", C.c_int32),
+                ("spread", C.c_int32), ("dual_stereo", C.c_int32), ("anti_collapse_on", C.c_int32), ("intensity", C.c_int32),
+                ("pf_pitch", C.c_int32), ("pf_gain", C.c_int32), ("pf_tapset", C.c_int32), ("n_leaves", C.c_int32),
+                ("celt_rng_final", C.c_uint32), ("bandE", C.c_int16 * 42), ("pulses", C.c_int16 * 21), ("tf_res", C.c_int8 * 21),
+                ("pad0", C.c_int8 * 3), ("syn_post", (C.c_int32 * 960) * 2), ("overlap_tail", (C.c_int32 * 60) * 2),
+                ("state_bandE", C.c_int16 * 42), ("state_logE1", C.c_int16 * 42), ("state_logE2", C.c_int16 * 42), ("pad1", C.c_int16),
+                ("state_rng", C.c_uint32), ("pf_period", C.c_int32), ("pf_gain_state", C.c_int32), ("pf_tapset_state", C.c_int32),
+                ("silk_valid", C.c_int32), ("silk_ret", C.c_int32), ("decode_only_middle", C.c_int32), ("ms_pred_q13", C.c_int32 * 2),
+                ("silk_ch", _SilkChTaps * 2), ("silk_out", (C.c_int16 * 320) * 2), ("silk_sLPC_Q14", (C.c_int32 * 16) * 2),
+                ("silk_fs_kHz", C.c_int32 * 2)]
 
 
 class FrameDesc(C.Structure):
@@ -92,6 +111,7 @@ def load_lib():
     lib.opusgpu_event_elapsed_ms.argtypes = [vp, vp, vp, C.POINTER(C.c_float)]
     lib.opusgpu_event_destroy.argtypes = [vp, vp]
     lib.opusgpu_stream_state_get.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.opusgpu_debug_stage_taps.argtypes = [vp, C.c_int, vp]
     lib.opusgpu_pages_demux.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     lib.opusgpu_page_batch_steps.argtypes = [vp]
     lib.opusgpu_page_batch_step.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
@@ -309,6 +329,12 @@ class Context:
 
     def d2h(self, arr, dptr):
         self._chk(self.lib.opusgpu_memcpy_d2h(self.h, arr.ctypes.data, dptr, arr.nbytes), "opusgpu_memcpy_d2h")
+
+    def debug_stage_taps(self, slot):
+        """Stage taps of slot `slot` of the last decode_step_device call (test / debug entry, include/opusgpu.h)."""
+        t = StageTaps()
+        self._chk(self.lib.opusgpu_debug_stage_taps(self.h, slot, C.byref(t)), "opusgpu_debug_stage_taps")
+        return t
 
     def decode_step_device(self, n, d_descs, d_arena, d_pcm, d_result, stream=None):
         self._chk(self.lib.opusgpu_decode_step_device(self.h, n, d_descs, d_arena, d_pcm, d_result, stream),

@@ -513,6 +513,9 @@ struct opusgpu_ctx {
     int split_hybrid = 1; // OPUSGPU_SPLIT_HYBRID=0 keeps SILK-only and hybrid frames entirely on the single-kernel path
     int fast_recon = 1;   // OPUSGPU_FAST_RECON=0: every CELT frame through the general reconstruction kernel (A/B measurements)
     int mode = OPUSGPU_MODE_REFERENCE; // opusgpu_set_mode
+    // the last decode step's tables, for opusgpu_debug_stage_taps
+    const void *last_descs = nullptr;
+    int last_n = 0, last_had_silk_recs = 0;
     // RFC mode, host side of the loss path: per stream, the frame count and descriptor flags of the last packet framed by
     // opusgpu_decode_packets -- what a lost packet of that stream is concealed as (0 frames: nothing framed yet)
     std::vector<int32_t> last_count, last_flags;
@@ -681,6 +684,9 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
     if (!d_descs || !d_arena || !d_pcm || !d_result) return OPUSGPU_BAD_ARG;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
     const int pcm_stride = (ctx->mode == OPUSGPU_MODE_RFC ? OPUSGPU_RFC_FRAME_SAMPLES : OPUSGPU_FRAME_SAMPLES) * ctx->channels;
+    ctx->last_descs = d_descs;
+    ctx->last_n = ctx->mode == OPUSGPU_MODE_RFC || !ctx->split_celt ? 0 : n;
+    ctx->last_had_silk_recs = ctx->split_celt && ctx->split_hybrid;
     if (ctx->mode == OPUSGPU_MODE_RFC) { // every frame on the one kernel of that mode (og_rfc.hip)
         HIPCHK(ctx, hipSetDevice(ctx->device));
         og_launch_decode_rfc(s, d_descs, d_arena, ctx->d_streams, d_pcm, d_result, n, ctx->n_streams, pcm_stride);
@@ -860,6 +866,80 @@ int opusgpu_event_destroy(opusgpu_ctx *ctx, void *event) {
 int opusgpu_stream_state_get(opusgpu_ctx *ctx, int index, void *dst, size_t bytes) {
     if (!ctx || !dst || index < 0 || index >= ctx->n_streams || bytes > sizeof(StreamState)) return OPUSGPU_BAD_ARG;
     return opusgpu_memcpy_d2h(ctx, dst, &ctx->d_streams[index], bytes);
+}
+
+int opusgpu_debug_stage_taps(opusgpu_ctx *ctx, int slot, opusgpu_stage_taps *out) {
+    if (!ctx || !out || slot < 0 || slot >= ctx->last_n || !ctx->last_descs) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memset(out, 0, sizeof(*out));
+    FrameDesc d;
+    HIPCHK(ctx, hipMemcpy(&d, (const FrameDesc *)ctx->last_descs + slot, sizeof(d), hipMemcpyDeviceToHost));
+    if (d.stream < 0 || d.stream >= ctx->n_streams) return OPUSGPU_BAD_ARG;
+    const int mode = MODE_SILK + (d.flags & 3);
+    std::unique_ptr<StreamState> st(new (std::nothrow) StreamState);
+    if (!st) return OPUSGPU_ALLOC_FAIL;
+    HIPCHK(ctx, hipMemcpy(st.get(), &ctx->d_streams[d.stream], sizeof(StreamState), hipMemcpyDeviceToHost));
+    if (mode != MODE_SILK && ctx->d_recs) {
+        std::unique_ptr<ParseRec> r(new (std::nothrow) ParseRec);
+        if (!r) return OPUSGPU_ALLOC_FAIL;
+        HIPCHK(ctx, hipMemcpy(r.get(), (const ParseRec *)ctx->d_recs + slot, sizeof(ParseRec), hipMemcpyDeviceToHost));
+        out->celt_valid = 1;
+        out->celt_ret = r->ret;
+        out->silence = (r->flags & RF_SILENCE) != 0;
+        out->transient = (r->flags & RF_TRANSIENT) != 0;
+        out->lm = (int)(r->flags >> RF_LM_SHIFT) & 3;
+        out->spread = (int)(r->flags >> RF_SPREAD_SHIFT) & 3;
+        out->dual_stereo = (r->flags & RF_DUAL) != 0;
+        out->anti_collapse_on = (r->flags & RF_ANTI_COLLAPSE) != 0;
+        out->intensity = r->intensity;
+        out->pf_pitch = r->pf_pitch;
+        out->pf_gain = r->pf_gain;
+        out->pf_tapset = r->pf_tapset;
+        out->n_leaves = r->n_leaves;
+        out->celt_rng_final = r->rng_final;
+        memcpy(out->bandE, r->bandE, sizeof(out->bandE));
+        memcpy(out->pulses, r->pulses, sizeof(out->pulses));
+        memcpy(out->tf_res, r->tf_res, sizeof(out->tf_res));
+    }
+    const CeltState &c = st->celt;
+    for (int ch = 0; ch < 2; ch++) {
+        for (int i = 0; i < 960; i++) out->syn_post[ch][i] = c.ring[ch][(c.ring_pos - 960 + i) & RING_MASK];
+        for (int i = 0; i < 60; i++) out->overlap_tail[ch][i] = c.tail[ch][i];
+    }
+    memcpy(out->state_bandE, c.bandE, sizeof(out->state_bandE));
+    memcpy(out->state_logE1, c.logE1, sizeof(out->state_logE1));
+    memcpy(out->state_logE2, c.logE2, sizeof(out->state_logE2));
+    out->state_rng = c.rng;
+    out->pf_period = c.pf_period;
+    out->pf_gain_state = c.pf_gain;
+    out->pf_tapset_state = c.pf_tapset;
+    if (mode != MODE_CELT && ctx->last_had_silk_recs && ctx->d_srecs) {
+        std::unique_ptr<SilkRec> r(new (std::nothrow) SilkRec);
+        if (!r) return OPUSGPU_ALLOC_FAIL;
+        HIPCHK(ctx, hipMemcpy(r.get(), (const SilkRec *)ctx->d_srecs + slot, sizeof(SilkRec), hipMemcpyDeviceToHost));
+        out->silk_valid = 1;
+        out->silk_ret = r->ret;
+        out->decode_only_middle = r->decode_only_middle;
+        out->ms_pred_q13[0] = r->MS_pred_Q13[0];
+        out->ms_pred_q13[1] = r->MS_pred_Q13[1];
+        for (int ch = 0; ch < 2; ch++) {
+            const SilkRecCh &k = r->ch[ch];
+            memcpy(out->silk_ch[ch].pitchL, k.pitchL, sizeof(k.pitchL));
+            memcpy(out->silk_ch[ch].Gains_Q16, k.Gains_Q16, sizeof(k.Gains_Q16));
+            memcpy(out->silk_ch[ch].PredCoef_Q12, k.PredCoef_Q12, sizeof(k.PredCoef_Q12));
+            memcpy(out->silk_ch[ch].LTPCoef_Q14, k.LTPCoef_Q14, sizeof(k.LTPCoef_Q14));
+            out->silk_ch[ch].LTP_scale_Q14 = k.LTP_scale_Q14;
+            out->silk_ch[ch].signalType = k.signalType;
+            out->silk_ch[ch].quantOffsetType = k.quantOffsetType;
+        }
+    }
+    for (int ch = 0; ch < 2; ch++) {
+        memcpy(out->silk_out[ch], st->silk.ch[ch].outBuf, sizeof(out->silk_out[ch]));
+        memcpy(out->silk_sLPC_Q14[ch], st->silk.ch[ch].sLPC_Q14_buf, sizeof(out->silk_sLPC_Q14[ch]));
+        out->silk_fs_kHz[ch] = st->silk.ch[ch].fs_kHz;
+    }
+    return OPUSGPU_OK;
 }
 
 int opusgpu_packet_to_frames(const uint8_t *packet, int32_t len, int32_t stream, opusgpu_frame_desc descs[48]) {

@@ -158,6 +158,42 @@ int opusgpu_event_destroy(opusgpu_ctx *ctx, void *event);
 /* Copies stream `index`'s raw state record to the host (tests / checkpointing). */
 int opusgpu_stream_state_get(opusgpu_ctx *ctx, int index, void *dst, size_t bytes);
 
+/* TEST / DEBUG ENTRY: what the kernels of the last opusgpu_decode_step_device call (reference mode, split path) left BETWEEN
+ * the stages, for slot `slot` of that step and the stream it belongs to -- so that a parity test can tell which kernel a
+ * difference comes from instead of seeing it only in the PCM (tests/test_gpu_stage_taps.py compares every field with the
+ * oracle's taps).  Synchronises the context's stream. */
+typedef struct opusgpu_stage_taps {
+    /* k_celt_parse's record (CELT-only and hybrid frames; celt_valid = 0 otherwise): the frame's header as parsed */
+    int32_t celt_valid, celt_ret, silence, transient, lm, spread, dual_stereo, anti_collapse_on, intensity, pf_pitch, pf_gain,
+        pf_tapset, n_leaves;
+    uint32_t celt_rng_final;
+    int16_t bandE[42];   /* final band energies (coarse + fine + finalise), both channels */
+    int16_t pulses[21];
+    int8_t tf_res[21];
+    int8_t pad0[3];
+    /* k_celt_recon / k_celt_recon_fb: the stream's state after the step -- the frame's synthesis output after the comb filter
+     * (the newest 960 samples of the history ring), the IMDCT overlap tail carried to the next frame, energies, rng */
+    int32_t syn_post[2][960];
+    int32_t overlap_tail[2][60];
+    int16_t state_bandE[42], state_logE1[42], state_logE2[42], pad1;
+    uint32_t state_rng;
+    int32_t pf_period, pf_gain_state, pf_tapset_state;
+    /* k_silk_parse's record (SILK-only and hybrid frames; silk_valid = 0 otherwise): dequantised parameters per coded channel */
+    int32_t silk_valid, silk_ret, decode_only_middle, ms_pred_q13[2];
+    struct {
+        int32_t pitchL[4], Gains_Q16[4];
+        int16_t PredCoef_Q12[2][16];
+        int16_t LTPCoef_Q14[20];
+        int32_t LTP_scale_Q14, signalType, quantOffsetType;
+    } silk_ch[2];
+    /* k_silk_synth: the channels' state after the step -- the synthesis core's output at the internal rate (for 20 ms frames
+     * the output history IS the frame), the LPC state */
+    int16_t silk_out[2][320];
+    int32_t silk_sLPC_Q14[2][16];
+    int32_t silk_fs_kHz[2];
+} opusgpu_stage_taps;
+int opusgpu_debug_stage_taps(opusgpu_ctx *ctx, int slot, opusgpu_stage_taps *out);
+
 /* ---- Ogg page ingest at scale (host only, no GPU involved) --------------------------------------
  * The batched equivalent of what the reference does one page at a time: page sync + header checks
  * (ogg_sync_pageseek src/ogg.cpp:839-923), the page CRC (ogg_page_checksum_set :439-480), lacing values -> packets

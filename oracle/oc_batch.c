@@ -81,11 +81,22 @@ int oc_taps_enable(oc_decoder *d) {
     if (!d->taps) d->taps = (oc_celt_taps *)calloc(1, sizeof(oc_celt_taps));
     return d->taps != NULL;
 }
-/* what: 0 = X (i16[1920]), 1 = bandE (i16[42]), 2 = syn_pre ch c (i32[1080]), 3 = syn_post ch c (i32[960]) */
+/* what: 0 = X (i16[1920]), 1 = bandE (i16[42]), 2 = syn_pre ch c (i32[1080]), 3 = syn_post ch c (i32[960]),
+ * 4 = the frame's header as i32[75]: {is_transient, silence, coded_bands, intensity, dual_stereo, spread, LM, pf_pitch, pf_gain,
+ * pf_tapset, anti_collapse_on, rng after the frame} then pulses[21], fine_quant[21], tf_res[21] */
 int oc_taps_copy(const oc_decoder *d, int what, int c, void *dst) {
     const oc_celt_taps *t = d->taps;
     if (!t || !t->valid) return -1;
     switch (what) {
+        case 4: {
+            i32 v[75] = {t->is_transient, t->silence, t->coded_bands, t->intensity, t->dual_stereo, t->spread, t->LM, t->pf_pitch,
+                         t->pf_gain, t->pf_tapset, t->anti_collapse_on, (i32)t->rc_rng_end};
+            memcpy(v + 12, t->pulses, sizeof(t->pulses));
+            memcpy(v + 33, t->fine_quant, sizeof(t->fine_quant));
+            memcpy(v + 54, t->tf_res, sizeof(t->tf_res));
+            memcpy(dst, v, sizeof(v));
+            return (int)sizeof(v);
+        }
         case 0: memcpy(dst, t->X, sizeof(t->X)); return (int)sizeof(t->X);
         case 1: memcpy(dst, t->bandE, sizeof(t->bandE)); return (int)sizeof(t->bandE);
         case 2: memcpy(dst, t->syn_pre[c], sizeof(t->syn_pre[c])); return (int)sizeof(t->syn_pre[c]);
