@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(64, 2) k_celt_parse(const FrameDesc *__restric
 // Split CELT path, second half: one frame per wave, driven by the parse record.
 // (20 ms CELT-only frames are reconstructed by k_celt_recon_fb, og_recon.hip; `rest_only`: skip what that kernel took)
 extern "C" void og_launch_celt_recon_fb(hipStream_t s, const void *descs, void *streams, const void *recs, void *result, int n,
-                                        int n_streams);
+                                        int n_streams, int hybrid);
 // RFC mode (opt-in): every frame of a step, at its true duration, incl. the loss path (og_rfc.hip)
 extern "C" void og_launch_decode_rfc(hipStream_t s, const void *descs, const void *arena, void *streams, void *pcm, void *result, int n,
                                      int n_streams, int pcm_stride);
@@ -748,7 +748,7 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
     if (ctx->split_celt) {
         // reconstruct (one frame per wave) -> de-emphasis, SILK mix and PCM (one (frame, channel) per lane)
         if (ctx->fast_recon)
-            og_launch_celt_recon_fb(s, d_descs, ctx->d_streams, ctx->d_recs, d_result, n, ctx->n_streams);
+            og_launch_celt_recon_fb(s, d_descs, ctx->d_streams, ctx->d_recs, d_result, n, ctx->n_streams, handoff ? 1 : 0);
         hipLaunchKernelGGL(k_celt_recon, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, ctx->d_streams,
                            (const ParseRec *)ctx->d_recs, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride,
                            handoff ? 1 : 0, ctx->fast_recon);

@@ -118,6 +118,7 @@ OG_LDS ParseLds PL;
 // LDS copy of the entropy-decoding ROM tables (see RomGlobal, og_celt_bands.hpp), loaded once per workgroup
 struct ParseTabLds {
     i32 eband[NBANDS + 1], logn[NBANDS], pulse_idx[105];
+    u32 pulse_v[392]; // size of the PVQ codebook a leaf's index is decoded against, by pulse-cache index (rom_pulse_v)
     u8 pulse_bits[392], band_alloc[231], pulse_caps[168], log2_frac[24], eprob[336];
 };
 OG_LDS ParseTabLds PT;
@@ -137,6 +138,7 @@ OG_DEV void parse_tables_load() {
     OG_FOR_LANES(i, NBANDS) PT.logn[i] = rom_logn[i];
     OG_FOR_LANES(i, 105) PT.pulse_idx[i] = rom_pulse_idx[i];
     OG_FOR_LANES(i, 392) PT.pulse_bits[i] = rom_pulse_bits[i];
+    OG_FOR_LANES(i, 392) PT.pulse_v[i] = rom_pulse_v[i];
     OG_FOR_LANES(i, 231) PT.band_alloc[i] = rom_band_alloc[i];
     OG_FOR_LANES(i, 168) PT.pulse_caps[i] = rom_pulse_caps[i];
     OG_FOR_LANES(i, 24) PT.log2_frac[i] = rom_log2_frac[i];
@@ -257,8 +259,8 @@ OG_DEV int parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits,
             }
             const int K = q ? get_pulses(q) : 0;
             OG_MARK(43);
-            if (K)
-                out.leaf(x, N, K, B, gain, off, rc_uint(rc, pvq_u_rom(N, K) + pvq_u_rom(N, K + 1)));
+            if (K) // V(N, K) = U(N, K) + U(N, K + 1) (celt.cpp:2622), found next to the cache entry that gave q
+                out.leaf(x, N, K, B, gain, off, rc_uint(rc, PT.pulse_v[pulse_cache<RomLds>(band, LM) + q]));
             else if (!silent) { // (a silent leaf stays zero, as the spectrum was initialised: nothing to record)
                 out.word((u32)off << LW_OFF_SHIFT | (u32)(B - 1) << LW_B_SHIFT | (u32)N << LW_N_SHIFT);
                 out.word((u32)x | (u32)(gain & 0xffff) << 11);
@@ -1241,7 +1243,8 @@ OG_DEV PmGrp pm_group(int g) { // group g of the coded spectrum: 0..99 first cha
 
 // B: one lane per (band, decode slot).  Returns (wave-uniform) which time-frequency passes some job needs: bit 0 the
 // interleave, bit 1 + 4 k + c the Haar stride 1 << c at step k; fill_lo / fill_hi: the jobs phase D has to run.
-OG_DEV u32 pm_setup_jobs(const ParseRec *rec, int C, int B, u32 &fill_lo, u32 &fill_hi, int &dual_end) {
+// (`start`: the frame's first band -- 17 for the CELT layer of a hybrid frame; the bands below it have no words in the record)
+OG_DEV u32 pm_setup_jobs(const ParseRec *rec, int C, int B, u32 &fill_lo, u32 &fill_hi, int &dual_end, int start = 0) {
     PmLds &P = PM();
     OG_SYNC();
     OG_FOR_LANES(bin, PM_GROUPS) {
@@ -1258,12 +1261,12 @@ OG_DEV u32 pm_setup_jobs(const ParseRec *rec, int C, int B, u32 &fill_lo, u32 &f
     u32 tfm = 0, flo = 0, fhi = 0, de = 0;
     const int logBf = ilog2(B);
     OG_FOR_LANES(l, 2 * NBANDS) {
-        const int band = l >> 1, jb = l & 1;
-        const u32 *wp = rec->words + rec->band_w[band];
-        const u32 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3], jw0 = wp[4];
+        const int band = l >> 1, jb = l & 1, coded = band >= start;
+        const u32 *wp = rec->words + (coded ? rec->band_w[band] : 0);
+        const u32 w0 = coded ? wp[0] : 0u, w1 = coded ? wp[1] : 0u, w2 = coded ? wp[2] : 0u, w3 = coded ? wp[3] : 0u, jw0 = coded ? wp[4] : 0u;
         const int N = (int)(w1 >> 22) & 255;
         const int stereo = (w0 & BW_STEREO) != 0, dual = (w0 & BW_DUAL) != 0, mid_first = (w0 & BW_MID_FIRST) != 0;
-        const int njobs = (stereo || dual) ? 2 : 1;
+        const int njobs = !coded ? 0 : (stereo || dual) ? 2 : 1;
         if (jb == 0) {
             P.bw0[band] = w0;
             P.bw1[band] = w1;
@@ -1273,7 +1276,7 @@ OG_DEV u32 pm_setup_jobs(const ParseRec *rec, int C, int B, u32 &fill_lo, u32 &f
         }
         const int exists = jb < njobs;
         const int ch = dual ? jb : stereo ? (((jb == 0) == mid_first) ? 0 : 1) : 0;
-        const int jpos = rec->band_w[band] + 4 + (jb ? 1 + 2 * (int)(jw0 & 31) : 0);
+        const int jpos = (coded ? rec->band_w[band] : 0) + 4 + (jb ? 1 + 2 * (int)(jw0 & 31) : 0);
         u32 jw = jw0;
         if (jb && exists) jw = rec->words[OG_MIN(jpos, REC_WORDS_CAP - 1)];
         const int n_fill = (int)(jw & 31), n_pvq = (int)(jw >> JW_NPVQ_SHIFT) & 31, first = (int)(jw >> JW_FIRST_SHIFT) & 1023;
@@ -1409,14 +1412,22 @@ OG_DEV void pm_tf_undo(u32 tfm) {
 // the folding source of job (band i, channel ch) made on demand: `n` entries from position p0 of the folding history as the
 // band walk would hold it when band i starts (lowband_out of the earlier bands, celt.cpp:1617; the two channels' histories
 // averaged once dual stereo has ended, celt.cpp:1856-1860)
-OG_DEV void pm_make_lowband(int dst, int p0, int n, int i, int use_y, int dual_end) {
+// (p0 counts from the frame's first band, like the folding history of the band walk: norm_offset celt.cpp:1787.  `dup`: the
+// second band of a frame that starts above band 0 is wider than the first, and the band walk fills the hole behind the first
+// band's history with a copy of its end -- special_hybrid_folding celt.cpp:1743: entries from n1 on repeat the n2 - n1 before n1)
+OG_DEV void pm_make_lowband(int dst, int p0, int n, int i, int use_y, int dual_end, int norm_offset = 0, int dup_n1 = 0, int dup_back = 0) {
     const PmLds &P = PM();
     OG_SYNC();
     OG_FOR_LANES(j, n) {
-        const int p = p0 + j, sb = P.binband[p >> 3];
+        int r = p0 + j;
+        const bool copied = dup_back && r >= dup_n1;
+        if (copied) r -= dup_back;
+        const int p = norm_offset + r, sb = P.binband[p >> 3];
         const i32 sc = P.scale[sb];
         i32 v;
-        if (i >= dual_end && sb < dual_end)
+        // (the copy is made before dual stereo is switched off at this very band, and that averages only the histories of the
+        // bands before it, celt.cpp:1856-1860: the copied entries stay the first channel's)
+        if (i >= dual_end && sb < dual_end && !copied)
             v = ((i32)(i16)mul16_q15(sc, S.v[V_X + p]) + (i32)(i16)mul16_q15(sc, S.v[V_X + 960 + p])) >> 1;
         else
             v = mul16_q15(sc, S.v[V_X + (use_y ? 960 : 0) + p]);
@@ -1434,7 +1445,10 @@ OG_DEV u32 pm_band_cm(int b, int c) {
 }
 
 // D: the jobs with leaves without pulses, in decode order
-OG_DEV void pm_fill_jobs(const u32 *words, const LcgTab &lcg, u32 fill_lo, u32 fill_hi, int C, int B, int dual_end, u32 &seed) {
+OG_DEV void pm_fill_jobs(const u32 *words, const LcgTab &lcg, u32 fill_lo, u32 fill_hi, int C, int B, int dual_end, u32 &seed,
+                         int start = 0) {
+    const int norm_offset = 8 * rom_eband[start];
+    const int dup_n1 = 8 * (rom_eband[start + 1] - rom_eband[start]), dup_n2 = 8 * (rom_eband[start + 2] - rom_eband[start + 1]);
     PmLds &P = PM();
     RecCur cur;
     cur.words = words;
@@ -1484,7 +1498,8 @@ OG_DEV void pm_fill_jobs(const u32 *words, const LcgTab &lcg, u32 fill_lo, u32 f
         const u32 jw = rec_word(cur);
         int low = -1;
         if ((w0 & BW_HAS_LOW) && want_low && (jw & JW_NEED_LOW)) {
-            pm_make_lowband(V_IY, (int)(w1 & 2047), N, i, dual && ch, dual_end);
+            const int dup = (i == start + 1 && dup_n2 > dup_n1) ? dup_n2 - dup_n1 : 0;
+            pm_make_lowband(V_IY, (int)(w1 & 2047), N, i, dual && ch, dual_end, norm_offset, dup_n1, dup);
             low = V_IY;
         }
         const u32 cm = recon_band_mono(cur, jw, lcg, tf_change, seed, V_X + 960 * ch + eb0, N, B, low, -1, 0, -1, jfill);
@@ -1574,12 +1589,12 @@ OG_DEV void pm_stereo_merge(int C) {
     OG_SYNC();
 }
 
-OG_DEV void recon_all_bands_pm(const ParseRec *rec, const LcgTab &lcg, int C, int shortBlocks, u32 &seed_io) {
+OG_DEV void recon_all_bands_pm(const ParseRec *rec, const LcgTab &lcg, int C, int shortBlocks, u32 &seed_io, int start = 0) {
     const int B = shortBlocks ? 8 : 1;
     u32 fill_lo, fill_hi, seed = seed_io;
     int dual_end;
     OG_MARK(3);
-    const u32 tfm = pm_setup_jobs(rec, C, B, fill_lo, fill_hi, dual_end);
+    const u32 tfm = pm_setup_jobs(rec, C, B, fill_lo, fill_hi, dual_end, start);
     OG_STAT(0, 1);                                  // frames
     OG_STAT(19, shortBlocks != 0);                  // transient frames
     OG_STAT(21, tfm != 0);                          // frames with a time-frequency change to undo in the parallel pass
@@ -1587,7 +1602,7 @@ OG_DEV void recon_all_bands_pm(const ParseRec *rec, const LcgTab &lcg, int C, in
     OG_STAT(23, (fill_lo | fill_hi) != 0);          // frames with fill jobs
     OG_MARK(8);
     if (tfm) pm_tf_undo(tfm);
-    if (fill_lo | fill_hi) pm_fill_jobs(rec->words, lcg, fill_lo, fill_hi, C, B, dual_end, seed);
+    if (fill_lo | fill_hi) pm_fill_jobs(rec->words, lcg, fill_lo, fill_hi, C, B, dual_end, seed, start);
     OG_MARK(10);
     pm_stereo_merge(C);
     OG_MARK(4);
@@ -1605,16 +1620,15 @@ OG_DEV void recon_all_bands_pm(const ParseRec *rec, const LcgTab &lcg, int C, in
 // One CELT-only frame, vector half + synthesis + stream bookkeeping (decode_frame_wave's CELT branch).
 // Returns the frame's result code (wave-uniform).  The comb-filtered output goes to the stream's history ring; the
 // last, strictly serial step -- de-emphasis to int16 PCM -- is celt_post_lane's, one (frame, channel) per lane.
-// Which reconstruction kernel takes a frame: 20 ms frames that start at band 0 and whose record is complete go to the
-// kernel with the 8 KB working set (og_recon.hip, phase-major band loop only), everything else -- the CELT half of hybrid
-// frames, the 2.5 ms transition frame, records that overflowed -- to the general one.
+// Which reconstruction kernel takes a frame: 20 ms frames whose record is complete -- CELT-only ones and the CELT half of
+// hybrid ones (bands 17 - 20) -- go to the kernel with the 8 KB working set (og_recon.hip, phase-major band loop only),
+// everything else -- the 2.5 ms transition frame, records that overflowed -- to the general one.
 constexpr int FAST_MAX_LEAVES = 416; // (og_state.hpp: the most a 20 ms frame can have)
 enum { RECON_ALL = 0, RECON_FAST_ONLY = 1, RECON_REST_ONLY = 2, RECON_NOT_MINE = -1000 };
 OG_DEV bool recon_fast_eligible(const ParseRec *rec) {
     const u32 flags = (u32)OG_UNI(rec->flags);
     if (flags & (RF_SKIP | RF_BAD_CELT)) return false;
-    return ((flags >> RF_LM_SHIFT) & 3) == 3 && OG_UNI(rec->start) == 0 && OG_UNI(rec->n_words) < REC_MAX_WORDS &&
-           OG_UNI(rec->n_leaves) <= FAST_MAX_LEAVES;
+    return ((flags >> RF_LM_SHIFT) & 3) == 3 && OG_UNI(rec->n_words) < REC_MAX_WORDS && OG_UNI(rec->n_leaves) <= FAST_MAX_LEAVES;
 }
 
 OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int ch, int role = RECON_ALL) {
@@ -1651,7 +1665,7 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
             S.tf_res[i] = rec->tf_res[i];
         }
 #endif
-        // the phase-major band loop takes every 20 ms frame that starts at band 0 (and whose record did not overflow)
+        // the phase-major band loop takes every 20 ms frame whose record did not overflow (hybrid: from band 17)
 #if defined(OG_NO_PM) && !defined(OG_RECON_TIGHT)
         const bool pm = false;
 #else
@@ -1703,7 +1717,7 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
 #endif
         u32 seed = cs->rng;
 #ifdef OG_RECON_TIGHT
-        recon_all_bands_pm(rec, lcg, C, transient ? M : 0, seed);
+        recon_all_bands_pm(rec, lcg, C, transient ? M : 0, seed, start);
         // what anti-collapse and the synthesis read besides the spectrum, staged only now (og_state.hpp, V_LATE: the rows
         // were the band loop's scratch until here; the bands' collapse masks are there already)
         OG_FOR_LANES(i, 2 * NBANDS) {
@@ -1715,7 +1729,7 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         OG_SYNC();
 #else
         if (pm)
-            recon_all_bands_pm(rec, lcg, C, transient ? M : 0, seed);
+            recon_all_bands_pm(rec, lcg, C, transient ? M : 0, seed, start);
         else
             recon_all_bands(rec->words, (u32)OG_UNI(rec->need_norm), lcg, start, end, C, N, transient ? M : 0, LM, seed);
 #endif

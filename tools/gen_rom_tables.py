@@ -86,6 +86,35 @@ def pvq_u_columns():
     assert max(cb) < 65536
     return tab, cb
 
+def pulse_v_table():
+    """V(N, K) = U(N, K) + U(N, K + 1), the size of the PVQ codebook a leaf's index is decoded against (celt.cpp:2622,
+    ec_dec_uint's ft), laid out like the pulse cache: entry rom_pulse_idx[(LM + 1) * 21 + band] + q holds V for the band's
+    N = width << LM (width >> 1 for LM = -1) and K = get_pulses(q).  The entropy half of the split path finds it with the
+    index it already has for the cache instead of two lookups in the big U table."""
+    cols = 178
+    U = [[0] * cols for _ in range(cols)]
+    U[0][0] = 1
+    for n in range(1, cols):
+        for k in range(1, cols):
+            U[n][k] = U[n - 1][k] + U[n][k - 1] + U[n - 1][k - 1]
+    out = [0] * len(PULSE_BITS)
+    for lmp1 in range(5):
+        for band in range(21):
+            base = PULSE_IDX[lmp1 * 21 + band]
+            if base < 0:
+                continue
+            width = EBAND[band + 1] - EBAND[band]
+            n = width << (lmp1 - 1) if lmp1 >= 1 else width >> 1
+            for q in range(1, PULSE_BITS[base] + 1):
+                k = q if q < 8 else (8 + (q & 7)) << ((q >> 3) - 1)
+                lo, hi = min(n, k), max(n, k)
+                lo1, hi1 = min(n, k + 1), max(n, k + 1)
+                v = U[lo][hi] + U[lo1][hi1]
+                assert 0 < v < 2 ** 32, (lmp1, band, q, n, k, v)
+                assert out[base + q] in (0, v), "two caches share an entry with different N"
+                out[base + q] = v
+    return out
+
 def mdct_trig():
     """cos(2*pi*(i+1/8)/N) in Q15 for N = 1920, 960, 480, 240 (N/2 entries each), concatenated."""
     out = []
@@ -271,6 +300,7 @@ def build_text():
     t += emit("rom_logn", "int16_t", LOGN, 21)
     t += emit("rom_pulse_idx", "int16_t", PULSE_IDX, 21)
     t += emit("rom_pulse_bits", "uint8_t", PULSE_BITS, 28)
+    t += emit("rom_pulse_v", "uint32_t", pulse_v_table(), 8)
     t += emit("rom_pulse_caps", "uint8_t", PULSE_CAPS, 21)
     t += emit("rom_log2_frac", "uint8_t", LOG2_FRAC, 24)
     t += emit("rom_emeans", "int8_t", EMEANS, 25)
