@@ -250,32 +250,49 @@ __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const Fra
                                                    StreamState *st, i16 *pcm, i32 *result, int n, int n_streams,
                                                    int pcm_stride, int skip_celt, SilkHandoff *handoff, const SilkRec *srecs,
                                                    int q4_only) {
-    const int f = (int)blockIdx.x;
-    if (f >= n) return;
-    const FrameDesc d = descs[f];
-    int ret;
-    if (d.stream < 0 || d.stream >= n_streams) {
-        ret = BAD_ARG;
-    } else if (desc_rfc(d.flags)) {
-        return; // RFC-mode frames belong to k_decode_rfc (og_rfc.hip)
-    } else if (skip_celt && desc_mode(d.flags) == MODE_CELT) {
-        return; // CELT-only frames take the split path (k_celt_parse + k_celt_recon)
-    } else if (q4_only && !(desc_mode(d.flags) == MODE_SILK && handoff[f].valid == 2)) {
-        return; // second pass of the split path: only the parked Q4 transition frames
-    } else {
-        StreamState *s = &st[d.stream];
-#ifdef OG_PROF_SINGLE // profiling builds: time the sections of the single-kernel path
-        OG_PROF_INIT();
-#endif
-        ret = decode_frame_wave<true>(s, arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
-                                      desc_channels(d.flags), pcm + (size_t)f * pcm_stride, handoff ? &handoff[f] : nullptr,
-                                      srecs ? &srecs[f] : nullptr, q4_only);
-#ifdef OG_PROF_SINGLE
-        OG_PROF_FLUSH();
-#endif
-        if (ret == CONTINUE_SPLIT) return; // the split path finishes this frame and reports its result
+    // First pass (or the only one): one workgroup per slot.  Second pass of the split path (q4_only): it almost never has a
+    // frame, so a workgroup looks at 64 slots -- one per lane -- and decodes the few that were parked for it one after the
+    // other: 1 / 64 of the workgroups to start and end for nothing.
+    unsigned long long todo = 1ull;
+    int base = (int)blockIdx.x;
+    if (q4_only) {
+        base = (int)blockIdx.x * 64;
+        const int f0 = base + (int)threadIdx.x;
+        bool mine = false;
+        if (f0 < n) {
+            const FrameDesc d0 = descs[f0];
+            mine = d0.stream >= 0 && d0.stream < n_streams && !desc_rfc(d0.flags) && desc_mode(d0.flags) == MODE_SILK && handoff[f0].valid == 2;
+        }
+        todo = __ballot(mine);
     }
-    if (threadIdx.x == 0) result[f] = ret;
+    while (todo) {
+        const int f = base + (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        if (f >= n) return;
+        const FrameDesc d = descs[f];
+        int ret;
+        if (d.stream < 0 || d.stream >= n_streams) {
+            ret = BAD_ARG;
+        } else if (desc_rfc(d.flags)) {
+            continue; // RFC-mode frames belong to k_decode_rfc (og_rfc.hip)
+        } else if (skip_celt && desc_mode(d.flags) == MODE_CELT) {
+            continue; // CELT-only frames take the split path (k_celt_parse + k_celt_recon)
+        } else {
+            StreamState *s = &st[d.stream];
+#ifdef OG_PROF_SINGLE // profiling builds: time the sections of the single-kernel path
+            OG_PROF_INIT();
+#endif
+            ret = decode_frame_wave<true>(s, arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
+                                          desc_channels(d.flags), pcm + (size_t)f * pcm_stride, handoff ? &handoff[f] : nullptr,
+                                          srecs ? &srecs[f] : nullptr, q4_only);
+#ifdef OG_PROF_SINGLE
+            OG_PROF_FLUSH();
+#endif
+            if (ret == CONTINUE_SPLIT) continue; // the split path finishes this frame and reports its result
+        }
+        if (threadIdx.x == 0) result[f] = ret;
+        __syncthreads();
+    }
 }
 
 // SILK-only and hybrid frames on the split path, arithmetic half: one frame per wave, no CELT code (see decode_frame_wave).
@@ -357,20 +374,44 @@ extern "C" void og_launch_decode_rfc(hipStream_t s, const void *descs, const voi
 __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDesc *__restrict__ descs, StreamState *st,
                                                                       const ParseRec *recs, i16 *pcm, i32 *result, int n,
                                                                       int n_streams, int pcm_stride, int hybrid, int rest_only) {
-    const int f = (int)blockIdx.x;
-    if (f >= n) return;
-    const FrameDesc d = descs[f];
-    const int mode = desc_mode(d.flags);
-    if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && hybrid)) || desc_rfc(d.flags)) return;
-    if (mode == MODE_HYBRID && (recs[f].flags & RF_SKIP)) return; // the single-kernel path already reported this frame
+    // rest_only (k_celt_recon_fb ran before): what is left -- records that overflowed -- is almost nothing, so a workgroup
+    // looks at 64 slots, one per lane, and reconstructs the few left to it one after the other (see k_decode_step)
+    unsigned long long todo = 1ull;
+    int base = (int)blockIdx.x;
+    if (rest_only) {
+        base = (int)blockIdx.x * 64;
+        const int f0 = base + (int)threadIdx.x;
+        bool mine = false;
+        if (f0 < n) {
+            const FrameDesc d0 = descs[f0];
+            const int m0 = desc_mode(d0.flags);
+            if (d0.stream >= 0 && d0.stream < n_streams && (m0 == MODE_CELT || (m0 == MODE_HYBRID && hybrid)) && !desc_rfc(d0.flags)) {
+                const u32 fl = recs[f0].flags; // (the lane's own look at recon_fast_eligible's conditions)
+                const bool fast = !(fl & (RF_SKIP | RF_BAD_CELT)) && ((fl >> RF_LM_SHIFT) & 3) == 3 && recs[f0].n_words < REC_MAX_WORDS &&
+                                  recs[f0].n_leaves <= FAST_MAX_LEAVES;
+                mine = !fast && !(m0 == MODE_HYBRID && (fl & RF_SKIP));
+            }
+        }
+        todo = __ballot(mine);
+    }
+    while (todo) {
+        const int f = base + (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        if (f >= n) return;
+        const FrameDesc d = descs[f];
+        const int mode = desc_mode(d.flags);
+        if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && hybrid)) || desc_rfc(d.flags)) continue;
+        if (mode == MODE_HYBRID && (recs[f].flags & RF_SKIP)) continue; // the single-kernel path already reported this frame
 #if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE) && !defined(OG_PROF_SPARSE) && !defined(OG_PROF_SSYNTH)
-    OG_PROF_INIT();
+        OG_PROF_INIT();
 #endif
-    const int ret = celt_recon_wave(&st[d.stream], &recs[f], mode, desc_channels(d.flags), rest_only ? RECON_REST_ONLY : RECON_ALL);
-    if (ret != RECON_NOT_MINE && threadIdx.x == 0) result[f] = ret;
+        const int ret = celt_recon_wave(&st[d.stream], &recs[f], mode, desc_channels(d.flags), rest_only ? RECON_REST_ONLY : RECON_ALL);
+        if (ret != RECON_NOT_MINE && threadIdx.x == 0) result[f] = ret;
 #if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE) && !defined(OG_PROF_SPARSE) && !defined(OG_PROF_SSYNTH)
-    OG_PROF_FLUSH();
+        OG_PROF_FLUSH();
 #endif
+        __syncthreads();
+    }
 }
 
 // Split CELT path, third step: de-emphasis (a rounding IIR: strictly serial per channel) and int16 PCM, one
@@ -749,8 +790,8 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
         // reconstruct (one frame per wave) -> de-emphasis, SILK mix and PCM (one (frame, channel) per lane)
         if (ctx->fast_recon)
             og_launch_celt_recon_fb(s, d_descs, ctx->d_streams, ctx->d_recs, d_result, n, ctx->n_streams, handoff ? 1 : 0);
-        hipLaunchKernelGGL(k_celt_recon, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, ctx->d_streams,
-                           (const ParseRec *)ctx->d_recs, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride,
+        hipLaunchKernelGGL(k_celt_recon, dim3(ctx->fast_recon ? (n + 63) / 64 : n), dim3(64), 0, s, (const FrameDesc *)d_descs,
+                           ctx->d_streams, (const ParseRec *)ctx->d_recs, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride,
                            handoff ? 1 : 0, ctx->fast_recon);
         hipLaunchKernelGGL(k_celt_post, dim3((n * ctx->channels + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs,
                            ctx->d_streams, (const ParseRec *)ctx->d_recs, (const i32 *)d_result, (i16 *)d_pcm, n, ctx->n_streams,
@@ -759,7 +800,7 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
     if (srecs) {
         // The rare hybrid -> SILK-only transition frames (Q4), parked by k_silk_synth, through the full kernel.  Nothing in
         // the step waits for it and almost all of its workgroups exit at once: it goes last.
-        hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
+        hipLaunchKernelGGL(k_decode_step, dim3((n + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
                            ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, 1, handoff,
                            (const SilkRec *)srecs, 1);
     }
