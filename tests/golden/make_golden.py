@@ -12,7 +12,12 @@ Two kinds of fixture:
   oracle_sequences.json -- explicit packet sequences (hex) for the quirk cases, with the oracle's return code and PCM hash
                         per call: mono decoders, a mono packet in a stereo decoder (Q3: only the defined half is
                         hashed), multi-frame packets of every frame-count code with room for three frames (Q6), and a
-                        mode-switch sequence incl. hybrid -> SILK-only (Q4) and CELT <-> SILK."""
+                        mode-switch sequence incl. hybrid -> SILK-only (Q4) and CELT <-> SILK.
+  rfc_sequences.json -- the same for RFC mode (oracle/oc_opus.h oc_decoder_set_rfc; PARITY-UNPINNED: these vectors freeze what
+                        the oracle does today, they do not come from any reference decoder): event sequences for a stereo
+                        and a mono decoder over every frame duration and frame-count code -- packets, lost packets
+                        (concealed for the last packet's duration), DTX frames, packets preceded by a forward error
+                        correction recovery (oc_decode_fec), hybrid packets with redundancy -- return code and PCM hash."""
 import json
 import os
 import sys
@@ -85,6 +90,60 @@ def sequences(o):
     return out
 
 
+def rfc_events(channels):
+    """[(kind, packet or None)]: kind in packet / lost / fec (fec: recover the packet lost before this one from it, then decode it)"""
+    from rfc_common import make_packet, redundancy_packet
+    rng = np.random.default_rng(20261004 + channels)
+    stereo = channels == 2
+    ev = []
+    walk = [31, 31, 29, 23, 19, 17, 16, 31, 15, 15, 13, 12, 14, 15, 1, 0, 2, 3, 9, 8, 10, 11, 5, 7, 15, 9, 31, 15, 1, 27]
+    for k, cfg in enumerate(walk):
+        code = (0, 0, 1, 2, 3)[k % 5]
+        ev.append(("packet", make_packet(rng, cfg, stereo, code, int(rng.choice([20, 40, 80, 120])))))
+        if k % 3 == 2:
+            ev.append(("lost", None))
+        if k % 7 == 6:
+            ev.append(("lost", None))  # (two in a row with the one above, now and then)
+        if k % 4 == 1:
+            ev.append(("fec", make_packet(rng, cfg if cfg < 16 else 9, stereo, 0, 100)))
+        if k % 9 == 4:
+            ev.append(("packet", make_packet(rng, cfg, stereo, 0, int(rng.integers(0, 2)))))  # a DTX frame
+        if k % 6 == 3:
+            ev.append(("packet", redundancy_packet(rng, channels)[0]))
+    return ev
+
+
+def rfc_sequences(o):
+    import ctypes as C
+    from rfc_common import fec_plan, dur, mode_bw, frame_payloads
+    o.lib.oc_decode_fec.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_int]
+    out = {"generator": "oracle RFC mode (oc_decoder_set_rfc), NOT the reference and NOT pinned by it", "frame_capacity": 6, "sequences": {}}
+    for channels in (2, 1):
+        d = o.decoder(channels)
+        d.init()
+        d.set_rfc(True)
+        last, calls = None, []
+        for kind, p in rfc_events(channels):
+            if kind == "lost":
+                want = last[0] * last[1] if last else 960
+                pcm, r = d.conceal(want)
+            elif kind == "fec":
+                total, _, _ = fec_plan((last[0], last[1], last[2]) if last else None, p[0], channels)
+                buf = np.zeros((5760, channels), dtype=np.int16)
+                r = o.lib.oc_decode_fec(d.h, p, len(p), buf.ctypes.data, total)
+                calls.append({"kind": "fec", "packet": p.hex(), "ret": int(r), "fnv1a_u16": oracle_py.fnv1a_u16(buf[:r]) if r > 0 else None})
+                pcm, r = d.decode(p)
+                kind = "packet"
+            else:
+                pcm, r = d.decode(p)
+            if kind == "packet" and frame_payloads(o, p) is not None:
+                last = (len(frame_payloads(o, p)), dur(p[0]), mode_bw(p[0])[0])
+            calls.append({"kind": kind, "packet": p.hex() if p else None, "ret": int(r),
+                          "fnv1a_u16": oracle_py.fnv1a_u16(pcm[:r]) if r > 0 else None})
+        out["sequences"]["stereo" if channels == 2 else "mono"] = {"channels": channels, "calls": calls}
+    return out
+
+
 def main():
     o = oracle_py.load()
     pkg = load_pkg()
@@ -100,7 +159,8 @@ def main():
                "modes": hashes}, open(os.path.join(HERE, "oracle_vectors.json"), "w"), indent=0)
     np.savez_compressed(os.path.join(HERE, "oracle_vectors_pcm.npz"), **pcm)
     json.dump(sequences(o), open(os.path.join(HERE, "oracle_sequences.json"), "w"), indent=0)
-    print("wrote oracle_vectors.json / oracle_vectors_pcm.npz / oracle_sequences.json")
+    json.dump(rfc_sequences(o), open(os.path.join(HERE, "rfc_sequences.json"), "w"), indent=0)
+    print("wrote oracle_vectors.json / oracle_vectors_pcm.npz / oracle_sequences.json / rfc_sequences.json")
 
 
 if __name__ == "__main__":

@@ -80,3 +80,58 @@ def test_gpu_matches_committed_sequences(pkg, gpu_ctx):
             assert res[0] == c["ret"], (name, i, res[0], c["ret"])
             if c["fnv1a_u16"] is not None:
                 assert fnv1a_u16(out[0, :c["ret"]]) == c["fnv1a_u16"], (name, i)
+
+
+def _rfc_sequences():
+    return json.load(open(os.path.join(HERE, "rfc_sequences.json")))
+
+
+def test_oracle_reproduces_committed_rfc_sequences(oracle):
+    """RFC mode (parity-unpinned: the vectors freeze the oracle's behaviour, no reference decoder made them): every frame
+    duration and frame-count code, lost packets, DTX frames, forward error correction, redundancy -- code and PCM hash per call."""
+    import ctypes as C
+    oracle.lib.oc_decode_fec.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_int]
+    seq = _rfc_sequences()
+    kinds = set()
+    for name, q in seq["sequences"].items():
+        d = oracle.decoder(q["channels"])
+        d.init()
+        d.set_rfc(True)
+        prev = 960
+        for i, c in enumerate(q["calls"]):
+            kinds.add(c["kind"])
+            if c["kind"] == "lost":
+                pcm, r = d.conceal(c["ret"])
+            elif c["kind"] == "fec":
+                pcm = np.zeros((5760, q["channels"]), dtype=np.int16)
+                p = bytes.fromhex(c["packet"])
+                r = oracle.lib.oc_decode_fec(d.h, p, len(p), pcm.ctypes.data, c["ret"])
+            else:
+                pcm, r = d.decode(bytes.fromhex(c["packet"]))
+            assert r == c["ret"], (name, i, c["kind"])
+            if c["fnv1a_u16"] is not None:
+                assert fnv1a_u16(pcm[:r]) == c["fnv1a_u16"], (name, i, c["kind"])
+    assert kinds == {"packet", "lost", "fec"}
+    rets = {c["ret"] for q in seq["sequences"].values() for c in q["calls"]}
+    assert {120, 240, 480, 960, 1920, 2880} <= rets  # every frame duration is in there
+
+
+@pytest.mark.gpu
+def test_gpu_matches_committed_rfc_sequences(pkg, gpu_ctx):
+    seq = _rfc_sequences()
+    gpu_ctx.set_mode(True)
+    try:
+        for name, q in seq["sequences"].items():
+            gpu_ctx.streams_alloc(1, q["channels"])
+            for i, c in enumerate(q["calls"]):
+                if c["kind"] == "lost":
+                    out, res = gpu_ctx.decode_packets([0], [b""], frame_capacity=seq["frame_capacity"])
+                elif c["kind"] == "fec":
+                    out, res = gpu_ctx.decode_packets_fec([0], [bytes.fromhex(c["packet"])], frame_capacity=seq["frame_capacity"])
+                else:
+                    out, res = gpu_ctx.decode_packets([0], [bytes.fromhex(c["packet"])], frame_capacity=seq["frame_capacity"])
+                assert res[0] == c["ret"], (name, i, c["kind"], int(res[0]), c["ret"])
+                if c["fnv1a_u16"] is not None:
+                    assert fnv1a_u16(out[0, :c["ret"]]) == c["fnv1a_u16"], (name, i, c["kind"])
+    finally:
+        gpu_ctx.set_mode(False)
