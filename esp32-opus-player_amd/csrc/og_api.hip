@@ -323,7 +323,10 @@ __global__ void __launch_bounds__(64, OG_SILK_WAVES) k_silk_synth(const FrameDes
 
 // SILK-only and hybrid frames, entropy half: ONE FRAME PER LANE (og_silk_parse.hpp).  Lane l of workgroup g decodes the
 // side information and pulses of frame OG_SP_LANES g + l (l < OG_SP_LANES = 32; the upper lanes idle) into srecs[frame] and leaves the coder state in handoff[frame].
-__global__ void __launch_bounds__(64, 2) k_silk_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
+#ifndef OG_SPARSE_WAVES
+#define OG_SPARSE_WAVES 4 // (9,156 B of LDS per workgroup allow 16 per CU; 128 VGPRs: 5 spilled. hybrid-256k: 4.80 -> 3.99 ms)
+#endif
+__global__ void __launch_bounds__(64, OG_SPARSE_WAVES) k_silk_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
                                                       const StreamState *st, SilkRec *srecs, SilkHandoff *handoff, int n,
                                                       int n_streams) {
     silk_tables_load();

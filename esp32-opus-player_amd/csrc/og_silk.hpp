@@ -609,26 +609,7 @@ OG_DEV void silk_decode_parameters(const i16 *prevNLSF_Q15, K &k, int fs_kHz, in
     }
 }
 
-// ---- lane-private parameter decoding for the parse kernel ----------------------------------------------------------
-// Arrays that are never live together share storage (4 KB less per wave: 12 instead of 9 parse waves fit a CU, which is
-// what the parse kernel's time on large batches depends on): pred_Q8 belongs to silk_nlsf_decode and is dead when
-// silk_nlsf2a starts; cosLSF, P and Q are dead once a32 is formed, and Atmp is used only after that
-// (silk_inverse_pred_gain, at the end of silk_nlsf2a).
-struct SilkParLds { // [element][lane]
-    i16 nlsf[SILK_MAX_LPC][OG_SP_LANES], nlsf0[SILK_MAX_LPC][OG_SP_LANES], res_Q10[SILK_MAX_LPC][OG_SP_LANES];
-    union {
-        i32 cosLSF[SILK_MAX_LPC][OG_SP_LANES];
-        i32 Atmp[SILK_MAX_LPC][OG_SP_LANES];
-    };
-    union {
-        struct {
-            i32 P[SILK_MAX_LPC / 2 + 1][OG_SP_LANES], Q[SILK_MAX_LPC / 2 + 1][OG_SP_LANES];
-        };
-        i32 pred_Q8[SILK_MAX_LPC][OG_SP_LANES];
-    };
-    i32 a32[SILK_MAX_LPC][OG_SP_LANES];
-};
-OG_LDS SilkParLds g_silk_par;
+// ---- lane-private parameter decoding for the parse kernel (scratch: SilkParLds, og_silk_parse.hpp) -----------------
 struct SilkParLane {
     typedef ArrV<i16, OG_SP_LANES> A16;
     typedef ArrV<i32, OG_SP_LANES> A32;

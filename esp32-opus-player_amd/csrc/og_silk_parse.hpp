@@ -151,8 +151,42 @@ OG_DEV void shell_split_tab(RcLane &rc, int &c1, int &c2, int p, int table) {
 #ifndef OG_SP_LANES
 #define OG_SP_LANES (OG_NLANES >= 32 ? 32 : OG_NLANES) // measured: 64 / 32 / 16 frames per wave, see DESIGN.md section 6
 #endif
-// per-lane block bookkeeping of the pulse decoder: sum_pulses (<= 16) | nLshifts (<= 10) << 5 per 16-sample block
-OG_LDS u16 g_silk_blk[SILK_REC_FRAME / 16][OG_SP_LANES];
+// Lane-private scratch of the parse kernel, [element][lane].  Arrays that are never live together share storage -- 9,156
+// bytes per workgroup with the table blob instead of 13,520: 8 instead of 11 LDS granules of 1,280 bytes, 16 instead of 11
+// workgroups per CU (what the kernel's time on large batches depends on: its waves wait, they do not compute) --
+//   blk      per-lane block bookkeeping of the pulse decoder (sum_pulses | nLshifts << 5 per 16-sample block): the pulses of
+//            a frame are all read before its parameters are dequantised, so it lies over the NLSF rows;
+//   res_Q10  belongs to silk_nlsf_decode and is dead when the interpolated NLSFs (nlsf0) are made;
+//   pred_Q8  belongs to silk_nlsf_decode too and is dead when silk_nlsf2a starts; cosLSF is dead once P and Q are formed,
+//            P and Q once a32 is, and Atmp is only used after that (silk_inverse_pred_gain, at the end of silk_nlsf2a).
+// Every array keeps the [row][lane] shape with rows of OG_SP_LANES elements of its size, so an element of one array and
+// the element of another that shares its bytes always belong to the same lane.
+struct SilkParLds {
+    union {
+        struct {
+            i16 nlsf[SILK_REC_LPC][OG_SP_LANES];
+            union {
+                i16 nlsf0[SILK_REC_LPC][OG_SP_LANES];
+                i16 res_Q10[SILK_REC_LPC][OG_SP_LANES];
+            };
+        };
+        u16 blk[SILK_REC_FRAME / 16][OG_SP_LANES];
+    };
+    union {
+        i32 cosLSF[SILK_REC_LPC][OG_SP_LANES];
+        i32 a32[SILK_REC_LPC][OG_SP_LANES];
+    };
+    union {
+        struct {
+            i32 P[SILK_REC_LPC / 2 + 1][OG_SP_LANES], Q[SILK_REC_LPC / 2 + 1][OG_SP_LANES];
+        };
+        i32 pred_Q8[SILK_REC_LPC][OG_SP_LANES];
+        i32 Atmp[SILK_REC_LPC][OG_SP_LANES];
+    };
+};
+static_assert(SILK_REC_FRAME / 16 <= 2 * SILK_REC_LPC, "the pulse decoder's block row fits over the two NLSF arrays");
+OG_LDS SilkParLds g_silk_par;
+#define g_silk_blk g_silk_par.blk
 
 // silk_decode_pulses silk.cpp:898.  The pulses of a channel go to the record (HBM) as they are produced; the later
 // passes (LSBs, signs) re-read them, one value ahead of their use.
