@@ -883,7 +883,7 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
 #define OG_AFFINE_SCAN_STEP(d)                                                                                      \
     do {                                                                                                            \
         const u32 Mp = (u32)__builtin_amdgcn_update_dpp(1, (i32)M, 0x110 + (d) /* row_shr:d */, 0xf, 0xf, false);   \
-        const u32 Bp = (u32)__builtin_amdgcn_update_dpp(0, (i32)B, 0x110 + (d), 0xf, 0xf, false);                   \
+        const u32 Bp = (u32)__builtin_amdgcn_update_dpp(0, (i32)B, 0x110 + (d), 0xf, 0xf, true);                    \
         B = M * Bp + B;                                                                                             \
         M = M * Mp;                                                                                                 \
     } while (0)
@@ -894,7 +894,7 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
 #undef OG_AFFINE_SCAN_STEP
             const u32 r0 = (u32)rand_seed;
             const u32 Me = (u32)__builtin_amdgcn_update_dpp(1, (i32)M, 0x111, 0xf, 0xf, false);
-            const u32 Be = (u32)__builtin_amdgcn_update_dpp(0, (i32)B, 0x111, 0xf, 0xf, false);
+            const u32 Be = (u32)__builtin_amdgcn_update_dpp(0, (i32)B, 0x111, 0xf, 0xf, true); // (bound_ctrl: a lane without a source reads 0 -- no register to preset)
             u32 r = Me * r0 + Be;                                              // seed before the lane's first sample
             rand_seed = row_sum16(j == 15 ? (i32)(M * r0 + B) : 0);            // seed after the subframe, in every lane
 #pragma unroll
@@ -952,7 +952,7 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
                             const i32 T_next = addw(order >> 1, row_sum16(smulwb(sLPC, A_next)));
                             const i32 LPC_pred_Q10 = addw(T, smulwb(s_last, A_0));
                             const i32 sn = __builtin_elementwise_add_sat(resb[i], lshift_sat32(LPC_pred_Q10, 4));
-                            const i32 shifted = __builtin_amdgcn_update_dpp(0, sLPC, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+                            const i32 shifted = __builtin_amdgcn_update_dpp(0, sLPC, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
                             sLPC = j == 0 ? sn : shifted;
                             s_last = sn;
                             T = T_next;
@@ -1061,7 +1061,7 @@ OG_DEV void silk_up2_rows(SilkState *st, int channels, int inLen) {
         i32 S = c->rs_sIIR[j], out = 0;
         i16 *dst = &up[8 + ph];
         for (int u = 0; u < inLen + 2; u++) { // branch-free body: every lane runs one section step, results kept if t is in range
-            const i32 prev_out = __builtin_amdgcn_update_dpp(0, out, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+            const i32 prev_out = __builtin_amdgcn_update_dpp(0, out, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
             const int t = u - sec;
             const bool live = (unsigned)t < (unsigned)inLen;
             const i32 v = sec == 0 ? in32[live ? t : 0] : prev_out;
