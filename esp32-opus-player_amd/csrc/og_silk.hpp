@@ -860,7 +860,6 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
         OG_MARK(61);
         i32 *resb = reinterpret_cast<i32 *>(sLTP); // residuals of this subframe (the whitened history is dead by now)
         enum { OWN = (SILK_MAX_FRAME / 4 + 15) / 16 };
-        i32 own[OWN] = {};
         {
             // The dither seed: r <- a r + c, used for the sign, then r <- r + pulse: one affine map mod 2^32 per sample, and
             // affine maps compose exactly.  Lane j folds its own `per` consecutive samples into one map, an inclusive scan
@@ -938,33 +937,42 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
         }
         OG_MARK(63);
         {
-            const i32 A_0 = (i32)A_Q12[0];
-            const i32 A_next = j + 1 < order ? (i32)A_Q12[j + 1] : 0; // lane j: the tap its sample meets one step later
-            i32 s_last = row_lane0(sLPC); // the previous output sample, in every lane of the row
-            i32 T = addw(order >> 1, row_sum16(j >= 1 ? smulwb(sLPC, A_j) : 0)); // taps 2 .. order of the first sample
-#pragma unroll
-            for (int b16 = 0; b16 < OWN; b16++) {
-                if (16 * b16 < subfr) {
-#pragma unroll
-                    for (int t = 0; t < 16; t++) {
-                        const int i = 16 * b16 + t;
-                        if (i < subfr) {
-                            const i32 T_next = addw(order >> 1, row_sum16(smulwb(sLPC, A_next)));
-                            const i32 LPC_pred_Q10 = addw(T, smulwb(s_last, A_0));
-                            const i32 sn = __builtin_elementwise_add_sat(resb[i], lshift_sat32(LPC_pred_Q10, 4));
-                            const i32 shifted = __builtin_amdgcn_update_dpp(0, sLPC, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
-                            sLPC = j == 0 ? sn : shifted;
-                            s_last = sn;
-                            T = T_next;
-                            if (t == j) own[b16] = sn;
-                        }
-                    }
-                }
+            // Transposed form of the predictor: lane j carries R_j = sum over u > j of A_u * s[n - (u - j)] -- what the samples
+            // decoded so far contribute to the prediction j samples ahead -- so lane 0 holds the whole prediction of the next
+            // sample.  A new sample costs every lane one product (its own tap times the sample, broadcast over the row) and one
+            // add that also passes the accumulator one lane down: ten vector instructions per sample where the direct form
+            // -- one product per lane and a four-step row reduction beside the saturating update -- took nineteen, in a kernel
+            // that is bound by vector-ALU issue.  The sums are the same products added in another order, and silk_SMLAWB
+            // wraps, so the order is free.
+            //   R_j = sum_k smulwb(h_k, A[j + k]),  h_k = the k-th last output (lane k of sLPC), A[] = A_Q12, zero past `order`
+            i32 R = 0, Arot = A_j;
+#define OG_ROW_BCAST(v, n) __builtin_amdgcn_update_dpp(0, (v), 0x150 + (n) /* row_newbcast:n */, 0xf, 0xf, true)
+#define OG_ACC_STEP(kk)                                                                             \
+    if ((kk) < order) {                                                                             \
+        R = addw(R, smulwb(OG_ROW_BCAST(sLPC, kk), Arot));                                          \
+        Arot = __builtin_amdgcn_update_dpp(0, Arot, 0x101 /* row_shl:1 */, 0xf, 0xf, true);         \
+    }
+            OG_ACC_STEP(0) OG_ACC_STEP(1) OG_ACC_STEP(2) OG_ACC_STEP(3) OG_ACC_STEP(4) OG_ACC_STEP(5) OG_ACC_STEP(6) OG_ACC_STEP(7)
+            OG_ACC_STEP(8) OG_ACC_STEP(9) OG_ACC_STEP(10) OG_ACC_STEP(11) OG_ACC_STEP(12) OG_ACC_STEP(13) OG_ACC_STEP(14) OG_ACC_STEP(15)
+#undef OG_ACC_STEP
+            const i32 bias = order >> 1; // (the rounding offset the prediction starts from, silk.cpp:1937)
+            i32 r_cur = resb[0];
+#pragma unroll 4
+            for (int i = 0; i < subfr; i++) {
+                const i32 r_next = resb[i + 1 < subfr ? i + 1 : i]; // (requested a sample ahead: its latency is off the chain)
+                const i32 LPC_pred_Q10 = addw(R, bias);            // (lane 0's is the prediction)
+                const i32 sn0 = __builtin_elementwise_add_sat(r_cur, lshift_sat32(LPC_pred_Q10, 4));
+                const i32 sn = OG_ROW_BCAST(sn0, 0);
+                resb[i] = sn; // the residual is consumed: its slot keeps the sample (output scaling, next history); every lane
+                              // of the row stores the same value to the same word
+                R = addw(__builtin_amdgcn_update_dpp(0, R, 0x101 /* row_shl:1 */, 0xf, 0xf, true), smulwb(sn, A_j));
+                r_cur = r_next;
             }
+#undef OG_ROW_BCAST
         }
-#pragma unroll
-        for (int b16 = 0; b16 < OWN; b16++)
-            if (16 * b16 + j < subfr) xq[pos + 16 * b16 + j] = (i16)sat16(rshift_round(smulww(own[b16], Gain_Q10), 8));
+        OG_ROW_SYNC();
+        for (int i = j; i < subfr; i += 16) xq[pos + i] = (i16)sat16(rshift_round(smulww(resb[i], Gain_Q10), 8));
+        sLPC = resb[subfr - 1 - j]; // the last sixteen samples, most recent in lane 0: the next subframe's (or frame's) history
         pos += subfr;
         if (voiced) OG_ROW_SYNC(); // this subframe's sLTP_Q15 / xq writes before the next subframe's reads
     }
