@@ -1068,7 +1068,10 @@ OG_DEV void silk_up2_rows(SilkState *st, int channels, int inLen) {
         const i32 coef = ph ? rom_silk_up2_hq1[sec] : rom_silk_up2_hq0[sec];
         i32 S = c->rs_sIIR[j], out = 0;
         i16 *dst = &up[8 + ph];
-        for (int u = 0; u < inLen + 2; u++) { // branch-free body: every lane runs one section step, results kept if t is in range
+        // Section `sec` handles input sample t = u - sec in step u.  The two steps that fill the pipeline and the two that drain it
+        // run the general body (a section without a sample keeps its state); the inLen - 2 steps in between have every section
+        // at work and carry no such bookkeeping: the kernel is bound by vector-ALU issue, and this loop is a third of it.
+        auto edge_step = [&](int u) {
             const i32 prev_out = __builtin_amdgcn_update_dpp(0, out, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
             const int t = u - sec;
             const bool live = (unsigned)t < (unsigned)inLen;
@@ -1079,7 +1082,29 @@ OG_DEV void silk_up2_rows(SilkState *st, int channels, int inLen) {
             out = live ? o : out;
             S = live ? v + X : S;
             if (live && sec == 2) dst[2 * t] = (i16)sat16(rshift_round(o, 10));
+        };
+        edge_step(0);
+        edge_step(1);
+        {
+            const bool first = sec == 0, last = sec == 2;
+            const i32 m2 = last ? -1 : 0;
+            i16 *d2 = dst - 2 * sec; // d2[2 u] is the slot of sample u - sec
+            i32 in_cur = in32[2];
+#pragma unroll 4
+            for (int u = 2; u < inLen; u++) {
+                const i32 in_next = in32[u + 1 < inLen ? u + 1 : u]; // (requested a step ahead)
+                const i32 prev_out = __builtin_amdgcn_update_dpp(0, out, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+                const i32 v = first ? in_cur : prev_out;
+                const i32 Y = v - S;
+                const i32 X = smulwb(Y, coef) + (Y & m2);
+                out = S + X;
+                S = v + X;
+                if (last) d2[2 * u] = (i16)sat16(rshift_round(out, 10));
+                in_cur = in_next;
+            }
         }
+        edge_step(inLen);
+        edge_step(inLen + 1);
         c->rs_sIIR[j] = S;
     }
     OG_ROW_SYNC();
