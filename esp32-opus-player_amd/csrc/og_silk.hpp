@@ -1474,8 +1474,8 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
                 const int nIn = t0 == 0 ? fs_kHz : OG_MIN(frame_length - t0, 10 * fs_kHz);
                 const i32 max_index_Q16 = shl32(nIn, 17);
                 const int count = (int)udiv((u32)max_index_Q16 + (u32)inv - 1u, (u32)inv);
-                OG_FOR_LANES(id, count * channels) {
-                    const int n = id / count, m = id - n * count;
+                for (int n = 0; n < channels; n++) // (a loop per channel: splitting one index by `count` costs a software division per output)
+                OG_FOR_LANES(m, count) {
                     const i32 index_Q16 = m * inv;
                     const int t = smulwb(index_Q16 & 0xFFFF, 12);
                     const i16 *b = &L.u.out.up[n][2 * t0 + (index_Q16 >> 16)];
