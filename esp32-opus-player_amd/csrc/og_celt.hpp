@@ -546,8 +546,8 @@ OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int sh
         // held in registers across the barrier.  The other channel (synthesised second) reads what the buffer does not touch.
         const bool reads_buffer = (C == 2 && (co == 1 || CC == 1));
         if (!reads_buffer) {
-            OG_FOR_LANES(id, B * N4) {
-                int b = id / N4, i = id - b * N4;
+            for (int b = 0; b < B; b++) // (a loop per block: splitting one index by N4 costs a software division per element)
+            OG_FOR_LANES(i, N4) {
                 i32 x1 = freq_out(co, b + B * (2 * i), N, LM, C, CC);
                 i32 x2 = freq_out(co, b + B * (N2 - 1 - 2 * i), N, LM, C, CC);
                 i32 t0 = trig[i], t1 = trig[N4 + i];
@@ -562,12 +562,15 @@ OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int sh
         } else {
         constexpr int NR = (480 + OG_NLANES - 1) / OG_NLANES;
         i32 hr[NR], hi[NR];
+        // pass `it`: a block takes ppb passes of the wave (8 for the one long block, 1 for each of the eight short blocks of a
+        // transient frame: this layout only sees 20 ms frames), so block and position follow from wave-uniform values and no
+        // lane has to divide its index
+        const int ppb = (N4 + OG_NLANES - 1) / OG_NLANES;
 #pragma unroll
         for (int it = 0; it < NR; it++) {
-            const int id = OG_LANE + it * OG_NLANES;
+            const int b = ppb == 1 ? it : it / ppb, i = OG_LANE + (it - b * ppb) * OG_NLANES;
             hr[it] = hi[it] = 0;
-            if (id < B * N4) {
-                int b = id / N4, i = id - b * N4;
+            if (i < N4 && b < B) {
                 i32 x1 = freq_out(co, b + B * (2 * i), N, LM, C, CC);
                 i32 x2 = freq_out(co, b + B * (N2 - 1 - 2 * i), N, LM, C, CC);
                 i32 t0 = trig[i], t1 = trig[N4 + i];
@@ -578,9 +581,8 @@ OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int sh
         OG_SYNC();
 #pragma unroll
         for (int it = 0; it < NR; it++) {
-            const int id = OG_LANE + it * OG_NLANES;
-            if (id < B * N4) {
-                int b = id / N4, i = id - b * N4;
+            const int b = ppb == 1 ? it : it / ppb, i = OG_LANE + (it - b * ppb) * OG_NLANES;
+            if (i < N4 && b < B) {
                 i32 *yp = &SY[NBk * b + (OVERLAP >> 1)];
                 int rev = br[i];
                 yp[2 * rev + 1] = hr[it];
@@ -591,8 +593,8 @@ OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int sh
         }
 #else
         OG_FOR_LANES(i, OVERLAP / 2) SY[i] = tail[i];
-        OG_FOR_LANES(id, B * N4) { // pre-rotation into digit-reversed order
-            int b = id / N4, i = id - b * N4;
+        for (int b = 0; b < B; b++) // pre-rotation into digit-reversed order (a loop per block: no index to divide)
+        OG_FOR_LANES(i, N4) {
             i32 x1 = freq_out(co, b + B * (2 * i), N, LM, C, CC);
             i32 x2 = freq_out(co, b + B * (N2 - 1 - 2 * i), N, LM, C, CC);
             i32 t0 = trig[i], t1 = trig[N4 + i];
@@ -605,8 +607,8 @@ OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int sh
         }
 #endif
         fft_blocks(&SY[OVERLAP >> 1], B, NBk, shift);
-        OG_FOR_LANES(id, B * (N4 >> 1)) { // post-rotation, pairs (i, N4-1-i)
-            int b = id / (N4 >> 1), i = id - b * (N4 >> 1);
+        for (int b = 0; b < B; b++) // post-rotation, pairs (i, N4-1-i)
+        OG_FOR_LANES(i, N4 >> 1) {
             i32 *yp0 = &SY[NBk * b + (OVERLAP >> 1) + 2 * i];
             i32 *yp1 = &SY[NBk * b + (OVERLAP >> 1) + N2 - 2 - 2 * i];
             i32 re = yp0[1], im = yp0[0];
