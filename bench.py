@@ -278,6 +278,30 @@ def traffic_for(name, n):
     return None, None
 
 
+def valu_issue_for(name, n, step_ms):
+    """SURVEY 8(d), caveat H1: the decode is bound by instruction issue, not HBM -- report that next to the HBM fraction.  From the
+    same committed PMC passes: vector-ALU wave-instructions of the step's kernels, the time the chip needs just to issue them
+    (a wave64 vector instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz), and that time over the measured
+    step.  None when no counters of this round exist for the workload."""
+    tpath = os.path.join(ROOT, "profiles", "r02", f"traffic_{name}.json")
+    if not os.path.exists(tpath):
+        return None
+    with open(tpath) as fh:
+        tj = json.load(fh)
+    ks = {k: v for k, v in tj.get("kernels", {}).items() if v.get("valu_insts_per_launch")}
+    if tj.get("frames_per_launch") != n or not ks:
+        return None
+    to_ms = 4.0 / (256 * 4 * 2.4e9) * 1e3
+    total = sum(v["valu_insts_per_launch"] for v in ks.values())
+    top = max(ks, key=lambda k: ks[k]["valu_insts_per_launch"])
+    return {"valu_wave_instructions_per_step": total, "issue_ms": total * to_ms, "frac_of_step": total * to_ms / step_ms,
+            "dominant_kernel": {"name": top, "valu_per_frame": ks[top]["valu_insts_per_launch"] / n,
+                                "issue_ms": ks[top]["valu_insts_per_launch"] * to_ms, "measured_ms": ks[top].get("avg_ms"),
+                                "frac": ks[top]["valu_insts_per_launch"] * to_ms / ks[top]["avg_ms"] if ks[top].get("avg_ms") else None},
+            "model": "wave64 VALU instruction = 4 cycles of one SIMD; 1024 SIMDs at 2.4 GHz (MI355X_MICROARCH.md)",
+            "source": tj.get("measured_on")}
+
+
 def kernels_of(name):
     split = os.environ.get("OPUSGPU_SPLIT", "1") != "0"
     split_silk = split and os.environ.get("OPUSGPU_SPLIT_HYBRID", "1") != "0"
@@ -398,7 +422,8 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": f"decode step = {kernels_of(name)} (launched back to back)", "avg_launch_ms": avg_kernel_s * 1e3,
-                     "algorithmic_bytes_per_frame": bytes_per_frame, "frames_per_launch": n},
+                     "algorithmic_bytes_per_frame": bytes_per_frame, "frames_per_launch": n,
+                     "valu_issue": valu_issue_for(name, n, avg_kernel_s * 1e3)},
         "parity_check": parity,
     }
     if ingest is not None:

@@ -40,6 +40,8 @@ for kern in kernels:
         # rocprofv3 reports KiB; on gfx950 FETCH_SIZE reads half of what a wide stream fetches (MI355X_MICROARCH.md, HBM)
         traffic[kern] = {"fetch_size_kib": fetch, "write_size_kib": write, "hbm_bytes_per_launch": (2 * fetch + write) * 1024,
                          "avg_ms": durations.get(kern)}
+        if "SQ_INSTS_VALU" in acc:  # vector-ALU wave-instructions per launch: what bounds the kernels that are not HBM-bound
+            traffic[kern]["valu_insts_per_launch"] = sum(acc["SQ_INSTS_VALU"]) / len(acc["SQ_INSTS_VALU"])
     print(f"== {kern} ({frames} frames per launch)")
     for name in sorted(acc):
         v = sum(acc[name]) / len(acc[name])
