@@ -421,7 +421,11 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
         "x_realtime_per_gpu": value / world / 50.0,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": f"decode step = {kernels_of(name)} (launched back to back)", "avg_launch_ms": avg_kernel_s * 1e3,
+                     "kernel": f"decode step = {kernels_of(name)} (launched back to back" +
+                               ("; pipelined steps, opusgpu_set_pipeline: the next step's k_celt_parse of CELT-only frames runs on "
+                                "the library's second stream next to this step's k_celt_recon_fb / k_celt_post)"
+                                if args.pipeline == "on" else ")"),
+                     "pipeline": args.pipeline, "avg_launch_ms": avg_kernel_s * 1e3,
                      "algorithmic_bytes_per_frame": bytes_per_frame, "frames_per_launch": n,
                      "valu_issue": valu_issue_for(name, n, avg_kernel_s * 1e3)},
         "parity_check": parity,
@@ -457,6 +461,8 @@ def main():
                     help="mixed_pages_2m with --ingest per-rank: who verifies the page checksums")
     ap.add_argument("--ingest", default="per-rank", choices=["rank0", "per-rank"],
                     help="mixed_pages_2m: who demuxes the Ogg pages (rank 0 for all, or every rank its own share)")
+    ap.add_argument("--pipeline", default="on", choices=["on", "off"],
+                    help="opusgpu_set_pipeline: step k+1's CELT parse next to step k's reconstruction (tables resident, as here)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work of the headline workload's cpu_baseline sample")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -491,6 +497,7 @@ def main():
 
     pkg = load_pkg()
     ctx = pkg.Context(local_rank)
+    ctx.set_pipeline(args.pipeline == "on")
     main_out = run_workload(args.workload, args, ranks, pkg, ctx, n_override=args.streams)
     others = []
     if not args.no_other_configs and args.workload == "celt_fb_stereo_64k" and not args.streams:

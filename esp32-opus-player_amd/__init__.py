@@ -26,7 +26,7 @@ EXPORTS = [
     "opusgpu_event_elapsed_ms", "opusgpu_event_destroy", "opusgpu_stream_state_get",
     "opusgpu_pages_demux", "opusgpu_page_batch_steps", "opusgpu_page_batch_step", "opusgpu_page_batch_arena",
     "opusgpu_page_batch_free", "opusgpu_pages_crc_device", "opusgpu_output_stage_device",
-    "opusgpu_set_mode", "opusgpu_get_mode", "opusgpu_packet_to_frames_mode",
+    "opusgpu_set_mode", "opusgpu_get_mode", "opusgpu_set_pipeline", "opusgpu_get_pipeline", "opusgpu_packet_to_frames_mode",
 ]
 
 
@@ -100,6 +100,8 @@ def load_lib():
     lib.opusgpu_packet_to_frames_mode.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int, C.POINTER(FrameDesc)]
     lib.opusgpu_set_mode.argtypes = [vp, C.c_int]
     lib.opusgpu_get_mode.argtypes = [vp]
+    lib.opusgpu_set_pipeline.argtypes = [vp, C.c_int]
+    lib.opusgpu_get_pipeline.argtypes = [vp]
     lib.opusgpu_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.opusgpu_dev_free.argtypes = [vp, vp]
     lib.opusgpu_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
@@ -262,6 +264,11 @@ class Context:
     def set_mode(self, rfc):
         """RFC mode on / off (include/opusgpu.h, OPUSGPU_MODE_RFC): frames at the durations their TOC names."""
         self._chk(self.lib.opusgpu_set_mode(self.h, 1 if rfc else 0), "opusgpu_set_mode")
+
+    def set_pipeline(self, on):
+        """Pipelined decode steps (include/opusgpu.h, opusgpu_set_pipeline): step k+1's CELT parse next to step k's
+        reconstruction.  The tables of a decode_step_device call must then be complete in device memory at the call."""
+        self._chk(self.lib.opusgpu_set_pipeline(self.h, 1 if on else 0), "opusgpu_set_pipeline")
 
     def streams_reset(self, first, count, full=True):
         self._chk(self.lib.opusgpu_streams_reset(self.h, first, count, 1 if full else 0), "opusgpu_streams_reset")

@@ -348,9 +348,21 @@ __global__ void __launch_bounds__(64, OG_SPARSE_WAVES) k_silk_parse(const FrameD
 
 // Split CELT path, first half: ONE FRAME PER LANE.  Lane l < OG_PL_LANES (= 32) of workgroup g parses frame OG_PL_LANES g + l (range decoder,
 // energies, allocation, band budget logic, PVQ indices) into recs[frame]; no vector work, no cross-lane traffic.
+// `which`: PARSE_ALL, or one of the two launches of a pipelined step (opusgpu_set_pipeline): PARSE_CELT_ONLY runs ahead on the
+// library's own stream, PARSE_HYBRID_ONLY behind the step's k_silk_parse (it resumes the range decoder that kernel hands off).
+enum { PARSE_ALL = 0, PARSE_CELT_ONLY = 1, PARSE_HYBRID_ONLY = 2 };
 __global__ void __launch_bounds__(64, 2) k_celt_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
-                                                      const StreamState *st, ParseRec *recs, int n, int n_streams,
-                                                      const SilkHandoff *handoff) {
+                                                      StreamState *st, ParseRec *recs, int n, int n_streams,
+                                                      const SilkHandoff *handoff, int which) {
+    if (which != PARSE_ALL) { // a launch that finds none of its frames among the workgroup's leaves without loading the tables
+        const int f0 = (int)blockIdx.x * OG_PL_LANES + (int)threadIdx.x;
+        bool mine = false;
+        if ((int)threadIdx.x < OG_PL_LANES && f0 < n) {
+            const int m0 = desc_mode(descs[f0].flags);
+            mine = which == PARSE_CELT_ONLY ? m0 == MODE_CELT : m0 == MODE_HYBRID;
+        }
+        if (!__ballot(mine)) return;
+    }
     parse_tables_load();
     if ((int)threadIdx.x >= OG_PL_LANES) return;
     const int f = (int)blockIdx.x * OG_PL_LANES + (int)threadIdx.x;
@@ -358,6 +370,7 @@ __global__ void __launch_bounds__(64, 2) k_celt_parse(const FrameDesc *__restric
     const FrameDesc d = descs[f];
     const int mode = desc_mode(d.flags);
     if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && handoff)) || desc_rfc(d.flags)) return;
+    if ((which == PARSE_CELT_ONLY && mode != MODE_CELT) || (which == PARSE_HYBRID_ONLY && mode != MODE_HYBRID)) return;
 #ifdef OG_PROF_PARSE // profiling builds: time the sections of the parse kernel instead of the recon kernel (full batches only)
     OG_PROF_INIT();
 #endif
@@ -557,6 +570,14 @@ struct opusgpu_ctx {
     int split_hybrid = 1; // OPUSGPU_SPLIT_HYBRID=0 keeps SILK-only and hybrid frames entirely on the single-kernel path
     int fast_recon = 1;   // OPUSGPU_FAST_RECON=0: every CELT frame through the general reconstruction kernel (A/B measurements)
     int mode = OPUSGPU_MODE_REFERENCE; // opusgpu_set_mode
+    // opusgpu_set_pipeline: the parse of step k + 1's CELT-only frames runs on parse_stream, next to step k's reconstruction
+    int pipeline = 0, parity = 0, front_recorded = 0;
+    hipStream_t parse_stream = nullptr, last_step_stream = nullptr;
+    hipEvent_t ev_front = nullptr;  // step k: every writer of what a parse reads has finished (on the step's stream)
+    hipEvent_t ev_parsed = nullptr; // step k + 1: its early parse has finished (on parse_stream)
+    void *d_recs_b = nullptr;       // the second set of parse records (a step's reconstruction reads one, the next parse fills the other)
+    size_t cap_recs_b = 0;
+    const void *last_recs = nullptr;
     // the last decode step's tables, for opusgpu_debug_stage_taps
     const void *last_descs = nullptr;
     int last_n = 0, last_had_silk_recs = 0;
@@ -635,7 +656,9 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     (void)hipFree(ctx->d_arena);
     (void)hipFree(ctx->d_pcm);
     (void)hipFree(ctx->d_result);
+    if (ctx->parse_stream) (void)hipStreamSynchronize(ctx->parse_stream);
     (void)hipFree(ctx->d_recs);
+    (void)hipFree(ctx->d_recs_b);
     (void)hipFree(ctx->d_handoff);
     (void)hipFree(ctx->d_srecs);
     (void)hipHostFree(ctx->h_pcm);
@@ -646,6 +669,9 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     for (hipEvent_t e : ctx->ev_part)
         if (e) (void)hipEventDestroy(e);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->parse_stream) (void)hipStreamDestroy(ctx->parse_stream);
+    if (ctx->ev_front) (void)hipEventDestroy(ctx->ev_front);
+    if (ctx->ev_parsed) (void)hipEventDestroy(ctx->ev_parsed);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -657,6 +683,27 @@ int opusgpu_set_mode(opusgpu_ctx *ctx, int mode) {
     return OPUSGPU_OK;
 }
 int opusgpu_get_mode(const opusgpu_ctx *ctx) { return ctx ? ctx->mode : OPUSGPU_MODE_REFERENCE; }
+int opusgpu_set_pipeline(opusgpu_ctx *ctx, int on) {
+    if (!ctx) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (on && !ctx->parse_stream) {
+        // the early parse is a single round of long-running workgroups: it is placed first (highest priority), the
+        // reconstruction it runs next to fills the slots around it
+        int least = 0, greatest = 0;
+        HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        if (const char *e = getenv("OPUSGPU_PARSE_PRIORITY")) greatest = e[0] == '0' ? least : greatest;
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->parse_stream, hipStreamNonBlocking, greatest));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_parsed, hipEventDisableTiming));
+    }
+    if ((on != 0) != (ctx->pipeline != 0)) { // switching: from an idle device (steps of either kind may be queued on any stream)
+        HIPCHK(ctx, hipDeviceSynchronize());
+        ctx->front_recorded = 0;
+    }
+    ctx->pipeline = on ? 1 : 0;
+    return OPUSGPU_OK;
+}
+int opusgpu_get_pipeline(const opusgpu_ctx *ctx) { return ctx ? ctx->pipeline : 0; }
 size_t opusgpu_stream_state_bytes(void) { return sizeof(StreamState); }
 int opusgpu_stream_count(const opusgpu_ctx *ctx) { return ctx ? ctx->n_streams : 0; }
 int opusgpu_stream_channels(const opusgpu_ctx *ctx) { return ctx ? ctx->channels : 0; }
@@ -665,6 +712,8 @@ int opusgpu_streams_reset(opusgpu_ctx *ctx, int first, int count, int full) {
     if (!ctx || first < 0 || count < 0 || first + count > ctx->n_streams) return OPUSGPU_BAD_ARG;
     if (count == 0) return OPUSGPU_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->parse_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->parse_stream));
+    ctx->front_recorded = 0; // (the reset below is synchronous: the next early parse has nothing to wait for)
     hipLaunchKernelGGL(k_stream_init, dim3(count), dim3(64), 0, ctx->stream, ctx->d_streams, first, count, ctx->channels,
                        full ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
@@ -721,8 +770,11 @@ int opusgpu_memcpy_d2h(opusgpu_ctx *ctx, void *dst, const void *src, size_t byte
     return OPUSGPU_OK;
 }
 
-int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm,
-                               void *d_result, void *hip_stream) {
+// `tables_resident`: the step's descriptors and payload bytes are complete in device memory now (the public entry's contract
+// when pipelining is on); false when this call's own uploads are still queued on the step's stream (opusgpu_decode_packets):
+// such a step does not run ahead of anything.
+static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm, void *d_result,
+                            void *hip_stream, bool tables_resident) {
     if (!ctx || n < 0 || !ctx->d_streams) return OPUSGPU_BAD_ARG;
     if (n == 0) return OPUSGPU_OK;
     if (!d_descs || !d_arena || !d_pcm || !d_result) return OPUSGPU_BAD_ARG;
@@ -735,15 +787,35 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
         HIPCHK(ctx, hipSetDevice(ctx->device));
         og_launch_decode_rfc(s, d_descs, d_arena, ctx->d_streams, d_pcm, d_result, n, ctx->n_streams, pcm_stride);
         HIPCHK(ctx, hipGetLastError());
+        if (ctx->pipeline) { // (a later pipelined step's early parse waits for all of this one)
+            HIPCHK(ctx, hipEventRecord(ctx->ev_front, s));
+            ctx->front_recorded = 1;
+        }
+        ctx->last_step_stream = s;
         return OPUSGPU_OK;
     }
     SilkHandoff *handoff = nullptr;
     SilkRec *srecs = nullptr;
+    const bool pipe = ctx->pipeline && ctx->split_celt && tables_resident;
+    if (ctx->pipeline && ctx->last_step_stream && ctx->last_step_stream != s) {
+        // consecutive steps on different streams: nothing orders them but the caller, so nothing may run ahead either
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->last_step_stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->parse_stream));
+        ctx->front_recorded = 0;
+    }
+    ctx->last_step_stream = s;
+    void **recs_slot = &ctx->d_recs;
+    size_t *recs_cap = &ctx->cap_recs;
+    if (pipe) {
+        ctx->parity ^= 1;
+        if (ctx->parity) { recs_slot = &ctx->d_recs_b; recs_cap = &ctx->cap_recs_b; }
+    }
     if (ctx->split_celt) {
         // The records / hand-off buffers only grow; growing frees the old one, which waits for the device to go idle.
-        if (ctx->cap_recs < sizeof(ParseRec) * (size_t)n) {
+        if (*recs_cap < sizeof(ParseRec) * (size_t)n) {
             HIPCHK(ctx, hipSetDevice(ctx->device));
-            const int rc = grow(ctx, &ctx->d_recs, &ctx->cap_recs, sizeof(ParseRec) * (size_t)n);
+            const int rc = grow(ctx, recs_slot, recs_cap, sizeof(ParseRec) * (size_t)n);
             if (rc) return rc;
         }
         if (ctx->split_hybrid) {
@@ -772,11 +844,30 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
     // 5 % on mixed-mode steps but costs 13 % on CELT-only steps -- k_celt_parse is a single round of long-running
     // workgroups, and anything occupying slots while it starts (even 65,536 workgroups that exit at once) leaves it
     // unevenly placed for its whole duration (0.86 -> 1.35 ms).  It therefore starts behind the tiny k_silk_parse only.
-    if (ctx->split_celt) {
+    // A pipelined step (opusgpu_set_pipeline):
+    //   parse_stream:  [wait: front of step k-1]  k_celt_parse[CELT-only frames]
+    //   step's stream: k_silk_parse  k_celt_parse[hybrid frames]  k_silk_synth  k_decode_step[Q4]  [front of step k]
+    //                  [wait: early parse]  k_celt_recon_fb  k_celt_recon  k_celt_post
+    // "front": every kernel that writes what a parse kernel reads -- CeltState::bandE (k_celt_parse itself, and the full
+    // kernel), the SILK state and prev_mode of streams k_silk_parse looks at (k_silk_synth, the full kernel) -- has run.
+    // The reconstruction and the de-emphasis of step k write none of that, so step k+1's CELT-only parse runs next to them.
+    ParseRec *const recs = (ParseRec *)*recs_slot;
+    ctx->last_recs = recs;
+    if (ctx->split_celt && !pipe) {
         // CELT-only frames and the CELT half of hybrid frames: parse (one frame per lane) -> records in HBM
         hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_LANES - 1) / OG_PL_LANES), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
-                           (const StreamState *)ctx->d_streams, (ParseRec *)ctx->d_recs, n, ctx->n_streams,
-                           (const SilkHandoff *)handoff);
+                           ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)handoff, (int)PARSE_ALL);
+    }
+    if (pipe) {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        if (ctx->front_recorded) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_front, 0));
+        hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_LANES - 1) / OG_PL_LANES), dim3(64), 0, ctx->parse_stream, (const FrameDesc *)d_descs,
+                           (const u8 *)d_arena, ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)nullptr, (int)PARSE_CELT_ONLY);
+        HIPCHK(ctx, hipEventRecord(ctx->ev_parsed, ctx->parse_stream));
+        if (handoff)
+            hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_LANES - 1) / OG_PL_LANES), dim3(64), 0, s, (const FrameDesc *)d_descs,
+                               (const u8 *)d_arena, ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)handoff,
+                               (int)PARSE_HYBRID_ONLY);
     }
     if (srecs) {
         // SILK-only frames and the SILK half of hybrid frames: arithmetic half, one frame per wave (also reports
@@ -789,26 +880,43 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
                            ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, ctx->split_celt, nullptr,
                            nullptr, 0);
     }
-    if (ctx->split_celt) {
-        // reconstruct (one frame per wave) -> de-emphasis, SILK mix and PCM (one (frame, channel) per lane)
-        if (ctx->fast_recon)
-            og_launch_celt_recon_fb(s, d_descs, ctx->d_streams, ctx->d_recs, d_result, n, ctx->n_streams, handoff ? 1 : 0);
-        hipLaunchKernelGGL(k_celt_recon, dim3(ctx->fast_recon ? (n + 63) / 64 : n), dim3(64), 0, s, (const FrameDesc *)d_descs,
-                           ctx->d_streams, (const ParseRec *)ctx->d_recs, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride,
-                           handoff ? 1 : 0, ctx->fast_recon);
-        hipLaunchKernelGGL(k_celt_post, dim3((n * ctx->channels + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs,
-                           ctx->d_streams, (const ParseRec *)ctx->d_recs, (const i32 *)d_result, (i16 *)d_pcm, n, ctx->n_streams,
-                           ctx->channels, pcm_stride, (const SilkHandoff *)handoff);
-    }
-    if (srecs) {
+    auto q4_pass = [&]() {
         // The rare hybrid -> SILK-only transition frames (Q4), parked by k_silk_synth, through the full kernel.  Nothing in
-        // the step waits for it and almost all of its workgroups exit at once: it goes last.
+        // the step waits for it and almost all of its workgroups exit at once: it goes last (pipelined steps: before the
+        // reconstruction, because the next step's parse waits for it).
         hipLaunchKernelGGL(k_decode_step, dim3((n + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
                            ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, 1, handoff,
                            (const SilkRec *)srecs, 1);
+    };
+    if (pipe) {
+        if (srecs) q4_pass();
+        HIPCHK(ctx, hipEventRecord(ctx->ev_front, s));
+        ctx->front_recorded = 1;
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_parsed, 0));
     }
+    if (ctx->split_celt) {
+        // reconstruct (one frame per wave) -> de-emphasis, SILK mix and PCM (one (frame, channel) per lane)
+        if (ctx->fast_recon)
+            og_launch_celt_recon_fb(s, d_descs, ctx->d_streams, recs, d_result, n, ctx->n_streams, handoff ? 1 : 0);
+        hipLaunchKernelGGL(k_celt_recon, dim3(ctx->fast_recon ? (n + 63) / 64 : n), dim3(64), 0, s, (const FrameDesc *)d_descs,
+                           ctx->d_streams, (const ParseRec *)recs, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride,
+                           handoff ? 1 : 0, ctx->fast_recon);
+        hipLaunchKernelGGL(k_celt_post, dim3((n * ctx->channels + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs,
+                           ctx->d_streams, (const ParseRec *)recs, (const i32 *)d_result, (i16 *)d_pcm, n, ctx->n_streams,
+                           ctx->channels, pcm_stride, (const SilkHandoff *)handoff);
+    }
+    if (srecs && !pipe) q4_pass();
     HIPCHK(ctx, hipGetLastError());
+    if (ctx->pipeline && !pipe) { // a step that ran in order: a later pipelined step's early parse waits for all of it
+        HIPCHK(ctx, hipEventRecord(ctx->ev_front, s));
+        ctx->front_recorded = 1;
+    }
     return OPUSGPU_OK;
+}
+
+int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm,
+                               void *d_result, void *hip_stream) {
+    return decode_step_impl(ctx, n, d_descs, d_arena, d_pcm, d_result, hip_stream, true);
 }
 
 #ifdef OG_PROF
@@ -924,10 +1032,10 @@ int opusgpu_debug_stage_taps(opusgpu_ctx *ctx, int slot, opusgpu_stage_taps *out
     std::unique_ptr<StreamState> st(new (std::nothrow) StreamState);
     if (!st) return OPUSGPU_ALLOC_FAIL;
     HIPCHK(ctx, hipMemcpy(st.get(), &ctx->d_streams[d.stream], sizeof(StreamState), hipMemcpyDeviceToHost));
-    if (mode != MODE_SILK && ctx->d_recs) {
+    if (mode != MODE_SILK && ctx->last_recs) {
         std::unique_ptr<ParseRec> r(new (std::nothrow) ParseRec);
         if (!r) return OPUSGPU_ALLOC_FAIL;
-        HIPCHK(ctx, hipMemcpy(r.get(), (const ParseRec *)ctx->d_recs + slot, sizeof(ParseRec), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(r.get(), (const ParseRec *)ctx->last_recs + slot, sizeof(ParseRec), hipMemcpyDeviceToHost));
         out->celt_valid = 1;
         out->celt_ret = r->ret;
         out->silence = (r->flags & RF_SILENCE) != 0;
@@ -1286,8 +1394,8 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
                         HIPCHK(ctx, hipMemcpyAsync((opusgpu_frame_desc *)ctx->d_descs + flo, all.get() + flo,
                                                    sizeof(opusgpu_frame_desc) * (fhi - flo), hipMemcpyHostToDevice, ctx->stream));
                 }
-                rc = opusgpu_decode_step_device(ctx, (int)(fhi - flo), (const opusgpu_frame_desc *)ctx->d_descs + flo, ctx->d_arena,
-                                                (uint8_t *)ctx->d_pcm + flo * frame_pcm * 2, (int32_t *)ctx->d_result + flo, nullptr);
+                rc = decode_step_impl(ctx, (int)(fhi - flo), (const opusgpu_frame_desc *)ctx->d_descs + flo, ctx->d_arena,
+                                      (uint8_t *)ctx->d_pcm + flo * frame_pcm * 2, (int32_t *)ctx->d_result + flo, nullptr, false);
                 if (rc) return rc; // (an empty part launches nothing; its pieces' events are still recorded below)
                 HIPCHK(ctx, hipEventRecord(ctx->ev_part[h], ctx->stream));
                 HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_part[h], 0));
@@ -1295,7 +1403,7 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
             }
             timer.mark("table upload + kernels + copy-back in parts (enqueue)");
         } else {
-            rc = opusgpu_decode_step_device(ctx, m, ctx->d_descs, ctx->d_arena, ctx->d_pcm, ctx->d_result, nullptr);
+            rc = decode_step_impl(ctx, m, ctx->d_descs, ctx->d_arena, ctx->d_pcm, ctx->d_result, nullptr, false);
             if (rc) return rc;
             timer.mark("table upload + kernels (enqueue)");
             if (timer.on) {

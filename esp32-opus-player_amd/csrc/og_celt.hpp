@@ -913,6 +913,7 @@ struct CeltSynth {
     int inline_deemph; // 1: de-emphasis + PCM planes here (single-kernel path); 0: left to celt_post_lane (split path)
     LossState *loss;   // RFC mode: the noise floor follows the decoded energies and the loss counter restarts (celt.cpp:2411-2440)
     int lost;          // a concealed frame (celt_decode_lost): the energy histories, the post-filter and its state stay as they are
+    int energies_kept_by_parse = 0; // split path: CeltState::bandE is written by the parse kernel (celt_parse_lane), not here
 };
 
 // De-emphasis and float-to-int16 of one channel of one frame, lane-private (celt.cpp:1965-2055, sig2word16 celt.h:413):
@@ -1057,7 +1058,7 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
             e = 0;
             l1 = l2 = -28 * 1024;
         }
-        st->bandE[i] = (i16)e;
+        if (!p.energies_kept_by_parse) st->bandE[i] = (i16)e;
         st->logE1[i] = (i16)l1;
         st->logE2[i] = (i16)l2;
     }

@@ -453,7 +453,10 @@ OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C
 // One CELT-only frame, lane-private.  `payload`/`len`: the frame's bytes; `ch`: channels coded in the packet,
 // CC: decoder channels.  Mirrors decode_frame_wave + celt_decode_frame up to (not including) every vector operation.
 // `handoff` (hybrid frames): resume the range decoder where the SILK half left it and start at band 17.
-OG_DEV void celt_parse_lane(const StreamState *st, const u8 *payload, int len, int ch, ParseRec *rec, const SilkHandoff *handoff) {
+// The stream's band energies (CeltState::bandE) are carried from frame to frame HERE, not by the reconstruction: they are the only
+// stream state this half reads, so the parse of a stream's next frame depends on nothing but the parse of this one and may run
+// while this frame is still being reconstructed (opusgpu_set_pipeline, og_api.hip).
+OG_DEV void celt_parse_lane(StreamState *st, const u8 *payload, int len, int ch, ParseRec *rec, const SilkHandoff *handoff) {
     const LaneArr a;
     const int CC = st->channels, C = ch, LM = 3, frame_size = 960, start = handoff ? 17 : 0, end = NBANDS;
     rec->start = start;
@@ -527,6 +530,17 @@ OG_DEV void celt_parse_lane(const StreamState *st, const u8 *payload, int len, i
     rec->pf_tapset = h.pf_tapset;
     rec->n_leaves = OG_MIN(out.nl, REC_MAX_LEAVES);
     rec->n_words = OG_MIN(out.nw, REC_MAX_WORDS);
+    // the energies the next frame predicts from, as celt_synthesis leaves them (celt.cpp:2404-2436): -28 dB in a silent frame,
+    // a mono frame's in both channels, zero outside start .. end.  Two bands per store.
+    for (int i = 0; i < 2 * NBANDS; i += 2) {
+        i32 e[2];
+        for (int k = 0; k < 2; k++) {
+            const int band = i + k >= NBANDS ? i + k - NBANDS : i + k;
+            e[k] = h.silence ? -28 * 1024 : (i32)a.bandE(C == 1 ? band : i + k);
+            if (band < start || band >= end) e[k] = 0;
+        }
+        *reinterpret_cast<u32 *>(&st->celt.bandE[i]) = (u32)(u16)e[0] | (u32)(u16)e[1] << 16;
+    }
 }
 
 // =====================================================================================================
@@ -1747,7 +1761,7 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         sp.N = N; sp.LM = LM; sp.C = C; sp.CC = CC; sp.start = start; sp.end = end; sp.silence = silence; sp.transient = transient;
         sp.pf_pitch = OG_UNI(rec->pf_pitch); sp.pf_tapset = OG_UNI(rec->pf_tapset); sp.pf_gain = OG_UNI(rec->pf_gain);
         sp.rng_final = rng_final; sp.rc_error = (flags & RF_RC_ERROR) != 0; sp.inline_deemph = 0;
-        sp.loss = nullptr; sp.lost = 0;
+        sp.loss = nullptr; sp.lost = 0; sp.energies_kept_by_parse = 1;
         OG_MARK(13);
         celt_synthesis(cs, sp);
         OG_MARK(17);

@@ -86,6 +86,23 @@ const char *opusgpu_last_error(const opusgpu_ctx *ctx);
 int opusgpu_set_mode(opusgpu_ctx *ctx, int mode);
 int opusgpu_get_mode(const opusgpu_ctx *ctx);
 
+/* Pipelined decode steps (off by default).  A stream's frames are sequential, but only two things tie step k+1 to step k
+ * before its reconstruction: the range decoder of a CELT frame predicts the band energies from the previous frame's, and
+ * the SILK half reads the SILK state.  With pipelining on, the library carries the band energies in the parse kernel
+ * (k_celt_parse) and runs that kernel for step k+1's CELT-only frames on a stream of its own, NEXT TO step k's
+ * reconstruction (k_celt_recon_fb / k_celt_post), into a second set of parse records; the step's own stream waits for it
+ * before reconstructing.  Results are bit-identical to the in-order flow (tests/test_gpu_pipeline.py); the step's stream
+ * still completes everything the step launched, so the caller synchronises exactly as before.
+ * What the caller additionally guarantees while it is on, for opusgpu_decode_step_device:
+ *   - d_descs and d_arena of a call are COMPLETE in device memory when the call is made (uploaded and synchronised, or
+ *     produced by work that has finished) -- not merely queued on `hip_stream` ahead of the call;
+ *   - consecutive steps use the same stream (a change of stream is honoured by draining both, i.e. no overlap).
+ * opusgpu_decode_packets (whose uploads are queued by the call itself) runs in order regardless.  Switching synchronises
+ * the device.  Reference: the per-packet call sequence this replaces is src/opus_decoder.cpp:931 -> :280 -> :154 ->
+ * src/celt.cpp:2162, one packet at a time; there is nothing to pipeline there. */
+int opusgpu_set_pipeline(opusgpu_ctx *ctx, int on);
+int opusgpu_get_pipeline(const opusgpu_ctx *ctx);
+
 /* ---- streams -------------------------------------------------------------------------------- */
 /* Allocates `n_streams` per-stream state records in HBM (replacing any previous set) and gives each
  * the fresh state of opus_multistream_decoder_init(48000, channels, 1, channels-1, {0,1})

@@ -1,0 +1,146 @@
+"""GPU parity of PIPELINED decode steps (opusgpu_set_pipeline, include/opusgpu.h): step k+1's CELT parse runs on the library's
+own stream next to step k's reconstruction.  All steps of a run are queued back to back with no synchronisation in between
+(so the overlap really happens), every PCM sample and return code is compared with the oracle, which decodes packet after
+packet as the reference does (src/opus_decoder.cpp:931 -> :280 -> :154)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = np.array([1, 5, 9, 13, 15, 19, 23, 27, 31])  # the 20 ms configuration of every mode / bandwidth
+LENS = np.array([0, 1, 2, 3, 5, 8, 13, 20, 30, 40, 60, 80, 100, 120, 160, 200, 320, 500, 800, 1275])
+
+
+def make_walk(rng, n, frames, channels, configs=CONFIGS, p_home=0.8):
+    """Random per-stream sequences of 20 ms packets: arena bytes, per-frame offsets / packet lengths / TOCs."""
+    home = rng.choice(configs, n)
+    cfg = np.where(rng.random((frames, n)) < p_home, home[None, :], rng.choice(configs, (frames, n)))
+    stereo = rng.random((frames, n)) < (0.85 if channels == 2 else 0.15)
+    toc = (cfg << 3 | np.where(stereo, 4, 0)).astype(np.uint8)
+    lens = rng.choice(LENS, (frames, n), p=np.r_[np.full(4, 0.02), np.full(15, 0.06), 0.02])
+    plen = (lens + 1).astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(plen.reshape(-1))[:-1]]).reshape(frames, n)
+    arena = rng.integers(0, 256, int(plen.sum()) + 16, dtype=np.uint8)
+    arena[offs.reshape(-1)] = toc.reshape(-1)
+    return arena, offs, plen, lens, toc
+
+
+def desc_flags(toc):
+    mode = np.where(toc & 0x80, 2, np.where((toc & 0x60) == 0x60, 1, 0)).astype(np.int32)
+    bw_c = ((toc >> 5) & 3).astype(np.int32)
+    bw = np.where(mode == 2, np.where(bw_c == 0, 0, bw_c + 1), np.where(mode == 1, np.where(toc & 0x10, 4, 3), bw_c))
+    return (mode | bw << 2 | np.where(toc & 4, 32, 0)).astype(np.int32), mode
+
+
+def run_queued(pkg, ctx, channels, arena, offs, lens, toc, pipeline, sync_every=0, reset_at=None):
+    """All steps queued back to back (tables of every step resident before the first call).  Returns PCM [frames, n, 960*ch]
+    and result codes [frames, n]."""
+    frames, n = offs.shape
+    flags, _ = desc_flags(toc)
+    ctx.streams_alloc(n, channels)
+    ctx.set_pipeline(pipeline)
+    frame_bytes = n * 960 * channels * 2
+    d_arena = ctx.dev_alloc(arena.size)
+    d_desc = [ctx.dev_alloc(16 * n) for _ in range(frames)]
+    d_pcm = [ctx.dev_alloc(frame_bytes) for _ in range(frames)]
+    d_res = [ctx.dev_alloc(4 * n) for _ in range(frames)]
+    ctx.h2d(d_arena, arena)
+    descs = np.zeros(n, dtype=pkg.DESC_DTYPE)
+    descs["stream"] = np.arange(n, dtype=np.int32)
+    for f in range(frames):
+        descs["offset"] = (offs[f] + 1).astype(np.int32)
+        descs["len"] = lens[f].astype(np.int32)
+        descs["flags"] = flags[f]
+        ctx.h2d(d_desc[f], descs)  # (synchronous: complete in device memory before any step is queued)
+    for f in range(frames):
+        if reset_at is not None and f == reset_at:
+            ctx.streams_reset(0, n, full=False)
+        ctx.decode_step_device(n, d_desc[f], d_arena, d_pcm[f], d_res[f])
+        if sync_every and (f + 1) % sync_every == 0:
+            ctx.synchronize()
+    ctx.synchronize()
+    pcm = np.zeros((frames, n, 960 * channels), dtype=np.int16)
+    res = np.zeros((frames, n), dtype=np.int32)
+    for f in range(frames):
+        ctx.d2h(pcm[f], d_pcm[f])
+        ctx.d2h(res[f], d_res[f])
+    for p in [d_arena] + d_desc + d_pcm + d_res:
+        ctx.dev_free(p)
+    ctx.set_pipeline(False)
+    return pcm, res
+
+
+def compare(pcm, res, ref, rets, toc, channels):
+    """ref [n, frames, 960, ch], rets [n, frames] from the oracle.  Returns the number of (frame, stream) blocks that differ."""
+    frames, n = res.shape
+    _, mode = desc_flags(toc)
+    bad = 0
+    for f in range(frames):
+        bad += int((res[f] != rets[:, f]).sum())
+        ok = rets[:, f] == 960
+        half = ok & (mode[f] == 0) & ((toc[f] & 4) == 0) & (channels == 2)  # Q3: only 960 interleaved entries are defined
+        full = ok & ~half
+        a, b = pcm[f], ref[:, f].reshape(n, -1)
+        bad += int((a[full] != b[full]).any(axis=1).sum())
+        if half.any():
+            bad += int((a[half][:, :960] != b[half][:, :960]).any(axis=1).sum())
+    return bad
+
+
+@pytest.mark.parametrize("channels", [2, 1])
+def test_pipelined_steps_random_mode_walks(pkg, oracle, gpu_ctx, channels):
+    """Every mode / bandwidth, switches between frames (incl. the hybrid -> SILK-only transition frames, Q4, whose full-kernel
+    pass writes the band energies a following CELT parse reads), payloads of 0 .. 1275 bytes."""
+    rng = np.random.default_rng(4100 + channels)
+    n, frames = 3072, 14
+    arena, offs, plen, lens, toc = make_walk(rng, n, frames, channels)
+    ref, rets = oracle.batch_decode_var(channels, arena, offs, plen.astype(np.int32))
+    pcm, res = run_queued(pkg, gpu_ctx, channels, arena, offs, lens, toc, pipeline=True)
+    assert compare(pcm, res, ref, rets, toc, channels) == 0
+    # and so is the in-order flow through the same harness
+    pcm0, res0 = run_queued(pkg, gpu_ctx, channels, arena, offs, lens, toc, pipeline=False)
+    assert compare(pcm0, res0, ref, rets, toc, channels) == 0
+
+
+def test_pipelined_celt_only_and_hybrid(pkg, oracle, gpu_ctx):
+    """The two workloads the overlap is for: CELT-only FB (the whole parse runs ahead) and hybrid FB (its parse stays behind the
+    step's SILK parse); long enough for the double-buffered records to be reused several times."""
+    for toc_byte, L in ((pkg.TOC_CELT_FB_STEREO, 160), (pkg.TOC_HYBRID_FB_STEREO, 120)):
+        n, frames = 4096, 10
+        pay = pkg.lcg_payloads(n, frames, L, seed_base=0x5150 + toc_byte)
+        ref, ok = oracle.batch_decode(2, toc_byte, pay)
+        assert ok == n * frames
+        plen = np.full((frames, n), L + 1, dtype=np.int64)
+        offs = np.arange(frames * n, dtype=np.int64).reshape(frames, n) * (L + 1)
+        arena = np.zeros(frames * n * (L + 1) + 16, dtype=np.uint8)
+        blk = arena[: frames * n * (L + 1)].reshape(frames, n, L + 1)
+        blk[:, :, 0] = toc_byte
+        blk[:, :, 1:] = pay
+        toc = np.full((frames, n), toc_byte, dtype=np.uint8)
+        pcm, res = run_queued(pkg, gpu_ctx, 2, arena, offs, plen - 1, toc, pipeline=True)
+        assert (res == 960).all()
+        assert np.array_equal(pcm.reshape(frames, n, 960, 2).transpose(1, 0, 2, 3), ref)
+
+
+def test_pipeline_with_synchronisation_points_and_reset(pkg, oracle, gpu_ctx):
+    """Synchronising between some steps and resetting the streams in the middle (OPUS_RESET_STATE keeps the band energies, Q5)
+    changes nothing; neither does switching the option off and on between runs."""
+    rng = np.random.default_rng(4200)
+    n, frames, channels = 1024, 10, 2
+    arena, offs, plen, lens, toc = make_walk(rng, n, frames, channels, configs=np.array([27, 31, 15, 31, 31]))
+    decs = [oracle.decoder(channels) for _ in range(64)]
+    pcm, res = run_queued(pkg, gpu_ctx, channels, arena, offs, lens, toc, pipeline=True, sync_every=3, reset_at=5)
+    pcm0, res0 = run_queued(pkg, gpu_ctx, channels, arena, offs, lens, toc, pipeline=False, reset_at=5)
+    assert np.array_equal(res, res0)
+    ok = res0 == 960
+    assert np.array_equal(pcm[ok], pcm0[ok])
+    for s, d in enumerate(decs):  # and a sample of the streams against the oracle, reset included
+        d.init()
+        for f in range(frames):
+            if f == 5:
+                d.reset()
+            o = int(offs[f, s])
+            out, r = d.decode(arena[o:o + int(plen[f, s])].tobytes())
+            assert r == res[f, s]
+            if r == 960:
+                assert np.array_equal(out[:960].reshape(-1), pcm[f, s])

@@ -6,7 +6,9 @@ usage (GPU box): python3 tools/soak_parity.py [streams] [frames] [rounds] [seed]
        --host: through opusgpu_decode_packets instead, packets of every frame-count code (1 - 48 frames, padding, VBR / CBR,
        some malformed), every configuration incl. the non-20 ms ones, room for three frames per call
        --rfc: RFC mode (true frame durations, all 32 configurations x codes 0..3) with 25 % lost packets, 6 % DTX packets and 10 % of the packets preceded by a recovery from their FEC data,
-       through opusgpu_decode_packets against one oracle decoder per stream (tests/test_gpu_rfc.py's comparison, larger)"""
+       through opusgpu_decode_packets against one oracle decoder per stream (tests/test_gpu_rfc.py's comparison, larger)
+       --pipeline: the device-resident path with pipelined steps (opusgpu_set_pipeline): the tables of every step are uploaded
+       first, all steps of a round are queued back to back (one PCM buffer per step), compared afterwards"""
 import importlib.util
 import os
 import sys
@@ -28,6 +30,9 @@ if HOST:
 RFC = "--rfc" in sys.argv
 if RFC:
     sys.argv.remove("--rfc")
+PIPE = "--pipeline" in sys.argv
+if PIPE:
+    sys.argv.remove("--pipeline")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
@@ -161,18 +166,34 @@ for rnd in range(rounds):
         ctx.streams_alloc(n, channels)
         d_arena = ctx.dev_alloc(arena.size)
         ctx.h2d(d_arena, arena)
-        d_desc, d_pcm, d_res = ctx.dev_alloc(16 * n), ctx.dev_alloc(n * 960 * channels * 2), ctx.dev_alloc(4 * n)
         out = np.zeros((n, 960, channels), dtype=np.int16)
         res = np.zeros(n, dtype=np.int32)
         descs = np.zeros(n, dtype=pkg.DESC_DTYPE)
         descs["stream"] = np.arange(n, dtype=np.int32)
-        for f in range(frames):
+        nbuf = frames if PIPE else 1
+        d_descs = [ctx.dev_alloc(16 * n) for _ in range(nbuf)]
+        d_pcms = [ctx.dev_alloc(n * 960 * channels * 2) for _ in range(nbuf)]
+        d_ress = [ctx.dev_alloc(4 * n) for _ in range(nbuf)]
+
+        def upload(f, d):
             descs["offset"] = (offs[f] + 1).astype(np.int32)
             descs["len"] = lens[f].astype(np.int32)
             descs["flags"] = flags[f]
-            ctx.h2d(d_desc, descs)
-            ctx.decode_step_device(n, d_desc, d_arena, d_pcm, d_res)
+            ctx.h2d(d, descs)
+
+        ctx.set_pipeline(PIPE)
+        if PIPE:
+            for f in range(frames):
+                upload(f, d_descs[f])
+            for f in range(frames):
+                ctx.decode_step_device(n, d_descs[f], d_arena, d_pcms[f], d_ress[f])
             ctx.synchronize()
+        for f in range(frames):
+            d_desc, d_pcm, d_res = d_descs[f % nbuf], d_pcms[f % nbuf], d_ress[f % nbuf]
+            if not PIPE:
+                upload(f, d_desc)
+                ctx.decode_step_device(n, d_desc, d_arena, d_pcm, d_res)
+                ctx.synchronize()
             ctx.d2h(out, d_pcm)
             ctx.d2h(res, d_res)
             code_bad = np.nonzero(res != rets[:, f])[0]
@@ -190,8 +211,8 @@ for rnd in range(rounds):
             bad_total += nb
             total += n
             errs += int((rets[:, f] != 960).sum())
-        for p in (d_arena, d_desc, d_pcm, d_res):
+        for p in [d_arena] + d_descs + d_pcms + d_ress:
             ctx.dev_free(p)
         print(f"round {rnd} channels {channels}: {n * frames} frames done, {bad_total} mismatches so far, {time.time() - t_start:.0f} s", flush=True)
-print(f"SOAK: {total} frames compared ({errs} of them error returns, compared as codes), {bad_total} mismatches")
+print(f"SOAK{' (pipelined steps)' if PIPE else ''}: {total} frames compared ({errs} of them error returns, compared as codes), {bad_total} mismatches")
 sys.exit(1 if bad_total else 0)
