@@ -346,27 +346,26 @@ __global__ void __launch_bounds__(64, OG_SPARSE_WAVES) k_silk_parse(const FrameD
 #endif
 }
 
-// Split CELT path, first half: ONE FRAME PER LANE.  Lane l < OG_PL_LANES (= 32) of workgroup g parses frame OG_PL_LANES g + l (range decoder,
+// Split CELT path, first half: ONE FRAME PER LANE.  Lane l < OG_PL_LANES (= 32) of wave w of workgroup g parses frame OG_PL_FRAMES g + OG_PL_LANES w + l (range decoder,
 // energies, allocation, band budget logic, PVQ indices) into recs[frame]; no vector work, no cross-lane traffic.
 // `which`: PARSE_ALL, or one of the two launches of a pipelined step (opusgpu_set_pipeline): PARSE_CELT_ONLY runs ahead on the
 // library's own stream, PARSE_HYBRID_ONLY behind the step's k_silk_parse (it resumes the range decoder that kernel hands off).
 enum { PARSE_ALL = 0, PARSE_CELT_ONLY = 1, PARSE_HYBRID_ONLY = 2 };
-__global__ void __launch_bounds__(64, 2) k_celt_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
+__global__ void __launch_bounds__(64 * OG_PL_WAVES, 2) k_celt_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
                                                       StreamState *st, ParseRec *recs, int n, int n_streams,
                                                       const SilkHandoff *handoff, int which) {
+    const bool lane_on = (int)(threadIdx.x & 63) < OG_PL_LANES;
+    const int f = (int)blockIdx.x * OG_PL_FRAMES + OG_PWAVE * OG_PL_LANES + OG_PCOL;
     if (which != PARSE_ALL) { // a launch that finds none of its frames among the workgroup's leaves without loading the tables
-        const int f0 = (int)blockIdx.x * OG_PL_LANES + (int)threadIdx.x;
         bool mine = false;
-        if ((int)threadIdx.x < OG_PL_LANES && f0 < n) {
-            const int m0 = desc_mode(descs[f0].flags);
+        if (lane_on && f < n) {
+            const int m0 = desc_mode(descs[f].flags);
             mine = which == PARSE_CELT_ONLY ? m0 == MODE_CELT : m0 == MODE_HYBRID;
         }
-        if (!__ballot(mine)) return;
+        if (!__syncthreads_or(mine)) return;
     }
     parse_tables_load();
-    if ((int)threadIdx.x >= OG_PL_LANES) return;
-    const int f = (int)blockIdx.x * OG_PL_LANES + (int)threadIdx.x;
-    if (f >= n) return;
+    if (!lane_on || f >= n) return;
     const FrameDesc d = descs[f];
     const int mode = desc_mode(d.flags);
     if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && handoff)) || desc_rfc(d.flags)) return;
@@ -855,17 +854,17 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     ctx->last_recs = recs;
     if (ctx->split_celt && !pipe) {
         // CELT-only frames and the CELT half of hybrid frames: parse (one frame per lane) -> records in HBM
-        hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_LANES - 1) / OG_PL_LANES), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
+        hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_FRAMES - 1) / OG_PL_FRAMES), dim3(64 * OG_PL_WAVES), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
                            ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)handoff, (int)PARSE_ALL);
     }
     if (pipe) {
         HIPCHK(ctx, hipSetDevice(ctx->device));
         if (ctx->front_recorded) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_front, 0));
-        hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_LANES - 1) / OG_PL_LANES), dim3(64), 0, ctx->parse_stream, (const FrameDesc *)d_descs,
+        hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_FRAMES - 1) / OG_PL_FRAMES), dim3(64 * OG_PL_WAVES), 0, ctx->parse_stream, (const FrameDesc *)d_descs,
                            (const u8 *)d_arena, ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)nullptr, (int)PARSE_CELT_ONLY);
         HIPCHK(ctx, hipEventRecord(ctx->ev_parsed, ctx->parse_stream));
         if (handoff)
-            hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_LANES - 1) / OG_PL_LANES), dim3(64), 0, s, (const FrameDesc *)d_descs,
+            hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_FRAMES - 1) / OG_PL_FRAMES), dim3(64 * OG_PL_WAVES), 0, s, (const FrameDesc *)d_descs,
                                (const u8 *)d_arena, ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)handoff,
                                (int)PARSE_HYBRID_ONLY);
     }

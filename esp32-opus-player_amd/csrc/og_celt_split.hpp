@@ -100,6 +100,22 @@ static_assert(sizeof(ParseRec) % 16 == 0, "record alignment");
 #ifndef OG_PL_LANES
 #define OG_PL_LANES (OG_NLANES >= 32 ? 32 : OG_NLANES) // measured: 64 / 32 / 16 frames per wave, see DESIGN.md section 6
 #endif
+// Waves per parse workgroup (they share one copy of the ROM tables, ParseTabLds, 3.3 KB: LDS per wave goes from 13 granules of
+// 1280 bytes to 11.5 at two, 10.75 at four).  Measured next to the reconstruction in pipelined steps (opusgpu_set_pipeline), where
+// LDS is what the two kernels compete for: 2.74 ms per step at one, 2.73 at two, 2.80 at four (a workgroup's LDS stays
+// allocated until its slowest wave is done) -- so one.
+#ifndef OG_PL_WAVES
+#define OG_PL_WAVES 1
+#endif
+// a thread's wave within the workgroup and the column of its frame in that wave's [element][column] arrays
+#ifdef OG_HOST_EMUL
+#define OG_PWAVE 0
+#define OG_PCOL OG_LANE
+#else
+#define OG_PWAVE ((int)(threadIdx.x >> 6))
+#define OG_PCOL ((int)(threadIdx.x & 63))
+#endif
+#define OG_PL_FRAMES (OG_PL_LANES * OG_PL_WAVES) // frames per workgroup
 struct ParseLds { // [element][lane]: lanes of a wave touch consecutive addresses, no bank conflicts
     i32 pulses[NBANDS][OG_PL_LANES];
     i16 bandE[2 * NBANDS][OG_PL_LANES];
@@ -113,7 +129,10 @@ struct ParseLds { // [element][lane]: lanes of a wave touch consecutive addresse
         i32 stack[5][6][OG_PL_LANES]; // split frames of the partition walk: [depth][word][lane]
     } u;
 };
-OG_LDS ParseLds PL;
+// One per wave.  The union below is private to a wave only because its lanes reconverge between compute_allocation and the band
+// walk; two waves of a workgroup do not, so they must not share rows of it.
+OG_LDS ParseLds PLs[OG_PL_WAVES];
+#define PL PLs[OG_PWAVE]
 
 // LDS copy of the entropy-decoding ROM tables (see RomGlobal, og_celt_bands.hpp), loaded once per workgroup
 struct ParseTabLds {
@@ -148,15 +167,15 @@ OG_DEV void parse_tables_load() {
 
 struct LaneArr {
     typedef RomLds Rom;
-    OG_MEMBER i32 &pulses(int i) const { return PL.pulses[i][OG_LANE]; }
-    OG_MEMBER i8 &fine_quant(int i) const { return PL.fine_quant[i][OG_LANE]; }
-    OG_MEMBER i8 &fine_prio(int i) const { return PL.fine_prio[i][OG_LANE]; }
-    OG_MEMBER i8 &tf_res(int i) const { return PL.tf_res[i][OG_LANE]; }
-    OG_MEMBER i16 &cap(int i) const { return PL.u.al.cap[i][OG_LANE]; }
-    OG_MEMBER i16 &offsets(int i) const { return PL.u.al.offsets[i][OG_LANE]; }
-    OG_MEMBER u16 &bits1(int i) const { return PL.u.al.bits1[i][OG_LANE]; }
-    OG_MEMBER u16 &bits2(int i) const { return PL.u.al.bits2[i][OG_LANE]; }
-    OG_MEMBER i16 &bandE(int i) const { return PL.bandE[i][OG_LANE]; }
+    OG_MEMBER i32 &pulses(int i) const { return PL.pulses[i][OG_PCOL]; }
+    OG_MEMBER i8 &fine_quant(int i) const { return PL.fine_quant[i][OG_PCOL]; }
+    OG_MEMBER i8 &fine_prio(int i) const { return PL.fine_prio[i][OG_PCOL]; }
+    OG_MEMBER i8 &tf_res(int i) const { return PL.tf_res[i][OG_PCOL]; }
+    OG_MEMBER i16 &cap(int i) const { return PL.u.al.cap[i][OG_PCOL]; }
+    OG_MEMBER i16 &offsets(int i) const { return PL.u.al.offsets[i][OG_PCOL]; }
+    OG_MEMBER u16 &bits1(int i) const { return PL.u.al.bits1[i][OG_PCOL]; }
+    OG_MEMBER u16 &bits2(int i) const { return PL.u.al.bits2[i][OG_PCOL]; }
+    OG_MEMBER i16 &bandE(int i) const { return PL.bandE[i][OG_PCOL]; }
 };
 
 OG_DEV u32 pvq_u_rom(int a, int b) { // U(a,b) from the ROM table (lane-private lookups)
@@ -225,7 +244,7 @@ OG_DEV int parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits,
             remaining_bits -= sc.qalloc;
             const int mid_first = mbits >= sbits;
             const int off_side = off + (B0 >> 1), silent_mid = silent | (itheta == 16384), silent_side = silent | (itheta == 0);
-            i32 *F = &PL.u.stack[depth][0][OG_LANE];
+            i32 *F = &PL.u.stack[depth][0][OG_PCOL];
             F[0 * OG_PL_LANES] = x | N << 11 | (LM + 1) << 19 | B << 22 | mid_first << 27 | 1 << 28;
             F[1 * OG_PL_LANES] = mbits;
             F[2 * OG_PL_LANES] = sbits;
@@ -276,7 +295,7 @@ OG_DEV int parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits,
                                     (need_low ? JW_NEED_LOW : 0));
                 return need_low;
             }
-            i32 *F = &PL.u.stack[depth - 1][0][OG_LANE];
+            i32 *F = &PL.u.stack[depth - 1][0][OG_PCOL];
             const i32 w0 = F[0];
             const int mid_first = (w0 >> 27) & 1, stage = (w0 >> 28) & 3;
             if (stage == 1) {
