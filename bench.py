@@ -358,7 +358,7 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
         frees += d_arena + d_desc
 
         def step(f):
-            ctx.decode_step_device(n, d_desc[f], d_arena[f], d_pcm, d_res)
+            ctx.decode_step_device(n, d_desc[f], d_arena[f], d_pcm, d_res, modes=pkg.toc_modes(toc))
 
     def barrier():
         ranks.barrier()

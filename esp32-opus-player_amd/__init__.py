@@ -22,7 +22,7 @@ EXPORTS = [
     "opusgpu_streams_alloc", "opusgpu_streams_reset", "opusgpu_stream_count", "opusgpu_stream_channels",
     "opusgpu_stream_state_bytes", "opusgpu_debug_stage_taps", "opusgpu_decode_packets", "opusgpu_decode_packets_fec", "opusgpu_packet_to_frames",
     "opusgpu_dev_alloc", "opusgpu_dev_free", "opusgpu_memcpy_h2d", "opusgpu_memcpy_d2h",
-    "opusgpu_decode_step_device", "opusgpu_synchronize", "opusgpu_event_create", "opusgpu_event_record",
+    "opusgpu_decode_step_device", "opusgpu_decode_step_device_modes", "opusgpu_synchronize", "opusgpu_event_create", "opusgpu_event_record",
     "opusgpu_event_elapsed_ms", "opusgpu_event_destroy", "opusgpu_stream_state_get",
     "opusgpu_pages_demux", "opusgpu_page_batch_steps", "opusgpu_page_batch_step", "opusgpu_page_batch_arena",
     "opusgpu_page_batch_free", "opusgpu_pages_crc_device", "opusgpu_output_stage_device",
@@ -60,6 +60,14 @@ class StageTaps(C.Structure):
 
 class FrameDesc(C.Structure):
     _fields_ = [("stream", C.c_int32), ("offset", C.c_int32), ("len", C.c_int32), ("flags", C.c_int32)]
+
+
+HAS_SILK, HAS_HYBRID, HAS_CELT = 1, 2, 4  # opusgpu_decode_step_device_modes
+
+
+def toc_modes(toc):
+    """The mode mask of a step whose frames all carry this TOC byte."""
+    return HAS_CELT if toc & 0x80 else (HAS_HYBRID if (toc & 0x60) == 0x60 else HAS_SILK)
 
 
 DESC_DTYPE = np.dtype([("stream", "<i4"), ("offset", "<i4"), ("len", "<i4"), ("flags", "<i4")])
@@ -107,6 +115,7 @@ def load_lib():
     lib.opusgpu_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     lib.opusgpu_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     lib.opusgpu_decode_step_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    lib.opusgpu_decode_step_device_modes.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int]
     lib.opusgpu_synchronize.argtypes = [vp]
     lib.opusgpu_event_create.argtypes = [vp, C.POINTER(vp)]
     lib.opusgpu_event_record.argtypes = [vp, vp]
@@ -343,9 +352,14 @@ class Context:
         self._chk(self.lib.opusgpu_debug_stage_taps(self.h, slot, C.byref(t)), "opusgpu_debug_stage_taps")
         return t
 
-    def decode_step_device(self, n, d_descs, d_arena, d_pcm, d_result, stream=None):
-        self._chk(self.lib.opusgpu_decode_step_device(self.h, n, d_descs, d_arena, d_pcm, d_result, stream),
-                  "opusgpu_decode_step_device")
+    def decode_step_device(self, n, d_descs, d_arena, d_pcm, d_result, stream=None, modes=0):
+        """modes: 0 = not known, else a mask of HAS_SILK / HAS_HYBRID / HAS_CELT (opusgpu_decode_step_device_modes)."""
+        if modes:
+            self._chk(self.lib.opusgpu_decode_step_device_modes(self.h, n, d_descs, d_arena, d_pcm, d_result, stream, modes),
+                      "opusgpu_decode_step_device_modes")
+        else:
+            self._chk(self.lib.opusgpu_decode_step_device(self.h, n, d_descs, d_arena, d_pcm, d_result, stream),
+                      "opusgpu_decode_step_device")
 
     def pages_crc_device(self, n_pages, d_blob, d_offsets, d_lens, d_status, stream=None):
         """Page checksums on the GPU (include/opusgpu.h): d_status[i] = 1 match, 0 mismatch, PAGE_BAD_CAPTURE malformed."""

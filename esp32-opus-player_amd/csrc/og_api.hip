@@ -381,14 +381,14 @@ __global__ void __launch_bounds__(64 * OG_PL_WAVES, 2) k_celt_parse(const FrameD
 
 // Split CELT path, second half: one frame per wave, driven by the parse record.
 // (20 ms CELT-only frames are reconstructed by k_celt_recon_fb, og_recon.hip; `rest_only`: skip what that kernel took)
-extern "C" void og_launch_celt_recon_fb(hipStream_t s, const void *descs, void *streams, const void *recs, void *result, int n,
+extern "C" void og_launch_celt_recon_fb(hipStream_t s, const void *descs, void *streams, const void *recs, void *rout, int n,
                                         int n_streams, int hybrid);
 // RFC mode (opt-in): every frame of a step, at its true duration, incl. the loss path (og_rfc.hip)
 extern "C" void og_launch_decode_rfc(hipStream_t s, const void *descs, const void *arena, void *streams, void *pcm, void *result, int n,
                                      int n_streams, int pcm_stride);
 __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDesc *__restrict__ descs, StreamState *st,
-                                                                      const ParseRec *recs, i16 *pcm, i32 *result, int n,
-                                                                      int n_streams, int pcm_stride, int hybrid, int rest_only) {
+                                                                      const ParseRec *recs, ReconOut *rout, int n,
+                                                                      int n_streams, int hybrid, int rest_only) {
     // rest_only (k_celt_recon_fb ran before): what is left -- records that overflowed -- is almost nothing, so a workgroup
     // looks at 64 slots, one per lane, and reconstructs the few left to it one after the other (see k_decode_step)
     unsigned long long todo = 1ull;
@@ -420,8 +420,9 @@ __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDe
 #if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE) && !defined(OG_PROF_SPARSE) && !defined(OG_PROF_SSYNTH)
         OG_PROF_INIT();
 #endif
+        const int pos = OG_UNI(st[d.stream].celt.ring_pos); // where the frame's first sample goes
         const int ret = celt_recon_wave(&st[d.stream], &recs[f], mode, desc_channels(d.flags), rest_only ? RECON_REST_ONLY : RECON_ALL);
-        if (ret != RECON_NOT_MINE && threadIdx.x == 0) result[f] = ret;
+        if (ret != RECON_NOT_MINE && threadIdx.x == 0) rout[f] = ReconOut{ret, pos};
 #if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE) && !defined(OG_PROF_SPARSE) && !defined(OG_PROF_SSYNTH)
         OG_PROF_FLUSH();
 #endif
@@ -429,11 +430,22 @@ __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDe
     }
 }
 
+// One wave that waits `ticks` of the 100 MHz wall clock (pipelined steps: the reconstruction's head start for the early parse,
+// see decode_step_impl).  Ends by itself: the clock only moves forward.
+__global__ void __launch_bounds__(64) k_head_start(int ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while ((long long)(wall_clock64() - t0) < (long long)ticks) __builtin_amdgcn_s_sleep(16);
+}
+
 // Split CELT path, third step: de-emphasis (a rounding IIR: strictly serial per channel) and int16 PCM, one
 // (frame, channel) per lane, from the samples k_celt_recon appended to the history ring.
+// It also hands the reconstruction's result codes (ReconOut) to the caller's array, and -- for a step whose caller named the
+// modes it contains (`modes`: bit 0 SILK-only, bit 1 hybrid, bit 2 CELT-only; the kernels of absent modes were not launched,
+// `others_ran` = 0 if that includes the kernels that report stream-index errors) -- reports what those kernels would have.
 __global__ void __launch_bounds__(64) k_celt_post(const FrameDesc *__restrict__ descs, StreamState *st, const ParseRec *recs,
-                                                  const i32 *__restrict__ result, i16 *pcm, int n, int n_streams, int channels,
-                                                  int pcm_stride, const SilkHandoff *handoff) {
+                                                  const ReconOut *__restrict__ rout, i32 *__restrict__ result, i16 *pcm, int n,
+                                                  int n_streams, int channels, int pcm_stride, const SilkHandoff *handoff,
+                                                  int modes, int others_ran) {
     // Fast path (two-channel decoder, every row of the wave live, ring positions on a 16-sample boundary): the 64 rows'
     // next 16 samples are fetched as full 64-byte lines by the whole wave (lane = quarter line of a row), transposed
     // through LDS to one row per lane for the recurrence, and the PCM goes out the same way (lane = 16 bytes of a frame's
@@ -454,25 +466,35 @@ __global__ void __launch_bounds__(64) k_celt_post(const FrameDesc *__restrict__ 
     StreamState *ss = nullptr;
     const i16 *silk = nullptr;
     int silk_n = 0;
+    int pos = 0;
     if (f < n) {
         const FrameDesc d = descs[f];
         const int mode = desc_mode(d.flags);
-        if (d.stream >= 0 && d.stream < n_streams && (mode == MODE_CELT || (mode == MODE_HYBRID && handoff)) && !desc_rfc(d.flags) &&
-            !(recs[f].flags & (RF_SKIP | RF_BAD_CELT))) {
-            live = true;
-            ss = &st[d.stream];
-            emit = result[f] >= 0;
-            if (mode == MODE_HYBRID) {
-                silk = handoff[f].pcm;
-                silk_n = 960 * desc_channels(d.flags);
+        const bool stream_ok = d.stream >= 0 && d.stream < n_streams;
+        if (!(modes >> (d.flags & 3) & 1) || (!stream_ok && !others_ran)) { // (a frame the caller's mode set left out is an error, not a skip)
+            if (c == 0) result[f] = BAD_ARG;
+        } else if (stream_ok && (mode == MODE_CELT || (mode == MODE_HYBRID && handoff)) && !desc_rfc(d.flags)) {
+            const u32 rf = recs[f].flags;
+            if (!(mode == MODE_HYBRID && (rf & RF_SKIP))) { // (those the single-kernel path has reported already)
+                const ReconOut ro = rout[f];
+                if (c == 0) result[f] = ro.ret;
+                if (!(rf & (RF_SKIP | RF_BAD_CELT))) {
+                    live = true;
+                    ss = &st[d.stream];
+                    emit = ro.ret >= 0;
+                    pos = ro.pos & RING_MASK;
+                    if (mode == MODE_HYBRID) {
+                        silk = handoff[f].pcm;
+                        silk_n = 960 * desc_channels(d.flags);
+                    }
+                }
             }
         }
     }
     i16 *out = pcm + (size_t)(f < n ? f : 0) * pcm_stride;
-    const int pos = live ? ((ss->celt.ring_pos - 960) & RING_MASK) : 0;
     const bool fast = channels == 2 && __all(live && emit && (pos & 15) == 0);
     if (!fast) {
-        if (live) celt_post_lane(&ss->celt, c, channels, 960, emit ? out : nullptr, silk, silk_n);
+        if (live) celt_post_lane(&ss->celt, c, channels, 960, pos, emit ? out : nullptr, silk, silk_n);
         return;
     }
     rows[lane].ring = ss->celt.ring[c];
@@ -563,20 +585,24 @@ struct opusgpu_ctx {
     hipEvent_t ev_part[OPUSGPU_COPY_PIECES] = {};
     int host_parts = 2; // OPUSGPU_HOST_PARTS=1: one batch, copy after the kernels (A/B measurements); 2, 4, 8, 16
     // parse records of the split CELT path (one per frame of a step), grown on demand
-    void *d_recs = nullptr, *d_handoff = nullptr, *d_srecs = nullptr;
-    size_t cap_recs = 0, cap_handoff = 0, cap_srecs = 0;
+    void *d_recs[3] = {}, *d_rout[3] = {}, *d_handoff = nullptr, *d_srecs = nullptr; // (three sets: pipelined steps rotate)
+    size_t cap_recs[3] = {}, cap_rout[3] = {}, cap_handoff = 0, cap_srecs = 0;
     int split_celt = 1;   // OPUSGPU_SPLIT=0 forces the single-kernel path for every mode (A/B measurements)
     int split_hybrid = 1; // OPUSGPU_SPLIT_HYBRID=0 keeps SILK-only and hybrid frames entirely on the single-kernel path
     int fast_recon = 1;   // OPUSGPU_FAST_RECON=0: every CELT frame through the general reconstruction kernel (A/B measurements)
     int mode = OPUSGPU_MODE_REFERENCE; // opusgpu_set_mode
     // opusgpu_set_pipeline: the parse of step k + 1's CELT-only frames runs on parse_stream, next to step k's reconstruction
-    int pipeline = 0, parity = 0, front_recorded = 0;
-    hipStream_t parse_stream = nullptr, last_step_stream = nullptr;
-    hipEvent_t ev_front = nullptr;  // step k: every writer of what a parse reads has finished (on the step's stream)
-    hipEvent_t ev_parsed = nullptr; // step k + 1: its early parse has finished (on parse_stream)
-    void *d_recs_b = nullptr;       // the second set of parse records (a step's reconstruction reads one, the next parse fills the other)
-    size_t cap_recs_b = 0;
+    // and its reconstruction on recon_stream; parse records and the reconstruction's per-frame output (d_recs, d_rout) rotate
+    int pipeline = 0, slot = 0, front_recorded = 0, rstart_recorded = 0, post_recorded[3] = {};
+    hipStream_t parse_stream = nullptr, recon_stream = nullptr, last_step_stream = nullptr;
+    hipEvent_t ev_front = nullptr;  // step k: its front kernels have finished (on the step's stream)
+    hipEvent_t ev_parsed = nullptr; // step k: its early parse has finished (on parse_stream)
+    hipEvent_t ev_rstart = nullptr; // step k: its reconstruction is about to start (on recon_stream, ahead of the kernel)
+    hipEvent_t ev_recon = nullptr;  // step k: its reconstruction has finished (on recon_stream)
+    hipEvent_t ev_post[3] = {};     // by slot: k_celt_post of the last step that used it has finished (on the step's stream)
     const void *last_recs = nullptr;
+    int head_start_ticks = 2500; // 25 us of the 100 MHz clock (OPUSGPU_HEAD_START_US)
+    int post_delay_ticks = 10000; // 100 us (OPUSGPU_POST_DELAY_US): see decode_step_impl
     // the last decode step's tables, for opusgpu_debug_stage_taps
     const void *last_descs = nullptr;
     int last_n = 0, last_had_silk_recs = 0;
@@ -634,6 +660,8 @@ int opusgpu_ctx_create(int device, opusgpu_ctx **out) {
     if (const char *e = getenv("OPUSGPU_SPLIT")) ctx->split_celt = e[0] != '0';
     if (const char *e = getenv("OPUSGPU_SPLIT_HYBRID")) ctx->split_hybrid = e[0] != '0';
     if (const char *e = getenv("OPUSGPU_FAST_RECON")) ctx->fast_recon = e[0] != '0';
+    if (const char *e = getenv("OPUSGPU_HEAD_START_US")) ctx->head_start_ticks = atoi(e) * 100;
+    if (const char *e = getenv("OPUSGPU_POST_DELAY_US")) ctx->post_delay_ticks = atoi(e) * 100;
     if (const char *e = getenv("OPUSGPU_HOST_PARTS")) {
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ctx->host_parts = v;
@@ -656,8 +684,12 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     (void)hipFree(ctx->d_pcm);
     (void)hipFree(ctx->d_result);
     if (ctx->parse_stream) (void)hipStreamSynchronize(ctx->parse_stream);
-    (void)hipFree(ctx->d_recs);
-    (void)hipFree(ctx->d_recs_b);
+    if (ctx->recon_stream) (void)hipStreamSynchronize(ctx->recon_stream);
+    for (int i = 0; i < 3; i++) {
+        (void)hipFree(ctx->d_recs[i]);
+        (void)hipFree(ctx->d_rout[i]);
+        if (ctx->ev_post[i]) (void)hipEventDestroy(ctx->ev_post[i]);
+    }
     (void)hipFree(ctx->d_handoff);
     (void)hipFree(ctx->d_srecs);
     (void)hipHostFree(ctx->h_pcm);
@@ -669,8 +701,11 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
         if (e) (void)hipEventDestroy(e);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->parse_stream) (void)hipStreamDestroy(ctx->parse_stream);
+    if (ctx->recon_stream) (void)hipStreamDestroy(ctx->recon_stream);
     if (ctx->ev_front) (void)hipEventDestroy(ctx->ev_front);
     if (ctx->ev_parsed) (void)hipEventDestroy(ctx->ev_parsed);
+    if (ctx->ev_recon) (void)hipEventDestroy(ctx->ev_recon);
+    if (ctx->ev_rstart) (void)hipEventDestroy(ctx->ev_rstart);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -692,12 +727,16 @@ int opusgpu_set_pipeline(opusgpu_ctx *ctx, int on) {
         HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
         if (const char *e = getenv("OPUSGPU_PARSE_PRIORITY")) greatest = e[0] == '0' ? least : greatest;
         HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->parse_stream, hipStreamNonBlocking, greatest));
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->recon_stream, hipStreamNonBlocking));
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_parsed, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_recon, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_rstart, hipEventDisableTiming));
+        for (int i = 0; i < 3; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_post[i], hipEventDisableTiming));
     }
     if ((on != 0) != (ctx->pipeline != 0)) { // switching: from an idle device (steps of either kind may be queued on any stream)
         HIPCHK(ctx, hipDeviceSynchronize());
-        ctx->front_recorded = 0;
+        ctx->front_recorded = ctx->rstart_recorded = ctx->post_recorded[0] = ctx->post_recorded[1] = ctx->post_recorded[2] = 0;
     }
     ctx->pipeline = on ? 1 : 0;
     return OPUSGPU_OK;
@@ -711,8 +750,12 @@ int opusgpu_streams_reset(opusgpu_ctx *ctx, int first, int count, int full) {
     if (!ctx || first < 0 || count < 0 || first + count > ctx->n_streams) return OPUSGPU_BAD_ARG;
     if (count == 0) return OPUSGPU_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (ctx->parse_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->parse_stream));
-    ctx->front_recorded = 0; // (the reset below is synchronous: the next early parse has nothing to wait for)
+    if (ctx->parse_stream) { // whatever pipelined steps still have in flight works on the state this resets
+        HIPCHK(ctx, hipStreamSynchronize(ctx->parse_stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->recon_stream));
+        if (ctx->last_step_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->last_step_stream));
+    }
+    ctx->front_recorded = ctx->rstart_recorded = ctx->post_recorded[0] = ctx->post_recorded[1] = ctx->post_recorded[2] = 0; // (the reset below is synchronous)
     hipLaunchKernelGGL(k_stream_init, dim3(count), dim3(64), 0, ctx->stream, ctx->d_streams, first, count, ctx->channels,
                        full ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
@@ -773,7 +816,7 @@ int opusgpu_memcpy_d2h(opusgpu_ctx *ctx, void *dst, const void *src, size_t byte
 // when pipelining is on); false when this call's own uploads are still queued on the step's stream (opusgpu_decode_packets):
 // such a step does not run ahead of anything.
 static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm, void *d_result,
-                            void *hip_stream, bool tables_resident) {
+                            void *hip_stream, bool tables_resident, int modes = 7) {
     if (!ctx || n < 0 || !ctx->d_streams) return OPUSGPU_BAD_ARG;
     if (n == 0) return OPUSGPU_OK;
     if (!d_descs || !d_arena || !d_pcm || !d_result) return OPUSGPU_BAD_ARG;
@@ -793,91 +836,113 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         ctx->last_step_stream = s;
         return OPUSGPU_OK;
     }
-    SilkHandoff *handoff = nullptr;
-    SilkRec *srecs = nullptr;
-    const bool pipe = ctx->pipeline && ctx->split_celt && tables_resident;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->split_celt) { // OPUSGPU_SPLIT=0 (A/B measurements): every frame through the single kernel, in order
+        hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams,
+                           (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, 0, nullptr, nullptr, 0);
+        HIPCHK(ctx, hipGetLastError());
+        ctx->last_step_stream = s;
+        return OPUSGPU_OK;
+    }
+    // `modes` (bit 0 SILK-only, 1 hybrid, 2 CELT-only frames may be present; 7 = not known): the kernels of modes the caller
+    // rules out are not launched; k_celt_post reports a frame of such a mode as OPUSGPU_BAD_ARG
+    modes &= 7;
+    if (!modes) modes = 7;
+    const bool any_silk = (modes & 3) != 0, any_celt = (modes & 6) != 0;
+    const bool pipe = ctx->pipeline && tables_resident && (modes & 4); // (only CELT-only frames have anything to run ahead)
     if (ctx->pipeline && ctx->last_step_stream && ctx->last_step_stream != s) {
         // consecutive steps on different streams: nothing orders them but the caller, so nothing may run ahead either
-        HIPCHK(ctx, hipSetDevice(ctx->device));
         HIPCHK(ctx, hipStreamSynchronize(ctx->last_step_stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->parse_stream));
-        ctx->front_recorded = 0;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->recon_stream));
+        ctx->front_recorded = ctx->rstart_recorded = ctx->post_recorded[0] = ctx->post_recorded[1] = ctx->post_recorded[2] = 0;
     }
     ctx->last_step_stream = s;
-    void **recs_slot = &ctx->d_recs;
-    size_t *recs_cap = &ctx->cap_recs;
-    if (pipe) {
-        ctx->parity ^= 1;
-        if (ctx->parity) { recs_slot = &ctx->d_recs_b; recs_cap = &ctx->cap_recs_b; }
-    }
-    if (ctx->split_celt) {
-        // The records / hand-off buffers only grow; growing frees the old one, which waits for the device to go idle.
-        if (*recs_cap < sizeof(ParseRec) * (size_t)n) {
-            HIPCHK(ctx, hipSetDevice(ctx->device));
-            const int rc = grow(ctx, recs_slot, recs_cap, sizeof(ParseRec) * (size_t)n);
-            if (rc) return rc;
-        }
-        if (ctx->split_hybrid) {
-            if (ctx->cap_handoff < sizeof(SilkHandoff) * (size_t)n) {
-                HIPCHK(ctx, hipSetDevice(ctx->device));
-                const int rc = grow(ctx, &ctx->d_handoff, &ctx->cap_handoff, sizeof(SilkHandoff) * (size_t)n);
-                if (rc) return rc;
-            }
-            if (ctx->cap_srecs < sizeof(SilkRec) * (size_t)n) {
-                HIPCHK(ctx, hipSetDevice(ctx->device));
-                const int rc = grow(ctx, &ctx->d_srecs, &ctx->cap_srecs, sizeof(SilkRec) * (size_t)n);
-                if (rc) return rc;
-            }
-            handoff = (SilkHandoff *)ctx->d_handoff;
-            srecs = (SilkRec *)ctx->d_srecs;
-            // SILK-only and hybrid frames: entropy half, one frame per lane
-            hipLaunchKernelGGL(k_silk_parse, dim3((n + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
-                               (const StreamState *)ctx->d_streams, srecs, handoff, n, ctx->n_streams);
+    // The records, the reconstruction's per-frame output and the hand-off buffers only grow; growing frees the old one, which
+    // waits for the device to go idle.  Records and reconstruction output exist twice: pipelined steps alternate.
+    if (pipe) ctx->slot = (ctx->slot + 1) % 3;
+    const int par = pipe ? ctx->slot : 0, par2 = (par + 1) % 3; // this step's slot; the slot of the step two before it
+    {
+        int rc;
+        if (ctx->cap_recs[par] < sizeof(ParseRec) * (size_t)n &&
+            (rc = grow(ctx, &ctx->d_recs[par], &ctx->cap_recs[par], sizeof(ParseRec) * (size_t)n)))
+            return rc;
+        if (ctx->cap_rout[par] < sizeof(ReconOut) * (size_t)n &&
+            (rc = grow(ctx, &ctx->d_rout[par], &ctx->cap_rout[par], sizeof(ReconOut) * (size_t)n)))
+            return rc;
+        if (ctx->split_hybrid && any_silk) {
+            if (ctx->cap_handoff < sizeof(SilkHandoff) * (size_t)n &&
+                (rc = grow(ctx, &ctx->d_handoff, &ctx->cap_handoff, sizeof(SilkHandoff) * (size_t)n)))
+                return rc;
+            if (ctx->cap_srecs < sizeof(SilkRec) * (size_t)n && (rc = grow(ctx, &ctx->d_srecs, &ctx->cap_srecs, sizeof(SilkRec) * (size_t)n)))
+                return rc;
         }
     }
-    // The launch order of a step on the split path, all on one stream:
-    //   k_silk_parse  k_celt_parse  k_silk_synth  k_celt_recon  k_celt_post  k_decode_step[Q4]
-    // After k_silk_parse the SILK synthesis and the CELT parse + reconstruction are independent (they share no field of
-    // the stream state: SilkRec::prev_mode, og_silk_parse.hpp); only k_celt_post needs both.  Running them on two streams
-    // was measured: next to k_celt_recon the synthesis gains nothing; next to k_celt_parse it gains
-    // 5 % on mixed-mode steps but costs 13 % on CELT-only steps -- k_celt_parse is a single round of long-running
-    // workgroups, and anything occupying slots while it starts (even 65,536 workgroups that exit at once) leaves it
-    // unevenly placed for its whole duration (0.86 -> 1.35 ms).  It therefore starts behind the tiny k_silk_parse only.
-    // A pipelined step (opusgpu_set_pipeline):
-    //   parse_stream:  [wait: front of step k-1]  k_celt_parse[CELT-only frames]
-    //   step's stream: k_silk_parse  k_celt_parse[hybrid frames]  k_silk_synth  k_decode_step[Q4]  [front of step k]
-    //                  [wait: early parse]  k_celt_recon_fb  k_celt_recon  k_celt_post
-    // "front": every kernel that writes what a parse kernel reads -- CeltState::bandE (k_celt_parse itself, and the full
-    // kernel), the SILK state and prev_mode of streams k_silk_parse looks at (k_silk_synth, the full kernel) -- has run.
-    // The reconstruction and the de-emphasis of step k write none of that, so step k+1's CELT-only parse runs next to them.
-    ParseRec *const recs = (ParseRec *)*recs_slot;
+    ParseRec *const recs = (ParseRec *)ctx->d_recs[par];
+    ReconOut *const rout = (ReconOut *)ctx->d_rout[par];
+    SilkHandoff *const handoff = ctx->split_hybrid && any_silk ? (SilkHandoff *)ctx->d_handoff : nullptr;
+    SilkRec *const srecs = ctx->split_hybrid && any_silk ? (SilkRec *)ctx->d_srecs : nullptr;
     ctx->last_recs = recs;
-    if (ctx->split_celt && !pipe) {
-        // CELT-only frames and the CELT half of hybrid frames: parse (one frame per lane) -> records in HBM
-        hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_FRAMES - 1) / OG_PL_FRAMES), dim3(64 * OG_PL_WAVES), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
-                           ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)handoff, (int)PARSE_ALL);
-    }
-    if (pipe) {
-        HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->last_had_silk_recs = srecs != nullptr;
+    const dim3 parse_grid((n + OG_PL_FRAMES - 1) / OG_PL_FRAMES), parse_block(64 * OG_PL_WAVES);
+    // The kernels of a step and what orders them:
+    //   FRONT   k_silk_parse  k_celt_parse  k_silk_synth (or the full kernel)  k_decode_step[Q4]
+    //   BACK    k_celt_recon_fb  k_celt_recon  ->  k_celt_post
+    // In order (the default): all on the step's stream.  After k_silk_parse the SILK synthesis and the CELT parse +
+    // reconstruction are independent (SilkRec::prev_mode, og_silk_parse.hpp); running them on two streams was measured
+    // (DESIGN.md section 6): next to k_celt_recon the synthesis gains nothing; next to k_celt_parse it gains 5 % on mixed-mode
+    // steps but costs 13 % on CELT-only steps.
+    // Pipelined (opusgpu_set_pipeline; the tables are resident, so nothing here waits for the caller's earlier work):
+    //   parse_stream   [front and start of the reconstruction of step k-1, post of step k-3]  k_celt_parse[CELT-only frames]
+    //   step's stream  k_silk_parse  k_celt_parse[hybrid]  k_silk_synth  k_decode_step[Q4]  (= front of step k)
+    //                  [reconstruction of step k]  k_celt_post
+    //   recon_stream   [early parse, front of step k, post of step k-2]  k_celt_recon_fb  k_celt_recon
+    // "front": every kernel that writes what a parse kernel reads -- CeltState::bandE (k_celt_parse itself, and the full
+    // kernel), the SILK state and prev_mode (k_silk_synth, the full kernel, the reconstruction of the step before, which the
+    // step's stream has waited for) -- or that writes the caller's buffers.  The reconstruction touches neither the caller's
+    // buffers (its result codes go through ReconOut) nor anything k_celt_post reads of the step BEFORE (the history ring is
+    // written 960 samples further on; the ring position travels in ReconOut), so when the caller rules out SILK-only and
+    // hybrid frames the reconstruction of step k+1 starts while k_celt_post of step k runs; two steps on, it waits for it
+    // (the ring holds two frames; records and ReconOut rotate through three sets).
+    if (!pipe) {
+        if (srecs)
+            hipLaunchKernelGGL(k_silk_parse, dim3((n + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, s, (const FrameDesc *)d_descs,
+                               (const u8 *)d_arena, (const StreamState *)ctx->d_streams, srecs, handoff, n, ctx->n_streams);
+        if (any_celt)
+            hipLaunchKernelGGL(k_celt_parse, parse_grid, parse_block, 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams,
+                               recs, n, ctx->n_streams, (const SilkHandoff *)handoff, (int)PARSE_ALL);
+    } else {
+        // the early parse: behind the front of the step before, its own slot's last user (three steps back), and -- so that it
+        // and the reconstruction of the step before START TOGETHER -- that reconstruction's start.  The parse is one round of
+        // 16 KB workgroups: it gets its places when the machine is being refilled anyway (it has the higher priority); coming
+        // 0.2 ms after the reconstruction's 7.5 KB workgroups have filled the CUs it was measured to take 2.9 ms instead of
+        // 0.9 - 1.4 (no hole a retiring reconstruction workgroup leaves fits it) and the step after waited for it.
         if (ctx->front_recorded) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_front, 0));
-        hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_FRAMES - 1) / OG_PL_FRAMES), dim3(64 * OG_PL_WAVES), 0, ctx->parse_stream, (const FrameDesc *)d_descs,
-                           (const u8 *)d_arena, ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)nullptr, (int)PARSE_CELT_ONLY);
+        if (ctx->rstart_recorded) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_rstart, 0));
+        if (ctx->post_recorded[par]) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_post[par], 0));
+        if (modes & 4)
+            hipLaunchKernelGGL(k_celt_parse, parse_grid, parse_block, 0, ctx->parse_stream, (const FrameDesc *)d_descs, (const u8 *)d_arena,
+                               ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)nullptr, (int)PARSE_CELT_ONLY);
         HIPCHK(ctx, hipEventRecord(ctx->ev_parsed, ctx->parse_stream));
-        if (handoff)
-            hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_FRAMES - 1) / OG_PL_FRAMES), dim3(64 * OG_PL_WAVES), 0, s, (const FrameDesc *)d_descs,
-                               (const u8 *)d_arena, ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)handoff,
-                               (int)PARSE_HYBRID_ONLY);
+        if (srecs) {
+            hipLaunchKernelGGL(k_silk_parse, dim3((n + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, s, (const FrameDesc *)d_descs,
+                               (const u8 *)d_arena, (const StreamState *)ctx->d_streams, srecs, handoff, n, ctx->n_streams);
+            if (modes & 2)
+                hipLaunchKernelGGL(k_celt_parse, parse_grid, parse_block, 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams,
+                                   recs, n, ctx->n_streams, (const SilkHandoff *)handoff, (int)PARSE_HYBRID_ONLY);
+        }
     }
+    bool others_ran = false; // (the kernels that report stream-index errors for every mode)
     if (srecs) {
-        // SILK-only frames and the SILK half of hybrid frames: arithmetic half, one frame per wave (also reports
-        // stream-index errors)
+        // SILK-only frames and the SILK half of hybrid frames: arithmetic half, one frame per wave
         hipLaunchKernelGGL(k_silk_synth, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams,
                            (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, handoff, (const SilkRec *)srecs);
-    } else {
-        // every frame (OPUSGPU_SPLIT=0), or every frame that is not CELT-only (OPUSGPU_SPLIT_HYBRID=0)
-        hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
-                           ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, ctx->split_celt, nullptr,
-                           nullptr, 0);
+        others_ran = true;
+    } else if (any_silk) {
+        // every frame that is not CELT-only (OPUSGPU_SPLIT_HYBRID=0)
+        hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams,
+                           (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, 1, nullptr, nullptr, 0);
+        others_ran = true;
     }
     auto q4_pass = [&]() {
         // The rare hybrid -> SILK-only transition frames (Q4), parked by k_silk_synth, through the full kernel.  Nothing in
@@ -887,26 +952,51 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
                            ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, 1, handoff,
                            (const SilkRec *)srecs, 1);
     };
+    hipStream_t back = s;
     if (pipe) {
-        if (srecs) q4_pass();
-        HIPCHK(ctx, hipEventRecord(ctx->ev_front, s));
-        ctx->front_recorded = 1;
-        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_parsed, 0));
+        if (srecs && (modes & 1)) q4_pass();
+        back = ctx->recon_stream;
+        HIPCHK(ctx, hipStreamWaitEvent(back, ctx->ev_parsed, 0));
+        if (any_silk) { // this step has front kernels on its stream
+            HIPCHK(ctx, hipEventRecord(ctx->ev_front, s));
+            ctx->front_recorded = 1;
+            HIPCHK(ctx, hipStreamWaitEvent(back, ctx->ev_front, 0));
+        }
+        if (ctx->post_recorded[par2]) HIPCHK(ctx, hipStreamWaitEvent(back, ctx->ev_post[par2], 0)); // (the ring: 2 x 960 of 2048)
+        HIPCHK(ctx, hipEventRecord(ctx->ev_rstart, back));
+        ctx->rstart_recorded = 1;
+        // the next step's early parse is released by that event and has to be placed BEFORE this reconstruction fills the CUs
+        // (see above): the event's way to the other queue takes ~10 us, so the reconstruction is held back a little longer
+        if (ctx->head_start_ticks > 0) hipLaunchKernelGGL(k_head_start, dim3(1), dim3(64), 0, back, ctx->head_start_ticks);
     }
-    if (ctx->split_celt) {
-        // reconstruct (one frame per wave) -> de-emphasis, SILK mix and PCM (one (frame, channel) per lane)
-        if (ctx->fast_recon)
-            og_launch_celt_recon_fb(s, d_descs, ctx->d_streams, recs, d_result, n, ctx->n_streams, handoff ? 1 : 0);
-        hipLaunchKernelGGL(k_celt_recon, dim3(ctx->fast_recon ? (n + 63) / 64 : n), dim3(64), 0, s, (const FrameDesc *)d_descs,
-                           ctx->d_streams, (const ParseRec *)recs, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride,
-                           handoff ? 1 : 0, ctx->fast_recon);
-        hipLaunchKernelGGL(k_celt_post, dim3((n * ctx->channels + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs,
-                           ctx->d_streams, (const ParseRec *)recs, (const i32 *)d_result, (i16 *)d_pcm, n, ctx->n_streams,
-                           ctx->channels, pcm_stride, (const SilkHandoff *)handoff);
+    if (any_celt) {
+        // reconstruct (one frame per wave) ...
+        if (ctx->fast_recon) og_launch_celt_recon_fb(back, d_descs, ctx->d_streams, recs, rout, n, ctx->n_streams, handoff ? 1 : 0);
+        hipLaunchKernelGGL(k_celt_recon, dim3(ctx->fast_recon ? (n + 63) / 64 : n), dim3(64), 0, back, (const FrameDesc *)d_descs,
+                           ctx->d_streams, (const ParseRec *)recs, rout, n, ctx->n_streams, handoff ? 1 : 0, ctx->fast_recon);
     }
-    if (srecs && !pipe) q4_pass();
+    if (pipe) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_recon, back));
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_recon, 0));
+        // k_celt_post becomes ready at the same moment as the next step's reconstruction and the parse after that; its 15 KB
+        // workgroups placed first keep the parse's 16 KB ones out until the reconstruction has filled the CUs (measured: the
+        // parse then takes 3.1 instead of 0.9 ms, 2.80 ms per step).  Nothing waits for the de-emphasis, so it goes last: held
+        // back until the other two are placed, it runs in the holes the parse leaves (0.9 ms instead of 0.2, 2.58 ms per step).
+        if (ctx->post_delay_ticks > 0 && !any_silk) hipLaunchKernelGGL(k_head_start, dim3(1), dim3(64), 0, s, ctx->post_delay_ticks);
+    }
+    if (any_celt || !others_ran || modes != 7) {
+        // ... -> de-emphasis, SILK mix and PCM (one (frame, channel) per lane); the result codes of CELT / hybrid frames
+        hipLaunchKernelGGL(k_celt_post, dim3((n * ctx->channels + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs, ctx->d_streams,
+                           (const ParseRec *)recs, (const ReconOut *)rout, (i32 *)d_result, (i16 *)d_pcm, n, ctx->n_streams, ctx->channels,
+                           pcm_stride, (const SilkHandoff *)handoff, modes, others_ran ? 1 : 0);
+    }
+    if (pipe) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_post[par], s));
+        ctx->post_recorded[par] = 1;
+    } else if (srecs && (modes & 1))
+        q4_pass();
     HIPCHK(ctx, hipGetLastError());
-    if (ctx->pipeline && !pipe) { // a step that ran in order: a later pipelined step's early parse waits for all of it
+    if (ctx->pipeline && !pipe) { // a step that ran in order: whatever a later pipelined step runs ahead waits for all of it
         HIPCHK(ctx, hipEventRecord(ctx->ev_front, s));
         ctx->front_recorded = 1;
     }
@@ -916,6 +1006,11 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
 int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm,
                                void *d_result, void *hip_stream) {
     return decode_step_impl(ctx, n, d_descs, d_arena, d_pcm, d_result, hip_stream, true);
+}
+int opusgpu_decode_step_device_modes(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm,
+                                     void *d_result, void *hip_stream, int modes) {
+    if (modes <= 0 || modes > 7) return OPUSGPU_BAD_ARG;
+    return decode_step_impl(ctx, n, d_descs, d_arena, d_pcm, d_result, hip_stream, true, modes);
 }
 
 #ifdef OG_PROF

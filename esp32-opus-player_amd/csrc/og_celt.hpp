@@ -999,8 +999,8 @@ OG_DEV void celt_post4(i32 &m, i32 s0, i32 s1, i32 s2, i32 s3, int j, int c, int
 #endif
 }
 
-OG_DEV void celt_post_lane(CeltState *st, int c, int CC, int N, i16 *__restrict__ pcm, const i16 *__restrict__ silk, int silk_n) {
-    const int pos = (st->ring_pos - N) & RING_MASK; // the frame's first sample (N is a multiple of 8, so is ring_pos)
+// `pos`: ring index of the frame's first sample (a multiple of 8, as N is)
+OG_DEV void celt_post_lane(CeltState *st, int c, int CC, int N, int pos, i16 *__restrict__ pcm, const i16 *__restrict__ silk, int silk_n) {
     const i32 *ring = st->ring[c];
     i32 m = st->deemph[c];
 #ifdef OG_HOST_EMUL

@@ -1658,6 +1658,13 @@ OG_DEV void recon_all_bands_pm(const ParseRec *rec, const LcgTab &lcg, int C, in
 // everything else -- the 2.5 ms transition frame, records that overflowed -- to the general one.
 constexpr int FAST_MAX_LEAVES = 416; // (og_state.hpp: the most a 20 ms frame can have)
 enum { RECON_ALL = 0, RECON_FAST_ONLY = 1, RECON_REST_ONLY = 2, RECON_NOT_MINE = -1000 };
+// What a reconstruction kernel reports per frame, read by the de-emphasis kernel (k_celt_post), which passes `ret` on to the
+// caller's result array: the frame's result code and where in the stream's history ring its first sample went.  (The ring
+// position is taken from here, not from the stream state: in pipelined steps the next step's reconstruction may already have
+// advanced it when this step's de-emphasis runs.)
+struct ReconOut {
+    i32 ret, pos;
+};
 OG_DEV bool recon_fast_eligible(const ParseRec *rec) {
     const u32 flags = (u32)OG_UNI(rec->flags);
     if (flags & (RF_SKIP | RF_BAD_CELT)) return false;
@@ -1799,7 +1806,7 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
 // (opus_decode_frame src/opus_decoder.cpp:271-273, Q3).
 OG_DEV void celt_post(StreamState *st, const ParseRec *rec, int result, int c, i16 *pcm, const i16 *silk, int ch) {
     if (rec->flags & (RF_SKIP | RF_BAD_CELT)) return;
-    celt_post_lane(&st->celt, c, st->channels, 960, result >= 0 ? pcm : nullptr, silk, 960 * ch);
+    celt_post_lane(&st->celt, c, st->channels, 960, (st->celt.ring_pos - 960) & RING_MASK, result >= 0 ? pcm : nullptr, silk, 960 * ch);
 }
 
 } // namespace og

@@ -18,7 +18,7 @@ using namespace og;
 // `hybrid`: the step's hybrid frames come through the split path too (their SILK half by k_silk_parse / k_silk_synth): this
 // kernel then also takes their CELT half
 __global__ void __launch_bounds__(64, OG_FAST_WAVES) k_celt_recon_fb(const FrameDesc *__restrict__ descs, StreamState *st,
-                                                                      const ParseRec *recs, i32 *result, int n, int n_streams,
+                                                                      const ParseRec *recs, ReconOut *rout, int n, int n_streams,
                                                                       int hybrid) {
     const int f = (int)blockIdx.x;
     if (f >= n) return;
@@ -27,15 +27,16 @@ __global__ void __launch_bounds__(64, OG_FAST_WAVES) k_celt_recon_fb(const Frame
     if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && hybrid)) || desc_rfc(d.flags)) return;
     if (mode == MODE_HYBRID && (recs[f].flags & RF_SKIP)) return; // the single-kernel path already reported this frame
     OG_PROF_INIT();
+    const int pos = OG_UNI(st[d.stream].celt.ring_pos); // where the frame's first sample goes
     const int ret = celt_recon_wave(&st[d.stream], &recs[f], mode, desc_channels(d.flags), RECON_FAST_ONLY);
-    if (ret != RECON_NOT_MINE && threadIdx.x == 0) result[f] = ret;
+    if (ret != RECON_NOT_MINE && threadIdx.x == 0) rout[f] = ReconOut{ret, pos};
     OG_PROF_FLUSH();
 }
 
-extern "C" void og_launch_celt_recon_fb(hipStream_t s, const void *descs, void *streams, const void *recs, void *result, int n,
+extern "C" void og_launch_celt_recon_fb(hipStream_t s, const void *descs, void *streams, const void *recs, void *rout, int n,
                                         int n_streams, int hybrid) {
     hipLaunchKernelGGL(k_celt_recon_fb, dim3(n), dim3(64), 0, s, (const FrameDesc *)descs, (StreamState *)streams,
-                       (const ParseRec *)recs, (i32 *)result, n, n_streams, hybrid);
+                       (const ParseRec *)recs, (ReconOut *)rout, n, n_streams, hybrid);
 }
 
 #ifdef OG_PROF

@@ -90,8 +90,9 @@ int opusgpu_get_mode(const opusgpu_ctx *ctx);
  * before its reconstruction: the range decoder of a CELT frame predicts the band energies from the previous frame's, and
  * the SILK half reads the SILK state.  With pipelining on, the library carries the band energies in the parse kernel
  * (k_celt_parse) and runs that kernel for step k+1's CELT-only frames on a stream of its own, NEXT TO step k's
- * reconstruction (k_celt_recon_fb / k_celt_post), into a second set of parse records; the step's own stream waits for it
- * before reconstructing.  Results are bit-identical to the in-order flow (tests/test_gpu_pipeline.py); the step's stream
+ * reconstruction (k_celt_recon_fb / k_celt_post), into a second set of parse records; the reconstruction runs on another
+ * stream of the library's own and never touches the caller's buffers, the step's own stream waits for it before the
+ * de-emphasis (k_celt_post) writes PCM and result codes.  Results are bit-identical to the in-order flow (tests/test_gpu_pipeline.py); the step's stream
  * still completes everything the step launched, so the caller synchronises exactly as before.
  * What the caller additionally guarantees while it is on, for opusgpu_decode_step_device:
  *   - d_descs and d_arena of a call are COMPLETE in device memory when the call is made (uploaded and synchronised, or
@@ -166,6 +167,16 @@ int opusgpu_memcpy_d2h(opusgpu_ctx *ctx, void *dst, const void *src, size_t byte
  * opusgpu_packet_to_frames, opusgpu_decode_packets and opusgpu_pages_demux produce tables that satisfy all of this. */
 int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm,
                                void *d_result, void *hip_stream);
+/* The same, for a caller that knows which kinds of frame the step contains (whoever framed the packets does: the TOC byte).
+ * `modes`: bit 0 SILK-only, bit 1 hybrid, bit 2 CELT-only frames MAY be present (1 .. 7).  The kernels of modes ruled out are
+ * not launched -- on a step of 65,536 frames the launches that find nothing to do cost 1 - 2 % -- and a pipelined step
+ * (opusgpu_set_pipeline) without SILK-only and hybrid frames also starts its reconstruction while the previous step's
+ * de-emphasis still runs.  A frame of a mode that was ruled out is reported as OPUSGPU_BAD_ARG in d_result and not decoded. */
+#define OPUSGPU_HAS_SILK 1
+#define OPUSGPU_HAS_HYBRID 2
+#define OPUSGPU_HAS_CELT 4
+int opusgpu_decode_step_device_modes(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm,
+                                     void *d_result, void *hip_stream, int modes);
 int opusgpu_synchronize(opusgpu_ctx *ctx);
 /* HIP events on the context's stream, for timing from hosts without HIP headers. */
 int opusgpu_event_create(opusgpu_ctx *ctx, void **event);

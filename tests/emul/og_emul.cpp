@@ -20,9 +20,15 @@ int emu_decode_frame_single(void *st, const uint8_t *payload, int len, int mode,
 }
 // what the library dispatches: CELT-only frames take the split path (parse per lane, reconstruct per wave, post per
 // channel); hybrid frames decode their SILK half on the single-kernel path and hand the CELT half over
+static og::ParseRec rec; // the last frame's parse record (emu_last_leaf_geom)
+// the (position, n, k, blocks) words of the last CELT / hybrid frame's PVQ leaves, in the order the reconstruction takes them
+int emu_last_leaf_geom(unsigned *out, int cap) {
+    const int n = rec.n_leaves < cap ? rec.n_leaves : cap;
+    for (int i = 0; i < n; i++) out[i] = rec.leaf_geom[i];
+    return rec.n_leaves;
+}
 int emu_decode_frame(void *stv, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm) {
     og::StreamState *st = (og::StreamState *)stv;
-    static og::ParseRec rec;
     static og::SilkHandoff handoff;
     static og::SilkRec srec;
     const og::SilkHandoff *h = nullptr;

@@ -32,7 +32,7 @@ def desc_flags(toc):
     return (mode | bw << 2 | np.where(toc & 4, 32, 0)).astype(np.int32), mode
 
 
-def run_queued(pkg, ctx, channels, arena, offs, lens, toc, pipeline, sync_every=0, reset_at=None):
+def run_queued(pkg, ctx, channels, arena, offs, lens, toc, pipeline, sync_every=0, reset_at=None, modes=0, one_pcm=False, streams=None):
     """All steps queued back to back (tables of every step resident before the first call).  Returns PCM [frames, n, 960*ch]
     and result codes [frames, n]."""
     frames, n = offs.shape
@@ -46,7 +46,7 @@ def run_queued(pkg, ctx, channels, arena, offs, lens, toc, pipeline, sync_every=
     d_res = [ctx.dev_alloc(4 * n) for _ in range(frames)]
     ctx.h2d(d_arena, arena)
     descs = np.zeros(n, dtype=pkg.DESC_DTYPE)
-    descs["stream"] = np.arange(n, dtype=np.int32)
+    descs["stream"] = np.arange(n, dtype=np.int32) if streams is None else streams
     for f in range(frames):
         descs["offset"] = (offs[f] + 1).astype(np.int32)
         descs["len"] = lens[f].astype(np.int32)
@@ -55,7 +55,7 @@ def run_queued(pkg, ctx, channels, arena, offs, lens, toc, pipeline, sync_every=
     for f in range(frames):
         if reset_at is not None and f == reset_at:
             ctx.streams_reset(0, n, full=False)
-        ctx.decode_step_device(n, d_desc[f], d_arena, d_pcm[f], d_res[f])
+        ctx.decode_step_device(n, d_desc[f], d_arena, d_pcm[f], d_res[f], modes=modes)
         if sync_every and (f + 1) % sync_every == 0:
             ctx.synchronize()
     ctx.synchronize()
@@ -117,9 +117,35 @@ def test_pipelined_celt_only_and_hybrid(pkg, oracle, gpu_ctx):
         blk[:, :, 0] = toc_byte
         blk[:, :, 1:] = pay
         toc = np.full((frames, n), toc_byte, dtype=np.uint8)
-        pcm, res = run_queued(pkg, gpu_ctx, 2, arena, offs, plen - 1, toc, pipeline=True)
+        for modes in (0, pkg.toc_modes(toc_byte)):  # not known / named by the caller (CELT-only: the reconstruction runs ahead too)
+            pcm, res = run_queued(pkg, gpu_ctx, 2, arena, offs, plen - 1, toc, pipeline=True, modes=modes)
+            assert (res == 960).all()
+            assert np.array_equal(pcm.reshape(frames, n, 960, 2).transpose(1, 0, 2, 3), ref)
+        pcm, res = run_queued(pkg, gpu_ctx, 2, arena, offs, plen - 1, toc, pipeline=False, modes=pkg.toc_modes(toc_byte))
         assert (res == 960).all()
         assert np.array_equal(pcm.reshape(frames, n, 960, 2).transpose(1, 0, 2, 3), ref)
+
+
+def test_mode_mask_is_checked(pkg, oracle, gpu_ctx):
+    """opusgpu_decode_step_device_modes: frames of a mode the caller ruled out come back as OPUSGPU_BAD_ARG, the others decode
+    as ever; so does a stream index out of range when the kernels that usually report it were not launched."""
+    rng = np.random.default_rng(4300)
+    n, frames, channels = 512, 4, 2
+    arena, offs, plen, lens, toc = make_walk(rng, n, frames, channels, configs=np.array([31, 31, 31, 27, 15, 1]), p_home=1.0)
+    _, mode = desc_flags(toc)
+    streams = np.arange(n, dtype=np.int32)
+    streams[7] = n + 5  # out of range
+    streams[9] = -1
+    for pipeline in (False, True):
+        pcm, res = run_queued(pkg, gpu_ctx, channels, arena, offs, lens, toc, pipeline=pipeline, modes=pkg.HAS_CELT, streams=streams)
+        pcm0, res0 = run_queued(pkg, gpu_ctx, channels, arena, offs, lens, toc, pipeline=False, streams=streams)
+        celt = mode == 2
+        celt[:, [7, 9]] = False
+        assert (res[~celt] == -1).all()                      # hybrid / SILK frames and the two bad stream indices
+        assert (res0[:, [7, 9]] == -1).all()
+        assert np.array_equal(res[celt], res0[celt])
+        ok = celt & (res0 == 960)
+        assert ok.sum() > 500 and np.array_equal(pcm[ok], pcm0[ok])
 
 
 def test_pipeline_with_synchronisation_points_and_reset(pkg, oracle, gpu_ctx):
