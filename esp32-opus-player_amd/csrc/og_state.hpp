@@ -188,6 +188,9 @@ constexpr int V_SYN = 960;              // the synthesis buffer: second channel'
 constexpr int SYN_LEN = 1088;
 struct FrameLds {
     alignas(16) i16 v[V_TOTAL];
+#ifdef OG_LDS_PAD /* occupancy experiments only: make the wave's LDS footprint larger */
+    u8 pad_experiment[OG_LDS_PAD];
+#endif
     // (named by code that this layout never runs)
     u8 pkt[0];
     i32 fine_quant[0], fine_prio[0], tf_res[0], cap[0], offsets[0], bits1[0], bits2[0];
@@ -207,7 +210,9 @@ static_assert(V_SYN * 2 + SYN_LEN * 4 <= V_MASK * 2, "the synthesis buffer ends 
 static_assert((V_MASK + 4 * NBANDS) * 2 + 120 <= V_TOTAL * 2, "synthesis tables fit behind the buffer");
 static_assert(V_LATE + 24 + 8 * NBANDS <= V_MASK && (V_LATE + 24) % 2 == 0, "the late-staged arrays fit the scratch rows");
 static_assert(V_MASK % 2 == 0 && V_NORM % 8 == 0 && V_IY % 8 == 0 && V_WIN % 2 == 0 && V_WIN + 128 <= V_MASK, "alignment of the overlays");
+#ifndef OG_LDS_PAD
 static_assert(sizeof(FrameLds) <= 7680, "six 1280-byte LDS granules: 21 workgroups per CU");
+#endif
 #endif
 
 } // namespace og
