@@ -1445,6 +1445,12 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
         //    landed, while the later pieces are still on their way.  A large batch goes in parts: a part's pieces travel (on the
         //    copy stream) while the next part's kernels run.  More parts start the copy earlier but pay the parse kernels' fixed
         //    latency once per part: two is the measured optimum at 65,536 frames (9.5 ms; one 11.8, four 10.7, eight 13.2).
+        // the modes a range of this call's frames contains (the kernels of the others are not launched)
+        auto modes_of = [&](size_t lo, size_t hi) {
+            int mask = 0;
+            for (size_t f = lo; f < hi && mask != 7; f++) mask |= 1 << (all[f].flags & 3);
+            return mask & 7;
+        };
         const int pieces = m >= 4096 ? OPUSGPU_COPY_PIECES : 1;
         const int parts = (pieces > 1 && !timer.on) ? ctx->host_parts : 1;
         for (int t = 0; t < pieces; t++)
@@ -1489,7 +1495,8 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
                                                    sizeof(opusgpu_frame_desc) * (fhi - flo), hipMemcpyHostToDevice, ctx->stream));
                 }
                 rc = decode_step_impl(ctx, (int)(fhi - flo), (const opusgpu_frame_desc *)ctx->d_descs + flo, ctx->d_arena,
-                                      (uint8_t *)ctx->d_pcm + flo * frame_pcm * 2, (int32_t *)ctx->d_result + flo, nullptr, false);
+                                      (uint8_t *)ctx->d_pcm + flo * frame_pcm * 2, (int32_t *)ctx->d_result + flo, nullptr, false,
+                                      modes_of(flo, fhi));
                 if (rc) return rc; // (an empty part launches nothing; its pieces' events are still recorded below)
                 HIPCHK(ctx, hipEventRecord(ctx->ev_part[h], ctx->stream));
                 HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_part[h], 0));
@@ -1497,7 +1504,7 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
             }
             timer.mark("table upload + kernels + copy-back in parts (enqueue)");
         } else {
-            rc = decode_step_impl(ctx, m, ctx->d_descs, ctx->d_arena, ctx->d_pcm, ctx->d_result, nullptr, false);
+            rc = decode_step_impl(ctx, m, ctx->d_descs, ctx->d_arena, ctx->d_pcm, ctx->d_result, nullptr, false, modes_of(0, m));
             if (rc) return rc;
             timer.mark("table upload + kernels (enqueue)");
             if (timer.on) {
