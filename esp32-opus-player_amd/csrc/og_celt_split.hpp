@@ -128,6 +128,9 @@ struct ParseLds { // [element][lane]: lanes of a wave touch consecutive addresse
         } al;
         i32 stack[5][6][OG_PL_LANES]; // split frames of the partition walk: [depth][word][lane]
     } u;
+#ifdef OG_PL_PAD /* occupancy experiments only */
+    u8 pad_experiment[OG_PL_PAD];
+#endif
 };
 // One per wave.  The union below is private to a wave only because its lanes reconverge between compute_allocation and the band
 // walk; two waves of a workgroup do not, so they must not share rows of it.

@@ -217,11 +217,13 @@ OG_DEV int rfc_end_band(int bandwidth) { // RFC 6716 section 4.3: NB 13, WB 17, 
 // the mode is the previous frame's; more than 20 ms goes in chunks of 20 ms; SILK conceals 10 or 20 ms (a 2.5 / 5 ms request takes
 // the head of a 10 ms concealment); CELT -- and hybrid's CELT layer from band 17 -- conceals with celt_decode_lost, its last band
 // what the last decoded frame made it.  `ch`: the channel count of the last packet (the descriptor's).
-OG_DEV int conceal_chunk_rfc(StreamState *st, int ch, i16 *pcm, int audiosize) { // at most 20 ms
+// `hold` (the transition smoothing of decode_frame_rfc): the audio goes to this LDS buffer of audiosize * channels entries instead
+// of `pcm`, zero where a SILK-only concealment of a mono packet in a stereo decoder defines nothing (Q3).
+OG_DEV int conceal_chunk_rfc(StreamState *st, int ch, i16 *pcm, int audiosize, i16 *hold = nullptr) { // at most 20 ms
     // the last used mode: CELT if the last frame ended with CELT redundancy
     const int CC = st->channels, mode = st->loss.prev_redundancy ? (int)MODE_CELT : st->prev_mode;
     if (mode == 0) { // nothing decoded yet: zeros
-        OG_FOR_LANES(i, audiosize * CC) pcm[i] = 0;
+        OG_FOR_LANES(i, audiosize * CC) (hold ? hold : pcm)[i] = 0;
         OG_SYNC();
         return audiosize;
     }
@@ -236,7 +238,10 @@ OG_DEV int conceal_chunk_rfc(StreamState *st, int ch, i16 *pcm, int audiosize) {
         if (ret) return INTERNAL_ERROR;
         if (mode == MODE_SILK) { // PCM = SAT16(0 + pcm_silk) over the frame's first nmix linear entries
             OG_SYNC();
-            OG_FOR_LANES(i, nmix) pcm[i] = SL().u.out.pcm[i];
+            if (hold)
+                OG_FOR_LANES(i, audiosize * CC) hold[i] = i < nmix ? SL().u.out.pcm[i] : (i16)0;
+            else
+                OG_FOR_LANES(i, nmix) pcm[i] = SL().u.out.pcm[i];
             OG_SYNC();
         }
     }
@@ -258,7 +263,13 @@ OG_DEV int conceal_chunk_rfc(StreamState *st, int ch, i16 *pcm, int audiosize) {
 #endif
         if (celt_ret >= 0) {
             OG_SYNC();
-            pcm_store(pcm, audiosize, CC, CC);
+            if (hold)
+                OG_FOR_LANES(i, audiosize * CC) {
+                    const int c = CC == 2 ? (i & 1) : 0, j = CC == 2 ? (i >> 1) : i;
+                    hold[i] = S.v[pcm_plane(c, CC, CC) + j];
+                }
+            else
+                pcm_store(pcm, audiosize, CC, CC);
             OG_SYNC();
         }
     }
@@ -310,6 +321,20 @@ OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mod
     // RFC mode keeps that and stops at the frame's own end
     const int nmix = audiosize * (ch < CC ? ch : CC);
     const int disable_inv = CC == 1, end_band = rfc_end_band(bandwidth);
+    // RFC 6716 section 4.5: a switch between CELT-only and the SILK modes that no redundant frame covers is smoothed with 5 ms of
+    // concealment from the OLD mode (as much as the frame is long, for a 2.5 ms frame), cross-faded into the new frame at the
+    // end.  The SILK modes' concealment runs before anything of the new frame is decoded, CELT's behind the frame's SILK layer.
+    // It waits in the SILK up-sampler's buffers (dead whenever it is needed; a frame with a redundant frame has no transition).
+    int transition = 0;
+#ifndef OG_NO_SILK
+    transition = prev_mode > 0 && ((mode == MODE_CELT && prev_mode != MODE_CELT && !prev_redundancy) || (mode != MODE_CELT && prev_mode == MODE_CELT));
+    i16 *const tr_hold = &SL().u.out.up[0][0];
+    const int tr_size = OG_MIN(240, audiosize);
+    if (transition && mode == MODE_CELT) {
+        const int r = conceal_chunk_rfc(st, ch, nullptr, tr_size, tr_hold);
+        if (r < 0) return r;
+    }
+#endif
     OG_SYNC();
     OG_FOR_LANES(i, len) S.pkt[i] = payload[i];
     OG_SYNC();
@@ -350,6 +375,16 @@ OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mod
         }
     }
     i16 *const red_hold = &SL().u.out.up[0][0]; // 240 * CC samples: the 2x up-sampler's buffers are dead once SILK's PCM is out
+    if (redundancy) transition = 0;
+    if (transition && mode != MODE_CELT) { // (before this frame's last band is recorded: the concealment keeps the old one)
+        const int r = conceal_chunk_rfc(st, ch, nullptr, tr_size, tr_hold);
+        if (r < 0) return r;
+        if (mode == MODE_HYBRID) { // the concealment's synthesis ran over the packet buffer: the frame's bytes again
+            OG_SYNC();
+            OG_FOR_LANES(i, len) S.pkt[i] = payload[i];
+            OG_SYNC();
+        }
+    }
 #else
     if (mode != MODE_CELT) return INTERNAL_ERROR;
     i16 *const red_hold = nullptr;
@@ -440,6 +475,12 @@ OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mod
         OG_SYNC();
         OG_FOR_LANES(i, 120 * CC) pcm[i] = red_hold[i];
         rfc_smooth_fade(pcm, CC * 120, red_hold, CC * 120, CC, false);
+    }
+    if (transition && celt_ret >= 0) { // 2.5 ms of the concealment as it is, then 2.5 ms of cross-fade (a 2.5 ms frame: from its start)
+        const int head = audiosize >= 240 ? 120 : 0;
+        OG_SYNC();
+        OG_FOR_LANES(i, head * CC) pcm[i] = tr_hold[i];
+        rfc_smooth_fade(pcm, CC * head, tr_hold, CC * head, CC, false);
     }
 #endif
     OG_SYNC();

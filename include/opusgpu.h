@@ -61,8 +61,10 @@ const char *opusgpu_last_error(const opusgpu_ctx *ctx);
  * (src/silk.cpp:1522-1540 with the real payload duration), hybrid 10 / 20 ms -- multi-frame packets (codes 1 - 3) accordingly;
  * CELT's last band follows the bandwidth (Q1 fixed) and a SILK-only frame after a hybrid one fades the CELT layer out with the
  * two-byte silence frame of RFC 6716 section 4.5.2 instead of Q4's frame off the stale coder; the redundant 5 ms CELT frames of
- * mode transitions (section 4.5.1) are decoded and cross-faded in (Q2 fixed).  Everything else stays as the reference has it
- * (Q3 mixing, Q5 partial reset, Q7 no transition smoothing).  The reference cannot produce these outputs and no libopus exists:
+ * mode transitions (section 4.5.1) are decoded and cross-faded in (Q2 fixed), and a switch between CELT-only and the SILK modes
+ * that no redundant frame covers starts with 5 ms of the old mode's concealment, cross-faded into the new frame (section 4.5).
+ * Everything else stays as the reference has it (Q3 mixing, Q5 partial reset).  The reference cannot produce these outputs and
+ * no libopus exists:
  * this mode is bit-exact to oracle/'s RFC mode (oc_decoder_set_rfc), which is PARITY-UNPINNED.
  * RFC-mode frames run on a kernel of their own (wave-uniform entropy decoding): the mode is for completeness, not speed.
  * LOSS PATH (the reference has none, Q8 -- in reference mode an empty packet stays OPUSGPU_BAD_ARG):

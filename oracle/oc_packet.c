@@ -211,7 +211,7 @@ static int rfc_end_band(int bandwidth) {
  * RFC 6716's opus_decode_frame with data == NULL.  The mode is the previous frame's; `frame_size` is what is to be concealed
  * (120 << k, or a multiple of 960): more than 20 ms goes in chunks of 20 ms; SILK conceals 10 or 20 ms (2.5 / 5 ms requests take
  * the head of a 10 ms concealment); CELT (and hybrid's CELT layer, from band 17) conceals with oc_celt_decode_lost.  No
- * transition smoothing and no redundancy, like the rest of this decoder (Q7, Q2). */
+ * redundancy (a concealed frame carries none). */
 static int conceal_frame(oc_decoder *d, i16 *out, int frame_size) {
     /* the last used mode: CELT if the last frame ended with CELT redundancy */
     const int mode = d->prev_redundancy ? OC_MODE_CELT : d->prev_mode, ch = d->stream_channels, CC = d->channels;
@@ -272,13 +272,26 @@ static int decode_frame(oc_decoder *d, const u8 *inbuf, i32 len, i16 *out, int f
      * lies beyond the frame's own 960 * channels entries is the next frame's space or past the caller's buffer.  RFC mode
      * keeps the arithmetic and stays inside the frame (packets of 120 ms fill the buffer to its last entry). */
     const int nmix = d->rfc ? audiosize * (ch < d->channels ? ch : d->channels) : audiosize * ch;
-    int i, c, celt_ret = 0, start_band, redundancy = 0, celt_to_silk = 0, celt_lost = 0;
+    int i, c, celt_ret = 0, start_band, redundancy = 0, celt_to_silk = 0, celt_lost = 0, transition = 0;
     i32 redundancy_bytes = 0;
     u32 redundant_rng = 0;
-    i16 pcm_silk[2880 * 2], redundant_audio[240 * 2];
+    i16 pcm_silk[2880 * 2], redundant_audio[240 * 2], pcm_transition[240 * 2];
     oc_rc *rc = &d->rc;
 
     if (d->rfc && (inbuf == NULL || len <= 1)) return conceal_frame(d, out, d->frame_size);
+    /* RFC 6716 section 4.5 (RFC mode; the reference has none of it): a switch between CELT-only and the SILK modes that no
+     * redundant frame covers is smoothed with 5 ms of concealment from the OLD mode, cross-faded into the new frame.  The
+     * concealment of the SILK modes runs before anything of the new frame is decoded, CELT's after the frame's SILK layer. */
+    if (d->rfc && d->prev_mode > 0 &&
+        ((mode == OC_MODE_CELT && d->prev_mode != OC_MODE_CELT && !d->prev_redundancy) || (mode != OC_MODE_CELT && d->prev_mode == OC_MODE_CELT)))
+        transition = 1;
+    /* (a SILK-only concealment of a mono packet in a stereo decoder defines only the first half of its entries, Q3: the rest
+     * cross-fades from zero) */
+    if (transition) memset(pcm_transition, 0, sizeof(pcm_transition));
+    if (transition && mode == OC_MODE_CELT) {
+        int ret = conceal_frame(d, pcm_transition, OC_MIN(240, audiosize));
+        if (ret < 0) return ret;
+    }
     oc_rc_init(rc, inbuf, len);
     if (mode != OC_MODE_CELT) {
         int decoded = 0, internal_hz;
@@ -321,6 +334,11 @@ static int decode_frame(oc_decoder *d, const u8 *inbuf, i32 len, i16 *out, int f
         }
     }
     if (mode != OC_MODE_CELT) start_band = 17;
+    if (redundancy) transition = 0;
+    if (transition && mode != OC_MODE_CELT) { /* (before the frame's own last band is set: the concealment keeps the old one) */
+        int ret = conceal_frame(d, pcm_transition, OC_MIN(240, audiosize));
+        if (ret < 0) return ret;
+    }
     if (d->bandwidth) d->celt.stream_channels = ch; /* END_BAND request has no effect (Q1) */
     d->celt.end_band = d->rfc ? rfc_end_band(d->bandwidth) : OC_NBANDS;
 
@@ -377,6 +395,16 @@ static int decode_frame(oc_decoder *d, const u8 *inbuf, i32 len, i16 *out, int f
             for (i = 0; i < 120; i++) {
                 const i32 w = m16_q15(rom_win120[i], rom_win120[i]);
                 o[i * CC + c] = (i16)((m16(w, b[i * CC + c]) + m16(32767 - w, a[i * CC + c])) >> 15);
+            }
+    }
+    if (transition) { /* 2.5 ms of the concealment as it is, then 2.5 ms of cross-fade; a 2.5 ms frame is cross-faded from its start */
+        const int CC = d->channels, head = audiosize >= 240 ? 120 : 0;
+        for (i = 0; i < head * CC; i++) out[i] = pcm_transition[i];
+        for (c = 0; c < CC; c++)
+            for (i = 0; i < 120; i++) {
+                const i32 w = m16_q15(rom_win120[i], rom_win120[i]);
+                const int at = (head + i) * CC + c;
+                out[at] = (i16)((m16(w, out[at]) + m16(32767 - w, pcm_transition[at])) >> 15);
             }
     }
     d->range_final = len <= 1 ? 0 : rc->rng ^ redundant_rng;

@@ -91,3 +91,38 @@ def test_oracle_celt_concealment_decays(oracle):
         assert early > 0 and late <= 1.15 * early, (seed, rms)
         fell += late < 0.5 * early
     assert fell >= 3, fell
+
+
+def test_oracle_mode_transitions_start_from_the_old_modes_concealment(oracle):
+    """RFC 6716 section 4.5: a CELT-only frame after SILK-only / hybrid frames (and the other way round) with no redundant frame in
+    between starts with 2.5 ms of the OLD mode's concealment, cross-fades over the next 2.5 ms and is the new frame's own audio
+    from 5 ms on.  Checked against a twin decoder with the same history that conceals 5 ms instead of decoding the packet:
+    the first 2.5 ms are identical; and against the frame decoded after a same-mode history: from 5 ms on ... the latter cannot be
+    asked of the oracle (it has no switch for the smoothing), so only the first property is pinned here."""
+    rng = np.random.default_rng(12)
+    # (old configuration, new configuration): SILK NB 20 -> CELT FB 20, hybrid FB 20 -> CELT FB 10, CELT FB 20 -> SILK WB 20,
+    # CELT WB 10 -> hybrid SWB 20, SILK WB 20 -> CELT FB 2.5 (a frame shorter than 5 ms: cross-faded from its start)
+    for channels in (1, 2):
+        for old, new in ((1, 31), (15, 30), (31, 9), (22, 13), (9, 28)):
+            st = 4 if channels == 2 else 0
+            twins = [oracle.decoder(channels) for _ in range(2)]
+            for d in twins:
+                d.init()
+                d.set_rfc(True)
+            for _ in range(3):
+                pkt = bytes([(old << 3) | st]) + rng.integers(0, 256, 8 if old < 12 else 90, dtype=np.uint8).tobytes()
+                a, ra = twins[0].decode(pkt)
+                b, rb = twins[1].decode(pkt)
+                assert ra == rb > 0 and np.array_equal(a[:ra], b[:rb])
+            # a hybrid / SILK frame that carries a redundant frame has no transition: keep the payload so short that it cannot
+            # (SILK-only: whatever follows the SILK data would be one)
+            pkt = bytes([(new << 3) | st]) + rng.integers(0, 256, 8 if new < 12 else 60, dtype=np.uint8).tobytes()
+            got, r = twins[0].decode(pkt)
+            plc, rp = twins[1].conceal(min(240, r))
+            assert r > 0 and rp == min(240, r)
+            head = 120 if r >= 240 else 0
+            if head:
+                assert np.array_equal(got[:head], plc[:head]), (channels, old, new)
+            # inside the cross-fade the frame moves away from the concealment: at its end the concealment's weight is ~ 0
+            # (the last sample's window value squared is 32767 * 32767 >> 15)
+            assert not np.array_equal(got[:r], plc[:r]) or not plc[:rp].any()
