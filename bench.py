@@ -453,8 +453,8 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=32)   # (pipelined steps: the first parse and the last de-emphasis of a run are not hidden)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="celt_fb_stereo_64k", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
     ap.add_argument("--page-crc", default="gpu", choices=["host", "gpu"],

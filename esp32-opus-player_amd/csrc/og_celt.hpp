@@ -24,7 +24,6 @@ struct WaveArr {
     OG_MEMBER i32 &fine_quant(int i) const { return S.fine_quant[i]; }
     OG_MEMBER i32 &fine_prio(int i) const { return S.fine_prio[i]; }
     OG_MEMBER i32 &tf_res(int i) const { return S.tf_res[i]; }
-    OG_MEMBER i32 &cap(int i) const { return S.cap[i]; }
     OG_MEMBER i32 &offsets(int i) const { return S.offsets[i]; }
     OG_MEMBER i32 &bits1(int i) const { return S.bits1[i]; }
     OG_MEMBER i32 &bits2(int i) const { return S.bits2[i]; }
@@ -140,6 +139,13 @@ OG_DEV void tf_decode(A a, R &rc, int start, int end, int transient, int LM) { /
     for (int i = start; i < end; i++) a.tf_res(i) = tf_select(LM, 4 * transient + 2 * tf_sel + a.tf_res(i));
 }
 
+// init_caps celt.cpp:911: the most bits a band can use, in 1/8 bit
+template <class T>
+OG_DEV i32 celt_band_cap(int j, int LM, int C) {
+    const int Nb = (T::eband(j + 1) - T::eband(j)) << LM;
+    return (T::pulse_caps(NBANDS * (2 * LM + C - 1) + j) + 64) * C * Nb >> 2;
+}
+
 // ---- bit allocation (clt_compute_allocation celt.cpp:3523, interp_bits2pulses :3298) ----------------
 template <class A, class R>
 OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i32 &intensity, i32 &dual_stereo, i32 total,
@@ -183,7 +189,7 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
             bitsj += a.offsets(j);
             if (bitsj >= thresh_of(j) || done) {
                 done = 1;
-                psum += OG_MIN(bitsj, a.cap(j));
+                psum += OG_MIN(bitsj, celt_band_cap<T>(j, LM, C));
             } else if (bitsj >= C << BITRES)
                 psum += C << BITRES;
         }
@@ -193,7 +199,7 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
     for (int j = start; j < end; j++) {
         int w = T::eband(j + 1) - T::eband(j);
         i32 b1 = C * w * T::band_alloc(lo * NBANDS + j) << LM >> 2;
-        i32 b2 = hi >= 11 ? a.cap(j) : C * w * T::band_alloc(hi * NBANDS + j) << LM >> 2;
+        i32 b2 = hi >= 11 ? celt_band_cap<T>(j, LM, C) : C * w * T::band_alloc(hi * NBANDS + j) << LM >> 2;
         if (b1 > 0) b1 = OG_MAX(0, b1 + trim_off_of(j));
         if (b2 > 0) b2 = OG_MAX(0, b2 + trim_off_of(j));
         if (lo > 0) b1 += a.offsets(j);
@@ -215,7 +221,7 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
             i32 tmp = a.bits1(j) + (mid * a.bits2(j) >> 6);
             if (tmp >= thresh_of(j) || done) {
                 done = 1;
-                psum += OG_MIN(tmp, a.cap(j));
+                psum += OG_MIN(tmp, celt_band_cap<T>(j, LM, C));
             } else if (tmp >= alloc_floor)
                 psum += alloc_floor;
         }
@@ -230,7 +236,7 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
                 tmp = tmp >= alloc_floor ? alloc_floor : 0;
             else
                 done = 1;
-            tmp = OG_MIN(tmp, a.cap(j));
+            tmp = OG_MIN(tmp, celt_band_cap<T>(j, LM, C));
             a.pulses(j) = tmp;
             psum += tmp;
         }
@@ -287,7 +293,7 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
         i32 N0 = T::eband(j + 1) - T::eband(j), N = N0 << LM, excess;
         i32 bit = a.pulses(j) + balance, bj, ej, fp;
         if (N > 1) {
-            excess = OG_MAX(bit - a.cap(j), 0);
+            excess = OG_MAX(bit - celt_band_cap<T>(j, LM, C), 0);
             bj = bit - excess;
             i32 den = C * N + ((C == 2 && N > 2 && !dual_stereo && j < intensity) ? 1 : 0);
             i32 NClogN = den * (T::logn(j) + logM);
@@ -827,10 +833,8 @@ OG_DEV void celt_parse_header(A a, R &rc, int start, int end, int C, int LM, Cel
         rc_renorm(rc);
         spread = ret;
     }
-    for (int i = 0; i < NBANDS; i++) { // init_caps celt.cpp:911
-        int Nb = (T::eband(i + 1) - T::eband(i)) << LM;
-        a.cap(i) = (T::pulse_caps(NBANDS * (2 * LM + C - 1) + i) + 64) * C * Nb >> 2;
-    }
+    // init_caps celt.cpp:911: a band's cap is a product of per-band constants -- computed where it is used instead of being kept
+    // in a per-band array (1.3 KB of the lane-per-frame parse kernel's LDS per wave: one allocation granule, see celt_band_cap)
     int dynalloc_logp = 6;
     total_bits <<= BITRES;
     tell = (i32)rc_tell_frac(rc);
@@ -838,7 +842,7 @@ OG_DEV void celt_parse_header(A a, R &rc, int start, int end, int C, int LM, Cel
         int width = C * (T::eband(i + 1) - T::eband(i)) << LM;
         int quanta = OG_MIN(width << BITRES, OG_MAX(6 << BITRES, width));
         int loop_logp = dynalloc_logp, boost = 0;
-        while (tell + (loop_logp << BITRES) < total_bits && boost < a.cap(i)) {
+        while (tell + (loop_logp << BITRES) < total_bits && boost < celt_band_cap<T>(i, LM, C)) {
             int flag = rc_bit_logp(rc, loop_logp);
             tell = (i32)rc_tell_frac(rc);
             if (!flag) break;

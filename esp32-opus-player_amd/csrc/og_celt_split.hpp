@@ -119,11 +119,13 @@ static_assert(sizeof(ParseRec) % 16 == 0, "record alignment");
 struct ParseLds { // [element][lane]: lanes of a wave touch consecutive addresses, no bank conflicts
     i32 pulses[NBANDS][OG_PL_LANES];
     i16 bandE[2 * NBANDS][OG_PL_LANES];
-    i8 fine_quant[NBANDS][OG_PL_LANES], fine_prio[NBANDS][OG_PL_LANES], tf_res[NBANDS][OG_PL_LANES];
+    i8 fine_quant[NBANDS][OG_PL_LANES];
+    i8 tf_prio[NBANDS][OG_PL_LANES]; // bits 0-3: tf_res (-3 .. 3, two's complement), bit 4: fine_prio
     union {
-        struct { // live until compute_allocation returns (caps and dynalloc boosts are made just before it), i.e. before
-                 // the first band is parsed: 14.5 KB per wave in all, 11 parse waves per CU
-            i16 cap[NBANDS][OG_PL_LANES], offsets[NBANDS][OG_PL_LANES];
+        struct { // live until compute_allocation returns (the dynalloc boosts are made just before it), i.e. before
+                 // the first band is parsed: 13.7 KB per wave in all with the ROM tables (16.1 KB before the caps went and
+                 // tf_res / fine_prio shared a byte): in pipelined steps the kernel's LDS x time is what it costs
+            i16 offsets[NBANDS][OG_PL_LANES]; // (the bands' caps are computed where they are used: celt_band_cap)
             u16 bits1[NBANDS][OG_PL_LANES], bits2[NBANDS][OG_PL_LANES];
         } al;
         i32 stack[5][6][OG_PL_LANES]; // split frames of the partition walk: [depth][word][lane]
@@ -139,7 +141,8 @@ OG_LDS ParseLds PLs[OG_PL_WAVES];
 
 // LDS copy of the entropy-decoding ROM tables (see RomGlobal, og_celt_bands.hpp), loaded once per workgroup
 struct ParseTabLds {
-    i32 eband[NBANDS + 1], logn[NBANDS], pulse_idx[105];
+    i16 eband[NBANDS + 1], logn[NBANDS];
+    u16 pulse_idx[105];
     u32 pulse_v[392]; // size of the PVQ codebook a leaf's index is decoded against, by pulse-cache index (rom_pulse_v)
     u8 pulse_bits[392], band_alloc[231], pulse_caps[168], log2_frac[24], eprob[336];
 };
@@ -168,13 +171,23 @@ OG_DEV void parse_tables_load() {
     OG_FULL_SYNC();
 }
 
+// tf_res and fine_prio of a band share a byte of the lane's column: what the shared header code sees are these two views of it
+struct TfResView {
+    i8 *p;
+    OG_MEMBER operator int() const { return (int)(i8)((u8)*p << 4) >> 4; }
+    OG_MEMBER void operator=(int v) const { *p = (i8)((*p & 0xF0) | (v & 15)); }
+};
+struct FinePrioView {
+    i8 *p;
+    OG_MEMBER operator int() const { return (*p >> 4) & 1; }
+    OG_MEMBER void operator=(int v) const { *p = (i8)((*p & ~0x10) | ((v & 1) << 4)); }
+};
 struct LaneArr {
     typedef RomLds Rom;
     OG_MEMBER i32 &pulses(int i) const { return PL.pulses[i][OG_PCOL]; }
     OG_MEMBER i8 &fine_quant(int i) const { return PL.fine_quant[i][OG_PCOL]; }
-    OG_MEMBER i8 &fine_prio(int i) const { return PL.fine_prio[i][OG_PCOL]; }
-    OG_MEMBER i8 &tf_res(int i) const { return PL.tf_res[i][OG_PCOL]; }
-    OG_MEMBER i16 &cap(int i) const { return PL.u.al.cap[i][OG_PCOL]; }
+    OG_MEMBER FinePrioView fine_prio(int i) const { return FinePrioView{&PL.tf_prio[i][OG_PCOL]}; }
+    OG_MEMBER TfResView tf_res(int i) const { return TfResView{&PL.tf_prio[i][OG_PCOL]}; }
     OG_MEMBER i16 &offsets(int i) const { return PL.u.al.offsets[i][OG_PCOL]; }
     OG_MEMBER u16 &bits1(int i) const { return PL.u.al.bits1[i][OG_PCOL]; }
     OG_MEMBER u16 &bits2(int i) const { return PL.u.al.bits2[i][OG_PCOL]; }

@@ -137,7 +137,7 @@ struct FrameLds {
     alignas(16) i16 v[V_TOTAL];
     u8 pkt[1344];              // packet bytes (<= 1275); the split path keeps its per-leaf collapse masks here
     u32 win[64];               // split path: window of the parse record's word stream
-    i32 pulses[NBANDS], fine_quant[NBANDS], fine_prio[NBANDS], tf_res[NBANDS], cap[NBANDS], offsets[NBANDS];
+    i32 pulses[NBANDS], fine_quant[NBANDS], fine_prio[NBANDS], tf_res[NBANDS], offsets[NBANDS];
     i32 bits1[NBANDS], bits2[NBANDS];
     i16 bandE[2 * NBANDS], logE1[2 * NBANDS], logE2[2 * NBANDS];
     i16 dn_g[2 * NBANDS], dn_shift[2 * NBANDS];
@@ -193,7 +193,7 @@ struct FrameLds {
 #endif
     // (named by code that this layout never runs)
     u8 pkt[0];
-    i32 fine_quant[0], fine_prio[0], tf_res[0], cap[0], offsets[0], bits1[0], bits2[0];
+    i32 fine_quant[0], fine_prio[0], tf_res[0], offsets[0], bits1[0], bits2[0];
     OG_MEMBER u8 *cmask_row() { return reinterpret_cast<u8 *>(&v[V_LATE]); }                 // 42 bytes
     OG_MEMBER i32 *pulses_row() { return reinterpret_cast<i32 *>(&v[V_LATE + 24]); }          // 21 words
     OG_MEMBER i16 *bandE_row() { return &v[V_LATE + 24 + 2 * NBANDS]; }
