@@ -123,7 +123,7 @@ struct ParseLds { // [element][lane]: lanes of a wave touch consecutive addresse
     i8 tf_prio[NBANDS][OG_PL_LANES]; // bits 0-3: tf_res (-3 .. 3, two's complement), bit 4: fine_prio
     union {
         struct { // live until compute_allocation returns (the dynalloc boosts are made just before it), i.e. before
-                 // the first band is parsed: 13.7 KB per wave in all with the ROM tables (16.1 KB before the caps went and
+                 // the first band is parsed: 14.0 KB per wave in all with the ROM tables (16.1 KB before the caps went and
                  // tf_res / fine_prio shared a byte): in pipelined steps the kernel's LDS x time is what it costs
             i16 offsets[NBANDS][OG_PL_LANES]; // (the bands' caps are computed where they are used: celt_band_cap)
             u16 bits1[NBANDS][OG_PL_LANES], bits2[NBANDS][OG_PL_LANES];
