@@ -170,3 +170,44 @@ def test_pipeline_with_synchronisation_points_and_reset(pkg, oracle, gpu_ctx):
             assert r == res[f, s]
             if r == 960:
                 assert np.array_equal(out[:960].reshape(-1), pcm[f, s])
+
+
+def test_host_path_and_device_steps_mix_with_pipelining_on(pkg, oracle, gpu_ctx):
+    """opusgpu_decode_packets queues its own uploads, so it runs in order even with pipelining on -- also right behind pipelined
+    device steps of the same streams, and before more of them."""
+    n, frames, L = 2048, 9, 160
+    toc_byte = pkg.TOC_CELT_FB_STEREO
+    pay = pkg.lcg_payloads(n, frames, L, seed_base=0x7171)
+    ref, ok = oracle.batch_decode(2, toc_byte, pay)
+    assert ok == n * frames
+    ctx = gpu_ctx
+    ctx.streams_alloc(n, 2)
+    ctx.set_pipeline(True)
+    try:
+        d_pcm, d_res = ctx.dev_alloc(n * 960 * 2 * 2), ctx.dev_alloc(4 * n)
+        tabs = []
+        for f in range(frames):
+            arena, descs = pkg.build_step(toc_byte, pay[f])
+            a, d = ctx.dev_alloc(arena.nbytes + 16), ctx.dev_alloc(descs.nbytes)
+            ctx.h2d(a, arena)
+            ctx.h2d(d, descs)
+            tabs.append((a, d))
+        got = np.zeros((n, 960, 2), dtype=np.int16)
+        res = np.zeros(n, dtype=np.int32)
+        for f in range(frames):
+            if f % 3 == 2:  # every third frame through the host-buffer path, no synchronisation before it
+                pkts = [bytes([toc_byte]) + pay[f, s].tobytes() for s in range(n)]
+                pcm, r = ctx.decode_packets(np.arange(n), pkts)
+                assert (r == 960).all() and np.array_equal(pcm.reshape(n, 960, 2), ref[:, f])
+            else:
+                ctx.decode_step_device(n, tabs[f][1], tabs[f][0], d_pcm, d_res, modes=pkg.HAS_CELT)
+                if f % 3 == 1:  # (the frame before a host-path call is read back; the other one is overwritten unseen)
+                    ctx.synchronize()
+                    ctx.d2h(got, d_pcm)
+                    ctx.d2h(res, d_res)
+                    assert (res == 960).all() and np.array_equal(got, ref[:, f])
+        ctx.synchronize()
+        for p in [d_pcm, d_res] + [x for t in tabs for x in t]:
+            ctx.dev_free(p)
+    finally:
+        ctx.set_pipeline(False)
