@@ -770,6 +770,11 @@ int opusgpu_streams_alloc(opusgpu_ctx *ctx, int n_streams, int channels) {
     if (!ctx || n_streams <= 0 || (channels != 1 && channels != 2)) return OPUSGPU_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->parse_stream) { // pipelined steps still in flight work on the state that is about to be freed
+        HIPCHK(ctx, hipStreamSynchronize(ctx->parse_stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->recon_stream));
+        if (ctx->last_step_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->last_step_stream));
+    }
     if (ctx->d_streams) {
         HIPCHK(ctx, hipFree(ctx->d_streams));
         ctx->d_streams = nullptr;
