@@ -21,7 +21,7 @@ FRAMES = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 11)
 HYBRID = len(sys.argv) > 4 and sys.argv[4] == "hybrid"
 out = np.zeros((960, 2), dtype=np.int16)
-n = bad = 0
+n = bad = left = 0
 for s in range(STREAMS):
     channels = int(rng.integers(1, 3))
     d = o.decoder(channels); d.init()
@@ -42,9 +42,12 @@ for s in range(STREAMS):
         out[:] = 0
         r2 = lib.emu_decode_frame(st, body, L, m, bw, 2 if stereo else 1, out.ctypes.data)
         n += 1
+        if r2 == -999:  # (the tight-layout library: a frame its kernel leaves to the general one -- the stream ends here)
+            left += 1
+            break
         if r != r2 or (r > 0 and not np.array_equal(out.reshape(-1)[:960 * channels], ref[:960].reshape(-1)[:960 * channels])):
             bad += 1
             if bad <= 5:
                 print("MISMATCH stream", s, "frame", f, "toc", hex(toc), "len", L, "channels", channels, r, r2)
-print(f"{n} frames, {bad} mismatches")
+print(f"{n} frames, {bad} mismatches" + (f" ({left} frames left to the general kernel)" if left else ""))
 sys.exit(1 if bad else 0)
