@@ -664,6 +664,12 @@ OG_DEV u32 pvq_mul(u32 a, u32 b) { return a * b; }
 OG_DEV u32 pvq_mul(u32 a, u32 b) { return __umul24(a, b); } // both below 256
 #endif
 
+#ifndef OG_SKIP_RATIO
+// A leaf's zero runs are skipped while it has more than this many dimensions per pulse left.  Measured (k_celt_recon_fb alone /
+// pipelined step): no skip 1.869 / 2.525 ms, ratio 1 (whenever n > k) 1.830 / 2.493, 2: 1.891, 3: 1.899, 4: 1.898 -- the wave's walk
+// is 34 steps long on average without, 10 with (tools/leaf_balance.py), but a step with a bisection in it costs three plain ones.
+#define OG_SKIP_RATIO 1
+#endif
 OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spread) {
     const int N = n, K = k, x = pos;
     const int logB = ilog2(B), blen = N >> logB; // B is a power of two
@@ -681,6 +687,46 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
     int cb_n = T.cb[n], cb_n1 = T.cb[n - 1]; // column bases of n and n - 1
     u32 t0 = T.cc[k >= 4 ? cb_n + k : 0], t1 = T.cc[k >= 3 ? cb_n + k + 1 : 0]; // U(n, k), U(n, k + 1) where they are table rows
     while (n > 2) {
+        if (k == 0) break; // every pulse is placed: what is left of the leaf stays zero
+#ifndef OG_NO_ZERO_SKIP
+        // A sparse leaf (many dimensions, few pulses) is mostly runs of zeros, and the wave waits for its longest leaf: the run is
+        // skipped in one go.  With V(a) = U(a, k) + U(a, k + 1) the dimensions n, n-1, .., a+1 all decode to zero exactly when
+        //     V(n) - V(a) <= 2 i < V(n) + V(a)
+        // (the zero steps subtract U(n, k), U(n-1, k), ..: their sum down to a+1 is (V(n) - V(a)) / 2 by the recurrence
+        // U(t, k+1) = U(t-1, k+1) + U(t, k) + U(t-1, k); the other bound is the one that keeps every step's sign test false);
+        // V grows with a, so the smallest such a is found by bisection over column entries that sit side by side.  Then
+        // i -= (V(n) - V(a)) / 2 and the walk goes on at dimension a -- with a pulse, unless the search range ended there.
+        // (tools/pvq_zero_run.py checks the identity against the step-by-step walk.)
+        if (k <= 13 && n > OG_SKIP_RATIO * k && n > 3) {
+            const u32 hn = (u32)n, w2 = 2u * hn - 1u, w3 = 2u * pvq_mul(hn, hn - 1u) + 1u;
+            const u32 un0 = k >= 4 ? t0 : pvq_row_sel(k, w2, w3), un1 = k >= 3 ? t1 : pvq_row_sel(k + 1, w2, w3);
+            const unsigned long long Vn = (unsigned long long)un0 + un1, i2 = 2ull * i;
+            unsigned long long Vlo = Vn;
+            int lo = k + 1 > 2 ? k + 1 : 2, hi = n;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1, cbm = T.cb[mid];
+                const u32 hm = (u32)mid, m2 = 2u * hm - 1u, m3 = 2u * pvq_mul(hm, hm - 1u) + 1u;
+                const u32 c0 = T.cc[k >= 4 ? cbm + k : 0], c1 = T.cc[k >= 3 ? cbm + k + 1 : 0];
+                const u32 a0 = k >= 4 ? c0 : pvq_row_sel(k, m2, m3), a1 = k >= 3 ? c1 : pvq_row_sel(k + 1, m2, m3);
+                const unsigned long long Va = (unsigned long long)a0 + a1;
+                if (Vn - Va <= i2 && i2 < Vn + Va) {
+                    hi = mid;
+                    Vlo = Va;
+                } else
+                    lo = mid + 1;
+            }
+            if (lo < n) {
+                i -= (u32)((Vn - Vlo) >> 1);
+                pos += n - lo;
+                n = lo;
+                if (n <= 2) break;
+                cb_n = T.cb[n];
+                cb_n1 = T.cb[n - 1];
+                t0 = T.cc[k >= 4 ? cb_n + k : 0];
+                t1 = T.cc[k >= 3 ? cb_n + k + 1 : 0];
+            }
+        }
+#endif
         const int cb_n2 = T.cb[n - 2];
         const u32 h = (u32)n, v2 = 2u * h - 1u, v3 = 2u * pvq_mul(h, h - 1u) + 1u; // U(2, n), U(3, n)
 #if defined(OG_WALK_ABL) && OG_WALK_ABL >= 3

@@ -27,6 +27,11 @@ int emu_last_leaf_geom(unsigned *out, int cap) {
     for (int i = 0; i < n; i++) out[i] = rec.leaf_geom[i];
     return rec.n_leaves;
 }
+int emu_last_leaf_idx(unsigned *out, int cap) { // ... and their codeword indices
+    const int n = rec.n_leaves < cap ? rec.n_leaves : cap;
+    for (int i = 0; i < n; i++) out[i] = rec.leaf_idx[i];
+    return rec.n_leaves;
+}
 int emu_decode_frame(void *stv, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm) {
     og::StreamState *st = (og::StreamState *)stv;
     static og::SilkHandoff handoff;

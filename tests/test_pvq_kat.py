@@ -82,3 +82,36 @@ def test_pvq_leaf_over_all_reachable_n_k(oracle):
                     assert (a[:n] == b[:n]).all(), ("X", n, k, index, B, spread, gain)
                     checked += 1
     assert checked > 20000
+
+
+def test_pvq_sparse_leaves_many_indices(oracle):
+    """The leaf walk skips runs of zeros in sparse leaves by bisection (og_celt_split.hpp, pvq_leaf_lane): every reachable
+    (N, K) with more than one dimension per pulse, many indices each -- random ones, the first and last, and the ones around
+    every U(N, j) boundary, where a run ends or a sign flips."""
+    emu = C.CDLL(os.path.join(ROOT, "tests", "emul", "libog_emul.so"))
+    emu.emu_pvq_leaf.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    emu.emu_pvq_leaf.restype = C.c_uint
+    oracle.lib.oc_test_pvq_leaf.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    oracle.lib.oc_test_pvq_leaf.restype = C.c_uint
+    rng = np.random.default_rng(18)
+    a, b = np.zeros(176, dtype=np.int16), np.zeros(176, dtype=np.int16)
+    memo = {}
+    _v(2, 2, memo)
+
+    def u(x, y):
+        _v(x, y, memo)
+        return memo[(x, y)]
+    checked = 0
+    for n, k in [(n, k) for n, k in reachable_nk() if n >= 4 and n > k]:
+        v = _v(n, k, memo)
+        idxs = {0, 1, v - 1, v - 2} | {int(x) for x in rng.integers(0, v, 60)}
+        for j in range(1, k + 2):
+            for d in (-1, 0, 1):
+                idxs.add(u(n, j) + d)
+                idxs.add(u(n - 1, j) + d)
+        for index in sorted(x for x in idxs if 0 <= x < v):
+            ma = emu.emu_pvq_leaf(n, k, index, 1, 32767, 0, a.ctypes.data)
+            mb = oracle.lib.oc_test_pvq_leaf(n, k, index, 0, 1, 32767, b.ctypes.data)
+            assert ma == mb and np.array_equal(a[:n], b[:n]), (n, k, index)
+            checked += 1
+    assert checked > 10000

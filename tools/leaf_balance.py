@@ -39,20 +39,21 @@ for s in range(S):
 print(f"{S * F} frames: leaves per frame mean {np.mean(nl):.0f} max {max(nl)}; cost model n + {W} k")
 print(f"  summed round maxima, record order {tot_now / (S * F):.0f} per frame; sorted by cost {tot_sorted / (S * F):.0f}; perfect balance {tot_sum / (S * F):.0f}")
 print("  leaf sizes n (count):", {int(i): int(c) for i, c in enumerate(hist_n) if c})
-# which leaf is the round's longest
-from collections import Counter
-cnt = Counter()
-zs = []
-for s in range(min(S, 32)):
+# the walk itself: the wave's loop runs as long as its longest leaf's (tools/pvq_zero_run.py restates the kernel's walk)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import pvq_zero_run as Z
+lib.emu_last_leaf_idx.argtypes = [C.c_void_p, C.c_int]
+idx = np.zeros(512, dtype=np.uint32)
+res = {r: [] for r in (0, 1, 2, 4)}
+for s in range(min(S, 24)):
     st = C.create_string_buffer(lib.emu_state_size()); lib.emu_stream_init(st, 2)
     for f in range(F):
         lib.emu_decode_frame(st, pay[f, s].tobytes(), 160, 1002, 1105, 2, out.ctypes.data)
-        n_l = lib.emu_last_leaf_geom(geom.ctypes.data, 512)
-        g = geom[:n_l]
-        n, k = ((g >> 11) & 255).astype(int), ((g >> 19) & 255).astype(int)
-        cost = n + W * k
-        j = int(np.argmax(cost))
-        cnt[(int(n[j]), int(k[j]))] += 1
-        zs.append((n[j], k[j], np.sort(cost)[::-1][:4].tolist()))
-print("  longest leaf (n, k): count", sorted(cnt.items(), key=lambda t: -t[1])[:16])
-print("  examples (n, k of the longest; top-4 costs):", zs[:8])
+        n_l = lib.emu_last_leaf_geom(geom.ctypes.data, 512); lib.emu_last_leaf_idx(idx.ctypes.data, 512)
+        for r in res:
+            its = [Z.walk_steps(int((g >> 11) & 255), int((g >> 19) & 255), int(ix), r) for g, ix in zip(geom[:n_l], idx[:n_l])]
+            res[r].append((max(t[0] for t in its), max(t[1] for t in its)))
+for r in res:
+    a = np.array(res[r])
+    print(f"  index walk, zero runs skipped while n > {r} k (0: never): the frame's longest leaf takes {a[:, 0].mean():.1f} steps, "
+          f"{a[:, 1].mean():.1f} of them with a bisection")
