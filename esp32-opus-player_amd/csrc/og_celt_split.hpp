@@ -666,7 +666,7 @@ OG_DEV u32 pvq_mul(u32 a, u32 b) { return __umul24(a, b); } // both below 256
 
 #ifndef OG_SKIP_RATIO
 // A leaf's zero runs are skipped while it has more than this many dimensions per pulse left.  Measured (k_celt_recon_fb alone /
-// pipelined step): no skip 1.869 / 2.525 ms, ratio 1 (whenever n > k) 1.830 / 2.493, 2: 1.891, 3: 1.899, 4: 1.898 -- the wave's walk
+// pipelined step): no skip 1.869 / 2.525 ms, ratio 1 (whenever n > k) 1.825 / 2.49, 2: 1.891, 3: 1.899, 4: 1.898 -- the wave's walk
 // is 34 steps long on average without, 10 with (tools/leaf_balance.py), but a step with a bisection in it costs three plain ones.
 #define OG_SKIP_RATIO 1
 #endif
@@ -691,7 +691,7 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
 #ifndef OG_NO_ZERO_SKIP
         // A sparse leaf (many dimensions, few pulses) is mostly runs of zeros, and the wave waits for its longest leaf: the run is
         // skipped in one go.  With V(a) = U(a, k) + U(a, k + 1) the dimensions n, n-1, .., a+1 all decode to zero exactly when
-        //     V(n) - V(a) <= 2 i < V(n) + V(a)
+        //     V(n) - V(a) <= 2 i < V(n) + V(a)          (one comparison: V(a) >= m, see below)
         // (the zero steps subtract U(n, k), U(n-1, k), ..: their sum down to a+1 is (V(n) - V(a)) / 2 by the recurrence
         // U(t, k+1) = U(t-1, k+1) + U(t, k) + U(t-1, k); the other bound is the one that keeps every step's sign test false);
         // V grows with a, so the smallest such a is found by bisection over column entries that sit side by side.  Then
@@ -700,25 +700,44 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
         if (k <= 13 && n > OG_SKIP_RATIO * k && n > 3) {
             const u32 hn = (u32)n, w2 = 2u * hn - 1u, w3 = 2u * pvq_mul(hn, hn - 1u) + 1u;
             const u32 un0 = k >= 4 ? t0 : pvq_row_sel(k, w2, w3), un1 = k >= 3 ? t1 : pvq_row_sel(k + 1, w2, w3);
-            const unsigned long long Vn = (unsigned long long)un0 + un1, i2 = 2ull * i;
-            unsigned long long Vlo = Vn;
-            int lo = k + 1 > 2 ? k + 1 : 2, hi = n;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1, cbm = T.cb[mid];
-                const u32 hm = (u32)mid, m2 = 2u * hm - 1u, m3 = 2u * pvq_mul(hm, hm - 1u) + 1u;
-                const u32 c0 = T.cc[k >= 4 ? cbm + k : 0], c1 = T.cc[k >= 3 ? cbm + k + 1 : 0];
-                const u32 a0 = k >= 4 ? c0 : pvq_row_sel(k, m2, m3), a1 = k >= 3 ? c1 : pvq_row_sel(k + 1, m2, m3);
-                const unsigned long long Va = (unsigned long long)a0 + a1;
-                if (Vn - Va <= i2 && i2 < Vn + Va) {
-                    hi = mid;
-                    Vlo = Va;
-                } else
-                    lo = mid + 1;
+            const unsigned long long Vn = (unsigned long long)un0 + un1;
+            // both bounds in one: with d = 2 i - V(n) (in [-V(n), V(n))) the run reaches down to a + 1 exactly when
+            // V(a) >= m, m = d >= 0 ? d + 1 : -d
+            const long long d = (long long)(2ull * i) - (long long)Vn;
+            const unsigned long long m = d >= 0 ? (unsigned long long)d + 1ull : (unsigned long long)(-d);
+            const int lo0 = k + 1 > 2 ? k + 1 : 2;
+            int a;
+            unsigned long long Va;
+            if (k <= 2) { // V(a, 1) = 2 a and V(a, 2) = 2 a^2: solved, not searched (m <= V(n) <= 2 * 176^2)
+                const u32 t = (u32)((m + 1ull) >> 1);
+                int r = (int)t;
+                if (k == 2) {
+                    r = (int)__builtin_sqrtf((float)t); // within one of the root (t < 2^24 is exact as a float): its ceiling after
+                    r += (u32)(r * r) < t;              // the two corrections
+                    r -= r > 0 && (u32)((r - 1) * (r - 1)) >= t;
+                }
+                a = r > lo0 ? r : lo0;
+                Va = k == 1 ? 2ull * (u32)a : 2ull * (u32)(a * a);
+            } else {
+                int lo = lo0, hi = n;
+                Va = Vn;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1, cbm = T.cb[mid];
+                    const u32 c0 = T.cc[k >= 4 ? cbm + k : 0], c1 = T.cc[cbm + k + 1];
+                    const u32 a0 = k >= 4 ? c0 : 2u * pvq_mul((u32)mid, (u32)mid - 1u) + 1u; // (row 3 in closed form)
+                    const unsigned long long Vm = (unsigned long long)a0 + c1;
+                    if (Vm >= m) {
+                        hi = mid;
+                        Va = Vm;
+                    } else
+                        lo = mid + 1;
+                }
+                a = lo;
             }
-            if (lo < n) {
-                i -= (u32)((Vn - Vlo) >> 1);
-                pos += n - lo;
-                n = lo;
+            if (a < n) {
+                i -= (u32)((Vn - Va) >> 1);
+                pos += n - a;
+                n = a;
                 if (n <= 2) break;
                 cb_n = T.cb[n];
                 cb_n1 = T.cb[n - 1];
