@@ -601,8 +601,9 @@ struct opusgpu_ctx {
     hipEvent_t ev_recon = nullptr;  // step k: its reconstruction has finished (on recon_stream)
     hipEvent_t ev_post[3] = {};     // by slot: k_celt_post of the last step that used it has finished (on the step's stream)
     const void *last_recs = nullptr;
-    int head_start_ticks = 2500; // 25 us of the 100 MHz clock (OPUSGPU_HEAD_START_US)
-    int post_delay_ticks = 10000; // 100 us (OPUSGPU_POST_DELAY_US): see decode_step_impl
+    int head_start_ticks = 4000; // 40 us of the 100 MHz clock (OPUSGPU_HEAD_START_US): the event's way to the parse queue was
+                                 // measured at 10 - 15 us; 15 / 25 / 40 us of head start give the same step time within 0.4 %
+    int post_delay_ticks = 15000; // 150 us (OPUSGPU_POST_DELAY_US): see decode_step_impl
     // the last decode step's tables, for opusgpu_debug_stage_taps
     const void *last_descs = nullptr;
     int last_n = 0, last_had_silk_recs = 0;
@@ -971,7 +972,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         HIPCHK(ctx, hipEventRecord(ctx->ev_rstart, back));
         ctx->rstart_recorded = 1;
         // the next step's early parse is released by that event and has to be placed BEFORE this reconstruction fills the CUs
-        // (see above): the event's way to the other queue takes ~10 us, so the reconstruction is held back a little longer
+        // (see above): the event's way to the other queue takes ~10 us, so the reconstruction is held back longer than that
         if (ctx->head_start_ticks > 0) hipLaunchKernelGGL(k_head_start, dim3(1), dim3(64), 0, back, ctx->head_start_ticks);
     }
     if (any_celt) {
