@@ -92,7 +92,7 @@ int opusgpu_get_mode(const opusgpu_ctx *ctx);
  * before its reconstruction: the range decoder of a CELT frame predicts the band energies from the previous frame's, and
  * the SILK half reads the SILK state.  With pipelining on, the library carries the band energies in the parse kernel
  * (k_celt_parse) and runs that kernel for step k+1's CELT-only frames on a stream of its own, NEXT TO step k's
- * reconstruction (k_celt_recon_fb / k_celt_post), into a second set of parse records; the reconstruction runs on another
+ * reconstruction (k_celt_recon_fb / k_celt_post), into one of three rotating sets of parse records; the reconstruction runs on another
  * stream of the library's own and never touches the caller's buffers, the step's own stream waits for it before the
  * de-emphasis (k_celt_post) writes PCM and result codes.  Results are bit-identical to the in-order flow (tests/test_gpu_pipeline.py); the step's stream
  * still completes everything the step launched, so the caller synchronises exactly as before.
