@@ -115,3 +115,30 @@ def test_pvq_sparse_leaves_many_indices(oracle):
             assert ma == mb and np.array_equal(a[:n], b[:n]), (n, k, index)
             checked += 1
     assert checked > 10000
+
+
+def test_zero_run_identity_in_exact_integers():
+    """What the kernel's zero-run skip rests on (tools/pvq_zero_run.py): with V(a) = U(a, k) + U(a, k + 1) the dimensions n .. a+1
+    of a codeword all decode to zero exactly when V(n) - V(a) <= 2 i < V(n) + V(a), and skipping them subtracts (V(n) - V(a)) / 2
+    -- checked against the step-by-step walk (cwrsi, src/celt.cpp:2545) in Python's exact integers."""
+    import random
+    spec = importlib.util.spec_from_file_location("pvq_zero_run", os.path.join(ROOT, "tools", "pvq_zero_run.py"))
+    z = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(z)
+    random.seed(5)
+    n_cases = 0
+    for n in (3, 4, 6, 8, 11, 16, 22, 24, 36, 48, 72, 96, 144, 176):
+        for k in (1, 2, 3, 4, 5, 7, 10, 13, 14, 20, 40):
+            v = z.V(n, k)
+            if v >= 2 ** 32:
+                continue
+            picks = [0, v - 1, z.U(n, k), z.U(n, k) - 1, z.U(n, k + 1), z.U(n, k + 1) - 1] + [random.randrange(v) for _ in range(12)]
+            for i in picks:
+                if not 0 <= i < v:
+                    continue
+                ref = z.cwrsi_ref(n, k, i)
+                assert sum(abs(x) for x in ref) == k and len(ref) == n
+                for ratio in (1, 2):
+                    assert z.cwrsi_skip2(n, k, i, ratio) == ref, (n, k, i, ratio)
+                n_cases += 1
+    assert n_cases > 1500
