@@ -211,3 +211,40 @@ def test_host_path_and_device_steps_mix_with_pipelining_on(pkg, oracle, gpu_ctx)
             ctx.dev_free(p)
     finally:
         ctx.set_pipeline(False)
+
+
+def test_placement_heuristics_change_no_result(pkg, oracle):
+    """The hold-backs and the LDS padding that decide which kernel of a pipelined step is placed first (OPUSGPU_HEAD_START_US,
+    OPUSGPU_POST_DELAY_US, OPUSGPU_POST_PAD, OPUSGPU_PARSE_PRIORITY) are performance heuristics: with any of them at an extreme the
+    kernels meet in a different order on the CUs and the bytes stay the same."""
+    import os
+    n, frames, L = 8192, 8, 160
+    toc_byte = pkg.TOC_CELT_FB_STEREO
+    pay = pkg.lcg_payloads(n, frames, L, seed_base=0x9191)
+    ref, ok = oracle.batch_decode(2, toc_byte, pay)
+    assert ok == n * frames
+    plen = np.full((frames, n), L + 1, dtype=np.int64)
+    offs = np.arange(frames * n, dtype=np.int64).reshape(frames, n) * (L + 1)
+    arena = np.zeros(frames * n * (L + 1) + 16, dtype=np.uint8)
+    blk = arena[: frames * n * (L + 1)].reshape(frames, n, L + 1)
+    blk[:, :, 0] = toc_byte
+    blk[:, :, 1:] = pay
+    toc = np.full((frames, n), toc_byte, dtype=np.uint8)
+    settings = [{"OPUSGPU_HEAD_START_US": "0"}, {"OPUSGPU_POST_DELAY_US": "0"}, {"OPUSGPU_POST_PAD": "0"},
+                {"OPUSGPU_POST_PAD": "40960"}, {"OPUSGPU_PARSE_PRIORITY": "0"},
+                {"OPUSGPU_HEAD_START_US": "300", "OPUSGPU_POST_DELAY_US": "2000"}]
+    for env in settings:
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ctx = pkg.Context(0)  # (the variables are read when a context is created)
+            pcm, res = run_queued(pkg, ctx, 2, arena, offs, plen - 1, toc, pipeline=True, modes=pkg.HAS_CELT)
+            assert (res == 960).all(), env
+            assert np.array_equal(pcm.reshape(frames, n, 960, 2).transpose(1, 0, 2, 3), ref), env
+            ctx.close() if hasattr(ctx, "close") else None
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
