@@ -353,30 +353,38 @@ __global__ void __launch_bounds__(64, OG_SPARSE_WAVES) k_silk_parse(const FrameD
 enum { PARSE_ALL = 0, PARSE_CELT_ONLY = 1, PARSE_HYBRID_ONLY = 2 };
 __global__ void __launch_bounds__(64 * OG_PL_WAVES, 2) k_celt_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
                                                       StreamState *st, ParseRec *recs, int n, int n_streams,
-                                                      const SilkHandoff *handoff, int which) {
+                                                      const SilkHandoff *handoff, int which, int groups) {
+    // `groups`: a workgroup parses that many groups of OG_PL_FRAMES frames one after the other (1: the grid covers the step once)
     const bool lane_on = (int)(threadIdx.x & 63) < OG_PL_LANES;
-    const int f = (int)blockIdx.x * OG_PL_FRAMES + OG_PWAVE * OG_PL_LANES + OG_PCOL;
+    const int f0 = (int)blockIdx.x * groups * OG_PL_FRAMES + OG_PWAVE * OG_PL_LANES + OG_PCOL;
     if (which != PARSE_ALL) { // a launch that finds none of its frames among the workgroup's leaves without loading the tables
         bool mine = false;
-        if (lane_on && f < n) {
-            const int m0 = desc_mode(descs[f].flags);
-            mine = which == PARSE_CELT_ONLY ? m0 == MODE_CELT : m0 == MODE_HYBRID;
+        for (int g = 0; g < groups; g++) {
+            const int f = f0 + g * OG_PL_FRAMES;
+            if (lane_on && f < n) {
+                const int m0 = desc_mode(descs[f].flags);
+                mine |= which == PARSE_CELT_ONLY ? m0 == MODE_CELT : m0 == MODE_HYBRID;
+            }
         }
         if (!__syncthreads_or(mine)) return;
     }
     parse_tables_load();
-    if (!lane_on || f >= n) return;
-    const FrameDesc d = descs[f];
-    const int mode = desc_mode(d.flags);
-    if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && handoff)) || desc_rfc(d.flags)) return;
-    if ((which == PARSE_CELT_ONLY && mode != MODE_CELT) || (which == PARSE_HYBRID_ONLY && mode != MODE_HYBRID)) return;
+    if (!lane_on) return;
+    for (int g = 0; g < groups; g++) {
+        const int f = f0 + g * OG_PL_FRAMES;
+        if (f >= n) break;
+        const FrameDesc d = descs[f];
+        const int mode = desc_mode(d.flags);
+        if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && handoff)) || desc_rfc(d.flags)) continue;
+        if ((which == PARSE_CELT_ONLY && mode != MODE_CELT) || (which == PARSE_HYBRID_ONLY && mode != MODE_HYBRID)) continue;
 #ifdef OG_PROF_PARSE // profiling builds: time the sections of the parse kernel instead of the recon kernel (full batches only)
-    OG_PROF_INIT();
+        OG_PROF_INIT();
 #endif
-    celt_parse_lane(&st[d.stream], arena + d.offset, d.len, desc_channels(d.flags), &recs[f], mode == MODE_HYBRID ? &handoff[f] : nullptr);
+        celt_parse_lane(&st[d.stream], arena + d.offset, d.len, desc_channels(d.flags), &recs[f], mode == MODE_HYBRID ? &handoff[f] : nullptr);
 #ifdef OG_PROF_PARSE
-    OG_PROF_FLUSH();
+        OG_PROF_FLUSH();
 #endif
+    }
 }
 
 // Split CELT path, second half: one frame per wave, driven by the parse record.
@@ -608,6 +616,11 @@ struct opusgpu_ctx {
                                  // measured at 10 - 15 us; 15 / 25 / 40 us of head start give the same step time within 0.4 %
     int post_delay_ticks = 15000; // 150 us (OPUSGPU_POST_DELAY_US): see decode_step_impl
     int post_pad_bytes = 10240;   // (OPUSGPU_POST_PAD): see decode_step_impl
+    // (OPUSGPU_PARSE_GROUPS) groups of 32 frames per workgroup of the early parse: with two, half as many parse workgroups are
+    // resident for about twice as long, each group runs nearer to a lone wave's pace, and the reconstruction next to them has
+    // the LDS of the other half -- 1 / 2 / 3 / 4 groups: 2.545 / 2.50 / 2.52 / 2.97 ms per step on one box (at four the parse
+    // outlasts the reconstruction and the next step waits for it)
+    int parse_groups = 2;
     // the last decode step's tables, for opusgpu_debug_stage_taps
     const void *last_descs = nullptr;
     int last_n = 0, last_had_silk_recs = 0;
@@ -668,6 +681,7 @@ int opusgpu_ctx_create(int device, opusgpu_ctx **out) {
     if (const char *e = getenv("OPUSGPU_HEAD_START_US")) ctx->head_start_ticks = atoi(e) * 100;
     if (const char *e = getenv("OPUSGPU_POST_DELAY_US")) ctx->post_delay_ticks = atoi(e) * 100;
     if (const char *e = getenv("OPUSGPU_POST_PAD")) ctx->post_pad_bytes = atoi(e);
+    if (const char *e = getenv("OPUSGPU_PARSE_GROUPS")) ctx->parse_groups = atoi(e) > 0 && atoi(e) <= 8 ? atoi(e) : 1;
     if (const char *e = getenv("OPUSGPU_HOST_PARTS")) {
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ctx->host_parts = v;
@@ -921,7 +935,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
                                (const u8 *)d_arena, (const StreamState *)ctx->d_streams, srecs, handoff, n, ctx->n_streams);
         if (any_celt)
             hipLaunchKernelGGL(k_celt_parse, parse_grid, parse_block, 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams,
-                               recs, n, ctx->n_streams, (const SilkHandoff *)handoff, (int)PARSE_ALL);
+                               recs, n, ctx->n_streams, (const SilkHandoff *)handoff, (int)PARSE_ALL, 1);
     } else {
         // the early parse: behind the front of the step before, its own slot's last user (three steps back), and -- so that it
         // and the reconstruction of the step before START TOGETHER -- that reconstruction's start.  The parse is one round of
@@ -932,15 +946,16 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         if (ctx->rstart_recorded) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_rstart, 0));
         if (ctx->post_recorded[par]) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_post[par], 0));
         if (modes & 4)
-            hipLaunchKernelGGL(k_celt_parse, parse_grid, parse_block, 0, ctx->parse_stream, (const FrameDesc *)d_descs, (const u8 *)d_arena,
-                               ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)nullptr, (int)PARSE_CELT_ONLY);
+            hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_FRAMES * ctx->parse_groups - 1) / (OG_PL_FRAMES * ctx->parse_groups)), parse_block, 0,
+                               ctx->parse_stream, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams, recs, n, ctx->n_streams,
+                               (const SilkHandoff *)nullptr, (int)PARSE_CELT_ONLY, ctx->parse_groups);
         HIPCHK(ctx, hipEventRecord(ctx->ev_parsed, ctx->parse_stream));
         if (srecs) {
             hipLaunchKernelGGL(k_silk_parse, dim3((n + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, s, (const FrameDesc *)d_descs,
                                (const u8 *)d_arena, (const StreamState *)ctx->d_streams, srecs, handoff, n, ctx->n_streams);
             if (modes & 2)
                 hipLaunchKernelGGL(k_celt_parse, parse_grid, parse_block, 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams,
-                                   recs, n, ctx->n_streams, (const SilkHandoff *)handoff, (int)PARSE_HYBRID_ONLY);
+                                   recs, n, ctx->n_streams, (const SilkHandoff *)handoff, (int)PARSE_HYBRID_ONLY, 1);
         }
     }
     bool others_ran = false; // (the kernels that report stream-index errors for every mode)
