@@ -248,3 +248,24 @@ def test_placement_heuristics_change_no_result(pkg, oracle):
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
+
+
+@pytest.mark.parametrize("n", [1, 33, 1000])
+def test_pipelined_steps_of_odd_sizes(pkg, oracle, gpu_ctx, n):
+    """Batch sizes that fill neither a parse wave's 32 lanes nor a parse workgroup's two groups."""
+    frames, L = 6, 160
+    toc_byte = pkg.TOC_CELT_FB_STEREO
+    pay = pkg.lcg_payloads(n, frames, L, seed_base=0x3300 + n)
+    ref, ok = oracle.batch_decode(2, toc_byte, pay)
+    assert ok == n * frames
+    plen = np.full((frames, n), L + 1, dtype=np.int64)
+    offs = np.arange(frames * n, dtype=np.int64).reshape(frames, n) * (L + 1)
+    arena = np.zeros(frames * n * (L + 1) + 16, dtype=np.uint8)
+    blk = arena[: frames * n * (L + 1)].reshape(frames, n, L + 1)
+    blk[:, :, 0] = toc_byte
+    blk[:, :, 1:] = pay
+    toc = np.full((frames, n), toc_byte, dtype=np.uint8)
+    for modes in (0, pkg.HAS_CELT):
+        pcm, res = run_queued(pkg, gpu_ctx, 2, arena, offs, plen - 1, toc, pipeline=True, modes=modes)
+        assert (res == 960).all()
+        assert np.array_equal(pcm.reshape(frames, n, 960, 2).transpose(1, 0, 2, 3), ref)
