@@ -829,9 +829,21 @@ int opusgpu_memcpy_h2d(opusgpu_ctx *ctx, void *dst, const void *src, size_t byte
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return OPUSGPU_OK;
 }
+// Whatever pipelined steps still have in flight -- the last step's reconstruction on recon_stream, an early parse, the step's
+// own stream when the caller supplied one -- works on state, records and ReconOut: a read-back waits for all of it, not only
+// for the context's stream.
+static int sync_in_flight(opusgpu_ctx *ctx) {
+    if (ctx->parse_stream) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->parse_stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->recon_stream));
+    }
+    if (ctx->last_step_stream && ctx->last_step_stream != ctx->stream) HIPCHK(ctx, hipStreamSynchronize(ctx->last_step_stream));
+    return OPUSGPU_OK;
+}
 int opusgpu_memcpy_d2h(opusgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx) return OPUSGPU_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_in_flight(ctx)) return rc;
     HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return OPUSGPU_OK;
@@ -1149,6 +1161,7 @@ int opusgpu_stream_state_get(opusgpu_ctx *ctx, int index, void *dst, size_t byte
 int opusgpu_debug_stage_taps(opusgpu_ctx *ctx, int slot, opusgpu_stage_taps *out) {
     if (!ctx || !out || slot < 0 || slot >= ctx->last_n || !ctx->last_descs) return OPUSGPU_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_in_flight(ctx)) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     memset(out, 0, sizeof(*out));
     FrameDesc d;
@@ -1477,10 +1490,14 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
         //    landed, while the later pieces are still on their way.  A large batch goes in parts: a part's pieces travel (on the
         //    copy stream) while the next part's kernels run.  More parts start the copy earlier but pay the parse kernels' fixed
         //    latency once per part: two is the measured optimum at 65,536 frames (9.5 ms; one 11.8, four 10.7, eight 13.2).
-        // the modes a range of this call's frames contains (the kernels of the others are not launched)
+        // the modes a range of this step's frames contains (the kernels of the others are not launched).  The range indexes the
+        // table that is uploaded: `all` itself in the pipelined flow (single-frame packets in packet order ARE the step table),
+        // `step` otherwise -- step[j] = all[first[owner[j]] + k], a different set of frames than all[lo .. hi) as soon as one packet
+        // of the call has more than one frame.
         auto modes_of = [&](size_t lo, size_t hi) {
+            const opusgpu_frame_desc *table = pipelined ? all.get() : step.data();
             int mask = 0;
-            for (size_t f = lo; f < hi && mask != 7; f++) mask |= 1 << (all[f].flags & 3);
+            for (size_t f = lo; f < hi && mask != 7; f++) mask |= 1 << (table[f].flags & 3);
             return mask & 7;
         };
         const int pieces = m >= 4096 ? OPUSGPU_COPY_PIECES : 1;

@@ -199,7 +199,7 @@ def test_more_short_frames_than_room_is_refused(pkg, gpu_ctx):
     assert (res2 == 960).all() and (res3 == 960).all() and (pcm2 == pcm3).all()
 
 
-def test_packets_in_one_array_decode_like_a_list_of_packets(pkg, gpu_ctx):
+def test_packets_in_one_array_decode_like_a_list_of_packets(pkg, oracle, gpu_ctx):
     """Context.decode_packets_arena (pointer table made by numpy) against Context.decode_packets (one buffer per packet):
     ragged packets of all three modes, multi-frame packets, an empty and a malformed packet, a reused PCM array."""
     rng = np.random.default_rng(17)
@@ -236,3 +236,46 @@ def test_packets_in_one_array_decode_like_a_list_of_packets(pkg, gpu_ctx):
             assert np.array_equal(out[i, :res[i]], want[rnd][0][i, :res[i]]), (rnd, i)
     with pytest.raises(ValueError):
         gpu_ctx.decode_packets_arena(ids, arena, offs + 10**9, lens)
+    # ... and both against the oracle: the two entry points share decode_packets_impl, so a framing or mode-mask slip in it
+    # would cancel out in the comparison above
+    dec = [oracle.decoder(2) for _ in range(n)]
+    for d in dec:
+        d.init()
+    for rnd in range(2):
+        for i in range(n):
+            o, r = dec[i].decode_cap(packets[i], cap)
+            assert want[rnd][1][i] == r, (rnd, i, want[rnd][1][i], r)
+            if r > 0:
+                assert np.array_equal(want[rnd][0][i, :r], o[:r]), (rnd, i)
+
+
+def test_steps_of_a_multi_frame_call_launch_the_kernels_of_their_own_modes(pkg, oracle, gpu_ctx):
+    """opusgpu_decode_packets with room for several frames runs one step per frame index; a step's mode mask (which kernels
+    are launched at all) has to come from that step's own table.  Packets whose frame counts differ by mode make the steps'
+    mode sets differ from any prefix of the call's frames in packet order: [2-frame CELT, 1-frame SILK, 2-frame hybrid],
+    and batches whose first packets do not hold every mode."""
+    rng = np.random.default_rng(23)
+
+    def body(L):
+        return rng.integers(0, 256, size=L, dtype=np.uint8).tobytes()
+
+    C, S, H = pkg.TOC_CELT_FB_STEREO, pkg.TOC_SILK_NB_STEREO, pkg.TOC_HYBRID_FB_STEREO
+    batches = [
+        [bytes([C | 1]) + body(2 * 70), bytes([S]) + body(40), bytes([H | 1]) + body(2 * 90)],
+        [bytes([C | 1]) + body(2 * 70), bytes([S]) + body(40)],                       # step 0 = [C, S], all[0..2) = [C, C]
+        [bytes([S | 1]) + body(2 * 30), bytes([C]) + body(100)],                      # step 0 = [S, C], all[0..2) = [S, S]
+        [bytes([H | 3, 3]) + body(3 * 60), bytes([H | 3, 3]) + body(3 * 60), bytes([S]) + body(33), bytes([C]) + body(77)],
+        [bytes([C | 3, 3]) + body(3 * 50)] * 5 + [bytes([S | 1]) + body(2 * 25)] + [bytes([H]) + body(64)],
+    ]
+    for bi, packets in enumerate(batches):
+        n = len(packets)
+        gpu_ctx.streams_alloc(n, 2)
+        dec = [oracle.decoder(2) for _ in range(n)]
+        for d in dec:
+            d.init()
+        for rnd in range(2):  # (a second round: the streams' state advanced for every packet of the first)
+            pcm, res = gpu_ctx.decode_packets(np.arange(n), packets, frame_capacity=3)
+            for i in range(n):
+                o, r = dec[i].decode_cap(packets[i], 3)
+                assert res[i] == r, (bi, rnd, i, int(res[i]), r)
+                assert r > 0 and np.array_equal(pcm[i, :r], o[:r]), (bi, rnd, i)

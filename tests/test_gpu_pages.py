@@ -20,7 +20,9 @@ def _shard():
     return m
 
 
-def _run(pkg, oracle, ctx, n, pages_per_stream, packets_per_page, threads):
+def _run(pkg, oracle, ctx, n, pages_per_stream, packets_per_page, threads, pipeline=False):
+    """pipeline: all steps queued back to back with opusgpu_set_pipeline on (each step's PCM and results in buffers of their
+    own), compared after one synchronisation -- the CELT-only third of every step parses ahead of the step before."""
     shard = _shard()
     modes = ((pkg.TOC_SILK_NB_STEREO, 40), (pkg.TOC_HYBRID_FB_STEREO, 120), (pkg.TOC_CELT_FB_STEREO, 160))
     frames = pages_per_stream * packets_per_page
@@ -48,15 +50,23 @@ def _run(pkg, oracle, ctx, n, pages_per_stream, packets_per_page, threads):
     assert lay.counts == [n] * frames
     ctx.streams_alloc(n, 2)
     d_work = ctx.dev_alloc(work.size)
-    d_pcm = ctx.dev_alloc(n * 960 * 2 * 2)
-    d_res = ctx.dev_alloc(4 * n)
+    nbuf = frames if pipeline else 1
+    d_pcms = [ctx.dev_alloc(n * 960 * 2 * 2) for _ in range(nbuf)]
+    d_ress = [ctx.dev_alloc(4 * n) for _ in range(nbuf)]
     out = np.zeros((n, 960, 2), dtype=np.int16)
     res = np.zeros(n, dtype=np.int32)
     try:
         ctx.h2d(d_work, work)
-        for k in range(frames):
-            ctx.decode_work_step(d_work, lay, k, d_pcm, d_res)
+        if pipeline:
+            ctx.set_pipeline(True)
+            for k in range(frames):
+                ctx.decode_work_step(d_work, lay, k, d_pcms[k], d_ress[k])
             ctx.synchronize()
+        for k in range(frames):
+            d_pcm, d_res = d_pcms[k % nbuf], d_ress[k % nbuf]
+            if not pipeline:
+                ctx.decode_work_step(d_work, lay, k, d_pcm, d_res)
+                ctx.synchronize()
             ctx.d2h(out, d_pcm)
             ctx.d2h(res, d_res)
             assert (res == 960).all(), f"step {k}: {(res != 960).sum()} frames failed"
@@ -72,12 +82,20 @@ def _run(pkg, oracle, ctx, n, pages_per_stream, packets_per_page, threads):
                 bad = np.nonzero((out[slots] != want).reshape(len(slots), -1).any(axis=1))[0]
                 assert bad.size == 0, f"step {k} mode {m}: {bad.size} streams differ from the oracle, first {stream[slots][bad[:5]]}"
     finally:
-        for p in (d_work, d_pcm, d_res):
+        if pipeline:
+            ctx.set_pipeline(False)
+        for p in [d_work] + d_pcms + d_ress:
             ctx.dev_free(p)
 
 
 def test_mixed_mode_pages_small(pkg, oracle, gpu_ctx):
     _run(pkg, oracle, gpu_ctx, 3 * 1024, 2, 5, threads=2)
+    _run(pkg, oracle, gpu_ctx, 3 * 1024, 2, 5, threads=2, pipeline=True)
+
+
+def test_mixed_mode_pages_c5_share_pipelined(pkg, oracle, gpu_ctx):
+    """The same share with pipelined steps, all ten queued back to back (what bench.py's mixed_pages_2m workload times)."""
+    _run(pkg, oracle, gpu_ctx, 262144 - 262144 % 3, 1, 10, threads=16, pipeline=True)
 
 
 def test_mixed_mode_pages_c5_share(pkg, oracle, gpu_ctx):
