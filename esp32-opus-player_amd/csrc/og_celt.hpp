@@ -540,6 +540,11 @@ OG_DEV void pcm_store(i16 *pcm, int n, int C, int CC) {
 // Inverse MDCT of every block of one output channel (clt_mdct_backward celt.cpp:3204), reading
 // the denormalised coefficients on the fly.  B blocks of NBk = N/B outputs, transform size 2*NBk.
 OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int shift, int C, int CC) {
+#if defined(OG_RECON_TIGHT) && !defined(OG_HOST_EMUL)
+    // this layout only sees 20 ms frames: one 1920-point transform or eight 240-point ones (the code of the other two sizes --
+    // a third of the kernel's instruction bytes -- is not generated)
+    if (!((N == 960 && LM == 3) && ((B == 1 && shift == 0) || (B == 8 && shift == 3)))) __builtin_unreachable();
+#endif
     const int NBk = N / B, N2 = NBk, N4 = N2 >> 1;
     const i16 *trig = rom_mdct_trig + (shift == 0 ? 0 : shift == 1 ? 960 : shift == 2 ? 1440 : 1680);
     const i16 *br = bitrev_for(shift);
@@ -655,7 +660,7 @@ OG_DEV i32 syn_at(const CeltState *st, int c, int idx) {
 // In-place pitch comb filter on the synthesis buffer [off .. off+N) of channel c (comb_filter celt.cpp:848).  In place the filter
 // is recursive with delay >= min(T0,T1)-2 >= 13 samples, so samples are produced in chunks of that
 // many, spread over the lanes; all taps of a chunk are already final.
-OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, int N, i32 g0, i32 g1, int tap0, int tap1) {
+OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, int N, i32 g0, i32 g1, int tap0, int tap1, int ring_pos_now) {
     if (g0 == 0 && g1 == 0) return;
     // gains[tapset][0..2] Q15 (celt.cpp:854)
     T0 = OG_MAX(T0, 15);
@@ -710,7 +715,7 @@ OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, in
     // The ring head does not move during the filter: read it once (a reload per tap would put an HBM round trip in front of
     // every history load).  LDS taps are plain LDS reads (index clamped), only the history taps branch to a global load --
     // never one generic pointer for both.
-    const int ring_pos = OG_UNI(st->ring_pos);
+    const int ring_pos = ring_pos_now; // (the ring head does not move during the frame: the caller has it)
     // (explicit address spaces: two generic pointers would be folded back into one flat load)
     const __attribute__((address_space(1))) i32 *ring = (const __attribute__((address_space(1))) i32 *)st->ring[c];
     const __attribute__((address_space(3))) i32 *lds = (const __attribute__((address_space(3))) i32 *)syn_buf();
@@ -918,6 +923,12 @@ struct CeltSynth {
     LossState *loss;   // RFC mode: the noise floor follows the decoded energies and the loss counter restarts (celt.cpp:2411-2440)
     int lost;          // a concealed frame (celt_decode_lost): the energy histories, the post-filter and its state stay as they are
     int energies_kept_by_parse = 0; // split path: CeltState::bandE is written by the parse kernel (celt_parse_lane), not here
+    // the stream's post-filter state and ring head, when the caller has them in registers already (the reconstruction kernel
+    // fetches every scalar it needs of the stream in one batch at its start, og_celt_split.hpp ReconHdr); else read here
+    int have_state = 0;
+    int st_pf_period, st_pf_period_old, st_pf_tapset, st_pf_tapset_old, st_ring_pos;
+    i32 st_pf_gain, st_pf_gain_old;
+    // the energy histories the frame starts from are in S.logE1_row() / S.logE2_row() (all callers stage them there)
 };
 
 // De-emphasis and float-to-int16 of one channel of one frame, lane-private (celt.cpp:1965-2055, sig2word16 celt.h:413):
@@ -1067,10 +1078,10 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
         st->logE2[i] = (i16)l2;
     }
     const int B = transient ? M : 1, shift = transient ? 3 : 3 - LM;
-    const int pp = OG_MAX(st->pf_period, 15), ppo = OG_MAX(st->pf_period_old, 15);
-    const i32 pg = st->pf_gain, pgo = st->pf_gain_old;
-    const int pt = st->pf_tapset, pto = st->pf_tapset_old;
-    const int pos = st->ring_pos;
+    const int pp = OG_MAX(p.have_state ? p.st_pf_period : st->pf_period, 15), ppo = OG_MAX(p.have_state ? p.st_pf_period_old : st->pf_period_old, 15);
+    const i32 pg = p.have_state ? p.st_pf_gain : st->pf_gain, pgo = p.have_state ? p.st_pf_gain_old : st->pf_gain_old;
+    const int pt = p.have_state ? p.st_pf_tapset : st->pf_tapset, pto = p.have_state ? p.st_pf_tapset_old : st->pf_tapset_old;
+    const int pos = p.have_state ? p.st_ring_pos : st->ring_pos;
     i32 *const SY = syn_buf();
     // ---- one output channel at a time through the single synthesis buffer
     // (the 8 KB layout synthesises the second channel first: its spectrum lies where the buffer starts)
@@ -1086,8 +1097,8 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
         OG_TAP(2 + 16 * c); // IMDCT output
 #if !(defined(OG_ABLATE) && OG_ABLATE == 3)
         if (!p.lost) {
-            comb_filter(st, c, 0, ppo, pp, 120, pgo, pg, pto, pt);
-            if (LM != 0) comb_filter(st, c, 120, pp, pf_pitch, N - 120, pg, pf_gain, pt, pf_tapset);
+            comb_filter(st, c, 0, ppo, pp, 120, pgo, pg, pto, pt, pos);
+            if (LM != 0) comb_filter(st, c, 120, pp, pf_pitch, N - 120, pg, pf_gain, pt, pf_tapset, pos);
         }
         OG_TAP(3 + 16 * c); // comb filter output
 #if !(defined(OG_ABLATE) && OG_ABLATE == 4)

@@ -586,21 +586,21 @@ OG_DEV void celt_parse_lane(StreamState *st, const u8 *payload, int len, int ch,
 // collapse mask (extract_collapse_mask :760).  Everything is a serial chain per leaf, so the frame's leaves run
 // one per lane; the result is written in place at S.v[pos .. pos+n).  Returns the collapse mask.
 #ifdef OG_LEAF_ROT_SIMPLE
-OG_DEV void rotate1_lane(int x, int len, int stride, i32 c, i32 s) { // exp_rotation1 celt.cpp:684
+OG_DEV void rotate1_lane(i16 *xv, int x, int len, int stride, i32 c, i32 s) { // exp_rotation1 celt.cpp:684
     const i32 ms = tr16(-s);
     for (int i = 0; i < len - stride; i++) {
-        const i32 x1 = S.v[x + i], x2 = S.v[x + i + stride];
-        S.v[x + i + stride] = (i16)pshr32(mul16(c, x2) + mul16(s, x1), 15);
-        S.v[x + i] = (i16)pshr32(mul16(c, x1) + mul16(ms, x2), 15);
+        const i32 x1 = xv[x + i], x2 = xv[x + i + stride];
+        xv[x + i + stride] = (i16)pshr32(mul16(c, x2) + mul16(s, x1), 15);
+        xv[x + i] = (i16)pshr32(mul16(c, x1) + mul16(ms, x2), 15);
     }
     for (int i = len - 2 * stride - 1; i >= 0; i--) {
-        const i32 x1 = S.v[x + i], x2 = S.v[x + i + stride];
-        S.v[x + i + stride] = (i16)pshr32(mul16(c, x2) + mul16(s, x1), 15);
-        S.v[x + i] = (i16)pshr32(mul16(c, x1) + mul16(ms, x2), 15);
+        const i32 x1 = xv[x + i], x2 = xv[x + i + stride];
+        xv[x + i + stride] = (i16)pshr32(mul16(c, x2) + mul16(s, x1), 15);
+        xv[x + i] = (i16)pshr32(mul16(c, x1) + mul16(ms, x2), 15);
     }
 }
 #else
-OG_DEV void rotate1_lane(int x, int len, int stride, i32 c, i32 s) { // exp_rotation1 celt.cpp:684
+OG_DEV void rotate1_lane(i16 *xv, int x, int len, int stride, i32 c, i32 s) { // exp_rotation1 celt.cpp:684
     // The reference sweeps i = 0 .. len-stride-1 forward, then len-2*stride-1 .. 0 backward, over pairs (i, i+stride).
     // Pairs with different i mod stride never touch the same element, so each residue class ("chain") can be walked
     // on its own, carrying the element both consecutive steps share in a register: one LDS read and one write per step.
@@ -608,24 +608,24 @@ OG_DEV void rotate1_lane(int x, int len, int stride, i32 c, i32 s) { // exp_rota
     for (int r = 0; r < stride; r++) {
         if (r < len - stride) { // forward along the chain r, r+stride, ...
             int i = r;
-            i32 x1 = S.v[x + i];
+            i32 x1 = xv[x + i];
             for (; i < len - stride; i += stride) {
-                const i32 x2 = S.v[x + i + stride];
-                S.v[x + i] = (i16)pshr32(mul16(c, x1) + mul16(ms, x2), 15);
+                const i32 x2 = xv[x + i + stride];
+                xv[x + i] = (i16)pshr32(mul16(c, x1) + mul16(ms, x2), 15);
                 x1 = tr16(pshr32(mul16(c, x2) + mul16(s, x1), 15));
             }
-            S.v[x + i] = (i16)x1;
+            xv[x + i] = (i16)x1;
         }
         const int last = len - 2 * stride - 1;
         if (last >= r) { // backward: from the chain's highest start index <= last down to r
             int i = last - (last - r) % stride;
-            i32 x2 = S.v[x + i + stride];
+            i32 x2 = xv[x + i + stride];
             for (; i >= 0; i -= stride) {
-                const i32 x1 = S.v[x + i];
-                S.v[x + i + stride] = (i16)pshr32(mul16(c, x2) + mul16(s, x1), 15);
+                const i32 x1 = xv[x + i];
+                xv[x + i + stride] = (i16)pshr32(mul16(c, x2) + mul16(s, x1), 15);
                 x2 = tr16(pshr32(mul16(c, x1) + mul16(ms, x2), 15));
             }
-            S.v[x + r] = (i16)x2;
+            xv[x + r] = (i16)x2;
         }
     }
 }
@@ -648,8 +648,25 @@ static_assert(sizeof(PvqLds) <= (V_TOTAL - V_NORM) * 2, "the PVQ table overlays 
 #endif
 OG_DEV PvqLds &pvq_lds() { return *reinterpret_cast<PvqLds *>(&S.v[V_NORM]); }
 OG_DEV void pvq_tab_load() { // (the caller synchronises)
+#ifdef OG_HOST_EMUL
     OG_FOR_LANES(t, ROM_PVQ_CC_LEN) pvq_lds().cc[t] = rom_pvq_cc[t];
     OG_FOR_LANES(t, 177) pvq_lds().cb[t] = rom_pvq_cb[t];
+#else
+    // every load requested before the first store waits for its data (a load - wait - store loop pays the L2's latency per pass)
+    constexpr int NCC = (ROM_PVQ_CC_LEN + OG_NLANES - 1) / OG_NLANES, NCB = (177 + OG_NLANES - 1) / OG_NLANES;
+    u32 cc[NCC];
+    u16 cb[NCB];
+#pragma unroll
+    for (int k = 0; k < NCC; k++) cc[k] = rom_pvq_cc[OG_MIN(OG_LANE + k * OG_NLANES, ROM_PVQ_CC_LEN - 1)];
+#pragma unroll
+    for (int k = 0; k < NCB; k++) cb[k] = rom_pvq_cb[OG_MIN(OG_LANE + k * OG_NLANES, 176)];
+#pragma unroll
+    for (int k = 0; k < NCC; k++)
+        if (OG_LANE + k * OG_NLANES < ROM_PVQ_CC_LEN) pvq_lds().cc[OG_LANE + k * OG_NLANES] = cc[k];
+#pragma unroll
+    for (int k = 0; k < NCB; k++)
+        if (OG_LANE + k * OG_NLANES < 177) pvq_lds().cb[OG_LANE + k * OG_NLANES] = cb[k];
+#endif
 }
 // U(r, h) for a row r <= 3 (<= h), given U(2, h) and U(3, h); written without branches on purpose: the lanes of a wave
 // ask for different rows, and as control flow every row would cost the wave a pass of its own
@@ -670,7 +687,9 @@ OG_DEV u32 pvq_mul(u32 a, u32 b) { return __umul24(a, b); } // both below 256
 // is 34 steps long on average without, 10 with (tools/leaf_balance.py), but a step with a bisection in it costs three plain ones.
 #define OG_SKIP_RATIO 1
 #endif
-OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spread) {
+// `xv`: the spectrum arena of the leaf's frame (the calling wave's own working set -- or another wave's when the leaves of the
+// workgroup's frames are pooled, og_recon.hip); `T`: the table copy to walk.
+OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos, int B, i32 gain, int spread) {
     const int N = n, K = k, x = pos;
     const int logB = ilog2(B), blen = N >> logB; // B is a power of two
     i32 yy = 0;
@@ -683,7 +702,6 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
     // so the step is a handful of register operations.  A pulse (k changes) refetches.  Steps with n <= k take the general
     // form below it.  The spectrum was cleared before the leaf pass: zeros are not stored.
     OG_MARK(56);
-    const PvqLds &T = pvq_lds();
     int cb_n = T.cb[n], cb_n1 = T.cb[n - 1]; // column bases of n and n - 1
     u32 t0 = T.cc[k >= 4 ? cb_n + k : 0], t1 = T.cc[k >= 3 ? cb_n + k + 1 : 0]; // U(n, k), U(n, k + 1) where they are table rows
     while (n > 2) {
@@ -749,7 +767,7 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
         const int cb_n2 = T.cb[n - 2];
         const u32 h = (u32)n, v2 = 2u * h - 1u, v3 = 2u * pvq_mul(h, h - 1u) + 1u; // U(2, n), U(3, n)
 #if defined(OG_WALK_ABL) && OG_WALK_ABL >= 3
-        if (true) { S.v[pos] = (i16)(i & 1); yy += 1; } else
+        if (true) { xv[pos] = (i16)(i & 1); yy += 1; } else
 #endif
         if (n > k) {
             const u32 nx0 = T.cc[k >= 4 ? cb_n1 + k : 0], nx1 = T.cc[k >= 3 ? cb_n1 + k + 1 : 0]; // the next step's, if k stays
@@ -794,7 +812,7 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
                 k = kk;
                 i -= plo;
                 const int val = (k0 - k + s) ^ s;
-                S.v[pos] = (i16)val;
+                xv[pos] = (i16)val;
                 yy += val * val;
                 t0 = T.cc[k >= 4 ? cb_n1 + k : 0];
                 t1 = T.cc[k >= 3 ? cb_n1 + k + 1 : 0];
@@ -830,7 +848,7 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
                 k = lo;
                 i -= plo;
                 const int val = (k0 - k + s) ^ s;
-                S.v[pos] = (i16)val;
+                xv[pos] = (i16)val;
                 yy += val * val;
             }
             t0 = T.cc[k >= 4 ? cb_n1 + k : 0]; // in case the next step has n - 1 > k
@@ -849,11 +867,11 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
         k = (int)((i + 1) >> 1);
         if (k) i -= 2 * (u32)k - 1;
         int val = (k0 - k + s) ^ s;
-        S.v[pos++] = (i16)val;
+        xv[pos++] = (i16)val;
         yy += val * val;
         s = -(int)i;
         val = (k + s) ^ s;
-        S.v[pos] = (i16)val;
+        xv[pos] = (i16)val;
         yy += val * val;
     }
     // collapse mask from the pulses
@@ -863,7 +881,7 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
         cm = 0;
         for (int b = 0, j = 0; b < B; b++) {
             u32 any = 0;
-            for (int e = 0; e < blen; e++, j++) any |= (u32)(u16)S.v[x + j];
+            for (int e = 0; e < blen; e++, j++) any |= (u32)(u16)xv[x + j];
             cm |= (u32)(any != 0) << b;
         }
     }
@@ -872,7 +890,7 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
     const int kk = ilog2(yy) >> 1;
     const i32 t = vshr32(yy, 2 * (kk - 7));
     const i32 g = tr16(mul16_p15(rsqrt_norm(t), gain));
-    for (int j = 0; j < N; j++) S.v[x + j] = (i16)pshr32(mul16(g, S.v[x + j]), kk + 1);
+    for (int j = 0; j < N; j++) xv[x + j] = (i16)pshr32(mul16(g, xv[x + j]), kk + 1);
     OG_MARK(59);
     if (2 * K < N && spread != 0) {
         const int factor = spread == 1 ? 15 : (spread == 2 ? 10 : 5);
@@ -885,8 +903,8 @@ OG_DEV u32 pvq_leaf_lane(int n, int k, u32 i, int pos, int B, i32 gain, int spre
             while ((stride2 * stride2 + stride2) * B + (B >> 2) < N) stride2++;
         }
         for (int blk2 = 0; blk2 < B; blk2++) {
-            if (stride2) rotate1_lane(x + blk2 * blen, blen, stride2, s, c);
-            rotate1_lane(x + blk2 * blen, blen, 1, c, s);
+            if (stride2) rotate1_lane(xv, x + blk2 * blen, blen, stride2, s, c);
+            rotate1_lane(xv, x + blk2 * blen, blen, 1, c, s);
         }
     }
     return cm;
@@ -1746,35 +1764,114 @@ enum { RECON_ALL = 0, RECON_FAST_ONLY = 1, RECON_REST_ONLY = 2, RECON_NOT_MINE =
 struct ReconOut {
     i32 ret, pos;
 };
-OG_DEV bool recon_fast_eligible(const ParseRec *rec) {
-    const u32 flags = (u32)OG_UNI(rec->flags);
-    if (flags & (RF_SKIP | RF_BAD_CELT)) return false;
-    return ((flags >> RF_LM_SHIFT) & 3) == 3 && OG_UNI(rec->n_words) < REC_MAX_WORDS && OG_UNI(rec->n_leaves) <= FAST_MAX_LEAVES;
-}
 
-OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int ch, int role = RECON_ALL) {
-    const u32 flags = (u32)OG_UNI(rec->flags);
-    const int ret = OG_UNI(rec->ret);
-    if (flags & RF_SKIP) return role == RECON_FAST_ONLY ? (int)RECON_NOT_MINE : ret;
-    const bool fast = recon_fast_eligible(rec);
-    if ((role == RECON_FAST_ONLY && !fast) || (role == RECON_REST_ONLY && fast)) return RECON_NOT_MINE;
-    const int CC = st->channels, C = ch, prev_mode = st->prev_mode;
+// Everything the reconstruction reads of the record's header and of the stream's scalars.  The kernel of 20 ms frames
+// (og_recon.hip) fills it from two batched loads at its start -- a dozen dependent round trips to HBM one after the other, each
+// followed by its wait, were 17 % of a wave's lifetime in the section profile (profiles/r02/a_celt_recon_sections_5: "outside") --
+// the general kernel and the host emulation by plain loads (recon_hdr_load).
+struct ReconHdr {
+    i32 ret;
+    u32 rng_final, flags;
+    i32 pf_pitch, pf_gain, pf_tapset, start, n_leaves, n_words;
+    u32 need_norm;
+    i32 channels, prev_mode, frames_decoded;
+    u32 rng;
+    i32 ring_pos, st_pf_period, st_pf_period_old, st_pf_gain, st_pf_gain_old, st_pf_tapset, st_pf_tapset_old;
+};
+OG_DEV void recon_hdr_load(const StreamState *st, const ParseRec *rec, ReconHdr &h) {
+    h.ret = OG_UNI(rec->ret); h.rng_final = (u32)OG_UNI(rec->rng_final); h.flags = (u32)OG_UNI(rec->flags);
+    h.pf_pitch = OG_UNI(rec->pf_pitch); h.pf_gain = OG_UNI(rec->pf_gain); h.pf_tapset = OG_UNI(rec->pf_tapset);
+    h.start = OG_UNI(rec->start); h.n_leaves = OG_UNI(rec->n_leaves); h.n_words = OG_UNI(rec->n_words);
+    h.need_norm = (u32)OG_UNI(rec->need_norm);
+    h.channels = OG_UNI(st->channels); h.prev_mode = OG_UNI(st->prev_mode); h.frames_decoded = OG_UNI(st->frames_decoded);
+    const CeltState *cs = &st->celt;
+    h.rng = (u32)OG_UNI(cs->rng); h.ring_pos = OG_UNI(cs->ring_pos);
+    h.st_pf_period = OG_UNI(cs->pf_period); h.st_pf_period_old = OG_UNI(cs->pf_period_old);
+    h.st_pf_gain = OG_UNI(cs->pf_gain); h.st_pf_gain_old = OG_UNI(cs->pf_gain_old);
+    h.st_pf_tapset = OG_UNI(cs->pf_tapset); h.st_pf_tapset_old = OG_UNI(cs->pf_tapset_old);
+}
+#ifndef OG_HOST_EMUL
+// The same in ONE vector load (per-lane addresses): lanes 0-15 the record's first 16 words, 16-19 the stream's first four,
+// 20-31 the twelve words of CeltState from `deemph` on; then lane reads.  (Layout asserted below.)
+static_assert(offsetof(ParseRec, ret) == 0 && offsetof(ParseRec, rng_final) == 4 && offsetof(ParseRec, flags) == 8 && offsetof(ParseRec, pf_pitch) == 16 &&
+              offsetof(ParseRec, pf_gain) == 20 && offsetof(ParseRec, pf_tapset) == 24 && offsetof(ParseRec, start) == 28 &&
+              offsetof(ParseRec, n_leaves) == 32 && offsetof(ParseRec, n_words) == 36 && offsetof(ParseRec, need_norm) == 40, "record header words");
+static_assert(offsetof(StreamState, channels) == 0 && offsetof(StreamState, prev_mode) == 4, "stream header words");
+static_assert(offsetof(CeltState, rng) == offsetof(CeltState, deemph) + 8 && offsetof(CeltState, ring_pos) == offsetof(CeltState, deemph) + 12 &&
+              offsetof(CeltState, pf_period) == offsetof(CeltState, deemph) + 16 && offsetof(CeltState, pf_tapset_old) == offsetof(CeltState, deemph) + 36,
+              "stream scalar words");
+OG_DEV i32 recon_hdr_fetch(const StreamState *st, const ParseRec *rec) { // the lane's word of the batch
+    const int l = OG_LANE;
+    const i32 *p = l < 16 ? reinterpret_cast<const i32 *>(rec) + l
+                 : l < 20 ? reinterpret_cast<const i32 *>(st) + (l - 16)
+                          : reinterpret_cast<const i32 *>(&st->celt.deemph[0]) + ((l < 32 ? l : 31) - 20);
+    return *p;
+}
+OG_DEV void recon_hdr_unpack(i32 w, ReconHdr &h) {
+#define OG_HW(lane) __builtin_amdgcn_readlane(w, lane)
+    h.ret = OG_HW(0); h.rng_final = (u32)OG_HW(1); h.flags = (u32)OG_HW(2); h.pf_pitch = OG_HW(4); h.pf_gain = OG_HW(5); h.pf_tapset = OG_HW(6);
+    h.start = OG_HW(7); h.n_leaves = OG_HW(8); h.n_words = OG_HW(9); h.need_norm = (u32)OG_HW(10);
+    h.channels = OG_HW(16); h.prev_mode = OG_HW(17); h.frames_decoded = OG_HW(18);
+    h.rng = (u32)OG_HW(22); h.ring_pos = OG_HW(23); h.st_pf_period = OG_HW(24); h.st_pf_period_old = OG_HW(25); h.st_pf_gain = OG_HW(26);
+    h.st_pf_gain_old = OG_HW(27); h.st_pf_tapset = OG_HW(28); h.st_pf_tapset_old = OG_HW(29);
+#undef OG_HW
+}
+#endif
+
+// The reconstruction of a frame in three stages, so that the middle one -- the PVQ leaves -- can be done for several frames of a
+// workgroup at once (og_recon.hip); celt_recon_wave below strings them together for one frame.
+//   recon_begin    is the frame this kernel's?  stream reset on a mode change, the spectrum cleared
+//   (leaf pass)    every PVQ leaf: index -> pulses -> scaled, de-rotated coefficients + collapse mask (pvq_leaf_lane)
+//   recon_finish   band loop, anti-collapse, synthesis, stream bookkeeping; returns the frame's result code
+struct ReconCtx {
+    ReconHdr h;
+    u32 flags, rng_final;
+    int ret, mode, C;
+    bool leaves; // the frame has a leaf pass and a synthesis (its record is not a BAD_CELT one)
+    bool fast;
+    bool was_reset = false; // the stream's CELT state was reset at this frame (mode change)
+    // what recon_finish stages late, fetched early by the caller (per lane: entry `lane` of the record's band energies and
+    // pulses, of the stream's two energy histories as they were BEFORE a reset), or not (pre == false: read there)
+    bool pre = false;
+    i32 pre_bandE, pre_logE1, pre_logE2, pre_pulses;
+};
+OG_DEV bool recon_fast_eligible(const ReconHdr &h) {
+    if (h.flags & (RF_SKIP | RF_BAD_CELT)) return false;
+    return ((h.flags >> RF_LM_SHIFT) & 3) == 3 && h.n_words < REC_MAX_WORDS && h.n_leaves <= FAST_MAX_LEAVES;
+}
+// (rx.h filled by the caller.)  Returns false when the frame is not for this kernel (rx.ret then holds what celt_recon_wave
+// returns for it)
+OG_DEV bool recon_begin(StreamState *st, const ParseRec *rec, int mode, int ch, int role, ReconCtx &rx) {
+    rx.flags = rx.h.flags;
+    rx.ret = rx.h.ret;
+    rx.mode = mode;
+    rx.C = ch;
+    rx.leaves = false;
+    if (rx.flags & RF_SKIP) {
+        if (role == RECON_FAST_ONLY) rx.ret = (int)RECON_NOT_MINE;
+        return false;
+    }
+    rx.fast = recon_fast_eligible(rx.h);
+    if ((role == RECON_FAST_ONLY && !rx.fast) || (role == RECON_REST_ONLY && rx.fast)) {
+        rx.ret = (int)RECON_NOT_MINE;
+        return false;
+    }
+    const int prev_mode = rx.h.prev_mode;
     if (mode != prev_mode && prev_mode > 0) {
-        celt_reset_state(&st->celt);
+        celt_reset_state(&st->celt); // (and the copies of what it clears)
+        rx.was_reset = true;
+        rx.h.rng = 0;
+        rx.h.st_pf_period = rx.h.st_pf_period_old = rx.h.st_pf_tapset = rx.h.st_pf_tapset_old = 0;
+        rx.h.st_pf_gain = rx.h.st_pf_gain_old = 0;
         OG_SYNC();
     }
-    const u32 rng_final = (u32)OG_UNI(rec->rng_final);
-    int result = ret;
-    if (!(flags & RF_BAD_CELT)) {
-        const int LM = (int)(flags >> RF_LM_SHIFT) & 3, M = 1 << LM, N = M * 120;
-        const int transient = (flags & RF_TRANSIENT) != 0, silence = (flags & RF_SILENCE) != 0;
-        const int spread = (int)(flags >> RF_SPREAD_SHIFT) & 3, start = OG_UNI(rec->start), end = NBANDS;
-        const int n_leaves = OG_UNI(rec->n_leaves);
-        CeltState *cs = &st->celt;
-        // ---- stage the record's header arrays and the persistent scalars
+    rx.rng_final = rx.h.rng_final;
+    if (!(rx.flags & RF_BAD_CELT)) {
+        rx.leaves = true;
         OG_MARK(1);
         OG_SYNC();
 #ifndef OG_RECON_TIGHT
+        CeltState *cs = &st->celt;
         OG_FOR_LANES(i, 2 * NBANDS) {
             S.bandE_row()[i] = rec->bandE[i];
             S.logE1_row()[i] = cs->logE1[i];
@@ -1786,73 +1883,97 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
             S.tf_res[i] = rec->tf_res[i];
         }
 #endif
-        // the phase-major band loop takes every 20 ms frame whose record did not overflow (hybrid: from band 17)
-#if defined(OG_NO_PM) && !defined(OG_RECON_TIGHT)
-        const bool pm = false;
-#else
-        const bool pm = fast;
-#endif
 #ifdef OG_HOST_EMUL
-        OG_FOR_LANES(i, 2 * N) S.v[V_X + i] = 0;
+        OG_FOR_LANES(i, 2 * 960) S.v[V_X + i] = 0;
 #else
-        OG_FOR_LANES(i, 2 * N / 8) *reinterpret_cast<og_v4i *>(&S.v[V_X + 8 * i]) = og_v4i{0, 0, 0, 0}; // 16 bytes per lane and store
+        OG_FOR_LANES(i, 2 * 960 / 8) *reinterpret_cast<og_v4i *>(&S.v[V_X + 8 * i]) = og_v4i{0, 0, 0, 0}; // 16 bytes per lane and store
 #endif
-        pvq_tab_load();
+    }
+    return true;
+}
+
+// the frame's own leaves, one per lane of its own wave (the general kernel, the host emulation, one frame per workgroup)
+// `pre`: the caller fetched leaf `lane`'s three words already (g0, aux0, idx0)
+OG_DEV void recon_leaves_own(const ParseRec *rec, const ReconCtx &rx, bool pre = false, u32 g0 = 0, u32 aux0 = 0, u32 idx0 = 0) {
+    const int n_leaves = rx.h.n_leaves, spread = (int)(rx.flags >> RF_SPREAD_SHIFT) & 3;
+#if defined(OG_HOST_EMUL) && defined(OG_STATS)
+    { // the wave pays for its longest leaf: what does that leaf look like?
+        int max_n = 0, k_at_max = 0, sum_n = 0;
+        for (int t = 0; t < n_leaves; t++) {
+            const u32 g = rec->leaf_geom[t];
+            const int n = (int)(g >> 11) & 255, k = (int)(g >> 19) & 255;
+            sum_n += n;
+            if (n > max_n) { max_n = n; k_at_max = k; }
+        }
+        OG_STAT(40, max_n); OG_STAT(41, k_at_max); OG_STAT(42, sum_n); OG_STAT(44, n_leaves);
+        OG_STAT(45, max_n >= 96); OG_STAT(46, max_n >= 144);
+    }
+#endif
+    OG_MARK(2);
+    OG_FOR_LANES(t, n_leaves) {
+        const bool first = pre && t < OG_NLANES;
+        const u32 g = first ? g0 : rec->leaf_geom[t];
+        const u32 aux = first ? aux0 : rec->leaf_aux[t];
+        const u32 idx = first ? idx0 : rec->leaf_idx[t];
+        leaf_masks()[t] = (u16)(pvq_leaf_lane(S.v, pvq_lds(), (int)(g >> 11) & 255, (int)(g >> 19) & 255, idx, V_X + (int)(g & 2047),
+                                              (int)(g >> 27) + 1, (i32)(aux & 0xffff), spread)
+                                << (aux >> 16));
+    }
+    OG_SYNC();
+}
+
+OG_DEV int recon_finish(StreamState *st, const ParseRec *rec, const ReconCtx &rx) {
+    const u32 flags = rx.flags;
+    const int mode = rx.mode, C = rx.C, CC = rx.h.channels;
+    int result = rx.ret;
+    if (rx.leaves) {
+        const int LM = (int)(flags >> RF_LM_SHIFT) & 3, M = 1 << LM, N = M * 120;
+        const int transient = (flags & RF_TRANSIENT) != 0, silence = (flags & RF_SILENCE) != 0;
+        const int start = rx.h.start, end = NBANDS;
+        CeltState *cs = &st->celt;
         LcgTab lcg;
         lcg.init();
-        OG_SYNC();
-#if defined(OG_RABL) && OG_RABL == 1
-        return ret;
-#endif
-        // ---- all PVQ leaves of the frame, one per lane
-#if defined(OG_HOST_EMUL) && defined(OG_STATS)
-        { // the wave pays for its longest leaf: what does that leaf look like?
-            int max_n = 0, k_at_max = 0, sum_n = 0;
-            for (int t = 0; t < n_leaves; t++) {
-                const u32 g = rec->leaf_geom[t];
-                const int n = (int)(g >> 11) & 255, k = (int)(g >> 19) & 255;
-                sum_n += n;
-                if (n > max_n) { max_n = n; k_at_max = k; }
-            }
-            OG_STAT(40, max_n); OG_STAT(41, k_at_max); OG_STAT(42, sum_n); OG_STAT(44, n_leaves);
-            OG_STAT(45, max_n >= 96); OG_STAT(46, max_n >= 144);
-        }
-#endif
-        OG_MARK(2);
-        OG_FOR_LANES(t, n_leaves) {
-            const u32 g = rec->leaf_geom[t];
-            const u32 aux = rec->leaf_aux[t];
-            leaf_masks()[t] = (u16)(pvq_leaf_lane((int)(g >> 11) & 255, (int)(g >> 19) & 255, rec->leaf_idx[t], V_X + (int)(g & 2047),
-                                                  (int)(g >> 27) + 1, (i32)(aux & 0xffff), spread)
-                                    << (aux >> 16));
-        }
-        OG_SYNC();
 #ifndef OG_RECON_TIGHT
-        if (!pm) { // the band walk starts from an empty folding history (the table above is no longer needed)
+        // the phase-major band loop takes every 20 ms frame whose record did not overflow (hybrid: from band 17)
+#if defined(OG_NO_PM)
+        const bool pm = false;
+#else
+        const bool pm = rx.fast;
+#endif
+        if (!pm) { // the band walk starts from an empty folding history (the PVQ table that was there is no longer needed)
             OG_FOR_LANES(i, 1248) S.v[V_NORM + i] = 0;
             OG_SYNC();
         }
 #endif
 #if defined(OG_RABL) && OG_RABL == 2
-        return ret;
+        return result;
 #endif
-        u32 seed = cs->rng;
+        u32 seed = rx.h.rng;
 #ifdef OG_RECON_TIGHT
         recon_all_bands_pm(rec, lcg, C, transient ? M : 0, seed, start);
         // what anti-collapse and the synthesis read besides the spectrum, staged only now (og_state.hpp, V_LATE: the rows
         // were the band loop's scratch until here; the bands' collapse masks are there already)
-        OG_FOR_LANES(i, 2 * NBANDS) {
-            S.bandE_row()[i] = rec->bandE[i];
-            S.logE1_row()[i] = cs->logE1[i];
-            S.logE2_row()[i] = cs->logE2[i];
+        if (rx.pre) {
+            if (OG_LANE < 2 * NBANDS) {
+                S.bandE_row()[OG_LANE] = (i16)rx.pre_bandE;
+                S.logE1_row()[OG_LANE] = (i16)(rx.was_reset ? -28 * 1024 : rx.pre_logE1);
+                S.logE2_row()[OG_LANE] = (i16)(rx.was_reset ? -28 * 1024 : rx.pre_logE2);
+            }
+            if (OG_LANE < NBANDS) S.pulses_row()[OG_LANE] = rx.pre_pulses;
+        } else {
+            OG_FOR_LANES(i, 2 * NBANDS) {
+                S.bandE_row()[i] = rec->bandE[i];
+                S.logE1_row()[i] = cs->logE1[i];
+                S.logE2_row()[i] = cs->logE2[i];
+            }
+            OG_FOR_LANES(i, NBANDS) S.pulses_row()[i] = rec->pulses[i];
         }
-        OG_FOR_LANES(i, NBANDS) S.pulses_row()[i] = rec->pulses[i];
         OG_SYNC();
 #else
         if (pm)
             recon_all_bands_pm(rec, lcg, C, transient ? M : 0, seed, start);
         else
-            recon_all_bands(rec->words, (u32)OG_UNI(rec->need_norm), lcg, start, end, C, N, transient ? M : 0, LM, seed);
+            recon_all_bands(rec->words, rx.h.need_norm, lcg, start, end, C, N, transient ? M : 0, LM, seed);
 #endif
         OG_MARK(12);
         if (flags & RF_ANTI_COLLAPSE) anti_collapse(LM, C, N, start, end, seed);
@@ -1862,12 +1983,16 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
         }
         OG_TAP(1);
 #if defined(OG_RABL) && OG_RABL == 3
-        return ret;
+        return result;
 #endif
         CeltSynth sp;
         sp.N = N; sp.LM = LM; sp.C = C; sp.CC = CC; sp.start = start; sp.end = end; sp.silence = silence; sp.transient = transient;
-        sp.pf_pitch = OG_UNI(rec->pf_pitch); sp.pf_tapset = OG_UNI(rec->pf_tapset); sp.pf_gain = OG_UNI(rec->pf_gain);
-        sp.rng_final = rng_final; sp.rc_error = (flags & RF_RC_ERROR) != 0; sp.inline_deemph = 0;
+        sp.pf_pitch = rx.h.pf_pitch; sp.pf_tapset = rx.h.pf_tapset; sp.pf_gain = rx.h.pf_gain;
+        sp.have_state = 1;
+        sp.st_pf_period = rx.h.st_pf_period; sp.st_pf_period_old = rx.h.st_pf_period_old; sp.st_pf_gain = rx.h.st_pf_gain;
+        sp.st_pf_gain_old = rx.h.st_pf_gain_old; sp.st_pf_tapset = rx.h.st_pf_tapset; sp.st_pf_tapset_old = rx.h.st_pf_tapset_old;
+        sp.st_ring_pos = rx.h.ring_pos;
+        sp.rng_final = rx.rng_final; sp.rc_error = (flags & RF_RC_ERROR) != 0; sp.inline_deemph = 0;
         sp.loss = nullptr; sp.lost = 0; sp.energies_kept_by_parse = 1;
         OG_MARK(13);
         celt_synthesis(cs, sp);
@@ -1876,10 +2001,25 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
     }
     if (OG_LANE == 0) {
         st->prev_mode = mode;
-        st->frames_decoded += 1;
-        st->range_final = rng_final;
+        st->frames_decoded = rx.h.frames_decoded + 1;
+        st->range_final = rx.rng_final;
     }
     return result; // de-emphasis and PCM: celt_post_lane (k_celt_post), from the history ring
+}
+
+OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int ch, int role = RECON_ALL) {
+    ReconCtx rx;
+    recon_hdr_load(st, rec, rx.h);
+    if (!recon_begin(st, rec, mode, ch, role, rx)) return rx.ret;
+    if (rx.leaves) {
+        pvq_tab_load();
+        OG_SYNC();
+#if defined(OG_RABL) && OG_RABL == 1
+        return rx.ret;
+#endif
+        recon_leaves_own(rec, rx);
+    }
+    return recon_finish(st, rec, rx);
 }
 
 // Third step of the split path for (frame, channel c): runs whenever the frame was synthesised; PCM only on success.

@@ -43,7 +43,14 @@ extern "C" void og_emul_tap(int id); // stage taps for parity tests (host emulat
 #define OG_DEV static __device__ __forceinline__
 #define OG_DEVN static __device__ __noinline__
 #define OG_MEMBER __device__ __forceinline__
+// A workgroup is one wave, except in the translation units that say otherwise before including this header (og_recon.hip:
+// several frames per workgroup, one per wave): there OG_LANE is the lane within the wave and OG_WAVE the wave's index.
+#ifndef OG_LANE
 #define OG_LANE ((int)threadIdx.x)
+#endif
+#ifndef OG_WAVE
+#define OG_WAVE 0
+#endif
 #define OG_NLANES 64
 #define OG_FULL_SYNC() __syncthreads()
 // LDS-only ordering between lanes of ONE wave: the LDS unit serves a wave's instructions in order, so only the
@@ -149,6 +156,17 @@ OG_DEV i32 mul16_q14(i32 a, i32 b) { return mul16(a, b) >> 14; }                
 OG_DEV i32 mul16_p15(i32 a, i32 b) { return (16384 + mul16(a, b)) >> 15; }           // :359
 #if defined(OG_HOST_EMUL) || defined(OG_MUL64)
 OG_DEV i32 mul16x32_q15(i32 a, i32 b) { return (i32)(((i64)(i16)a * (i64)b) >> 15); } // MULT16_32_Q15 :263
+#elif !defined(OG_NO_MAD64)
+// The 64-bit product in one instruction.  Measured on gfx950 (profiles/r03/a_valu_issue_rates.txt): v_mad_i64_i32 issues at the
+// rate of a 24-bit multiply -- 32-bit multiplies are not quarter rate here -- so product + v_alignbit_b32 is two instructions
+// against four.  Written as inline assembly because the compiler, given the C expression above in these kernels, expands the
+// sign-extended operands into mul_lo / mul_hi / mad_u64 sequences instead.
+OG_DEV i32 mul16x32_q15(i32 a, i32 b) { // MULT16_32_Q15 :263
+    i64 p;
+    u64 carry;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0" : "=v"(p), "=s"(carry) : "v"((i32)(i16)a), "v"(b));
+    return (i32)(p >> 15);
+}
 #else
 // Same value without a 64-bit product (v_mul_hi/lo are quarter-rate): with b = bh * 65536 + bl (bl unsigned 16 bit),
 // (a * b) >> 15 = 2 * (a * bh) + ((a * bl) >> 15) exactly, and both partial products fit 24 x 24 -> 32 bit multiplies.

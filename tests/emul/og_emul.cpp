@@ -67,7 +67,7 @@ int emu_last_record_words(void) { return 0; }
 extern "C" unsigned emu_pvq_leaf(int n, int k, unsigned index, int B, int gain, int spread, int16_t *X) {
     for (int i = 0; i < n; i++) og::S.v[og::V_X + i] = 0; // the leaf function relies on a cleared spectrum
     og::pvq_tab_load();
-    const unsigned cm = og::pvq_leaf_lane(n, k, index, og::V_X, B, gain, spread);
+    const unsigned cm = og::pvq_leaf_lane(og::S.v, og::pvq_lds(), n, k, index, og::V_X, B, gain, spread);
     memcpy(X, &og::S.v[og::V_X], sizeof(int16_t) * n);
     return cm;
 }
