@@ -537,6 +537,154 @@ OG_DEV void pcm_store(i16 *pcm, int n, int C, int CC) {
     }
 }
 
+#if defined(OG_RECON_TIGHT) && !defined(OG_HOST_EMUL)
+// ---- the long block (one 1920-point transform per channel: seven frames of eight on the bench payloads), restructured ----------
+// clt_mdct_backward celt.cpp:3204 + opus_fft_impl :2997 for nfft = 480 = 4 x 2 x 4 x 3 x 5 (innermost radix first), every
+// butterfly's arithmetic as kf_bfly4 / kf_bfly2 (:2794-2995); what changes is who computes what, and where it waits:
+//   A  The digit reversal of the pre-rotation's output (rom_bitrev480) puts input i = d0 + 5 d1 + 15 d2 + 60 d3 + 120 d4 at
+//      position 8 (12 d0 + 4 d1 + d2) + (4 d3 + d4): the eight inputs i0 + 60 m of one lane g = 12 d0 + 4 d1 + d2 ARE the eight
+//      consecutive points its radix-4 (m = 1) and radix-2 butterflies work on.  So lane g de-normalises and pre-rotates those
+//      eight (coefficients 2 i and 959 - 2 i: constant offsets from two per-lane bases, for the spectrum and for the per-bin
+//      gain table alike, since 120 m is a multiple of the 8 coefficients of a bin) and runs both stages on them in registers:
+//      no scatter through the permutation table, no LDS round trip between the first two stages, 60 lanes busy in ONE pass
+//      (the generic code: eight passes of pre-rotation with two band look-ups per coefficient, two of radix-4, four of radix-2
+//      with a four-way branch per lane).  Results go to LDS transposed ([point within the lane][lane]: conflict-free stores).
+//   B  radix-4, m = 8: butterfly (i2, j) takes point j of lanes 4 i2 .. 4 i2 + 3 -- 32 contiguous bytes of the transposed
+//      layout -- with twiddles that depend on j = lane & 7 only (fetched once); both passes' inputs are read before the
+//      first output is stored (the stage is not in place across the two layouts), outputs in natural order.
+//   C, D  radix-3 and radix-5 in place as before (fft_stage), then post-rotation, TDAC, saturation as before.
+// The spectrum this reads may lie where the buffer it writes starts (og_state.hpp): every lane's reads are instructions
+// before the first store in program order, and the wave executes them in order.
+typedef i32 og_v2i __attribute__((ext_vector_type(2)));
+typedef i32 og_v4i __attribute__((ext_vector_type(4)));
+// 120 words behind denorm_gains' rows (og_state.hpp: 288 of the 832 bytes at V_MASK): g (Q15) | right shift << 16 | left shift << 24
+OG_DEV u32 *binpar_row() { return reinterpret_cast<u32 *>(S.dn_g_row() + 144); }
+// denormalise_bands' per-band gain (celt.cpp:948-1007) of coded channel c -- as denorm_gains left it: the band energies it read
+// lie inside the synthesis buffer and are gone once the first channel's transform has run -- laid out per 5 ms bin = per group
+// of 8 coefficients of a 20 ms frame; bins 100 .. 119 (coefficients the mode does not code) scale to zero
+OG_DEV void denorm_bins(int c) {
+    OG_SYNC();
+    if (OG_LANE <= NBANDS) {
+        const int i = OG_LANE;
+        u32 w = 0;
+        int b0 = 100, b1 = 120;
+        if (i < NBANDS) {
+            const i32 g = S.dn_g_row()[c * NBANDS + i], shift = S.dn_shift_row()[c * NBANDS + i];
+            w = (u32)(g & 0xffff) | (u32)(shift > 0 ? shift : 0) << 16 | (u32)(shift < 0 ? -shift : 0) << 24;
+            b0 = rom_eband[i];
+            b1 = rom_eband[i + 1];
+        }
+        for (int b = b0; b < b1; b++) binpar_row()[b] = w;
+    }
+    OG_SYNC();
+}
+OG_DEV i32 denorm_coef(i32 x, u32 par) { // freq_coded with the band's parameters in hand
+    const i32 p = mul16(x, (i32)(i16)(par & 0xffff));
+    return shl32(p >> ((par >> 16) & 31), (int)(par >> 24));
+}
+struct CpxT { i32 r, i; };
+OG_DEV CpxT ctw32(CpxT a, u32 w) { // C_MUL by a packed twiddle (rom_fft_tw32)
+    const i32 wr = (i32)(i16)(w & 0xffff), wi = (i32)w >> 16;
+    CpxT m = {subw(mul16x32_q15(wr, a.r), mul16x32_q15(wi, a.i)), addw(mul16x32_q15(wi, a.r), mul16x32_q15(wr, a.i))};
+    return m;
+}
+// `SYF`: the transform's 480 complex points (&SY[60]); `xs`: the coded channel's spectrum; binpar_row() holds its gains
+OG_DEV void imdct_long_front(i32 *SYF, const i16 *xs) {
+    const int g = OG_LANE;
+    CpxT v[8];
+    if (g < 60) {
+        const int d0 = g / 12, r12 = g - 12 * d0, i0 = d0 + 5 * (r12 >> 2) + 15 * (r12 & 3);
+        const i16 *x_lo = xs + 2 * i0, *x_hi = xs + 959 - 2 * i0;
+        const u32 *p_lo = binpar_row() + (i0 >> 2), *p_hi = binpar_row() + ((959 - 2 * i0) >> 3);
+        const u32 *tp = rom_prerot480 + i0;
+#pragma unroll
+        for (int m = 0; m < 8; m++) { // input i0 + 60 m -> point 4 (m & 1) + (m >> 1) of the lane's eight
+            const i32 x1 = denorm_coef(x_lo[120 * m], p_lo[15 * m]), x2 = denorm_coef(x_hi[-120 * m], p_hi[-15 * m]);
+            const u32 tt = tp[60 * m];
+            const i32 t0 = (i32)(i16)(tt & 0xffff), t1 = (i32)tt >> 16;
+            const i32 yr = addw(mul16x32_q15(t0, x2), mul16x32_q15(t1, x1));
+            const i32 yi = subw(mul16x32_q15(t0, x1), mul16x32_q15(t1, x2));
+            const int k = 4 * (m & 1) + (m >> 1);
+            v[k].r = yi;
+            v[k].i = yr;
+        }
+        // radix-4, m = 1 (kf_bfly4 celt.cpp:2841 with unit twiddles), on points 0..3 and 4..7
+#pragma unroll
+        for (int h = 0; h < 8; h += 4) {
+            CpxT f0 = v[h], f1 = v[h + 1], f2 = v[h + 2], f3 = v[h + 3];
+            CpxT s0 = {subw(f0.r, f2.r), subw(f0.i, f2.i)};
+            f0.r = addw(f0.r, f2.r); f0.i = addw(f0.i, f2.i);
+            CpxT s1 = {addw(f1.r, f3.r), addw(f1.i, f3.i)};
+            f2.r = subw(f0.r, s1.r); f2.i = subw(f0.i, s1.i);
+            f0.r = addw(f0.r, s1.r); f0.i = addw(f0.i, s1.i);
+            s1.r = subw(f1.r, f3.r); s1.i = subw(f1.i, f3.i);
+            f1.r = addw(s0.r, s1.i); f1.i = subw(s0.i, s1.r);
+            f3.r = subw(s0.r, s1.i); f3.i = addw(s0.i, s1.r);
+            v[h] = f0; v[h + 1] = f1; v[h + 2] = f2; v[h + 3] = f3;
+        }
+        // radix-2, m = 4 (kf_bfly2 celt.cpp:2794): pairs (q, q + 4), twiddles 1, e^{-i pi/4}, -i, e^{-3i pi/4}
+        const i32 tw = 23170;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const CpxT a = v[q], b = v[q + 4];
+            CpxT t;
+            if (q == 0)
+                t = b;
+            else if (q == 1) {
+                t.r = mul16x32_q15(tw, addw(b.r, b.i));
+                t.i = mul16x32_q15(tw, subw(b.i, b.r));
+            } else if (q == 2) {
+                t.r = b.i;
+                t.i = negw(b.r);
+            } else {
+                t.r = mul16x32_q15(tw, subw(b.i, b.r));
+                t.i = mul16x32_q15(tw, negw(addw(b.i, b.r)));
+            }
+            v[q + 4].r = subw(a.r, t.r); v[q + 4].i = subw(a.i, t.i);
+            v[q].r = addw(a.r, t.r); v[q].i = addw(a.i, t.i);
+        }
+    }
+    OG_SYNC(); // (every read of the spectrum above, every store below)
+    if (g < 60) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) *reinterpret_cast<og_v2i *>(&SYF[2 * (k * 60 + g)]) = og_v2i{v[k].r, v[k].i};
+    }
+    OG_SYNC();
+    // B: radix-4, m = 8 (kf_bfly4 celt.cpp:2841): butterfly (i2, j), j = lane & 7, i2 = lane >> 3 and 8 + (lane >> 3)
+    {
+        const int j = OG_LANE & 7, ia = OG_LANE >> 3, ib = 8 + ia;
+        const bool has_b = ib < 15;
+        const u32 w1 = rom_fft_tw32[15 * j], w2 = rom_fft_tw32[30 * j], w3 = rom_fft_tw32[45 * j];
+        CpxT in[2][4];
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int i2 = it ? (has_b ? ib : ia) : ia;
+            const og_v4i lo = *reinterpret_cast<const og_v4i *>(&SYF[2 * (j * 60 + 4 * i2)]);
+            const og_v4i hi = *reinterpret_cast<const og_v4i *>(&SYF[2 * (j * 60 + 4 * i2) + 4]);
+            in[it][0] = CpxT{lo.x, lo.y}; in[it][1] = CpxT{lo.z, lo.w}; in[it][2] = CpxT{hi.x, hi.y}; in[it][3] = CpxT{hi.z, hi.w};
+        }
+        OG_SYNC();
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            if (it == 1 && !has_b) break;
+            const int i2 = it ? ib : ia, o = 32 * i2 + j;
+            CpxT f0 = in[it][0];
+            const CpxT a = ctw32(in[it][1], w1), b = ctw32(in[it][2], w2), c = ctw32(in[it][3], w3);
+            const CpxT s5 = {subw(f0.r, b.r), subw(f0.i, b.i)};
+            f0.r = addw(f0.r, b.r); f0.i = addw(f0.i, b.i);
+            const CpxT s3 = {addw(a.r, c.r), addw(a.i, c.i)}, s4 = {subw(a.r, c.r), subw(a.i, c.i)};
+            const CpxT f2 = {subw(f0.r, s3.r), subw(f0.i, s3.i)};
+            f0.r = addw(f0.r, s3.r); f0.i = addw(f0.i, s3.i);
+            const CpxT f1 = {addw(s5.r, s4.i), subw(s5.i, s4.r)}, f3 = {subw(s5.r, s4.i), addw(s5.i, s4.r)};
+            *reinterpret_cast<og_v2i *>(&SYF[2 * o]) = og_v2i{f0.r, f0.i};
+            *reinterpret_cast<og_v2i *>(&SYF[2 * (o + 8)]) = og_v2i{f1.r, f1.i};
+            *reinterpret_cast<og_v2i *>(&SYF[2 * (o + 16)]) = og_v2i{f2.r, f2.i};
+            *reinterpret_cast<og_v2i *>(&SYF[2 * (o + 24)]) = og_v2i{f3.r, f3.i};
+        }
+    }
+}
+#endif
+
 // Inverse MDCT of every block of one output channel (clt_mdct_backward celt.cpp:3204), reading
 // the denormalised coefficients on the fly.  B blocks of NBk = N/B outputs, transform size 2*NBk.
 OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int shift, int C, int CC) {
@@ -551,6 +699,21 @@ OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int sh
     i32 *const SY = syn_buf();
     {
         OG_SYNC();
+#if defined(OG_RECON_TIGHT) && !defined(OG_HOST_EMUL)
+#ifdef OG_NO_LONG_FAST
+        const bool long_fast = false;
+#else
+        const bool long_fast = B == 1 && !(CC == 1 && C == 2); // (a down-mix reads two spectra per coefficient: generic code)
+#endif
+        if (long_fast) {
+            const int c_src = (CC == 2 && C == 1) ? 0 : co;
+            const i32 tail_l = OG_LANE < OVERLAP / 2 ? tail[OG_LANE] : 0; // (requested before the stages, stored behind them)
+            imdct_long_front(&SY[OVERLAP >> 1], &S.v[V_X + c_src * N]);
+            if (OG_LANE < OVERLAP / 2) SY[OG_LANE] = tail_l;
+            fft_stage(&SY[OVERLAP >> 1], 1, NBk, 3, 32, 5, 96, 5);
+            fft_stage(&SY[OVERLAP >> 1], 1, NBk, 5, 96, 1, 1, 1);
+        } else {
+#endif
 #ifdef OG_RECON_TIGHT
         // The buffer starts inside X, over the second channel's spectrum (og_state.hpp).  A channel that reads that spectrum
         // has every coefficient read, and rotated, before the first word of the buffer is written: 480 rotations, 8 per lane,
@@ -618,6 +781,9 @@ OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int sh
         }
 #endif
         fft_blocks(&SY[OVERLAP >> 1], B, NBk, shift);
+#if defined(OG_RECON_TIGHT) && !defined(OG_HOST_EMUL)
+        }
+#endif
         for (int b = 0; b < B; b++) // post-rotation, pairs (i, N4-1-i)
         OG_FOR_LANES(i, N4 >> 1) {
             i32 *yp0 = &SY[NBk * b + (OVERLAP >> 1) + 2 * i];
@@ -1092,6 +1258,11 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
 #endif
         OG_SYNC();
         OG_MARK(14);
+#if defined(OG_RECON_TIGHT) && !defined(OG_HOST_EMUL)
+#ifndef OG_NO_LONG_FAST
+        if (B == 1 && !(CC == 1 && C == 2)) denorm_bins((CC == 2 && C == 1) ? 0 : c); // (from denorm_gains' rows)
+#endif
+#endif
         imdct_channel(st->tail[c], c, N, LM, B, shift, C, CC);
         OG_MARK(15);
         OG_TAP(2 + 16 * c); // IMDCT output

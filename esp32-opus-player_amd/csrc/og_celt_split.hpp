@@ -957,6 +957,14 @@ OG_DEV void rec_word4(RecCur &cur, u32 &w0, u32 &w1, u32 &w2, u32 &w3) {
 struct LcgTab {
     u32 a[3], c[3];
     OG_MEMBER void init() {
+#if !defined(OG_HOST_EMUL) && !defined(OG_NO_LCG_ROM)
+        // (the jumps by 1 .. 192 steps are constants: rom_lcg_jump, tools/gen_rom_tables.py)
+        for (int k = 0; k < 3; k++) {
+            a[k] = rom_lcg_jump[2 * (OG_LANE + 64 * k)];
+            c[k] = rom_lcg_jump[2 * (OG_LANE + 64 * k) + 1];
+        }
+        return;
+#endif
         for (int k = 0; k < 3; k++) {
             u32 n = (u32)(OG_LANE + 64 * k + 1), ra = 1u, rc = 0u, ba = 1664525u, bc = 1013904223u;
             while (n) {

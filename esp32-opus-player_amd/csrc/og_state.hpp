@@ -207,7 +207,8 @@ struct FrameLds {
 };
 constexpr int MAX_LEAF_MASKS = 416;
 static_assert(V_SYN * 2 + SYN_LEN * 4 <= V_MASK * 2, "the synthesis buffer ends before the synthesis gains");
-static_assert((V_MASK + 4 * NBANDS) * 2 + 120 <= V_TOTAL * 2, "synthesis tables fit behind the buffer");
+static_assert((V_MASK + 4 * NBANDS) * 2 + 120 <= (V_MASK + 144) * 2 && (V_MASK + 144) * 2 + 480 <= V_TOTAL * 2,
+              "synthesis tables fit behind the buffer: the gains per band, bin -> band, then the long block's gains per bin (og_celt.hpp)");
 static_assert(V_LATE + 24 + 8 * NBANDS <= V_MASK && (V_LATE + 24) % 2 == 0, "the late-staged arrays fit the scratch rows");
 static_assert(V_MASK % 2 == 0 && V_NORM % 8 == 0 && V_IY % 8 == 0 && V_WIN % 2 == 0 && V_WIN + 128 <= V_MASK, "alignment of the overlays");
 #ifndef OG_LDS_PAD

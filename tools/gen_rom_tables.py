@@ -308,6 +308,17 @@ def build_text():
     t += emit("rom_mdct_trig", "int16_t", mdct_trig(), 12)
     t += emit("rom_fft_tw", "int16_t", fft_twiddles(), 12)
     t += emit("rom_win120", "int16_t", window120(), 12)
+    # pairs a lane fetches together, packed into one word (low half | high half << 16): the long block's pre-rotation
+    # twiddles (trig[i], trig[480 + i]) and the FFT twiddles (real, imaginary)
+    trig, tw = mdct_trig(), fft_twiddles()
+    t += emit("rom_prerot480", "uint32_t", [(trig[i] & 0xFFFF) | (trig[480 + i] & 0xFFFF) << 16 for i in range(480)], 8)
+    t += emit("rom_fft_tw32", "uint32_t", [(tw[2 * i] & 0xFFFF) | (tw[2 * i + 1] & 0xFFFF) << 16 for i in range(480)], 8)
+    # the noise generator jumped ahead by n = 1 .. 192 steps (celt_lcg_rand celt.cpp:921 composed with itself: s -> a s + c mod 2^32)
+    jump, a, c = [], 1, 0
+    for _ in range(192):
+        a, c = (1664525 * a) & 0xFFFFFFFF, (1664525 * c + 1013904223) & 0xFFFFFFFF
+        jump += [a, c]
+    t += emit("rom_lcg_jump", "uint32_t", jump, 8)
     for n in (480, 240, 120, 60):
         t += emit(f"rom_bitrev{n}", "int16_t", digit_reversal(FFT_FACTORS[n], n), 20)
     for name, (ctype, vals) in SILK_TABLES.items():
