@@ -585,21 +585,7 @@ OG_DEV void celt_parse_lane(StreamState *st, const u8 *payload, int len, int ch,
 // scaled to the leaf's gain (normalise_residual :745), spreading rotation undone (exp_rotation :707, dir = -1),
 // collapse mask (extract_collapse_mask :760).  Everything is a serial chain per leaf, so the frame's leaves run
 // one per lane; the result is written in place at S.v[pos .. pos+n).  Returns the collapse mask.
-#ifdef OG_LEAF_ROT_SIMPLE
-OG_DEV void rotate1_lane(i16 *xv, int x, int len, int stride, i32 c, i32 s) { // exp_rotation1 celt.cpp:684
-    const i32 ms = tr16(-s);
-    for (int i = 0; i < len - stride; i++) {
-        const i32 x1 = xv[x + i], x2 = xv[x + i + stride];
-        xv[x + i + stride] = (i16)pshr32(mul16(c, x2) + mul16(s, x1), 15);
-        xv[x + i] = (i16)pshr32(mul16(c, x1) + mul16(ms, x2), 15);
-    }
-    for (int i = len - 2 * stride - 1; i >= 0; i--) {
-        const i32 x1 = xv[x + i], x2 = xv[x + i + stride];
-        xv[x + i + stride] = (i16)pshr32(mul16(c, x2) + mul16(s, x1), 15);
-        xv[x + i] = (i16)pshr32(mul16(c, x1) + mul16(ms, x2), 15);
-    }
-}
-#else
+#if defined(OG_HOST_EMUL) || defined(OG_LEAF_ROT_PLAIN)
 OG_DEV void rotate1_lane(i16 *xv, int x, int len, int stride, i32 c, i32 s) { // exp_rotation1 celt.cpp:684
     // The reference sweeps i = 0 .. len-stride-1 forward, then len-2*stride-1 .. 0 backward, over pairs (i, i+stride).
     // Pairs with different i mod stride never touch the same element, so each residue class ("chain") can be walked
@@ -626,6 +612,84 @@ OG_DEV void rotate1_lane(i16 *xv, int x, int len, int stride, i32 c, i32 s) { //
                 x2 = tr16(pshr32(mul16(c, x1) + mul16(ms, x2), 15));
             }
             xv[x + r] = (i16)x2;
+        }
+    }
+}
+#else
+// The same chain walk for the GPU, where a wave runs it for 64 leaves in lock-step and pays for the longest: (a) a step's two
+// outputs are each one v_dot2_i32_i16 -- c x1 + s x2 + 16384 with the pair (x1, x2) packed in one register -- and a shift;
+// (b) four steps at a time, their four new elements requested together before the first result is stored (a store to the
+// spectrum keeps the compiler from moving the next element's read above it, so step by step every element costs an LDS round
+// trip); (c) the backward sweep starts where the forward one counted to (no remainder to divide out).
+OG_DEV i32 rot_dot2(u32 pair, u32 coef, i32 half) {
+    i32 r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(pair), "v"(coef), "v"(half));
+    return r >> 15;
+}
+OG_DEV u32 rot_pack(i32 lo, i32 hi) { return __builtin_amdgcn_perm((u32)hi, (u32)lo, 0x05040100u); } // low halves of both
+OG_DEV void rotate1_lane(i16 *xv, int x, int len, int stride, i32 c, i32 s) { // exp_rotation1 celt.cpp:684
+    const u32 k_a = rot_pack(c, -s), k_b = rot_pack(s, c); // first output: c x1 - s x2; second (carried on): s x1 + c x2
+    const i32 half = 16384;
+    i16 *const p0 = xv + x;
+    for (int r = 0; r < stride; r++) {
+        if (r >= len - stride) break; // (the chains are in order: no later one has a pair either)
+        // forward along the chain r, r + stride, ..: pairs (i, i + stride) while i < len - stride
+        int i = r, steps = 0;
+        i32 x1 = p0[i];
+        for (; i + 3 * stride < len - stride; i += 4 * stride, steps += 4) {
+            const i32 e1 = p0[i + stride], e2 = p0[i + 2 * stride], e3 = p0[i + 3 * stride], e4 = p0[i + 4 * stride];
+            u32 pk = rot_pack(x1, e1);
+            const i32 o0 = rot_dot2(pk, k_a, half);
+            x1 = rot_dot2(pk, k_b, half);
+            pk = rot_pack(x1, e2);
+            const i32 o1 = rot_dot2(pk, k_a, half);
+            x1 = rot_dot2(pk, k_b, half);
+            pk = rot_pack(x1, e3);
+            const i32 o2 = rot_dot2(pk, k_a, half);
+            x1 = rot_dot2(pk, k_b, half);
+            pk = rot_pack(x1, e4);
+            const i32 o3 = rot_dot2(pk, k_a, half);
+            x1 = rot_dot2(pk, k_b, half);
+            p0[i] = (i16)o0;
+            p0[i + stride] = (i16)o1;
+            p0[i + 2 * stride] = (i16)o2;
+            p0[i + 3 * stride] = (i16)o3;
+        }
+        for (; i < len - stride; i += stride, steps++) {
+            const u32 pk = rot_pack(x1, p0[i + stride]);
+            p0[i] = (i16)rot_dot2(pk, k_a, half);
+            x1 = rot_dot2(pk, k_b, half);
+        }
+        p0[i] = (i16)x1;
+        // backward: pairs (i, i + stride) from the chain's highest i <= len - 2 stride - 1 down to r -- one pair fewer than forward
+        if (steps >= 2) {
+            i -= 2 * stride; // (forward ended on the chain's last element, r + steps * stride)
+            i32 x2 = p0[i + stride];
+            for (; i - 3 * stride >= 0; i -= 4 * stride) {
+                const i32 e1 = p0[i], e2 = p0[i - stride], e3 = p0[i - 2 * stride], e4 = p0[i - 3 * stride];
+                u32 pk = rot_pack(e1, x2); // (x1, x2) = (element i, carried): second output goes to i + stride, first is carried down
+                const i32 o0 = rot_dot2(pk, k_b, half);
+                x2 = rot_dot2(pk, k_a, half);
+                pk = rot_pack(e2, x2);
+                const i32 o1 = rot_dot2(pk, k_b, half);
+                x2 = rot_dot2(pk, k_a, half);
+                pk = rot_pack(e3, x2);
+                const i32 o2 = rot_dot2(pk, k_b, half);
+                x2 = rot_dot2(pk, k_a, half);
+                pk = rot_pack(e4, x2);
+                const i32 o3 = rot_dot2(pk, k_b, half);
+                x2 = rot_dot2(pk, k_a, half);
+                p0[i + stride] = (i16)o0;
+                p0[i] = (i16)o1;
+                p0[i - stride] = (i16)o2;
+                p0[i - 2 * stride] = (i16)o3;
+            }
+            for (; i >= 0; i -= stride) {
+                const u32 pk = rot_pack(p0[i], x2);
+                p0[i + stride] = (i16)rot_dot2(pk, k_b, half);
+                x2 = rot_dot2(pk, k_a, half);
+            }
+            p0[r] = (i16)x2;
         }
     }
 }
@@ -1387,11 +1451,9 @@ OG_DEV PmGrp pm_group(int g) { // group g of the coded spectrum: 0..99 first cha
 OG_DEV u32 pm_setup_jobs(const ParseRec *rec, int C, int B, u32 &fill_lo, u32 &fill_hi, int &dual_end, int start = 0) {
     PmLds &P = PM();
     OG_SYNC();
-    OG_FOR_LANES(bin, PM_GROUPS) {
-        int b = 0;
-        while (rom_eband[b + 1] <= bin) b++;
-        P.binband[bin] = (u8)b;
-        P.binoff[bin] = (u8)(bin - rom_eband[b]);
+    OG_FOR_LANES(bin, PM_GROUPS) { // (tables: the search they replace was up to 21 dependent loads per lane)
+        P.binband[bin] = rom_bin2band[bin];
+        P.binoff[bin] = rom_binoff[bin];
     }
     OG_FOR_LANES(i, 2 * NBANDS) {
         P.jdesc[i] = 0;

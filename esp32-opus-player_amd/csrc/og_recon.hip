@@ -39,7 +39,7 @@ using namespace og;
 constexpr int RG = OG_RECON_FRAMES;
 static_assert(RG == 1 || RG == 2 || RG == 4, "frames per reconstruction workgroup");
 
-#if OG_RECON_FRAMES > 1
+#if OG_RECON_FRAMES > 1 && defined(OG_RECON_POOL)
 // ---- the pooled leaf pass -----------------------------------------------------------------------------------------------
 // While the leaves are decoded nothing else lives behind the spectra: frame 0's rows hold the PVQ table, the other frames'
 // rows the pool -- the leaves of one round (leaf 64 r + lane of every frame) in ranked order -- and the ranking's counters.
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(64 * RG, OG_FAST_WAVES) k_celt_recon_fb(const 
             mine = recon_begin(sp, rec, mode, desc_channels(d.flags), RECON_FAST_ONLY, rx);
         }
     }
-#if OG_RECON_FRAMES > 1
+#if OG_RECON_FRAMES > 1 && defined(OG_RECON_POOL)
     leaf_pass_pooled(rec, mine && rx.leaves ? rx.h.n_leaves : 0, (int)(rx.flags >> RF_SPREAD_SHIFT) & 3);
 #if defined(OG_RABL) && OG_RABL == 1
     return;

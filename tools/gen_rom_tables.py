@@ -298,6 +298,10 @@ def build_text():
     t += emit("rom_band_alloc", "uint8_t", BAND_ALLOC, 21)
     t += emit("rom_eband", "int16_t", EBAND, 22)
     t += emit("rom_logn", "int16_t", LOGN, 21)
+    # 5 ms bin (= 8 coefficients of a 20 ms frame) -> band that holds it, and the bin's index within that band
+    b2b = [max(b for b in range(21) if EBAND[b] <= x) for x in range(100)]
+    t += emit("rom_bin2band", "uint8_t", b2b, 25)
+    t += emit("rom_binoff", "uint8_t", [x - EBAND[b2b[x]] for x in range(100)], 25)
     t += emit("rom_pulse_idx", "int16_t", PULSE_IDX, 21)
     t += emit("rom_pulse_bits", "uint8_t", PULSE_BITS, 28)
     t += emit("rom_pulse_v", "uint32_t", pulse_v_table(), 8)
