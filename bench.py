@@ -360,24 +360,37 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
         def step(f):
             ctx.decode_step_device(n, d_desc[f], d_arena[f], d_pcm, d_res, modes=pkg.toc_modes(toc))
 
+        def window(f0, f1):  # steps f0 .. f1-1 queued by ONE call: the library sees which step follows which
+            ctx.decode_steps_device([n] * (f1 - f0), d_desc[f0:f1], d_arena[f0:f1], [d_pcm] * (f1 - f0), [d_res] * (f1 - f0),
+                                    modes=pkg.toc_modes(toc))
+
     def barrier():
         ranks.barrier()
         ctx.synchronize()
 
-    for f in range(W):
-        step(f)
+    windowed = (not mixed) and args.window == "on"
+    if windowed and W:
+        window(0, W)
+    else:
+        for f in range(W):
+            step(f)
     ctx.synchronize()
     ev = [ctx.event() for _ in range(K + 1)]
     barrier()
     t0 = time.perf_counter()
     ctx.event_record(ev[0])
-    for f in range(K):
-        step(W + f)
-        ctx.event_record(ev[f + 1])
+    if windowed:
+        window(W, W + K)
+        ctx.event_record(ev[K])
+    else:
+        for f in range(K):
+            step(W + f)
+            ctx.event_record(ev[f + 1])
     ctx.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    kernel_ms = [ctx.event_elapsed_ms(ev[f], ev[f + 1]) for f in range(K)]
+    kernel_ms = ([ctx.event_elapsed_ms(ev[0], ev[K]) / K] * K if windowed else
+                 [ctx.event_elapsed_ms(ev[f], ev[f + 1]) for f in range(K)])
     for e in ev:
         ctx.event_destroy(e)
     res = np.zeros(n, dtype=np.int32)
@@ -425,7 +438,7 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
                                ("; pipelined steps, opusgpu_set_pipeline: the next step's k_celt_parse of CELT-only frames runs on "
                                 "the library's second stream next to this step's k_celt_recon_fb / k_celt_post)"
                                 if args.pipeline == "on" else ")"),
-                     "pipeline": args.pipeline, "avg_launch_ms": avg_kernel_s * 1e3,
+                     "pipeline": args.pipeline, "window": "on" if windowed else "off", "avg_launch_ms": avg_kernel_s * 1e3,
                      "algorithmic_bytes_per_frame": bytes_per_frame, "frames_per_launch": n,
                      "valu_issue": valu_issue_for(name, n, avg_kernel_s * 1e3)},
         "parity_check": parity,
@@ -463,6 +476,9 @@ def main():
                     help="mixed_pages_2m: who demuxes the Ogg pages (rank 0 for all, or every rank its own share)")
     ap.add_argument("--pipeline", default="on", choices=["on", "off"],
                     help="opusgpu_set_pipeline: step k+1's CELT parse next to step k's reconstruction (tables resident, as here)")
+    ap.add_argument("--window", default="on", choices=["on", "off"],
+                    help="queue the K timed steps with ONE opusgpu_decode_steps_device call (the library then orders the kernels of "
+                         "neighbouring pipelined steps by dependencies); off: one opusgpu_decode_step_device_modes call per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work of the headline workload's cpu_baseline sample")
     ap.add_argument("--rendezvous-only", action="store_true",

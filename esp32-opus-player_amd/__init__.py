@@ -22,7 +22,7 @@ EXPORTS = [
     "opusgpu_streams_alloc", "opusgpu_streams_reset", "opusgpu_stream_count", "opusgpu_stream_channels",
     "opusgpu_stream_state_bytes", "opusgpu_debug_stage_taps", "opusgpu_decode_packets", "opusgpu_decode_packets_fec", "opusgpu_packet_to_frames",
     "opusgpu_dev_alloc", "opusgpu_dev_free", "opusgpu_memcpy_h2d", "opusgpu_memcpy_d2h",
-    "opusgpu_decode_step_device", "opusgpu_decode_step_device_modes", "opusgpu_synchronize", "opusgpu_event_create", "opusgpu_event_record",
+    "opusgpu_decode_step_device", "opusgpu_decode_step_device_modes", "opusgpu_decode_steps_device", "opusgpu_synchronize", "opusgpu_event_create", "opusgpu_event_record",
     "opusgpu_event_elapsed_ms", "opusgpu_event_destroy", "opusgpu_stream_state_get",
     "opusgpu_pages_demux", "opusgpu_page_batch_steps", "opusgpu_page_batch_step", "opusgpu_page_batch_arena",
     "opusgpu_page_batch_free", "opusgpu_pages_crc_device", "opusgpu_output_stage_device",
@@ -116,6 +116,7 @@ def load_lib():
     lib.opusgpu_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     lib.opusgpu_decode_step_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     lib.opusgpu_decode_step_device_modes.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int]
+    lib.opusgpu_decode_steps_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int]
     lib.opusgpu_synchronize.argtypes = [vp]
     lib.opusgpu_event_create.argtypes = [vp, C.POINTER(vp)]
     lib.opusgpu_event_record.argtypes = [vp, vp]
@@ -360,6 +361,17 @@ class Context:
         else:
             self._chk(self.lib.opusgpu_decode_step_device(self.h, n, d_descs, d_arena, d_pcm, d_result, stream),
                       "opusgpu_decode_step_device")
+
+    def decode_steps_device(self, n, d_descs, d_arena, d_pcm, d_result, stream=None, modes=0):
+        """A window of consecutive steps in one call (opusgpu_decode_steps_device): n is a list of frame counts, the others lists
+        of device pointers, one entry per step."""
+        k = len(n)
+
+        def ptrs(v):
+            return (C.c_void_p * k)(*[p.value if isinstance(p, C.c_void_p) else int(p) for p in v])
+        counts = (C.c_int32 * k)(*[int(x) for x in n])
+        self._chk(self.lib.opusgpu_decode_steps_device(self.h, k, counts, ptrs(d_descs), ptrs(d_arena), ptrs(d_pcm), ptrs(d_result), stream, modes),
+                  "opusgpu_decode_steps_device")
 
     def pages_crc_device(self, n_pages, d_blob, d_offsets, d_lens, d_status, stream=None):
         """Page checksums on the GPU (include/opusgpu.h): d_status[i] = 1 match, 0 mismatch, PAGE_BAD_CAPTURE malformed."""

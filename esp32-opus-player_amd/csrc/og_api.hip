@@ -353,8 +353,11 @@ __global__ void __launch_bounds__(64, OG_SPARSE_WAVES) k_silk_parse(const FrameD
 enum { PARSE_ALL = 0, PARSE_CELT_ONLY = 1, PARSE_HYBRID_ONLY = 2 };
 __global__ void __launch_bounds__(64 * OG_PL_WAVES, 2) k_celt_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
                                                       StreamState *st, ParseRec *recs, int n, int n_streams,
-                                                      const SilkHandoff *handoff, int which, int groups) {
+                                                      const SilkHandoff *handoff, int which, int groups, u32 *started) {
     // `groups`: a workgroup parses that many groups of OG_PL_FRAMES frames one after the other (1: the grid covers the step once)
+    // `started` (steps queued as a window, opusgpu_decode_steps_device): every workgroup counts itself in when it starts -- the
+    // reconstruction of the step before is held (a stream memory wait) until this launch's workgroups have their places
+    if (started && threadIdx.x == 0) __hip_atomic_fetch_add(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const bool lane_on = (int)(threadIdx.x & 63) < OG_PL_LANES;
     const int f0 = (int)blockIdx.x * groups * OG_PL_FRAMES + OG_PWAVE * OG_PL_LANES + OG_PCOL;
     if (which != PARSE_ALL) { // a launch that finds none of its frames among the workgroup's leaves without loading the tables
@@ -390,7 +393,8 @@ __global__ void __launch_bounds__(64 * OG_PL_WAVES, 2) k_celt_parse(const FrameD
 // Split CELT path, second half: one frame per wave, driven by the parse record.
 // (20 ms CELT-only frames are reconstructed by k_celt_recon_fb, og_recon.hip; `rest_only`: skip what that kernel took)
 extern "C" void og_launch_celt_recon_fb(hipStream_t s, const void *descs, void *streams, const void *recs, void *rout, int n,
-                                        int n_streams, int hybrid);
+                                        int n_streams, int hybrid, unsigned *started);
+extern "C" int og_celt_recon_fb_signals(int n); // how often a launch over n frames bumps `started`
 // RFC mode (opt-in): every frame of a step, at its true duration, incl. the loss path (og_rfc.hip)
 extern "C" void og_launch_decode_rfc(hipStream_t s, const void *descs, const void *arena, void *streams, void *pcm, void *result, int n,
                                      int n_streams, int pcm_stride);
@@ -436,13 +440,6 @@ __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDe
 #endif
         __syncthreads();
     }
-}
-
-// One wave that waits `ticks` of the 100 MHz wall clock (pipelined steps: the reconstruction's head start for the early parse,
-// see decode_step_impl).  Ends by itself: the clock only moves forward.
-__global__ void __launch_bounds__(64) k_head_start(int ticks) {
-    const unsigned long long t0 = wall_clock64();
-    while ((long long)(wall_clock64() - t0) < (long long)ticks) __builtin_amdgcn_s_sleep(16);
 }
 
 // Split CELT path, third step: de-emphasis (a rounding IIR: strictly serial per channel) and int16 PCM, one
@@ -604,18 +601,19 @@ struct opusgpu_ctx {
     int mode = OPUSGPU_MODE_REFERENCE; // opusgpu_set_mode
     // opusgpu_set_pipeline: the parse of step k + 1's CELT-only frames runs on parse_stream, next to step k's reconstruction
     // and its reconstruction on recon_stream; parse records and the reconstruction's per-frame output (d_recs, d_rout) rotate
-    int pipeline = 0, slot = 0, front_recorded = 0, rstart_recorded = 0, post_recorded[3] = {};
+    int pipeline = 0, slot = 0, front_recorded = 0, post_recorded[3] = {};
     hipStream_t parse_stream = nullptr, recon_stream = nullptr, last_step_stream = nullptr;
     hipEvent_t ev_front = nullptr;  // step k: its front kernels have finished (on the step's stream)
     hipEvent_t ev_parsed = nullptr; // step k: its early parse has finished (on parse_stream)
-    hipEvent_t ev_rstart = nullptr; // step k: its reconstruction is about to start (on recon_stream, ahead of the kernel)
     hipEvent_t ev_recon = nullptr;  // step k: its reconstruction has finished (on recon_stream)
     hipEvent_t ev_post[3] = {};     // by slot: k_celt_post of the last step that used it has finished (on the step's stream)
     const void *last_recs = nullptr;
-    int head_start_ticks = 4000; // 40 us of the 100 MHz clock (OPUSGPU_HEAD_START_US): the event's way to the parse queue was
-                                 // measured at 10 - 15 us; 15 / 25 / 40 us of head start give the same step time within 0.4 %
-    int post_delay_ticks = 15000; // 150 us (OPUSGPU_POST_DELAY_US): see decode_step_impl
-    int post_pad_bytes = 10240;   // (OPUSGPU_POST_PAD): see decode_step_impl
+    // Steps queued as a window (opusgpu_decode_steps_device): the kernels of neighbouring steps are placed in the order that
+    // works -- the next step's parse, then this step's reconstruction, then the de-emphasis of the step before -- by stream
+    // memory waits on two counters the parse / reconstruction workgroups bump when they start (device words, 64 bytes apart;
+    // the host keeps the totals they will reach).  Round 2 got that order from a spin-wait kernel watching the wall clock.
+    u32 *d_started = nullptr; // [0] early-parse workgroups started, [16] every 64th reconstruction workgroup started
+    u32 parse_started_total = 0, recon_started_total = 0;
     // (OPUSGPU_PARSE_GROUPS) groups of 32 frames per workgroup of the early parse: with two, half as many parse workgroups are
     // resident for about twice as long, each group runs nearer to a lone wave's pace, and the reconstruction next to them has
     // the LDS of the other half -- 1 / 2 / 3 / 4 groups: 2.545 / 2.50 / 2.52 / 2.97 ms per step on one box (at four the parse
@@ -678,9 +676,6 @@ int opusgpu_ctx_create(int device, opusgpu_ctx **out) {
     if (const char *e = getenv("OPUSGPU_SPLIT")) ctx->split_celt = e[0] != '0';
     if (const char *e = getenv("OPUSGPU_SPLIT_HYBRID")) ctx->split_hybrid = e[0] != '0';
     if (const char *e = getenv("OPUSGPU_FAST_RECON")) ctx->fast_recon = e[0] != '0';
-    if (const char *e = getenv("OPUSGPU_HEAD_START_US")) ctx->head_start_ticks = atoi(e) * 100;
-    if (const char *e = getenv("OPUSGPU_POST_DELAY_US")) ctx->post_delay_ticks = atoi(e) * 100;
-    if (const char *e = getenv("OPUSGPU_POST_PAD")) ctx->post_pad_bytes = atoi(e);
     if (const char *e = getenv("OPUSGPU_PARSE_GROUPS")) ctx->parse_groups = atoi(e) > 0 && atoi(e) <= 8 ? atoi(e) : 1;
     if (const char *e = getenv("OPUSGPU_HOST_PARTS")) {
         const int v = atoi(e);
@@ -715,6 +710,7 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     (void)hipHostFree(ctx->h_pcm);
     (void)hipHostFree(ctx->h_res);
     (void)hipFree(ctx->d_crc_tables);
+    (void)hipFree(ctx->d_started);
     for (hipEvent_t e : ctx->ev_piece)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_part)
@@ -725,7 +721,6 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     if (ctx->ev_front) (void)hipEventDestroy(ctx->ev_front);
     if (ctx->ev_parsed) (void)hipEventDestroy(ctx->ev_parsed);
     if (ctx->ev_recon) (void)hipEventDestroy(ctx->ev_recon);
-    if (ctx->ev_rstart) (void)hipEventDestroy(ctx->ev_rstart);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -751,12 +746,13 @@ int opusgpu_set_pipeline(opusgpu_ctx *ctx, int on) {
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_parsed, hipEventDisableTiming));
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_recon, hipEventDisableTiming));
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_rstart, hipEventDisableTiming));
         for (int i = 0; i < 3; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_post[i], hipEventDisableTiming));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_started, 128));
+        HIPCHK(ctx, hipMemset(ctx->d_started, 0, 128));
     }
     if ((on != 0) != (ctx->pipeline != 0)) { // switching: from an idle device (steps of either kind may be queued on any stream)
         HIPCHK(ctx, hipDeviceSynchronize());
-        ctx->front_recorded = ctx->rstart_recorded = ctx->post_recorded[0] = ctx->post_recorded[1] = ctx->post_recorded[2] = 0;
+        ctx->front_recorded = ctx->post_recorded[0] = ctx->post_recorded[1] = ctx->post_recorded[2] = 0;
     }
     ctx->pipeline = on ? 1 : 0;
     return OPUSGPU_OK;
@@ -775,7 +771,7 @@ int opusgpu_streams_reset(opusgpu_ctx *ctx, int first, int count, int full) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->recon_stream));
         if (ctx->last_step_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->last_step_stream));
     }
-    ctx->front_recorded = ctx->rstart_recorded = ctx->post_recorded[0] = ctx->post_recorded[1] = ctx->post_recorded[2] = 0; // (the reset below is synchronous)
+    ctx->front_recorded = ctx->post_recorded[0] = ctx->post_recorded[1] = ctx->post_recorded[2] = 0; // (the reset below is synchronous)
     hipLaunchKernelGGL(k_stream_init, dim3(count), dim3(64), 0, ctx->stream, ctx->d_streams, first, count, ctx->channels,
                        full ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
@@ -852,8 +848,10 @@ int opusgpu_memcpy_d2h(opusgpu_ctx *ctx, void *dst, const void *src, size_t byte
 // `tables_resident`: the step's descriptors and payload bytes are complete in device memory now (the public entry's contract
 // when pipelining is on); false when this call's own uploads are still queued on the step's stream (opusgpu_decode_packets):
 // such a step does not run ahead of anything.
+// `next_n` (steps queued as a window, opusgpu_decode_steps_device): the number of frames of the step that the same call queues
+// right behind this one with the same mode mask, 0 when there is none or it is not known.
 static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm, void *d_result,
-                            void *hip_stream, bool tables_resident, int modes = 7) {
+                            void *hip_stream, bool tables_resident, int modes = 7, int next_n = 0) {
     if (!ctx || n < 0 || !ctx->d_streams) return OPUSGPU_BAD_ARG;
     if (n == 0) return OPUSGPU_OK;
     if (!d_descs || !d_arena || !d_pcm || !d_result) return OPUSGPU_BAD_ARG;
@@ -887,12 +885,13 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     if (!modes) modes = 7;
     const bool any_silk = (modes & 3) != 0, any_celt = (modes & 6) != 0;
     const bool pipe = ctx->pipeline && tables_resident && (modes & 4); // (only CELT-only frames have anything to run ahead)
+    const bool window = pipe && modes == 4 && next_n > 0;              // the next step is queued by this very call: see PLACEMENT
     if (ctx->pipeline && ctx->last_step_stream && ctx->last_step_stream != s) {
         // consecutive steps on different streams: nothing orders them but the caller, so nothing may run ahead either
         HIPCHK(ctx, hipStreamSynchronize(ctx->last_step_stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->parse_stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->recon_stream));
-        ctx->front_recorded = ctx->rstart_recorded = ctx->post_recorded[0] = ctx->post_recorded[1] = ctx->post_recorded[2] = 0;
+        ctx->front_recorded = ctx->post_recorded[0] = ctx->post_recorded[1] = ctx->post_recorded[2] = 0;
     }
     ctx->last_step_stream = s;
     // The records, the reconstruction's per-frame output and the hand-off buffers only grow; growing frees the old one, which
@@ -930,10 +929,11 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     // (DESIGN.md section 6): next to k_celt_recon the synthesis gains nothing; next to k_celt_parse it gains 5 % on mixed-mode
     // steps but costs 13 % on CELT-only steps.
     // Pipelined (opusgpu_set_pipeline; the tables are resident, so nothing here waits for the caller's earlier work):
-    //   parse_stream   [front and start of the reconstruction of step k-1, post of step k-3]  k_celt_parse[CELT-only frames]
+    //   parse_stream   [front of step k-1, post of step k-3]  k_celt_parse[CELT-only frames]
     //   step's stream  k_silk_parse  k_celt_parse[hybrid]  k_silk_synth  k_decode_step[Q4]  (= front of step k)
-    //                  [reconstruction of step k]  k_celt_post
-    //   recon_stream   [early parse, front of step k, post of step k-2]  k_celt_recon_fb  k_celt_recon
+    //                  [reconstruction of step k; in a window: the first round of the reconstruction of step k+1]  k_celt_post
+    //   recon_stream   [early parse, front of step k, post of step k-2; in a window: every workgroup of the parse of step k+1]
+    //                  k_celt_recon_fb  k_celt_recon
     // "front": every kernel that writes what a parse kernel reads -- CeltState::bandE (k_celt_parse itself, and the full
     // kernel), the SILK state and prev_mode (k_silk_synth, the full kernel, the reconstruction of the step before, which the
     // step's stream has waited for) -- or that writes the caller's buffers.  The reconstruction touches neither the caller's
@@ -941,33 +941,41 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     // written 960 samples further on; the ring position travels in ReconOut), so when the caller rules out SILK-only and
     // hybrid frames the reconstruction of step k+1 starts while k_celt_post of step k runs; two steps on, it waits for it
     // (the ring holds two frames; records and ReconOut rotate through three sets).
+    // PLACEMENT.  The three kernels compete for LDS: the parse is one round of 14 KB workgroups that live ~1 ms, the
+    // reconstruction 65,536 workgroups of 7.5 KB that live ~0.15 ms, the de-emphasis 10 KB ones that nothing waits for.  A parse
+    // workgroup that arrives when the CUs are full of reconstruction workgroups finds no hole that fits it (3.1 ms per step
+    // instead of 2.3), so the order that works is: parse of step k+1, THEN reconstruction of step k, THEN de-emphasis of step
+    // k-1.  Events cannot say "that kernel's workgroups have started"; round 2 approximated it with a wave that watched the wall
+    // clock.  When the caller queues a window of steps (opusgpu_decode_steps_device) the next step is known, and the order is a
+    // real dependency: the parse and reconstruction workgroups count themselves in when they start, and the stream that
+    // launches the dependent kernel waits on that count (hipStreamWaitValue32) -- placement does not depend on how long a launch
+    // or an event takes to arrive.  A single step (opusgpu_decode_step_device) cannot know whether another follows: its kernels
+    // are released by their data dependencies alone.
     if (!pipe) {
         if (srecs)
             hipLaunchKernelGGL(k_silk_parse, dim3((n + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, s, (const FrameDesc *)d_descs,
                                (const u8 *)d_arena, (const StreamState *)ctx->d_streams, srecs, handoff, n, ctx->n_streams);
         if (any_celt)
             hipLaunchKernelGGL(k_celt_parse, parse_grid, parse_block, 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams,
-                               recs, n, ctx->n_streams, (const SilkHandoff *)handoff, (int)PARSE_ALL, 1);
+                               recs, n, ctx->n_streams, (const SilkHandoff *)handoff, (int)PARSE_ALL, 1, (u32 *)nullptr);
     } else {
-        // the early parse: behind the front of the step before, its own slot's last user (three steps back), and -- so that it
-        // and the reconstruction of the step before START TOGETHER -- that reconstruction's start.  The parse is one round of
-        // 16 KB workgroups: it gets its places when the machine is being refilled anyway (it has the higher priority); coming
-        // 0.2 ms after the reconstruction's 7.5 KB workgroups have filled the CUs it was measured to take 2.9 ms instead of
-        // 0.9 - 1.4 (no hole a retiring reconstruction workgroup leaves fits it) and the step after waited for it.
+        // the early parse: behind the front of the step before and its own slot's last user (three steps back)
         if (ctx->front_recorded) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_front, 0));
-        if (ctx->rstart_recorded) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_rstart, 0));
         if (ctx->post_recorded[par]) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_post[par], 0));
-        if (modes & 4)
-            hipLaunchKernelGGL(k_celt_parse, dim3((n + OG_PL_FRAMES * ctx->parse_groups - 1) / (OG_PL_FRAMES * ctx->parse_groups)), parse_block, 0,
-                               ctx->parse_stream, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams, recs, n, ctx->n_streams,
-                               (const SilkHandoff *)nullptr, (int)PARSE_CELT_ONLY, ctx->parse_groups);
+        if (modes & 4) {
+            const int grid = (n + OG_PL_FRAMES * ctx->parse_groups - 1) / (OG_PL_FRAMES * ctx->parse_groups);
+            hipLaunchKernelGGL(k_celt_parse, dim3(grid), parse_block, 0, ctx->parse_stream, (const FrameDesc *)d_descs, (const u8 *)d_arena,
+                               ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)nullptr, (int)PARSE_CELT_ONLY, ctx->parse_groups,
+                               ctx->d_started);
+            ctx->parse_started_total += (u32)grid;
+        }
         HIPCHK(ctx, hipEventRecord(ctx->ev_parsed, ctx->parse_stream));
         if (srecs) {
             hipLaunchKernelGGL(k_silk_parse, dim3((n + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, s, (const FrameDesc *)d_descs,
                                (const u8 *)d_arena, (const StreamState *)ctx->d_streams, srecs, handoff, n, ctx->n_streams);
             if (modes & 2)
                 hipLaunchKernelGGL(k_celt_parse, parse_grid, parse_block, 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams,
-                                   recs, n, ctx->n_streams, (const SilkHandoff *)handoff, (int)PARSE_HYBRID_ONLY, 1);
+                                   recs, n, ctx->n_streams, (const SilkHandoff *)handoff, (int)PARSE_HYBRID_ONLY, 1, (u32 *)nullptr);
         }
     }
     bool others_ran = false; // (the kernels that report stream-index errors for every mode)
@@ -1001,35 +1009,34 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
             HIPCHK(ctx, hipStreamWaitEvent(back, ctx->ev_front, 0));
         }
         if (ctx->post_recorded[par2]) HIPCHK(ctx, hipStreamWaitEvent(back, ctx->ev_post[par2], 0)); // (the ring: 2 x 960 of 2048)
-        HIPCHK(ctx, hipEventRecord(ctx->ev_rstart, back));
-        ctx->rstart_recorded = 1;
-        // the next step's early parse is released by that event and has to be placed BEFORE this reconstruction fills the CUs
-        // (see above): the event's way to the other queue takes ~10 us, so the reconstruction is held back longer than that
-        if (ctx->head_start_ticks > 0) hipLaunchKernelGGL(k_head_start, dim3(1), dim3(64), 0, back, ctx->head_start_ticks);
+        if (window) { // ... and every workgroup of the next step's parse has its place
+            const int next_grid = (next_n + OG_PL_FRAMES * ctx->parse_groups - 1) / (OG_PL_FRAMES * ctx->parse_groups);
+            HIPCHK(ctx, hipStreamWaitValue32(back, ctx->d_started, ctx->parse_started_total + (u32)next_grid, hipStreamWaitValueGte, 0xffffffffu));
+        }
     }
     if (any_celt) {
         // reconstruct (one frame per wave) ...
-        if (ctx->fast_recon) og_launch_celt_recon_fb(back, d_descs, ctx->d_streams, recs, rout, n, ctx->n_streams, handoff ? 1 : 0);
+        if (ctx->fast_recon) {
+            og_launch_celt_recon_fb(back, d_descs, ctx->d_streams, recs, rout, n, ctx->n_streams, handoff ? 1 : 0, pipe ? ctx->d_started + 16 : nullptr);
+            if (pipe) ctx->recon_started_total += (u32)og_celt_recon_fb_signals(n);
+        }
         hipLaunchKernelGGL(k_celt_recon, dim3(ctx->fast_recon ? (n + 63) / 64 : n), dim3(64), 0, back, (const FrameDesc *)d_descs,
                            ctx->d_streams, (const ParseRec *)recs, rout, n, ctx->n_streams, handoff ? 1 : 0, ctx->fast_recon);
     }
     if (pipe) {
         HIPCHK(ctx, hipEventRecord(ctx->ev_recon, back));
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_recon, 0));
-        // k_celt_post becomes ready at the same moment as the next step's reconstruction and the parse after that; its 15 KB
-        // workgroups placed first keep the parse's 16 KB ones out until the reconstruction has filled the CUs (measured: the
-        // parse then takes 3.1 instead of 0.9 ms, 2.80 ms per step).  Nothing waits for the de-emphasis, so it goes last: held
-        // back until the other two are placed, it runs in the holes the parse leaves (0.9 ms instead of 0.2, 2.58 ms per step).
-        if (ctx->post_delay_ticks > 0 && !any_silk) hipLaunchKernelGGL(k_head_start, dim3(1), dim3(64), 0, s, ctx->post_delay_ticks);
+        // Nothing waits for the de-emphasis for two steps, and placed before the next step's reconstruction its 10 KB workgroups
+        // take room that kernel -- the critical one -- would use: in a window it is held until the first round of that
+        // reconstruction has started (its count of started workgroups, one in 64 counted)
+        if (window && ctx->fast_recon) {
+            const int first_round = OG_MIN(og_celt_recon_fb_signals(next_n), 32);
+            HIPCHK(ctx, hipStreamWaitValue32(s, ctx->d_started + 16, ctx->recon_started_total + (u32)first_round, hipStreamWaitValueGte, 0xffffffffu));
+        }
     }
     if (any_celt || !others_ran || modes != 7) {
         // ... -> de-emphasis, SILK mix and PCM (one (frame, channel) per lane); the result codes of CELT / hybrid frames
-        // (Next to the next step's reconstruction the de-emphasis should stay out of the way -- nothing waits for it for two
-        // steps: with its LDS footprint padded from the 10 KB it needs to 20 KB its workgroups do not fit the 14 KB holes the
-        // parse leaves, those go to the reconstruction, and the step is 2 % shorter.  Measured on one box, padding 0 / 5 / 7.5 /
-        // 10 / 12.5 / 15 / 20 / 30 / 40 KB: 2.55 / 2.51 / 2.49 / 2.49 / 2.51 / 2.52 / 2.53 / 2.55 / 2.57 ms per step.  Alone --
-        // in-order steps, hybrid and mixed batches -- the small footprint is the fast one.)
-        const size_t post_pad = pipe && !any_silk ? (size_t)ctx->post_pad_bytes : 0;
+        const size_t post_pad = 0;
         hipLaunchKernelGGL(k_celt_post, dim3((n * ctx->channels + 63) / 64), dim3(64), post_pad, s, (const FrameDesc *)d_descs, ctx->d_streams,
                            (const ParseRec *)recs, (const ReconOut *)rout, (i32 *)d_result, (i16 *)d_pcm, n, ctx->n_streams, ctx->channels,
                            pcm_stride, (const SilkHandoff *)handoff, modes, others_ran ? 1 : 0);
@@ -1055,6 +1062,27 @@ int opusgpu_decode_step_device_modes(opusgpu_ctx *ctx, int n, const void *d_desc
                                      void *d_result, void *hip_stream, int modes) {
     if (modes <= 0 || modes > 7) return OPUSGPU_BAD_ARG;
     return decode_step_impl(ctx, n, d_descs, d_arena, d_pcm, d_result, hip_stream, true, modes);
+}
+int opusgpu_decode_steps_device(opusgpu_ctx *ctx, int n_steps, const int32_t *n, const void *const *d_descs, const void *const *d_arena,
+                                void *const *d_pcm, void *const *d_result, void *hip_stream, int modes) {
+    if (!ctx || n_steps < 0 || modes < 0 || modes > 7) return OPUSGPU_BAD_ARG;
+    if (n_steps == 0) return OPUSGPU_OK;
+    if (!n || !d_descs || !d_arena || !d_pcm || !d_result) return OPUSGPU_BAD_ARG;
+    if (ctx->d_started && (ctx->parse_started_total > 0x70000000u || ctx->recon_started_total > 0x70000000u)) {
+        // the start counters only grow: long before they could wrap they restart from zero, on an idle device
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        if (int rc = sync_in_flight(ctx)) return rc;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemset(ctx->d_started, 0, 128));
+        ctx->parse_started_total = ctx->recon_started_total = 0;
+    }
+    for (int k = 0; k < n_steps; k++) {
+        const int next_n = k + 1 < n_steps ? n[k + 1] : 0;
+        const int rc = decode_step_impl(ctx, n[k], d_descs[k], d_arena[k], d_pcm[k], d_result[k], hip_stream, true, modes ? modes : 7,
+                                        next_n > 0 ? next_n : 0);
+        if (rc) return rc;
+    }
+    return OPUSGPU_OK;
 }
 
 #ifdef OG_PROF

@@ -132,7 +132,10 @@ OG_DEV void leaf_pass_pooled(const ParseRec *rec, int n_leaves, int spread) {
 // kernel then also takes their CELT half
 __global__ void __launch_bounds__(64 * RG, OG_FAST_WAVES) k_celt_recon_fb(const FrameDesc *__restrict__ descs, StreamState *st,
                                                                            const ParseRec *recs, ReconOut *rout, int n, int n_streams,
-                                                                           int hybrid) {
+                                                                           int hybrid, u32 *started) {
+    // `started` (steps queued as a window, opusgpu_decode_steps_device): every 64th workgroup counts itself in when it starts --
+    // the de-emphasis of the step before is held until the first round of this launch has its places
+    if (started && threadIdx.x == 0 && (blockIdx.x & 63) == 0) __hip_atomic_fetch_add(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int f = (int)blockIdx.x * RG + OG_WAVE;
     // the wave's frame, if it has one this kernel takes
     StreamState *sp = nullptr;
@@ -196,10 +199,11 @@ __global__ void __launch_bounds__(64 * RG, OG_FAST_WAVES) k_celt_recon_fb(const 
 }
 
 extern "C" void og_launch_celt_recon_fb(hipStream_t s, const void *descs, void *streams, const void *recs, void *rout, int n,
-                                        int n_streams, int hybrid) {
+                                        int n_streams, int hybrid, unsigned *started) {
     hipLaunchKernelGGL(k_celt_recon_fb, dim3((n + RG - 1) / RG), dim3(64 * RG), 0, s, (const FrameDesc *)descs, (StreamState *)streams,
-                       (const ParseRec *)recs, (ReconOut *)rout, n, n_streams, hybrid);
+                       (const ParseRec *)recs, (ReconOut *)rout, n, n_streams, hybrid, started);
 }
+extern "C" int og_celt_recon_fb_signals(int n) { return ((n + RG - 1) / RG + 63) / 64; }
 
 #ifdef OG_PROF
 // profiling builds only: this kernel's section counters (OG_MARK) -- the other translation unit has its own copy

@@ -179,6 +179,15 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
 #define OPUSGPU_HAS_CELT 4
 int opusgpu_decode_step_device_modes(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm,
                                      void *d_result, void *hip_stream, int modes);
+/* A WINDOW of consecutive decode steps in one call: step j has n[j] frames and the tables d_descs[j] / d_arena[j], and writes
+ * d_pcm[j] / d_result[j]; everything opusgpu_decode_step_device_modes says holds per step (`modes`: 0 = not known), the tables of
+ * every step are complete in device memory at the call.  Same results as n_steps single calls.  The point is pipelined steps
+ * (opusgpu_set_pipeline) of CELT-only frames: knowing the step that follows, the library orders the kernels of neighbouring
+ * steps by real dependencies -- the next step's parse is placed before this step's reconstruction, that before the previous
+ * step's de-emphasis, each held by a stream memory wait on a count of started workgroups -- where a single call has to leave
+ * the order to the hardware queues (round 2 used a spin-wait kernel and an unused LDS request for it; both are gone). */
+int opusgpu_decode_steps_device(opusgpu_ctx *ctx, int n_steps, const int32_t *n, const void *const *d_descs, const void *const *d_arena,
+                                void *const *d_pcm, void *const *d_result, void *hip_stream, int modes);
 int opusgpu_synchronize(opusgpu_ctx *ctx);
 /* HIP events on the context's stream, for timing from hosts without HIP headers. */
 int opusgpu_event_create(opusgpu_ctx *ctx, void **event);
