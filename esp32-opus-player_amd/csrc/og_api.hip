@@ -17,6 +17,7 @@
 #include "og_decode.hpp"
 #include "og_packet.hpp"
 #include "og_output.hpp"
+#include "og_debug.hpp"
 
 using namespace og;
 
@@ -643,7 +644,7 @@ static int fail(opusgpu_ctx *ctx, int code, const char *what, hipError_t e) {
 struct HostPhaseTimer {
     bool on;
     std::chrono::steady_clock::time_point t;
-    HostPhaseTimer() : on(getenv("OPUSGPU_HOST_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+    HostPhaseTimer() : on(og_debug().host_timing != 0), t(std::chrono::steady_clock::now()) {}
     void mark(const char *what) {
         if (!on) return;
         const auto now = std::chrono::steady_clock::now();
@@ -673,14 +674,11 @@ int opusgpu_ctx_create(int device, opusgpu_ctx **out) {
     opusgpu_ctx *ctx = new (std::nothrow) opusgpu_ctx();
     if (!ctx) return OPUSGPU_ALLOC_FAIL;
     ctx->device = device;
-    if (const char *e = getenv("OPUSGPU_SPLIT")) ctx->split_celt = e[0] != '0';
-    if (const char *e = getenv("OPUSGPU_SPLIT_HYBRID")) ctx->split_hybrid = e[0] != '0';
-    if (const char *e = getenv("OPUSGPU_FAST_RECON")) ctx->fast_recon = e[0] != '0';
-    if (const char *e = getenv("OPUSGPU_PARSE_GROUPS")) ctx->parse_groups = atoi(e) > 0 && atoi(e) <= 8 ? atoi(e) : 1;
-    if (const char *e = getenv("OPUSGPU_HOST_PARTS")) {
-        const int v = atoi(e);
-        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ctx->host_parts = v;
-    }
+    ctx->split_celt = og_debug().split; // (og_debug.hpp: A/B switches, read from the environment once per process)
+    ctx->split_hybrid = og_debug().split_hybrid;
+    ctx->fast_recon = og_debug().fast_recon;
+    ctx->parse_groups = og_debug().parse_groups;
+    ctx->host_parts = og_debug().host_parts;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return OPUSGPU_ERR_HIP;
@@ -740,7 +738,7 @@ int opusgpu_set_pipeline(opusgpu_ctx *ctx, int on) {
         // reconstruction it runs next to fills the slots around it
         int least = 0, greatest = 0;
         HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        if (const char *e = getenv("OPUSGPU_PARSE_PRIORITY")) greatest = e[0] == '0' ? least : greatest;
+        if (!og_debug().parse_priority) greatest = least;
         HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->parse_stream, hipStreamNonBlocking, greatest));
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->recon_stream, hipStreamNonBlocking));
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
@@ -848,6 +846,11 @@ int opusgpu_memcpy_d2h(opusgpu_ctx *ctx, void *dst, const void *src, size_t byte
 // `tables_resident`: the step's descriptors and payload bytes are complete in device memory now (the public entry's contract
 // when pipelining is on); false when this call's own uploads are still queued on the step's stream (opusgpu_decode_packets):
 // such a step does not run ahead of anything.
+// OPUSGPU_LAUNCH_DELAY_US (og_debug.hpp): the host dawdles before the launches of a decode step -- what a loaded host, a slow
+// event hop or another thread's launches would do -- so that tools/launch_jitter.py can show the step time does not depend on it
+static void launch_jitter() {
+    if (const int us = og_debug().launch_delay_us) std::this_thread::sleep_for(std::chrono::microseconds(us));
+}
 // `next_n` (steps queued as a window, opusgpu_decode_steps_device): the number of frames of the step that the same call queues
 // right behind this one with the same mode mask, 0 when there is none or it is not known.
 static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm, void *d_result,
@@ -964,6 +967,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         if (ctx->post_recorded[par]) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_post[par], 0));
         if (modes & 4) {
             const int grid = (n + OG_PL_FRAMES * ctx->parse_groups - 1) / (OG_PL_FRAMES * ctx->parse_groups);
+            launch_jitter();
             hipLaunchKernelGGL(k_celt_parse, dim3(grid), parse_block, 0, ctx->parse_stream, (const FrameDesc *)d_descs, (const u8 *)d_arena,
                                ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)nullptr, (int)PARSE_CELT_ONLY, ctx->parse_groups,
                                ctx->d_started);
@@ -1017,6 +1021,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     if (any_celt) {
         // reconstruct (one frame per wave) ...
         if (ctx->fast_recon) {
+            if (pipe) launch_jitter();
             og_launch_celt_recon_fb(back, d_descs, ctx->d_streams, recs, rout, n, ctx->n_streams, handoff ? 1 : 0, pipe ? ctx->d_started + 16 : nullptr);
             if (pipe) ctx->recon_started_total += (u32)og_celt_recon_fb_signals(n);
         }
@@ -1037,6 +1042,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     if (any_celt || !others_ran || modes != 7) {
         // ... -> de-emphasis, SILK mix and PCM (one (frame, channel) per lane); the result codes of CELT / hybrid frames
         const size_t post_pad = 0;
+        if (pipe) launch_jitter();
         hipLaunchKernelGGL(k_celt_post, dim3((n * ctx->channels + 63) / 64), dim3(64), post_pad, s, (const FrameDesc *)d_descs, ctx->d_streams,
                            (const ParseRec *)recs, (const ReconOut *)rout, (i32 *)d_result, (i16 *)d_pcm, n, ctx->n_streams, ctx->channels,
                            pcm_stride, (const SilkHandoff *)handoff, modes, others_ran ? 1 : 0);

@@ -1,0 +1,51 @@
+// og_debug.hpp -- every debugging / measurement switch of the library in one place, read from the environment ONCE per process.
+//
+// None of them is needed in production: the defaults are what the measurements in DESIGN.md settled on.  They exist for A/B
+// runs of the same binary (tools/kstats.sh) and for the robustness test of pipelined steps (tools/launch_jitter.py).
+//
+//   variable                  field            default  meaning
+//   OPUSGPU_SPLIT             split            1        0: every frame through the single kernel k_decode_step (round 1's design)
+//   OPUSGPU_SPLIT_HYBRID      split_hybrid     1        0: SILK-only and hybrid frames stay on the single kernel
+//   OPUSGPU_FAST_RECON        fast_recon       1        0: every CELT frame through the general reconstruction kernel
+//   OPUSGPU_PARSE_GROUPS      parse_groups     2        groups of 32 frames per workgroup of the early parse (1 .. 8)
+//   OPUSGPU_PARSE_PRIORITY    parse_priority   1        0: the early parse's stream gets the LOWEST priority instead of the highest
+//   OPUSGPU_HOST_PARTS        host_parts       2        parts a large opusgpu_decode_packets call is cut into (1, 2, 4, 8, 16)
+//   OPUSGPU_HOST_TIMING       host_timing      0        1: wall time of the phases of opusgpu_decode_packets on stderr
+//   OPUSGPU_PAGES_TIMING      pages_timing     0        1: wall time of the phases of opusgpu_pages_demux on stderr
+//   OPUSGPU_LAUNCH_DELAY_US   launch_delay_us  0        the host sleeps this long before every kernel launch of a decode step
+//                                                       (robustness of the placement of pipelined steps against launch jitter)
+#pragma once
+#include <stdlib.h>
+
+struct og_debug_knobs {
+    int split = 1, split_hybrid = 1, fast_recon = 1, parse_groups = 2, parse_priority = 1, host_parts = 2, host_timing = 0,
+        pages_timing = 0, launch_delay_us = 0;
+};
+inline const og_debug_knobs &og_debug() {
+    static const og_debug_knobs k = [] {
+        og_debug_knobs v;
+        auto flag = [](const char *name, int &field) {
+            if (const char *e = getenv(name)) field = e[0] != '0' && e[0] != '\0';
+        };
+        auto number = [](const char *name, int &field, int lo, int hi) {
+            if (const char *e = getenv(name)) {
+                const int x = atoi(e);
+                if (x >= lo && x <= hi) field = x;
+            }
+        };
+        flag("OPUSGPU_SPLIT", v.split);
+        flag("OPUSGPU_SPLIT_HYBRID", v.split_hybrid);
+        flag("OPUSGPU_FAST_RECON", v.fast_recon);
+        number("OPUSGPU_PARSE_GROUPS", v.parse_groups, 1, 8);
+        flag("OPUSGPU_PARSE_PRIORITY", v.parse_priority);
+        if (const char *e = getenv("OPUSGPU_HOST_PARTS")) {
+            const int x = atoi(e);
+            if (x == 1 || x == 2 || x == 4 || x == 8 || x == 16) v.host_parts = x;
+        }
+        v.host_timing = getenv("OPUSGPU_HOST_TIMING") != nullptr;
+        v.pages_timing = getenv("OPUSGPU_PAGES_TIMING") != nullptr;
+        number("OPUSGPU_LAUNCH_DELAY_US", v.launch_delay_us, 0, 100000);
+        return v;
+    }();
+    return k;
+}

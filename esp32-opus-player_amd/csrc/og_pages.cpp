@@ -20,6 +20,7 @@
 #include <unordered_map>
 #include <vector>
 #include "og_packet.hpp"
+#include "og_debug.hpp"
 #include "../../include/opusgpu.h"
 
 namespace {
@@ -184,7 +185,7 @@ PageScan scan_page(const uint8_t *pg, int32_t len, int flags, opusgpu_page_info 
 struct PhaseTimer {
     bool on;
     std::chrono::steady_clock::time_point t;
-    PhaseTimer() : on(getenv("OPUSGPU_PAGES_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+    PhaseTimer() : on(og_debug().pages_timing != 0), t(std::chrono::steady_clock::now()) {}
     void mark(const char *what) {
         if (!on) return;
         const auto now = std::chrono::steady_clock::now();

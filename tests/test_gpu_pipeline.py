@@ -32,9 +32,11 @@ def desc_flags(toc):
     return (mode | bw << 2 | np.where(toc & 4, 32, 0)).astype(np.int32), mode
 
 
-def run_queued(pkg, ctx, channels, arena, offs, lens, toc, pipeline, sync_every=0, reset_at=None, modes=0, one_pcm=False, streams=None):
+def run_queued(pkg, ctx, channels, arena, offs, lens, toc, pipeline, sync_every=0, reset_at=None, modes=0, one_pcm=False, streams=None,
+               window=False):
     """All steps queued back to back (tables of every step resident before the first call).  Returns PCM [frames, n, 960*ch]
-    and result codes [frames, n]."""
+    and result codes [frames, n].  window: the steps go in ONE opusgpu_decode_steps_device call (cut where a reset or a
+    synchronisation point is asked for) instead of one call per step."""
     frames, n = offs.shape
     flags, _ = desc_flags(toc)
     ctx.streams_alloc(n, channels)
@@ -52,12 +54,22 @@ def run_queued(pkg, ctx, channels, arena, offs, lens, toc, pipeline, sync_every=
         descs["len"] = lens[f].astype(np.int32)
         descs["flags"] = flags[f]
         ctx.h2d(d_desc[f], descs)  # (synchronous: complete in device memory before any step is queued)
-    for f in range(frames):
-        if reset_at is not None and f == reset_at:
-            ctx.streams_reset(0, n, full=False)
-        ctx.decode_step_device(n, d_desc[f], d_arena, d_pcm[f], d_res[f], modes=modes)
-        if sync_every and (f + 1) % sync_every == 0:
-            ctx.synchronize()
+    if window:
+        cuts = sorted({0, frames} | ({reset_at} if reset_at is not None else set()) |
+                      (set(range(sync_every, frames, sync_every)) if sync_every else set()))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if reset_at is not None and a == reset_at:
+                ctx.streams_reset(0, n, full=False)
+            ctx.decode_steps_device([n] * (b - a), d_desc[a:b], [d_arena] * (b - a), d_pcm[a:b], d_res[a:b], modes=modes)
+            if sync_every and b % sync_every == 0:
+                ctx.synchronize()
+    else:
+        for f in range(frames):
+            if reset_at is not None and f == reset_at:
+                ctx.streams_reset(0, n, full=False)
+            ctx.decode_step_device(n, d_desc[f], d_arena, d_pcm[f], d_res[f], modes=modes)
+            if sync_every and (f + 1) % sync_every == 0:
+                ctx.synchronize()
     ctx.synchronize()
     pcm = np.zeros((frames, n, 960 * channels), dtype=np.int16)
     res = np.zeros((frames, n), dtype=np.int32)
@@ -97,6 +109,8 @@ def test_pipelined_steps_random_mode_walks(pkg, oracle, gpu_ctx, channels):
     ref, rets = oracle.batch_decode_var(channels, arena, offs, plen.astype(np.int32))
     pcm, res = run_queued(pkg, gpu_ctx, channels, arena, offs, lens, toc, pipeline=True)
     assert compare(pcm, res, ref, rets, toc, channels) == 0
+    pcm, res = run_queued(pkg, gpu_ctx, channels, arena, offs, lens, toc, pipeline=True, window=True)
+    assert compare(pcm, res, ref, rets, toc, channels) == 0
     # and so is the in-order flow through the same harness
     pcm0, res0 = run_queued(pkg, gpu_ctx, channels, arena, offs, lens, toc, pipeline=False)
     assert compare(pcm0, res0, ref, rets, toc, channels) == 0
@@ -118,9 +132,10 @@ def test_pipelined_celt_only_and_hybrid(pkg, oracle, gpu_ctx):
         blk[:, :, 1:] = pay
         toc = np.full((frames, n), toc_byte, dtype=np.uint8)
         for modes in (0, pkg.toc_modes(toc_byte)):  # not known / named by the caller (CELT-only: the reconstruction runs ahead too)
-            pcm, res = run_queued(pkg, gpu_ctx, 2, arena, offs, plen - 1, toc, pipeline=True, modes=modes)
-            assert (res == 960).all()
-            assert np.array_equal(pcm.reshape(frames, n, 960, 2).transpose(1, 0, 2, 3), ref)
+            for window in (False, True):  # (a window of CELT-only steps: the kernels wait on each other's start counts)
+                pcm, res = run_queued(pkg, gpu_ctx, 2, arena, offs, plen - 1, toc, pipeline=True, modes=modes, window=window)
+                assert (res == 960).all()
+                assert np.array_equal(pcm.reshape(frames, n, 960, 2).transpose(1, 0, 2, 3), ref)
         pcm, res = run_queued(pkg, gpu_ctx, 2, arena, offs, plen - 1, toc, pipeline=False, modes=pkg.toc_modes(toc_byte))
         assert (res == 960).all()
         assert np.array_equal(pcm.reshape(frames, n, 960, 2).transpose(1, 0, 2, 3), ref)
@@ -160,6 +175,8 @@ def test_pipeline_with_synchronisation_points_and_reset(pkg, oracle, gpu_ctx):
     assert np.array_equal(res, res0)
     ok = res0 == 960
     assert np.array_equal(pcm[ok], pcm0[ok])
+    pcm1, res1 = run_queued(pkg, gpu_ctx, channels, arena, offs, lens, toc, pipeline=True, sync_every=4, reset_at=5, window=True)
+    assert np.array_equal(res1, res0) and np.array_equal(pcm1[ok], pcm0[ok])
     for s, d in enumerate(decs):  # and a sample of the streams against the oracle, reset included
         d.init()
         for f in range(frames):
@@ -213,41 +230,67 @@ def test_host_path_and_device_steps_mix_with_pipelining_on(pkg, oracle, gpu_ctx)
         ctx.set_pipeline(False)
 
 
-def test_placement_heuristics_change_no_result(pkg, oracle):
-    """The hold-backs and the LDS padding that decide which kernel of a pipelined step is placed first (OPUSGPU_HEAD_START_US,
-    OPUSGPU_POST_DELAY_US, OPUSGPU_POST_PAD, OPUSGPU_PARSE_PRIORITY) are performance heuristics: with any of them at an extreme the
-    kernels meet in a different order on the CUs and the bytes stay the same."""
+def test_placement_knobs_change_no_result(pkg, oracle):
+    """What decides which kernel of a pipelined step meets which on the CUs -- the early parse's stream priority and workgroup
+    size, how late the host's launches arrive (og_debug.hpp: OPUSGPU_PARSE_PRIORITY, OPUSGPU_PARSE_GROUPS,
+    OPUSGPU_LAUNCH_DELAY_US) -- changes no byte.  The switches are read once per process: each setting runs in a child process
+    (tests/pipeline_knob_worker.py), which checks a window of CELT-only steps and the same steps one call each against the oracle."""
     import os
-    n, frames, L = 8192, 8, 160
-    toc_byte = pkg.TOC_CELT_FB_STEREO
-    pay = pkg.lcg_payloads(n, frames, L, seed_base=0x9191)
-    ref, ok = oracle.batch_decode(2, toc_byte, pay)
-    assert ok == n * frames
-    plen = np.full((frames, n), L + 1, dtype=np.int64)
-    offs = np.arange(frames * n, dtype=np.int64).reshape(frames, n) * (L + 1)
-    arena = np.zeros(frames * n * (L + 1) + 16, dtype=np.uint8)
-    blk = arena[: frames * n * (L + 1)].reshape(frames, n, L + 1)
-    blk[:, :, 0] = toc_byte
-    blk[:, :, 1:] = pay
-    toc = np.full((frames, n), toc_byte, dtype=np.uint8)
-    settings = [{"OPUSGPU_HEAD_START_US": "0"}, {"OPUSGPU_POST_DELAY_US": "0"}, {"OPUSGPU_POST_PAD": "0"},
-                {"OPUSGPU_POST_PAD": "40960"}, {"OPUSGPU_PARSE_PRIORITY": "0"},
-                {"OPUSGPU_HEAD_START_US": "300", "OPUSGPU_POST_DELAY_US": "2000"}]
+    import subprocess
+    import sys
+    settings = [{"OPUSGPU_PARSE_PRIORITY": "0"}, {"OPUSGPU_PARSE_GROUPS": "1"}, {"OPUSGPU_PARSE_GROUPS": "4"},
+                {"OPUSGPU_LAUNCH_DELAY_US": "250"}]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pipeline_knob_worker.py")
     for env in settings:
-        saved = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
-            ctx = pkg.Context(0)  # (the variables are read when a context is created)
-            pcm, res = run_queued(pkg, ctx, 2, arena, offs, plen - 1, toc, pipeline=True, modes=pkg.HAS_CELT)
-            assert (res == 960).all(), env
-            assert np.array_equal(pcm.reshape(frames, n, 960, 2).transpose(1, 0, 2, 3), ref), env
-            ctx.close() if hasattr(ctx, "close") else None
-        finally:
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+        out = subprocess.run([sys.executable, worker], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "knob worker ok" in out.stdout, (env, out.stdout[-400:], out.stderr[-400:])
+
+
+def test_window_with_steps_of_different_sizes(pkg, oracle, gpu_ctx):
+    """opusgpu_decode_steps_device: the steps of a window need not have the same number of frames (the wait on the next step's
+    parse counts THAT step's workgroups); streams 0 .. n_k - 1 take part in step k."""
+    sizes = [4096, 100, 4096, 33, 2500, 1, 4096, 4096]
+    n, frames, L = max(sizes), len(sizes), 160
+    toc_byte = pkg.TOC_CELT_FB_STEREO
+    rng = np.random.default_rng(515)
+    pay = rng.integers(0, 256, (frames, n, L), dtype=np.uint8)
+    ctx = gpu_ctx
+    ctx.streams_alloc(n, 2)
+    ctx.set_pipeline(True)
+    frees = []
+    try:
+        tabs = []
+        for f in range(frames):
+            arena, descs = pkg.build_step(toc_byte, pay[f, :sizes[f]])
+            a, d = ctx.dev_alloc(arena.nbytes + 16), ctx.dev_alloc(descs.nbytes)
+            ctx.h2d(a, arena)
+            ctx.h2d(d, descs)
+            p, r = ctx.dev_alloc(sizes[f] * 960 * 2 * 2), ctx.dev_alloc(4 * sizes[f])
+            tabs.append((d, a, p, r))
+            frees += [a, d, p, r]
+        ctx.decode_steps_device(sizes, [t[0] for t in tabs], [t[1] for t in tabs], [t[2] for t in tabs], [t[3] for t in tabs],
+                                modes=pkg.HAS_CELT)
+        ctx.synchronize()
+        decs = {}
+        for f in range(frames):  # the oracle: stream s decodes the frames of the steps it takes part in, in order
+            got = np.zeros((sizes[f], 960, 2), dtype=np.int16)
+            res = np.zeros(sizes[f], dtype=np.int32)
+            ctx.d2h(got, tabs[f][2])
+            ctx.d2h(res, tabs[f][3])
+            assert (res == 960).all(), f
+            for s in list(range(min(sizes[f], 40))) + ([sizes[f] - 1] if sizes[f] > 40 else []):
+                if s not in decs:
+                    decs[s] = (oracle.decoder(2), [])
+                    decs[s][0].init()
+                    for g in range(f):  # (catch up on the earlier steps this stream took part in)
+                        if s < sizes[g]:
+                            decs[s][0].decode(bytes([toc_byte]) + pay[g, s].tobytes())
+                out, r = decs[s][0].decode(bytes([toc_byte]) + pay[f, s].tobytes())
+                assert r == 960 and np.array_equal(out[:960], got[s]), (f, s)
+    finally:
+        ctx.set_pipeline(False)
+        for p in frees:
+            ctx.dev_free(p)
 
 
 @pytest.mark.parametrize("n", [1, 33, 1000])
@@ -266,6 +309,7 @@ def test_pipelined_steps_of_odd_sizes(pkg, oracle, gpu_ctx, n):
     blk[:, :, 1:] = pay
     toc = np.full((frames, n), toc_byte, dtype=np.uint8)
     for modes in (0, pkg.HAS_CELT):
-        pcm, res = run_queued(pkg, gpu_ctx, 2, arena, offs, plen - 1, toc, pipeline=True, modes=modes)
-        assert (res == 960).all()
-        assert np.array_equal(pcm.reshape(frames, n, 960, 2).transpose(1, 0, 2, 3), ref)
+        for window in (False, True):
+            pcm, res = run_queued(pkg, gpu_ctx, 2, arena, offs, plen - 1, toc, pipeline=True, modes=modes, window=window)
+            assert (res == 960).all()
+            assert np.array_equal(pcm.reshape(frames, n, 960, 2).transpose(1, 0, 2, 3), ref)
