@@ -322,8 +322,8 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
     n = n_override or default_streams
     K, W = args.steps, args.warmup
     mixed = name == "mixed_pages_2m"
-    if mixed:
-        n -= n % 3  # equal numbers of streams per mode
+    if mixed:  # stream s has mode s % 3: 262,144 streams per GPU are 87,382 SILK-NB + 87,381 hybrid + 87,381 CELT (8 ranks: 2,097,152 pages)
+        bytes_per_frame = sum(len(range(m, n, 3)) * b for m, b in enumerate((5953, 24945, 21633))) / n
     ctx.streams_alloc(n, 2)
     ingest, pay, e2e = None, None, None
     frees = []

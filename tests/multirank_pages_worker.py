@@ -18,7 +18,7 @@ import bench  # noqa: E402
 pkg = bench.load_pkg()
 shard = bench.load_shard()
 ranks = shard.Ranks(backend="gloo")
-m, npk = 30, 4  # streams per rank, packets per page
+m, npk = int(os.environ.get("OG_TEST_STREAMS", "30")), 4  # streams per rank, packets per page
 TOCS = (pkg.TOC_SILK_NB_STEREO, pkg.TOC_HYBRID_FB_STEREO, pkg.TOC_CELT_FB_STEREO)
 LENS = (40, 120, 160)
 

@@ -95,12 +95,13 @@ def test_mixed_mode_pages_small(pkg, oracle, gpu_ctx):
 
 def test_mixed_mode_pages_c5_share_pipelined(pkg, oracle, gpu_ctx):
     """The same share with pipelined steps, all ten queued back to back (what bench.py's mixed_pages_2m workload times)."""
-    _run(pkg, oracle, gpu_ctx, 262144 - 262144 % 3, 1, 10, threads=16, pipeline=True)
+    _run(pkg, oracle, gpu_ctx, 262144, 1, 10, threads=16, pipeline=True)
 
 
 def test_mixed_mode_pages_c5_share(pkg, oracle, gpu_ctx):
-    """One GPU's share of config C5 (2 M pages over 8 GPUs): 262,143 pages of 10 packets, one page per stream."""
-    _run(pkg, oracle, gpu_ctx, 262144 - 262144 % 3, 1, 10, threads=16)
+    """One GPU's share of config C5 (2,097,152 pages over 8 GPUs): 262,144 pages of 10 packets, one page per stream (modes by
+    stream id mod 3: the SILK-NB third is one stream larger)."""
+    _run(pkg, oracle, gpu_ctx, 262144, 1, 10, threads=16)
 
 
 def test_ragged_pages_random_modes(pkg, oracle, gpu_ctx):

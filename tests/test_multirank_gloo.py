@@ -72,3 +72,48 @@ def test_bench_refuses_a_rank_count_that_is_not_gpus():
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "refusing" in p.stderr
     assert not [x for x in p.stdout.splitlines() if x.startswith("{")]
+
+
+def test_work_queue_scatter_eight_ranks_with_a_remainder(tmp_path):
+    """BASELINE config 5's shape at world_size 8 (gloo, CPU): the per-rank share is NOT a multiple of the three modes (262,144 =
+    3 x 87,381 + 1; here 100 = 3 x 33 + 1 streams per rank), rank 0 routes 800 pages by owner, scatters raw pages and packed work,
+    and every rank must hold exactly its own share -- byte for byte what it would have built itself."""
+    env = dict(os.environ, OG_TEST_OUT=str(tmp_path), OMP_NUM_THREADS="1", OG_TEST_STREAMS="100")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "multirank_pages_worker.py")]
+    subprocess.run(cmd, check=True, env=env, cwd=ROOT, timeout=600)
+    r = [json.load(open(tmp_path / f"pages_rank{k}.json")) for k in range(8)]
+    for k, x in enumerate(r):
+        assert x["rank"] == k and x["same"] and x["per_rank_same"], x
+        assert x["n_steps"] == 4 and x["counts"] == [100] * 4 and x["grouped"] and x["size"] == x["nbytes"]
+    assert len({x["crc"] for x in r}) == 8
+
+
+def test_config5_page_arithmetic():
+    """2,097,152 pages over 8 ranks, as bench.py's mixed_pages_2m shards them: page p belongs to global stream p, its owner is
+    p // 262,144 (shard.Ranks.owner_of), its mode the local id mod 3.  Every page has exactly one owner, every rank 262,144 of
+    them -- 87,382 SILK-NB, 87,381 hybrid, 87,381 CELT -- and nothing is trimmed (round 2 dropped 8 pages to make the share a
+    multiple of three)."""
+    import importlib.util
+
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("og_shard_arith", os.path.join(ROOT, "esp32-opus-player_amd", "shard.py"))
+    shard = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shard)
+    total, world = 2097152, 8
+    per_rank = total // world
+    assert per_rank * world == total and per_rank == 262144
+    pages = np.arange(total, dtype=np.int64)
+    owner = np.array([shard.Ranks.owner_of(None, int(p), per_rank) for p in (0, per_rank - 1, per_rank, total - 1)])
+    assert owner.tolist() == [0, 0, 1, 7]
+    owner = pages // per_rank  # (owner_of, vectorised)
+    local = pages - owner * per_rank
+    assert np.array_equal(np.bincount(owner, minlength=world), np.full(world, per_rank))
+    for r in range(world):
+        modes = np.bincount(local[owner == r] % 3, minlength=3)
+        assert modes.tolist() == [87382, 87381, 87381] and modes.sum() == per_rank
+        # the streams bench.py gives mode m on a rank: range(m, n, 3)
+        assert [len(range(m, per_rank, 3)) for m in range(3)] == modes.tolist()
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.WORKLOADS["mixed_pages_2m"][3] == per_rank
