@@ -698,12 +698,15 @@ OG_DEV void rotate1_lane(i16 *xv, int x, int len, int stride, i32 c, i32 s) { //
 // U(a, b) for the leaf pass.  64 lanes walking 64 different leaves ask for 64 unrelated entries per step: from global
 // memory that is one cache line per lane and the texture path serialises them (measured: a third of the walk at best, with
 // the dense table evicted from L1 by the streaming traffic all the time).  Here rows 0..3 are closed forms and rows 4..14
-// sit in LDS, stored by COLUMN (rom_pvq_cc / rom_pvq_cb, 2.7 KB over the folding-history, pulse and scratch rows, none of
-// which is in use during the leaf pass): cwrsi keeps the dimension n for a whole step and counts it down by one, so the
-// column base of the next step is fetched a step ahead and every candidate of a step lies next to the others.
+// sit in LDS, stored by ROW (rom_pvq_rr / rom_pvq_rb, 2.4 KB over the folding-history, pulse and scratch rows, none of
+// which is in use during the leaf pass): U(lo, hi) = rr[rb[lo] + hi].  Round 2 stored columns (one base per dimension n,
+// fetched a step ahead); what the walk spends its time on since zero runs are skipped is the SEARCH for the next pulse's
+// dimension at a fixed number of pulses k, i.e. along rows k and k + 1: with rows, a probe is two independent reads off two
+// bases that change only when k does (a column base per probe made it two dependent round trips), a pulse's size candidates
+// (rows 4..7 at column n) need no base at all, and the two entries of a step with n <= k are neighbours in row n.
 struct PvqLds {
-    u32 cc[ROM_PVQ_CC_LEN];
-    u16 cb[177 + 1];
+    u32 rr[ROM_PVQ_RR_LEN];
+    u16 rb[16];
 };
 #ifdef OG_RECON_TIGHT
 static_assert(sizeof(PvqLds) <= (V_MASK - V_NORM) * 2, "the PVQ table overlays the band loop's tables and scratch rows");
@@ -713,23 +716,19 @@ static_assert(sizeof(PvqLds) <= (V_TOTAL - V_NORM) * 2, "the PVQ table overlays 
 OG_DEV PvqLds &pvq_lds() { return *reinterpret_cast<PvqLds *>(&S.v[V_NORM]); }
 OG_DEV void pvq_tab_load() { // (the caller synchronises)
 #ifdef OG_HOST_EMUL
-    OG_FOR_LANES(t, ROM_PVQ_CC_LEN) pvq_lds().cc[t] = rom_pvq_cc[t];
-    OG_FOR_LANES(t, 177) pvq_lds().cb[t] = rom_pvq_cb[t];
+    OG_FOR_LANES(t, ROM_PVQ_RR_LEN) pvq_lds().rr[t] = rom_pvq_rr[t];
+    OG_FOR_LANES(t, 16) pvq_lds().rb[t] = rom_pvq_rb[t];
 #else
     // every load requested before the first store waits for its data (a load - wait - store loop pays the L2's latency per pass)
-    constexpr int NCC = (ROM_PVQ_CC_LEN + OG_NLANES - 1) / OG_NLANES, NCB = (177 + OG_NLANES - 1) / OG_NLANES;
-    u32 cc[NCC];
-    u16 cb[NCB];
+    constexpr int NRR = (ROM_PVQ_RR_LEN + OG_NLANES - 1) / OG_NLANES;
+    u32 rr[NRR];
 #pragma unroll
-    for (int k = 0; k < NCC; k++) cc[k] = rom_pvq_cc[OG_MIN(OG_LANE + k * OG_NLANES, ROM_PVQ_CC_LEN - 1)];
+    for (int k = 0; k < NRR; k++) rr[k] = rom_pvq_rr[OG_MIN(OG_LANE + k * OG_NLANES, ROM_PVQ_RR_LEN - 1)];
+    const u16 rb = rom_pvq_rb[OG_LANE & 15];
 #pragma unroll
-    for (int k = 0; k < NCB; k++) cb[k] = rom_pvq_cb[OG_MIN(OG_LANE + k * OG_NLANES, 176)];
-#pragma unroll
-    for (int k = 0; k < NCC; k++)
-        if (OG_LANE + k * OG_NLANES < ROM_PVQ_CC_LEN) pvq_lds().cc[OG_LANE + k * OG_NLANES] = cc[k];
-#pragma unroll
-    for (int k = 0; k < NCB; k++)
-        if (OG_LANE + k * OG_NLANES < 177) pvq_lds().cb[OG_LANE + k * OG_NLANES] = cb[k];
+    for (int k = 0; k < NRR; k++)
+        if (OG_LANE + k * OG_NLANES < ROM_PVQ_RR_LEN) pvq_lds().rr[OG_LANE + k * OG_NLANES] = rr[k];
+    if (OG_LANE < 16) pvq_lds().rb[OG_LANE] = rb;
 #endif
 }
 // U(r, h) for a row r <= 3 (<= h), given U(2, h) and U(3, h); written without branches on purpose: the lanes of a wave
@@ -744,11 +743,12 @@ OG_DEV u32 pvq_mul(u32 a, u32 b) { return a * b; }
 #else
 OG_DEV u32 pvq_mul(u32 a, u32 b) { return __umul24(a, b); } // both below 256
 #endif
+OG_DEV int pvq_row_base(const PvqLds &T, int r) { return (int)T.rb[r < 4 ? 4 : (r > 14 ? 14 : r)]; } // (rows outside 4..14 are not table rows)
 
 #ifndef OG_SKIP_RATIO
-// A leaf's zero runs are skipped while it has more than this many dimensions per pulse left.  Measured (k_celt_recon_fb alone /
-// pipelined step): no skip 1.869 / 2.525 ms, ratio 1 (whenever n > k) 1.825 / 2.49, 2: 1.891, 3: 1.899, 4: 1.898 -- the wave's walk
-// is 34 steps long on average without, 10 with (tools/leaf_balance.py), but a step with a bisection in it costs three plain ones.
+// A leaf's zero runs are skipped while it has more than this many dimensions per pulse left.  Measured in round 2 (k_celt_recon_fb
+// alone / pipelined step): no skip 1.869 / 2.525 ms, ratio 1 (whenever n > k) 1.825 / 2.49, 2: 1.891, 3: 1.899, 4: 1.898 -- the wave's
+// walk is 34 steps long on average without, 10 with (tools/leaf_balance.py).
 #define OG_SKIP_RATIO 1
 #endif
 // `xv`: the spectrum arena of the leaf's frame (the calling wave's own working set -- or another wave's when the leaves of the
@@ -761,97 +761,84 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
     // that differ only in how they walk its triangular table; with U(a, b) available for any pair both are
     //   s = (i >= U(n, k+1));  i -= s ? U(n, k+1) : 0;  k' = max { k' <= k : U(n, k') <= i };  value = +-(k - k');  i -= U(n, k')
     // The lanes of a wave decode different leaves and the wave waits for its longest one -- a leaf of many dimensions and
-    // few pulses, so what counts is the step that decodes a zero while n > k: there U(n, k) and U(n, k + 1) sit side by side
-    // in column n, the column's base was fetched two steps ago and the two entries one step ago (on the guess that k stays),
-    // so the step is a handful of register operations.  A pulse (k changes) refetches.  Steps with n <= k take the general
-    // form below it.  The spectrum was cleared before the leaf pass: zeros are not stored.
+    // few pulses: its runs of zeros are skipped in one go (below), so a step of such a leaf places a pulse.  Steps with n <= k
+    // take the general form below it.  The spectrum was cleared before the leaf pass: zeros are not stored.
     OG_MARK(56);
-    int cb_n = T.cb[n], cb_n1 = T.cb[n - 1]; // column bases of n and n - 1
-    u32 t0 = T.cc[k >= 4 ? cb_n + k : 0], t1 = T.cc[k >= 3 ? cb_n + k + 1 : 0]; // U(n, k), U(n, k + 1) where they are table rows
+    int b0 = pvq_row_base(T, k), b1 = pvq_row_base(T, k + 1); // where rows k and k + 1 start (while they are table rows)
     while (n > 2) {
         if (k == 0) break; // every pulse is placed: what is left of the leaf stays zero
-#ifndef OG_NO_ZERO_SKIP
-        // A sparse leaf (many dimensions, few pulses) is mostly runs of zeros, and the wave waits for its longest leaf: the run is
-        // skipped in one go.  With V(a) = U(a, k) + U(a, k + 1) the dimensions n, n-1, .., a+1 all decode to zero exactly when
-        //     V(n) - V(a) <= 2 i < V(n) + V(a)          (one comparison: V(a) >= m, see below)
-        // (the zero steps subtract U(n, k), U(n-1, k), ..: their sum down to a+1 is (V(n) - V(a)) / 2 by the recurrence
-        // U(t, k+1) = U(t-1, k+1) + U(t, k) + U(t-1, k); the other bound is the one that keeps every step's sign test false);
-        // V grows with a, so the smallest such a is found by bisection over column entries that sit side by side.  Then
-        // i -= (V(n) - V(a)) / 2 and the walk goes on at dimension a -- with a pulse, unless the search range ended there.
-        // (tools/pvq_zero_run.py checks the identity against the step-by-step walk.)
-        if (k <= 13 && n > OG_SKIP_RATIO * k && n > 3) {
-            const u32 hn = (u32)n, w2 = 2u * hn - 1u, w3 = 2u * pvq_mul(hn, hn - 1u) + 1u;
-            const u32 un0 = k >= 4 ? t0 : pvq_row_sel(k, w2, w3), un1 = k >= 3 ? t1 : pvq_row_sel(k + 1, w2, w3);
-            const unsigned long long Vn = (unsigned long long)un0 + un1;
-            // both bounds in one: with d = 2 i - V(n) (in [-V(n), V(n))) the run reaches down to a + 1 exactly when
-            // V(a) >= m, m = d >= 0 ? d + 1 : -d
-            const long long d = (long long)(2ull * i) - (long long)Vn;
-            const unsigned long long m = d >= 0 ? (unsigned long long)d + 1ull : (unsigned long long)(-d);
-            const int lo0 = k + 1 > 2 ? k + 1 : 2;
-            int a;
-            unsigned long long Va;
-            if (k <= 2) { // V(a, 1) = 2 a and V(a, 2) = 2 a^2: solved, not searched (m <= V(n) <= 2 * 176^2)
-                const u32 t = (u32)((m + 1ull) >> 1);
-                int r = (int)t;
-                if (k == 2) {
-                    r = (int)__builtin_sqrtf((float)t); // within one of the root (t < 2^24 is exact as a float): its ceiling after
-                    r += (u32)(r * r) < t;              // the two corrections
-                    r -= r > 0 && (u32)((r - 1) * (r - 1)) >= t;
-                }
-                a = r > lo0 ? r : lo0;
-                Va = k == 1 ? 2ull * (u32)a : 2ull * (u32)(a * a);
-            } else {
-                int lo = lo0, hi = n;
-                Va = Vn;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1, cbm = T.cb[mid];
-                    const u32 c0 = T.cc[k >= 4 ? cbm + k : 0], c1 = T.cc[cbm + k + 1];
-                    const u32 a0 = k >= 4 ? c0 : 2u * pvq_mul((u32)mid, (u32)mid - 1u) + 1u; // (row 3 in closed form)
-                    const unsigned long long Vm = (unsigned long long)a0 + c1;
-                    if (Vm >= m) {
-                        hi = mid;
-                        Va = Vm;
-                    } else
-                        lo = mid + 1;
-                }
-                a = lo;
-            }
-            if (a < n) {
-                i -= (u32)((Vn - Va) >> 1);
-                pos += n - a;
-                n = a;
-                if (n <= 2) break;
-                cb_n = T.cb[n];
-                cb_n1 = T.cb[n - 1];
-                t0 = T.cc[k >= 4 ? cb_n + k : 0];
-                t1 = T.cc[k >= 3 ? cb_n + k + 1 : 0];
-            }
-        }
-#endif
-        const int cb_n2 = T.cb[n - 2];
-        const u32 h = (u32)n, v2 = 2u * h - 1u, v3 = 2u * pvq_mul(h, h - 1u) + 1u; // U(2, n), U(3, n)
-#if defined(OG_WALK_ABL) && OG_WALK_ABL >= 3
-        if (true) { xv[pos] = (i16)(i & 1); yy += 1; } else
-#endif
+        u32 h = (u32)n, v2 = 2u * h - 1u, v3 = 2u * pvq_mul(h, h - 1u) + 1u; // U(2, n), U(3, n)
         if (n > k) {
-            const u32 nx0 = T.cc[k >= 4 ? cb_n1 + k : 0], nx1 = T.cc[k >= 3 ? cb_n1 + k + 1 : 0]; // the next step's, if k stays
-            const u32 p0 = k >= 4 ? t0 : pvq_row_sel(k, v2, v3), p1 = k >= 3 ? t1 : pvq_row_sel(k + 1, v2, v3);
+            u32 c0 = T.rr[k >= 4 ? b0 + n : 0], c1 = T.rr[k >= 3 ? b1 + n : 0];
+            u32 p0 = k >= 4 ? c0 : pvq_row_sel(k, v2, v3), p1 = k >= 3 ? c1 : pvq_row_sel(k + 1, v2, v3); // U(k, n), U(k + 1, n)
+#ifndef OG_NO_ZERO_SKIP
+            // A sparse leaf (many dimensions, few pulses) is mostly runs of zeros, and the wave waits for its longest leaf: the run is
+            // skipped in one go.  With V(a) = U(a, k) + U(a, k + 1) the dimensions n, n-1, .., a+1 all decode to zero exactly when
+            //     V(n) - V(a) <= 2 i < V(n) + V(a)          (one comparison: V(a) >= m, see below)
+            // (the zero steps subtract U(n, k), U(n-1, k), ..: their sum down to a+1 is (V(n) - V(a)) / 2 by the recurrence
+            // U(t, k+1) = U(t-1, k+1) + U(t, k) + U(t-1, k); the other bound is the one that keeps every step's sign test false);
+            // V grows with a, so the smallest such a is found by bisection along rows k and k + 1.  Then i -= (V(n) - V(a)) / 2 and
+            // the walk goes on at dimension a -- with a pulse, unless the search range ended there.
+            // (tools/pvq_zero_run.py checks the identity against the step-by-step walk.)  Everything fits 32 bits: V(n) is the
+            // size of a legal codebook, i < V(n), and with t = V(n) - i the two bounds in one read
+            //     V(a) >= m,   m = i >= t ? i - t + 1 : t - i          (= d >= 0 ? d + 1 : -d for d = 2 i - V(n))
+            if (k <= 13 && n > OG_SKIP_RATIO * k && n > 3) {
+                const u32 Vn = p0 + p1, t = Vn - i, m = i >= t ? i - t + 1u : t - i;
+                const int lo0 = k + 1 > 2 ? k + 1 : 2;
+                int a;
+                u32 Va;
+                if (k <= 2) { // V(a, 1) = 2 a and V(a, 2) = 2 a^2: solved, not searched (m <= V(n) <= 2 * 176^2)
+                    const u32 tq = (m + 1u) >> 1;
+                    int r = (int)tq;
+                    if (k == 2) {
+                        r = (int)__builtin_sqrtf((float)tq); // within one of the root (tq < 2^24 is exact as a float): its ceiling after
+                        r += (u32)(r * r) < tq;              // the two corrections
+                        r -= r > 0 && (u32)((r - 1) * (r - 1)) >= tq;
+                    }
+                    a = r > lo0 ? r : lo0;
+                    Va = k == 1 ? 2u * (u32)a : 2u * (u32)(a * a);
+                } else {
+                    int lo = lo0, hi = n;
+                    Va = Vn;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        const u32 m0 = T.rr[k >= 4 ? b0 + mid : 0], m1 = T.rr[b1 + mid];
+                        const u32 a0 = k >= 4 ? m0 : 2u * pvq_mul((u32)mid, (u32)mid - 1u) + 1u; // (row 3 in closed form)
+                        const u32 Vm = a0 + m1;
+                        if (Vm >= m) {
+                            hi = mid;
+                            Va = Vm;
+                        } else
+                            lo = mid + 1;
+                    }
+                    a = lo;
+                }
+                if (a < n) {
+                    i -= (Vn - Va) >> 1;
+                    pos += n - a;
+                    n = a;
+                    if (n <= 2) break;
+                    h = (u32)n;
+                    v2 = 2u * h - 1u;
+                    v3 = 2u * pvq_mul(h, h - 1u) + 1u;
+                    c0 = T.rr[k >= 4 ? b0 + n : 0];
+                    c1 = T.rr[k >= 3 ? b1 + n : 0];
+                    p0 = k >= 4 ? c0 : pvq_row_sel(k, v2, v3);
+                    p1 = k >= 3 ? c1 : pvq_row_sel(k + 1, v2, v3);
+                }
+            }
+#endif
             const int s = -(int)(i >= p1);
             i -= p1 & (u32)s;
             if (p0 <= i && s == 0) {
                 i -= p0;
-                t0 = nx0;
-                t1 = nx1;
             } else {
-                // the largest k' < k with U(k', n) <= i: rows k' < k <= n of column n
+                // the largest k' < k with U(k', n) <= i: rows k' < k < n at column n
                 const int k0 = k;
                 u32 plo = 0;
                 int kk = 0;
-#if defined(OG_WALK_ABL) && OG_WALK_ABL >= 2
-                if (true) { kk = k - 1; } else
-#endif
-                if (k <= 8) { // all candidates at once (rows 1..3 computed, rows 4..7 side by side in the column)
-                    const u32 c4 = T.cc[cb_n + 4], c5 = T.cc[cb_n + 5], c6 = T.cc[cb_n + 6], c7 = T.cc[cb_n + 7];
+                if (k <= 8) { // all candidates at once (rows 1..3 computed, rows 4..7 at fixed bases)
+                    const u32 c4 = T.rr[ROM_PVQ_RB4 + n], c5 = T.rr[ROM_PVQ_RB5 + n], c6 = T.rr[ROM_PVQ_RB6 + n], c7 = T.rr[ROM_PVQ_RB7 + n];
                     const u32 cand[7] = {1u, v2, v3, c4, c5, c6, c7};
 #pragma unroll
                     for (int r = 1; r <= 7; r++) {
@@ -863,7 +850,7 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
                     int lo = 0, hi = k - 1; // U(0, n) = 0 <= i; U(k, n) > i here
                     while (lo < hi) {
                         const int mid = (lo + hi + 1) >> 1;
-                        const u32 tm = T.cc[mid >= 4 ? cb_n + mid : 0];
+                        const u32 tm = T.rr[mid >= 4 ? pvq_row_base(T, mid) + n : 0];
                         const u32 pm = mid >= 4 ? tm : pvq_row_sel(mid, v2, v3);
                         if (pm <= i) {
                             lo = mid;
@@ -878,12 +865,13 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
                 const int val = (k0 - k + s) ^ s;
                 xv[pos] = (i16)val;
                 yy += val * val;
-                t0 = T.cc[k >= 4 ? cb_n1 + k : 0];
-                t1 = T.cc[k >= 3 ? cb_n1 + k + 1 : 0];
+                b0 = pvq_row_base(T, k);
+                b1 = pvq_row_base(T, k + 1);
             }
-        } else { // n <= k: row n of columns k, k + 1 (and of the columns below them in the search)
+        } else { // n <= k: U(n, k) and U(n, k + 1) are neighbours in row n (and the search runs along that row while k' >= n)
             const u32 hk = (u32)k;
-            const u32 a0 = T.cc[n >= 4 ? T.cb[k] + n : 0], a1 = T.cc[n >= 4 ? T.cb[k + 1] + n : 0];
+            const int bn = pvq_row_base(T, n);
+            const u32 a0 = T.rr[n >= 4 ? bn + k : 0], a1 = T.rr[n >= 4 ? bn + k + 1 : 0];
             const u32 p0 = n >= 4 ? a0 : pvq_row_sel(n, 2u * hk - 1u, 2u * pvq_mul(hk, hk - 1u) + 1u);
             const u32 p1 = n >= 4 ? a1 : pvq_row_sel(n, 2u * hk + 1u, 2u * pvq_mul(hk + 1u, hk) + 1u);
             const int s = -(int)(i >= p1);
@@ -894,14 +882,11 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
                 const int k0 = k;
                 int lo = 0, hi = k - 1; // U(n, 0) = 0 <= i; U(n, k) > i here
                 u32 plo = 0;
-#if defined(OG_WALK_ABL) && OG_WALK_ABL >= 1 /* timing experiment only (wrong output) */
-                hi = lo = k - 1;
-#endif
                 while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1;
                     const int r = n < mid ? n : mid;
                     const u32 hm = (u32)mid;
-                    const u32 tm = T.cc[r >= 4 ? (n < mid ? T.cb[mid] + n : cb_n + mid) : 0];
+                    const u32 tm = T.rr[r >= 4 ? (n < mid ? bn + mid : pvq_row_base(T, mid) + n) : 0];
                     const u32 pm = r >= 4 ? tm : (n < mid ? pvq_row_sel(n, 2u * hm - 1u, 2u * pvq_mul(hm, hm - 1u) + 1u) : pvq_row_sel(mid, v2, v3));
                     if (pm <= i) {
                         lo = mid;
@@ -914,14 +899,12 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
                 const int val = (k0 - k + s) ^ s;
                 xv[pos] = (i16)val;
                 yy += val * val;
+                b0 = pvq_row_base(T, k); // (in case a later step has n > k)
+                b1 = pvq_row_base(T, k + 1);
             }
-            t0 = T.cc[k >= 4 ? cb_n1 + k : 0]; // in case the next step has n - 1 > k
-            t1 = T.cc[k >= 3 ? cb_n1 + k + 1 : 0];
         }
         pos++;
         n--;
-        cb_n = cb_n1;
-        cb_n1 = cb_n2;
     }
     {
         const u32 p = 2 * (u32)k + 1;
@@ -938,6 +921,9 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
         xv[pos] = (i16)val;
         yy += val * val;
     }
+#if defined(OG_LEAF_ABL) && OG_LEAF_ABL >= 2 /* timing experiments only (wrong output): the walk alone */
+    return 1;
+#endif
     // collapse mask from the pulses
     OG_MARK(57);
     u32 cm = 1;
@@ -956,6 +942,9 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
     const i32 g = tr16(mul16_p15(rsqrt_norm(t), gain));
     for (int j = 0; j < N; j++) xv[x + j] = (i16)pshr32(mul16(g, xv[x + j]), kk + 1);
     OG_MARK(59);
+#if defined(OG_LEAF_ABL) && OG_LEAF_ABL >= 1 /* ... without the rotation */
+    return cm;
+#endif
     if (2 * K < N && spread != 0) {
         const int factor = spread == 1 ? 15 : (spread == 2 ? 10 : 5);
         const i32 rg = tr16(mul32_q31(mul16(32767, N), celt_rcp(N + factor * K))); // celt_div celt.h:367

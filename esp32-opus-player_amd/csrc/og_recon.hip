@@ -73,8 +73,8 @@ OG_DEV void leaf_pass_pooled(const ParseRec *rec, int n_leaves, int spread) {
     const int tid = (int)threadIdx.x, lane = OG_LANE, wave = OG_WAVE;
     { // the one PVQ table, loaded by everybody
         PvqLds &T = pvq_shared();
-        for (int t = tid; t < ROM_PVQ_CC_LEN; t += 64 * RG) T.cc[t] = rom_pvq_cc[t];
-        for (int t = tid; t < 177; t += 64 * RG) T.cb[t] = rom_pvq_cb[t];
+        for (int t = tid; t < ROM_PVQ_RR_LEN; t += 64 * RG) T.rr[t] = rom_pvq_rr[t];
+        if (tid < 16) T.rb[tid] = rom_pvq_rb[tid];
     }
     if (lane == 0) pool_nl()[wave] = (u32)n_leaves;
     __syncthreads();

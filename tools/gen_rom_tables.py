@@ -68,23 +68,27 @@ def pvq_u_table(rows=15, cols=177):
             U[n][k] = U[n - 1][k] + U[n][k - 1] + U[n - 1][k - 1]
     return [U[n][k] & 0xFFFFFFFF for n in range(rows) for k in range(cols)]
 
-def pvq_u_columns():
-    """U(lo, hi) for lo = 4 .. 14 stored by COLUMN hi (lo <= hi <= 176; entries that fit 32 bits), columns back to back behind
-    4 unused words: entry (lo, hi) is at CB[hi] + lo.  A walk that keeps one of its arguments fixed for a step (cwrsi: the
-    dimension n) then needs one base per step, known a step ahead, and finds all its candidates next to each other.
-    Rows 0..3 have closed forms (0 / 1 / 2h-1 / 2h(h-1)+1).  Returns (table, CB[0..176])."""
+def pvq_u_rows():
+    """U(lo, hi) for lo = 4 .. 14 stored by ROW lo (columns hi = lo .. the last one whose entry fits 32 bits), rows back to back
+    behind 4 unused words: entry (lo, hi) is at RB[lo] + hi.  What the leaf walk of the split path searches at a fixed number of
+    pulses k -- the next pulse's dimension -- lies along rows k and k + 1, so a probe is two independent reads off two bases
+    that only change when k does; the candidates of a pulse's size (rows 4 .. 7 at one column) need no base look-up at all.
+    Rows 0..3 have closed forms (0 / 1 / 2h-1 / 2h(h-1)+1).  Returns (table, RB[0..15])."""
     cols = 177
     U = [[0] * cols for _ in range(cols)]
     U[0][0] = 1
     for n in range(1, cols):
         for k in range(1, cols):
             U[n][k] = U[n - 1][k] + U[n][k - 1] + U[n - 1][k - 1]
-    tab, cb = [0, 0, 0, 0], [0] * cols
-    for hi in range(4, cols):
-        cb[hi] = len(tab) - 4
-        tab += [U[lo][hi] for lo in range(4, min(14, hi) + 1) if U[lo][hi] < 2 ** 32]
-    assert max(cb) < 65536
-    return tab, cb
+    tab, rb = [0, 0, 0, 0], [0] * 16
+    for lo in range(4, 15):
+        rb[lo] = len(tab) - lo
+        tab += [U[lo][hi] for hi in range(lo, cols) if U[lo][hi] < 2 ** 32]
+    for lo in range(4):
+        rb[lo] = rb[4]
+    rb[15] = rb[14]
+    assert min(rb) >= 0 and max(rb) < 65536
+    return tab, rb
 
 def pulse_v_table():
     """V(N, K) = U(N, K) + U(N, K + 1), the size of the PVQ codebook a leaf's index is decoded against (celt.cpp:2622,
@@ -291,10 +295,11 @@ def build_text():
             u192.append(u[r * 177 + c] if (r < 15 and c < 177) else 0)
     t += emit("rom_pvq_u192", "uint32_t", u192, 8)
     # rows 4..14 by column for an LDS copy (the split path's leaf pass)
-    uc, cb = pvq_u_columns()
-    t += "#define ROM_PVQ_CC_LEN %d\n" % len(uc)
-    t += emit("rom_pvq_cc", "uint32_t", uc, 8)
-    t += emit("rom_pvq_cb", "uint16_t", cb, 16)
+    ur, rb = pvq_u_rows()
+    t += "#define ROM_PVQ_RR_LEN %d\n" % len(ur)
+    t += "".join("#define ROM_PVQ_RB%d %d\n" % (r, rb[r]) for r in range(4, 15))
+    t += emit("rom_pvq_rr", "uint32_t", ur, 8)
+    t += emit("rom_pvq_rb", "uint16_t", rb, 16)
     t += emit("rom_band_alloc", "uint8_t", BAND_ALLOC, 21)
     t += emit("rom_eband", "int16_t", EBAND, 22)
     t += emit("rom_logn", "int16_t", LOGN, 21)
