@@ -394,8 +394,11 @@ __global__ void __launch_bounds__(64 * OG_PL_WAVES, 2) k_celt_parse(const FrameD
 // Split CELT path, second half: one frame per wave, driven by the parse record.
 // (20 ms CELT-only frames are reconstructed by k_celt_recon_fb, og_recon.hip; `rest_only`: skip what that kernel took)
 extern "C" void og_launch_celt_recon_fb(hipStream_t s, const void *descs, void *streams, const void *recs, void *rout, int n,
-                                        int n_streams, int hybrid, unsigned *started);
+                                        int n_streams, int hybrid, unsigned *started, const void *leaves);
 extern "C" int og_celt_recon_fb_signals(int n); // how often a launch over n frames bumps `started`
+// The PVQ leaves of those frames, one leaf per lane across frames in order of cost (og_leaves.hip), ahead of the kernel above
+extern "C" void og_launch_celt_leaves(hipStream_t s, const void *descs, const void *recs, void *leaf_out, int n, int n_streams, int hybrid);
+extern "C" size_t og_leaf_out_bytes(void);
 // RFC mode (opt-in): every frame of a step, at its true duration, incl. the loss path (og_rfc.hip)
 extern "C" void og_launch_decode_rfc(hipStream_t s, const void *descs, const void *arena, void *streams, void *pcm, void *result, int n,
                                      int n_streams, int pcm_stride);
@@ -594,8 +597,9 @@ struct opusgpu_ctx {
     hipEvent_t ev_part[OPUSGPU_COPY_PIECES] = {};
     int host_parts = 2; // OPUSGPU_HOST_PARTS=1: one batch, copy after the kernels (A/B measurements); 2, 4, 8, 16
     // parse records of the split CELT path (one per frame of a step), grown on demand
-    void *d_recs[3] = {}, *d_rout[3] = {}, *d_handoff = nullptr, *d_srecs = nullptr; // (three sets: pipelined steps rotate)
-    size_t cap_recs[3] = {}, cap_rout[3] = {}, cap_handoff = 0, cap_srecs = 0;
+    void *d_recs[3] = {}, *d_rout[3] = {}, *d_leaf[3] = {}, *d_handoff = nullptr, *d_srecs = nullptr; // (three sets: pipelined steps rotate)
+    size_t cap_recs[3] = {}, cap_rout[3] = {}, cap_leaf[3] = {}, cap_handoff = 0, cap_srecs = 0;
+    int leaf_kernel = 0; // OPUSGPU_LEAF_KERNEL=1: k_celt_leaves decodes the PVQ leaves ahead of the reconstruction (og_leaves.hip; measured slower)
     int split_celt = 1;   // OPUSGPU_SPLIT=0 forces the single-kernel path for every mode (A/B measurements)
     int split_hybrid = 1; // OPUSGPU_SPLIT_HYBRID=0 keeps SILK-only and hybrid frames entirely on the single-kernel path
     int fast_recon = 1;   // OPUSGPU_FAST_RECON=0: every CELT frame through the general reconstruction kernel (A/B measurements)
@@ -677,6 +681,7 @@ int opusgpu_ctx_create(int device, opusgpu_ctx **out) {
     ctx->split_celt = og_debug().split; // (og_debug.hpp: A/B switches, read from the environment once per process)
     ctx->split_hybrid = og_debug().split_hybrid;
     ctx->fast_recon = og_debug().fast_recon;
+    ctx->leaf_kernel = og_debug().leaf_kernel;
     ctx->parse_groups = og_debug().parse_groups;
     ctx->host_parts = og_debug().host_parts;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -701,6 +706,7 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     for (int i = 0; i < 3; i++) {
         (void)hipFree(ctx->d_recs[i]);
         (void)hipFree(ctx->d_rout[i]);
+        (void)hipFree(ctx->d_leaf[i]);
         if (ctx->ev_post[i]) (void)hipEventDestroy(ctx->ev_post[i]);
     }
     (void)hipFree(ctx->d_handoff);
@@ -909,6 +915,9 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         if (ctx->cap_rout[par] < sizeof(ReconOut) * (size_t)n &&
             (rc = grow(ctx, &ctx->d_rout[par], &ctx->cap_rout[par], sizeof(ReconOut) * (size_t)n)))
             return rc;
+        if (ctx->fast_recon && ctx->leaf_kernel && any_celt && ctx->cap_leaf[par] < og_leaf_out_bytes() * (size_t)n &&
+            (rc = grow(ctx, &ctx->d_leaf[par], &ctx->cap_leaf[par], og_leaf_out_bytes() * (size_t)n)))
+            return rc;
         if (ctx->split_hybrid && any_silk) {
             if (ctx->cap_handoff < sizeof(SilkHandoff) * (size_t)n &&
                 (rc = grow(ctx, &ctx->d_handoff, &ctx->cap_handoff, sizeof(SilkHandoff) * (size_t)n)))
@@ -1022,7 +1031,10 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         // reconstruct (one frame per wave) ...
         if (ctx->fast_recon) {
             if (pipe) launch_jitter();
-            og_launch_celt_recon_fb(back, d_descs, ctx->d_streams, recs, rout, n, ctx->n_streams, handoff ? 1 : 0, pipe ? ctx->d_started + 16 : nullptr);
+            void *const leaves = ctx->leaf_kernel ? ctx->d_leaf[par] : nullptr;
+            if (leaves) og_launch_celt_leaves(back, d_descs, recs, leaves, n, ctx->n_streams, handoff ? 1 : 0);
+            og_launch_celt_recon_fb(back, d_descs, ctx->d_streams, recs, rout, n, ctx->n_streams, handoff ? 1 : 0, pipe ? ctx->d_started + 16 : nullptr,
+                                    leaves);
             if (pipe) ctx->recon_started_total += (u32)og_celt_recon_fb_signals(n);
         }
         hipLaunchKernelGGL(k_celt_recon, dim3(ctx->fast_recon ? (n + 63) / 64 : n), dim3(64), 0, back, (const FrameDesc *)d_descs,

@@ -79,7 +79,8 @@ struct ParseRec {
     i32 intensity, pf_pitch, pf_gain, pf_tapset, start;
     i32 n_leaves, n_words;
     u32 need_norm; // bands whose folding history is read by a later band
-    i32 reserved[5];
+    i32 n_coef;    // coefficients in PVQ leaves (the sum of their N): how much the leaf kernel writes for this frame (LeafOut)
+    i32 reserved[4];
     i16 bandE[2 * NBANDS]; // final band energies (coarse + fine + finalise)
     i16 pulses[NBANDS];
     u16 band_w[NBANDS];    // where each band's four header words start in words[] (its job words follow them)
@@ -87,10 +88,21 @@ struct ParseRec {
     i8 pad[256 - 64 - 4 * NBANDS - 2 * NBANDS - 2 * NBANDS - NBANDS];
     u32 leaf_idx[REC_MAX_LEAVES];  // PVQ codeword index
     u32 leaf_geom[REC_MAX_LEAVES]; // x | N << 11 | K << 19 | (B - 1) << 27   (x: offset into S.v[V_X..])
-    u32 leaf_aux[REC_MAX_LEAVES];  // gain (product of the split gains above the leaf, Q15) | mask offset << 16
+    u32 leaf_aux[REC_MAX_LEAVES];  // gain (product of the split gains above the leaf, Q15) | mask offset << 16 (4 bits) | where the
+                                   // leaf's coefficients start in the frame's packed leaf output (sum of N before it) << 20
     u32 words[(REC_MAX_WORDS + 64) / 64 * 64]; // read in windows of 64 (REC_WORDS_CAP)
 };
 static_assert(sizeof(ParseRec) % 16 == 0, "record alignment");
+
+// What the leaf kernel (og_leaves.hip) leaves for the reconstruction kernel of 20 ms frames, per frame: the coefficients of the
+// frame's PVQ leaves packed in leaf order (leaf t at leaf_aux[t] >> 20, N entries: scaled, rotation undone) and the leaves'
+// collapse masks, shifted to their place in the job's mask.
+constexpr int FAST_MAX_LEAVES = 416; // (og_state.hpp: the most a 20 ms frame can have)
+struct LeafOut {
+    alignas(16) i16 coef[1600 + 8]; // (a stereo frame codes 2 x 800 coefficients; the reader fetches in groups of 8)
+    u16 mask[FAST_MAX_LEAVES];
+};
+static_assert(sizeof(LeafOut) % 16 == 0, "leaf output alignment");
 
 // =====================================================================================================
 //  parse: one frame per lane
@@ -201,7 +213,7 @@ OG_DEV u32 pvq_u_rom(int a, int b) { // U(a,b) from the ROM table (lane-private 
 
 struct RecWriter {
     ParseRec *rec;
-    int nw, nl;
+    int nw, nl, ncoef = 0;
     OG_MEMBER void word(u32 w) {
         if (nw < REC_MAX_WORDS) rec->words[nw] = w;
         nw++;
@@ -214,9 +226,10 @@ struct RecWriter {
         if (nl < REC_MAX_LEAVES) {
             rec->leaf_idx[nl] = idx;
             rec->leaf_geom[nl] = (u32)x | (u32)N << 11 | (u32)K << 19 | (u32)(B - 1) << 27;
-            rec->leaf_aux[nl] = (u32)(gain & 0xffff) | (u32)off << 16;
+            rec->leaf_aux[nl] = (u32)(gain & 0xffff) | (u32)off << 16 | (u32)ncoef << 20;
         }
         nl++;
+        ncoef += N;
     }
 };
 
@@ -564,6 +577,7 @@ OG_DEV void celt_parse_lane(StreamState *st, const u8 *payload, int len, int ch,
     rec->pf_gain = h.pf_gain;
     rec->pf_tapset = h.pf_tapset;
     rec->n_leaves = OG_MIN(out.nl, REC_MAX_LEAVES);
+    rec->n_coef = out.ncoef;
     rec->n_words = OG_MIN(out.nw, REC_MAX_WORDS);
     // the energies the next frame predicts from, as celt_synthesis leaves them (celt.cpp:2404-2436): -28 dB in a silent frame,
     // a mono frame's in both channels, zero outside start .. end.  Two bands per store.
@@ -1814,7 +1828,6 @@ OG_DEV void recon_all_bands_pm(const ParseRec *rec, const LcgTab &lcg, int C, in
 // Which reconstruction kernel takes a frame: 20 ms frames whose record is complete -- CELT-only ones and the CELT half of
 // hybrid ones (bands 17 - 20) -- go to the kernel with the 8 KB working set (og_recon.hip, phase-major band loop only),
 // everything else -- the 2.5 ms transition frame, records that overflowed -- to the general one.
-constexpr int FAST_MAX_LEAVES = 416; // (og_state.hpp: the most a 20 ms frame can have)
 enum { RECON_ALL = 0, RECON_FAST_ONLY = 1, RECON_REST_ONLY = 2, RECON_NOT_MINE = -1000 };
 // What a reconstruction kernel reports per frame, read by the de-emphasis kernel (k_celt_post), which passes `ret` on to the
 // caller's result array: the frame's result code and where in the stream's history ring its first sample went.  (The ring
@@ -1831,7 +1844,7 @@ struct ReconOut {
 struct ReconHdr {
     i32 ret;
     u32 rng_final, flags;
-    i32 pf_pitch, pf_gain, pf_tapset, start, n_leaves, n_words;
+    i32 pf_pitch, pf_gain, pf_tapset, start, n_leaves, n_words, n_coef;
     u32 need_norm;
     i32 channels, prev_mode, frames_decoded;
     u32 rng;
@@ -1841,7 +1854,7 @@ OG_DEV void recon_hdr_load(const StreamState *st, const ParseRec *rec, ReconHdr 
     h.ret = OG_UNI(rec->ret); h.rng_final = (u32)OG_UNI(rec->rng_final); h.flags = (u32)OG_UNI(rec->flags);
     h.pf_pitch = OG_UNI(rec->pf_pitch); h.pf_gain = OG_UNI(rec->pf_gain); h.pf_tapset = OG_UNI(rec->pf_tapset);
     h.start = OG_UNI(rec->start); h.n_leaves = OG_UNI(rec->n_leaves); h.n_words = OG_UNI(rec->n_words);
-    h.need_norm = (u32)OG_UNI(rec->need_norm);
+    h.need_norm = (u32)OG_UNI(rec->need_norm); h.n_coef = OG_UNI(rec->n_coef);
     h.channels = OG_UNI(st->channels); h.prev_mode = OG_UNI(st->prev_mode); h.frames_decoded = OG_UNI(st->frames_decoded);
     const CeltState *cs = &st->celt;
     h.rng = (u32)OG_UNI(cs->rng); h.ring_pos = OG_UNI(cs->ring_pos);
@@ -1854,7 +1867,8 @@ OG_DEV void recon_hdr_load(const StreamState *st, const ParseRec *rec, ReconHdr 
 // 20-31 the twelve words of CeltState from `deemph` on; then lane reads.  (Layout asserted below.)
 static_assert(offsetof(ParseRec, ret) == 0 && offsetof(ParseRec, rng_final) == 4 && offsetof(ParseRec, flags) == 8 && offsetof(ParseRec, pf_pitch) == 16 &&
               offsetof(ParseRec, pf_gain) == 20 && offsetof(ParseRec, pf_tapset) == 24 && offsetof(ParseRec, start) == 28 &&
-              offsetof(ParseRec, n_leaves) == 32 && offsetof(ParseRec, n_words) == 36 && offsetof(ParseRec, need_norm) == 40, "record header words");
+              offsetof(ParseRec, n_leaves) == 32 && offsetof(ParseRec, n_words) == 36 && offsetof(ParseRec, need_norm) == 40 &&
+              offsetof(ParseRec, n_coef) == 44, "record header words");
 static_assert(offsetof(StreamState, channels) == 0 && offsetof(StreamState, prev_mode) == 4, "stream header words");
 static_assert(offsetof(CeltState, rng) == offsetof(CeltState, deemph) + 8 && offsetof(CeltState, ring_pos) == offsetof(CeltState, deemph) + 12 &&
               offsetof(CeltState, pf_period) == offsetof(CeltState, deemph) + 16 && offsetof(CeltState, pf_tapset_old) == offsetof(CeltState, deemph) + 36,
@@ -1869,7 +1883,7 @@ OG_DEV i32 recon_hdr_fetch(const StreamState *st, const ParseRec *rec) { // the 
 OG_DEV void recon_hdr_unpack(i32 w, ReconHdr &h) {
 #define OG_HW(lane) __builtin_amdgcn_readlane(w, lane)
     h.ret = OG_HW(0); h.rng_final = (u32)OG_HW(1); h.flags = (u32)OG_HW(2); h.pf_pitch = OG_HW(4); h.pf_gain = OG_HW(5); h.pf_tapset = OG_HW(6);
-    h.start = OG_HW(7); h.n_leaves = OG_HW(8); h.n_words = OG_HW(9); h.need_norm = (u32)OG_HW(10);
+    h.start = OG_HW(7); h.n_leaves = OG_HW(8); h.n_words = OG_HW(9); h.need_norm = (u32)OG_HW(10); h.n_coef = OG_HW(11);
     h.channels = OG_HW(16); h.prev_mode = OG_HW(17); h.frames_decoded = OG_HW(18);
     h.rng = (u32)OG_HW(22); h.ring_pos = OG_HW(23); h.st_pf_period = OG_HW(24); h.st_pf_period_old = OG_HW(25); h.st_pf_gain = OG_HW(26);
     h.st_pf_gain_old = OG_HW(27); h.st_pf_tapset = OG_HW(28); h.st_pf_tapset_old = OG_HW(29);
@@ -1976,10 +1990,37 @@ OG_DEV void recon_leaves_own(const ParseRec *rec, const ReconCtx &rx, bool pre =
         const u32 idx = first ? idx0 : rec->leaf_idx[t];
         leaf_masks()[t] = (u16)(pvq_leaf_lane(S.v, pvq_lds(), (int)(g >> 11) & 255, (int)(g >> 19) & 255, idx, V_X + (int)(g & 2047),
                                               (int)(g >> 27) + 1, (i32)(aux & 0xffff), spread)
-                                << (aux >> 16));
+                                << ((aux >> 16) & 15));
     }
     OG_SYNC();
 }
+
+// ... or fetched: the leaf kernel decoded them (og_leaves.hip).  The frame's packed coefficients come in with 16-byte loads through
+// the rows behind the spectrum (free until the band loop's tables are made), then every leaf's lane copies its N to their place;
+// the masks are a coalesced copy.  `g0`, `aux0`: leaf `lane`'s geometry and aux words, fetched by the caller already.
+#if defined(OG_RECON_TIGHT) && !defined(OG_HOST_EMUL)
+OG_DEV void recon_leaves_fetch(const ParseRec *rec, const ReconCtx &rx, const LeafOut *lo, u32 g0, u32 aux0) {
+    const int n_leaves = rx.h.n_leaves, n_coef = rx.h.n_coef;
+    constexpr int CH = (V_MASK - V_NORM) / 8 * 8; // coefficients per chunk (1376: one chunk unless the frame has > 1376 in leaves)
+    i16 *const stage = &S.v[V_NORM];
+    OG_MARK(2);
+    OG_FOR_LANES(t, n_leaves) leaf_masks()[t] = lo->mask[t];
+    for (int c0 = 0; c0 < n_coef; c0 += CH) {
+        const int len = OG_MIN(CH, n_coef - c0);
+        OG_SYNC();
+        for (int j = 8 * OG_LANE; j < len; j += 8 * OG_NLANES)
+            *reinterpret_cast<og_v4i *>(&stage[j]) = *reinterpret_cast<const og_v4i *>(&lo->coef[c0 + j]);
+        OG_SYNC();
+        OG_FOR_LANES(t, n_leaves) {
+            const u32 g = t < OG_NLANES ? g0 : rec->leaf_geom[t], aux = t < OG_NLANES ? aux0 : rec->leaf_aux[t];
+            const int x = V_X + (int)(g & 2047), N = (int)(g >> 11) & 255, a = (int)(aux >> 20) - c0;
+            const int j0 = OG_MAX(0, -a), j1 = OG_MIN(N, len - a); // the part of the leaf this chunk holds
+            for (int j = j0; j < j1; j++) S.v[x + j] = stage[a + j];
+        }
+    }
+    OG_SYNC();
+}
+#endif
 
 OG_DEV int recon_finish(StreamState *st, const ParseRec *rec, const ReconCtx &rx) {
     const u32 flags = rx.flags;

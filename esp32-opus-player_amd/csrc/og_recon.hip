@@ -121,7 +121,7 @@ OG_DEV void leaf_pass_pooled(const ParseRec *rec, int n_leaves, int spread) {
             const int meta = pool_meta()[tid], fr = meta & 3, leaf = (meta >> 2) & 511;
             const u32 cm = pvq_leaf_lane(Sx[fr].v, pvq_shared(), (int)(pg >> 11) & 255, (int)(pg >> 19) & 255, pool_idx()[tid], V_X + (int)(pg & 2047),
                                          (int)(pg >> 27) + 1, (i32)(aux & 0xffff), meta >> 11);
-            Sx[fr].leaf_mask_row()[leaf] = (u16)(cm << (aux >> 16));
+            Sx[fr].leaf_mask_row()[leaf] = (u16)(cm << ((aux >> 16) & 15));
         }
         __syncthreads();
     }
@@ -132,7 +132,8 @@ OG_DEV void leaf_pass_pooled(const ParseRec *rec, int n_leaves, int spread) {
 // kernel then also takes their CELT half
 __global__ void __launch_bounds__(64 * RG, OG_FAST_WAVES) k_celt_recon_fb(const FrameDesc *__restrict__ descs, StreamState *st,
                                                                            const ParseRec *recs, ReconOut *rout, int n, int n_streams,
-                                                                           int hybrid, u32 *started) {
+                                                                           int hybrid, u32 *started, const LeafOut *leaves) {
+    // `leaves`: what k_celt_leaves (og_leaves.hip) decoded of this step's frames -- null: the frame's own wave decodes its leaves
     // `started` (steps queued as a window, opusgpu_decode_steps_device): every 64th workgroup counts itself in when it starts --
     // the de-emphasis of the step before is held until the first round of this launch has its places
     if (started && threadIdx.x == 0 && (blockIdx.x & 63) == 0) __hip_atomic_fetch_add(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -183,12 +184,16 @@ __global__ void __launch_bounds__(64 * RG, OG_FAST_WAVES) k_celt_recon_fb(const 
 #endif
 #else
     if (mine && rx.leaves) {
-        pvq_tab_load();
-        OG_SYNC();
+        if (leaves)
+            recon_leaves_fetch(rec, rx, &leaves[f], lg, la);
+        else {
+            pvq_tab_load();
+            OG_SYNC();
 #if defined(OG_RABL) && OG_RABL == 1
-        return;
+            return;
 #endif
-        recon_leaves_own(rec, rx, true, lg, la, li);
+            recon_leaves_own(rec, rx, true, lg, la, li);
+        }
     }
 #endif
     if (mine) {
@@ -199,9 +204,9 @@ __global__ void __launch_bounds__(64 * RG, OG_FAST_WAVES) k_celt_recon_fb(const 
 }
 
 extern "C" void og_launch_celt_recon_fb(hipStream_t s, const void *descs, void *streams, const void *recs, void *rout, int n,
-                                        int n_streams, int hybrid, unsigned *started) {
+                                        int n_streams, int hybrid, unsigned *started, const void *leaves) {
     hipLaunchKernelGGL(k_celt_recon_fb, dim3((n + RG - 1) / RG), dim3(64 * RG), 0, s, (const FrameDesc *)descs, (StreamState *)streams,
-                       (const ParseRec *)recs, (ReconOut *)rout, n, n_streams, hybrid, started);
+                       (const ParseRec *)recs, (ReconOut *)rout, n, n_streams, hybrid, started, (const LeafOut *)leaves);
 }
 extern "C" int og_celt_recon_fb_signals(int n) { return ((n + RG - 1) / RG + 63) / 64; }
 
