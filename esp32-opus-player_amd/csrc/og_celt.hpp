@@ -679,6 +679,39 @@ OG_DEV void imdct_long_front(i32 *SYF, const i16 *xs) {
         }
     }
 }
+// The long block's post-rotation (pairs (i, 479 - i), celt.cpp:3252-3284), TDAC mirror (:3286-3296) and the saturation of the
+// 960 output samples (celt_synthesis celt.cpp:2121) in two passes instead of three: a value is clamped where it is last written.
+// Post-rotation pair i writes words 60 + 2 i, 61 + 2 i, 1018 - 2 i, 1019 - 2 i of SY: for i >= 30 all four are output samples
+// (120 .. 959) and final; for i < 30 the first two (60 .. 119) are still the TDAC's input and the last two (960 .. 1019) are
+// the overlap tail the next frame starts from -- neither is saturated (the generic code saturates SY[0 .. 960) in a pass of its
+// own).  The TDAC writes words 0 .. 119: final.  Twiddles: trig[i] | trig[480 + i] packed (rom_prerot480).
+OG_DEV void imdct_long_back(i32 *SY) {
+    i32 *const F = &SY[OVERLAP >> 1];
+    OG_SYNC();
+    for (int i = OG_LANE; i < 240; i += OG_NLANES) {
+        i32 *yp0 = &F[2 * i], *yp1 = &F[958 - 2 * i];
+        const og_v2i a = *reinterpret_cast<const og_v2i *>(yp0), b = *reinterpret_cast<const og_v2i *>(yp1);
+        const u32 ta = rom_prerot480[i], tb = rom_prerot480[479 - i];
+        const i32 t0 = (i32)(i16)(ta & 0xffff), t1 = (i32)ta >> 16, u0 = (i32)(i16)(tb & 0xffff), u1 = (i32)tb >> 16;
+        // (re, im) = (word 1, word 0) of a point
+        i32 yr = addw(mul16x32_q15(t0, a.y), mul16x32_q15(t1, a.x)), yi = subw(mul16x32_q15(t1, a.y), mul16x32_q15(t0, a.x));
+        i32 zr = addw(mul16x32_q15(u0, b.y), mul16x32_q15(u1, b.x)), zi = subw(mul16x32_q15(u1, b.y), mul16x32_q15(u0, b.x));
+        if (i >= 30) {
+            yr = clampsym(yr, SIG_SAT); yi = clampsym(yi, SIG_SAT); zr = clampsym(zr, SIG_SAT); zi = clampsym(zi, SIG_SAT);
+        }
+        *reinterpret_cast<og_v2i *>(yp0) = og_v2i{yr, zi}; // yp0[0] = yr, yp0[1] = second rotation's yi
+        *reinterpret_cast<og_v2i *>(yp1) = og_v2i{zr, yi}; // yp1[0] = second rotation's yr, yp1[1] = yi
+    }
+    OG_SYNC();
+    if (OG_LANE < OVERLAP / 2) { // TDAC mirror
+        const int i = OG_LANE;
+        const i32 x1 = SY[OVERLAP - 1 - i], x2 = SY[i];
+        const i32 w1 = rom_win120[i], w2 = rom_win120[OVERLAP - 1 - i];
+        SY[i] = clampsym(subw(mul16x32_q15(w2, x2), mul16x32_q15(w1, x1)), SIG_SAT);
+        SY[OVERLAP - 1 - i] = clampsym(addw(mul16x32_q15(w1, x2), mul16x32_q15(w2, x1)), SIG_SAT);
+    }
+    OG_SYNC();
+}
 #endif
 
 // Inverse MDCT of every block of one output channel (clt_mdct_backward celt.cpp:3204), reading
@@ -708,9 +741,20 @@ OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int sh
             if (OG_LANE < OVERLAP / 2) SY[OG_LANE] = tail_l;
             fft_stage(&SY[OVERLAP >> 1], 1, NBk, 3, 32, 5, 96, 5);
             fft_stage(&SY[OVERLAP >> 1], 1, NBk, 5, 96, 1, 1, 1);
+            imdct_long_back(SY);
+            return;
         } else {
 #endif
 #ifdef OG_RECON_TIGHT
+#if !defined(OG_HOST_EMUL) && !defined(OG_NO_LONG_FAST)
+        // (short blocks: the coefficient's gain from the per-bin table of denorm_bins -- one look-up instead of three -- unless
+        // this is a down-mix, which reads two spectra with two sets of gains)
+        const bool bins = !(CC == 1 && C == 2);
+        const i16 *const xsrc = &S.v[V_X + ((CC == 2 && C == 1) ? 0 : co) * N];
+#define OG_FREQ(j) (bins ? denorm_coef(xsrc[(j)], binpar_row()[(j) >> 3]) : freq_out(co, (j), N, LM, C, CC))
+#else
+#define OG_FREQ(j) freq_out(co, (j), N, LM, C, CC)
+#endif
         // The buffer starts inside X, over the second channel's spectrum (og_state.hpp).  A channel that reads that spectrum
         // has every coefficient read, and rotated, before the first word of the buffer is written: 480 rotations, 8 per lane,
         // held in registers across the barrier.  The other channel (synthesised second) reads what the buffer does not touch.
@@ -718,8 +762,8 @@ OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int sh
         if (!reads_buffer) {
             for (int b = 0; b < B; b++) // (a loop per block: splitting one index by N4 costs a software division per element)
             OG_FOR_LANES(i, N4) {
-                i32 x1 = freq_out(co, b + B * (2 * i), N, LM, C, CC);
-                i32 x2 = freq_out(co, b + B * (N2 - 1 - 2 * i), N, LM, C, CC);
+                i32 x1 = OG_FREQ(b + B * (2 * i));
+                i32 x2 = OG_FREQ(b + B * (N2 - 1 - 2 * i));
                 i32 t0 = trig[i], t1 = trig[N4 + i];
                 i32 yr = addw(OG_SMUL(x2, t0), OG_SMUL(x1, t1));
                 i32 yi = subw(OG_SMUL(x1, t0), OG_SMUL(x2, t1));
@@ -741,8 +785,8 @@ OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int sh
             const int b = ppb == 1 ? it : it / ppb, i = OG_LANE + (it - b * ppb) * OG_NLANES;
             hr[it] = hi[it] = 0;
             if (i < N4 && b < B) {
-                i32 x1 = freq_out(co, b + B * (2 * i), N, LM, C, CC);
-                i32 x2 = freq_out(co, b + B * (N2 - 1 - 2 * i), N, LM, C, CC);
+                i32 x1 = OG_FREQ(b + B * (2 * i));
+                i32 x2 = OG_FREQ(b + B * (N2 - 1 - 2 * i));
                 i32 t0 = trig[i], t1 = trig[N4 + i];
                 hr[it] = addw(OG_SMUL(x2, t0), OG_SMUL(x1, t1));
                 hi[it] = subw(OG_SMUL(x1, t0), OG_SMUL(x2, t1));
@@ -761,6 +805,7 @@ OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int sh
         }
         OG_FOR_LANES(i, OVERLAP / 2) SY[i] = tail[i];
         }
+#undef OG_FREQ
 #else
         OG_FOR_LANES(i, OVERLAP / 2) SY[i] = tail[i];
         for (int b = 0; b < B; b++) // pre-rotation into digit-reversed order (a loop per block: no index to divide)
@@ -1256,7 +1301,7 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
         OG_MARK(14);
 #if defined(OG_RECON_TIGHT) && !defined(OG_HOST_EMUL)
 #ifndef OG_NO_LONG_FAST
-        if (B == 1 && !(CC == 1 && C == 2)) denorm_bins((CC == 2 && C == 1) ? 0 : c); // (from denorm_gains' rows)
+        if (!(CC == 1 && C == 2)) denorm_bins((CC == 2 && C == 1) ? 0 : c); // (from denorm_gains' rows)
 #endif
 #endif
         imdct_channel(st->tail[c], c, N, LM, B, shift, C, CC);
