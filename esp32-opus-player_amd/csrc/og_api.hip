@@ -359,6 +359,9 @@ __global__ void __launch_bounds__(64 * OG_PL_WAVES, 2) k_celt_parse(const FrameD
     // `started` (steps queued as a window, opusgpu_decode_steps_device): every workgroup counts itself in when it starts -- the
     // reconstruction of the step before is held (a stream memory wait) until this launch's workgroups have their places
     if (started && threadIdx.x == 0) __hip_atomic_fetch_add(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef OG_PARSE_PRIO
+    __builtin_amdgcn_s_setprio(OG_PARSE_PRIO);
+#endif
     const bool lane_on = (int)(threadIdx.x & 63) < OG_PL_LANES;
     const int f0 = (int)blockIdx.x * groups * OG_PL_FRAMES + OG_PWAVE * OG_PL_LANES + OG_PCOL;
     if (which != PARSE_ALL) { // a launch that finds none of its frames among the workgroup's leaves without loading the tables
@@ -608,6 +611,8 @@ struct opusgpu_ctx {
     // and its reconstruction on recon_stream; parse records and the reconstruction's per-frame output (d_recs, d_rout) rotate
     int pipeline = 0, slot = 0, front_recorded = 0, post_recorded[3] = {};
     hipStream_t parse_stream = nullptr, recon_stream = nullptr, last_step_stream = nullptr;
+    hipStream_t side_stream = nullptr;                // in-order steps with SILK frames: the second half's chain (decode_step_impl)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_front = nullptr;  // step k: its front kernels have finished (on the step's stream)
     hipEvent_t ev_parsed = nullptr; // step k: its early parse has finished (on parse_stream)
     hipEvent_t ev_recon = nullptr;  // step k: its reconstruction has finished (on recon_stream)
@@ -719,6 +724,14 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_part)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->side_stream) {
+        (void)hipStreamSynchronize(ctx->side_stream);
+        (void)hipStreamDestroy(ctx->side_stream);
+    }
+    if (ctx->ev_fork) {
+        (void)hipEventDestroy(ctx->ev_fork);
+        (void)hipEventDestroy(ctx->ev_join);
+    }
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->parse_stream) (void)hipStreamDestroy(ctx->parse_stream);
     if (ctx->recon_stream) (void)hipStreamDestroy(ctx->recon_stream);
@@ -854,6 +867,9 @@ int opusgpu_memcpy_d2h(opusgpu_ctx *ctx, void *dst, const void *src, size_t byte
 // such a step does not run ahead of anything.
 // OPUSGPU_LAUNCH_DELAY_US (og_debug.hpp): the host dawdles before the launches of a decode step -- what a loaded host, a slow
 // event hop or another thread's launches would do -- so that tools/launch_jitter.py can show the step time does not depend on it
+#ifndef OG_HALVES_MIN
+#define OG_HALVES_MIN 4096 // frames per half below which an in-order step with SILK frames is not cut in two
+#endif
 static void launch_jitter() {
     if (const int us = og_debug().launch_delay_us) std::this_thread::sleep_for(std::chrono::microseconds(us));
 }
@@ -893,8 +909,11 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     modes &= 7;
     if (!modes) modes = 7;
     const bool any_silk = (modes & 3) != 0, any_celt = (modes & 6) != 0;
-    const bool pipe = ctx->pipeline && tables_resident && (modes & 4); // (only CELT-only frames have anything to run ahead)
-    const bool window = pipe && modes == 4 && next_n > 0;              // the next step is queued by this very call: see PLACEMENT
+    // Only a step the caller declares CELT-only runs ahead of the step before it.  (Round 2 also ran the CELT-only part of a
+    // mixed step's parse ahead: 4 % on the mixed-pages workload.  Cutting such a step into two halves -- below -- gains 6 %, and
+    // the two do not combine: a mixed or undeclared step takes the halves.)
+    const bool pipe = ctx->pipeline && tables_resident && modes == 4;
+    const bool window = pipe && next_n > 0; // the next step is queued by this very call: see PLACEMENT
     if (ctx->pipeline && ctx->last_step_stream && ctx->last_step_stream != s) {
         // consecutive steps on different streams: nothing orders them but the caller, so nothing may run ahead either
         HIPCHK(ctx, hipStreamSynchronize(ctx->last_step_stream));
@@ -933,6 +952,64 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     ctx->last_recs = recs;
     ctx->last_had_silk_recs = srecs != nullptr;
     const dim3 parse_grid((n + OG_PL_FRAMES - 1) / OG_PL_FRAMES), parse_block(64 * OG_PL_WAVES);
+    if (!pipe && srecs && n >= 2 * OG_HALVES_MIN && og_debug().halves) {
+        // TWO HALVES.  A step with SILK-only / hybrid frames runs in order -- k_silk_parse reads state the step's later kernels
+        // write, so nothing of the next step can start early -- and its kernels are of two kinds: the lane-per-frame parse
+        // kernels wait on latency with 13 % of their lanes active (k_silk_parse: 3.97 of a 15.4 ms step of 262,144 hybrid
+        // frames), the wave-per-frame ones are bound by vector-instruction issue.  The frames of a step belong to different
+        // streams and share nothing, so the step is cut in two and the halves' chains run on two streams: while one half's
+        // synthesis fills the SIMDs the other half parses in its gaps.  No state changes hands: each half is the in-order chain
+        // of its own frames over its own part of the records; the caller's stream forks the second one and joins it.
+        if (!ctx->ev_fork) {
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        // (the second chain's stream: the one pipelined steps reconstruct on when there is one -- it is idle here, the caller's
+        // stream has waited for everything on it -- rather than one more: measured with a fourth stream of the context, the two
+        // chains no longer overlapped at all, 2.14 instead of 1.89 ms per SILK-NB step; the hardware queues are few)
+        if (!ctx->recon_stream && !ctx->side_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        hipStream_t const side = ctx->recon_stream ? ctx->recon_stream : ctx->side_stream;
+        // (Both chains start together.  Staggered -- the second one behind the first one's parse kernels, so that one half parses
+        // while the other synthesises from the start -- was measured SLOWER, 14.9 against 14.5 ms per step of 262,144 hybrid
+        // frames and 2.44 against 1.90 ms per SILK-NB step: half a batch's parse takes as long as a whole batch's.)
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
+        HIPCHK(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
+        const int h = (n / 2 + 63) / 64 * 64; // (a multiple of the parse kernels' frames per workgroup)
+        for (int half = 0; half < 2; half++) {
+            hipStream_t q = half ? side : s;
+            const int f0 = half ? h : 0, cnt = half ? n - h : h;
+            const FrameDesc *dd = (const FrameDesc *)d_descs + f0;
+            i16 *pp = (i16 *)d_pcm + (size_t)f0 * pcm_stride;
+            i32 *rr = (i32 *)d_result + f0;
+            hipLaunchKernelGGL(k_silk_parse, dim3((cnt + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, q, dd, (const u8 *)d_arena,
+                               (const StreamState *)ctx->d_streams, srecs + f0, handoff + f0, cnt, ctx->n_streams);
+            if (any_celt)
+                hipLaunchKernelGGL(k_celt_parse, dim3((cnt + OG_PL_FRAMES - 1) / OG_PL_FRAMES), parse_block, 0, q, dd, (const u8 *)d_arena,
+                                   ctx->d_streams, recs + f0, cnt, ctx->n_streams, (const SilkHandoff *)(handoff + f0), (int)PARSE_ALL, 1, (u32 *)nullptr);
+            hipLaunchKernelGGL(k_silk_synth, dim3(cnt), dim3(64), 0, q, dd, (const u8 *)d_arena, ctx->d_streams, pp, rr, cnt, ctx->n_streams,
+                               pcm_stride, handoff + f0, (const SilkRec *)(srecs + f0));
+            if (any_celt) {
+                if (ctx->fast_recon)
+                    og_launch_celt_recon_fb(q, dd, ctx->d_streams, recs + f0, rout + f0, cnt, ctx->n_streams, 1, nullptr, nullptr);
+                hipLaunchKernelGGL(k_celt_recon, dim3(ctx->fast_recon ? (cnt + 63) / 64 : cnt), dim3(64), 0, q, dd, ctx->d_streams,
+                                   (const ParseRec *)(recs + f0), rout + f0, cnt, ctx->n_streams, 1, ctx->fast_recon);
+            }
+            hipLaunchKernelGGL(k_celt_post, dim3((cnt * ctx->channels + 63) / 64), dim3(64), 0, q, dd, ctx->d_streams, (const ParseRec *)(recs + f0),
+                               (const ReconOut *)(rout + f0), rr, pp, cnt, ctx->n_streams, ctx->channels, pcm_stride,
+                               (const SilkHandoff *)(handoff + f0), modes, 1);
+            if (modes & 1)
+                hipLaunchKernelGGL(k_decode_step, dim3((cnt + 63) / 64), dim3(64), 0, q, dd, (const u8 *)d_arena, ctx->d_streams, pp, rr, cnt,
+                                   ctx->n_streams, pcm_stride, 1, handoff + f0, (const SilkRec *)(srecs + f0), 1);
+        }
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join, side));
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+        HIPCHK(ctx, hipGetLastError());
+        if (ctx->pipeline) { // (a step that ran in order: whatever a later pipelined step runs ahead waits for all of it)
+            HIPCHK(ctx, hipEventRecord(ctx->ev_front, s));
+            ctx->front_recorded = 1;
+        }
+        return OPUSGPU_OK;
+    }
     // The kernels of a step and what orders them:
     //   FRONT   k_silk_parse  k_celt_parse  k_silk_synth (or the full kernel)  k_decode_step[Q4]
     //   BACK    k_celt_recon_fb  k_celt_recon  ->  k_celt_post
@@ -940,19 +1017,17 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     // reconstruction are independent (SilkRec::prev_mode, og_silk_parse.hpp); running them on two streams was measured
     // (DESIGN.md section 6): next to k_celt_recon the synthesis gains nothing; next to k_celt_parse it gains 5 % on mixed-mode
     // steps but costs 13 % on CELT-only steps.
-    // Pipelined (opusgpu_set_pipeline; the tables are resident, so nothing here waits for the caller's earlier work):
-    //   parse_stream   [front of step k-1, post of step k-3]  k_celt_parse[CELT-only frames]
-    //   step's stream  k_silk_parse  k_celt_parse[hybrid]  k_silk_synth  k_decode_step[Q4]  (= front of step k)
-    //                  [reconstruction of step k; in a window: the first round of the reconstruction of step k+1]  k_celt_post
-    //   recon_stream   [early parse, front of step k, post of step k-2; in a window: every workgroup of the parse of step k+1]
-    //                  k_celt_recon_fb  k_celt_recon
-    // "front": every kernel that writes what a parse kernel reads -- CeltState::bandE (k_celt_parse itself, and the full
-    // kernel), the SILK state and prev_mode (k_silk_synth, the full kernel, the reconstruction of the step before, which the
-    // step's stream has waited for) -- or that writes the caller's buffers.  The reconstruction touches neither the caller's
-    // buffers (its result codes go through ReconOut) nor anything k_celt_post reads of the step BEFORE (the history ring is
-    // written 960 samples further on; the ring position travels in ReconOut), so when the caller rules out SILK-only and
-    // hybrid frames the reconstruction of step k+1 starts while k_celt_post of step k runs; two steps on, it waits for it
-    // (the ring holds two frames; records and ReconOut rotate through three sets).
+    // Pipelined (opusgpu_set_pipeline, a step the caller declares CELT-only; the tables are resident, so nothing here waits for
+    // the caller's earlier work):
+    //   parse_stream   [the last in-order step, post of step k-3]  k_celt_parse
+    //   recon_stream   [the parse, post of step k-2; in a window: every workgroup of the parse of step k+1]  k_celt_recon_fb  k_celt_recon
+    //   step's stream  [reconstruction of step k; in a window: the first round of the reconstruction of step k+1]  k_celt_post
+    // The entropy half reads one thing of the stream's state, the band energies, and writes them itself (celt_parse_lane): the
+    // parse of step k+1 depends on the parse of step k only.  The reconstruction touches neither the caller's buffers (its result
+    // codes go through ReconOut) nor anything k_celt_post reads of the step BEFORE (the history ring is written 960 samples
+    // further on; the ring position travels in ReconOut), so the reconstruction of step k+1 starts while k_celt_post of step k
+    // runs; two steps on, it waits for it (the ring holds two frames; records and ReconOut rotate through three sets).
+    // A step that is not declared CELT-only runs in order (ev_front: a later pipelined step's parse waits for all of it).
     // PLACEMENT.  The three kernels compete for LDS: the parse is one round of 14 KB workgroups that live ~1 ms, the
     // reconstruction 65,536 workgroups of 7.5 KB that live ~0.15 ms, the de-emphasis 10 KB ones that nothing waits for.  A parse
     // workgroup that arrives when the CUs are full of reconstruction workgroups finds no hole that fits it (3.1 ms per step
@@ -974,7 +1049,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         // the early parse: behind the front of the step before and its own slot's last user (three steps back)
         if (ctx->front_recorded) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_front, 0));
         if (ctx->post_recorded[par]) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_post[par], 0));
-        if (modes & 4) {
+        {
             const int grid = (n + OG_PL_FRAMES * ctx->parse_groups - 1) / (OG_PL_FRAMES * ctx->parse_groups);
             launch_jitter();
             hipLaunchKernelGGL(k_celt_parse, dim3(grid), parse_block, 0, ctx->parse_stream, (const FrameDesc *)d_descs, (const u8 *)d_arena,
@@ -983,13 +1058,6 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
             ctx->parse_started_total += (u32)grid;
         }
         HIPCHK(ctx, hipEventRecord(ctx->ev_parsed, ctx->parse_stream));
-        if (srecs) {
-            hipLaunchKernelGGL(k_silk_parse, dim3((n + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, s, (const FrameDesc *)d_descs,
-                               (const u8 *)d_arena, (const StreamState *)ctx->d_streams, srecs, handoff, n, ctx->n_streams);
-            if (modes & 2)
-                hipLaunchKernelGGL(k_celt_parse, parse_grid, parse_block, 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams,
-                                   recs, n, ctx->n_streams, (const SilkHandoff *)handoff, (int)PARSE_HYBRID_ONLY, 1, (u32 *)nullptr);
-        }
     }
     bool others_ran = false; // (the kernels that report stream-index errors for every mode)
     if (srecs) {
@@ -1013,14 +1081,8 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     };
     hipStream_t back = s;
     if (pipe) {
-        if (srecs && (modes & 1)) q4_pass();
         back = ctx->recon_stream;
         HIPCHK(ctx, hipStreamWaitEvent(back, ctx->ev_parsed, 0));
-        if (any_silk) { // this step has front kernels on its stream
-            HIPCHK(ctx, hipEventRecord(ctx->ev_front, s));
-            ctx->front_recorded = 1;
-            HIPCHK(ctx, hipStreamWaitEvent(back, ctx->ev_front, 0));
-        }
         if (ctx->post_recorded[par2]) HIPCHK(ctx, hipStreamWaitEvent(back, ctx->ev_post[par2], 0)); // (the ring: 2 x 960 of 2048)
         if (window) { // ... and every workgroup of the next step's parse has its place
             const int next_grid = (next_n + OG_PL_FRAMES * ctx->parse_groups - 1) / (OG_PL_FRAMES * ctx->parse_groups);
