@@ -40,6 +40,11 @@ WORKLOADS = {
     # Rank 0 ingests (page demux on the host) and scatters every rank's decode steps (the one collective of the path).
     "mixed_pages_2m": (None, None, (5953 + 24945 + 21633) / 3.0, 262144),
 }
+# RFC mode (include/opusgpu.h OPUSGPU_MODE_RFC): stream s keeps TOC configuration s % 32 -- all modes, bandwidths and
+# frame durations 2.5 ... 60 ms -- one stereo code-0 packet per step, 5 % of the packets lost: concealed, or (SILK-only / hybrid
+# streams whose next packet arrived) recovered from that packet's forward error correction data.  Not a BASELINE config.
+RFC_WORKLOAD = "rfc_mixed_64k"
+RFC_LOSS = 0.05
 MIX = ((0x0C, 40), (0x7C, 120), (0xFC, 160))  # mode of local stream s = s % 3: SILK-NB, hybrid FB, CELT FB
 PACKETS_PER_PAGE = 10
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -127,6 +132,7 @@ def prepare_pages_work(pkg, shard, ranks, ctx, n, frames, ingest="rank0", page_c
     threads = shard.usable_cpus()
     per_rank = ingest == "per-rank"
     buffers, stats = None, None
+    RAW_PAGES.clear()
     if ranks.rank == 0:
         buffers, n_pages, page_bytes, t_demux, t_gen = [], 0, 0, 0.0, 0.0
         for r in range(ranks.world):
@@ -173,6 +179,7 @@ def prepare_pages_work(pkg, shard, ranks, ctx, n, frames, ingest="rank0", page_c
         # this rank's raw pages -> host (they may have arrived in HBM), demux here, steps -> HBM
         raw = mine if isinstance(mine, np.ndarray) else mine.cpu().numpy()
         blob, offs, lens, sids = shard.unpack_pages(raw)
+        RAW_PAGES.update({"blob": blob, "offs": offs, "lens": lens, "sids": sids, "raw": raw})  # for overlapped_end_to_end()
         if page_crc == "gpu":
             import ctypes
             if isinstance(mine, np.ndarray):  # one rank, no scatter: put the raw pages where a scatter would have put them
@@ -213,6 +220,40 @@ def prepare_pages_work(pkg, shard, ranks, ctx, n, frames, ingest="rank0", page_c
         stats["scatter_s"] = t_scatter if ranks.dist is not None else None
         stats["work_bytes_per_rank"] = int(lay.nbytes)
     return base, lay, stats, keep
+
+
+RAW_PAGES = {}  # this rank's share of the raw pages, as prepare_pages_work (per-rank ingest) received it
+
+
+def overlapped_end_to_end(pkg, ranks, ctx, n, d_pcm, d_res, threads):
+    """Config 5 end to end with the ingest UNDER the decode (esp32-opus-player_amd/ingest.py): this rank's raw pages, in batches
+    of one page per stream, are demuxed (checksums verified on the host's cores) and uploaded on the copy stream by a second host
+    thread while the batch before decodes.  Streams are reset first, so the last step leaves the same PCM as the timed run did.
+    -> (statistics of this rank, PCM of the last step)"""
+    spec = importlib.util.spec_from_file_location(pkg.__name__ + ".ingest", os.path.join(ROOT, "esp32-opus-player_amd", "ingest.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    blob, offs, lens, sids = (RAW_PAGES[k] for k in ("blob", "offs", "lens", "sids"))
+    if len(lens) % n:
+        raise SystemExit("raw pages are not whole batches of one page per stream")
+    batches = [(blob, offs[q * n:(q + 1) * n], lens[q * n:(q + 1) * n], sids[q * n:(q + 1) * n]) for q in range(len(lens) // n)]
+    if os.environ.get("BENCH_E2E_SPLIT_FIRST", "1") != "0":
+        # the first batch's ingest is the one nothing hides: it goes in two halves (by page order), so that decoding starts after half of it
+        b0 = batches[0]
+        h = n // 2
+        batches = [(blob, b0[1][:h], b0[2][:h], b0[3][:h]), (blob, b0[1][h:], b0[2][h:], b0[3][h:])] + batches[1:]
+    ctx.streams_reset(0, n)
+    ctx.synchronize()
+    pipe = mod.OverlappedPageDecode(ctx, threads=int(os.environ.get("BENCH_E2E_THREADS", threads)), depth=int(os.environ.get("BENCH_E2E_DEPTH", "3")))
+    pipe.reserve(int(max(int(b[2].sum()) + 32 * len(b[2]) for b in batches)) + 4096)  # a service sets its slots up once, not per job
+    ranks.barrier()
+    st = pipe.run(batches, d_pcm, d_res)
+    ranks.barrier()
+    pipe.close()
+    out = np.zeros((n, 960, 2), dtype=np.int16)
+    ctx.d2h(out, d_pcm)
+    return st, out
 
 
 def launch_ranks(args, argv):
@@ -406,6 +447,15 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
         ctx.d2h(last, ctypes.c_void_p(at + lay.desc_at[K + W - 1]))
         parity = check_against_oracle(pkg, ctx, name, n, K + W, d_pcm, slot_stream=last["stream"].astype(np.int64),
                                       pages_seed=lambda m: (0x9E3779B9 ^ (r * 0x01000193) ^ (m * 0x5bd1e995)) & 0xFFFFFFFF)
+        if RAW_PAGES:
+            timed_pcm = np.zeros((n, 960, 2), dtype=np.int16)
+            ctx.d2h(timed_pcm, d_pcm)
+            e2e_stats, e2e_pcm = overlapped_end_to_end(pkg, ranks, ctx, n, d_pcm, d_res, max(1, shard.usable_cpus() - 2))
+            if not np.array_equal(timed_pcm, e2e_pcm):
+                raise SystemExit(f"{name}: the overlapped end-to-end run left other PCM than the timed run")
+            e2e = {"wall_s": ranks.max_over_ranks(e2e_stats["wall_s"]), "pages": ranks.sum_over_ranks(e2e_stats["pages"]),
+                   "rank0": e2e_stats}
+            del timed_pcm, e2e_pcm
     else:
         parity = check_against_oracle(pkg, ctx, name, n, K + W, d_pcm, pay=pay)
 
@@ -450,10 +500,25 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
         ingest["ingest_wall_s"] = t_in
         pages = ingest["pages"]
         decode_s = (dt / K) * (K + W)
-        ingest["end_to_end_pages_per_s"] = pages / (t_in + decode_s)
-        ingest["end_to_end_note"] = ("pages of all ranks / (routing + packing + scatter + demux + upload of the steps, wall time, max "
-                                     "over ranks; making the synthetic pages excluded) + (their decode steps at the measured step time); "
-                                     "nothing overlaps: ingest of the next batch could run under the decode of this one")
+        ingest["serial_end_to_end_pages_per_s"] = pages / (t_in + decode_s)
+        ingest["serial_end_to_end_note"] = ("pages of all ranks / (routing + packing + scatter + demux + upload of the steps, wall time, "
+                                            "max over ranks; making the synthetic pages excluded) + (their decode steps at the measured "
+                                            "step time): nothing overlapped")
+        ingest["decode_only_pages_per_s"] = pages / decode_s
+        if e2e is not None:
+            r0 = e2e["rank0"]
+            nb = len(r0["ingest_s"])
+            ingest["end_to_end_pages_per_s"] = e2e["pages"] / e2e["wall_s"]
+            ingest["end_to_end_over_decode_only"] = ingest["end_to_end_pages_per_s"] / ingest["decode_only_pages_per_s"]
+            ingest["end_to_end"] = {
+                "what": "every rank, from its share of the raw pages (where the scatter left them, host side) to the last PCM: batches of "
+                        "one page per stream; a host thread demuxes batch b + 1 (checksums verified on the host's cores) and uploads its "
+                        "step tables and packets on the copy stream while batch b decodes (esp32-opus-player_amd/ingest.py); wall time "
+                        "of the whole job incl. the first batch's ingest, which nothing hides; final PCM identical to the timed run's",
+                "wall_s": e2e["wall_s"], "batches": nb, "steps": r0["steps"], "first_batch_ready_s": r0["first_batch_ready_s"],
+                "ingest_s_per_batch": r0["ingest_s"], "demux_s_per_batch": r0["demux_s"], "slot_wait_s_per_batch": r0["slot_wait_s"],
+                "gpu_ms_between_batch_ends": r0["gpu_ms_between_batch_ends"],
+                }
         out["ingest"] = ingest
     if cpu and not args.no_cpu_baseline:
         out["cpu_baseline"] = mixed_cpu_baseline() if mixed else cpu_baseline(toc, L, seconds_target=args.cpu_seconds)
@@ -463,12 +528,185 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
     return out
 
 
+def rfc_frame_bytes(toc, L, lost):
+    """Algorithmic bytes of one RFC-mode frame, by SURVEY 8d's rule (packet in, PCM out, the minimal state a bit-exact decoder reads
+    and writes back) at the frame's own duration D: CELT history read 8,672 + 400 B, write (D + 60) samples x 4 B x 2 ch + 400;
+    SILK state 2,072 (NB) / 2,712 (MB) / 3,352 B (WB, hybrid) read + write; a concealed frame has no packet bytes."""
+    import rfc_common
+    D = rfc_common.dur(toc)
+    mode, bw = rfc_common.mode_bw(toc)
+    b = (0 if lost else L + 1) + 4 * D
+    if mode != rfc_common.MODE_SILK:
+        b += 9072 + 8 * (D + 60) + 400
+    if mode != rfc_common.MODE_CELT:
+        b += 3352 if mode == rfc_common.MODE_HYBRID else {1101: 2072, 1102: 2712, 1103: 3352}[bw]
+    return b
+
+
+def run_rfc_workload(args, ranks, pkg, ctx, n_override=0, cpu=True):
+    """RFC mode, one measured line: every TOC configuration, lost packets and forward error correction through the device-resident
+    entry (opusgpu_decode_step_device in OPUSGPU_MODE_RFC: one k_decode_rfc launch per step).  -> dict (rank 0)."""
+    import zlib
+    import rfc_common
+    import oracle_py
+    shard = load_shard()
+    rank, world = ranks.rank, ranks.world
+    n = n_override or 65536
+    K, W = min(args.steps, 8), min(args.warmup, 2)
+    F = K + W
+    rng = np.random.default_rng(0xC0DEC + rank)
+    cfg = np.arange(n) % 32
+    toc_of = ((np.arange(32) << 3) | 4).astype(np.uint8)
+    dur_of = np.array([rfc_common.dur(int(t)) for t in toc_of])
+    mode_of = np.array([rfc_common.mode_bw(int(t))[0] for t in toc_of])
+    # bytes per frame: about 64 kbit/s at every duration, SILK-only at about 24 kbit/s
+    L_of = np.array([max(8, min(600, int((24000 if mode_of[c] == rfc_common.MODE_SILK else 64000) * dur_of[c] / 48000 / 8))) for c in range(32)])
+    flags_of = np.zeros(32, dtype=np.int32)
+    for c in range(32):  # the library's own framing names the descriptor flags of a configuration
+        d = (pkg.FrameDesc * 48)()
+        pkt = bytes([int(toc_of[c])]) + bytes(int(L_of[c]))
+        if pkg.load_lib().opusgpu_packet_to_frames_mode(pkt, len(pkt), 0, 1, d) != 1 or d[0].offset != 1 or d[0].len != L_of[c]:
+            raise SystemExit("rfc workload: unexpected framing of a code-0 packet")
+        flags_of[c] = d[0].flags
+    Ls, tocs, durs = L_of[cfg], toc_of[cfg], dur_of[cfg]
+    size = Ls + 1
+    at = np.concatenate([[0], np.cumsum(size)]).astype(np.int64)  # packet s of a step lies at at[s] of that step's arena
+    # ops[f, s]: 0 decode, 1 lost and concealed, 2 lost and recovered from packet f + 1 (never at step 0: nothing to continue from)
+    lost = rng.random((F + 1, n)) < RFC_LOSS
+    lost[0] = False
+    lost[F] = False
+    can_fec = (mode_of[cfg] != rfc_common.MODE_CELT)[None, :] & ~np.roll(lost, -1, axis=0)
+    ops = np.where(lost, np.where(can_fec & (rng.random((F + 1, n)) < 0.5), 2, 1), 0).astype(np.uint8)[:F]
+    arenas = []
+    for f in range(F + 1):  # packet bytes of every step (step F: only read by the recoveries of step F - 1)
+        a = rng.integers(0, 256, int(at[n]), dtype=np.uint8)
+        a[at[:-1]] = tocs
+        arenas.append(a)
+    ctx.set_mode(True)
+    ctx.streams_alloc(n, 2)
+    stride = 2880 * 2
+    d_pcm = ctx.dev_alloc(n * stride * 2)
+    d_res = ctx.dev_alloc(4 * n)
+    frees = [d_pcm, d_res]
+    d_arena, d_desc = [], []
+    host_arena, offs = [], np.zeros((F, n), dtype=np.int64)
+    arena_at = 0
+    for f in range(F):
+        if (ops[f] == 2).any():  # a recovery reads the NEXT step's packet: this step's arena carries a copy of it
+            a = arenas[f].copy()
+            for s_ in np.nonzero(ops[f] == 2)[0]:
+                a[at[s_]:at[s_ + 1]] = arenas[f + 1][at[s_]:at[s_ + 1]]
+        else:
+            a = arenas[f]
+        descs = np.zeros(n, dtype=pkg.DESC_DTYPE)
+        descs["stream"] = np.arange(n, dtype=np.int32)
+        descs["offset"] = np.where(ops[f] == 1, 0, at[:-1] + 1)
+        descs["len"] = np.where(ops[f] == 1, 0, Ls)
+        descs["flags"] = flags_of[cfg] | np.where(ops[f] == 2, 1 << 10, 0)
+        da, dd = ctx.dev_alloc(a.nbytes + 16), ctx.dev_alloc(descs.nbytes)
+        ctx.h2d(da, a)
+        ctx.h2d(dd, descs)
+        d_arena.append(da)
+        d_desc.append(dd)
+        host_arena.append(a)
+        offs[f] = arena_at + at[:-1]
+        arena_at += a.nbytes
+    frees += d_arena + d_desc
+    lens = np.where(ops == 1, 0, size[None, :]).astype(np.int32)
+
+    def step(f):
+        ctx.decode_step_device(n, d_desc[f], d_arena[f], d_pcm, d_res)
+
+    for f in range(W):
+        step(f)
+    ctx.synchronize()
+    ev = [ctx.event() for _ in range(K + 1)]
+    ranks.barrier()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.event_record(ev[0])
+    for f in range(K):
+        step(W + f)
+        ctx.event_record(ev[f + 1])
+    ctx.synchronize()
+    ranks.barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = [ctx.event_elapsed_ms(ev[f], ev[f + 1]) for f in range(K)]
+    for e in ev:
+        ctx.event_destroy(e)
+    res = np.zeros(n, dtype=np.int32)
+    ctx.d2h(res, d_res)
+    if not (res == durs).all():
+        raise SystemExit(f"{RFC_WORKLOAD}: {(res != durs).sum()} frames of the last step did not return their TOC's duration")
+    # parity of what was timed: the last step's PCM of 10 streams per configuration against the oracle's RFC mode, which decodes,
+    # conceals and recovers those streams' whole history
+    pick = np.unique(np.concatenate([np.arange(0, n, max(1, n // 320)), np.arange(n - 32, n)])).astype(np.int64)
+    out = np.zeros((n, 2880, 2), dtype=np.int16)
+    ctx.d2h(out, d_pcm)
+    o = oracle_py.load()
+    big = np.concatenate(host_arena)
+    ref, rets = o.batch_decode_rfc(2, big, offs[:, pick], lens[:, pick], ops[:, pick])
+    crc, bad = 0, []
+    for i, s_ in enumerate(pick):
+        D = int(durs[s_])
+        if rets[i, F - 1] != D or not np.array_equal(out[s_, :D], ref[i, :D]):
+            bad.append(int(s_))
+        crc = zlib.crc32(out[s_, :D].tobytes(), crc)
+    if bad:
+        raise SystemExit(f"{RFC_WORKLOAD}: GPU PCM of the last timed step differs from the CPU oracle's RFC mode for streams {bad[:8]} "
+                         f"({len(bad)} of {len(pick)} checked)")
+    parity = {"streams_checked": len(pick), "frames_of_history": F,
+              "lost_or_recovered_in_last_step": int((ops[F - 1, pick] != 0).sum()),
+              "result": "last timed step bit-exact vs the CPU oracle's RFC mode (itself parity-unpinned: DESIGN.md section 11)",
+              "pcm_crc32": f"{crc:08x}"}
+    timed = ops[W:]
+    alg = sum(rfc_frame_bytes(int(toc_of[c]), int(L_of[c]), False) * int(((cfg == c)[None, :] & (timed != 1)).sum()) +
+              rfc_frame_bytes(int(toc_of[c]), int(L_of[c]), True) * int(((cfg == c)[None, :] & (timed == 1)).sum()) for c in range(32))
+    audio_s = float(durs.sum()) * K / 48000.0
+    value, dt, total_frames = shard.aggregate_throughput(ranks, n * K, dt)
+    for p in frees:
+        ctx.dev_free(p)
+    ctx.set_mode(False)
+    if rank != 0:
+        return None
+    avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
+    achieved = alg / K / avg_kernel_s / 1e9
+    out_line = {
+        "name": RFC_WORKLOAD, "value": value, "unit": "frames/s", "ms_per_step": dt / K * 1e3, "steps": K, "warmup": W,
+        "config": {"workload": f"{RFC_WORKLOAD}: RFC mode (frames at the durations their TOC names), {n} streams/GPU, stream s keeps TOC "
+                               f"configuration s % 32 (SILK NB/MB/WB 10-60 ms, hybrid SWB/FB 10/20 ms, CELT NB-FB 2.5-20 ms), one "
+                               f"stereo code-0 packet per stream and step (about 64 kbit/s, SILK-only 24 kbit/s, random bytes), "
+                               f"{100 * RFC_LOSS:.0f} % of the packets lost: concealed, or for half of the SILK-only / hybrid losses "
+                               f"whose next packet arrived recovered from its forward error correction data",
+                   "streams_per_gpu": n, "sharding": "streams partitioned across ranks, no data-path collective",
+                   "lost_frames": int((timed == 1).sum()), "recovered_frames": int((timed == 2).sum())},
+        "x_realtime_per_gpu": audio_s / dt,
+        "audio_seconds_per_step": audio_s / K,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "decode step = k_decode_rfc (one frame per wave at its true duration; og_rfc.hip)",
+                     "avg_launch_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_frame": alg / K / n, "frames_per_launch": n},
+        "parity_check": parity,
+    }
+    if cpu and not args.no_cpu_baseline:
+        cores = shard.usable_cpus()
+        ns = min(n, 4096)
+        t1 = time.perf_counter()
+        _, r2 = o.batch_decode_rfc(2, big, offs[:, :ns], lens[:, :ns], ops[:, :ns], threads=cores, want_pcm=False)
+        dt_cpu = time.perf_counter() - t1
+        out_line["cpu_baseline"] = {
+            "value": float((r2 > 0).sum()) / dt_cpu, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"the first {ns} streams x {F} steps of the same workload (losses and recoveries included), {cores} threads, one "
+                      f"oracle decoder in RFC mode per stream, {dt_cpu:.2f} s wall",
+            "calibration": "oracle only; its RFC mode has no reference-origin vector (parity-unpinned)"}
+    return out_line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)   # (pipelined steps: the first parse and the last de-emphasis of a run are not hidden)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--workload", default="celt_fb_stereo_64k", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="celt_fb_stereo_64k", choices=sorted(WORKLOADS) + [RFC_WORKLOAD])
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
     ap.add_argument("--page-crc", default="gpu", choices=["host", "gpu"],
                     help="mixed_pages_2m with --ingest per-rank: who verifies the page checksums")
@@ -514,6 +752,16 @@ def main():
     pkg = load_pkg()
     ctx = pkg.Context(local_rank)
     ctx.set_pipeline(args.pipeline == "on")
+    if args.workload == RFC_WORKLOAD:  # not a BASELINE config: its own line, same fields
+        o = run_rfc_workload(args, ranks, pkg, ctx, n_override=args.streams)
+        if rank == 0:
+            o.update({"metric": "decoded 48 kHz stereo frames/sec/GPU, RFC mode (x real-time); HBM GB/s vs roofline", "n_gpus": world,
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+                      "dtype": "int32 fixed-point (int16/int32 with 64-bit products)"})
+            print(json.dumps(o), flush=True)
+        ranks.close()
+        ctx.close()
+        return
     main_out = run_workload(args.workload, args, ranks, pkg, ctx, n_override=args.streams)
     others = []
     if not args.no_other_configs and args.workload == "celt_fb_stereo_64k" and not args.streams:
@@ -526,6 +774,9 @@ def main():
             if o is not None:
                 o["name"] = name
                 others.append(o)
+        o = run_rfc_workload(args, ranks, pkg, ctx)
+        if o is not None:
+            others.append(o)
         args.cpu_seconds = saved
     if rank == 0:
         line = {

@@ -23,8 +23,9 @@ EXPORTS = [
     "opusgpu_stream_state_bytes", "opusgpu_debug_stage_taps", "opusgpu_decode_packets", "opusgpu_decode_packets_fec", "opusgpu_packet_to_frames",
     "opusgpu_dev_alloc", "opusgpu_dev_free", "opusgpu_memcpy_h2d", "opusgpu_memcpy_d2h",
     "opusgpu_decode_step_device", "opusgpu_decode_step_device_modes", "opusgpu_decode_steps_device", "opusgpu_synchronize", "opusgpu_event_create", "opusgpu_event_record",
-    "opusgpu_event_elapsed_ms", "opusgpu_event_destroy", "opusgpu_stream_state_get",
-    "opusgpu_pages_demux", "opusgpu_page_batch_steps", "opusgpu_page_batch_step", "opusgpu_page_batch_arena",
+    "opusgpu_event_elapsed_ms", "opusgpu_event_destroy", "opusgpu_event_synchronize", "opusgpu_stream_state_get",
+    "opusgpu_upload_async", "opusgpu_upload_fence", "opusgpu_stream_wait_event", "opusgpu_host_register", "opusgpu_host_unregister",
+    "opusgpu_pages_demux", "opusgpu_pages_demux_into", "opusgpu_page_batch_arena_offset", "opusgpu_page_batch_steps", "opusgpu_page_batch_step", "opusgpu_page_batch_arena",
     "opusgpu_page_batch_free", "opusgpu_pages_crc_device", "opusgpu_output_stage_device",
     "opusgpu_set_mode", "opusgpu_get_mode", "opusgpu_set_pipeline", "opusgpu_get_pipeline", "opusgpu_packet_to_frames_mode",
 ]
@@ -122,9 +123,18 @@ def load_lib():
     lib.opusgpu_event_record.argtypes = [vp, vp]
     lib.opusgpu_event_elapsed_ms.argtypes = [vp, vp, vp, C.POINTER(C.c_float)]
     lib.opusgpu_event_destroy.argtypes = [vp, vp]
+    lib.opusgpu_event_synchronize.argtypes = [vp, vp]
+    lib.opusgpu_upload_async.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.opusgpu_upload_fence.argtypes = [vp, vp]
+    lib.opusgpu_stream_wait_event.argtypes = [vp, vp, vp]
+    lib.opusgpu_host_register.argtypes = [vp, vp, C.c_size_t]
+    lib.opusgpu_host_unregister.argtypes = [vp, vp]
     lib.opusgpu_stream_state_get.argtypes = [vp, C.c_int, vp, C.c_size_t]
     lib.opusgpu_debug_stage_taps.argtypes = [vp, C.c_int, vp]
     lib.opusgpu_pages_demux.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    lib.opusgpu_pages_demux_into.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(vp)]
+    lib.opusgpu_page_batch_arena_offset.argtypes = [vp]
+    lib.opusgpu_page_batch_arena_offset.restype = C.c_size_t
     lib.opusgpu_page_batch_steps.argtypes = [vp]
     lib.opusgpu_page_batch_step.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
     lib.opusgpu_page_batch_arena.argtypes = [vp, C.POINTER(C.c_size_t)]
@@ -142,6 +152,12 @@ class OpusGpuError(RuntimeError):
     pass
 
 
+class BufferTooSmall(OpusGpuError):
+    def __init__(self, need):
+        super().__init__(f"output memory too small: {need} bytes needed")
+        self.need = need
+
+
 def packet_to_frames(packet: bytes, stream: int = 0):
     """Host-only: frame descriptors of one packet (list of (offset, len, flags)) or a negative code."""
     lib = load_lib()
@@ -157,7 +173,10 @@ class PageBatch:
     `blob` holds the pages back to back, page i = blob[offsets[i] : offsets[i] + lens[i]]; stream_ids[i] is the decoder
     stream page i belongs to.  info: one PAGE_INFO_DTYPE record per page (status = frames contributed or PAGE_*)."""
 
-    def __init__(self, blob, offsets, lens, stream_ids, flags=PAGES_VERIFY_CRC | PAGES_GROUP_BY_MODE, threads=1):
+    def __init__(self, blob, offsets, lens, stream_ids, flags=PAGES_VERIFY_CRC | PAGES_GROUP_BY_MODE, threads=1, out_mem=None):
+        """out_mem: a uint8 array (16-byte aligned, e.g. page-locked by Context.host_register) that receives the step tables and the
+        arena (opusgpu_pages_demux_into); raises BufferTooSmall(need) when it is too small.  Then `self.image` is the part of out_mem
+        that holds [tables | arena] and `self.arena_offset` where the arena begins in it: one upload carries the whole batch."""
         lib = load_lib()
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         offsets = np.asarray(offsets, dtype=np.int64)
@@ -171,8 +190,16 @@ class PageBatch:
         ptrs = (np.uint64(blob.ctypes.data) + offsets.astype(np.uint64)).astype(np.uint64)
         self.info = np.zeros(n, dtype=PAGE_INFO_DTYPE)
         h = C.c_void_p()
-        r = lib.opusgpu_pages_demux(n, ptrs.ctypes.data, lens.ctypes.data, ids.ctypes.data, flags, threads,
-                                    self.info.ctypes.data, C.byref(h))
+        self.image, self.arena_offset = None, 0
+        if out_mem is None:
+            r = lib.opusgpu_pages_demux(n, ptrs.ctypes.data, lens.ctypes.data, ids.ctypes.data, flags, threads,
+                                        self.info.ctypes.data, C.byref(h))
+        else:
+            need = C.c_size_t()
+            r = lib.opusgpu_pages_demux_into(n, ptrs.ctypes.data, lens.ctypes.data, ids.ctypes.data, flags, threads,
+                                             self.info.ctypes.data, out_mem.ctypes.data, out_mem.nbytes, C.byref(need), C.byref(h))
+            if r == -2:
+                raise BufferTooSmall(need.value)
         if r != 0:
             raise OpusGpuError(f"opusgpu_pages_demux failed: {r}")
         self.lib, self.h = lib, h
@@ -180,6 +207,10 @@ class PageBatch:
         nbytes = C.c_size_t()
         a = lib.opusgpu_page_batch_arena(h, C.byref(nbytes))
         self.arena = np.ctypeslib.as_array((C.c_uint8 * nbytes.value).from_address(a)) if nbytes.value else np.zeros(0, np.uint8)
+        if out_mem is not None:
+            self.arena_offset = lib.opusgpu_page_batch_arena_offset(h)
+            self.image = out_mem[:self.arena_offset + nbytes.value]
+            self._out_mem = out_mem
 
     @classmethod
     def with_gpu_crc(cls, ctx, d_blob, blob, offsets, lens, stream_ids, flags=PAGES_GROUP_BY_MODE, threads=1):
@@ -410,6 +441,28 @@ class Context:
 
     def event_destroy(self, e):
         self.lib.opusgpu_event_destroy(self.h, e)
+
+    def event_synchronize(self, e):
+        self._chk(self.lib.opusgpu_event_synchronize(self.h, e), "opusgpu_event_synchronize")
+
+    # uploads next to the decode (include/opusgpu.h: opusgpu_upload_async and friends; ingest.py drives them)
+    def upload_async(self, dptr, arr):
+        """Queue a host -> HBM copy on the context's copy stream; `arr` must stay alive until a later fence has passed."""
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.lib.opusgpu_upload_async(self.h, dptr, arr.ctypes.data, arr.nbytes), "opusgpu_upload_async")
+        return arr
+
+    def upload_fence(self, e):
+        self._chk(self.lib.opusgpu_upload_fence(self.h, e), "opusgpu_upload_fence")
+
+    def stream_wait_event(self, e, stream=None):
+        self._chk(self.lib.opusgpu_stream_wait_event(self.h, e, stream), "opusgpu_stream_wait_event")
+
+    def host_register(self, arr):
+        self._chk(self.lib.opusgpu_host_register(self.h, arr.ctypes.data, arr.nbytes), "opusgpu_host_register")
+
+    def host_unregister(self, arr):
+        self._chk(self.lib.opusgpu_host_unregister(self.h, arr.ctypes.data), "opusgpu_host_unregister")
 
 
 # ---- synthetic workloads (SURVEY.md section 8d) ---------------------------------------------------

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <memory>
 #include <new>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "og_decode.hpp"
@@ -1258,6 +1259,60 @@ int opusgpu_event_elapsed_ms(opusgpu_ctx *ctx, void *start, void *stop, float *m
 int opusgpu_event_destroy(opusgpu_ctx *ctx, void *event) {
     if (!ctx || !event) return OPUSGPU_BAD_ARG;
     HIPCHK(ctx, hipEventDestroy((hipEvent_t)event));
+    return OPUSGPU_OK;
+}
+
+// ---- uploads NEXT TO the decode (the ingest of the next batch of pages under the decode of this one).
+// The upload runs on the context's copy stream, never on the decode stream: a host thread demuxes batch b + 1 and queues its
+// tables and packet bytes here while the caller's thread has batch b's steps in flight; the fence event orders the two.
+static std::mutex g_copy_stream_mutex;
+static int copy_stream_of(opusgpu_ctx *ctx, hipStream_t *out) {
+    std::lock_guard<std::mutex> lock(g_copy_stream_mutex);
+    if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    *out = ctx->copy_stream;
+    return OPUSGPU_OK;
+}
+int opusgpu_upload_async(opusgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t cs;
+    if (int rc = copy_stream_of(ctx, &cs)) return rc;
+    if (bytes) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs));
+    return OPUSGPU_OK;
+}
+int opusgpu_upload_fence(opusgpu_ctx *ctx, void *event) {
+    if (!ctx || !event) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t cs;
+    if (int rc = copy_stream_of(ctx, &cs)) return rc;
+    HIPCHK(ctx, hipEventRecord((hipEvent_t)event, cs));
+    return OPUSGPU_OK;
+}
+int opusgpu_stream_wait_event(opusgpu_ctx *ctx, void *event, void *hip_stream) {
+    if (!ctx || !event) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamWaitEvent(hip_stream ? (hipStream_t)hip_stream : ctx->stream, (hipEvent_t)event, 0));
+    return OPUSGPU_OK;
+}
+int opusgpu_event_synchronize(opusgpu_ctx *ctx, void *event) {
+    if (!ctx || !event) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipEventSynchronize((hipEvent_t)event));
+    return OPUSGPU_OK;
+}
+// Caller-owned host buffers made DMA-able in place (page-locked): uploads from and PCM copies into registered memory run at
+// the full PCIe rate without the staging copy (opusgpu_decode_packets notices registered PCM buffers by itself).
+int opusgpu_host_register(opusgpu_ctx *ctx, void *ptr, size_t bytes) {
+    if (!ctx || !ptr || !bytes) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) return fail(ctx, OPUSGPU_ALLOC_FAIL, "hipHostRegister", e);
+    return OPUSGPU_OK;
+}
+int opusgpu_host_unregister(opusgpu_ctx *ctx, void *ptr) {
+    if (!ctx || !ptr) return OPUSGPU_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipHostUnregister(ptr));
     return OPUSGPU_OK;
 }
 

@@ -84,12 +84,22 @@ template <class T>
 struct RawBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool borrowed = false; // caller's memory (opusgpu_pages_demux_into): not freed here
     RawBuf() = default;
     RawBuf(const RawBuf &) = delete;
     RawBuf &operator=(const RawBuf &) = delete;
-    ~RawBuf() { free(p); }
+    ~RawBuf() {
+        if (!borrowed) free(p);
+    }
+    void borrow(void *mem, size_t count) {
+        if (!borrowed) free(p);
+        p = static_cast<T *>(mem);
+        n = count;
+        borrowed = true;
+    }
     void alloc(size_t count) {
-        free(p);
+        if (!borrowed) free(p);
+        borrowed = false;
         p = nullptr;
         n = count;
         const size_t bytes = (count ? count : 1) * sizeof(T), huge = (size_t)2 << 20;
@@ -217,12 +227,29 @@ struct opusgpu_page_batch {
     RawBuf<int32_t> slot_pages;       // parallel to descs
     std::vector<size_t> step_begin;   // n_steps + 1
     RawBuf<uint8_t> arena;
+    size_t arena_offset = 0; // opusgpu_pages_demux_into: where the arena begins in the caller's memory
 };
+
+static int pages_demux_impl(int n_pages, const uint8_t *const *pages, const int32_t *page_lens, const int32_t *stream_ids, int flags,
+                            int threads, opusgpu_page_info *info, opusgpu_page_batch **out, void *out_mem, size_t out_cap, size_t *out_need);
 
 int opusgpu_pages_demux(int n_pages, const uint8_t *const *pages, const int32_t *page_lens, const int32_t *stream_ids,
                         int flags, int threads, opusgpu_page_info *info, opusgpu_page_batch **out) {
+    return pages_demux_impl(n_pages, pages, page_lens, stream_ids, flags, threads, info, out, nullptr, 0, nullptr);
+}
+int opusgpu_pages_demux_into(int n_pages, const uint8_t *const *pages, const int32_t *page_lens, const int32_t *stream_ids,
+                             int flags, int threads, opusgpu_page_info *info, void *out_mem, size_t out_cap, size_t *out_need,
+                             opusgpu_page_batch **out) {
+    if (!out_mem || ((uintptr_t)out_mem & 15)) return OPUSGPU_BAD_ARG;
+    return pages_demux_impl(n_pages, pages, page_lens, stream_ids, flags, threads, info, out, out_mem, out_cap, out_need);
+}
+size_t opusgpu_page_batch_arena_offset(const opusgpu_page_batch *b) { return b ? b->arena_offset : 0; }
+
+static int pages_demux_impl(int n_pages, const uint8_t *const *pages, const int32_t *page_lens, const int32_t *stream_ids, int flags,
+                            int threads, opusgpu_page_info *info, opusgpu_page_batch **out, void *out_mem, size_t out_cap, size_t *out_need) {
     if (!out) return OPUSGPU_BAD_ARG;
     *out = nullptr;
+    if (out_need) *out_need = 0;
     if (n_pages < 0 || (n_pages > 0 && (!pages || !page_lens || !stream_ids))) return OPUSGPU_BAD_ARG;
     try {
         opusgpu_page_batch *b = new opusgpu_page_batch;
@@ -341,9 +368,21 @@ int opusgpu_pages_demux(int n_pages, const uint8_t *const *pages, const int32_t 
         timer.mark("slot numbering");
         b->step_begin.resize((size_t)n_steps + 1);
         for (int s = 0; s <= n_steps; s++) b->step_begin[s] = count[(size_t)s * G];
-        b->descs.alloc(total);
         b->slot_pages.alloc(total);
-        b->arena.alloc(arena_bytes + 16); // the kernels read packets through aligned 32-bit words: keep a tail
+        if (out_mem) { // the caller's memory: [descriptors of all steps | padding to 256 | arena + 16]
+            const size_t arena_off = ((size_t)total * sizeof(opusgpu_frame_desc) + 255) / 256 * 256, need = arena_off + arena_bytes + 16;
+            if (out_need) *out_need = need;
+            if (need > out_cap) {
+                delete b;
+                return OPUSGPU_BUFFER_TOO_SMALL;
+            }
+            b->descs.borrow(out_mem, total);
+            b->arena.borrow(static_cast<uint8_t *>(out_mem) + arena_off, arena_bytes + 16);
+            b->arena_offset = arena_off;
+        } else {
+            b->descs.alloc(total);
+            b->arena.alloc(arena_bytes + 16); // the kernels read packets through aligned 32-bit words: keep a tail
+        }
         memset(b->arena.data() + arena_bytes, 0, 16);
         timer.mark("allocate outputs");
         // pass 3: bodies and descriptors

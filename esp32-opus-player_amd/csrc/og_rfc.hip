@@ -10,7 +10,10 @@
 
 using namespace og;
 
-__global__ void __launch_bounds__(64, 1) k_decode_rfc(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena, StreamState *st,
+#ifndef OG_RFC_WAVES
+#define OG_RFC_WAVES 2 // (294 registers unbounded = one wave per SIMD; bounded to 256: 107 -> 65 ms per step of the rfc_mixed workload; 3: no gain)
+#endif
+__global__ void __launch_bounds__(64, OG_RFC_WAVES) k_decode_rfc(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena, StreamState *st,
                                                       i16 *pcm, i32 *result, int n, int n_streams, int pcm_stride) {
     const int f = (int)blockIdx.x;
     if (f >= n) return;

@@ -194,6 +194,18 @@ int opusgpu_event_create(opusgpu_ctx *ctx, void **event);
 int opusgpu_event_record(opusgpu_ctx *ctx, void *event);
 int opusgpu_event_elapsed_ms(opusgpu_ctx *ctx, void *start, void *stop, float *ms); /* synchronises on stop */
 int opusgpu_event_destroy(opusgpu_ctx *ctx, void *event);
+int opusgpu_event_synchronize(opusgpu_ctx *ctx, void *event); /* the host waits for it */
+/* Uploads NEXT TO the decode (config 5: the ingest of the next batch of Ogg pages under the decode of this one).  The copy runs on
+ * a stream of the context's own, not on the decode stream: one host thread demuxes batch b + 1 (opusgpu_pages_demux) and queues
+ * its step tables and packet bytes with opusgpu_upload_async, then records a fence; the thread that decodes lets its stream wait
+ * for that fence (opusgpu_stream_wait_event; hip_stream NULL = the context's stream) before batch b + 1's first step.  `src` must
+ * stay valid until the fence has passed (opusgpu_event_synchronize).  These four calls may come from a second host thread. */
+int opusgpu_upload_async(opusgpu_ctx *ctx, void *dst, const void *src, size_t bytes);
+int opusgpu_upload_fence(opusgpu_ctx *ctx, void *event);
+int opusgpu_stream_wait_event(opusgpu_ctx *ctx, void *event, void *hip_stream);
+/* Page-lock a caller-owned host buffer in place (and undo it): transfers from / into it need no staging copy. */
+int opusgpu_host_register(opusgpu_ctx *ctx, void *ptr, size_t bytes);
+int opusgpu_host_unregister(opusgpu_ctx *ctx, void *ptr);
 /* Copies stream `index`'s raw state record to the host (tests / checkpointing). */
 int opusgpu_stream_state_get(opusgpu_ctx *ctx, int index, void *dst, size_t bytes);
 
@@ -274,6 +286,16 @@ typedef struct opusgpu_page_batch opusgpu_page_batch; /* owns the step tables an
  * a failure of the call), OPUSGPU_BAD_ARG or OPUSGPU_ALLOC_FAIL. */
 int opusgpu_pages_demux(int n_pages, const uint8_t *const *pages, const int32_t *page_lens, const int32_t *stream_ids,
                         int flags, int threads, opusgpu_page_info *info, opusgpu_page_batch **out);
+/* The same demux with the step tables and the packet arena placed in the CALLER's memory (16-byte aligned; page-locked memory makes
+ * the batch uploadable as it lies, in one copy): out_mem = [descriptors of all steps, step after step | padding to a multiple of 256
+ * | arena + 16 bytes].  *out_need (may be NULL) receives the bytes needed; OPUSGPU_BUFFER_TOO_SMALL when out_cap is less (nothing is
+ * written then; n_pages * 16 * 255 + the pages' bytes + 512 always suffices).  The batch object still owns the per-slot page
+ * indices; opusgpu_page_batch_step / _arena point into out_mem, which must outlive the batch.  Descriptor offsets index the arena,
+ * which begins opusgpu_page_batch_arena_offset(batch) bytes into out_mem. */
+int opusgpu_pages_demux_into(int n_pages, const uint8_t *const *pages, const int32_t *page_lens, const int32_t *stream_ids,
+                             int flags, int threads, opusgpu_page_info *info, void *out_mem, size_t out_cap, size_t *out_need,
+                             opusgpu_page_batch **out);
+size_t opusgpu_page_batch_arena_offset(const opusgpu_page_batch *b);
 int opusgpu_page_batch_steps(const opusgpu_page_batch *b);
 /* Step `step`: returns its descriptor count and points *descs at the table and *slot_pages (may be NULL) at the index
  * of the input page each descriptor came from (the PCM block of slot s belongs to page (*slot_pages)[s]). */

@@ -76,6 +76,46 @@ long oc_batch_decode_var_cap(int channels, const u8 *arena, const long long *off
     return ok;
 }
 
+/* RFC mode (oc_decoder_set_rfc), with lost packets and forward error correction: entry k = f * n_streams + s is what stream s does
+ * at step f -- ops[k] 0: decode the packet arena[offs[k] .. + lens[k]);  1: the packet was LOST and is concealed for as long as
+ * the stream's last packet was (oc_decode(NULL), 20 ms before the first packet);  2: the packet was lost and is RECOVERED from the
+ * forward error correction data of the stream's NEXT packet, which is what offs[k] / lens[k] name (oc_decode_fec over the last
+ * packet's duration).  Streams [s0, s1) run on a fresh decoder each, state carried across steps.  rets: [n_streams][n_frames]
+ * return values; pcm_last (may be NULL): [n_streams][5760][channels], the output of every stream's LAST step.  Returns the
+ * number of calls that produced samples. */
+long oc_batch_decode_rfc(int channels, const u8 *arena, const long long *offs, const i32 *lens, const u8 *ops, int n_streams,
+                         int n_frames, int s0, int s1, i16 *pcm_last, i32 *rets) {
+    oc_decoder *d = oc_decoder_create(channels);
+    i16 *tmp = (i16 *)malloc(sizeof(i16) * 5760 * 2);
+    long ok = 0;
+    int s, f;
+    if (!d || !tmp) return -1;
+    for (s = s0; s < s1; s++) {
+        int last_dur = 960;
+        oc_decoder_init(d, channels);
+        oc_decoder_set_rfc(d, 1);
+        for (f = 0; f < n_frames; f++) {
+            const size_t k = (size_t)f * n_streams + s;
+            int r;
+            if (ops[k] == 1)
+                r = oc_decode(d, NULL, 0, tmp, last_dur);
+            else if (ops[k] == 2)
+                r = oc_decode_fec(d, arena + offs[k], lens[k], tmp, last_dur);
+            else {
+                r = oc_decode(d, arena + offs[k], lens[k], tmp, 5760);
+                if (r > 0) last_dur = r;
+            }
+            rets[(size_t)s * n_frames + f] = r;
+            if (r > 0) ok++;
+            if (pcm_last && f == n_frames - 1 && r > 0 && r <= 5760)
+                memcpy(pcm_last + (size_t)s * 5760 * channels, tmp, sizeof(i16) * (size_t)r * channels);
+        }
+    }
+    free(tmp);
+    oc_decoder_destroy(d);
+    return ok;
+}
+
 /* stage taps for parity tests of the HIP kernels: enable once, then copy after each oc_decode() call */
 int oc_taps_enable(oc_decoder *d) {
     if (!d->taps) d->taps = (oc_celt_taps *)calloc(1, sizeof(oc_celt_taps));

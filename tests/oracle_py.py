@@ -99,6 +99,35 @@ class Oracle:
             x.join()
         return pcm, rets
 
+    def batch_decode_rfc(self, channels, arena, offs, lens, ops, threads=None, want_pcm=True):
+        """RFC mode with losses (oracle/oc_batch.c oc_batch_decode_rfc): offs / lens / ops [frames, streams]; ops 0 decode, 1 lost
+        (concealed), 2 lost and recovered from the next packet's FEC data (offs / lens name THAT packet).
+        -> (pcm of every stream's last step int16 [streams, 5760, ch] or None, return values int32 [streams, frames])."""
+        import threading
+        nf, ns = offs.shape
+        threads = max(1, min(threads or usable_cpus(), ns))
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        ops = np.ascontiguousarray(ops, dtype=np.uint8)
+        pcm = np.zeros((ns, 5760, channels), dtype=np.int16) if want_pcm else None
+        rets = np.zeros((ns, nf), dtype=np.int32)
+        fn = self.lib.oc_batch_decode_rfc
+        fn.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 2
+        fn.restype = C.c_long
+        cuts = [ns * t // threads for t in range(threads + 1)]
+
+        def work(t):
+            fn(channels, arena.ctypes.data, offs.ctypes.data, lens.ctypes.data, ops.ctypes.data, ns, nf, cuts[t], cuts[t + 1],
+               pcm.ctypes.data if want_pcm else None, rets.ctypes.data)
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        return pcm, rets
+
     def decoder(self, channels):
         return OracleDecoder(self, channels)
 

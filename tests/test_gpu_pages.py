@@ -296,3 +296,65 @@ def test_demux_with_gpu_checksums_equals_demux_with_host_checksums(pkg, gpu_ctx)
         b.close()
     finally:
         ctx.dev_free(d_blob)
+
+
+def _ingest_mod(pkg):
+    import sys
+    name = pkg.__name__ + ".ingest"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "esp32-opus-player_amd", "ingest.py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("n,depth", [(3 * 2048, 2), (3 * 700, 3)])
+def test_overlapped_ingest_matches_the_oracle(pkg, oracle, gpu_ctx, n, depth):
+    """esp32-opus-player_amd/ingest.py: five batches of one page per stream, demuxed and uploaded by a second host thread on the copy
+    stream while the batch before decodes (ring of `depth` device slots, so slots are reused); after every batch the PCM of its
+    last step -- which depends on every step before it -- is compared with the oracle, every stream, every sample."""
+    ctx = gpu_ctx
+    modes = ((pkg.TOC_SILK_NB_STEREO, 40), (pkg.TOC_HYBRID_FB_STEREO, 120), (pkg.TOC_CELT_FB_STEREO, 160))
+    nb, ppp = 5, 4
+    frames = nb * ppp
+    ids_of = [np.arange(m, n, 3, dtype=np.int32) for m in range(3)]
+    ref, per_batch = [None] * 3, [[] for _ in range(nb)]
+    for m, (toc, L) in enumerate(modes):
+        pay = pkg.lcg_payloads(len(ids_of[m]), frames, L, seed_base=0x1234567 + m)
+        ref[m], ok = oracle.batch_decode_threads(2, toc, pay)
+        assert ok == len(ids_of[m]) * frames
+        for q in range(nb):
+            per_batch[q].append((pkg.build_pages(toc, pay[q * ppp:(q + 1) * ppp], ids_of[m].astype(np.uint32) + 5, seqno=2 + q), ids_of[m]))
+    batches = []
+    for q in range(nb):
+        blob = np.concatenate([pg.reshape(-1) for pg, _ in per_batch[q]])
+        lens = np.concatenate([np.full(pg.shape[0], pg.shape[1], dtype=np.int32) for pg, _ in per_batch[q]])
+        offs = np.concatenate([[0], np.cumsum(lens.astype(np.int64))[:-1]])
+        batches.append((blob, offs, lens, np.concatenate([i for _, i in per_batch[q]])))
+    ctx.streams_alloc(n, 2)
+    d_pcm, d_res = ctx.dev_alloc(n * 960 * 2 * 2), ctx.dev_alloc(4 * n)
+    pipe = _ingest_mod(pkg).OverlappedPageDecode(ctx, threads=3, depth=depth)
+    seen = []
+
+    def check(b):  # (called on the decoding thread between batches: reading back waits for the batch's steps)
+        out, res = np.zeros((n, 960, 2), dtype=np.int16), np.zeros(n, dtype=np.int32)
+        ctx.d2h(out, d_pcm)
+        ctx.d2h(res, d_res)
+        assert (res == 960).all()
+        k = (b + 1) * ppp - 1
+        # step tables are grouped by mode, streams in page order within a mode: SILK-NB, hybrid, CELT
+        order = np.concatenate(ids_of)
+        for m in range(3):
+            slots = np.nonzero(order % 3 == m)[0]
+            assert np.array_equal(out[slots], ref[m][order[slots] // 3, k]), (b, m)
+        seen.append(b)
+
+    try:
+        st = pipe.run(batches, d_pcm, d_res, on_batch_done=check)
+    finally:
+        pipe.close()
+        ctx.dev_free(d_pcm)
+        ctx.dev_free(d_res)
+    assert seen == list(range(nb)) and st["steps"] == frames and st["pages"] == nb * n

@@ -61,3 +61,41 @@ def test_threaded_batch_decode_matches_single_thread(pkg, oracle):
         many, okn = oracle.batch_decode_threads(2, toc, pay, threads=5)
         assert ok1 == okn == 37 * 3
         assert (one == many).all()
+
+
+def test_rfc_batch_matches_one_decoder_per_stream(oracle):
+    """oc_batch_decode_rfc (bench.py's rfc workload: checker and CPU baseline) against the same calls made one by one: every
+    configuration, lost packets concealed, lost packets recovered from the next packet's forward error correction data"""
+    import ctypes as C
+    from rfc_common import dur, make_packet
+    rng = np.random.default_rng(5)
+    n, F = 64, 6
+    pk = [[make_packet(rng, s % 32, True, 0, int(rng.choice([20, 60, 120]))) for s in range(n)] for _ in range(F + 1)]
+    ops = (rng.random((F, n)) < 0.25).astype(np.uint8)
+    ops[0] = 0
+    ops[(ops == 1) & (rng.random((F, n)) < 0.5)] = 2
+    arena, offs, lens = bytearray(), np.zeros((F, n), dtype=np.int64), np.zeros((F, n), dtype=np.int32)
+    for f in range(F):
+        for s in range(n):
+            p = pk[f + 1][s] if ops[f, s] == 2 else (b"" if ops[f, s] == 1 else pk[f][s])
+            offs[f, s], lens[f, s] = len(arena), len(p)
+            arena += p
+    pcm, rets = oracle.batch_decode_rfc(2, np.frombuffer(bytes(arena), dtype=np.uint8), offs, lens, ops, threads=3)
+    oracle.lib.oc_decode_fec.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_int]
+    for s in range(n):
+        d = oracle.decoder(2)
+        d.init()
+        d.set_rfc(True)
+        last = 960
+        for f in range(F):
+            if ops[f, s] == 1:
+                out, r = d.conceal(last)
+            elif ops[f, s] == 2:
+                r = oracle.lib.oc_decode_fec(d.h, pk[f + 1][s], len(pk[f + 1][s]), d.buf.ctypes.data, last)
+                out = d.buf
+            else:
+                out, r = d.decode(pk[f][s])
+                last = r if r > 0 else last
+            assert rets[s, f] == r, (s, f, int(ops[f, s]))
+        if r > 0:
+            assert r == dur(pk[0][s][0]) and np.array_equal(pcm[s, :r], out[:r]), s

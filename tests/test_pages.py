@@ -207,3 +207,38 @@ def test_slot_order_is_the_stable_order_for_any_thread_count(pkg, id_scale):
         if b is not b1:
             b.close()
     b1.close()
+
+
+def test_demux_into_caller_memory_makes_the_same_tables_and_arena(pkg):
+    """opusgpu_pages_demux_into (the overlapped ingest's demux: output in the caller's page-locked slot, uploadable in one copy)
+    against opusgpu_pages_demux; a slot that is too small is reported with the size needed and left untouched."""
+    n, ppp = 300, 7
+    parts = []
+    for m, (toc, L) in enumerate(((pkg.TOC_SILK_NB_STEREO, 40), (pkg.TOC_HYBRID_FB_STEREO, 120), (pkg.TOC_CELT_FB_STEREO, 160))):
+        ids = np.arange(m, n, 3, dtype=np.int32)
+        pay = pkg.lcg_payloads(len(ids), ppp, L, seed_base=99 + m)
+        parts.append((pkg.build_pages(toc, pay, ids.astype(np.uint32) + 3), ids))
+    blob = np.concatenate([pg.reshape(-1) for pg, _ in parts])
+    lens = np.concatenate([np.full(pg.shape[0], pg.shape[1], dtype=np.int32) for pg, _ in parts])
+    offs = np.concatenate([[0], np.cumsum(lens.astype(np.int64))[:-1]])
+    ids = np.concatenate([i for _, i in parts])
+    a = pkg.PageBatch(blob, offs, lens, ids, threads=2)
+    small = np.full(1024, 0xAB, dtype=np.uint8)
+    with pytest.raises(pkg.BufferTooSmall) as e:
+        pkg.PageBatch(blob, offs, lens, ids, threads=2, out_mem=small)
+    assert (small == 0xAB).all()
+    raw = np.zeros(e.value.need + 64, dtype=np.uint8)
+    mem = raw[(-raw.ctypes.data) % 16:][:e.value.need]
+    b = pkg.PageBatch(blob, offs, lens, ids, threads=2, out_mem=mem)
+    assert b.n_steps == a.n_steps == ppp and np.array_equal(a.info, b.info)
+    assert b.arena_offset % 256 == 0 and b.image.nbytes == e.value.need
+    assert np.array_equal(a.arena, b.arena) and np.array_equal(b.arena, mem[b.arena_offset:b.arena_offset + b.arena.size])
+    at = 0
+    for k in range(ppp):
+        da, pa = a.step(k)
+        db, pb_ = b.step(k)
+        assert np.array_equal(da, db) and np.array_equal(pa, pb_)
+        assert np.array_equal(mem[at:at + 16 * len(db)].view(pkg.DESC_DTYPE), db)  # tables lie step after step from the start
+        at += 16 * len(db)
+    a.close()
+    b.close()

@@ -1,7 +1,12 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/prof_pmc.sh <tag> [bench args...]
 # Runs the bench under rocprofv3: one kernel-trace/stats pass and several separate --pmc passes (never combined
-# with other trace domains), then prints the per-launch averages of k_decode_step.  Output: gpurun_out/<tag>/
+# with other trace domains), then prints the per-launch averages of the decode kernels.  Output: gpurun_out/<tag>/
+# The --pmc passes run the steps IN ORDER (--pipeline off): counter collection serialises kernel dispatches, and a windowed
+# pipelined step holds its reconstruction behind a stream memory wait for the NEXT step's parse kernel to start -- which a
+# serialised queue never lets happen (the pass would sit in that wait until its timeout).  Counters per kernel do not depend on
+# what runs next to it; durations next to the neighbours come from the kernel-trace pass, which runs the default (pipelined) bench.
+# PROF_FRAMES: frames per launch for the per-frame figures (default 65536).
 tag=$1; shift
 out=$PWD/gpurun_out/$tag
 mkdir -p $out
@@ -17,6 +22,6 @@ for set in \
   "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT TCC_MISS TCC_EA0_RDREQ TCC_EA0_WRREQ" ; do
   i=$((i+1))
   echo "pmc pass $i: $set"
-  timeout -k 5 150 rocprofv3 --pmc $set --output-format csv -d $out/pmc$i -o p -- python3 bench.py $args > $out/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -3 $out/pmc$i.log; }
+  timeout -k 5 150 rocprofv3 --pmc $set --output-format csv -d $out/pmc$i -o p -- python3 bench.py $args --pipeline off > $out/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -3 $out/pmc$i.log; exit 1; }
 done
-python3 tools/pmc_summary.py $out | tee $out/summary.txt
+python3 tools/pmc_summary.py $out ${PROF_FRAMES:-65536} | tee $out/summary.txt
