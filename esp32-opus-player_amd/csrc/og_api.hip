@@ -9,7 +9,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sched.h>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <new>
 #include <mutex>
@@ -581,6 +585,65 @@ __global__ void __launch_bounds__(64) k_celt_post(const FrameDesc *__restrict__ 
 }
 
 // ---- context ----------------------------------------------------------------------------------------
+// Worker threads of the host-buffer path, started once per context: a large opusgpu_decode_packets call hands them ranges of its
+// packets four times (scan, place per part, delivery); starting 16 threads each time cost 0.6 ms per hand-over at 65,536 packets.
+struct HostPool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable wake, done;
+    std::function<void(int)> job;
+    int generation = 0, want = 0, pending = 0;
+    bool quit = false;
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> l(m);
+            quit = true;
+        }
+        wake.notify_all();
+        for (auto &t : th) t.join();
+    }
+    void worker(int id) {
+        int seen = 0;
+        for (;;) {
+            std::function<void(int)> f;
+            {
+                std::unique_lock<std::mutex> l(m);
+                wake.wait(l, [&] { return quit || (generation != seen && id < want); });
+                if (quit) return;
+                seen = generation;
+                f = job;
+            }
+            f(id);
+            {
+                std::lock_guard<std::mutex> l(m);
+                if (--pending == 0) done.notify_all();
+            }
+        }
+    }
+    // f(t) for t = 0 .. count - 1, t = 0 on the calling thread; returns when all are through
+    void run(int count, const std::function<void(int)> &f) {
+        if (count <= 1) {
+            f(0);
+            return;
+        }
+        while ((int)th.size() < count - 1) {
+            const int id = (int)th.size();
+            th.emplace_back([this, id] { worker(id); });
+        }
+        {
+            std::lock_guard<std::mutex> l(m);
+            job = [&f](int id) { f(id + 1); };
+            want = count - 1;
+            pending = count - 1;
+            generation++;
+        }
+        wake.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> l(m);
+        done.wait(l, [&] { return pending == 0; });
+    }
+};
+
 struct opusgpu_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -593,13 +656,19 @@ struct opusgpu_ctx {
     // a fresh temporary per call); the caller's pageable buffer is filled from it by a few host threads
     void *h_pcm = nullptr, *h_res = nullptr;
     size_t cap_h_pcm = 0, cap_h_res = 0;
+    // ... and of the way in: the call's packet bytes and step table are gathered in page-locked memory that lives as long as the
+    // context (a fresh 10 MB allocation per call is 2,600 page faults in front of the first upload, and a copy from pageable
+    // memory holds the calling thread until the runtime has staged it)
+    void *h_arena = nullptr, *h_descs = nullptr;
+    size_t cap_h_arena = 0, cap_h_descs = 0;
+    HostPool pool;
     u32 *d_crc_tables = nullptr; // 8 x 256 words, made on first use (opusgpu_pages_crc_device)
     hipEvent_t ev_piece[OPUSGPU_COPY_PIECES] = {}; // one per piece of the PCM's way back to the host (opusgpu_decode_packets)
     // large batches on the host-buffer path run in parts: a part's PCM travels back (on a stream of its own) while the next
     // part's kernels run
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_part[OPUSGPU_COPY_PIECES] = {};
-    int host_parts = 2; // OPUSGPU_HOST_PARTS=1: one batch, copy after the kernels (A/B measurements); 2, 4, 8, 16
+    int host_parts = 8; // OPUSGPU_HOST_PARTS=1: one batch, copy after the kernels (A/B measurements); 2, 4, 8, 16
     // parse records of the split CELT path (one per frame of a step), grown on demand
     void *d_recs[3] = {}, *d_rout[3] = {}, *d_leaf[3] = {}, *d_handoff = nullptr, *d_srecs = nullptr; // (three sets: pipelined steps rotate)
     size_t cap_recs[3] = {}, cap_rout[3] = {}, cap_leaf[3] = {}, cap_handoff = 0, cap_srecs = 0;
@@ -652,11 +721,11 @@ static int fail(opusgpu_ctx *ctx, int code, const char *what, hipError_t e) {
 // OPUSGPU_HOST_TIMING=1: wall time of the phases of opusgpu_decode_packets on stderr (adds a stream synchronise after the
 // kernels so that decode and copy-back can be told apart; for tuning only)
 struct HostPhaseTimer {
-    bool on;
+    bool on, light; // on: OPUSGPU_HOST_TIMING=1, the one-batch flow with a wait after the kernels; light (=2): the flow as it is
     std::chrono::steady_clock::time_point t;
-    HostPhaseTimer() : on(og_debug().host_timing != 0), t(std::chrono::steady_clock::now()) {}
+    HostPhaseTimer() : on(og_debug().host_timing == 1), light(og_debug().host_timing == 2), t(std::chrono::steady_clock::now()) {}
     void mark(const char *what) {
-        if (!on) return;
+        if (!on && !light) return;
         const auto now = std::chrono::steady_clock::now();
         fprintf(stderr, "[opusgpu_decode_packets] %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
         t = now;
@@ -719,6 +788,8 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     (void)hipFree(ctx->d_srecs);
     (void)hipHostFree(ctx->h_pcm);
     (void)hipHostFree(ctx->h_res);
+    (void)hipHostFree(ctx->h_arena);
+    (void)hipHostFree(ctx->h_descs);
     (void)hipFree(ctx->d_crc_tables);
     (void)hipFree(ctx->d_started);
     for (hipEvent_t e : ctx->ev_piece)
@@ -876,8 +947,16 @@ static void launch_jitter() {
 }
 // `next_n` (steps queued as a window, opusgpu_decode_steps_device): the number of frames of the step that the same call queues
 // right behind this one with the same mode mask, 0 when there is none or it is not known.
+// `slices` (opusgpu_decode_packets: PCM that leaves in pieces): the step's entropy kernels run once over all n frames -- they wait
+// on latency, a fraction of the frames takes them as long as all -- and the arithmetic kernels slice by slice, frames
+// [bounds[i], bounds[i + 1]); after_slice(i) is called behind slice i's last launch (to queue that slice's copies).
+struct StepSlices {
+    int count = 0;
+    const size_t *bounds = nullptr;
+    std::function<int(int)> after_slice;
+};
 static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm, void *d_result,
-                            void *hip_stream, bool tables_resident, int modes = 7, int next_n = 0) {
+                            void *hip_stream, bool tables_resident, int modes = 7, int next_n = 0, const StepSlices *slices = nullptr) {
     if (!ctx || n < 0 || !ctx->d_streams) return OPUSGPU_BAD_ARG;
     if (n == 0) return OPUSGPU_OK;
     if (!d_descs || !d_arena || !d_pcm || !d_result) return OPUSGPU_BAD_ARG;
@@ -929,20 +1008,21 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     const int par = pipe ? ctx->slot : 0, par2 = (par + 1) % 3; // this step's slot; the slot of the step two before it
     {
         int rc;
-        if (ctx->cap_recs[par] < sizeof(ParseRec) * (size_t)n &&
-            (rc = grow(ctx, &ctx->d_recs[par], &ctx->cap_recs[par], sizeof(ParseRec) * (size_t)n)))
+        const size_t need = (size_t)n;
+        if (ctx->cap_recs[par] < sizeof(ParseRec) * need &&
+            (rc = grow(ctx, &ctx->d_recs[par], &ctx->cap_recs[par], sizeof(ParseRec) * need)))
             return rc;
-        if (ctx->cap_rout[par] < sizeof(ReconOut) * (size_t)n &&
-            (rc = grow(ctx, &ctx->d_rout[par], &ctx->cap_rout[par], sizeof(ReconOut) * (size_t)n)))
+        if (ctx->cap_rout[par] < sizeof(ReconOut) * need &&
+            (rc = grow(ctx, &ctx->d_rout[par], &ctx->cap_rout[par], sizeof(ReconOut) * need)))
             return rc;
-        if (ctx->fast_recon && ctx->leaf_kernel && any_celt && ctx->cap_leaf[par] < og_leaf_out_bytes() * (size_t)n &&
-            (rc = grow(ctx, &ctx->d_leaf[par], &ctx->cap_leaf[par], og_leaf_out_bytes() * (size_t)n)))
+        if (ctx->fast_recon && ctx->leaf_kernel && any_celt && ctx->cap_leaf[par] < og_leaf_out_bytes() * need &&
+            (rc = grow(ctx, &ctx->d_leaf[par], &ctx->cap_leaf[par], og_leaf_out_bytes() * need)))
             return rc;
         if (ctx->split_hybrid && any_silk) {
-            if (ctx->cap_handoff < sizeof(SilkHandoff) * (size_t)n &&
-                (rc = grow(ctx, &ctx->d_handoff, &ctx->cap_handoff, sizeof(SilkHandoff) * (size_t)n)))
+            if (ctx->cap_handoff < sizeof(SilkHandoff) * need &&
+                (rc = grow(ctx, &ctx->d_handoff, &ctx->cap_handoff, sizeof(SilkHandoff) * need)))
                 return rc;
-            if (ctx->cap_srecs < sizeof(SilkRec) * (size_t)n && (rc = grow(ctx, &ctx->d_srecs, &ctx->cap_srecs, sizeof(SilkRec) * (size_t)n)))
+            if (ctx->cap_srecs < sizeof(SilkRec) * need && (rc = grow(ctx, &ctx->d_srecs, &ctx->cap_srecs, sizeof(SilkRec) * need)))
                 return rc;
         }
     }
@@ -952,58 +1032,91 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     SilkRec *const srecs = ctx->split_hybrid && any_silk ? (SilkRec *)ctx->d_srecs : nullptr;
     ctx->last_recs = recs;
     ctx->last_had_silk_recs = srecs != nullptr;
-    const dim3 parse_grid((n + OG_PL_FRAMES - 1) / OG_PL_FRAMES), parse_block(64 * OG_PL_WAVES);
-    if (!pipe && srecs && n >= 2 * OG_HALVES_MIN && og_debug().halves) {
-        // TWO HALVES.  A step with SILK-only / hybrid frames runs in order -- k_silk_parse reads state the step's later kernels
-        // write, so nothing of the next step can start early -- and its kernels are of two kinds: the lane-per-frame parse
-        // kernels wait on latency with 13 % of their lanes active (k_silk_parse: 3.97 of a 15.4 ms step of 262,144 hybrid
-        // frames), the wave-per-frame ones are bound by vector-instruction issue.  The frames of a step belong to different
-        // streams and share nothing, so the step is cut in two and the halves' chains run on two streams: while one half's
-        // synthesis fills the SIMDs the other half parses in its gaps.  No state changes hands: each half is the in-order chain
-        // of its own frames over its own part of the records; the caller's stream forks the second one and joins it.
-        if (!ctx->ev_fork) {
-            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-        }
-        // (the second chain's stream: the one pipelined steps reconstruct on when there is one -- it is idle here, the caller's
-        // stream has waited for everything on it -- rather than one more: measured with a fourth stream of the context, the two
-        // chains no longer overlapped at all, 2.14 instead of 1.89 ms per SILK-NB step; the hardware queues are few)
-        if (!ctx->recon_stream && !ctx->side_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-        hipStream_t const side = ctx->recon_stream ? ctx->recon_stream : ctx->side_stream;
-        // (Both chains start together.  Staggered -- the second one behind the first one's parse kernels, so that one half parses
-        // while the other synthesises from the start -- was measured SLOWER, 14.9 against 14.5 ms per step of 262,144 hybrid
-        // frames and 2.44 against 1.90 ms per SILK-NB step: half a batch's parse takes as long as a whole batch's.)
-        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
-        HIPCHK(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
-        const int h = (n / 2 + 63) / 64 * 64; // (a multiple of the parse kernels' frames per workgroup)
-        for (int half = 0; half < 2; half++) {
-            hipStream_t q = half ? side : s;
-            const int f0 = half ? h : 0, cnt = half ? n - h : h;
-            const FrameDesc *dd = (const FrameDesc *)d_descs + f0;
-            i16 *pp = (i16 *)d_pcm + (size_t)f0 * pcm_stride;
-            i32 *rr = (i32 *)d_result + f0;
+    const dim3 parse_block(64 * OG_PL_WAVES);
+    // The in-order chain of frames [f0, f0 + cnt) of the step, in two halves: the ENTROPY kernels (one frame per lane) ...
+    auto front = [&](hipStream_t q, size_t f0, int cnt) {
+        const FrameDesc *dd = (const FrameDesc *)d_descs + f0;
+        if (srecs)
             hipLaunchKernelGGL(k_silk_parse, dim3((cnt + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, q, dd, (const u8 *)d_arena,
                                (const StreamState *)ctx->d_streams, srecs + f0, handoff + f0, cnt, ctx->n_streams);
-            if (any_celt)
-                hipLaunchKernelGGL(k_celt_parse, dim3((cnt + OG_PL_FRAMES - 1) / OG_PL_FRAMES), parse_block, 0, q, dd, (const u8 *)d_arena,
-                                   ctx->d_streams, recs + f0, cnt, ctx->n_streams, (const SilkHandoff *)(handoff + f0), (int)PARSE_ALL, 1, (u32 *)nullptr);
+        if (any_celt)
+            hipLaunchKernelGGL(k_celt_parse, dim3((cnt + OG_PL_FRAMES - 1) / OG_PL_FRAMES), parse_block, 0, q, dd, (const u8 *)d_arena,
+                               ctx->d_streams, recs + f0, cnt, ctx->n_streams, (const SilkHandoff *)(handoff ? handoff + f0 : nullptr),
+                               (int)PARSE_ALL, 1, (u32 *)nullptr);
+    };
+    // ... and the ARITHMETIC ones (one frame per wave), which also write the PCM and the result codes
+    auto back_half = [&](hipStream_t q, size_t f0, int cnt) {
+        const FrameDesc *dd = (const FrameDesc *)d_descs + f0;
+        i16 *pp = (i16 *)d_pcm + f0 * (size_t)pcm_stride;
+        i32 *rr = (i32 *)d_result + f0;
+        const SilkHandoff *hh = handoff ? handoff + f0 : nullptr;
+        bool others = false; // (the kernels that report stream-index errors for every mode)
+        if (srecs) { // SILK-only frames and the SILK half of hybrid frames
             hipLaunchKernelGGL(k_silk_synth, dim3(cnt), dim3(64), 0, q, dd, (const u8 *)d_arena, ctx->d_streams, pp, rr, cnt, ctx->n_streams,
                                pcm_stride, handoff + f0, (const SilkRec *)(srecs + f0));
-            if (any_celt) {
-                if (ctx->fast_recon)
-                    og_launch_celt_recon_fb(q, dd, ctx->d_streams, recs + f0, rout + f0, cnt, ctx->n_streams, 1, nullptr, nullptr);
-                hipLaunchKernelGGL(k_celt_recon, dim3(ctx->fast_recon ? (cnt + 63) / 64 : cnt), dim3(64), 0, q, dd, ctx->d_streams,
-                                   (const ParseRec *)(recs + f0), rout + f0, cnt, ctx->n_streams, 1, ctx->fast_recon);
-            }
-            hipLaunchKernelGGL(k_celt_post, dim3((cnt * ctx->channels + 63) / 64), dim3(64), 0, q, dd, ctx->d_streams, (const ParseRec *)(recs + f0),
-                               (const ReconOut *)(rout + f0), rr, pp, cnt, ctx->n_streams, ctx->channels, pcm_stride,
-                               (const SilkHandoff *)(handoff + f0), modes, 1);
-            if (modes & 1)
-                hipLaunchKernelGGL(k_decode_step, dim3((cnt + 63) / 64), dim3(64), 0, q, dd, (const u8 *)d_arena, ctx->d_streams, pp, rr, cnt,
-                                   ctx->n_streams, pcm_stride, 1, handoff + f0, (const SilkRec *)(srecs + f0), 1);
+            others = true;
+        } else if (any_silk) { // every frame that is not CELT-only (OPUSGPU_SPLIT_HYBRID=0)
+            hipLaunchKernelGGL(k_decode_step, dim3(cnt), dim3(64), 0, q, dd, (const u8 *)d_arena, ctx->d_streams, pp, rr, cnt, ctx->n_streams,
+                               pcm_stride, 1, nullptr, nullptr, 0);
+            others = true;
         }
-        HIPCHK(ctx, hipEventRecord(ctx->ev_join, side));
-        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+        if (any_celt) {
+            if (ctx->fast_recon) {
+                void *const leaves = ctx->leaf_kernel ? (void *)((uint8_t *)ctx->d_leaf[par] + og_leaf_out_bytes() * f0) : nullptr;
+                if (leaves) og_launch_celt_leaves(q, dd, recs + f0, leaves, cnt, ctx->n_streams, handoff ? 1 : 0);
+                og_launch_celt_recon_fb(q, dd, ctx->d_streams, recs + f0, rout + f0, cnt, ctx->n_streams, handoff ? 1 : 0, nullptr, leaves);
+            }
+            hipLaunchKernelGGL(k_celt_recon, dim3(ctx->fast_recon ? (cnt + 63) / 64 : cnt), dim3(64), 0, q, dd, ctx->d_streams,
+                               (const ParseRec *)(recs + f0), rout + f0, cnt, ctx->n_streams, handoff ? 1 : 0, ctx->fast_recon);
+        }
+        if (any_celt || !others || modes != 7)
+            hipLaunchKernelGGL(k_celt_post, dim3((cnt * ctx->channels + 63) / 64), dim3(64), 0, q, dd, ctx->d_streams, (const ParseRec *)(recs + f0),
+                               (const ReconOut *)(rout + f0), rr, pp, cnt, ctx->n_streams, ctx->channels, pcm_stride, hh, modes, others ? 1 : 0);
+        if (srecs && (modes & 1)) // the rare hybrid -> SILK-only transition frames (Q4), parked by k_silk_synth, through the full kernel
+            hipLaunchKernelGGL(k_decode_step, dim3((cnt + 63) / 64), dim3(64), 0, q, dd, (const u8 *)d_arena, ctx->d_streams, pp, rr, cnt,
+                               ctx->n_streams, pcm_stride, 1, handoff + f0, (const SilkRec *)(srecs + f0), 1);
+    };
+    if (!pipe) {
+        if (!slices && srecs && n >= 2 * OG_HALVES_MIN && og_debug().halves) {
+            // TWO HALVES.  A step with SILK-only / hybrid frames runs in order -- k_silk_parse reads state the step's later kernels
+            // write, so nothing of the next step can start early -- and its kernels are of two kinds: the lane-per-frame parse
+            // kernels wait on latency with 13 % of their lanes active (k_silk_parse: 3.97 of a 15.4 ms step of 262,144 hybrid
+            // frames), the wave-per-frame ones are bound by vector-instruction issue.  The frames of a step belong to different
+            // streams and share nothing, so the step is cut in two and the halves' chains run on two streams: while one half's
+            // synthesis fills the SIMDs the other half parses in its gaps.  No state changes hands: each half is the in-order chain
+            // of its own frames over its own part of the records; the caller's stream forks the second one and joins it.
+            if (!ctx->ev_fork) {
+                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+            }
+            // (the second chain's stream: the one pipelined steps reconstruct on when there is one -- it is idle here, the caller's
+            // stream has waited for everything on it -- rather than one more: measured with a fourth stream of the context, the two
+            // chains no longer overlapped at all, 2.14 instead of 1.89 ms per SILK-NB step; the hardware queues are few)
+            if (!ctx->recon_stream && !ctx->side_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            hipStream_t const side = ctx->recon_stream ? ctx->recon_stream : ctx->side_stream;
+            // (Both chains start together.  Staggered -- the second one behind the first one's parse kernels, so that one half parses
+            // while the other synthesises from the start -- was measured SLOWER, 14.9 against 14.5 ms per step of 262,144 hybrid
+            // frames and 2.44 against 1.90 ms per SILK-NB step: half a batch's parse takes as long as a whole batch's.)
+            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
+            HIPCHK(ctx, hipStreamWaitEvent(side, ctx->ev_fork, 0));
+            const int h = (n / 2 + 63) / 64 * 64; // (a multiple of the parse kernels' frames per workgroup)
+            front(s, 0, h);
+            back_half(s, 0, h);
+            front(side, (size_t)h, n - h);
+            back_half(side, (size_t)h, n - h);
+            HIPCHK(ctx, hipEventRecord(ctx->ev_join, side));
+            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+        } else if (slices && slices->count > 1) {
+            front(s, 0, n);
+            for (int i = 0; i < slices->count; i++) {
+                const size_t lo = slices->bounds[i], hi = slices->bounds[i + 1];
+                if (hi > lo) back_half(s, lo, (int)(hi - lo));
+                if (int rc = slices->after_slice(i)) return rc;
+            }
+        } else {
+            front(s, 0, n);
+            back_half(s, 0, n);
+        }
         HIPCHK(ctx, hipGetLastError());
         if (ctx->pipeline) { // (a step that ran in order: whatever a later pipelined step runs ahead waits for all of it)
             HIPCHK(ctx, hipEventRecord(ctx->ev_front, s));
@@ -1039,99 +1152,53 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     // launches the dependent kernel waits on that count (hipStreamWaitValue32) -- placement does not depend on how long a launch
     // or an event takes to arrive.  A single step (opusgpu_decode_step_device) cannot know whether another follows: its kernels
     // are released by their data dependencies alone.
-    if (!pipe) {
-        if (srecs)
-            hipLaunchKernelGGL(k_silk_parse, dim3((n + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, s, (const FrameDesc *)d_descs,
-                               (const u8 *)d_arena, (const StreamState *)ctx->d_streams, srecs, handoff, n, ctx->n_streams);
-        if (any_celt)
-            hipLaunchKernelGGL(k_celt_parse, parse_grid, parse_block, 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams,
-                               recs, n, ctx->n_streams, (const SilkHandoff *)handoff, (int)PARSE_ALL, 1, (u32 *)nullptr);
-    } else {
-        // the early parse: behind the front of the step before and its own slot's last user (three steps back)
-        if (ctx->front_recorded) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_front, 0));
-        if (ctx->post_recorded[par]) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_post[par], 0));
-        {
-            const int grid = (n + OG_PL_FRAMES * ctx->parse_groups - 1) / (OG_PL_FRAMES * ctx->parse_groups);
-            launch_jitter();
-            hipLaunchKernelGGL(k_celt_parse, dim3(grid), parse_block, 0, ctx->parse_stream, (const FrameDesc *)d_descs, (const u8 *)d_arena,
-                               ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)nullptr, (int)PARSE_CELT_ONLY, ctx->parse_groups,
-                               ctx->d_started);
-            ctx->parse_started_total += (u32)grid;
-        }
-        HIPCHK(ctx, hipEventRecord(ctx->ev_parsed, ctx->parse_stream));
+    // (from here on: a pipelined step -- CELT-only frames, no SILK records, no hand-off)
+    // the early parse: behind the front of the step before and its own slot's last user (three steps back)
+    if (ctx->front_recorded) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_front, 0));
+    if (ctx->post_recorded[par]) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_post[par], 0));
+    {
+        const int grid = (n + OG_PL_FRAMES * ctx->parse_groups - 1) / (OG_PL_FRAMES * ctx->parse_groups);
+        launch_jitter();
+        hipLaunchKernelGGL(k_celt_parse, dim3(grid), parse_block, 0, ctx->parse_stream, (const FrameDesc *)d_descs, (const u8 *)d_arena,
+                           ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)nullptr, (int)PARSE_CELT_ONLY, ctx->parse_groups,
+                           ctx->d_started);
+        ctx->parse_started_total += (u32)grid;
     }
-    bool others_ran = false; // (the kernels that report stream-index errors for every mode)
-    if (srecs) {
-        // SILK-only frames and the SILK half of hybrid frames: arithmetic half, one frame per wave
-        hipLaunchKernelGGL(k_silk_synth, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams,
-                           (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, handoff, (const SilkRec *)srecs);
-        others_ran = true;
-    } else if (any_silk) {
-        // every frame that is not CELT-only (OPUSGPU_SPLIT_HYBRID=0)
-        hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams,
-                           (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, 1, nullptr, nullptr, 0);
-        others_ran = true;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_parsed, ctx->parse_stream));
+    hipStream_t const back = ctx->recon_stream;
+    HIPCHK(ctx, hipStreamWaitEvent(back, ctx->ev_parsed, 0));
+    if (ctx->post_recorded[par2]) HIPCHK(ctx, hipStreamWaitEvent(back, ctx->ev_post[par2], 0)); // (the ring: 2 x 960 of 2048)
+    if (window) { // ... and every workgroup of the next step's parse has its place
+        const int next_grid = (next_n + OG_PL_FRAMES * ctx->parse_groups - 1) / (OG_PL_FRAMES * ctx->parse_groups);
+        HIPCHK(ctx, hipStreamWaitValue32(back, ctx->d_started, ctx->parse_started_total + (u32)next_grid, hipStreamWaitValueGte, 0xffffffffu));
     }
-    auto q4_pass = [&]() {
-        // The rare hybrid -> SILK-only transition frames (Q4), parked by k_silk_synth, through the full kernel.  Nothing in
-        // the step waits for it and almost all of its workgroups exit at once: it goes last (pipelined steps: before the
-        // reconstruction, because the next step's parse waits for it).
-        hipLaunchKernelGGL(k_decode_step, dim3((n + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena,
-                           ctx->d_streams, (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, 1, handoff,
-                           (const SilkRec *)srecs, 1);
-    };
-    hipStream_t back = s;
-    if (pipe) {
-        back = ctx->recon_stream;
-        HIPCHK(ctx, hipStreamWaitEvent(back, ctx->ev_parsed, 0));
-        if (ctx->post_recorded[par2]) HIPCHK(ctx, hipStreamWaitEvent(back, ctx->ev_post[par2], 0)); // (the ring: 2 x 960 of 2048)
-        if (window) { // ... and every workgroup of the next step's parse has its place
-            const int next_grid = (next_n + OG_PL_FRAMES * ctx->parse_groups - 1) / (OG_PL_FRAMES * ctx->parse_groups);
-            HIPCHK(ctx, hipStreamWaitValue32(back, ctx->d_started, ctx->parse_started_total + (u32)next_grid, hipStreamWaitValueGte, 0xffffffffu));
-        }
+    // reconstruct (one frame per wave) ...
+    if (ctx->fast_recon) {
+        launch_jitter();
+        void *const leaves = ctx->leaf_kernel ? ctx->d_leaf[par] : nullptr;
+        if (leaves) og_launch_celt_leaves(back, d_descs, recs, leaves, n, ctx->n_streams, 0);
+        og_launch_celt_recon_fb(back, d_descs, ctx->d_streams, recs, rout, n, ctx->n_streams, 0, ctx->d_started + 16, leaves);
+        ctx->recon_started_total += (u32)og_celt_recon_fb_signals(n);
     }
-    if (any_celt) {
-        // reconstruct (one frame per wave) ...
-        if (ctx->fast_recon) {
-            if (pipe) launch_jitter();
-            void *const leaves = ctx->leaf_kernel ? ctx->d_leaf[par] : nullptr;
-            if (leaves) og_launch_celt_leaves(back, d_descs, recs, leaves, n, ctx->n_streams, handoff ? 1 : 0);
-            og_launch_celt_recon_fb(back, d_descs, ctx->d_streams, recs, rout, n, ctx->n_streams, handoff ? 1 : 0, pipe ? ctx->d_started + 16 : nullptr,
-                                    leaves);
-            if (pipe) ctx->recon_started_total += (u32)og_celt_recon_fb_signals(n);
-        }
-        hipLaunchKernelGGL(k_celt_recon, dim3(ctx->fast_recon ? (n + 63) / 64 : n), dim3(64), 0, back, (const FrameDesc *)d_descs,
-                           ctx->d_streams, (const ParseRec *)recs, rout, n, ctx->n_streams, handoff ? 1 : 0, ctx->fast_recon);
+    hipLaunchKernelGGL(k_celt_recon, dim3(ctx->fast_recon ? (n + 63) / 64 : n), dim3(64), 0, back, (const FrameDesc *)d_descs, ctx->d_streams,
+                       (const ParseRec *)recs, rout, n, ctx->n_streams, 0, ctx->fast_recon);
+    HIPCHK(ctx, hipEventRecord(ctx->ev_recon, back));
+    HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_recon, 0));
+    // Nothing waits for the de-emphasis for two steps, and placed before the next step's reconstruction its 10 KB workgroups
+    // take room that kernel -- the critical one -- would use: in a window it is held until the first round of that
+    // reconstruction has started (its count of started workgroups, one in 64 counted)
+    if (window && ctx->fast_recon) {
+        const int first_round = OG_MIN(og_celt_recon_fb_signals(next_n), 32);
+        HIPCHK(ctx, hipStreamWaitValue32(s, ctx->d_started + 16, ctx->recon_started_total + (u32)first_round, hipStreamWaitValueGte, 0xffffffffu));
     }
-    if (pipe) {
-        HIPCHK(ctx, hipEventRecord(ctx->ev_recon, back));
-        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_recon, 0));
-        // Nothing waits for the de-emphasis for two steps, and placed before the next step's reconstruction its 10 KB workgroups
-        // take room that kernel -- the critical one -- would use: in a window it is held until the first round of that
-        // reconstruction has started (its count of started workgroups, one in 64 counted)
-        if (window && ctx->fast_recon) {
-            const int first_round = OG_MIN(og_celt_recon_fb_signals(next_n), 32);
-            HIPCHK(ctx, hipStreamWaitValue32(s, ctx->d_started + 16, ctx->recon_started_total + (u32)first_round, hipStreamWaitValueGte, 0xffffffffu));
-        }
-    }
-    if (any_celt || !others_ran || modes != 7) {
-        // ... -> de-emphasis, SILK mix and PCM (one (frame, channel) per lane); the result codes of CELT / hybrid frames
-        const size_t post_pad = 0;
-        if (pipe) launch_jitter();
-        hipLaunchKernelGGL(k_celt_post, dim3((n * ctx->channels + 63) / 64), dim3(64), post_pad, s, (const FrameDesc *)d_descs, ctx->d_streams,
-                           (const ParseRec *)recs, (const ReconOut *)rout, (i32 *)d_result, (i16 *)d_pcm, n, ctx->n_streams, ctx->channels,
-                           pcm_stride, (const SilkHandoff *)handoff, modes, others_ran ? 1 : 0);
-    }
-    if (pipe) {
-        HIPCHK(ctx, hipEventRecord(ctx->ev_post[par], s));
-        ctx->post_recorded[par] = 1;
-    } else if (srecs && (modes & 1))
-        q4_pass();
+    // ... -> de-emphasis and PCM (one (frame, channel) per lane); the result codes
+    launch_jitter();
+    hipLaunchKernelGGL(k_celt_post, dim3((n * ctx->channels + 63) / 64), dim3(64), 0, s, (const FrameDesc *)d_descs, ctx->d_streams,
+                       (const ParseRec *)recs, (const ReconOut *)rout, (i32 *)d_result, (i16 *)d_pcm, n, ctx->n_streams, ctx->channels,
+                       pcm_stride, (const SilkHandoff *)nullptr, modes, 0);
+    HIPCHK(ctx, hipEventRecord(ctx->ev_post[par], s));
+    ctx->post_recorded[par] = 1;
     HIPCHK(ctx, hipGetLastError());
-    if (ctx->pipeline && !pipe) { // a step that ran in order: whatever a later pipelined step runs ahead waits for all of it
-        HIPCHK(ctx, hipEventRecord(ctx->ev_front, s));
-        ctx->front_recorded = 1;
-    }
     return OPUSGPU_OK;
 }
 
@@ -1461,12 +1528,33 @@ static int conceal_pieces(int total, int last_fs, int32_t base_flags, int32_t ou
     return n;
 }
 
+// CPUs this process may run on (its affinity mask: a container's share, not the machine's), at most `most`.
+static int host_cpus(int most) {
+    cpu_set_t set;
+    int c = 8;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) c = CPU_COUNT(&set);
+    return c < 1 ? 1 : (c > most ? most : c);
+}
+
+// Is [p, p + bytes) page-locked host memory the device can write (both ends known to the runtime as host memory)?
+static bool host_range_is_pinned(const void *p, size_t bytes) {
+    if (!p || !bytes) return false;
+    hipPointerAttribute_t a{}, b{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess || hipPointerGetAttributes(&b, (const uint8_t *)p + bytes - 1) != hipSuccess) {
+        (void)hipGetLastError(); // (pageable memory is reported as an error: not one of ours)
+        return false;
+    }
+    return a.type == hipMemoryTypeHost && b.type == hipMemoryTypeHost;
+}
+
 static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, const uint8_t *const *packets,
                                const int32_t *lens, int16_t *pcm, int frame_capacity, int32_t *result, const bool fec) {
     if (!ctx || n < 0 || !ctx->d_streams) return OPUSGPU_BAD_ARG;
     if (n == 0) return OPUSGPU_OK;
     if (!stream_ids || !packets || !lens || !pcm || !result || frame_capacity <= 0) return OPUSGPU_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->pipeline) // (pipelined device-resident steps may still be in flight on the library's streams, which the parts below use)
+        if (int rc0 = sync_in_flight(ctx)) return rc0;
     const int CC = ctx->channels;
     const bool rfc = ctx->mode == OPUSGPU_MODE_RFC;
     if (fec && !rfc) return OPUSGPU_BAD_ARG;
@@ -1477,22 +1565,41 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
     //    packets on a few threads, in two passes: frame counts and sizes, then (after the prefix sums that place every
     //    packet) descriptors and packet bytes.
     HostPhaseTimer timer;
-    const int host_threads = n >= 4096 ? 8 : 1;
+    const int host_threads = n >= 4096 ? host_cpus(16) : 1;
     auto on_subranges = [&](int from, int to, auto &&f) { // f(lo, hi) over [from, to), on the host threads
         if (host_threads == 1 || to - from < 1024) {
             f(from, to);
             return;
         }
-        std::vector<std::thread> th;
         const int64_t w = to - from;
-        for (int t = 0; t < host_threads; t++)
-            th.emplace_back(f, from + (int)(w * t / host_threads), from + (int)(w * (t + 1) / host_threads));
-        for (auto &x : th) x.join();
+        ctx->pool.run(host_threads, [&](int t) { f(from + (int)(w * t / host_threads), from + (int)(w * (t + 1) / host_threads)); });
     };
     auto on_ranges = [&](auto &&f) { on_subranges(0, n, f); };
     std::vector<int> first(n + 1, 0), nframes(n, 0);
     std::vector<uint8_t> is_lost(rfc ? n : 0, 0);
-    on_ranges([&](int lo, int hi) {
+    // The common large call is REGULAR: every packet holds one frame (frame-count code 0) of a stream that exists, of a size and
+    // duration the call has room for.  One look at the TOC bytes settles that, and then nothing of the first framing pass is
+    // needed: packet i is frame i of the one step, its bytes lie at the running sum of the lengths, and the (only) framing pass
+    // runs part by part next to the device (0.63 + 0.17 ms of host work less in front of the first kernel at 65,536 packets).
+    bool regular = !rfc && !fec && n >= 4096 && ctx->host_parts > 1 && !timer.on;
+    if (regular) {
+        std::atomic<int> irregular{0};
+        on_ranges([&](int lo, int hi) {
+            for (int i = lo; i < hi; i++) {
+                const uint8_t *p = packets[i];
+                if (stream_ids[i] < 0 || stream_ids[i] >= ctx->n_streams || !p || lens[i] < 1 || lens[i] > 1276 || (p[0] & 3) != 0 ||
+                    ogh::toc_samples_per_frame(p[0], 48000) > frame_capacity * OPUSGPU_FRAME_SAMPLES) {
+                    irregular.store(1, std::memory_order_relaxed);
+                    return;
+                }
+                result[i] = 0;
+                nframes[i] = 1;
+            }
+        });
+        regular = irregular.load() == 0;
+        if (!regular) std::fill(nframes.begin(), nframes.end(), 0);
+    }
+    if (!regular) on_ranges([&](int lo, int hi) {
         for (int i = lo; i < hi; i++) {
             result[i] = 0;
             if (stream_ids[i] < 0 || stream_ids[i] >= ctx->n_streams || lens[i] < 0) {
@@ -1565,10 +1672,14 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
         base[i + 1] = base[i] + (nframes[i] && !(rfc && (is_lost[i] == 1 || is_lost[i] == 3)) ? (size_t)lens[i] : 0);
         if (nframes[i] > max_frames) max_frames = nframes[i];
     }
+    timer.mark("prefix sums");
     if (first[n] == 0) return OPUSGPU_OK;
     if (base[n] > 0x7fffffffu) return OPUSGPU_BAD_ARG; // descriptor offsets are 32-bit: split the call
-    std::unique_ptr<opusgpu_frame_desc[]> all(new opusgpu_frame_desc[first[n]]); // frames in (packet, frame) order
-    std::unique_ptr<uint8_t[]> arena(new uint8_t[base[n] + 1]);
+    if (int rc0 = grow_pinned(ctx, &ctx->h_descs, &ctx->cap_h_descs, sizeof(opusgpu_frame_desc) * (size_t)first[n])) return rc0;
+    if (int rc0 = grow_pinned(ctx, &ctx->h_arena, &ctx->cap_h_arena, base[n] + 1)) return rc0;
+    opusgpu_frame_desc *const all = (opusgpu_frame_desc *)ctx->h_descs; // frames in (packet, frame) order
+    uint8_t *const arena = (uint8_t *)ctx->h_arena;
+    timer.mark("staging");
     auto place = [&](int lo, int hi) { // framing pass 2: descriptors and packet bytes of packets [lo, hi) to their places
         for (int i = lo; i < hi; i++) {
             if (!nframes[i]) continue;
@@ -1590,7 +1701,7 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
                                      lc ? ctx->last_flags[sid] : d0[0].flags, fl);
                 for (int k = 0; k < np; k++) all[first[i] + k] = opusgpu_frame_desc{sid, 0, 0, fl[k]};
                 if (is_lost[i] == 2) {
-                    memcpy(arena.get() + base[i], packets[i], (size_t)lens[i]);
+                    memcpy(arena + base[i], packets[i], (size_t)lens[i]);
                     d0[0].offset += (int32_t)base[i];
                     d0[0].flags |= 1 << 10;
                     all[first[i] + np] = d0[0];
@@ -1599,7 +1710,7 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
             }
             opusgpu_frame_desc d[48];
             (void)opusgpu_packet_to_frames_mode(packets[i], lens[i], stream_ids[i], ctx->mode, d);
-            memcpy(arena.get() + base[i], packets[i], (size_t)lens[i]);
+            memcpy(arena + base[i], packets[i], (size_t)lens[i]);
             for (int k = 0; k < nframes[i]; k++) {
                 d[k].offset += (int32_t)base[i];
                 all[first[i] + k] = d[k];
@@ -1616,7 +1727,7 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
         on_ranges(place);
         timer.mark("prefix + framing pass 2 (place)");
         // 2. upload the arena once; run one step per frame index (frames of one packet are sequential)
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_arena, arena.get(), base[n], hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_arena, arena, base[n], hipMemcpyHostToDevice, ctx->stream));
         timer.mark("arena upload (enqueue)");
     }
     std::vector<opusgpu_frame_desc> step;
@@ -1625,7 +1736,9 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
     for (int k = 0; k < max_frames; k++) {
         step.clear();
         owner.clear();
-        if (pipelined) {
+        if (regular) {
+            // (frame j belongs to packet j)
+        } else if (pipelined) {
             owner.reserve(first[n]);
             for (int i = 0; i < n; i++)
                 if (nframes[i]) owner.push_back(i);
@@ -1635,7 +1748,7 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
                     step.push_back(all[first[i] + k]);
                     owner.push_back(i);
                 }
-        const int m = (int)owner.size();
+        const int m = regular ? n : (int)owner.size();
         if (m == 0) break;
         timer.mark("step table");
         if ((rc = grow(ctx, &ctx->d_descs, &ctx->cap_descs, sizeof(opusgpu_frame_desc) * m))) return rc;
@@ -1658,13 +1771,16 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
         // `step` otherwise -- step[j] = all[first[owner[j]] + k], a different set of frames than all[lo .. hi) as soon as one packet
         // of the call has more than one frame.
         auto modes_of = [&](size_t lo, size_t hi) {
-            const opusgpu_frame_desc *table = pipelined ? all.get() : step.data();
+            const opusgpu_frame_desc *table = pipelined ? all : step.data();
             int mask = 0;
             for (size_t f = lo; f < hi && mask != 7; f++) mask |= 1 << (table[f].flags & 3);
             return mask & 7;
         };
         const int pieces = m >= 4096 ? OPUSGPU_COPY_PIECES : 1;
-        const int parts = (pieces > 1 && !timer.on) ? ctx->host_parts : 1;
+        // (slices cost one more launch of the arithmetic kernels each; parts that are steps of their own pay the entropy kernels'
+        // latency each: two of those at most)
+        const bool sliced = pipelined && og_debug().host_slices;
+        const int parts = !(pieces > 1 && !timer.on) ? 1 : (sliced ? ctx->host_parts : OG_MIN(ctx->host_parts, 2));
         for (int t = 0; t < pieces; t++)
             if (!ctx->ev_piece[t]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_piece[t], hipEventDisableTiming));
         // frames [bound[t], bound[t + 1]) make piece t; a part is pieces / parts consecutive pieces.  Pipelined: a part is a range
@@ -1677,14 +1793,17 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
             for (int t = t0; t <= t1; t++) bound[t] = flo + (size_t)((int64_t)(fhi - flo) * (t - t0) / (t1 - t0));
         }
         auto piece_lo = [&](int t) { return bound[t]; };
+        // DIRECT: the caller's PCM buffer is page-locked (opusgpu_host_register, hipHostMalloc, hipHostRegister) and the step table is
+        // the packets in order, one 20 ms block each: the pieces travel straight into it -- no landing zone, no host copy behind it.
+        const bool direct = pipelined && m == n && frame_capacity == 1 && !rfc && host_range_is_pinned(pcm, (size_t)n * cap_pcm * 2);
         auto copy_pieces = [&](hipStream_t cs, int t0, int t1) -> int { // results of the pieces' frames first, then the pieces
             const size_t flo = piece_lo(t0), fhi = piece_lo(t1);
             HIPCHK(ctx, hipMemcpyAsync((int32_t *)ctx->h_res + flo, (const int32_t *)ctx->d_result + flo, sizeof(int32_t) * (fhi - flo),
                                        hipMemcpyDeviceToHost, cs));
             for (int t = t0; t < t1; t++) {
                 const size_t lo = piece_lo(t), hi = piece_lo(t + 1);
-                HIPCHK(ctx, hipMemcpyAsync((uint8_t *)ctx->h_pcm + lo * frame_pcm * 2, (const uint8_t *)ctx->d_pcm + lo * frame_pcm * 2,
-                                           (hi - lo) * frame_pcm * 2, hipMemcpyDeviceToHost, cs));
+                HIPCHK(ctx, hipMemcpyAsync((direct ? (uint8_t *)pcm : (uint8_t *)ctx->h_pcm) + lo * frame_pcm * 2,
+                                           (const uint8_t *)ctx->d_pcm + lo * frame_pcm * 2, (hi - lo) * frame_pcm * 2, hipMemcpyDeviceToHost, cs));
                 HIPCHK(ctx, hipEventRecord(ctx->ev_piece[t], cs));
             }
             return OPUSGPU_OK;
@@ -1693,27 +1812,54 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
             if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
             for (int h = 0; h < parts; h++)
                 if (!ctx->ev_part[h]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_part[h], hipEventDisableTiming));
+        }
+        if (parts > 1 && sliced) {
+            // SLICES: everything placed and uploaded at once (0.2 ms of host work at 65,536 packets), the entropy kernels once over
+            // the whole table, the arithmetic kernels slice by slice with the slice's PCM leaving behind them
+            on_ranges(place);
+            timer.mark("  all packets placed");
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_arena, arena, base[n], hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_descs, all, sizeof(opusgpu_frame_desc) * m, hipMemcpyHostToDevice, ctx->stream));
+            size_t cut[OPUSGPU_COPY_PIECES + 1];
+            for (int h = 0; h <= parts; h++) cut[h] = piece_lo(h * pieces / parts);
+            StepSlices sl;
+            sl.count = parts;
+            sl.bounds = cut;
+            sl.after_slice = [&](int h) -> int {
+                HIPCHK(ctx, hipEventRecord(ctx->ev_part[h], ctx->stream));
+                HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_part[h], 0));
+                return copy_pieces(ctx->copy_stream, h * pieces / parts, (h + 1) * pieces / parts);
+            };
+            rc = decode_step_impl(ctx, m, ctx->d_descs, ctx->d_arena, ctx->d_pcm, ctx->d_result, nullptr, false, modes_of(0, m), 0, &sl);
+            if (rc) return rc;
+            timer.mark("  uploaded, launched, copies queued");
+        } else if (parts > 1) {
+            // (A/B flow, OPUSGPU_HOST_SLICES=0: every part its own in-order step -- the entropy kernels' latency is paid per part.
+            //  Measured also: the parts' chains alternating between two streams, 6.8 - 7.0 ms per 65,536 packets like the slices.)
             for (int h = 0; h < parts; h++) {
                 const int t0 = h * pieces / parts, t1 = (h + 1) * pieces / parts;
                 const size_t flo = piece_lo(t0), fhi = piece_lo(t1);
+                hipStream_t const q = ctx->stream;
                 if (pipelined) { // this part's packets: place, upload
                     const int plo = (int)((int64_t)n * h / parts), phi = (int)((int64_t)n * (h + 1) / parts);
                     on_subranges(plo, phi, place);
+                    timer.mark("  part placed");
                     if (base[phi] > base[plo])
-                        HIPCHK(ctx, hipMemcpyAsync((uint8_t *)ctx->d_arena + base[plo], arena.get() + base[plo], base[phi] - base[plo],
-                                                   hipMemcpyHostToDevice, ctx->stream));
+                        HIPCHK(ctx, hipMemcpyAsync((uint8_t *)ctx->d_arena + base[plo], arena + base[plo], base[phi] - base[plo],
+                                                   hipMemcpyHostToDevice, q));
                     if (fhi > flo)
-                        HIPCHK(ctx, hipMemcpyAsync((opusgpu_frame_desc *)ctx->d_descs + flo, all.get() + flo,
-                                                   sizeof(opusgpu_frame_desc) * (fhi - flo), hipMemcpyHostToDevice, ctx->stream));
+                        HIPCHK(ctx, hipMemcpyAsync((opusgpu_frame_desc *)ctx->d_descs + flo, all + flo,
+                                                   sizeof(opusgpu_frame_desc) * (fhi - flo), hipMemcpyHostToDevice, q));
                 }
                 rc = decode_step_impl(ctx, (int)(fhi - flo), (const opusgpu_frame_desc *)ctx->d_descs + flo, ctx->d_arena,
-                                      (uint8_t *)ctx->d_pcm + flo * frame_pcm * 2, (int32_t *)ctx->d_result + flo, nullptr, false,
-                                      modes_of(flo, fhi));
+                                      (uint8_t *)ctx->d_pcm + flo * frame_pcm * 2, (int32_t *)ctx->d_result + flo, nullptr, false, modes_of(flo, fhi));
                 if (rc) return rc; // (an empty part launches nothing; its pieces' events are still recorded below)
-                HIPCHK(ctx, hipEventRecord(ctx->ev_part[h], ctx->stream));
+                HIPCHK(ctx, hipEventRecord(ctx->ev_part[h], q));
                 HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_part[h], 0));
                 if ((rc = copy_pieces(ctx->copy_stream, t0, t1))) return rc;
+                timer.mark("  part uploaded, launched, copies queued");
             }
+
             timer.mark("table upload + kernels + copy-back in parts (enqueue)");
         } else {
             rc = decode_step_impl(ctx, m, ctx->d_descs, ctx->d_arena, ctx->d_pcm, ctx->d_result, nullptr, false, modes_of(0, m));
@@ -1737,9 +1883,14 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
                 const int64_t plo = (int64_t)bound[p], phi = (int64_t)bound[p + 1];
                 const int lo = (int)(plo + (phi - plo) * t / threads), hi = (int)(plo + (phi - plo) * (t + 1) / threads);
                 for (int j = lo; j < hi; j++) {
-                    const int i = owner[j];
+                    const int i = regular ? j : owner[j];
                     if (h_res[j] < 0) {
                         result[i] = h_res[j];
+                        if (direct) memset(pcm + (size_t)i * cap_pcm, 0, frame_pcm * 2); // (whatever the device buffer held: not the caller's)
+                        continue;
+                    }
+                    if (direct) { // the PCM is in place already
+                        result[i] += h_res[j];
                         continue;
                     }
                     if (rfc) { // a packet appears once per step: nobody else touches placed[i]
@@ -1754,9 +1905,7 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
         if (threads == 1)
             deliver(0);
         else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < threads; t++) th.emplace_back(deliver, t);
-            for (auto &x : th) x.join();
+            ctx->pool.run(threads, deliver);
         }
         for (int t = 0; t < threads; t++)
             if (thread_err[t] != hipSuccess) return fail(ctx, OPUSGPU_ERR_HIP, "hipEventSynchronize (PCM piece)", thread_err[t]);

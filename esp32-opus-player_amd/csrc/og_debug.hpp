@@ -12,8 +12,9 @@
 //   OPUSGPU_HALVES            halves           1        0: an in-order step with SILK-only / hybrid frames runs as ONE chain of kernels, not two
 //   OPUSGPU_PARSE_GROUPS      parse_groups     2        groups of 32 frames per workgroup of the early parse (1 .. 8)
 //   OPUSGPU_PARSE_PRIORITY    parse_priority   1        0: the early parse's stream gets the LOWEST priority instead of the highest
-//   OPUSGPU_HOST_PARTS        host_parts       2        parts a large opusgpu_decode_packets call is cut into (1, 2, 4, 8, 16)
-//   OPUSGPU_HOST_TIMING       host_timing      0        1: wall time of the phases of opusgpu_decode_packets on stderr
+//   OPUSGPU_HOST_PARTS        host_parts       8        slices a large opusgpu_decode_packets call's PCM leaves in (1, 2, 4, 8, 16)
+//   OPUSGPU_HOST_SLICES       host_slices      1        0: the round-2 flow -- every part its own in-order step (A/B measurements)
+//   OPUSGPU_HOST_TIMING       host_timing      0        1: wall time of the phases of opusgpu_decode_packets on stderr (one batch, waits between phases); 2: of the flow as it is
 //   OPUSGPU_PAGES_TIMING      pages_timing     0        1: wall time of the phases of opusgpu_pages_demux on stderr
 //   OPUSGPU_LAUNCH_DELAY_US   launch_delay_us  0        the host sleeps this long before every kernel launch of a decode step
 //                                                       (robustness of the placement of pipelined steps against launch jitter)
@@ -21,7 +22,7 @@
 #include <stdlib.h>
 
 struct og_debug_knobs {
-    int split = 1, split_hybrid = 1, fast_recon = 1, leaf_kernel = 0, halves = 1, parse_groups = 2, parse_priority = 1, host_parts = 2, host_timing = 0,
+    int split = 1, split_hybrid = 1, fast_recon = 1, leaf_kernel = 0, halves = 1, parse_groups = 2, parse_priority = 1, host_parts = 8, host_slices = 1, host_timing = 0,
         pages_timing = 0, launch_delay_us = 0;
 };
 inline const og_debug_knobs &og_debug() {
@@ -47,7 +48,8 @@ inline const og_debug_knobs &og_debug() {
             const int x = atoi(e);
             if (x == 1 || x == 2 || x == 4 || x == 8 || x == 16) v.host_parts = x;
         }
-        v.host_timing = getenv("OPUSGPU_HOST_TIMING") != nullptr;
+        flag("OPUSGPU_HOST_SLICES", v.host_slices);
+        if (const char *e = getenv("OPUSGPU_HOST_TIMING")) v.host_timing = atoi(e) == 2 ? 2 : 1;
         v.pages_timing = getenv("OPUSGPU_PAGES_TIMING") != nullptr;
         number("OPUSGPU_LAUNCH_DELAY_US", v.launch_delay_us, 0, 100000);
         return v;

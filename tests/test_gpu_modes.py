@@ -279,3 +279,50 @@ def test_steps_of_a_multi_frame_call_launch_the_kernels_of_their_own_modes(pkg, 
                 o, r = dec[i].decode_cap(packets[i], 3)
                 assert res[i] == r, (bi, rnd, i, int(res[i]), r)
                 assert r > 0 and np.array_equal(pcm[i, :r], o[:r]), (bi, rnd, i)
+
+
+@pytest.mark.parametrize("registered", [False, True])
+def test_large_regular_call_in_slices(pkg, oracle, gpu_ctx, registered):
+    """The host-buffer path's large regular call (>= 4096 packets of one frame each): one framing pass, the entropy kernels once,
+    the arithmetic kernels in slices with each slice's PCM leaving behind it -- into a landing zone and on into the caller's
+    pageable array, or straight into the caller's array when that is page-locked (Context.host_register).  Three modes in one call
+    (ragged lengths), three calls in a row, every sample of every packet against the oracle; then an irregular call of the same
+    size (one two-frame packet, one empty packet) takes the general flow and must match as well."""
+    rng = np.random.default_rng(23)
+    n, rounds = 6000, 3
+    tocs = [pkg.TOC_SILK_NB_STEREO, pkg.TOC_HYBRID_FB_STEREO, pkg.TOC_CELT_FB_STEREO]
+    calls = []
+    for r in range(rounds + 1):
+        pk = [bytes([tocs[i % 3]]) + rng.integers(0, 256, size=int(rng.integers(8, 200)), dtype=np.uint8).tobytes() for i in range(n)]
+        if r == rounds:
+            pk[7] = bytes([pk[7][0] | 1]) + pk[7][1:41] + pk[7][1:41]
+            pk[11] = b""
+        calls.append(pk)
+    dec = [oracle.decoder(2) for _ in range(n)]
+    for d in dec:
+        d.init()
+    gpu_ctx.streams_alloc(n, 2)
+    ids = np.arange(n, dtype=np.int32)
+    raw = np.zeros(n * 2 * 960 * 2 + 4096, dtype=np.int16)
+    out2 = raw[(-raw.ctypes.data) % 4096 // 2:][:n * 2 * 960 * 2].reshape(n, 2 * 960, 2)
+    if registered:
+        gpu_ctx.host_register(out2)
+    try:
+        for r, pk in enumerate(calls):
+            cap = 2 if r == rounds else 1
+            lens = np.array([len(p) for p in pk], dtype=np.int32)
+            offs = np.concatenate([[0], np.cumsum(lens.astype(np.int64))[:-1]])
+            arena = np.frombuffer(b"".join(pk) + b"\0", dtype=np.uint8)
+            out = out2.reshape(-1)[:n * cap * 960 * 2].reshape(n, cap * 960, 2)
+            out[...] = 0x5555
+            _, res = gpu_ctx.decode_packets_arena(ids, arena, offs, lens, frame_capacity=cap, pcm=out)
+            for i in range(n):
+                o, want = dec[i].decode_cap(pk[i], cap)
+                assert res[i] == want, (r, i, int(res[i]), want)
+                if want > 0:
+                    assert np.array_equal(out[i, :want], o[:want]), (r, i)
+            if r == rounds:
+                assert res[7] == 1920 and res[11] < 0
+    finally:
+        if registered:
+            gpu_ctx.host_unregister(out2)
