@@ -307,9 +307,9 @@ def check_against_oracle(pkg, ctx, name, n, frames, d_pcm, pay=None, pages_seed=
 
 
 def traffic_for(name, n):
-    """HBM bytes per step from the committed PMC passes of THIS round's build (tools/prof_pmc.sh -> profiles/r02/), taken
+    """HBM bytes per step from the committed PMC passes of THIS round's build (tools/prof_pmc.sh -> profiles/r03/), taken
     at this batch size; null when no such file exists.  The file names the build it was measured on."""
-    for rnd in ("r02",):
+    for rnd in ("r03",):
         tpath = os.path.join(ROOT, "profiles", rnd, f"traffic_{name}.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
@@ -324,7 +324,7 @@ def valu_issue_for(name, n, step_ms):
     same committed PMC passes: vector-ALU wave-instructions of the step's kernels, the time the chip needs just to issue them
     (a wave64 vector instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz), and that time over the measured
     step.  None when no counters of this round exist for the workload."""
-    tpath = os.path.join(ROOT, "profiles", "r02", f"traffic_{name}.json")
+    tpath = os.path.join(ROOT, "profiles", "r03", f"traffic_{name}.json")
     if not os.path.exists(tpath):
         return None
     with open(tpath) as fh:
@@ -447,7 +447,7 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
         ctx.d2h(last, ctypes.c_void_p(at + lay.desc_at[K + W - 1]))
         parity = check_against_oracle(pkg, ctx, name, n, K + W, d_pcm, slot_stream=last["stream"].astype(np.int64),
                                       pages_seed=lambda m: (0x9E3779B9 ^ (r * 0x01000193) ^ (m * 0x5bd1e995)) & 0xFFFFFFFF)
-        if RAW_PAGES:
+        if RAW_PAGES and os.environ.get("BENCH_E2E", "1") != "0":  # (BENCH_E2E=0: profiling runs count the timed steps' kernels only)
             timed_pcm = np.zeros((n, 960, 2), dtype=np.int16)
             ctx.d2h(timed_pcm, d_pcm)
             e2e_stats, e2e_pcm = overlapped_end_to_end(pkg, ranks, ctx, n, d_pcm, d_res, max(1, shard.usable_cpus() - 2))

@@ -4,6 +4,7 @@ plus per-frame figures.  usage: pmc_summary.py <dir> [frames_per_launch]"""
 import csv
 import glob
 import json
+import os
 import sys
 from collections import defaultdict
 
@@ -17,10 +18,12 @@ for f in sorted(glob.glob(root + "/trace/**/*kernel_stats.csv", recursive=True))
                   f"  min {float(row['MinNs'])/1e6:8.3f}  max {float(row['MaxNs'])/1e6:8.3f}")
 traffic = {}
 durations = {}
+steps = int(os.environ.get("PROF_STEPS", "4"))  # steps of the traced run (bench --steps 3 --warmup 1)
 for f in sorted(glob.glob(root + "/trace/**/*kernel_stats.csv", recursive=True)):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            durations[row["Name"].split("(")[0]] = float(row["AverageNs"]) / 1e6
+            # per STEP: a step with SILK frames launches its kernels twice (two halves on two streams, og_api.hip)
+            durations[row["Name"].split("(")[0]] = float(row["TotalDurationNs"]) / steps / 1e6
 for kern in kernels:
     acc = defaultdict(list)
     for f in sorted(glob.glob(root + "/pmc*/**/*counter_collection.csv", recursive=True)):
@@ -50,7 +53,9 @@ for kern in kernels:
 if traffic:
     out = {"frames_per_launch": frames, "kernels": traffic,
            "hbm_bytes_per_step": sum(k["hbm_bytes_per_launch"] for k in traffic.values()),
-           "note": "per launch, (2 x FETCH_SIZE + WRITE_SIZE) x 1024: separate --pmc passes, gfx950 FETCH_SIZE correction"}
+           "note": "counters per launch = per step (in-order steps, one launch per kernel and step), (2 x FETCH_SIZE + WRITE_SIZE) x 1024: "
+                   "separate --pmc passes, gfx950 FETCH_SIZE correction; avg_ms = the kernel's total time per step in the kernel-trace "
+                   "pass, which runs the bench as it is (pipelined / windowed / in halves: next to its neighbours)"}
     with open(root + "/traffic.json", "w") as fh:
         json.dump(out, fh, indent=1)
     print("traffic:", json.dumps(out))

@@ -6,13 +6,18 @@
 # pipelined step holds its reconstruction behind a stream memory wait for the NEXT step's parse kernel to start -- which a
 # serialised queue never lets happen (the pass would sit in that wait until its timeout).  Counters per kernel do not depend on
 # what runs next to it; durations next to the neighbours come from the kernel-trace pass, which runs the default (pipelined) bench.
+# For the same reason they run steps with SILK frames as ONE chain (OPUSGPU_HALVES=0): one launch of every kernel per step, so
+# that "per launch" is "per step"; the counters of a kernel do not depend on how its frames are cut into launches.
 # PROF_FRAMES: frames per launch for the per-frame figures (default 65536).
 tag=$1; shift
 out=$PWD/gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
+export BENCH_E2E=0 # (mixed_pages_2m: no overlapped end-to-end run behind the timed steps -- its batches would count as launches)
 args="--steps 3 --warmup 1 --no-cpu-baseline --no-other-configs $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py $args > $out/trace.log 2>&1 || exit 1
+# the kernel-trace pass: the bench as it is (pipelined, windowed, in halves), 10 + 2 steps
+export PROF_STEPS=12
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs $* > $out/trace.log 2>&1 || exit 1
 i=0
 for set in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVES" \
@@ -22,6 +27,6 @@ for set in \
   "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT TCC_MISS TCC_EA0_RDREQ TCC_EA0_WRREQ" ; do
   i=$((i+1))
   echo "pmc pass $i: $set"
-  timeout -k 5 150 rocprofv3 --pmc $set --output-format csv -d $out/pmc$i -o p -- python3 bench.py $args --pipeline off > $out/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -3 $out/pmc$i.log; exit 1; }
+  OPUSGPU_HALVES=0 timeout -k 5 ${PROF_PASS_TIMEOUT:-150} rocprofv3 --pmc $set --output-format csv -d $out/pmc$i -o p -- python3 bench.py $args --pipeline off > $out/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -3 $out/pmc$i.log; exit 1; }
 done
 python3 tools/pmc_summary.py $out ${PROF_FRAMES:-65536} | tee $out/summary.txt
