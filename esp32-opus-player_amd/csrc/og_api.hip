@@ -332,9 +332,11 @@ __global__ void __launch_bounds__(64, OG_SILK_WAVES) k_silk_synth(const FrameDes
 #ifndef OG_SPARSE_WAVES
 #define OG_SPARSE_WAVES 4 // (9,156 B of LDS per workgroup allow 16 per CU; 128 VGPRs: 5 spilled. hybrid-256k: 4.80 -> 3.99 ms)
 #endif
+// `shadow` (null in in-order steps): the per-stream copies of what the entropy half needs of the past, kept by this kernel for
+// pipelined SILK-only steps (SilkShadow, og_silk_parse.hpp); `epoch`: the context's current one.
 __global__ void __launch_bounds__(64, OG_SPARSE_WAVES) k_silk_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
                                                       const StreamState *st, SilkRec *srecs, SilkHandoff *handoff, int n,
-                                                      int n_streams) {
+                                                      int n_streams, SilkShadow *shadow, u32 epoch) {
     silk_tables_load();
     if ((int)threadIdx.x >= OG_SP_LANES) return;
     const int f = (int)blockIdx.x * OG_SP_LANES + (int)threadIdx.x;
@@ -345,8 +347,10 @@ __global__ void __launch_bounds__(64, OG_SPARSE_WAVES) k_silk_parse(const FrameD
 #ifdef OG_PROF_SPARSE // profiling builds: time the sections of the SILK parse kernel (full batches only)
     OG_PROF_INIT();
 #endif
-    silk_parse_lane(&st[d.stream], arena + d.offset, d.len, mode, desc_bandwidth(d.flags), desc_channels(d.flags), &srecs[f], &handoff[f]);
-    silk_params_lane(&st[d.stream], mode, desc_bandwidth(d.flags), desc_channels(d.flags), &srecs[f]);
+    SilkShadow *const sh = shadow ? &shadow[d.stream] : nullptr;
+    const SilkPast past(&st[d.stream], sh, epoch);
+    silk_parse_lane(past, arena + d.offset, d.len, mode, desc_bandwidth(d.flags), desc_channels(d.flags), &srecs[f], &handoff[f]);
+    silk_params_lane(past, mode, desc_bandwidth(d.flags), desc_channels(d.flags), &srecs[f], sh, epoch);
 #ifdef OG_PROF_SPARSE
     OG_PROF_FLUSH();
 #endif
@@ -1038,7 +1042,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         const FrameDesc *dd = (const FrameDesc *)d_descs + f0;
         if (srecs)
             hipLaunchKernelGGL(k_silk_parse, dim3((cnt + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, q, dd, (const u8 *)d_arena,
-                               (const StreamState *)ctx->d_streams, srecs + f0, handoff + f0, cnt, ctx->n_streams);
+                               (const StreamState *)ctx->d_streams, srecs + f0, handoff + f0, cnt, ctx->n_streams, (SilkShadow *)nullptr, 0u);
         if (any_celt)
             hipLaunchKernelGGL(k_celt_parse, dim3((cnt + OG_PL_FRAMES - 1) / OG_PL_FRAMES), parse_block, 0, q, dd, (const u8 *)d_arena,
                                ctx->d_streams, recs + f0, cnt, ctx->n_streams, (const SilkHandoff *)(handoff ? handoff + f0 : nullptr),

@@ -631,31 +631,69 @@ static_assert(2 * SILK_MAX_FRAME * 4 * 2 >= 1920 * 2 && SILK_MAX_FRAME * 4 * 2 <
 // NLSFs) are taken as the wave kernel will see them after its own (re-)initialisations: decoder init on a CELT ->
 // SILK/hybrid switch, channel 1 init when the packet adds a channel, silk_decoder_set_fs on a rate change, side-channel
 // restart after a mid-only frame (silk.cpp:1639).  Nothing but the record is written.
-OG_DEV void silk_params_lane(const StreamState *st, int mode, int bandwidth, int channels, SilkRec *rec) {
-    if (rec->ret < 0) return;
+// `shadow` (pipelined SILK-only steps, see SilkShadow): where the lane leaves what the NEXT frame's entropy half needs -- the
+// values the synthesis kernel will have written to the stream's state by the time it is through with this frame
+// (silk_decode_packet: silk_init_state on a switch from CELT, silk_chan_init for a channel the packet adds, silk_set_fs, the
+// side channel's restart, the indices' history, the gain index, the stabilised NLSFs; decode_frame_wave: prev_mode).
+OG_DEV void silk_params_lane(const SilkPast &past, int mode, int bandwidth, int channels, SilkRec *rec, SilkShadow *shadow = nullptr,
+                             u32 epoch = 0) {
+    if (rec->ret < 0) return; // (the frame ends in an error before anything of the state is touched: the past stays what it is)
     int internal_hz = 16000;
     if (mode == MODE_SILK) internal_hz = bandwidth == BW_NB ? 8000 : (bandwidth == BW_MB ? 12000 : 16000);
     const int fs_kHz = (internal_hz >> 10) + 1, order = fs_kHz == 16 ? 16 : 10;
-    const SilkState *s = &st->silk;
-    const int fresh_all = st->prev_mode == MODE_CELT, fresh_ch1 = channels > s->nChannelsInternal;
-    const int prev_dom = fresh_all ? 0 : s->prev_decode_only_middle, dom = rec->decode_only_middle;
+    const int fresh_all = past.prev_mode() == MODE_CELT, fresh_ch1 = channels > past.nChannelsInternal();
+    const int prev_dom = fresh_all ? 0 : past.prev_dom(), dom = rec->decode_only_middle;
     for (int n = 0; n < channels; n++) {
         if (n == 1 && dom) continue; // no side channel this frame
-        const SilkChannel *c = &s->ch[n];
-        const int fresh = fresh_all || (n == 1 && fresh_ch1), changed = fresh || c->fs_kHz != fs_kHz;
-        i32 lastGain = changed ? 10 : c->LastGainIndex;
-        int ffar = changed ? 1 : c->first_frame_after_reset;
+        const int fresh = fresh_all || (n == 1 && fresh_ch1), changed = fresh || past.fs_kHz(n) != fs_kHz;
+        i32 lastGain = changed ? 10 : past.lastGain(n);
+        int ffar = changed ? 1 : past.ffar(n);
         if (n == 1 && channels == 2 && dom == 0 && prev_dom == 1) {
             lastGain = 10;
             ffar = 1;
         }
         SilkRecCh &k = rec->ch[n];
         OG_MARK(53);
-        silk_decode_parameters<SilkParLane>(c->prevNLSF_Q15, k, fs_kHz, 0, lastGain, ffar);
+        silk_decode_parameters<SilkParLane>(past.prevNLSF(n), k, fs_kHz, 0, lastGain, ffar);
         k.LastGainIndex = lastGain;
         const SilkParLane::A16 nl = SilkParLane::nlsf();
         for (int i = 0; i < order; i++) k.nlsf[i] = nl[i];
     }
+    if (!shadow) return;
+    // ---- the past of the next frame (written over the one just read: every input above has been consumed)
+    for (int n = 0; n < 2; n++) {
+        const int fresh = fresh_all || (n == 1 && fresh_ch1); // the channel was (re-)initialised: everything zero, first frame after a reset
+        // (the indices' history: what the entropy half ended with -- a frame's LBRR copies move it on even for a channel whose
+        // regular frame is not coded, and the synthesis stores both channels' values whatever the packet's channel count)
+        const i32 ecType = rec->ch[n].ec_prevSignalType, ecLag = rec->ch[n].ec_prevLagIndex;
+        i32 fs = fresh ? 0 : past.fs_kHz(n);
+        i32 lastGain = fresh ? 0 : past.lastGain(n), ffar = fresh ? 1 : past.ffar(n);
+        i16 nl[SILK_REC_LPC];
+        for (int i = 0; i < SILK_REC_LPC; i++) nl[i] = fresh ? (i16)0 : past.prevNLSF(n)[i];
+        if (n < channels) {
+            if (fs != fs_kHz) { // silk_set_fs
+                ffar = 1;
+                lastGain = 10;
+                fs = fs_kHz;
+            }
+            if (n == 0 || !dom) { // a coded frame
+                lastGain = rec->ch[n].LastGainIndex;
+                ffar = 0;
+                for (int i = 0; i < order; i++) nl[i] = rec->ch[n].nlsf[i];
+            }
+        }
+        SilkShadow::Ch &o = shadow->ch[n];
+        o.ec_prevSignalType = ecType;
+        o.ec_prevLagIndex = ecLag;
+        o.fs_kHz = fs;
+        o.LastGainIndex = lastGain;
+        o.first_frame_after_reset = ffar;
+        for (int i = 0; i < SILK_REC_LPC; i++) o.prevNLSF_Q15[i] = nl[i];
+    }
+    shadow->prev_mode = mode;
+    shadow->nChannelsInternal = channels;
+    shadow->prev_decode_only_middle = dom; // (0 for a mono packet: silk_decode_packet stores its local, which only stereo packets set)
+    shadow->epoch = epoch;
 }
 
 // ---- synthesis: one lane per channel (silk_decode_core silk.cpp:1806, LPC analysis filter :2268) --------------

@@ -45,6 +45,40 @@ struct SilkRec {
 };
 static_assert(sizeof(SilkRec) % 16 == 0, "record alignment");
 
+// What the ENTROPY half of a SILK / hybrid frame needs of the frames before it, and nothing else: a copy the parse kernel keeps
+// per stream for pipelined SILK-only steps (opusgpu_set_pipeline, og_api.hip), where the parse of step k + 1 runs next to the
+// synthesis of step k and so cannot wait for that kernel to write these values into the stream's state.  The parse kernel
+// computes what the synthesis WILL leave there (the same values: silk_shadow_next) and hands it to its own next run.
+// `epoch`: the copy counts only if it carries the context's current epoch -- every step that is not such a pipelined step, every
+// reset and mode change advances the epoch on the host (whatever they do to the state, the copy is then stale by definition),
+// and the parse falls back to the state itself, which nothing in flight is writing then.
+struct SilkShadow {
+    u32 epoch;
+    i32 prev_mode, nChannelsInternal, prev_decode_only_middle;
+    struct Ch {
+        i32 ec_prevSignalType, ec_prevLagIndex, fs_kHz, LastGainIndex, first_frame_after_reset;
+        i16 prevNLSF_Q15[SILK_REC_LPC];
+    } ch[2];
+    i32 pad[2];
+};
+static_assert(sizeof(SilkShadow) == 128, "one shadow per 128 bytes");
+
+// the entropy half's view of the frames before: the shadow when it is current, the stream's state otherwise
+struct SilkPast {
+    const StreamState *st;
+    const SilkShadow *sh; // null: the state
+    OG_MEMBER SilkPast(const StreamState *st_, const SilkShadow *shadow, u32 epoch) : st(st_), sh(shadow && shadow->epoch == epoch ? shadow : nullptr) {}
+    OG_MEMBER i32 prev_mode() const { return sh ? sh->prev_mode : st->prev_mode; }
+    OG_MEMBER i32 nChannelsInternal() const { return sh ? sh->nChannelsInternal : st->silk.nChannelsInternal; }
+    OG_MEMBER i32 prev_dom() const { return sh ? sh->prev_decode_only_middle : st->silk.prev_decode_only_middle; }
+    OG_MEMBER i32 ecType(int n) const { return sh ? sh->ch[n].ec_prevSignalType : st->silk.ch[n].ec_prevSignalType; }
+    OG_MEMBER i32 ecLag(int n) const { return sh ? sh->ch[n].ec_prevLagIndex : st->silk.ch[n].ec_prevLagIndex; }
+    OG_MEMBER i32 fs_kHz(int n) const { return sh ? sh->ch[n].fs_kHz : st->silk.ch[n].fs_kHz; }
+    OG_MEMBER i32 lastGain(int n) const { return sh ? sh->ch[n].LastGainIndex : st->silk.ch[n].LastGainIndex; }
+    OG_MEMBER i32 ffar(int n) const { return sh ? sh->ch[n].first_frame_after_reset : st->silk.ch[n].first_frame_after_reset; }
+    OG_MEMBER const i16 *prevNLSF(int n) const { return sh ? sh->ch[n].prevNLSF_Q15 : st->silk.ch[n].prevNLSF_Q15; }
+};
+
 OG_LDS u8 g_silk_tab[SILK_BLOB_SIZE]; // LDS copy of rom_silk_u8_blob
 OG_DEV void silk_tables_load() {      // cooperative, whole workgroup; ends with a barrier
     const u32 *src = reinterpret_cast<const u32 *>(rom_silk_u8_blob);
@@ -297,10 +331,10 @@ OG_DEV void silk_parse_stereo_pred(RcLane &rc, i32 pred_Q13[2]) { // silk_stereo
 
 // The entropy half of one SILK-only or hybrid frame, lane-private (decode_frame_wave's head + silk_Decode's).
 // Reads the stream's state, writes only the record and the hand-off.
-OG_DEV void silk_parse_lane(const StreamState *st, const u8 *payload, int len, int mode, int bandwidth, int channels, SilkRec *rec,
+OG_DEV void silk_parse_lane(const SilkPast &past, const u8 *payload, int len, int mode, int bandwidth, int channels, SilkRec *rec,
                             SilkHandoff *handoff) {
     handoff->valid = 0;
-    rec->prev_mode = st->prev_mode;
+    rec->prev_mode = past.prev_mode();
     if (len < 0 || len > 1275) {
         rec->ret = BAD_ARG;
         return;
@@ -319,10 +353,9 @@ OG_DEV void silk_parse_lane(const StreamState *st, const u8 *payload, int len, i
     rc_init(rc, (u32)len);
     // entropy-side state, as the wave kernel will see it after its own (re-)initialisations:
     // silk_init_state on a CELT -> SILK/hybrid switch, channel 1 init when the packet adds a channel
-    const SilkState *s = &st->silk;
-    const int fresh_all = st->prev_mode == MODE_CELT, fresh_ch1 = channels > s->nChannelsInternal;
-    i32 ecType0 = fresh_all ? 0 : s->ch[0].ec_prevSignalType, ecLag0 = fresh_all ? 0 : s->ch[0].ec_prevLagIndex;
-    i32 ecType1 = (fresh_all || fresh_ch1) ? 0 : s->ch[1].ec_prevSignalType, ecLag1 = (fresh_all || fresh_ch1) ? 0 : s->ch[1].ec_prevLagIndex;
+    const int fresh_all = past.prev_mode() == MODE_CELT, fresh_ch1 = channels > past.nChannelsInternal();
+    i32 ecType0 = fresh_all ? 0 : past.ecType(0), ecLag0 = fresh_all ? 0 : past.ecLag(0);
+    i32 ecType1 = (fresh_all || fresh_ch1) ? 0 : past.ecType(1), ecLag1 = (fresh_all || fresh_ch1) ? 0 : past.ecLag(1);
     int vad0 = rc_bit_logp(rc, 1), lbrr0 = rc_bit_logp(rc, 1), vad1 = 0, lbrr1 = 0;
     if (channels == 2) {
         vad1 = rc_bit_logp(rc, 1);

@@ -39,8 +39,9 @@ int emu_decode_frame(void *stv, const uint8_t *payload, int len, int mode, int b
     const og::SilkHandoff *h = nullptr;
     if (mode != og::MODE_CELT) { // SILK entropy half per lane, then the frame-per-wave kernel from the record
         og::silk_tables_load();
-        og::silk_parse_lane(st, payload, len, mode, bw, ch, &srec, &handoff);
-        og::silk_params_lane(st, mode, bw, ch, &srec);
+        const og::SilkPast past(st, nullptr, 0);
+        og::silk_parse_lane(past, payload, len, mode, bw, ch, &srec, &handoff);
+        og::silk_params_lane(past, mode, bw, ch, &srec);
         int r = og::decode_frame_wave<false>(st, payload, len, mode, bw, ch, pcm, &handoff, &srec);
         if (r == og::CONTINUE_Q4) return og::decode_frame_wave<true>(st, payload, len, mode, bw, ch, pcm, &handoff, &srec, 1);
         if (r != og::CONTINUE_SPLIT) return r;
@@ -51,6 +52,47 @@ int emu_decode_frame(void *stv, const uint8_t *payload, int len, int mode, int b
     const int ret = og::celt_recon_wave(st, &rec, mode, ch);
     for (int c = 0; c < st->channels; c++) og::celt_post(st, &rec, ret, c, pcm, h ? h->pcm : nullptr, ch);
     return ret;
+}
+// A SILK-only / hybrid frame the way pipelined SILK-only steps decode it: the entropy half takes the past from `shadow` (128 bytes,
+// og::SilkShadow) when that carries `epoch`, from the state otherwise, and leaves the next frame's past there.
+int emu_decode_frame_shadowed(void *stv, void *shadow, unsigned epoch, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm) {
+    og::StreamState *st = (og::StreamState *)stv;
+    static og::SilkHandoff handoff;
+    static og::SilkRec srec;
+    if (mode == og::MODE_CELT) return -1000;
+    og::silk_tables_load();
+    const og::SilkPast past(st, (const og::SilkShadow *)shadow, epoch);
+    og::silk_parse_lane(past, payload, len, mode, bw, ch, &srec, &handoff);
+    og::silk_params_lane(past, mode, bw, ch, &srec, (og::SilkShadow *)shadow, epoch);
+    int r = og::decode_frame_wave<false>(st, payload, len, mode, bw, ch, pcm, &handoff, &srec);
+    if (r == og::CONTINUE_Q4) return og::decode_frame_wave<true>(st, payload, len, mode, bw, ch, pcm, &handoff, &srec, 1);
+    if (r != og::CONTINUE_SPLIT) return r;
+    og::parse_tables_load();
+    og::celt_parse_lane(st, payload, len, ch, &rec, &handoff);
+    const int ret = og::celt_recon_wave(st, &rec, mode, ch);
+    for (int c = 0; c < st->channels; c++) og::celt_post(st, &rec, ret, c, pcm, handoff.pcm, ch);
+    return ret;
+}
+// 0 when `shadow` holds exactly what the state holds of the entropy half's past (it must, after every frame that decoded);
+// otherwise the number of the first field that differs
+int emu_shadow_vs_state(const void *stv, const void *shadow) {
+    const og::StreamState *st = (const og::StreamState *)stv;
+    const og::SilkShadow *sh = (const og::SilkShadow *)shadow;
+    if (sh->prev_mode != st->prev_mode) return 1;
+    if (sh->nChannelsInternal != st->silk.nChannelsInternal) return 2;
+    if (sh->prev_decode_only_middle != st->silk.prev_decode_only_middle) return 3;
+    for (int n = 0; n < 2; n++) {
+        const og::SilkChannel &c = st->silk.ch[n];
+        const og::SilkShadow::Ch &o = sh->ch[n];
+        if (o.ec_prevSignalType != c.ec_prevSignalType) return 10 + 10 * n;
+        if (o.ec_prevLagIndex != c.ec_prevLagIndex) return 11 + 10 * n;
+        if (o.fs_kHz != c.fs_kHz) return 12 + 10 * n;
+        if (o.LastGainIndex != c.LastGainIndex) return 13 + 10 * n;
+        if (o.first_frame_after_reset != c.first_frame_after_reset) return 14 + 10 * n;
+        for (int i = 0; i < 16; i++)
+            if (o.prevNLSF_Q15[i] != c.prevNLSF_Q15[i]) return 100 + 16 * n + i;
+    }
+    return 0;
 }
 // RFC mode (opt-in): one Opus frame at its true duration through the single-kernel code (og_decode.hpp, decode_frame_rfc)
 int emu_decode_frame_rfc(void *st, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm, int frame_size) {

@@ -63,3 +63,51 @@ def test_emulated_kernels_match_oracle(emu, oracle, seed, modes, switch):
                 pch = 2 if stereo else 1
                 ncmp = 960 * pch if (m == 1000 and pch < channels) else 960 * channels  # Q3: see test_gpu_modes
                 assert np.array_equal(out.reshape(-1)[:ncmp], ref[:960].reshape(-1)[:ncmp]), (stream, f, hex(toc))
+
+
+@pytest.mark.parametrize("seed,modes", [(11, [0]), (12, [0, 1]), (13, [0, 1, 2])])
+def test_entropy_half_past_kept_by_the_parse_matches_the_state(emu, oracle, seed, modes):
+    """Pipelined SILK-only steps (og_api.hip): the parse kernel keeps its own copy of what the entropy half needs of the frames
+    before (SilkShadow) and computes what the synthesis WILL write to the state.  Here, frame by frame in emulation: random walks
+    over SILK NB / MB / WB and hybrid configurations, mono and stereo packets in mono and stereo decoders, empty-ish and error
+    frames -- after every frame that decoded, the copy must equal the state field by field, and PCM and return codes the oracle's.
+    A CELT frame in between goes the ordinary way and ends the copy's epoch, as the host does for every step of another kind."""
+    emu.emu_decode_frame_shadowed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    emu.emu_shadow_vs_state.argtypes = [C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(seed)
+    st = C.create_string_buffer(emu.emu_state_size())
+    out = np.zeros((960, 2), dtype=np.int16)
+    shadowed = 0
+    for stream in range(60):
+        channels = int(rng.integers(1, 3))
+        d = oracle.decoder(channels)
+        d.init()
+        emu.emu_stream_init(st, channels)
+        shadow = C.create_string_buffer(128)
+        epoch = 1
+        mode = int(rng.choice(modes))
+        for f in range(14):
+            if rng.random() < 0.3:
+                mode = int(rng.choice(modes))
+            stereo = (channels == 2) if rng.random() < 0.8 else bool(rng.integers(2))
+            toc = (int(rng.choice(CFGS[mode])) << 3) | (4 if stereo else 0)
+            L = int(rng.choice([40, 120, 160, 3, 1, 333, 1275]))
+            kind = int(rng.integers(12))
+            body = bytes(L) if kind == 0 else (b"\xff" * L if kind == 1 else rng.integers(0, 256, L, dtype=np.uint8).tobytes())
+            ref, r = d.decode(bytes([toc]) + body)
+            m, bw = _mode_bw(toc)
+            out[:] = 0
+            if m == 1002:
+                r2 = emu.emu_decode_frame(st, body, L, m, bw, 2 if stereo else 1, out.ctypes.data)
+                epoch += 1
+            else:
+                r2 = emu.emu_decode_frame_shadowed(st, shadow, epoch, body, L, m, bw, 2 if stereo else 1, out.ctypes.data)
+                if r2 > 0:
+                    assert emu.emu_shadow_vs_state(st, shadow) == 0, (stream, f, hex(toc), emu.emu_shadow_vs_state(st, shadow))
+                    shadowed += 1
+            assert r == r2, (stream, f, hex(toc), r, r2)
+            if r > 0:
+                pch = 2 if stereo else 1
+                ncmp = 960 * pch if (m == 1000 and pch < channels) else 960 * channels
+                assert np.array_equal(out.reshape(-1)[:ncmp], ref[:960].reshape(-1)[:ncmp]), (stream, f, hex(toc))
+    assert shadowed > 300
