@@ -674,8 +674,17 @@ struct opusgpu_ctx {
     hipEvent_t ev_part[OPUSGPU_COPY_PIECES] = {};
     int host_parts = 8; // OPUSGPU_HOST_PARTS=1: one batch, copy after the kernels (A/B measurements); 2, 4, 8, 16
     // parse records of the split CELT path (one per frame of a step), grown on demand
-    void *d_recs[3] = {}, *d_rout[3] = {}, *d_leaf[3] = {}, *d_handoff = nullptr, *d_srecs = nullptr; // (three sets: pipelined steps rotate)
-    size_t cap_recs[3] = {}, cap_rout[3] = {}, cap_leaf[3] = {}, cap_handoff = 0, cap_srecs = 0;
+    void *d_recs[3] = {}, *d_rout[3] = {}, *d_leaf[3] = {}; // (three sets: pipelined steps rotate)
+    size_t cap_recs[3] = {}, cap_rout[3] = {}, cap_leaf[3] = {};
+    void *d_handoff[2] = {}, *d_srecs[2] = {}; // (two sets: pipelined SILK-only steps alternate; everything else uses set 0)
+    size_t cap_handoff[2] = {}, cap_srecs[2] = {};
+    const void *last_srecs = nullptr; // the SILK records of the last step (opusgpu_debug_stage_taps)
+    // Pipelined SILK-only steps (a step the caller declares SILK-only): the parse kernel keeps what its next run needs of the past
+    // in d_shadow (SilkShadow per stream, og_silk_parse.hpp) and runs for step k + 1 on parse_stream next to step k's synthesis.
+    void *d_shadow = nullptr;
+    unsigned shadow_epoch = 1; // advanced by everything else that may change a stream's SILK state: stale copies are ignored
+    int silk_slot = 0, sdone_recorded[2] = {}, last_silk_mask = 0, last_kind = 0; // last_kind: 0 in order, 1 pipelined CELT-only, 2 pipelined SILK-only
+    hipEvent_t ev_sparsed = nullptr, ev_sdone[2] = {};
     int leaf_kernel = 0; // OPUSGPU_LEAF_KERNEL=1: k_celt_leaves decodes the PVQ leaves ahead of the reconstruction (og_leaves.hip; measured slower)
     int split_celt = 1;   // OPUSGPU_SPLIT=0 forces the single-kernel path for every mode (A/B measurements)
     int split_hybrid = 1; // OPUSGPU_SPLIT_HYBRID=0 keeps SILK-only and hybrid frames entirely on the single-kernel path
@@ -788,8 +797,13 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
         (void)hipFree(ctx->d_leaf[i]);
         if (ctx->ev_post[i]) (void)hipEventDestroy(ctx->ev_post[i]);
     }
-    (void)hipFree(ctx->d_handoff);
-    (void)hipFree(ctx->d_srecs);
+    for (int i = 0; i < 2; i++) {
+        (void)hipFree(ctx->d_handoff[i]);
+        (void)hipFree(ctx->d_srecs[i]);
+        if (ctx->ev_sdone[i]) (void)hipEventDestroy(ctx->ev_sdone[i]);
+    }
+    if (ctx->ev_sparsed) (void)hipEventDestroy(ctx->ev_sparsed);
+    (void)hipFree(ctx->d_shadow);
     (void)hipHostFree(ctx->h_pcm);
     (void)hipHostFree(ctx->h_res);
     (void)hipHostFree(ctx->h_arena);
@@ -846,6 +860,9 @@ int opusgpu_set_pipeline(opusgpu_ctx *ctx, int on) {
     if ((on != 0) != (ctx->pipeline != 0)) { // switching: from an idle device (steps of either kind may be queued on any stream)
         HIPCHK(ctx, hipDeviceSynchronize());
         ctx->front_recorded = ctx->post_recorded[0] = ctx->post_recorded[1] = ctx->post_recorded[2] = 0;
+        ctx->sdone_recorded[0] = ctx->sdone_recorded[1] = 0;
+        ctx->last_kind = 0;
+        ctx->shadow_epoch++;
     }
     ctx->pipeline = on ? 1 : 0;
     return OPUSGPU_OK;
@@ -865,6 +882,8 @@ int opusgpu_streams_reset(opusgpu_ctx *ctx, int first, int count, int full) {
         if (ctx->last_step_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->last_step_stream));
     }
     ctx->front_recorded = ctx->post_recorded[0] = ctx->post_recorded[1] = ctx->post_recorded[2] = 0; // (the reset below is synchronous)
+    ctx->sdone_recorded[0] = ctx->sdone_recorded[1] = 0;
+    ctx->shadow_epoch++; // (the parse kernel's copies of these streams' past are stale now)
     hipLaunchKernelGGL(k_stream_init, dim3(count), dim3(64), 0, ctx->stream, ctx->d_streams, first, count, ctx->channels,
                        full ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
@@ -891,6 +910,12 @@ int opusgpu_streams_alloc(opusgpu_ctx *ctx, int n_streams, int channels) {
     }
     hipError_t e = hipMalloc((void **)&ctx->d_streams, sizeof(StreamState) * (size_t)n_streams);
     if (e != hipSuccess) return fail(ctx, OPUSGPU_ALLOC_FAIL, "hipMalloc(streams)", e);
+    if (ctx->d_shadow) HIPCHK(ctx, hipFree(ctx->d_shadow));
+    ctx->d_shadow = nullptr;
+    e = hipMalloc(&ctx->d_shadow, sizeof(SilkShadow) * (size_t)n_streams);
+    if (e != hipSuccess) return fail(ctx, OPUSGPU_ALLOC_FAIL, "hipMalloc(shadow)", e);
+    HIPCHK(ctx, hipMemset(ctx->d_shadow, 0, sizeof(SilkShadow) * (size_t)n_streams)); // (epoch 0: never current)
+    ctx->shadow_epoch++;
     ctx->n_streams = n_streams;
     ctx->channels = channels;
     ctx->last_count.assign((size_t)n_streams, 0);
@@ -954,6 +979,24 @@ static void launch_jitter() {
 // `slices` (opusgpu_decode_packets: PCM that leaves in pieces): the step's entropy kernels run once over all n frames -- they wait
 // on latency, a fraction of the frames takes them as long as all -- and the arithmetic kernels slice by slice, frames
 // [bounds[i], bounds[i + 1]); after_slice(i) is called behind slice i's last launch (to queue that slice's copies).
+// A step is of one of three kinds: in order (0), pipelined CELT-only (1), pipelined SILK-only (2).  Going into or out of a run of
+// pipelined SILK-only steps happens from an idle device (their parse reads the stream state when it has no current copy of its
+// own, and whatever follows them reads what their last kernels write); every step of another kind ends the epoch of the parse
+// kernel's copies (it may write SILK state, or prev_mode, behind that kernel's back).
+static int enter_step_kind(opusgpu_ctx *ctx, int kind, hipStream_t s) {
+    if ((kind == 2) != (ctx->last_kind == 2)) {
+        if (int rc = sync_in_flight(ctx)) return rc;
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->front_recorded = ctx->post_recorded[0] = ctx->post_recorded[1] = ctx->post_recorded[2] = 0;
+        ctx->sdone_recorded[0] = ctx->sdone_recorded[1] = 0;
+        ctx->last_silk_mask = 0;
+    }
+    if (kind != 2) ctx->shadow_epoch++;
+    ctx->last_kind = kind;
+    return OPUSGPU_OK;
+}
+
 struct StepSlices {
     int count = 0;
     const size_t *bounds = nullptr;
@@ -971,6 +1014,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     ctx->last_had_silk_recs = ctx->split_celt && ctx->split_hybrid;
     if (ctx->mode == OPUSGPU_MODE_RFC) { // every frame on the one kernel of that mode (og_rfc.hip)
         HIPCHK(ctx, hipSetDevice(ctx->device));
+        if (int rc = enter_step_kind(ctx, 0, s)) return rc;
         og_launch_decode_rfc(s, d_descs, d_arena, ctx->d_streams, d_pcm, d_result, n, ctx->n_streams, pcm_stride);
         HIPCHK(ctx, hipGetLastError());
         if (ctx->pipeline) { // (a later pipelined step's early parse waits for all of this one)
@@ -982,6 +1026,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!ctx->split_celt) { // OPUSGPU_SPLIT=0 (A/B measurements): every frame through the single kernel, in order
+        if (int rc = enter_step_kind(ctx, 0, s)) return rc;
         hipLaunchKernelGGL(k_decode_step, dim3(n), dim3(64), 0, s, (const FrameDesc *)d_descs, (const u8 *)d_arena, ctx->d_streams,
                            (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, 0, nullptr, nullptr, 0);
         HIPCHK(ctx, hipGetLastError());
@@ -998,6 +1043,10 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     // the two do not combine: a mixed or undeclared step takes the halves.)
     const bool pipe = ctx->pipeline && tables_resident && modes == 4;
     const bool window = pipe && next_n > 0; // the next step is queued by this very call: see PLACEMENT
+    // ... and a step declared free of CELT-only frames runs its parse kernels ahead (PIPELINED SILK / HYBRID STEPS below)
+    const bool pipe_silk = ctx->pipeline && tables_resident && (modes & 4) == 0 && ctx->split_hybrid && !slices &&
+                           (modes == 1 ? og_debug().silk_pipeline : og_debug().hybrid_pipeline);
+    if (int rc = enter_step_kind(ctx, pipe ? 1 : pipe_silk ? 2 : 0, s)) return rc;
     if (ctx->pipeline && ctx->last_step_stream && ctx->last_step_stream != s) {
         // consecutive steps on different streams: nothing orders them but the caller, so nothing may run ahead either
         HIPCHK(ctx, hipStreamSynchronize(ctx->last_step_stream));
@@ -1009,7 +1058,9 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     // The records, the reconstruction's per-frame output and the hand-off buffers only grow; growing frees the old one, which
     // waits for the device to go idle.  Records and reconstruction output exist twice: pipelined steps alternate.
     if (pipe) ctx->slot = (ctx->slot + 1) % 3;
-    const int par = pipe ? ctx->slot : 0, par2 = (par + 1) % 3; // this step's slot; the slot of the step two before it
+    if (pipe_silk) ctx->silk_slot ^= 1;
+    const int sset = pipe_silk ? ctx->silk_slot : 0; // the set of SILK records and hand-offs this step uses (and of CELT records with them)
+    const int par = pipe ? ctx->slot : sset, par2 = (par + 1) % 3; // this step's slot; the slot of the step two before it
     {
         int rc;
         const size_t need = (size_t)n;
@@ -1022,27 +1073,36 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         if (ctx->fast_recon && ctx->leaf_kernel && any_celt && ctx->cap_leaf[par] < og_leaf_out_bytes() * need &&
             (rc = grow(ctx, &ctx->d_leaf[par], &ctx->cap_leaf[par], og_leaf_out_bytes() * need)))
             return rc;
-        if (ctx->split_hybrid && any_silk) {
-            if (ctx->cap_handoff < sizeof(SilkHandoff) * need &&
-                (rc = grow(ctx, &ctx->d_handoff, &ctx->cap_handoff, sizeof(SilkHandoff) * need)))
+    }
+    if (ctx->split_hybrid && any_silk) {
+        int rc;
+        if (ctx->cap_handoff[sset] < sizeof(SilkHandoff) * (size_t)n || ctx->cap_srecs[sset] < sizeof(SilkRec) * (size_t)n) {
+            if (pipe_silk) { // (growing frees: not under kernels of the other set that are still in flight)
+                if ((rc = sync_in_flight(ctx))) return rc;
+                HIPCHK(ctx, hipStreamSynchronize(s));
+            }
+            if (ctx->cap_handoff[sset] < sizeof(SilkHandoff) * (size_t)n &&
+                (rc = grow(ctx, &ctx->d_handoff[sset], &ctx->cap_handoff[sset], sizeof(SilkHandoff) * (size_t)n)))
                 return rc;
-            if (ctx->cap_srecs < sizeof(SilkRec) * need && (rc = grow(ctx, &ctx->d_srecs, &ctx->cap_srecs, sizeof(SilkRec) * need)))
+            if (ctx->cap_srecs[sset] < sizeof(SilkRec) * (size_t)n &&
+                (rc = grow(ctx, &ctx->d_srecs[sset], &ctx->cap_srecs[sset], sizeof(SilkRec) * (size_t)n)))
                 return rc;
         }
     }
     ParseRec *const recs = (ParseRec *)ctx->d_recs[par];
     ReconOut *const rout = (ReconOut *)ctx->d_rout[par];
-    SilkHandoff *const handoff = ctx->split_hybrid && any_silk ? (SilkHandoff *)ctx->d_handoff : nullptr;
-    SilkRec *const srecs = ctx->split_hybrid && any_silk ? (SilkRec *)ctx->d_srecs : nullptr;
+    SilkHandoff *const handoff = ctx->split_hybrid && any_silk ? (SilkHandoff *)ctx->d_handoff[sset] : nullptr;
+    SilkRec *const srecs = ctx->split_hybrid && any_silk ? (SilkRec *)ctx->d_srecs[sset] : nullptr;
     ctx->last_recs = recs;
+    ctx->last_srecs = srecs;
     ctx->last_had_silk_recs = srecs != nullptr;
     const dim3 parse_block(64 * OG_PL_WAVES);
     // The in-order chain of frames [f0, f0 + cnt) of the step, in two halves: the ENTROPY kernels (one frame per lane) ...
-    auto front = [&](hipStream_t q, size_t f0, int cnt) {
+    auto front = [&](hipStream_t q, size_t f0, int cnt, SilkShadow *shadow = nullptr, u32 epoch = 0) {
         const FrameDesc *dd = (const FrameDesc *)d_descs + f0;
         if (srecs)
             hipLaunchKernelGGL(k_silk_parse, dim3((cnt + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, q, dd, (const u8 *)d_arena,
-                               (const StreamState *)ctx->d_streams, srecs + f0, handoff + f0, cnt, ctx->n_streams, (SilkShadow *)nullptr, 0u);
+                               (const StreamState *)ctx->d_streams, srecs + f0, handoff + f0, cnt, ctx->n_streams, shadow, epoch);
         if (any_celt)
             hipLaunchKernelGGL(k_celt_parse, dim3((cnt + OG_PL_FRAMES - 1) / OG_PL_FRAMES), parse_block, 0, q, dd, (const u8 *)d_arena,
                                ctx->d_streams, recs + f0, cnt, ctx->n_streams, (const SilkHandoff *)(handoff ? handoff + f0 : nullptr),
@@ -1080,6 +1140,35 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
             hipLaunchKernelGGL(k_decode_step, dim3((cnt + 63) / 64), dim3(64), 0, q, dd, (const u8 *)d_arena, ctx->d_streams, pp, rr, cnt,
                                ctx->n_streams, pcm_stride, 1, handoff + f0, (const SilkRec *)(srecs + f0), 1);
     };
+    if (pipe_silk) {
+        // PIPELINED SILK / HYBRID STEPS (no CELT-only frames).  k_silk_parse waits on latency (0.9 ms of one lane's serial chain for 0.27 ms of issue time at
+        // 65,536 frames), k_silk_synth is bound by issue: they fit next to each other, but within a step the second needs the
+        // first.  Across steps the parse needs of step k only what step k's parse already knows -- the indices' history, the gain
+        // index, the NLSFs, the rate and channel count, prev_mode: all of it entropy-side -- so it keeps a copy of its own
+        // (SilkShadow) and runs for step k + 1 on parse_stream while step k's synthesis is under way on the step's stream -- for
+        // hybrid frames followed by their CELT parse, which resumes its range decoder and carries the band energies itself as in
+        // pipelined CELT-only steps.  Two sets of records and hand-offs alternate; the parse of step k + 1 waits for the last kernel of step k - 1 (its set's
+        // last reader -- and with it for every write to the state of streams it may have no current copy of).
+        if (!ctx->ev_sparsed) {
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_sparsed, hipEventDisableTiming));
+            for (int i = 0; i < 2; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_sdone[i], hipEventDisableTiming));
+        }
+        if (ctx->sdone_recorded[sset]) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_sdone[sset], 0));
+        // One thing of the step before is not entropy-side: a SILK-only frame right behind a hybrid one (Q4) decodes a 2.5 ms CELT
+        // frame in the step's LAST kernel (the full kernel's second pass), which writes the band energies a hybrid frame's CELT parse
+        // predicts from.  So a step that may hold hybrid frames does not run ahead of a step that may have held SILK-only ones.
+        if ((modes & 2) && (ctx->last_silk_mask & 1) && ctx->sdone_recorded[sset ^ 1])
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_sdone[sset ^ 1], 0));
+        ctx->last_silk_mask = modes;
+        front(ctx->parse_stream, 0, n, (SilkShadow *)ctx->d_shadow, (u32)ctx->shadow_epoch);
+        HIPCHK(ctx, hipEventRecord(ctx->ev_sparsed, ctx->parse_stream));
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_sparsed, 0));
+        back_half(s, 0, n);
+        HIPCHK(ctx, hipEventRecord(ctx->ev_sdone[sset], s));
+        ctx->sdone_recorded[sset] = 1;
+        HIPCHK(ctx, hipGetLastError());
+        return OPUSGPU_OK;
+    }
     if (!pipe) {
         if (!slices && srecs && n >= 2 * OG_HALVES_MIN && og_debug().halves) {
             // TWO HALVES.  A step with SILK-only / hybrid frames runs in order -- k_silk_parse reads state the step's later kernels
@@ -1439,10 +1528,10 @@ int opusgpu_debug_stage_taps(opusgpu_ctx *ctx, int slot, opusgpu_stage_taps *out
     out->pf_period = c.pf_period;
     out->pf_gain_state = c.pf_gain;
     out->pf_tapset_state = c.pf_tapset;
-    if (mode != MODE_CELT && ctx->last_had_silk_recs && ctx->d_srecs) {
+    if (mode != MODE_CELT && ctx->last_had_silk_recs && ctx->last_srecs) {
         std::unique_ptr<SilkRec> r(new (std::nothrow) SilkRec);
         if (!r) return OPUSGPU_ALLOC_FAIL;
-        HIPCHK(ctx, hipMemcpy(r.get(), (const SilkRec *)ctx->d_srecs + slot, sizeof(SilkRec), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(r.get(), (const SilkRec *)ctx->last_srecs + slot, sizeof(SilkRec), hipMemcpyDeviceToHost));
         out->silk_valid = 1;
         out->silk_ret = r->ret;
         out->decode_only_middle = r->decode_only_middle;

@@ -9,6 +9,8 @@
 //   OPUSGPU_FAST_RECON        fast_recon       1        0: every CELT frame through the general reconstruction kernel
 //   OPUSGPU_LEAF_KERNEL       leaf_kernel      0        1: the PVQ leaves of 20 ms frames are decoded by k_celt_leaves (og_leaves.hip: one leaf per
 //                                                       lane across frames, sorted by cost) ahead of the reconstruction kernel -- measured slower
+//   OPUSGPU_SILK_PIPELINE     silk_pipeline    1        0: steps declared SILK-only run in order even with pipelining on (A/B measurements)
+//   OPUSGPU_HYBRID_PIPELINE   hybrid_pipeline  1        0: the same for steps declared hybrid (or SILK-only + hybrid)
 //   OPUSGPU_HALVES            halves           1        0: an in-order step with SILK-only / hybrid frames runs as ONE chain of kernels, not two
 //   OPUSGPU_PARSE_GROUPS      parse_groups     2        groups of 32 frames per workgroup of the early parse (1 .. 8)
 //   OPUSGPU_PARSE_PRIORITY    parse_priority   1        0: the early parse's stream gets the LOWEST priority instead of the highest
@@ -22,7 +24,7 @@
 #include <stdlib.h>
 
 struct og_debug_knobs {
-    int split = 1, split_hybrid = 1, fast_recon = 1, leaf_kernel = 0, halves = 1, parse_groups = 2, parse_priority = 1, host_parts = 8, host_slices = 1, host_timing = 0,
+    int split = 1, split_hybrid = 1, fast_recon = 1, leaf_kernel = 0, halves = 1, silk_pipeline = 1, hybrid_pipeline = 1, parse_groups = 2, parse_priority = 1, host_parts = 8, host_slices = 1, host_timing = 0,
         pages_timing = 0, launch_delay_us = 0;
 };
 inline const og_debug_knobs &og_debug() {
@@ -42,6 +44,8 @@ inline const og_debug_knobs &og_debug() {
         flag("OPUSGPU_FAST_RECON", v.fast_recon);
         flag("OPUSGPU_LEAF_KERNEL", v.leaf_kernel);
         flag("OPUSGPU_HALVES", v.halves);
+        flag("OPUSGPU_SILK_PIPELINE", v.silk_pipeline);
+        flag("OPUSGPU_HYBRID_PIPELINE", v.hybrid_pipeline);
         number("OPUSGPU_PARSE_GROUPS", v.parse_groups, 1, 8);
         flag("OPUSGPU_PARSE_PRIORITY", v.parse_priority);
         if (const char *e = getenv("OPUSGPU_HOST_PARTS")) {

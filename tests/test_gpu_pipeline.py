@@ -313,3 +313,115 @@ def test_pipelined_steps_of_odd_sizes(pkg, oracle, gpu_ctx, n):
             pcm, res = run_queued(pkg, gpu_ctx, 2, arena, offs, plen - 1, toc, pipeline=True, modes=modes, window=window)
             assert (res == 960).all()
             assert np.array_equal(pcm.reshape(frames, n, 960, 2).transpose(1, 0, 2, 3), ref)
+
+
+SILK_CONFIGS = np.array([1, 5, 9])  # SILK-only NB / MB / WB, 20 ms
+
+
+@pytest.mark.parametrize("channels,configs,mask", [(2, SILK_CONFIGS, 1), (1, SILK_CONFIGS, 1), (2, np.array([1, 5, 9, 13, 15]), 3),
+                                                   (1, np.array([13, 15, 9]), 3), (2, np.array([13, 15]), 2)])
+def test_pipelined_silk_only_steps_random_walks(pkg, oracle, gpu_ctx, channels, configs, mask):
+    """Steps the caller declares SILK-only (mode mask 1) with pipelining on: the parse of step k + 1 runs on the library's stream
+    next to step k's synthesis, from the copy of the entropy half's past that the parse kernel keeps (SilkShadow).  Random walks
+    over NB / MB / WB, mono and stereo packets in mono and stereo decoders (the side channel appears, vanishes and restarts), payloads
+    of 0 .. 1275 bytes (error frames leave the past alone); queued back to back, one call per step and as a window, with
+    synchronisation points and a reset in the middle (which ends the copies' epoch)."""
+    rng = np.random.default_rng(5200 + channels + 10 * mask)
+    n, frames = 3072, 16
+    # (mask 3 / 2: hybrid frames among them or alone -- their CELT parse runs ahead with the SILK parse; SILK-only frames right
+    # behind hybrid ones are Q4 transition frames)
+    arena, offs, plen, lens, toc = make_walk(rng, n, frames, channels, configs=configs, p_home=0.7)
+    ref, rets = oracle.batch_decode_var(channels, arena, offs, plen.astype(np.int32))
+    for window in (False, True):
+        pcm, res = run_queued(pkg, gpu_ctx, channels, arena, offs, lens, toc, pipeline=True, modes=mask, window=window)
+        assert compare(pcm, res, ref, rets, toc, channels) == 0
+    pcm, res = run_queued(pkg, gpu_ctx, channels, arena, offs, lens, toc, pipeline=True, modes=mask, sync_every=3)
+    assert compare(pcm, res, ref, rets, toc, channels) == 0
+    # a reset between steps 7 and 8: the oracle's decoders are reset there too
+    decs = [oracle.decoder(channels) for _ in range(256)]
+    sub = slice(0, 256)
+    want = np.zeros((256, frames, 960, channels), dtype=np.int16)
+    wret = np.zeros((256, frames), dtype=np.int32)
+    for s_, d in enumerate(decs):
+        d.init()
+        for f in range(frames):
+            if f == 8:
+                d.reset()
+            o, r = d.decode(arena[offs[f, s_]:offs[f, s_] + plen[f, s_]].tobytes())
+            wret[s_, f] = r
+            if r > 0:
+                want[s_, f] = o[:960]
+    pcm, res = run_queued(pkg, gpu_ctx, channels, arena, offs[:, sub], lens[:, sub], toc[:, sub], pipeline=True, modes=mask, reset_at=8)
+    assert compare(pcm, res, want, wret, toc[:, sub], channels) == 0
+
+
+def test_pipelined_silk_only_steps_between_steps_of_other_kinds(pkg, oracle, gpu_ctx):
+    """Runs of declared SILK-only steps between in-order steps (undeclared, any mode) and pipelined CELT-only steps over the SAME
+    streams: every switch of kind starts from an idle device and a new epoch, so the parse re-reads the state the other kinds left
+    (prev_mode = CELT makes the next SILK frame start from a fresh SILK decoder; a hybrid frame before a SILK-only one makes it a Q4
+    transition frame).  Streams also sit out some SILK-only steps (descriptor tables of a part of the streams)."""
+    rng = np.random.default_rng(5300)
+    channels, n = 2, 2048
+    plan = [0, 1, 1, 1, 4, 4, 1, 1, 0, 1, 1, 2, 1, 1, 1, 4, 1, 1]  # per step: mode mask the caller declares (0 = undeclared, any mode)
+    frames = len(plan)
+    pick = {1: SILK_CONFIGS, 2: np.array([13, 15]), 4: np.array([19, 23, 27, 31]), 0: CONFIGS}
+    cfg = np.stack([rng.choice(pick[m], n) for m in plan])
+    stereo = rng.random((frames, n)) < 0.85
+    toc = (cfg << 3 | np.where(stereo, 4, 0)).astype(np.uint8)
+    lens = rng.choice(LENS, (frames, n), p=np.r_[np.full(4, 0.02), np.full(15, 0.06), 0.02])
+    plen = (lens + 1).astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(plen.reshape(-1))[:-1]]).reshape(frames, n)
+    arena = rng.integers(0, 256, int(plen.sum()) + 16, dtype=np.uint8)
+    arena[offs.reshape(-1)] = toc.reshape(-1)
+    # which streams take part in a step: all, except in some SILK-only steps where a random third sits out
+    part = np.ones((frames, n), dtype=bool)
+    for f, m in enumerate(plan):
+        if m == 1 and f % 2 == 0:
+            part[f] = rng.random(n) < 0.67
+    # the oracle: every stream decodes the packets of the steps it takes part in
+    want = np.zeros((frames, n, 960 * channels), dtype=np.int16)
+    wret = np.full((frames, n), -12345, dtype=np.int32)
+    for s_ in range(n):
+        d = oracle.decoder(channels)
+        d.init()
+        for f in range(frames):
+            if part[f, s_]:
+                o, r = d.decode(arena[offs[f, s_]:offs[f, s_] + plen[f, s_]].tobytes())
+                wret[f, s_] = r
+                if r > 0:
+                    want[f, s_] = o[:960].reshape(-1)
+    ctx = gpu_ctx
+    flags, mode = desc_flags(toc)
+    ctx.streams_alloc(n, channels)
+    ctx.set_pipeline(True)
+    d_arena = ctx.dev_alloc(arena.size)
+    ctx.h2d(d_arena, arena)
+    bufs = []
+    try:
+        tables = []
+        for f in range(frames):
+            ids = np.nonzero(part[f])[0].astype(np.int32)
+            descs = np.zeros(len(ids), dtype=pkg.DESC_DTYPE)
+            descs["stream"], descs["offset"], descs["len"], descs["flags"] = ids, (offs[f, ids] + 1).astype(np.int32), lens[f, ids].astype(np.int32), flags[f, ids]
+            dd, dp, dr = ctx.dev_alloc(16 * len(ids)), ctx.dev_alloc(len(ids) * 960 * channels * 2), ctx.dev_alloc(4 * len(ids))
+            ctx.h2d(dd, descs)
+            bufs += [dd, dp, dr]
+            tables.append((ids, dd, dp, dr))
+        for f, (ids, dd, dp, dr) in enumerate(tables):  # queued back to back, no synchronisation by the caller
+            ctx.decode_step_device(len(ids), dd, d_arena, dp, dr, modes=plan[f])
+        ctx.synchronize()
+        for f, (ids, dd, dp, dr) in enumerate(tables):
+            pcm = np.zeros((len(ids), 960 * channels), dtype=np.int16)
+            res = np.zeros(len(ids), dtype=np.int32)
+            ctx.d2h(pcm, dp)
+            ctx.d2h(res, dr)
+            assert np.array_equal(res, wret[f, ids]), (f, plan[f], int((res != wret[f, ids]).sum()))
+            ok = res == 960
+            half = ok & (mode[f, ids] == 0) & ((toc[f, ids] & 4) == 0)  # Q3
+            full = ok & ~half
+            assert np.array_equal(pcm[full], want[f, ids][full]), (f, plan[f])
+            assert np.array_equal(pcm[half][:, :960], want[f, ids][half][:, :960]), (f, plan[f])
+    finally:
+        ctx.set_pipeline(False)
+        for p in [d_arena] + bufs:
+            ctx.dev_free(p)

@@ -60,7 +60,9 @@ def test_celt_stage_taps_match(pkg, oracle, emu, L):
             for c in range(2):
                 pre = np.ctypeslib.as_array(emu.emu_tap_syn_pre(c), shape=(1080,))
                 assert np.count_nonzero(pre) > 500, ("the IMDCT tap carries no signal", c, where)
-                assert (pre == _oracle_taps(oracle, d, 2, c, np.int32, 1080)).all(), ("IMDCT output", c, where)
+                # (the transform defines 60 words of overlap tail + 960 outputs; the 60 words behind them are whatever the
+                # emulation's working set held before -- other tests of this process decode other frames first)
+                assert (pre[:1020] == _oracle_taps(oracle, d, 2, c, np.int32, 1080)[:1020]).all(), ("IMDCT output", c, where)
                 post = np.ctypeslib.as_array(emu.emu_tap_syn_post(c), shape=(1080,))[:960]
                 assert (post == _oracle_taps(oracle, d, 3, c, np.int32, 960)).all(), ("comb filter output", c, where)
 

@@ -8,7 +8,9 @@ usage (GPU box): python3 tools/soak_parity.py [streams] [frames] [rounds] [seed]
        --rfc: RFC mode (true frame durations, all 32 configurations x codes 0..3) with 25 % lost packets, 6 % DTX packets and 10 % of the packets preceded by a recovery from their FEC data,
        through opusgpu_decode_packets against one oracle decoder per stream (tests/test_gpu_rfc.py's comparison, larger)
        --pipeline: the device-resident path with pipelined steps (opusgpu_set_pipeline): the tables of every step are uploaded
-       first, all steps of a round are queued back to back (one PCM buffer per step), compared afterwards"""
+       first, all steps of a round are queued back to back (one PCM buffer per step), compared afterwards
+       --pipeline --masks: ... and every step declares a mode mask and holds only frames of those modes: runs of SILK-only, hybrid,
+       CELT-only and mixed steps follow each other, so every kind of pipelined step and every switch between kinds is exercised"""
 import importlib.util
 import os
 import sys
@@ -33,6 +35,9 @@ if RFC:
 PIPE = "--pipeline" in sys.argv
 if PIPE:
     sys.argv.remove("--pipeline")
+MASKS = "--masks" in sys.argv  # with --pipeline: every step declares a mode mask (runs of SILK-only, hybrid, CELT-only, mixed steps)
+if MASKS:
+    sys.argv.remove("--masks")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
@@ -145,6 +150,21 @@ for rnd in range(rounds):
         # per stream a "home" configuration; each frame keeps it with probability 0.8, else any configuration
         home = rng.choice(CONFIGS, n)
         cfg = np.where(rng.random((frames, n)) < 0.8, home[None, :], rng.choice(CONFIGS, (frames, n)))
+        masks = [0] * frames
+        if MASKS:  # step f holds only frames of the modes in masks[f]: bit 0 SILK-only, 1 hybrid, 2 CELT-only (the library's mask)
+            by_mode = [np.array([1, 5, 9]), np.array([13, 15]), np.array([19, 23, 27, 31])]
+            homes = [rng.choice(c, n) for c in by_mode]
+            m = int(rng.choice([1, 2, 3, 4, 6, 7]))
+            for f in range(frames):
+                if rng.random() > 0.7:
+                    m = int(rng.choice([1, 1, 2, 2, 3, 4, 6, 7]))
+                masks[f] = m
+                allowed = [k for k in range(3) if m >> k & 1]
+                pick = rng.choice(allowed, n)
+                away = rng.random(n) > 0.8
+                for k in allowed:
+                    sel = pick == k
+                    cfg[f, sel] = np.where(away[sel], rng.choice(by_mode[k], int(sel.sum())), homes[k][sel])
         stereo = (rng.random((frames, n)) < (0.85 if channels == 2 else 0.15))
         toc = (cfg << 3 | np.where(stereo, 4, 0)).astype(np.uint8)
         lens = rng.choice(LENS, (frames, n), p=np.r_[np.full(4, 0.02), np.full(15, 0.06), 0.02])
@@ -186,7 +206,7 @@ for rnd in range(rounds):
             for f in range(frames):
                 upload(f, d_descs[f])
             for f in range(frames):
-                ctx.decode_step_device(n, d_descs[f], d_arena, d_pcms[f], d_ress[f])
+                ctx.decode_step_device(n, d_descs[f], d_arena, d_pcms[f], d_ress[f], modes=masks[f])
             ctx.synchronize()
         for f in range(frames):
             d_desc, d_pcm, d_res = d_descs[f % nbuf], d_pcms[f % nbuf], d_ress[f % nbuf]
@@ -214,5 +234,5 @@ for rnd in range(rounds):
         for p in [d_arena] + d_descs + d_pcms + d_ress:
             ctx.dev_free(p)
         print(f"round {rnd} channels {channels}: {n * frames} frames done, {bad_total} mismatches so far, {time.time() - t_start:.0f} s", flush=True)
-print(f"SOAK{' (pipelined steps)' if PIPE else ''}: {total} frames compared ({errs} of them error returns, compared as codes), {bad_total} mismatches")
+print(f"SOAK{' (pipelined steps' + (', declared mode masks' if MASKS else '') + ')' if PIPE else ''}: {total} frames compared ({errs} of them error returns, compared as codes), {bad_total} mismatches")
 sys.exit(1 if bad_total else 0)
