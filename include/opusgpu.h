@@ -75,7 +75,12 @@ const char *opusgpu_last_error(const opusgpu_ctx *ctx);
  *   - opusgpu_decode_step_device: a descriptor with len <= 1 conceals the duration in its flags; mode and bandwidth come from
  *     the stream's state, the stereo bit should be that of the stream's last packet.
  *   SILK conceals with the reference's own (unreachable) silk_PLC / silk_CNG code restated (src/silk.cpp:2862-3185, :1305-1432),
- *   CELT with the noise-based concealment of RFC 6716's decoder; hybrid with both.  Use one mode per stream from its (re)set on:
+ *   CELT with the noise-based concealment of RFC 6716's decoder; hybrid with both.
+ *   TWO DEVIATIONS from what RFC 6716's decoder does (neither is normative -- a decoder may conceal as it likes -- and the oracle's
+ *   RFC mode makes the same choices, so GPU and oracle agree with each other, not with libopus): (1) CELT concealment is ALWAYS the
+ *   noise-based branch; libopus extrapolates the first lost frames of a CELT stream from the pitch period (celt_decode_lost with
+ *   loss_count < 5 and start == 0) and only then falls back to noise; (2) a concealment is cut into pieces of the stream's LAST
+ *   frame duration (what opus_decode(NULL) is asked for), with a remainder of 30 / 50 ms as 20 / 40 + 10 ms.  Use one mode per stream from its (re)set on:
  *   the state the concealment needs is only kept by RFC-mode frames.
  * Applies to opusgpu_packet_to_frames_mode / opusgpu_decode_packets / opusgpu_decode_step_device calls made after it is set:
  *   - descriptors carry the duration and the mode bit (frame_desc.flags bits 6 - 9); one without the bit is OPUSGPU_BAD_ARG;
@@ -100,6 +105,14 @@ int opusgpu_get_mode(const opusgpu_ctx *ctx);
  *   - d_descs and d_arena of a call are COMPLETE in device memory when the call is made (uploaded and synchronised, or
  *     produced by work that has finished) -- not merely queued on `hip_stream` ahead of the call;
  *   - consecutive steps use the same stream (a change of stream is honoured by draining both, i.e. no overlap).
+ * Which steps run ahead: a step the caller declares CELT-only (opusgpu_decode_step_device_modes, OPUSGPU_HAS_CELT alone) as
+ * described; a step declared free of CELT-only frames (OPUSGPU_HAS_SILK, OPUSGPU_HAS_HYBRID or both) runs its SILK parse -- and a
+ * hybrid frame's CELT parse behind it -- for step k+1 next to step k's SILK synthesis: the SILK parse keeps a copy of its own of
+ * what the entropy half needs of the frames before (indices' history, gain index, NLSFs, rate, channel count, prev_mode), which is
+ * exactly what it can compute itself (tests/test_emul_vs_oracle.py checks the copy against the state frame by frame); only a
+ * step that may hold hybrid frames waits for a step that may have held SILK-only ones (the hybrid -> SILK-only transition frame
+ * decodes a CELT frame in the step's last kernel).  A step that is undeclared or mixes CELT-only frames with the others runs in
+ * order (cut into two halves on two streams when it has SILK frames).  Going from one kind of step to another drains the device.
  * opusgpu_decode_packets (whose uploads are queued by the call itself) runs in order regardless.  Switching synchronises
  * the device.  Reference: the per-packet call sequence this replaces is src/opus_decoder.cpp:931 -> :280 -> :154 ->
  * src/celt.cpp:2162, one packet at a time; there is nothing to pipeline there. */
@@ -182,7 +195,7 @@ int opusgpu_decode_step_device_modes(opusgpu_ctx *ctx, int n, const void *d_desc
 /* A WINDOW of consecutive decode steps in one call: step j has n[j] frames and the tables d_descs[j] / d_arena[j], and writes
  * d_pcm[j] / d_result[j]; everything opusgpu_decode_step_device_modes says holds per step (`modes`: 0 = not known), the tables of
  * every step are complete in device memory at the call.  Same results as n_steps single calls.  The point is pipelined steps
- * (opusgpu_set_pipeline) of CELT-only frames: knowing the step that follows, the library orders the kernels of neighbouring
+ * (opusgpu_set_pipeline) of CELT-only frames (SILK-only and hybrid steps pipeline the same way with either entry): knowing the step that follows, the library orders the kernels of neighbouring
  * steps by real dependencies -- the next step's parse is placed before this step's reconstruction, that before the previous
  * step's de-emphasis, each held by a stream memory wait on a count of started workgroups -- where a single call has to leave
  * the order to the hardware queues (round 2 used a spin-wait kernel and an unused LDS request for it; both are gone). */

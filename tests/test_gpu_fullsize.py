@@ -61,10 +61,14 @@ def test_fullsize_hybrid_c4(pkg, oracle, gpu_ctx):
     _run(pkg, oracle, gpu_ctx, pkg.TOC_HYBRID_FB_STEREO, 120, 262144, 2)
 
 
-def test_fullsize_celt_pipelined_queued(pkg, oracle, gpu_ctx):
-    """What `python bench.py` times: 65,536 CELT-FB streams, pipelined steps with the mode mask, no synchronisation between
-    the steps (every step's tables resident before the first call).  Every sample of every step against the oracle."""
-    ctx, toc, L, n, steps = gpu_ctx, pkg.TOC_CELT_FB_STEREO, 160, 65536, 8
+@pytest.mark.parametrize("which", ["celt", "silk_nb", "hybrid"])
+def test_fullsize_pipelined_queued(pkg, oracle, gpu_ctx, which):
+    """What `python bench.py` times: 65,536 CELT-FB / SILK-NB / hybrid-FB streams, pipelined steps with the mode mask (CELT-only: parse,
+    reconstruction and de-emphasis of neighbouring steps overlap; SILK-only and hybrid: the parse kernels of step k + 1 next to the
+    synthesis of step k), no synchronisation between the steps (every step's tables resident before the first call), queued one
+    call per step and, a second time on fresh streams, as one window.  Every sample of every step against the oracle."""
+    toc, L = {"celt": (pkg.TOC_CELT_FB_STEREO, 160), "silk_nb": (pkg.TOC_SILK_NB_STEREO, 40), "hybrid": (pkg.TOC_HYBRID_FB_STEREO, 120)}[which]
+    ctx, n, steps = gpu_ctx, 65536, 8
     pay = pkg.lcg_payloads(n, steps, L, seed_base=0x0C2B1A5)
     ref, ok = oracle.batch_decode_threads(2, toc, pay)
     assert ok == n * steps
@@ -81,15 +85,20 @@ def test_fullsize_celt_pipelined_queued(pkg, oracle, gpu_ctx):
             ctx.h2d(d_arena[f], arena)
             ctx.h2d(d_desc[f], descs)
         ctx.set_pipeline(True)
-        for f in range(steps):
-            ctx.decode_step_device(n, d_desc[f], d_arena[f], d_pcm[f], d_res[f], modes=pkg.toc_modes(toc))
-        ctx.synchronize()
-        for f in range(steps):
-            ctx.d2h(out, d_pcm[f])
-            ctx.d2h(res, d_res[f])
-            assert (res == 960).all(), f"step {f}: {(res != 960).sum()} frames failed"
-            bad = np.nonzero((out != ref[:, f]).reshape(n, -1).any(axis=1))[0]
-            assert bad.size == 0, f"step {f}: {bad.size} of {n} streams differ from the oracle, first {bad[:5]}"
+        for window in (False, True):
+            if window:
+                ctx.streams_reset(0, n)
+                ctx.decode_steps_device([n] * steps, d_desc, d_arena, d_pcm, d_res, modes=pkg.toc_modes(toc))
+            else:
+                for f in range(steps):
+                    ctx.decode_step_device(n, d_desc[f], d_arena[f], d_pcm[f], d_res[f], modes=pkg.toc_modes(toc))
+            ctx.synchronize()
+            for f in range(steps):
+                ctx.d2h(out, d_pcm[f])
+                ctx.d2h(res, d_res[f])
+                assert (res == 960).all(), f"step {f}: {(res != 960).sum()} frames failed"
+                bad = np.nonzero((out != ref[:, f]).reshape(n, -1).any(axis=1))[0]
+                assert bad.size == 0, f"window {window} step {f}: {bad.size} of {n} streams differ from the oracle, first {bad[:5]}"
     finally:
         ctx.set_pipeline(False)
         for p in d_desc + d_arena + d_pcm + d_res:
