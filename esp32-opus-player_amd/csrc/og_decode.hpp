@@ -7,6 +7,7 @@
 #include "og_celt_split.hpp"
 #ifndef OG_NO_SILK
 #include "og_silk.hpp"
+#include "og_plc.hpp"
 #endif
 
 namespace og {
@@ -250,7 +251,7 @@ OG_DEV int conceal_chunk_rfc(StreamState *st, int ch, i16 *pcm, int audiosize, i
 #endif
     int celt_ret = 0;
     if (mode != MODE_SILK) {
-        celt_ret = celt_decode_lost(&st->celt, &st->loss, audiosize, CC, mode == MODE_CELT ? 0 : 17, st->loss.celt_end_band);
+        celt_ret = celt_conceal(&st->celt, &st->loss, audiosize, CC, mode == MODE_CELT ? 0 : 17, st->loss.celt_end_band);
 #ifndef OG_NO_SILK
         if (mode == MODE_HYBRID && celt_ret >= 0) {
             OG_SYNC();
@@ -422,7 +423,7 @@ OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mod
         const int lost = fec || celt_lost;
         const int Cp = lost ? CC : ch; // (a concealment runs over the decoder's channels: its PCM planes are laid out for C == CC)
         if (lost)
-            celt_ret = celt_decode_lost(&st->celt, &st->loss, audiosize, CC, mode == MODE_CELT ? 0 : 17, end_band);
+            celt_ret = celt_conceal(&st->celt, &st->loss, audiosize, CC, mode == MODE_CELT ? 0 : 17, end_band);
         else
             celt_ret = celt_decode_frame(&st->celt, rc, audiosize, ch, CC, mode == MODE_CELT ? 0 : 17, disable_inv, end_band, &st->loss);
 #ifndef OG_NO_SILK

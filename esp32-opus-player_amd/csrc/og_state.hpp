@@ -85,7 +85,8 @@ struct LossState {
     i32 celt_loss_count;
     i32 celt_end_band;         // last band by the bandwidth of the last decoded frame (what a concealment fills up to)
     i32 prev_redundancy;       // the last frame ended with a redundant CELT frame: a SILK -> CELT transition is under way
-    i32 reserved[1];
+    i32 plc_pitch;             // pitch-based CELT concealment (og_plc.hpp): the period found at the first lost frame,
+    i16 plc_lpc[2][24];        // and each channel's LPC filter of that frame, kept for the losses that follow
 };
 
 struct StreamState {

@@ -1260,7 +1260,243 @@ int oc_celt_decode(oc_celt *st, oc_rc *rc, i16 *pcm, int frame_size, oc_celt_tap
     return frame_size;
 }
 
-/* RFC 6716's celt_decode_lost, noise-based branch, then the tail of celt_decode_with_ec for a lost frame (de-emphasis only) */
+/* ---- pitch-based concealment (RFC mode) -------------------------------------------------------------------
+ * What RFC 6716's decoder does for the first lost frames of a CELT-only stream (celt_decode_lost with loss_count < 5 and
+ * start == 0): find the pitch period of the last output, take the LPC residual of the last two periods, repeat it -- decaying
+ * by the energy ratio of its two halves per period -- through the LPC synthesis filter continued from the history, keep the
+ * result from getting louder than what it continues, and leave an overlap tail (pre-filtered against the post-filter, folded
+ * by the window) for the next decoded frame's transform to blend into.  A decoder's concealment is not normative and neither
+ * the reference nor this image holds libopus' source: the STRUCTURE follows that decoder, the fixed-point detail below is this
+ * repository's own (64-bit accumulators instead of libopus' block-wise shifts; the 1,024 samples of history the decoder keeps
+ * anyway instead of 2,048, so the pitch search correlates the last 304 samples against lags 100 .. 720).  PARITY-UNPINNED; the
+ * HIP side (og_plc.hpp) makes the same choices and is compared with this, sample by sample. */
+#define PLC_LPC 24
+#define PLC_PMIN 100
+#define PLC_PMAX 720
+static int ilog64(unsigned long long x) { /* bits needed: 0 for 0 */
+    int n = 0;
+    while (x) {
+        n++;
+        x >>= 1;
+    }
+    return n;
+}
+static u32 isqrt64(unsigned long long x) { /* floor(sqrt(x)) for x < 2^62 */
+    unsigned long long r = 0, bit = 1ull << 60;
+    while (bit > x) bit >>= 2;
+    while (bit) {
+        if (x >= r + bit) {
+            x -= r + bit;
+            r = (r >> 1) + bit;
+        } else
+            r >>= 1;
+        bit >>= 2;
+    }
+    return (u32)r;
+}
+static i32 mul32_q31(i32 a, i32 b) { return (i32)(((i64)a * b) >> 31); }
+static i16 sat16_64(i64 x) { return x > 32767 ? 32767 : (x < -32768 ? -32768 : (i16)x); }
+#define PLC_ABS(x) ((x) < 0 ? -(x) : (x))
+/* sqrt(a / b) in Q15, at most 32767 (a, b >= 0, b > 0; both scaled down together until b < 2^30) */
+static i16 plc_ratio_q15(i64 a, i64 b) {
+    const int sh = OC_MAX(0, ilog64((unsigned long long)b) - 30);
+    u32 r;
+    a >>= sh;
+    b >>= sh;
+    if (b <= 0) return 32767;
+    if (a >= b) return 32767;
+    r = isqrt64((unsigned long long)(a << 30) / (unsigned long long)b);
+    return (i16)OC_MIN((u32)32767, r);
+}
+
+/* pitch period of v[0 .. 1024) (16-bit samples, newest last), 100 .. 720 */
+static int plc_pitch_search(const i16 *v) {
+    i16 lp[512], w[1024];
+    int i, L, best = 50, sh, mx = 0;
+    i64 bnum = -1, bden = 1;
+    /* half rate: (1 2 1) / 4, then scaled so that |lp| < 2^9 (sums of 152 products stay below 2^27) */
+    for (i = 0; i < 512; i++) {
+        const i32 a = i ? v[2 * i - 1] : 0, b = v[2 * i], c = v[2 * i + 1];
+        lp[i] = (i16)((a + 2 * b + c + 2) >> 2);
+        if (PLC_ABS(lp[i]) > mx) mx = PLC_ABS(lp[i]);
+    }
+    sh = OC_MAX(0, ilog64((unsigned long long)mx) - 9);
+    for (i = 0; i < 512; i++) lp[i] = (i16)(lp[i] >> sh);
+    for (L = PLC_PMIN / 2; L <= PLC_PMAX / 2; L++) { /* the last 152 samples against the 152 samples L earlier */
+        i64 xc = 0, en = 1, num;
+        for (i = 0; i < 152; i++) {
+            xc += (i32)lp[360 + i] * lp[360 - L + i];
+            en += (i32)lp[360 - L + i] * lp[360 - L + i];
+        }
+        if (xc <= 0) continue;
+        num = (xc * xc) >> 20;
+        if (num * bden > bnum * en) { /* strictly better: the shortest lag wins a tie */
+            bnum = num;
+            bden = en;
+            best = L;
+        }
+    }
+    /* full rate around 2 * best */
+    mx = 0;
+    for (i = 0; i < 1024; i++)
+        if (PLC_ABS(v[i]) > mx) mx = PLC_ABS(v[i]);
+    sh = OC_MAX(0, ilog64((unsigned long long)mx) - 9);
+    for (i = 0; i < 1024; i++) w[i] = (i16)(v[i] >> sh);
+    {
+        int P, bestP = 2 * best;
+        bnum = -1;
+        bden = 1;
+        for (P = 2 * best - 1; P <= 2 * best + 1; P++) {
+            i64 xc = 0, en = 1, num;
+            if (P < PLC_PMIN || P > PLC_PMAX) continue;
+            for (i = 0; i < 304; i++) {
+                xc += (i32)w[720 + i] * w[720 - P + i];
+                en += (i32)w[720 - P + i] * w[720 - P + i];
+            }
+            if (xc <= 0) continue;
+            num = (xc * xc) >> 20;
+            if (num * bden > bnum * en) {
+                bnum = num;
+                bden = en;
+                bestP = P;
+            }
+        }
+        return OC_MIN(PLC_PMAX, OC_MAX(PLC_PMIN, bestP));
+    }
+}
+
+/* order-24 LPC of v[0 .. 1024) in Q12 (autocorrelation, -40 dB noise floor, lag window, Levinson-Durbin) */
+static void plc_lpc(const i16 *v, i16 *lpc16) {
+    i64 acc[PLC_LPC + 1];
+    i32 ac[PLC_LPC + 1], lpc[PLC_LPC], err;
+    int i, j, k, sh;
+    for (k = 0; k <= PLC_LPC; k++) {
+        i64 a = 0;
+        for (i = k; i < 1024; i++) a += (i32)v[i] * v[i - k];
+        acc[k] = a;
+    }
+    sh = OC_MAX(0, ilog64((unsigned long long)acc[0]) - 29);
+    for (k = 0; k <= PLC_LPC; k++) ac[k] = (i32)(acc[k] >> sh);
+    ac[0] += ac[0] >> 13;
+    for (k = 1; k <= PLC_LPC; k++) ac[k] -= (i32)(((i64)ac[k] * (2 * k * k)) >> 15);
+    for (i = 0; i < PLC_LPC; i++) lpc[i] = 0;
+    err = ac[0];
+    if (ac[0] > 0)
+        for (i = 0; i < PLC_LPC; i++) {
+            i64 rr = 0, q;
+            i32 r;
+            for (j = 0; j < i; j++) rr += mul32_q31(lpc[j], ac[i - j]); /* lpc in Q25 */
+            rr += ac[i + 1] >> 6;
+            q = -((rr << 6) << 25) / err; /* reflection coefficient, Q25 */
+            if (q > (1 << 25) - 1) q = (1 << 25) - 1;
+            if (q < -(1 << 25) + 1) q = -(1 << 25) + 1;
+            r = (i32)q;
+            lpc[i] = r;
+            for (j = 0; j < (i + 1) >> 1; j++) {
+                const i32 t1 = lpc[j], t2 = lpc[i - 1 - j];
+                lpc[j] = t1 + (i32)(((i64)r * t2) >> 25);
+                lpc[i - 1 - j] = t2 + (i32)(((i64)r * t1) >> 25);
+            }
+            err -= (i32)(((i64)(i32)(((i64)r * r) >> 25) * err) >> 25);
+            if (err < (ac[0] >> 10)) break;
+        }
+    for (i = 0; i < PLC_LPC; i++) lpc16[i] = sat16(pshr32(lpc[i], 13));
+}
+
+static void celt_decode_lost_pitch(oc_celt *st, i16 *pcm, int N) {
+    static const i16 gains[3][3] = {{10048, 7112, 4248}, {15200, 8784, 0}, {26208, 3280, 0}};
+    const int C = st->channels, len = N + OC_OVERLAP, cmp = OC_MIN(len, 1024);
+    i32 *out_syn[2];
+    i16 v[2][1024 + PLC_LPC], mono[1024], lpc16[PLC_LPC], e[1024], sy[PLC_LPC + 960 + OC_OVERLAP];
+    i32 etmp[OC_OVERLAP];
+    int c, i, j, pitch, exc_len;
+    for (c = 0; c < C; c++) {
+        out_syn[c] = st->syn[c] + OC_HIST;
+        for (i = 0; i < PLC_LPC; i++) v[c][i] = 0; /* (nothing older than the history is known) */
+        for (i = 0; i < 1024; i++) v[c][PLC_LPC + i] = sat16(pshr32(st->syn[c][i], 12));
+    }
+    for (i = 0; i < 1024; i++) mono[i] = C == 2 ? (i16)((v[0][PLC_LPC + i] + v[1][PLC_LPC + i]) >> 1) : v[0][PLC_LPC + i];
+    if (st->loss_count == 0) st->plc_pitch = plc_pitch_search(mono);
+    pitch = st->plc_pitch;
+    exc_len = OC_MIN(2 * pitch, 1000);
+    for (c = 0; c < C; c++) {
+        const i16 *x = v[c] + PLC_LPC; /* x[-24 .. 1024) */
+        const i16 fade = st->loss_count == 0 ? 32767 : 26214; /* Q15: 1, 0.8 */
+        i64 E1 = 1, E2 = 1, S1 = 0, S2 = 0;
+        i32 att;
+        i16 decay;
+        if (st->loss_count == 0) {
+            plc_lpc(x, lpc16);
+            for (i = 0; i < PLC_LPC; i++) st->plc_lpc[c][i] = lpc16[i];
+        } else
+            for (i = 0; i < PLC_LPC; i++) lpc16[i] = st->plc_lpc[c][i];
+        /* the residual of the last exc_len samples */
+        for (i = 1024 - exc_len; i < 1024; i++) {
+            i64 a = 0;
+            for (j = 0; j < PLC_LPC; j++) a += (i32)lpc16[j] * x[i - 1 - j];
+            e[i] = sat16_64(x[i] + ((a + 2048) >> 12));
+        }
+        /* how much it decays from its first half to its second */
+        for (i = 0; i < exc_len / 2; i++) {
+            const i32 a = e[1024 - exc_len / 2 + i], b = e[1024 - 2 * (exc_len / 2) + i];
+            E1 += a * a;
+            E2 += b * b;
+        }
+        decay = plc_ratio_q15(OC_MIN(E1, E2), E2);
+        /* the period before the end, again and again, a little quieter each time, through the synthesis filter */
+        for (i = 0; i < PLC_LPC; i++) sy[i] = x[1024 - PLC_LPC + i];
+        att = m16_q15(fade, decay);
+        for (i = 0, j = 0; i < len; i++, j++) {
+            i64 a;
+            int k;
+            if (j >= pitch) {
+                j -= pitch;
+                att = m16_q15(att, decay);
+            }
+            a = (i64)m16_q15(att, e[1024 - pitch + j]) << 12;
+            for (k = 0; k < PLC_LPC; k++) a -= (i32)lpc16[k] * sy[PLC_LPC + i - 1 - k];
+            sy[PLC_LPC + i] = sat16_64((a + 2048) >> 12);
+        }
+        /* not louder than what it continues */
+        for (i = 0; i < cmp; i++) {
+            S1 += (i32)x[1024 - cmp + i] * x[1024 - cmp + i];
+            S2 += (i32)sy[PLC_LPC + i] * sy[PLC_LPC + i];
+        }
+        if (!(S1 > (S2 >> 2)))
+            for (i = 0; i < len; i++) sy[PLC_LPC + i] = 0;
+        else if (S1 < S2) {
+            const i16 ratio = plc_ratio_q15((S1 >> 1) + 1, S2 + 1);
+            for (i = 0; i < OC_OVERLAP; i++) {
+                const i16 g = (i16)(32767 - m16_q15(rom_win120[i], 32767 - ratio));
+                sy[PLC_LPC + i] = (i16)m16_q15(g, sy[PLC_LPC + i]);
+            }
+            for (i = OC_OVERLAP; i < len; i++) sy[PLC_LPC + i] = (i16)m16_q15(ratio, sy[PLC_LPC + i]);
+        }
+        for (i = 0; i < len; i++) out_syn[c][i] = (i32)sy[PLC_LPC + i] << 12;
+        /* the overlap for the next frame: pre-filtered against the post-filter that frame will run over it, folded by the window */
+        {
+            const int T = OC_MAX(st->pf_period, 15), tap = st->pf_tapset;
+            const i16 g = (i16)-st->pf_gain;
+            const i16 g0 = (i16)m16_p15(g, gains[tap][0]), g1 = (i16)m16_p15(g, gains[tap][1]), g2 = (i16)m16_p15(g, gains[tap][2]);
+            const i32 *xx = out_syn[c] + N;
+            for (i = 0; i < OC_OVERLAP; i++) {
+                i32 y = xx[i];
+                if (st->pf_gain != 0)
+                    y = satsym(y + m16x32_q15(g0, xx[i - T]) + m16x32_q15(g1, xx[i - T + 1] + xx[i - T - 1]) +
+                                   m16x32_q15(g2, xx[i - T + 2] + xx[i - T - 2]), OC_SIG_SAT);
+                etmp[i] = y;
+            }
+            for (i = 0; i < OC_OVERLAP / 2; i++)
+                out_syn[c][N + i] = m16x32_q15(rom_win120[i], etmp[OC_OVERLAP - 1 - i]) + m16x32_q15(rom_win120[OC_OVERLAP - 1 - i], etmp[i]);
+        }
+    }
+    deemphasis(out_syn, pcm, N, C, st->deemph_mem);
+    st->loss_count++;
+    for (c = 0; c < C; c++) memmove(st->syn[c], st->syn[c] + N, (OC_HIST + OC_OVERLAP / 2) * sizeof(i32));
+}
+
+/* RFC 6716's celt_decode_lost: the pitch-based branch above for the first lost frames of a stream that codes from band 0, else the
+ * noise-based branch, then the tail of celt_decode_with_ec for a lost frame (de-emphasis only) */
 int oc_celt_decode_lost(oc_celt *st, i16 *pcm, int frame_size) {
     const i32 *eb = rom_eband;
     const int C = st->channels; /* the concealment runs over the decoder's channels, not the last packet's */
@@ -1275,6 +1511,10 @@ int oc_celt_decode_lost(oc_celt *st, i16 *pcm, int frame_size) {
         if (120 << LM == frame_size) break;
     if (LM > 3 || pcm == NULL) return OC_BAD_ARG;
     N = 120 << LM;
+    if (st->loss_count < 5 && start == 0) {
+        celt_decode_lost_pitch(st, pcm, N);
+        return frame_size;
+    }
     for (c = 0; c < C; c++) out_syn[c] = st->syn[c] + OC_HIST;
     for (c = 0; c < C; c++)
         for (i = start; i < end; i++)

@@ -82,6 +82,8 @@ typedef struct {
     i16 bandE[2 * OC_NBANDS], logE1[2 * OC_NBANDS], logE2[2 * OC_NBANDS];
     i16 backgroundLogE[2 * OC_NBANDS]; /* celt.cpp:2206, :2413-2418: the noise floor the concealment decays to */
     i32 loss_count;                    /* celt.h:161 */
+    i32 plc_pitch;                     /* pitch-based concealment: the period found at the first lost frame, */
+    i16 plc_lpc[2][24];                /* and each channel's LPC filter of that frame (kept for the losses that follow) */
 } oc_celt;
 
 /* optional stage taps for parity tests of the HIP kernels (filled when non-NULL) */

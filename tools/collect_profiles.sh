@@ -22,7 +22,7 @@ else
     done; } > $out/host_path_rate.txt 2>&1
   tools/host_path_timeline.sh collect/host_timeline 65536 6 1 1 > $out/host_path_timeline.txt 2>&1
   timeout -k 10 300 python tools/launch_jitter.py > $out/launch_jitter.txt 2>&1
-  { timeout -k 10 500 python tools/soak_parity.py 32768 24 8 31; timeout -k 10 500 python tools/soak_parity.py --pipeline 32768 24 8 32;
+  { timeout -k 10 500 python tools/soak_parity.py 32768 24 8 31; timeout -k 10 500 python tools/soak_parity.py --pipeline 32768 24 8 32; timeout -k 10 500 python tools/soak_parity.py --pipeline --masks 16384 32 4 77;
     timeout -k 10 400 python tools/soak_parity.py --host 32768 8 2 33; timeout -k 10 400 python tools/soak_parity.py --rfc 4096 12 4 34; } > $out/soaks.log 2>&1
   tail -4 $out/soaks.log
 fi
