@@ -1431,8 +1431,8 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
 // Concealment of a lost CELT frame (RFC mode only; the reference has none, Q8): the noise-based branch of RFC 6716's
 // celt_decode_lost, as the oracle restates it (oc_celt_decode_lost).  The band energies decay towards the noise floor
 // (1.5 dB for the first lost frame, 0.5 dB after), every band from `start` to `end` of every DECODER channel is filled with LCG
-// noise and renormalised, then one long MDCT, no post-filter, de-emphasis.  The pitch-based branch is in neither the reference's
-// source nor normative and is not built.  PCM planes as after celt_decode_frame with C == CC.
+// noise and renormalised, then one long MDCT, no post-filter, de-emphasis.  (The pitch-based branch, taken for the first lost frames
+// of a CELT-only stream, is og_plc.hpp; celt_conceal there chooses.)  PCM planes as after celt_decode_frame with C == CC.
 OG_DEV int celt_decode_lost(CeltState *st, LossState *loss, int frame_size, int CC, int start, int end) {
     const i32 *eb = rom_eband;
     int LM;

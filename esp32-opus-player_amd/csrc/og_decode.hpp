@@ -378,6 +378,8 @@ OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mod
     i16 *const red_hold = &SL().u.out.up[0][0]; // 240 * CC samples: the 2x up-sampler's buffers are dead once SILK's PCM is out
     if (redundancy) transition = 0;
     if (transition && mode != MODE_CELT) { // (before this frame's last band is recorded: the concealment keeps the old one)
+        // (a hybrid frame's SILK PCM waits in SL().u.out.pcm for the CELT layer: the pitch-based concealment of the old mode, CELT,
+        // keeps its scratch out of those bytes -- og_plc.hpp)
         const int r = conceal_chunk_rfc(st, ch, nullptr, tr_size, tr_hold);
         if (r < 0) return r;
         if (mode == MODE_HYBRID) { // the concealment's synthesis ran over the packet buffer: the frame's bytes again

@@ -21,20 +21,40 @@ namespace og {
 
 constexpr int PLC_LPC = 24, PLC_PMIN = 100, PLC_PMAX = 720, PLC_HIST = 1024;
 
-struct PlcLds {
-    i16 x[PLC_LPC + PLC_HIST];              // the channel's history in 16 bits, 24 zeros in front (during the search: both channels' mean)
-    i16 e[PLC_HIST];                        // the residual (during the search: the scaled copy)
-    i16 sy[PLC_LPC + 960 + OVERLAP];        // synthesis: 24 samples of history, then the concealed frame and its overlap
-    i16 lp[PLC_HIST / 2];
-    long long acc[PLC_LPC + 1];             // autocorrelation; later: lane sums
-    long long part[2][64];                  // per-lane partial sums / per-lane best scores
-    i32 best_l[64];
+// Scratch.  A lost CELT-only frame has the SILK kernels' LDS objects to itself -- with one exception: when the concealment smooths
+// a switch from CELT to hybrid (RFC 6716 section 4.5), the new frame's SILK PCM is already waiting in SL().u.out.pcm for its CELT
+// layer.  So the scratch keeps out of those 3,840 bytes: three pieces -- A: from behind that PCM to the end of the SILK synthesis'
+// object (the up-sampler's buffers, where the concealment's OUTPUT is parked afterwards, and the decoder controls); B: the
+// synthesis' look-back rows in front of it; C: the wave-uniform SILK parse's object.
+struct PlcA {
+    i16 xs[PLC_LPC + 960 + OVERLAP];  // first the channel's history in 16 bits behind 24 zeros (x, 1,048 entries; during the search the
+                                      // channels' mean), then -- x is dead by then -- the synthesis: 24 samples of history, the frame, its overlap
+    i16 e[PLC_HIST];                  // the residual (during the search: the scaled copy)
     i32 etmp[OVERLAP];
+    long long acc[PLC_LPC + 1];       // autocorrelation
     i16 lpc16[PLC_LPC];
-    i32 scal[8];                            // [0] pitch, [1] decay, [2] ratio / verdict, [3] shift
+    i32 scal[8];                      // [0] a search's result, [3] a shift
 };
-static_assert(sizeof(PlcLds) <= sizeof(SilkLds), "the concealment's scratch lives in the SILK synthesis' LDS object");
-OG_DEV PlcLds &PL() { return *reinterpret_cast<PlcLds *>(&g_silk_lds); }
+struct PlcB {
+    long long part[2][OG_NLANES > 1 ? 64 : 1]; // per-lane partial sums / per-lane best scores
+    i32 best_l[OG_NLANES > 1 ? 64 : 1];
+};
+struct PlcC {
+    i16 lp[PLC_HIST / 2];             // the half-rate signal of the search
+};
+constexpr size_t PLC_A_AT = offsetof(SilkLds, u) + sizeof(i16) * 1920; // behind u.out.pcm
+static_assert(offsetof(SilkLds, u) % 8 == 0 && PLC_A_AT % 8 == 0, "scratch alignment");
+static_assert(PLC_A_AT + sizeof(PlcA) <= sizeof(SilkLds), "piece A: behind the SILK PCM");
+static_assert(sizeof(PlcB) <= offsetof(SilkLds, u), "piece B: in front of the SILK PCM");
+static_assert(sizeof(PlcC) <= sizeof(SilkWaveParseLds), "piece C: the wave-uniform SILK parse's object");
+struct PlcLds {
+    PlcA &a;
+    PlcB &b;
+    PlcC &c;
+};
+OG_DEV PlcA &PLA() { return *reinterpret_cast<PlcA *>(reinterpret_cast<u8 *>(&g_silk_lds) + PLC_A_AT); }
+OG_DEV PlcB &PLB() { return *reinterpret_cast<PlcB *>(&g_silk_lds); }
+OG_DEV PlcC &PLCc() { return *reinterpret_cast<PlcC *>(&g_silk_wp); }
 
 OG_DEV int plc_ilog64(unsigned long long x) { // bits needed: 0 for 0
     int n = 0;
@@ -77,9 +97,9 @@ OG_DEV bool plc_better(long long num, long long den, int l, long long bnum, long
 }
 
 // one round of the search: lags l0 + k * step ... <= l1 over buf (scaled 16-bit samples), window [at, at + n) against [at - lag, ...);
-// leaves the best lag in PL().scal[0] (or `fallback` when no lag correlates positively)
+// leaves the best lag in PLCS().scal[0] (or `fallback` when no lag correlates positively)
 OG_DEV void plc_search(const i16 *buf, int at, int n, int l0, int l1, int fallback) {
-    PlcLds &L = PL();
+    PlcA &L = PLA(); PlcB &LB = PLB(); PlcC &LC = PLCc(); (void)LB; (void)LC;
     long long bnum = -1, bden = 1;
     int bl = 0x7fffffff;
     for (int l = l0 + OG_LANE; l <= l1; l += OG_NLANES) {
@@ -96,17 +116,17 @@ OG_DEV void plc_search(const i16 *buf, int at, int n, int l0, int l1, int fallba
             bl = l;
         }
     }
-    L.part[0][OG_LANE] = bnum;
-    L.part[1][OG_LANE] = bden;
-    L.best_l[OG_LANE] = bl;
+    LB.part[0][OG_LANE] = bnum;
+    LB.part[1][OG_LANE] = bden;
+    LB.best_l[OG_LANE] = bl;
     OG_SYNC();
     if (OG_LANE == 0) {
         bnum = -1, bden = 1, bl = 0x7fffffff;
         for (int t = 0; t < OG_NLANES; t++)
-            if (L.part[0][t] >= 0 && plc_better(L.part[0][t], L.part[1][t], L.best_l[t], bnum, bden, bl)) {
-                bnum = L.part[0][t];
-                bden = L.part[1][t];
-                bl = L.best_l[t];
+            if (LB.part[0][t] >= 0 && plc_better(LB.part[0][t], LB.part[1][t], LB.best_l[t], bnum, bden, bl)) {
+                bnum = LB.part[0][t];
+                bden = LB.part[1][t];
+                bl = LB.best_l[t];
             }
         L.scal[0] = bnum >= 0 ? bl : fallback;
     }
@@ -115,16 +135,16 @@ OG_DEV void plc_search(const i16 *buf, int at, int n, int l0, int l1, int fallba
 
 // largest magnitude of buf[0 .. n) -> the shift that brings it below 2^9
 OG_DEV int plc_shift_for(const i16 *buf, int n) {
-    PlcLds &L = PL();
+    PlcA &L = PLA(); PlcB &LB = PLB(); PlcC &LC = PLCc(); (void)LB; (void)LC;
     int mx = 0;
     OG_FOR_LANES(i, n) {
         const int a = buf[i] < 0 ? -(int)buf[i] : (int)buf[i];
         mx = OG_MAX(mx, a);
     }
-    L.best_l[OG_LANE] = mx;
+    LB.best_l[OG_LANE] = mx;
     OG_SYNC();
     if (OG_LANE == 0) {
-        for (int t = 1; t < OG_NLANES; t++) mx = OG_MAX(mx, L.best_l[t]);
+        for (int t = 1; t < OG_NLANES; t++) mx = OG_MAX(mx, LB.best_l[t]);
         L.scal[3] = OG_MAX(0, plc_ilog64((unsigned long long)mx) - 9);
     }
     OG_SYNC();
@@ -133,20 +153,20 @@ OG_DEV int plc_shift_for(const i16 *buf, int n) {
     return sh;
 }
 
-// PL().x holds the signal to search (24 zeros, then 1024 samples): -> pitch period 100 .. 720
+// PLCS().x holds the signal to search (24 zeros, then 1024 samples): -> pitch period 100 .. 720
 OG_DEV int plc_pitch_search() {
-    PlcLds &L = PL();
-    const i16 *v = L.x + PLC_LPC;
+    PlcA &L = PLA(); PlcB &LB = PLB(); PlcC &LC = PLCc(); (void)LB; (void)LC;
+    const i16 *v = L.xs + PLC_LPC;
     OG_SYNC();
     OG_FOR_LANES(i, PLC_HIST / 2) {
         const i32 a = i ? v[2 * i - 1] : 0, b = v[2 * i], c = v[2 * i + 1];
-        L.lp[i] = (i16)((a + 2 * b + c + 2) >> 2);
+        LC.lp[i] = (i16)((a + 2 * b + c + 2) >> 2);
     }
     OG_SYNC();
-    int sh = plc_shift_for(L.lp, PLC_HIST / 2);
-    OG_FOR_LANES(i, PLC_HIST / 2) L.lp[i] = (i16)(L.lp[i] >> sh);
+    int sh = plc_shift_for(LC.lp, PLC_HIST / 2);
+    OG_FOR_LANES(i, PLC_HIST / 2) LC.lp[i] = (i16)(LC.lp[i] >> sh);
     OG_SYNC();
-    plc_search(L.lp, 360, 152, PLC_PMIN / 2, PLC_PMAX / 2, PLC_PMIN / 2);
+    plc_search(LC.lp, 360, 152, PLC_PMIN / 2, PLC_PMAX / 2, PLC_PMIN / 2);
     const int best = L.scal[0];
     OG_SYNC();
     sh = plc_shift_for(v, PLC_HIST);
@@ -158,10 +178,10 @@ OG_DEV int plc_pitch_search() {
     return p;
 }
 
-// order-24 LPC of PL().x[24 ..) in Q12 -> PL().lpc16
+// order-24 LPC of PLCS().x[24 ..) in Q12 -> PLCS().lpc16
 OG_DEV void plc_lpc() {
-    PlcLds &L = PL();
-    const i16 *v = L.x + PLC_LPC;
+    PlcA &L = PLA(); PlcB &LB = PLB(); PlcC &LC = PLCc(); (void)LB; (void)LC;
+    const i16 *v = L.xs + PLC_LPC;
     OG_SYNC();
     OG_FOR_LANES(k, PLC_LPC + 1) {
         long long a = 0;
@@ -202,15 +222,15 @@ OG_DEV void plc_lpc() {
 
 // sum over lanes of two 64-bit parts -> (a, b), on every lane
 OG_DEV void plc_sum2(long long &a, long long &b) {
-    PlcLds &L = PL();
+    PlcA &L = PLA(); PlcB &LB = PLB(); PlcC &LC = PLCc(); (void)LB; (void)LC;
     OG_SYNC();
-    L.part[0][OG_LANE] = a;
-    L.part[1][OG_LANE] = b;
+    LB.part[0][OG_LANE] = a;
+    LB.part[1][OG_LANE] = b;
     OG_SYNC();
     a = b = 0;
     for (int t = 0; t < OG_NLANES; t++) {
-        a += L.part[0][t];
-        b += L.part[1][t];
+        a += LB.part[0][t];
+        b += LB.part[1][t];
     }
     OG_SYNC();
 }
@@ -218,14 +238,14 @@ OG_DEV void plc_sum2(long long &a, long long &b) {
 // The concealed frame of every decoder channel: N samples into the history ring, the overlap tail, the de-emphasis memory, the
 // PCM planes (as after celt_decode_frame with C == CC).  Returns frame_size.
 OG_DEV int celt_decode_lost_pitch(CeltState *st, LossState *loss, int N, int CC) {
-    PlcLds &L = PL();
+    PlcA &L = PLA(); PlcB &LB = PLB(); PlcC &LC = PLCc(); (void)LB; (void)LC;
     const int len = N + OVERLAP, cmp = OG_MIN(len, PLC_HIST), pos = st->ring_pos;
     const int first = loss->celt_loss_count == 0;
     i32 *const SY = syn_buf();
     OG_SYNC();
-    OG_FOR_LANES(i, PLC_LPC) L.x[i] = 0;
+    OG_FOR_LANES(i, PLC_LPC) L.xs[i] = 0;
     if (first) { // the pitch period: searched once, on the mean of the channels
-        OG_FOR_LANES(i, PLC_HIST) L.x[PLC_LPC + i] = CC == 2 ? (i16)((plc_hist16(st, 0, pos, i) + plc_hist16(st, 1, pos, i)) >> 1) : (i16)plc_hist16(st, 0, pos, i);
+        OG_FOR_LANES(i, PLC_HIST) L.xs[PLC_LPC + i] = CC == 2 ? (i16)((plc_hist16(st, 0, pos, i) + plc_hist16(st, 1, pos, i)) >> 1) : (i16)plc_hist16(st, 0, pos, i);
         OG_SYNC();
         const int p = plc_pitch_search();
         if (OG_LANE == 0) loss->plc_pitch = p;
@@ -234,9 +254,9 @@ OG_DEV int celt_decode_lost_pitch(CeltState *st, LossState *loss, int N, int CC)
     const int pitch = OG_UNI(loss->plc_pitch), exc_len = OG_MIN(2 * pitch, 1000), half = exc_len / 2;
     for (int c = 0; c < CC; c++) {
         OG_SYNC();
-        OG_FOR_LANES(i, PLC_HIST) L.x[PLC_LPC + i] = (i16)plc_hist16(st, c, pos, i);
+        OG_FOR_LANES(i, PLC_HIST) L.xs[PLC_LPC + i] = (i16)plc_hist16(st, c, pos, i);
         OG_SYNC();
-        const i16 *x = L.x + PLC_LPC; // x[-24 .. 1024)
+        const i16 *x = L.xs + PLC_LPC; // x[-24 .. 1024)
         if (first) {
             plc_lpc();
             OG_FOR_LANES(i, PLC_LPC) loss->plc_lpc[c][i] = L.lpc16[i];
@@ -262,8 +282,24 @@ OG_DEV int celt_decode_lost_pitch(CeltState *st, LossState *loss, int N, int CC)
         E1 += 1;
         E2 += 1;
         const i32 decay = plc_ratio_q15(OG_MIN(E1, E2), E2);
+        // (the energy of what the concealment continues, while x is still there: the synthesis is written over it)
+        long long S1 = 0, S1b = 0;
+        OG_FOR_LANES(i, cmp) S1 += (i32)x[PLC_HIST - cmp + i] * (i32)x[PLC_HIST - cmp + i];
+        plc_sum2(S1, S1b);
         // the period before the end, again and again, a little quieter each time, through the synthesis filter (a recurrence: lane 0)
-        OG_FOR_LANES(i, PLC_LPC) L.sy[i] = x[PLC_HIST - PLC_LPC + i];
+        i32 keep = 0; // the filter's memory: the last 24 samples of x move to the front of the same array
+        if (OG_LANE < PLC_LPC) keep = x[PLC_HIST - PLC_LPC + OG_LANE];
+#ifdef OG_HOST_EMUL
+        i16 keep_all[PLC_LPC]; // (one lane stands for all)
+        for (int i = 0; i < PLC_LPC; i++) keep_all[i] = x[PLC_HIST - PLC_LPC + i];
+#endif
+        OG_SYNC();
+        i16 *const sy = L.xs;
+#ifdef OG_HOST_EMUL
+        for (int i = 0; i < PLC_LPC; i++) sy[i] = keep_all[i];
+#else
+        if (OG_LANE < PLC_LPC) sy[OG_LANE] = (i16)keep;
+#endif
         OG_SYNC();
         if (OG_LANE == 0) {
             const i32 fade = first ? 32767 : 26214; // Q15: 1, 0.8
@@ -274,29 +310,26 @@ OG_DEV int celt_decode_lost_pitch(CeltState *st, LossState *loss, int N, int CC)
                     att = mul16_q15(att, decay);
                 }
                 long long a = (long long)mul16_q15(att, L.e[PLC_HIST - pitch + j]) << 12;
-                for (int k = 0; k < PLC_LPC; k++) a -= (i32)L.lpc16[k] * (i32)L.sy[PLC_LPC + i - 1 - k];
-                L.sy[PLC_LPC + i] = (i16)plc_sat16_64((a + 2048) >> 12);
+                for (int k = 0; k < PLC_LPC; k++) a -= (i32)L.lpc16[k] * (i32)sy[PLC_LPC + i - 1 - k];
+                sy[PLC_LPC + i] = (i16)plc_sat16_64((a + 2048) >> 12);
             }
         }
         OG_SYNC();
         // not louder than what it continues
-        long long S1 = 0, S2 = 0;
-        OG_FOR_LANES(i, cmp) {
-            S1 += (i32)x[PLC_HIST - cmp + i] * (i32)x[PLC_HIST - cmp + i];
-            S2 += (i32)L.sy[PLC_LPC + i] * (i32)L.sy[PLC_LPC + i];
-        }
-        plc_sum2(S1, S2);
+        long long S2 = 0, S2b = 0;
+        OG_FOR_LANES(i, cmp) S2 += (i32)sy[PLC_LPC + i] * (i32)sy[PLC_LPC + i];
+        plc_sum2(S2, S2b);
         if (!(S1 > (S2 >> 2))) {
-            OG_FOR_LANES(i, len) L.sy[PLC_LPC + i] = 0;
+            OG_FOR_LANES(i, len) sy[PLC_LPC + i] = 0;
         } else if (S1 < S2) {
             const i32 ratio = plc_ratio_q15((S1 >> 1) + 1, S2 + 1);
             OG_FOR_LANES(i, len) {
                 const i32 g = i < OVERLAP ? (i32)(i16)(32767 - mul16_q15(rom_win120[i], 32767 - ratio)) : ratio;
-                L.sy[PLC_LPC + i] = (i16)mul16_q15(g, L.sy[PLC_LPC + i]);
+                sy[PLC_LPC + i] = (i16)mul16_q15(g, sy[PLC_LPC + i]);
             }
         }
         OG_SYNC();
-        OG_FOR_LANES(i, len) SY[i] = (i32)L.sy[PLC_LPC + i] << 12;
+        OG_FOR_LANES(i, len) SY[i] = (i32)sy[PLC_LPC + i] << 12;
         OG_SYNC();
         // the overlap for the next frame: pre-filtered against the post-filter that frame will run over it, folded by the window
         {

@@ -75,12 +75,15 @@ const char *opusgpu_last_error(const opusgpu_ctx *ctx);
  *   - opusgpu_decode_step_device: a descriptor with len <= 1 conceals the duration in its flags; mode and bandwidth come from
  *     the stream's state, the stereo bit should be that of the stream's last packet.
  *   SILK conceals with the reference's own (unreachable) silk_PLC / silk_CNG code restated (src/silk.cpp:2862-3185, :1305-1432),
- *   CELT with the noise-based concealment of RFC 6716's decoder; hybrid with both.
- *   TWO DEVIATIONS from what RFC 6716's decoder does (neither is normative -- a decoder may conceal as it likes -- and the oracle's
- *   RFC mode makes the same choices, so GPU and oracle agree with each other, not with libopus): (1) CELT concealment is ALWAYS the
- *   noise-based branch; libopus extrapolates the first lost frames of a CELT stream from the pitch period (celt_decode_lost with
- *   loss_count < 5 and start == 0) and only then falls back to noise; (2) a concealment is cut into pieces of the stream's LAST
- *   frame duration (what opus_decode(NULL) is asked for), with a remainder of 30 / 50 ms as 20 / 40 + 10 ms.  Use one mode per stream from its (re)set on:
+ *   CELT like RFC 6716's decoder (celt_decode_lost): the first five lost frames of a CELT-only stream are extrapolated from the
+ *   pitch period of the last output (pitch search, order-24 LPC, the residual of the last two periods repeated through the
+ *   synthesis filter with a decay, an overlap tail for the next frame's transform), later ones and hybrid's CELT layer are
+ *   noise at the decaying band energies; hybrid conceals with both coders.
+ *   Two things to know (a decoder's concealment is not normative, and the oracle's RFC mode makes the same choices, so GPU and
+ *   oracle agree with each other, not sample by sample with libopus): (1) the pitch-based branch follows that decoder's
+ *   STRUCTURE with fixed-point detail of this repository's own (64-bit accumulators, the 1,024 samples of history the decoder
+ *   keeps, csrc/og_plc.hpp); (2) a concealment is cut into pieces of the stream's LAST frame duration (what opus_decode(NULL)
+ *   is asked for), with a remainder of 30 / 50 ms as 20 / 40 + 10 ms.  Use one mode per stream from its (re)set on:
  *   the state the concealment needs is only kept by RFC-mode frames.
  * Applies to opusgpu_packet_to_frames_mode / opusgpu_decode_packets / opusgpu_decode_step_device calls made after it is set:
  *   - descriptors carry the duration and the mode bit (frame_desc.flags bits 6 - 9); one without the bit is OPUSGPU_BAD_ARG;

@@ -103,9 +103,11 @@ typedef struct {
 void oc_celt_init(oc_celt *st, int channels);           /* celt_decoder_init  celt.cpp:1933 */
 void oc_celt_reset(oc_celt *st);                        /* OPUS_RESET_STATE   celt.cpp:2479 (partial, Q5) */
 int oc_celt_decode(oc_celt *st, oc_rc *rc, i16 *pcm, int frame_size, oc_celt_taps *taps); /* celt.cpp:2162 */
-/* Concealment of a lost CELT frame (RFC mode only; the reference has none, Q8): the noise-based branch of RFC 6716's decoder
- * (celt_decode_lost): band energies decay towards backgroundLogE, every band is filled with renormalised LCG noise, one long
- * MDCT, no post-filter.  The pitch-based branch is in neither the reference nor normative and is not restated. */
+/* Concealment of a lost CELT frame (RFC mode only; the reference has none, Q8), after RFC 6716's decoder (celt_decode_lost): the
+ * first five lost frames of a stream that codes from band 0 are extrapolated from the pitch period of the last output
+ * (celt_decode_lost_pitch in oc_celt.c: the structure of that decoder, fixed-point detail of this repository's own); after that,
+ * and for hybrid's CELT layer, the noise-based branch: band energies decay towards backgroundLogE, every band is filled with
+ * renormalised LCG noise, one long MDCT, no post-filter.  No reference output pins either (PARITY-UNPINNED). */
 int oc_celt_decode_lost(oc_celt *st, i16 *pcm, int frame_size);
 
 /* stage functions exported for unit tests of the HIP kernels */

@@ -71,26 +71,31 @@ def test_oracle_conceals_the_duration_asked_for(oracle):
 
 
 def test_oracle_celt_concealment_decays(oracle):
-    """a burst of lost CELT frames fades towards the noise floor (1.5 dB for the first frame, 0.5 dB per frame after, never below
-    the floor the decoded frames left): over a burst the level never grows, and where the last decoded frame was well above
-    the floor it falls"""
-    fell = 0
+    """a burst of lost CELT frames: the first five are extrapolated from the pitch period of the last output (each period a little
+    quieter, never louder than what it continues); from the sixth on the noise-based branch takes over from the energies the last
+    DECODED frame left and fades towards the noise floor (0.5 dB per frame, never below the floor).  Within either phase the level
+    does not grow, and over the noise phase it falls where the last decoded frame was well above the floor."""
+    fell = quieter = 0
     for seed in range(12):
         rng = np.random.default_rng(seed)
         d = oracle.decoder(2)
         d.init()
         d.set_rfc(True)
         for _ in range(6):
-            d.decode(bytes([0xFC]) + rng.integers(0, 256, 120, dtype=np.uint8).tobytes())
+            ref, _r = d.decode(bytes([0xFC]) + rng.integers(0, 256, 120, dtype=np.uint8).tobytes())
+        last = float(np.sqrt(np.mean(ref[:960].astype(np.float64) ** 2)))
         rms = []
-        for _ in range(16):
+        for _ in range(24):
             buf, r = d.conceal(960)
             assert r == 960
             rms.append(float(np.sqrt(np.mean(buf[:960].astype(np.float64) ** 2))))
-        early, late = np.mean(rms[1:5]), np.mean(rms[-4:])  # (the first frame still carries the overlap of the last decoded one)
-        assert early > 0 and late <= 1.15 * early, (seed, rms)
-        fell += late < 0.5 * early
-    assert fell >= 3, fell
+        assert max(rms[:5]) <= 1.3 * last + 1, (seed, last, rms[:5])  # the pitch phase continues the last frame, no louder
+        assert all(rms[k + 1] <= 1.05 * rms[k] + 1 for k in range(4)), (seed, rms[:5])
+        quieter += rms[4] < 0.8 * rms[0]
+        early, late = np.mean(rms[6:10]), np.mean(rms[-4:])  # the noise phase
+        assert late <= 1.15 * early + 1, (seed, rms)
+        fell += late < 0.7 * early
+    assert fell >= 3 and quieter >= 6, (fell, quieter)
 
 
 def test_oracle_mode_transitions_start_from_the_old_modes_concealment(oracle):
