@@ -194,3 +194,13 @@ def test_reference_mode_unchanged_after_rfc(pkg, oracle, gpu_ctx):
         pcm, res = ctx.decode_packets(np.arange(n), pk)
         assert (res == 960).all()
         assert (pcm == ref[:, f]).all()
+
+
+@pytest.mark.parametrize("channels", [2, 1])
+def test_rfc_celt_loss_bursts_pitch_then_noise(pkg, oracle, gpu_ctx, channels):
+    """CELT-only streams of every bandwidth and frame duration (configurations 16 .. 31) losing half of their packets: bursts of one
+    to ten lost frames -- the first five of a burst extrapolated from the pitch period (og_plc.hpp: the search and the LPC analysis at
+    the burst's first frame, period and filter kept for the rest), the later ones noise at the decaying band energies -- and the
+    first decoded frame behind a burst blending into the concealment's overlap tail.  Every sample against the oracle's RFC mode."""
+    plan = {"streams": 640, "steps": 14, "pick": lambda s, f, rng: (16 + s % 16, int(rng.choice([0, 0, 1, 3])))}
+    assert _run(pkg, oracle, gpu_ctx, channels, plan, 901 + channels, p_loss=0.5, p_dtx=0.03) > 640 * 9
