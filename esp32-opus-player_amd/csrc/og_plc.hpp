@@ -202,7 +202,7 @@ OG_DEV void plc_lpc() {
                 long long rr = 0;
                 for (int j = 0; j < i; j++) rr += (i32)(((long long)lpc[j] * ac[i - j]) >> 31); // lpc in Q25
                 rr += ac[i + 1] >> 6;
-                long long q = -((rr << 6) << 25) / err; // reflection coefficient, Q25
+                long long q = -(rr * 64 * 33554432) / err; // reflection coefficient, Q25
                 if (q > (1 << 25) - 1) q = (1 << 25) - 1;
                 if (q < -(1 << 25) + 1) q = -(1 << 25) + 1;
                 const i32 r = (i32)q;
@@ -309,7 +309,7 @@ OG_DEV int celt_decode_lost_pitch(CeltState *st, LossState *loss, int N, int CC)
                     j -= pitch;
                     att = mul16_q15(att, decay);
                 }
-                long long a = (long long)mul16_q15(att, L.e[PLC_HIST - pitch + j]) << 12;
+                long long a = (long long)mul16_q15(att, L.e[PLC_HIST - pitch + j]) * 4096;
                 for (int k = 0; k < PLC_LPC; k++) a -= (i32)L.lpc16[k] * (i32)sy[PLC_LPC + i - 1 - k];
                 sy[PLC_LPC + i] = (i16)plc_sat16_64((a + 2048) >> 12);
             }
@@ -329,7 +329,7 @@ OG_DEV int celt_decode_lost_pitch(CeltState *st, LossState *loss, int N, int CC)
             }
         }
         OG_SYNC();
-        OG_FOR_LANES(i, len) SY[i] = (i32)sy[PLC_LPC + i] << 12;
+        OG_FOR_LANES(i, len) SY[i] = (i32)sy[PLC_LPC + i] * 4096;
         OG_SYNC();
         // the overlap for the next frame: pre-filtered against the post-filter that frame will run over it, folded by the window
         {

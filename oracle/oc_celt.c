@@ -1387,7 +1387,7 @@ static void plc_lpc(const i16 *v, i16 *lpc16) {
             i32 r;
             for (j = 0; j < i; j++) rr += mul32_q31(lpc[j], ac[i - j]); /* lpc in Q25 */
             rr += ac[i + 1] >> 6;
-            q = -((rr << 6) << 25) / err; /* reflection coefficient, Q25 */
+            q = -(rr * 64 * 33554432) / err; /* reflection coefficient, Q25 */
             if (q > (1 << 25) - 1) q = (1 << 25) - 1;
             if (q < -(1 << 25) + 1) q = -(1 << 25) + 1;
             r = (i32)q;
@@ -1453,7 +1453,7 @@ static void celt_decode_lost_pitch(oc_celt *st, i16 *pcm, int N) {
                 j -= pitch;
                 att = m16_q15(att, decay);
             }
-            a = (i64)m16_q15(att, e[1024 - pitch + j]) << 12;
+            a = (i64)m16_q15(att, e[1024 - pitch + j]) * 4096;
             for (k = 0; k < PLC_LPC; k++) a -= (i32)lpc16[k] * sy[PLC_LPC + i - 1 - k];
             sy[PLC_LPC + i] = sat16_64((a + 2048) >> 12);
         }
@@ -1472,7 +1472,7 @@ static void celt_decode_lost_pitch(oc_celt *st, i16 *pcm, int N) {
             }
             for (i = OC_OVERLAP; i < len; i++) sy[PLC_LPC + i] = (i16)m16_q15(ratio, sy[PLC_LPC + i]);
         }
-        for (i = 0; i < len; i++) out_syn[c][i] = (i32)sy[PLC_LPC + i] << 12;
+        for (i = 0; i < len; i++) out_syn[c][i] = (i32)sy[PLC_LPC + i] * 4096;
         /* the overlap for the next frame: pre-filtered against the post-filter that frame will run over it, folded by the window */
         {
             const int T = OC_MAX(st->pf_period, 15), tap = st->pf_tapset;
