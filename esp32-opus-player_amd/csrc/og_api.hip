@@ -463,6 +463,12 @@ __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDe
 // It also hands the reconstruction's result codes (ReconOut) to the caller's array, and -- for a step whose caller named the
 // modes it contains (`modes`: bit 0 SILK-only, bit 1 hybrid, bit 2 CELT-only; the kernels of absent modes were not launched,
 // `others_ran` = 0 if that includes the kernels that report stream-index errors) -- reports what those kernels would have.
+// two int16 lanes of a word added with saturation (v_pk_add_i16 ... clamp)
+static __device__ __forceinline__ i32 pk_add_sat_i16(i32 a, i32 b) {
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const s2 r = __builtin_elementwise_add_sat(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b));
+    return __builtin_bit_cast(i32, r);
+}
 __global__ void __launch_bounds__(64) k_celt_post(const FrameDesc *__restrict__ descs, StreamState *st, const ParseRec *recs,
                                                   const ReconOut *__restrict__ rout, i32 *__restrict__ result, i16 *pcm, int n,
                                                   int n_streams, int channels, int pcm_stride, const SilkHandoff *handoff,
@@ -548,20 +554,21 @@ __global__ void __launch_bounds__(64) k_celt_post(const FrameDesc *__restrict__ 
         i16 o[16];
         for (int g4 = 0; g4 < 4; g4++) {
             const og_v4i sv = *reinterpret_cast<const og_v4i *>(&tin[b][lane][4 * g4]);
-            const int j = 16 * ch + 4 * g4;
-            const PostAdd ad = post_addends(silk, silk_n, j, c, 2);
+            // (a hybrid frame's SILK PCM is added where the PCM leaves, below: there a frame's 16-byte pieces are read by
+            // neighbouring lanes as whole 64-byte lines; read here, one row per lane, every 16 bytes came from a line of
+            // their own -- 33 KB fetched per hybrid frame for 11.5 KB needed, and the kernel is HBM-bound)
             i32 tt = sv.x + m;
             m = mul16x32_q15(27853, tt);
-            o[4 * g4 + 0] = (i16)sat16(sat16(pshr32(tt, 12)) + ad.a0);
+            o[4 * g4 + 0] = (i16)sat16(pshr32(tt, 12));
             tt = sv.y + m;
             m = mul16x32_q15(27853, tt);
-            o[4 * g4 + 1] = (i16)sat16(sat16(pshr32(tt, 12)) + ad.a1);
+            o[4 * g4 + 1] = (i16)sat16(pshr32(tt, 12));
             tt = sv.z + m;
             m = mul16x32_q15(27853, tt);
-            o[4 * g4 + 2] = (i16)sat16(sat16(pshr32(tt, 12)) + ad.a2);
+            o[4 * g4 + 2] = (i16)sat16(pshr32(tt, 12));
             tt = sv.w + m;
             m = mul16x32_q15(27853, tt);
-            o[4 * g4 + 3] = (i16)sat16(sat16(pshr32(tt, 12)) + ad.a3);
+            o[4 * g4 + 3] = (i16)sat16(pshr32(tt, 12));
         }
         for (int g8 = 0; g8 < 2; g8++) {
             og_v4i w;
@@ -582,7 +589,16 @@ __global__ void __launch_bounds__(64) k_celt_post(const FrameDesc *__restrict__ 
             w.y = (i32)(L.x >> 16 | (R.x & 0xffff0000u));
             w.z = (i32)((L.y & 0xffffu) | R.y << 16);
             w.w = (i32)(L.y >> 16 | (R.y & 0xffff0000u));
-            *reinterpret_cast<og_v4i *>(rows[2 * fr].pcm + (16 * ch + 4 * q) * 2) = w;
+            const int at = (16 * ch + 4 * q) * 2; // the piece's place in the frame's interleaved PCM -- and in its SILK PCM (Q3: by linear index)
+            const i16 *const sk = rows[2 * fr].silk;
+            if (sk && at < rows[2 * fr].silk_n) { // SAT16(celt + silk), two samples per saturating packed add
+                const og_v4i a = *reinterpret_cast<const og_v4i *>(sk + at);
+                w.x = pk_add_sat_i16(w.x, a.x);
+                w.y = pk_add_sat_i16(w.y, a.y);
+                w.z = pk_add_sat_i16(w.z, a.z);
+                w.w = pk_add_sat_i16(w.w, a.w);
+            }
+            *reinterpret_cast<og_v4i *>(rows[2 * fr].pcm + at) = w;
         }
     }
     ss->celt.deemph[c] = m;
