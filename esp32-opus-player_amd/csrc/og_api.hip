@@ -356,52 +356,12 @@ __global__ void __launch_bounds__(64, OG_SPARSE_WAVES) k_silk_parse(const FrameD
 #endif
 }
 
-// Split CELT path, first half: ONE FRAME PER LANE.  Lane l < OG_PL_LANES (= 32) of wave w of workgroup g parses frame OG_PL_FRAMES g + OG_PL_LANES w + l (range decoder,
-// energies, allocation, band budget logic, PVQ indices) into recs[frame]; no vector work, no cross-lane traffic.
-// `which`: PARSE_ALL, or one of the two launches of a pipelined step (opusgpu_set_pipeline): PARSE_CELT_ONLY runs ahead on the
-// library's own stream, PARSE_HYBRID_ONLY behind the step's k_silk_parse (it resumes the range decoder that kernel hands off).
-enum { PARSE_ALL = 0, PARSE_CELT_ONLY = 1, PARSE_HYBRID_ONLY = 2 };
-__global__ void __launch_bounds__(64 * OG_PL_WAVES, 2) k_celt_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
-                                                      StreamState *st, ParseRec *recs, int n, int n_streams,
-                                                      const SilkHandoff *handoff, int which, int groups, u32 *started) {
-    // `groups`: a workgroup parses that many groups of OG_PL_FRAMES frames one after the other (1: the grid covers the step once)
-    // `started` (steps queued as a window, opusgpu_decode_steps_device): every workgroup counts itself in when it starts -- the
-    // reconstruction of the step before is held (a stream memory wait) until this launch's workgroups have their places
-    if (started && threadIdx.x == 0) __hip_atomic_fetch_add(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#ifdef OG_PARSE_PRIO
-    __builtin_amdgcn_s_setprio(OG_PARSE_PRIO);
-#endif
-    const bool lane_on = (int)(threadIdx.x & 63) < OG_PL_LANES;
-    const int f0 = (int)blockIdx.x * groups * OG_PL_FRAMES + OG_PWAVE * OG_PL_LANES + OG_PCOL;
-    if (which != PARSE_ALL) { // a launch that finds none of its frames among the workgroup's leaves without loading the tables
-        bool mine = false;
-        for (int g = 0; g < groups; g++) {
-            const int f = f0 + g * OG_PL_FRAMES;
-            if (lane_on && f < n) {
-                const int m0 = desc_mode(descs[f].flags);
-                mine |= which == PARSE_CELT_ONLY ? m0 == MODE_CELT : m0 == MODE_HYBRID;
-            }
-        }
-        if (!__syncthreads_or(mine)) return;
-    }
-    parse_tables_load();
-    if (!lane_on) return;
-    for (int g = 0; g < groups; g++) {
-        const int f = f0 + g * OG_PL_FRAMES;
-        if (f >= n) break;
-        const FrameDesc d = descs[f];
-        const int mode = desc_mode(d.flags);
-        if (d.stream < 0 || d.stream >= n_streams || !(mode == MODE_CELT || (mode == MODE_HYBRID && handoff)) || desc_rfc(d.flags)) continue;
-        if ((which == PARSE_CELT_ONLY && mode != MODE_CELT) || (which == PARSE_HYBRID_ONLY && mode != MODE_HYBRID)) continue;
-#ifdef OG_PROF_PARSE // profiling builds: time the sections of the parse kernel instead of the recon kernel (full batches only)
-        OG_PROF_INIT();
-#endif
-        celt_parse_lane(&st[d.stream], arena + d.offset, d.len, desc_channels(d.flags), &recs[f], mode == MODE_HYBRID ? &handoff[f] : nullptr);
-#ifdef OG_PROF_PARSE
-        OG_PROF_FLUSH();
-#endif
-    }
-}
+#define OG_PARSE_KERNEL_NAME k_celt_parse
+#include "og_parse_kernel.hpp"
+// ... and with 64 frames per wave, for pipelined steps (og_parse64.hip)
+extern "C" void og_launch_celt_parse64(hipStream_t s, int grid, const void *descs, const void *arena, void *streams, void *recs, int n,
+                                       int n_streams, const void *handoff, int which, int groups, unsigned *started);
+extern "C" int og_celt_parse64_frames(void); // frames per group of that kernel
 
 // Split CELT path, second half: one frame per wave, driven by the parse record.
 // (20 ms CELT-only frames are reconstructed by k_celt_recon_fb, og_recon.hip; `rest_only`: skip what that kernel took)
@@ -1119,7 +1079,11 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         if (srecs)
             hipLaunchKernelGGL(k_silk_parse, dim3((cnt + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, q, dd, (const u8 *)d_arena,
                                (const StreamState *)ctx->d_streams, srecs + f0, handoff + f0, cnt, ctx->n_streams, shadow, epoch);
-        if (any_celt)
+        if (any_celt && shadow && og_debug().parse_wide) { // (a pipelined step: the wide parse, like pipelined CELT-only steps)
+            const int fr = og_celt_parse64_frames();
+            og_launch_celt_parse64(q, (cnt + fr - 1) / fr, dd, d_arena, ctx->d_streams, recs + f0, cnt, ctx->n_streams,
+                                   handoff ? handoff + f0 : nullptr, (int)PARSE_ALL, 1, nullptr);
+        } else if (any_celt)
             hipLaunchKernelGGL(k_celt_parse, dim3((cnt + OG_PL_FRAMES - 1) / OG_PL_FRAMES), parse_block, 0, q, dd, (const u8 *)d_arena,
                                ctx->d_streams, recs + f0, cnt, ctx->n_streams, (const SilkHandoff *)(handoff ? handoff + f0 : nullptr),
                                (int)PARSE_ALL, 1, (u32 *)nullptr);
@@ -1265,12 +1229,17 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     // the early parse: behind the front of the step before and its own slot's last user (three steps back)
     if (ctx->front_recorded) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_front, 0));
     if (ctx->post_recorded[par]) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_post[par], 0));
+    const int wide = og_debug().parse_wide ? og_celt_parse64_frames() : OG_PL_FRAMES; // frames per group of the early parse
     {
-        const int grid = (n + OG_PL_FRAMES * ctx->parse_groups - 1) / (OG_PL_FRAMES * ctx->parse_groups);
+        const int grid = (n + wide * ctx->parse_groups - 1) / (wide * ctx->parse_groups);
         launch_jitter();
-        hipLaunchKernelGGL(k_celt_parse, dim3(grid), parse_block, 0, ctx->parse_stream, (const FrameDesc *)d_descs, (const u8 *)d_arena,
-                           ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)nullptr, (int)PARSE_CELT_ONLY, ctx->parse_groups,
-                           ctx->d_started);
+        if (og_debug().parse_wide) // (64 frames per wave: next to the reconstruction the parse costs its issue slots, not its latency)
+            og_launch_celt_parse64(ctx->parse_stream, grid, d_descs, d_arena, ctx->d_streams, recs, n, ctx->n_streams, nullptr, (int)PARSE_CELT_ONLY,
+                                   ctx->parse_groups, ctx->d_started);
+        else
+            hipLaunchKernelGGL(k_celt_parse, dim3(grid), parse_block, 0, ctx->parse_stream, (const FrameDesc *)d_descs, (const u8 *)d_arena,
+                               ctx->d_streams, recs, n, ctx->n_streams, (const SilkHandoff *)nullptr, (int)PARSE_CELT_ONLY, ctx->parse_groups,
+                               ctx->d_started);
         ctx->parse_started_total += (u32)grid;
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev_parsed, ctx->parse_stream));
@@ -1278,7 +1247,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     HIPCHK(ctx, hipStreamWaitEvent(back, ctx->ev_parsed, 0));
     if (ctx->post_recorded[par2]) HIPCHK(ctx, hipStreamWaitEvent(back, ctx->ev_post[par2], 0)); // (the ring: 2 x 960 of 2048)
     if (window) { // ... and every workgroup of the next step's parse has its place
-        const int next_grid = (next_n + OG_PL_FRAMES * ctx->parse_groups - 1) / (OG_PL_FRAMES * ctx->parse_groups);
+        const int next_grid = (next_n + wide * ctx->parse_groups - 1) / (wide * ctx->parse_groups);
         HIPCHK(ctx, hipStreamWaitValue32(back, ctx->d_started, ctx->parse_started_total + (u32)next_grid, hipStreamWaitValueGte, 0xffffffffu));
     }
     // reconstruct (one frame per wave) ...

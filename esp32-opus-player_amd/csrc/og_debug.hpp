@@ -11,6 +11,7 @@
 //                                                       lane across frames, sorted by cost) ahead of the reconstruction kernel -- measured slower
 //   OPUSGPU_SILK_PIPELINE     silk_pipeline    1        0: steps declared SILK-only run in order even with pipelining on (A/B measurements)
 //   OPUSGPU_HYBRID_PIPELINE   hybrid_pipeline  1        0: the same for steps declared hybrid (or SILK-only + hybrid)
+//   OPUSGPU_PARSE_WIDE        parse_wide       1        0: pipelined steps parse with 32 frames per wave like in-order steps (k_celt_parse instead of k_celt_parse64)
 //   OPUSGPU_HALVES            halves           1        0: an in-order step with SILK-only / hybrid frames runs as ONE chain of kernels, not two
 //   OPUSGPU_PARSE_GROUPS      parse_groups     2        groups of 32 frames per workgroup of the early parse (1 .. 8)
 //   OPUSGPU_PARSE_PRIORITY    parse_priority   1        0: the early parse's stream gets the LOWEST priority instead of the highest
@@ -24,7 +25,7 @@
 #include <stdlib.h>
 
 struct og_debug_knobs {
-    int split = 1, split_hybrid = 1, fast_recon = 1, leaf_kernel = 0, halves = 1, silk_pipeline = 1, hybrid_pipeline = 1, parse_groups = 2, parse_priority = 1, host_parts = 8, host_slices = 1, host_timing = 0,
+    int split = 1, split_hybrid = 1, fast_recon = 1, leaf_kernel = 0, halves = 1, silk_pipeline = 1, hybrid_pipeline = 1, parse_wide = 1, parse_groups = 2, parse_priority = 1, host_parts = 8, host_slices = 1, host_timing = 0,
         pages_timing = 0, launch_delay_us = 0;
 };
 inline const og_debug_knobs &og_debug() {
@@ -46,6 +47,7 @@ inline const og_debug_knobs &og_debug() {
         flag("OPUSGPU_HALVES", v.halves);
         flag("OPUSGPU_SILK_PIPELINE", v.silk_pipeline);
         flag("OPUSGPU_HYBRID_PIPELINE", v.hybrid_pipeline);
+        flag("OPUSGPU_PARSE_WIDE", v.parse_wide);
         number("OPUSGPU_PARSE_GROUPS", v.parse_groups, 1, 8);
         flag("OPUSGPU_PARSE_PRIORITY", v.parse_priority);
         if (const char *e = getenv("OPUSGPU_HOST_PARTS")) {
