@@ -1,10 +1,12 @@
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-for w in celt_fb_stereo_64k hybrid_fb_stereo_256k mixed_pages_2m silk_nb_stereo_64k; do
-timeout -k 10 200 python bench.py --workload $w --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
+for rep in 1 2; do for v in default sp64; do
+  if [ $v = default ]; then unset OPUSGPU_LIB; else export OPUSGPU_LIB=$PWD/build_exp/lib_$v.so; fi
+  for w in silk_nb_stereo_64k hybrid_fb_stereo_256k; do
+  timeout -k 10 200 python bench.py --workload $w --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('$w', round(d['ms_per_step'],3), round(d['value']), d['parity_check']['pcm_crc32'])"
-done
-OPUSGPU_PARSE_WIDE=0 timeout -k 10 200 python bench.py --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
+d=json.loads(sys.stdin.read()); print('$v $w', round(d['ms_per_step'],3), d['parity_check']['pcm_crc32'])"
+  done
+done; done
+export OPUSGPU_LIB=$PWD/build_exp/lib_sp64.so
+timeout -k 10 200 python bench.py --workload mixed_pages_2m --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('celt narrow', round(d['ms_per_step'],3))"
-timeout -k 10 300 python tools/soak_parity.py --pipeline --masks 16384 32 2 78 2>&1 | tail -1
+d=json.loads(sys.stdin.read()); print('sp64 mixed', round(d['ms_per_step'],3), d['parity_check']['pcm_crc32'])"
