@@ -1079,7 +1079,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         if (srecs)
             hipLaunchKernelGGL(k_silk_parse, dim3((cnt + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, q, dd, (const u8 *)d_arena,
                                (const StreamState *)ctx->d_streams, srecs + f0, handoff + f0, cnt, ctx->n_streams, shadow, epoch);
-        if (any_celt && shadow && og_debug().parse_wide) { // (a pipelined step: the wide parse, like pipelined CELT-only steps)
+        if (any_celt && ((shadow && og_debug().parse_wide) || og_debug().parse_wide == 2)) { // (a pipelined step: the wide parse, like pipelined CELT-only steps)
             const int fr = og_celt_parse64_frames();
             og_launch_celt_parse64(q, (cnt + fr - 1) / fr, dd, d_arena, ctx->d_streams, recs + f0, cnt, ctx->n_streams,
                                    handoff ? handoff + f0 : nullptr, (int)PARSE_ALL, 1, nullptr);

@@ -11,7 +11,8 @@
 //                                                       lane across frames, sorted by cost) ahead of the reconstruction kernel -- measured slower
 //   OPUSGPU_SILK_PIPELINE     silk_pipeline    1        0: steps declared SILK-only run in order even with pipelining on (A/B measurements)
 //   OPUSGPU_HYBRID_PIPELINE   hybrid_pipeline  1        0: the same for steps declared hybrid (or SILK-only + hybrid)
-//   OPUSGPU_PARSE_WIDE        parse_wide       1        0: pipelined steps parse with 32 frames per wave like in-order steps (k_celt_parse instead of k_celt_parse64)
+//   OPUSGPU_PARSE_WIDE        parse_wide       1        0: pipelined steps parse with 32 frames per wave like in-order steps (k_celt_parse instead of k_celt_parse64);
+//                                                       2: in-order steps use the wide kernel too (counter passes: --pmc serialises kernels, so only in-order steps can be counted)
 //   OPUSGPU_HALVES            halves           1        0: an in-order step with SILK-only / hybrid frames runs as ONE chain of kernels, not two
 //   OPUSGPU_PARSE_GROUPS      parse_groups     2        groups of 32 frames per workgroup of the early parse (1 .. 8)
 //   OPUSGPU_PARSE_PRIORITY    parse_priority   1        0: the early parse's stream gets the LOWEST priority instead of the highest
@@ -47,7 +48,7 @@ inline const og_debug_knobs &og_debug() {
         flag("OPUSGPU_HALVES", v.halves);
         flag("OPUSGPU_SILK_PIPELINE", v.silk_pipeline);
         flag("OPUSGPU_HYBRID_PIPELINE", v.hybrid_pipeline);
-        flag("OPUSGPU_PARSE_WIDE", v.parse_wide);
+        number("OPUSGPU_PARSE_WIDE", v.parse_wide, 0, 2);
         number("OPUSGPU_PARSE_GROUPS", v.parse_groups, 1, 8);
         flag("OPUSGPU_PARSE_PRIORITY", v.parse_priority);
         if (const char *e = getenv("OPUSGPU_HOST_PARTS")) {

@@ -8,6 +8,8 @@
 # what runs next to it; durations next to the neighbours come from the kernel-trace pass, which runs the default (pipelined) bench.
 # For the same reason they run steps with SILK frames as ONE chain (OPUSGPU_HALVES=0): one launch of every kernel per step, so
 # that "per launch" is "per step"; the counters of a kernel do not depend on how its frames are cut into launches.
+# PROF_PARSE_WIDE=2: the counter passes use the parse kernel of PIPELINED steps (k_celt_parse64, 64 frames per wave) in their in-order
+# steps -- for workloads whose bench run is pipelined (CELT-only, hybrid), so that the counters are those of the kernel that runs.
 # PROF_FRAMES: frames per launch for the per-frame figures (default 65536).
 tag=$1; shift
 out=$PWD/gpurun_out/$tag
@@ -27,6 +29,6 @@ for set in \
   "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT TCC_MISS TCC_EA0_RDREQ TCC_EA0_WRREQ" ; do
   i=$((i+1))
   echo "pmc pass $i: $set"
-  OPUSGPU_HALVES=0 timeout -k 5 ${PROF_PASS_TIMEOUT:-150} rocprofv3 --pmc $set --output-format csv -d $out/pmc$i -o p -- python3 bench.py $args --pipeline off > $out/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -3 $out/pmc$i.log; exit 1; }
+  OPUSGPU_HALVES=0 OPUSGPU_PARSE_WIDE=${PROF_PARSE_WIDE:-1} timeout -k 5 ${PROF_PASS_TIMEOUT:-150} rocprofv3 --pmc $set --output-format csv -d $out/pmc$i -o p -- python3 bench.py $args --pipeline off > $out/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -3 $out/pmc$i.log; exit 1; }
 done
 python3 tools/pmc_summary.py $out ${PROF_FRAMES:-65536} | tee $out/summary.txt
