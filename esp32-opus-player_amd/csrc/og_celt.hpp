@@ -868,6 +868,10 @@ OG_DEV i32 syn_at(const CeltState *st, int c, int idx) {
 // is recursive with delay >= min(T0,T1)-2 >= 13 samples, so samples are produced in chunks of that
 // many, spread over the lanes; all taps of a chunk are already final.
 OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, int N, i32 g0, i32 g1, int tap0, int tap1, int ring_pos_now) {
+    // (every argument is the wave's -- but a function that is not inlined receives them in vector registers, and everything derived
+    // from them would be vector work: 86 vector instructions before the first sample, four calls per frame)
+    c = OG_UNI(c); off = OG_UNI(off); T0 = OG_UNI(T0); T1 = OG_UNI(T1); N = OG_UNI(N); g0 = OG_UNI(g0); g1 = OG_UNI(g1);
+    tap0 = OG_UNI(tap0); tap1 = OG_UNI(tap1); ring_pos_now = OG_UNI(ring_pos_now);
     if (g0 == 0 && g1 == 0) return;
     // gains[tapset][0..2] Q15 (celt.cpp:854)
     T0 = OG_MAX(T0, 15);
@@ -941,7 +945,26 @@ OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, in
             const bool live = it + OG_LANE < lim;
             const i32 y0 = live ? syn_buf()[p] : 0;
             auto window = [&](int T, i32 &t4, i32 &t3, i32 &t2, i32 &t1, i32 &t0) {
-                // t0 = x[p-T+2] (e[l+4]) ... t4 = x[p-T-2] (e[l]); indices past this step's last live sample are clamped
+                // t0 = x[p-T+2] (e[l+4]) ... t4 = x[p-T-2] (e[l]).
+                // Where the step's whole 68-element window lies is the same for every lane (off, base, it and T are the wave's): all of
+                // it in the synthesis buffer -- five LDS reads at constant offsets from one address -- or all of it in the history
+                // ring without crossing the ring's end -- five loads at constant offsets -- are the common cases and cost no vector
+                // ALU work beyond one address (the kernel is bound by vector-instruction issue: the shifting scheme below spends
+                // 8 instructions moving four taps across lanes and 10 more telling the two memories apart).  A dead lane's taps
+                // (past the step's last live sample) may be anything: nothing is stored for it and no lane reads another's.
+                const int first = off + base + it - T - 2; // index of e[0] of lane 0
+                if (first >= 0) {
+                    const __attribute__((address_space(3))) i32 *e = lds + (p - T - 2);
+                    t4 = e[0]; t3 = e[1]; t2 = e[2]; t1 = e[3]; t0 = e[4];
+                    return;
+                }
+                const int head = (ring_pos + first) & RING_MASK; // where e[0] of lane 0 lies in the ring
+                if (first + 67 < 0 && head + 67 <= RING_MASK) {
+                    const __attribute__((address_space(1))) i32 *e = ring + head + OG_LANE;
+                    t4 = e[0]; t3 = e[1]; t2 = e[2]; t1 = e[3]; t0 = e[4];
+                    return;
+                }
+                // (a window that straddles the two memories or the ring's end; indices past this step's last live sample are clamped)
                 const int q = OG_MIN(p, off + base + lim - 1) - T + 2;
                 t0 = tap_at(q);
                 const i32 w = OG_LANE < 4 ? tap_at(off + base + it - T - 2 + OG_LANE) : 0;

@@ -1,12 +1,7 @@
-for rep in 1 2; do for v in default sp64; do
-  if [ $v = default ]; then unset OPUSGPU_LIB; else export OPUSGPU_LIB=$PWD/build_exp/lib_$v.so; fi
-  for w in silk_nb_stereo_64k hybrid_fb_stereo_256k; do
-  timeout -k 10 200 python bench.py --workload $w --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
+timeout -k 10 600 python -m pytest tests/test_gpu_celt.py tests/test_gpu_stage_taps.py tests/test_gpu_fullsize.py -x -q -m gpu 2>&1 | tail -2
+for rep in 1 2; do
+timeout -k 10 200 python bench.py --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('$v $w', round(d['ms_per_step'],3), d['parity_check']['pcm_crc32'])"
-  done
-done; done
-export OPUSGPU_LIB=$PWD/build_exp/lib_sp64.so
-timeout -k 10 200 python bench.py --workload mixed_pages_2m --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('sp64 mixed', round(d['ms_per_step'],3), d['parity_check']['pcm_crc32'])"
+d=json.loads(sys.stdin.read()); print('celt', round(d['ms_per_step'],3), round(d['value']), d['parity_check']['pcm_crc32'])"
+done
+PMC_KERNELS=k_celt_recon_fb tools/pmc_quick.sh default 2>&1 | grep k_celt_recon_fb
