@@ -717,6 +717,8 @@ OG_DEV void imdct_long_back(i32 *SY) {
 // Inverse MDCT of every block of one output channel (clt_mdct_backward celt.cpp:3204), reading
 // the denormalised coefficients on the fly.  B blocks of NBk = N/B outputs, transform size 2*NBk.
 OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int shift, int C, int CC) {
+    // (the wave's values, in vector registers because the function is not inlined: scalar again, see comb_filter)
+    co = OG_UNI(co); N = OG_UNI(N); LM = OG_UNI(LM); B = OG_UNI(B); shift = OG_UNI(shift); C = OG_UNI(C); CC = OG_UNI(CC);
 #if defined(OG_RECON_TIGHT) && !defined(OG_HOST_EMUL)
     // this layout only sees 20 ms frames: one 1920-point transform or eight 240-point ones (the code of the other two sizes --
     // a third of the kernel's instruction bytes -- is not generated)
@@ -936,11 +938,13 @@ OG_DEVN void comb_filter(const CeltState *st, int c, int off, int T0, int T1, in
         if (idx < 0) in_ring = ring[(ring_pos + idx) & RING_MASK];
         return idx < 0 ? in_ring : in_lds;
     };
-    for (int base = 0, chunk; base < end; base += chunk) {
-        chunk = base < overlap ? chunk_fade : chunk_rest;
+    // (a step: up to 64 consecutive samples, never more than the lag allows -- ANY run of at most T - 2 samples is independent, so
+    // the steps need not respect the boundaries of chunks of T - 2: 64, 64, 64 ... instead of 64, 34, 64, 34 ... at T = 100)
+    for (int base = 0, lim; base < end; base += lim) {
+        lim = OG_MIN(OG_MIN(base < overlap ? chunk_fade : chunk_rest, 64), end - base);
         OG_SYNC();
-        const int lim = OG_MIN(chunk, end - base);
-        for (int it = 0; it < lim; it += 64) {
+        {
+            const int it = 0;
             const int i = base + it + OG_LANE, p = off + i;
             const bool live = it + OG_LANE < lim;
             const i32 y0 = live ? syn_buf()[p] : 0;

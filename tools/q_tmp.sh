@@ -1,4 +1,4 @@
-timeout -k 10 600 python -m pytest tests/test_gpu_celt.py tests/test_gpu_stage_taps.py tests/test_gpu_fullsize.py -x -q -m gpu 2>&1 | tail -2
+timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
 for rep in 1 2; do
 timeout -k 10 200 python bench.py --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
 import json,sys
