@@ -2,6 +2,10 @@
 // A translation unit of its own because the frames per wave size the kernel's LDS arrays at compile time.
 #include <hip/hip_runtime.h>
 #define OG_PL_LANES 64
+#ifndef OG_PL64_WAVES
+#define OG_PL64_WAVES 2 // two such waves per workgroup share one copy of the ROM tables (3.3 KB): next to the reconstruction it is LDS x residency that counts
+#endif
+#define OG_PL_WAVES OG_PL64_WAVES
 #define OG_PARSE_KERNEL_NAME k_celt_parse64
 #include "og_parse_kernel.hpp"
 
