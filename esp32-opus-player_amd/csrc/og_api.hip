@@ -1007,6 +1007,9 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
                            (i16 *)d_pcm, (i32 *)d_result, n, ctx->n_streams, pcm_stride, 0, nullptr, nullptr, 0);
         HIPCHK(ctx, hipGetLastError());
         ctx->last_step_stream = s;
+        if (slices) // (one kernel for the whole step: every slice's PCM is there behind it)
+            for (int i = 0; i < slices->count; i++)
+                if (int rc = slices->after_slice(i)) return rc;
         return OPUSGPU_OK;
     }
     // `modes` (bit 0 SILK-only, 1 hybrid, 2 CELT-only frames may be present; 7 = not known): the kernels of modes the caller

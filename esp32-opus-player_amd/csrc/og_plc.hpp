@@ -25,7 +25,8 @@ constexpr int PLC_LPC = 24, PLC_PMIN = 100, PLC_PMAX = 720, PLC_HIST = 1024;
 // a switch from CELT to hybrid (RFC 6716 section 4.5), the new frame's SILK PCM is already waiting in SL().u.out.pcm for its CELT
 // layer.  So the scratch keeps out of those 3,840 bytes: three pieces -- A: from behind that PCM to the end of the SILK synthesis'
 // object (the up-sampler's buffers, where the concealment's OUTPUT is parked afterwards, and the decoder controls); B: the
-// synthesis' look-back rows in front of it; C: the wave-uniform SILK parse's object.
+// synthesis' look-back rows in front of it; C: the wave-uniform SILK parse's scratch (the head of the CELT spectrum X, dead until
+// the concealed frame's PCM planes are written there -- after the search).
 struct PlcA {
     i16 xs[PLC_LPC + 960 + OVERLAP];  // first the channel's history in 16 bits behind 24 zeros (x, 1,048 entries; during the search the
                                       // channels' mean), then -- x is dead by then -- the synthesis: 24 samples of history, the frame, its overlap
@@ -54,7 +55,7 @@ struct PlcLds {
 };
 OG_DEV PlcA &PLA() { return *reinterpret_cast<PlcA *>(reinterpret_cast<u8 *>(&g_silk_lds) + PLC_A_AT); }
 OG_DEV PlcB &PLB() { return *reinterpret_cast<PlcB *>(&g_silk_lds); }
-OG_DEV PlcC &PLCc() { return *reinterpret_cast<PlcC *>(&g_silk_wp); }
+OG_DEV PlcC &PLCc() { return *reinterpret_cast<PlcC *>(&PW()); } // (over the head of X: the search is over before a PCM plane is written there)
 
 OG_DEV int plc_ilog64(unsigned long long x) { // bits needed: 0 for 0
     int n = 0;

@@ -6,6 +6,8 @@
 // mode exists for completeness, not speed: entropy decoding is wave-uniform, the synthesis of loss-aware SILK frames runs one
 // lane per channel.
 #include <hip/hip_runtime.h>
+#define OG_NO_SPLIT_LDS // the record window of the split path's reconstruction: 256 bytes this kernel does not need -- with them it is
+                        // 8 bytes over the 20,480 that eight workgroups per CU (two waves per SIMD, what its 256 registers allow) have
 #include "og_decode.hpp"
 
 using namespace og;

@@ -67,8 +67,12 @@ struct SilkWaveParseLds {
     i32 pred_Q8[SILK_MAX_LPC];
     i32 cosLSF[SILK_MAX_LPC], P[SILK_MAX_LPC / 2 + 1], Q[SILK_MAX_LPC / 2 + 1], a32[SILK_MAX_LPC], Atmp[SILK_MAX_LPC];
 };
-OG_LDS SilkWaveParseLds g_silk_wp;
-OG_DEV SilkWaveParseLds &PW() { return g_silk_wp; }
+// It has no bytes of its own: whenever the wave-uniform SILK parse (or the SILK concealment's LPC scratch) runs, the CELT working
+// set's spectrum X is dead -- a frame's SILK layer comes before its CELT layer, a concealment's SILK part before its CELT part, and
+// what SILK hands on waits in SilkLds -- so the object lies over the first 2 KB of X.  (k_decode_rfc: 22.5 -> 20.5 KB of LDS, eight
+// instead of seven workgroups per CU; k_decode_step likewise.)
+static_assert(sizeof(SilkWaveParseLds) <= sizeof(i16) * 1920 && alignof(SilkWaveParseLds) <= 16, "the wave parse's scratch lies over X");
+OG_DEV SilkWaveParseLds &PW() { return *reinterpret_cast<SilkWaveParseLds *>(&S.v[V_X]); }
 
 // ---- state ------------------------------------------------------------------------------------------
 // `lc`: the channel's loss-concealment state (RFC mode; reference-mode callers pass none and never look at it)

@@ -137,7 +137,9 @@ constexpr int SYN_LEN = 1088;  // 960 + 120 (+8 pad)
 struct FrameLds {
     alignas(16) i16 v[V_TOTAL];
     u8 pkt[1344];              // packet bytes (<= 1275); the split path keeps its per-leaf collapse masks here
+#ifndef OG_NO_SPLIT_LDS        // (og_rfc.hip: a translation unit that never instantiates the split path's reconstruction)
     u32 win[64];               // split path: window of the parse record's word stream
+#endif
     i32 pulses[NBANDS], fine_quant[NBANDS], fine_prio[NBANDS], tf_res[NBANDS], offsets[NBANDS];
     i32 bits1[NBANDS], bits2[NBANDS];
     i16 bandE[2 * NBANDS], logE1[2 * NBANDS], logE2[2 * NBANDS];
@@ -153,7 +155,11 @@ struct FrameLds {
     OG_MEMBER u8 *cmask_row() { return cmask; }
     OG_MEMBER i32 *pulses_row() { return pulses; }
     OG_MEMBER u16 *leaf_mask_row() { return reinterpret_cast<u16 *>(&pkt[0]); }
+#ifndef OG_NO_SPLIT_LDS
     OG_MEMBER u32 *word_window() { return win; }
+#else
+    OG_MEMBER u32 *word_window() { return reinterpret_cast<u32 *>(pkt); } // (never called there)
+#endif
     OG_MEMBER i16 *dn_g_row() { return dn_g; }
     OG_MEMBER i16 *dn_shift_row() { return dn_shift; }
     OG_MEMBER u8 *bin2band_row() { return bin2band; }
