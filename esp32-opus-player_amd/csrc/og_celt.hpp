@@ -1397,9 +1397,9 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
     int LM;
     for (LM = 0; LM <= 3; LM++)
         if (120 << LM == frame_size) break;
-    if (LM > 3) return BAD_ARG;
+    if (LM > 3) return CELT_BAD_ARG; // celt.cpp:2211
     const int M = 1 << LM, N = M * 120;
-    if (rc.storage > 1275 || rc.storage <= 1) return BAD_ARG;
+    if (rc.storage > 1275 || rc.storage <= 1) return CELT_BAD_ARG; // :2216, :2225
 
     // ---- stage persistent scalars in LDS
     OG_SYNC();

@@ -41,7 +41,7 @@ enum { // ParseRec.flags
     RF_DUAL = 128, RF_ANTI_COLLAPSE = 256, RF_RC_ERROR = 512, RF_TELL_OVERFLOW = 1024,
     RF_SKIP = 2048,    // descriptor rejected before any state change (decode_frame_wave's BAD_ARG), or (hybrid) the
                        // single-kernel path already reported the frame's error: nothing to do, result untouched
-    RF_BAD_CELT = 4096 // celt_decode_frame's early BAD_ARG: bookkeeping only
+    RF_BAD_CELT = 4096 // celt_decode_frame's early CELT_BAD_ARG: bookkeeping only
 };
 // Band words.  W0: flags below; W1: eff_low | x << 11 | N << 22 (positions relative to their arena rows);
 // W2: imid | iside << 16 (stereo split gains, Q15); W3: lowband_out scale sqrt(N) (Q?) in the low 16 bits.
@@ -524,8 +524,8 @@ OG_DEV void celt_parse_lane(StreamState *st, const u8 *payload, int len, int ch,
         rc_lane_resume(rc);
     } else
         rc_init(rc, (u32)len);
-    if (rc.storage <= 1) { // celt_decode_frame's early exit
-        rec->ret = BAD_ARG;
+    if (rc.storage <= 1) { // celt_decode_frame's early exit (celt.cpp:2225)
+        rec->ret = CELT_BAD_ARG;
         rec->flags = RF_BAD_CELT;
         rec->rng_final = rc.rng;
         return;

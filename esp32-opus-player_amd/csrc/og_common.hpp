@@ -145,7 +145,8 @@ extern long long og_stats[64];
 namespace og {
 
 // ---- error / mode codes (values follow the reference's opus_decoder.h / celt.h) -----------------
-enum { OK = 0, BAD_ARG = -1, BUFFER_TOO_SMALL = -2, INTERNAL_ERROR = -3, INVALID_PACKET = -4 };
+enum { OK = 0, BAD_ARG = -1, BUFFER_TOO_SMALL = -2, INTERNAL_ERROR = -3, INVALID_PACKET = -4,
+       CELT_BAD_ARG = -18 }; // ERR_OPUS_CELT_BAD_ARG (src/opus_decoder.h:55): celt_decode_with_ec's refusals, src/celt.cpp:2211-2225
 enum { MODE_SILK = 1000, MODE_HYBRID = 1001, MODE_CELT = 1002 };
 enum { BW_NB = 1101, BW_MB = 1102, BW_WB = 1103, BW_SWB = 1104, BW_FB = 1105 };
 

@@ -15,6 +15,9 @@
 #define OPUS_UNIMPLEMENTED -5
 #define OPUS_INVALID_STATE -6
 #define OPUS_ALLOC_FAIL -7
+/* celt_decode_with_ec's own refusals (reference src/opus_decoder.h:43-65, enum; src/celt.cpp:2211,2216,2225): a CELT-only or
+ * hybrid frame of <= 1 byte comes back from opus_decode / opus_multistream_decode as this value, not as OPUS_BAD_ARG */
+#define ERR_OPUS_CELT_BAD_ARG -18
 
 #define OPUS_GET_BANDWIDTH_REQUEST 4009
 #define OPUS_RESET_STATE 4028

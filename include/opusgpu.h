@@ -29,6 +29,7 @@ extern "C" {
 #define OPUSGPU_INVALID_PACKET (-4)   /* OPUS_INVALID_PACKET */
 #define OPUSGPU_UNIMPLEMENTED (-5)    /* OPUS_UNIMPLEMENTED */
 #define OPUSGPU_ALLOC_FAIL (-7)       /* OPUS_ALLOC_FAIL */
+#define OPUSGPU_CELT_BAD_ARG (-18)    /* ERR_OPUS_CELT_BAD_ARG: a CELT-only / hybrid frame of <= 1 byte (src/celt.cpp:2225) */
 #define OPUSGPU_ERR_NO_DEVICE (-100)  /* no usable HIP device / kernel image: there is NO CPU fallback */
 #define OPUSGPU_ERR_HIP (-101)        /* a HIP runtime call failed; see opusgpu_last_error() */
 

@@ -1092,12 +1092,12 @@ int oc_celt_decode(oc_celt *st, oc_rc *rc, i16 *pcm, int frame_size, oc_celt_tap
 
     for (LM = 0; LM <= 3; LM++)
         if (120 << LM == frame_size) break;
-    if (LM > 3) return OC_BAD_ARG;
+    if (LM > 3) return OC_CELT_BAD_ARG; /* celt.cpp:2211 */
     M = 1 << LM;
-    if (rc->storage > 1275 || pcm == NULL) return OC_BAD_ARG;
+    if (rc->storage > 1275 || pcm == NULL) return OC_CELT_BAD_ARG; /* :2216 */
     N = M * 120;
     for (c = 0; c < CC; c++) out_syn[c] = st->syn[c] + OC_HIST;
-    if (rc->storage <= 1) return OC_BAD_ARG;
+    if (rc->storage <= 1) return OC_CELT_BAD_ARG; /* :2225 */
 
     if (C == 1)
         for (i = 0; i < NB; i++) bandE[i] = OC_MAX(bandE[i], bandE[NB + i]);

@@ -28,6 +28,9 @@ extern "C" {
 #define OC_BUFFER_TOO_SMALL (-2)
 #define OC_INTERNAL_ERROR (-3)
 #define OC_INVALID_PACKET (-4)
+/* what celt_decode_with_ec returns for a frame it refuses (src/celt.cpp:2211,2216,2225: ERR_OPUS_CELT_BAD_ARG,
+ * src/opus_decoder.h:55); opus_decode_frame / opus_decode_native pass it up unchanged (src/opus_decoder.cpp:277,333-337) */
+#define OC_CELT_BAD_ARG (-18)
 
 #define OC_MODE_SILK 1000
 #define OC_MODE_HYBRID 1001

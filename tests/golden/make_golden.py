@@ -12,7 +12,8 @@ Two kinds of fixture:
   oracle_sequences.json -- explicit packet sequences (hex) for the quirk cases, with the oracle's return code and PCM hash
                         per call: mono decoders, a mono packet in a stereo decoder (Q3: only the defined half is
                         hashed), multi-frame packets of every frame-count code with room for three frames (Q6), and a
-                        mode-switch sequence incl. hybrid -> SILK-only (Q4) and CELT <-> SILK.
+                        mode-switch sequence incl. hybrid -> SILK-only (Q4) and CELT <-> SILK, and frames of 0 / 1 payload bytes
+                        (CELT-only and hybrid: the reference's ERR_OPUS_CELT_BAD_ARG, -18).
   rfc_sequences.json -- the same for RFC mode (oracle/oc_opus.h oc_decoder_set_rfc; PARITY-UNPINNED: these vectors freeze what
                         the oracle does today, they do not come from any reference decoder): event sequences for a stereo
                         and a mono decoder over every frame duration and frame-count code -- packets, lost packets
@@ -69,6 +70,14 @@ def sequence_packets():
     # Q4 and friends: CELT -> hybrid -> SILK-only (the transition frame) -> hybrid -> CELT -> SILK -> CELT, varying bandwidth
     order = (0xFC, 0x7C, 0x0C, 0x0C, 0x6C, 0x2C, 0x7C, 0xFC, 0xDC, 0x4C, 0xFC, 0x7C, 0x4C, 0x0C)
     seqs["mode_switches"] = (2, [bytes([t]) + _bytes(rng, 50 + 7 * i) for i, t in enumerate(order)])
+    # frames of 0 / 1 payload bytes: celt_decode_with_ec refuses them with ERR_OPUS_CELT_BAD_ARG = -18 (src/celt.cpp:2225,
+    # src/opus_decoder.h:55) in CELT-only and hybrid mode, SILK-only decodes them (the range decoder runs out of bytes); ordinary
+    # frames in between so that what such a frame leaves behind (prev_mode, SILK state of a refused hybrid frame) is pinned too
+    tiny = []
+    for toc in (0xFC, 0x7C, 0x0C):
+        tiny += [bytes([toc]) + _bytes(rng, 40), bytes([toc]), bytes([toc]) + _bytes(rng, 1), bytes([toc, 0xFF]), bytes([toc]) + _bytes(rng, 2),
+                 bytes([toc]) + _bytes(rng, 45)]
+    seqs["tiny_frames"] = (2, tiny)
     return seqs
 
 

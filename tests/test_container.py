@@ -112,6 +112,14 @@ def test_opus_decoder_h_surface_on_gpu(tmp_path, oracle):
                   ("R",), ("D", 5760, bytes([toc]) + body(100)), ("Q",)]
     over_long = bytes([(28 << 3) | 4 | 3, 4]) + body(4 * 20)        # CELT FB 2.5 ms x 4: 480 samples by the TOC
     steps += [("D", 960, over_long), ("Q",), ("D", 960, bytes([0xFC]) + body(90))]
+    # frames of 0 / 1 payload bytes: the reference's ERR_OPUS_CELT_BAD_ARG (-18, src/celt.cpp:2225, src/opus_decoder.h:55) in
+    # CELT-only and hybrid mode through BOTH entry points; SILK-only decodes them.  Hand-derived, not read off the oracle.
+    tiny = {}
+    for toc, want in ((0xFC, -18), (0x7C, -18), (0x0C, 960)):
+        for pkt in (bytes([toc]), bytes([toc, 0xFF]), bytes([toc, 0x00])):
+            steps.append(("D", 960, pkt))
+            tiny[len(steps) - 1] = want
+        steps.append(("D", 960, bytes([toc]) + body(50)))
     script = b""
     for s in steps:
         script += s[0].encode() + (struct.pack("<II", s[1], len(s[2])) + s[2] if s[0] == "D" else b"")
@@ -122,13 +130,15 @@ def test_opus_decoder_h_surface_on_gpu(tmp_path, oracle):
     d = oracle.decoder(2)
     d.init()
     at, last, last_ret = 0, None, 0
-    for s in steps:
+    for k, s in enumerate(steps):
         if s[0] == "R":
             d.reset()
         elif s[0] == "D":
             fs, pkt = s[1], s[2]
             ra, rb = struct.unpack_from("<ii", got, at)
             at += 8
+            if k in tiny:
+                assert ra == rb == tiny[k], (pkt.hex(), ra, rb, tiny[k])
             # the oracle with generous room decodes every frame (Q6: 960 samples each); with the caller's room it applies
             # the reference's size check
             pcm, r = d.decode_cap(pkt, 6) if pkt is over_long else d.decode_cap(pkt, fs // 960)

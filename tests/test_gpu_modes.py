@@ -174,6 +174,23 @@ def test_tiny_frames(pkg, oracle, gpu_ctx):
                 assert (pcm[s].reshape(-1)[:ncmp] == ref[s, f].reshape(-1)[:ncmp]).all(), (channels, s, f, hex(toc), len(pk[s][f]))
 
 
+def test_tiny_celt_and_hybrid_frames_return_the_reference_code(pkg, gpu_ctx):
+    """Hand-derived known answers (tests/test_oracle_kat.py::TINY_KAT, reference src/celt.cpp:2225 / src/opus_decoder.h:55):
+    CELT-only and hybrid frames of 0 / 1 bytes come back as -18 (ERR_OPUS_CELT_BAD_ARG), SILK-only ones decode; both through the
+    split kernels (steps of many frames) and the single-frame call, in order and pipelined."""
+    from test_oracle_kat import TINY_KAT
+    for channels in (2, 1):
+        n = len(TINY_KAT)
+        gpu_ctx.streams_alloc(n, channels)
+        _, res = gpu_ctx.decode_packets(np.arange(n), [p for p, _ in TINY_KAT], frame_capacity=1)
+        assert res.tolist() == [w for _, w in TINY_KAT], (channels, res.tolist())
+        _, res = gpu_ctx.decode_packets(np.arange(n), [bytes([p[0]]) + bytes(range(40)) for p, _ in TINY_KAT], frame_capacity=1)
+        assert (res == 960).all()
+        for s, (p, w) in enumerate(TINY_KAT):  # one packet per call
+            _, res = gpu_ctx.decode_packets([s], [p], frame_capacity=1)
+            assert res[0] == w, (channels, p.hex(), res[0])
+
+
 def test_more_short_frames_than_room_is_refused(pkg, gpu_ctx):
     """include/opusgpu.h, opusgpu_decode_packets: four 2.5 ms CELT frames are 480 samples by the TOC, which passes the
     reference's size check against one 960-sample frame of room -- and the reference then writes 4 x 960 samples (Q6).  The

@@ -52,6 +52,24 @@ def test_kat2_fresh_state_per_mode(oracle):
         assert h == expect[m], (m, hex(h))
 
 
+# celt_decode_with_ec refuses a frame of <= 1 byte with ERR_OPUS_CELT_BAD_ARG = -18 (reference src/celt.cpp:2225, enum
+# src/opus_decoder.h:55), opus_decode_frame returns `celt_ret < 0 ? celt_ret : audiosize` (src/opus_decoder.cpp:277) and
+# opus_decode_native passes it up (:333-337).  SILK-only frames never reach CELT (the 2.5 ms transition frame's result is ignored,
+# :265-268).  Derived by hand from those lines, not read off the oracle.
+TINY_KAT = [(bytes([0xFC]), -18), (bytes([0xFC, 0xFF]), -18), (bytes([0xFC, 0x00]), -18), (bytes([0x7C]), -18), (bytes([0x7C, 0xFF]), -18),
+            (bytes([0x7C, 0x00]), -18), (bytes([0x0C]), 960), (bytes([0x0C, 0xFF]), 960), (bytes([0xF8]), -18), (bytes([0x78, 0x55]), -18),
+            (bytes([0x08]), 960)]
+
+
+def test_tiny_celt_and_hybrid_frames_return_the_reference_code(oracle):
+    for channels in (2, 1):
+        for pkt, want in TINY_KAT:
+            d = oracle.decoder(channels)
+            d.init()
+            assert d.decode(pkt)[1] == want, (channels, pkt.hex())
+            assert d.decode(bytes([pkt[0]]) + bytes(range(40)))[1] == 960  # the decoder goes on after a refused frame
+
+
 def test_threaded_batch_decode_matches_single_thread(pkg, oracle):
     """The threaded helper the full-size GPU tests rely on returns exactly what one thread returns (streams are
     independent; each thread owns a stream range)."""
