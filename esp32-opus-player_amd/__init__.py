@@ -149,7 +149,7 @@ def load_lib():
 
 
 class OpusGpuError(RuntimeError):
-    pass
+    code = 0  # the negative OPUSGPU_* value the call returned
 
 
 class BufferTooSmall(OpusGpuError):
@@ -296,7 +296,9 @@ class Context:
 
     def _chk(self, rc, what):
         if rc != 0:
-            raise OpusGpuError(f"{what} failed: {rc} ({self.lib.opusgpu_last_error(self.h).decode()})")
+            e = OpusGpuError(f"{what} failed: {rc} ({self.lib.opusgpu_last_error(self.h).decode()})")
+            e.code = rc
+            raise e
 
     def streams_alloc(self, n, channels):
         self._chk(self.lib.opusgpu_streams_alloc(self.h, n, channels), "opusgpu_streams_alloc")

@@ -647,6 +647,8 @@ struct opusgpu_ctx {
     // large batches on the host-buffer path run in parts: a part's PCM travels back (on a stream of its own) while the next
     // part's kernels run
     hipStream_t copy_stream = nullptr;
+    std::mutex registered_mutex;
+    std::vector<std::pair<uintptr_t, size_t>> registered; // host ranges page-locked through opusgpu_host_register
     hipEvent_t ev_part[OPUSGPU_COPY_PIECES] = {};
     int host_parts = 8; // OPUSGPU_HOST_PARTS=1: one batch, copy after the kernels (A/B measurements); 2, 4, 8, 16
     // parse records of the split CELT path (one per frame of a step), grown on demand
@@ -683,6 +685,7 @@ struct opusgpu_ctx {
     // the host keeps the totals they will reach).  Round 2 got that order from a spin-wait kernel watching the wall clock.
     u32 *d_started = nullptr; // [0] early-parse workgroups started, [16] every 64th reconstruction workgroup started
     u32 parse_started_total = 0, recon_started_total = 0;
+    u32 window_parse_target = 0, window_recon_target = 0; // the counts the last queued step of an unfinished window waits for (0: none)
     // (OPUSGPU_PARSE_GROUPS) groups of 32 frames per workgroup of the early parse: with two, half as many parse workgroups are
     // resident for about twice as long, each group runs nearer to a lone wave's pace, and the reconstruction next to them has
     // the LDS of the other half -- 1 / 2 / 3 / 4 groups: 2.545 / 2.50 / 2.52 / 2.97 ms per step on one box (at four the parse
@@ -973,6 +976,39 @@ static int enter_step_kind(opusgpu_ctx *ctx, int kind, hipStream_t s) {
     return OPUSGPU_OK;
 }
 
+// Records, reconstruction output and (leaf kernel) leaf output of slot `par` for a step of `need` frames.
+static int grow_step_slot(opusgpu_ctx *ctx, int par, size_t need, bool any_celt) {
+    int rc;
+    if (ctx->cap_recs[par] < sizeof(ParseRec) * need && (rc = grow(ctx, &ctx->d_recs[par], &ctx->cap_recs[par], sizeof(ParseRec) * need)))
+        return rc;
+    if (ctx->cap_rout[par] < sizeof(ReconOut) * need && (rc = grow(ctx, &ctx->d_rout[par], &ctx->cap_rout[par], sizeof(ReconOut) * need)))
+        return rc;
+    if (ctx->fast_recon && ctx->leaf_kernel && any_celt && ctx->cap_leaf[par] < og_leaf_out_bytes() * need &&
+        (rc = grow(ctx, &ctx->d_leaf[par], &ctx->cap_leaf[par], og_leaf_out_bytes() * need)))
+        return rc;
+    return OPUSGPU_OK;
+}
+
+// A window that ends early (a HIP error between two of its steps): the placement waits of the last step queued -- for workgroups
+// of a step that will not come -- are let go by writing the counts they wait for; the waits are placement only (events carry the
+// data dependencies), so whatever is queued completes.  Then the device drains and the counters restart from zero.
+static void release_window_waits(opusgpu_ctx *ctx) {
+    if (!ctx->d_started || (!ctx->window_parse_target && !ctx->window_recon_target)) return;
+    hipStream_t q = nullptr;
+    if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess) {
+        if (ctx->window_parse_target) (void)hipStreamWriteValue32(q, ctx->d_started, ctx->window_parse_target, 0);
+        if (ctx->window_recon_target) (void)hipStreamWriteValue32(q, ctx->d_started + 16, ctx->window_recon_target, 0);
+        (void)hipStreamSynchronize(q);
+        (void)hipStreamDestroy(q);
+    }
+    (void)sync_in_flight(ctx);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemset(ctx->d_started, 0, 128);
+    ctx->parse_started_total = ctx->recon_started_total = 0;
+    ctx->window_parse_target = ctx->window_recon_target = 0;
+    (void)hipGetLastError();
+}
+
 struct StepSlices {
     int count = 0;
     const size_t *bounds = nullptr;
@@ -1040,19 +1076,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     if (pipe_silk) ctx->silk_slot ^= 1;
     const int sset = pipe_silk ? ctx->silk_slot : 0; // the set of SILK records and hand-offs this step uses (and of CELT records with them)
     const int par = pipe ? ctx->slot : sset, par2 = (par + 1) % 3; // this step's slot; the slot of the step two before it
-    {
-        int rc;
-        const size_t need = (size_t)n;
-        if (ctx->cap_recs[par] < sizeof(ParseRec) * need &&
-            (rc = grow(ctx, &ctx->d_recs[par], &ctx->cap_recs[par], sizeof(ParseRec) * need)))
-            return rc;
-        if (ctx->cap_rout[par] < sizeof(ReconOut) * need &&
-            (rc = grow(ctx, &ctx->d_rout[par], &ctx->cap_rout[par], sizeof(ReconOut) * need)))
-            return rc;
-        if (ctx->fast_recon && ctx->leaf_kernel && any_celt && ctx->cap_leaf[par] < og_leaf_out_bytes() * need &&
-            (rc = grow(ctx, &ctx->d_leaf[par], &ctx->cap_leaf[par], og_leaf_out_bytes() * need)))
-            return rc;
-    }
+    if (int rc = grow_step_slot(ctx, par, (size_t)n, any_celt)) return rc; // (a window's slots were sized before its first launch)
     if (ctx->split_hybrid && any_silk) {
         int rc;
         if (ctx->cap_handoff[sset] < sizeof(SilkHandoff) * (size_t)n || ctx->cap_srecs[sset] < sizeof(SilkRec) * (size_t)n) {
@@ -1251,7 +1275,8 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     if (ctx->post_recorded[par2]) HIPCHK(ctx, hipStreamWaitEvent(back, ctx->ev_post[par2], 0)); // (the ring: 2 x 960 of 2048)
     if (window) { // ... and every workgroup of the next step's parse has its place
         const int next_grid = (next_n + wide * ctx->parse_groups - 1) / (wide * ctx->parse_groups);
-        HIPCHK(ctx, hipStreamWaitValue32(back, ctx->d_started, ctx->parse_started_total + (u32)next_grid, hipStreamWaitValueGte, 0xffffffffu));
+        ctx->window_parse_target = ctx->parse_started_total + (u32)next_grid;
+        HIPCHK(ctx, hipStreamWaitValue32(back, ctx->d_started, ctx->window_parse_target, hipStreamWaitValueGte, 0xffffffffu));
     }
     // reconstruct (one frame per wave) ...
     if (ctx->fast_recon) {
@@ -1270,7 +1295,8 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     // reconstruction has started (its count of started workgroups, one in 64 counted)
     if (window && ctx->fast_recon) {
         const int first_round = OG_MIN(og_celt_recon_fb_signals(next_n), 32);
-        HIPCHK(ctx, hipStreamWaitValue32(s, ctx->d_started + 16, ctx->recon_started_total + (u32)first_round, hipStreamWaitValueGte, 0xffffffffu));
+        ctx->window_recon_target = ctx->recon_started_total + (u32)first_round;
+        HIPCHK(ctx, hipStreamWaitValue32(s, ctx->d_started + 16, ctx->window_recon_target, hipStreamWaitValueGte, 0xffffffffu));
     }
     // ... -> de-emphasis and PCM (one (frame, channel) per lane); the result codes
     launch_jitter();
@@ -1305,12 +1331,35 @@ int opusgpu_decode_steps_device(opusgpu_ctx *ctx, int n_steps, const int32_t *n,
         HIPCHK(ctx, hipMemset(ctx->d_started, 0, 128));
         ctx->parse_started_total = ctx->recon_started_total = 0;
     }
+    // Everything that can refuse a step is looked at BEFORE the first launch: step k of a window holds its reconstruction and its
+    // de-emphasis until workgroups of step k + 1 have started (hipStreamWaitValue32 below), so a call that stopped between the two
+    // would leave waits nothing satisfies.
+    if (!ctx->d_streams) return OPUSGPU_BAD_ARG;
+    int max_n = 0;
+    for (int k = 0; k < n_steps; k++) {
+        if (n[k] < 0) return OPUSGPU_BAD_ARG;
+        if (n[k] > 0 && (!d_descs[k] || !d_arena[k] || !d_pcm[k] || !d_result[k])) return OPUSGPU_BAD_ARG;
+        max_n = OG_MAX(max_n, n[k]);
+    }
+    if (max_n == 0) return OPUSGPU_OK;
+    const int m = modes ? modes : 7;
+    if (ctx->pipeline && m == 4 && ctx->split_celt && ctx->mode != OPUSGPU_MODE_RFC) {
+        // ... and so is every allocation: the record slots only grow, growing frees the old buffer, and hipFree waits for ALL
+        // streams of the device -- among them the one whose head is such a wait for a parse that this thread has yet to launch.
+        // All three slots take the window's largest step now, while nothing of the window is queued.
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        for (int par = 0; par < 3; par++)
+            if (int rc = grow_step_slot(ctx, par, (size_t)max_n, true)) return rc;
+    }
     for (int k = 0; k < n_steps; k++) {
         const int next_n = k + 1 < n_steps ? n[k + 1] : 0;
-        const int rc = decode_step_impl(ctx, n[k], d_descs[k], d_arena[k], d_pcm[k], d_result[k], hip_stream, true, modes ? modes : 7,
-                                        next_n > 0 ? next_n : 0);
-        if (rc) return rc;
+        const int rc = decode_step_impl(ctx, n[k], d_descs[k], d_arena[k], d_pcm[k], d_result[k], hip_stream, true, m, next_n > 0 ? next_n : 0);
+        if (rc) { // (a HIP error in the middle of a window: let go of what the steps before it wait for, then report it)
+            release_window_waits(ctx);
+            return rc;
+        }
     }
+    ctx->window_parse_target = ctx->window_recon_target = 0; // (every wait of this window has its kernel queued behind it)
     return OPUSGPU_OK;
 }
 
@@ -1455,11 +1504,21 @@ int opusgpu_host_register(opusgpu_ctx *ctx, void *ptr, size_t bytes) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
     if (e != hipSuccess) return fail(ctx, OPUSGPU_ALLOC_FAIL, "hipHostRegister", e);
+    std::lock_guard<std::mutex> lock(ctx->registered_mutex);
+    ctx->registered.emplace_back((uintptr_t)ptr, bytes);
     return OPUSGPU_OK;
 }
 int opusgpu_host_unregister(opusgpu_ctx *ctx, void *ptr) {
     if (!ctx || !ptr) return OPUSGPU_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+        std::lock_guard<std::mutex> lock(ctx->registered_mutex);
+        for (size_t i = 0; i < ctx->registered.size(); i++)
+            if (ctx->registered[i].first == (uintptr_t)ptr) {
+                ctx->registered.erase(ctx->registered.begin() + i);
+                break;
+            }
+    }
     HIPCHK(ctx, hipHostUnregister(ptr));
     return OPUSGPU_OK;
 }
@@ -1617,15 +1676,30 @@ static int host_cpus(int most) {
     return c < 1 ? 1 : (c > most ? most : c);
 }
 
-// Is [p, p + bytes) page-locked host memory the device can write (both ends known to the runtime as host memory)?
-static bool host_range_is_pinned(const void *p, size_t bytes) {
+// Is [p, p + bytes) page-locked host memory the device can write?  ONE page-locked range must cover all of it: either one the
+// caller registered through opusgpu_host_register (the context keeps the list), or one allocation / registration the runtime knows
+// (its start and size are asked for: two ends that are each page-locked may have pageable memory between them).
+static bool host_range_is_pinned(opusgpu_ctx *ctx, const void *p, size_t bytes) {
     if (!p || !bytes) return false;
-    hipPointerAttribute_t a{}, b{};
-    if (hipPointerGetAttributes(&a, p) != hipSuccess || hipPointerGetAttributes(&b, (const uint8_t *)p + bytes - 1) != hipSuccess) {
+    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+    {
+        std::lock_guard<std::mutex> lock(ctx->registered_mutex);
+        for (const auto &r : ctx->registered)
+            if (lo >= r.first && hi <= r.first + r.second) return true;
+    }
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess || a.type != hipMemoryTypeHost) {
         (void)hipGetLastError(); // (pageable memory is reported as an error: not one of ours)
         return false;
     }
-    return a.type == hipMemoryTypeHost && b.type == hipMemoryTypeHost;
+    void *start = nullptr;
+    size_t size = 0;
+    if (hipPointerGetAttribute(&start, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, (hipDeviceptr_t)p) != hipSuccess ||
+        hipPointerGetAttribute(&size, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, (hipDeviceptr_t)p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return lo >= (uintptr_t)start && hi <= (uintptr_t)start + size;
 }
 
 static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_ids, const uint8_t *const *packets,
@@ -1876,7 +1950,7 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
         auto piece_lo = [&](int t) { return bound[t]; };
         // DIRECT: the caller's PCM buffer is page-locked (opusgpu_host_register, hipHostMalloc, hipHostRegister) and the step table is
         // the packets in order, one 20 ms block each: the pieces travel straight into it -- no landing zone, no host copy behind it.
-        const bool direct = pipelined && m == n && frame_capacity == 1 && !rfc && host_range_is_pinned(pcm, (size_t)n * cap_pcm * 2);
+        const bool direct = pipelined && m == n && frame_capacity == 1 && !rfc && host_range_is_pinned(ctx, pcm, (size_t)n * cap_pcm * 2);
         auto copy_pieces = [&](hipStream_t cs, int t0, int t1) -> int { // results of the pieces' frames first, then the pieces
             const size_t flo = piece_lo(t0), fhi = piece_lo(t1);
             HIPCHK(ctx, hipMemcpyAsync((int32_t *)ctx->h_res + flo, (const int32_t *)ctx->d_result + flo, sizeof(int32_t) * (fhi - flo),
@@ -1890,7 +1964,8 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
             return OPUSGPU_OK;
         };
         if (parts > 1) {
-            if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            hipStream_t made;
+            if (int rc = copy_stream_of(ctx, &made)) return rc; // (opusgpu_upload_async makes it too, from another thread)
             for (int h = 0; h < parts; h++)
                 if (!ctx->ev_part[h]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_part[h], hipEventDisableTiming));
         }

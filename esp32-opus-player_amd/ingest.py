@@ -70,6 +70,7 @@ class OverlappedPageDecode:
         ready = queue.Queue()
         done_ev, done_flag = {}, {}
         err = []
+        stop = threading.Event()  # set when the decode loop raises: the ingest thread leaves without touching another slot
         stats = {"ingest_s": [], "demux_s": [], "slot_wait_s": [], "pages": 0, "steps": 0}
         batches = list(batches)
         for b in range(len(batches)):
@@ -82,7 +83,11 @@ class OverlappedPageDecode:
                     i = b % self.depth
                     if b >= self.depth:  # the slot's previous tenant must have been decoded
                         done_flag[b - self.depth].wait()
+                        if stop.is_set():  # (the decode side gave up: its flags were set to let this thread go, no event behind them)
+                            return
                         ctx.event_synchronize(done_ev[b - self.depth])
+                    if stop.is_set():
+                        return
                     t1 = time.perf_counter()
                     kw = {} if self.page_flags is None else {"flags": self.page_flags}
                     host, dev = self._slot(i, int(np.sum(lens, dtype=np.int64)) + 32 * len(lens) + 4096)
@@ -135,10 +140,24 @@ class OverlappedPageDecode:
                 if on_batch_done:
                     on_batch_done(b)
             ctx.synchronize()
+        except BaseException:
+            stop.set()
+            raise
         finally:
             for f in done_flag.values():
                 f.set()
             th.join()
+            if stop.is_set():  # (the error path: whatever was queued ends before its events go; fences the thread made but
+                try:           #  never handed over are in the queue)
+                    ctx.synchronize()
+                except Exception:  # noqa: BLE001
+                    pass
+                while not ready.empty():
+                    item = ready.get_nowait()
+                    if item is not None and item[4] not in fences:
+                        fences.append(item[4])
+                for e in list(done_ev.values()) + fences:
+                    ctx.event_destroy(e)
         stats["wall_s"] = time.perf_counter() - t_start
         stats["first_batch_ready_s"] = first_wait
         stats["gpu_ms_between_batch_ends"] = [ctx.event_elapsed_ms(done_ev[b - 1], done_ev[b]) for b in range(1, len(batches))]

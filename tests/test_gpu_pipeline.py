@@ -246,6 +246,17 @@ def test_placement_knobs_change_no_result(pkg, oracle):
         assert out.returncode == 0 and "knob worker ok" in out.stdout, (env, out.stdout[-400:], out.stderr[-400:])
 
 
+def test_windows_that_grow_on_a_fresh_context():
+    """Buffer growth under queued windows (tests/window_growth_worker.py): every other test here shares a context whose record
+    slots the full-size tests have already grown.  In a child process with a timeout, so that a host deadlock fails the test."""
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "window_growth_worker.py")
+    out = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "window growth worker ok" in out.stdout, (out.stdout[-600:], out.stderr[-600:])
+
+
 def test_window_with_steps_of_different_sizes(pkg, oracle, gpu_ctx):
     """opusgpu_decode_steps_device: the steps of a window need not have the same number of frames (the wait on the next step's
     parse counts THAT step's workgroups); streams 0 .. n_k - 1 take part in step k."""
