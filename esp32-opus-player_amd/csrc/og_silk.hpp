@@ -47,11 +47,15 @@ struct SilkLds {
         } core;
         struct {
             i16 pcm[1920];                          // SILK output at 48 kHz, interleaved over the packet's channels
+            i16 raw_tail[2 * SILK_MAX_FRAME];       // (the rest of sLTP_Q15: the up-sampler's 32-bit rows end here, see silk_up2_rows)
             i16 up[2][8 + 2 * SILK_MAX_FRAME + 8];  // FIR history + 2x up-sampled frame
+            i32 sink[2][4][4];                      // where the up-sampler's inner sections "store" (silk_up2_rows)
         } out;
     } u;
     SilkCtrl ctrl[2];
 };
+static_assert(sizeof(((SilkLds *)0)->u.out) <= sizeof(((SilkLds *)0)->u.core) && 2 * (1920 + 2 * SILK_MAX_FRAME) == 4 * 2 * 2 * SILK_MAX_FRAME,
+              "the resampler's buffers lie over the synthesis core's; `up` starts where sLTP_Q15 ends");
 // SILK's working set is its own LDS object: only the kernels that run SILK pay for it.
 OG_LDS SilkLds g_silk_lds;
 OG_DEV SilkLds &SL() { return g_silk_lds; }
@@ -998,17 +1002,28 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
             OG_ACC_STEP(8) OG_ACC_STEP(9) OG_ACC_STEP(10) OG_ACC_STEP(11) OG_ACC_STEP(12) OG_ACC_STEP(13) OG_ACC_STEP(14) OG_ACC_STEP(15)
 #undef OG_ACC_STEP
             const i32 bias = order >> 1; // (the rounding offset the prediction starts from, silk.cpp:1937)
-            i32 r_cur = resb[0];
-#pragma unroll 4
-            for (int i = 0; i < subfr; i++) {
-                const i32 r_next = resb[i + 1 < subfr ? i + 1 : i]; // (requested a sample ahead: its latency is off the chain)
-                const i32 LPC_pred_Q10 = addw(R, bias);            // (lane 0's is the prediction)
-                const i32 sn0 = __builtin_elementwise_add_sat(r_cur, lshift_sat32(LPC_pred_Q10, 4));
-                const i32 sn = OG_ROW_BCAST(sn0, 0);
-                resb[i] = sn; // the residual is consumed: its slot keeps the sample (output scaling, next history); every lane
-                              // of the row stores the same value to the same word
-                R = addw(__builtin_amdgcn_update_dpp(0, R, 0x101 /* row_shl:1 */, 0xf, 0xf, true), smulwb(sn, A_j));
-                r_cur = r_next;
+            // silk_SMULWB(sn, A_j) = (sn * A_j) >> 16 = the high word of sn * (A_j << 16): ONE instruction (v_mul_hi_i32) where two
+            // 24-bit multiplies, a shift and an add stood; the shifted accumulator arrives through the add's own DPP operand.  Four
+            // samples per trip (a subframe is 40, 60 or 80): their residuals come as one 16-byte read a trip ahead, their outputs
+            // leave as one 16-byte write.  7 vector instructions per sample (12 before), in the kernel's longest serial loop.
+            const i32 A16 = shl32(A_j, 16);
+            typedef i32 i32x4 __attribute__((ext_vector_type(4)));
+            i32x4 rq = *reinterpret_cast<const i32x4 *>(&resb[0]);
+#pragma unroll 2
+            for (int i = 0; i < subfr; i += 4) {
+                const i32x4 nx = *reinterpret_cast<const i32x4 *>(&resb[i + 4 < subfr ? i + 4 : i]); // (its latency is off the chain)
+                i32x4 sv;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const i32 LPC_pred_Q10 = addw(R, bias);            // (lane 0's is the prediction)
+                    const i32 sn0 = __builtin_elementwise_add_sat(rq[t], lshift_sat32(LPC_pred_Q10, 4));
+                    const i32 sn = OG_ROW_BCAST(sn0, 0);
+                    sv[t] = sn; // the residual is consumed: its slot keeps the sample (output scaling, next history); every lane
+                                // of the row stores the same value to the same word
+                    R = addw(__builtin_amdgcn_update_dpp(0, R, 0x101 /* row_shl:1 */, 0xf, 0xf, true), smmul(sn, A16));
+                }
+                *reinterpret_cast<i32x4 *>(&resb[i]) = sv;
+                rq = nx;
             }
 #undef OG_ROW_BCAST
         }
@@ -1092,66 +1107,99 @@ OG_DEV void silk_set_fs(SilkChannel *c, int fs_kHz) {
 // three first-order all-pass sections; lane (phase, section) owns one section's state, takes its input from the lane
 // before it (row_shr:1, the previous step's output) and works on sample t = step - section.  inLen + 2 steps of one
 // section each instead of inLen steps of six.  Must be entered by all 64 lanes.
+// A step is seven vector instructions (round 3: seventeen, and an exec-mask branch around the store): the section's product is
+// the high word of Y * (coef << 16) (silk_SMULWB as one v_mul_hi_i32); the last sections store their 32-bit outputs as they are
+// -- phase 0 over the input samples it has consumed, phase 1 into the row's other half -- and the rounding to 16 bits is done
+// afterwards by all 64 lanes at once; the inner sections, which have nothing to store, write to a sink instead of branching.
 OG_DEV void silk_up2_rows(SilkState *st, int channels, int inLen) {
     SilkLds &L = SL();
     const int row = OG_LANE >> 4, j = OG_LANE & 15;
-    if (row >= channels) return;
-    SilkChannel *c = &st->ch[row];
-    const i16 *in = &L.xq[row][1];
-    i16 *up = L.u.out.up[row];
-    const int delay = c->rs_inputDelay;
-    if (j < 8) up[j] = c->rs_sFIR[j];
-    // the input stream [delayBuf | in] as 32-bit Q10 values, staged once (the sLTP_Q15 row of this channel is free by now)
-    i32 *in32 = L.u.core.sLTP_Q15[row];
-    for (int t = j; t < inLen; t += 16) in32[t] = shl32(t < delay ? (i32)c->rs_delayBuf[t] : (i32)in[t - delay], 10);
-    OG_ROW_SYNC();
-    if (j < 6) {
-        const int ph = j >= 3, sec = j - 3 * ph;
-        const i32 coef = ph ? rom_silk_up2_hq1[sec] : rom_silk_up2_hq0[sec];
-        i32 S = c->rs_sIIR[j], out = 0;
-        i16 *dst = &up[8 + ph];
-        // Section `sec` handles input sample t = u - sec in step u.  The two steps that fill the pipeline and the two that drain it
-        // run the general body (a section without a sample keeps its state); the inLen - 2 steps in between have every section
-        // at work and carry no such bookkeeping: the kernel is bound by vector-ALU issue, and this loop is a third of it.
-        auto edge_step = [&](int u) {
-            const i32 prev_out = __builtin_amdgcn_update_dpp(0, out, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
-            const int t = u - sec;
-            const bool live = (unsigned)t < (unsigned)inLen;
-            const i32 v = sec == 0 ? in32[live ? t : 0] : prev_out;
-            const i32 Y = v - S;
-            const i32 X = smulwb(Y, coef) + (sec == 2 ? Y : 0);
-            const i32 o = S + X;
-            out = live ? o : out;
-            S = live ? v + X : S;
-            if (live && sec == 2) dst[2 * t] = (i16)sat16(rshift_round(o, 10));
-        };
-        edge_step(0);
-        edge_step(1);
-        {
+    if (row < channels) {
+        SilkChannel *c = &st->ch[row];
+        const i16 *in = &L.xq[row][1];
+        i16 *up = L.u.out.up[row];
+        const int delay = c->rs_inputDelay;
+        if (j < 8) up[j] = c->rs_sFIR[j];
+        // the input stream [delayBuf | in] as 32-bit Q10 values, staged once (the sLTP_Q15 row of this channel is free by now)
+        i32 *in32 = L.u.core.sLTP_Q15[row], *raw1 = in32 + SILK_MAX_FRAME;
+        if (j < delay) in32[j] = shl32((i32)c->rs_delayBuf[j], 10); // (delay is 0, 4 or 7: rom_silk_delay_dec)
+        for (int t = j; t < inLen - delay; t += 16) in32[delay + t] = shl32((i32)in[t], 10);
+        OG_ROW_SYNC();
+        if (j < 6) {
+            const int ph = j >= 3, sec = j - 3 * ph;
             const bool first = sec == 0, last = sec == 2;
+            const i32 coef = ph ? rom_silk_up2_hq1[sec] : rom_silk_up2_hq0[sec], coef16 = shl32(coef, 16);
             const i32 m2 = last ? -1 : 0;
-            i16 *d2 = dst - 2 * sec; // d2[2 u] is the slot of sample u - sec
-            i32 in_cur = in32[2];
-#pragma unroll 4
-            for (int u = 2; u < inLen; u++) {
-                const i32 in_next = in32[u + 1 < inLen ? u + 1 : u]; // (requested a step ahead)
+            i32 S = c->rs_sIIR[j], out = 0;
+            i32 *const raw = ph ? raw1 : in32; // the last section's outputs, sample t at [t]
+            // Section `sec` handles input sample t = u - sec in step u.  The two steps that fill the pipeline and the two that drain it
+            // run the general body (a section without a sample keeps its state); the inLen - 2 steps in between have every section
+            // at work and carry no such bookkeeping.
+            auto edge_step = [&](int u) {
                 const i32 prev_out = __builtin_amdgcn_update_dpp(0, out, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
-                const i32 v = first ? in_cur : prev_out;
+                const int t = u - sec;
+                const bool live = (unsigned)t < (unsigned)inLen;
+                const i32 v = first ? in32[live ? t : 0] : prev_out;
                 const i32 Y = v - S;
-                const i32 X = smulwb(Y, coef) + (Y & m2);
-                out = S + X;
-                S = v + X;
-                if (last) d2[2 * u] = (i16)sat16(rshift_round(out, 10));
-                in_cur = in_next;
+                const i32 X = smmul(Y, coef16) + (Y & m2);
+                const i32 o = S + X;
+                out = live ? o : out;
+                S = live ? v + X : S;
+                if (live && last) raw[t] = o;
+            };
+#define OG_UP2_STEP(in_u, slot)                                                                                  \
+    do {                                                                                                         \
+        const i32 prev_out = __builtin_amdgcn_update_dpp(0, out, 0x111 /* row_shr:1 */, 0xf, 0xf, true);         \
+        const i32 v = first ? (in_u) : prev_out;                                                                 \
+        const i32 Y = v - S;                                                                                     \
+        const i32 X = smmul(Y, coef16) + (Y & m2);                                                               \
+        out = S + X;                                                                                             \
+        S = v + X;                                                                                               \
+        wr[slot] = out;                                                                                          \
+    } while (0)
+            edge_step(0);
+            edge_step(1);
+            {
+                // steps 2 .. inLen - 1 (inLen is 160, 240 or 320): two single ones, then four per trip with the trip's inputs read as
+                // one 16-byte word a trip ahead.  wr: where sample u - 2 goes -- only the last sections' pointer moves.
+                typedef i32 i32x4 __attribute__((ext_vector_type(4)));
+                i32 *wr = last ? raw : &L.u.out.sink[row][j - ph][0];
+                const int adv = last ? 4 : 0;
+                OG_UP2_STEP(in32[2], 0);
+                OG_UP2_STEP(in32[3], 1);
+                wr += adv >> 1;
+                i32x4 cur = *reinterpret_cast<const i32x4 *>(&in32[4]);
+                for (int u = 4; u < inLen; u += 4) {
+                    const i32x4 nxt = *reinterpret_cast<const i32x4 *>(&in32[u + 4 < inLen ? u + 4 : u]);
+                    OG_UP2_STEP(cur[0], 0);
+                    OG_UP2_STEP(cur[1], 1);
+                    OG_UP2_STEP(cur[2], 2);
+                    OG_UP2_STEP(cur[3], 3);
+                    wr += adv;
+                    cur = nxt;
+                }
             }
+#undef OG_UP2_STEP
+            edge_step(inLen);
+            edge_step(inLen + 1);
+            c->rs_sIIR[j] = S;
         }
-        edge_step(inLen);
-        edge_step(inLen + 1);
-        c->rs_sIIR[j] = S;
     }
-    OG_ROW_SYNC();
-    if (j < 8) c->rs_sFIR[j] = up[2 * inLen + j];
-    if (j < delay) c->rs_delayBuf[j] = in[inLen - delay + j];
+    OG_SYNC();
+    // the 32-bit outputs to the FIR's 16-bit input rows, phases interleaved (silk.cpp:3515: silk_SAT16(silk_RSHIFT_ROUND(out, 10)))
+    for (int n = 0; n < channels; n++) {
+        const i32 *in32 = L.u.core.sLTP_Q15[n];
+        i16 *up = &L.u.out.up[n][8];
+        OG_FOR_LANES(m, 2 * inLen) up[m] = (i16)sat16(rshift_round(in32[(m & 1) * SILK_MAX_FRAME + (m >> 1)], 10));
+    }
+    OG_SYNC();
+    if (row < channels) {
+        SilkChannel *c = &st->ch[row];
+        const i16 *in = &L.xq[row][1], *up = L.u.out.up[row];
+        const int delay = c->rs_inputDelay;
+        if (j < 8) c->rs_sFIR[j] = up[2 * inLen + j];
+        if (j < delay) c->rs_delayBuf[j] = in[inLen - delay + j];
+    }
 }
 #endif
 
@@ -1521,6 +1569,7 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
                     const i32 index_Q16 = m * inv;
                     const int t = smulwb(index_Q16 & 0xFFFF, 12);
                     const i16 *b = &L.u.out.up[n][2 * t0 + (index_Q16 >> 16)];
+#ifdef OG_HOST_EMUL
                     const i16 *f0 = &rom_silk_frac_fir12[4 * t], *f1 = &rom_silk_frac_fir12[4 * (11 - t)];
                     i32 res = smulbb(b[0], f0[0]);
                     res = smlabb(res, b[1], f0[1]);
@@ -1530,6 +1579,19 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
                     res = smlabb(res, b[5], f1[2]);
                     res = smlabb(res, b[6], f1[1]);
                     res = smlabb(res, b[7], f1[0]);
+#else
+                    // the eight products two at a time (v_dot2_i32_i16 adds like silk_SMLABB, mod 2^32): the samples as the four
+                    // words they lie in, the phase's taps packed the same way (rom_silk_fir12_taps8)
+                    typedef u32 u32x4u __attribute__((ext_vector_type(4), aligned(2)));
+                    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4u x = *reinterpret_cast<const u32x4u *>(b);
+                    const u32x4 f = *reinterpret_cast<const u32x4 *>(&rom_silk_fir12_taps8[4 * t]);
+                    i32 res;
+                    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(res) : "v"(x[0]), "v"(f[0]));
+                    asm("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(res) : "v"(x[1]), "v"(f[1]));
+                    asm("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(res) : "v"(x[2]), "v"(f[2]));
+                    asm("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(res) : "v"(x[3]), "v"(f[3]));
+#endif
                     SL().u.out.pcm[(out0 + m) * channels + n] = (i16)sat16(rshift_round(res, 15));
                 }
                 t0 += nIn;

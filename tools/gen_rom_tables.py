@@ -332,6 +332,16 @@ def build_text():
         t += emit(f"rom_bitrev{n}", "int16_t", digit_reversal(FFT_FACTORS[n], n), 20)
     for name, (ctype, vals) in SILK_TABLES.items():
         t += emit(name, ctype, vals, 16)
+    if "rom_silk_frac_fir12" in SILK_TABLES:
+        # the 12 phases of the 8-tap interpolation filter (silk_resampler_private_IIR_FIR_INTERPOL, src/silk.cpp:3451-3472) as the
+        # kernel multiplies them: per phase t the taps that meet input samples b[0..7] in order -- row t of the table forwards, row
+        # 11 - t backwards -- packed two to a word (low half first) for v_dot2_i32_i16
+        f = SILK_TABLES["rom_silk_frac_fir12"][1]
+        packed = []
+        for ph in range(12):
+            taps = list(f[4 * ph:4 * ph + 4]) + list(reversed(f[4 * (11 - ph):4 * (11 - ph) + 4]))
+            packed += [(taps[2 * i] & 0xFFFF) | (taps[2 * i + 1] & 0xFFFF) << 16 for i in range(4)]
+        t += emit("rom_silk_fir12_taps8", "uint32_t", packed, 4)
     # Every 8-bit SILK table once more as ONE blob (+ offsets): the lane-per-frame SILK parse kernel copies it to LDS in
     # one go and addresses tables as SILK_BLOB_<name> + index.
     blob, offs = [], []
