@@ -49,7 +49,7 @@ struct SilkLds {
             i16 pcm[1920];                          // SILK output at 48 kHz, interleaved over the packet's channels
             i16 raw_tail[2 * SILK_MAX_FRAME];       // (the rest of sLTP_Q15: the up-sampler's 32-bit rows end here, see silk_up2_rows)
             i16 up[2][8 + 2 * SILK_MAX_FRAME + 8];  // FIR history + 2x up-sampled frame
-            i32 sink[2][4][4];                      // where the up-sampler's inner sections "store" (silk_up2_rows)
+            i32 sink[4][2][4];                      // where the up-sampler's inner sections "store" (silk_up2_rows)
         } out;
     } u;
     SilkCtrl ctrl[2];
@@ -1103,87 +1103,95 @@ OG_DEV void silk_set_fs(SilkChannel *c, int fs_kHz) {
 }
 
 #ifndef OG_HOST_EMUL
-// The same up-sampler as a systolic array: per channel (one 16-lane row each) the two output phases are two cascades of
-// three first-order all-pass sections; lane (phase, section) owns one section's state, takes its input from the lane
-// before it (row_shr:1, the previous step's output) and works on sample t = step - section.  inLen + 2 steps of one
-// section each instead of inLen steps of six.  Must be entered by all 64 lanes.
-// A step is seven vector instructions (round 3: seventeen, and an exec-mask branch around the store): the section's product is
-// the high word of Y * (coef << 16) (silk_SMULWB as one v_mul_hi_i32); the last sections store their 32-bit outputs as they are
-// -- phase 0 over the input samples it has consumed, phase 1 into the row's other half -- and the rounding to 16 bits is done
-// afterwards by all 64 lanes at once; the inner sections, which have nothing to store, write to a sink instead of branching.
+// The same up-sampler as a systolic array: the two output phases of a channel are two cascades of three first-order all-pass
+// sections; lane (phase, section) owns one section's state, takes its input from the lane before it (row_shr:1, the previous
+// step's output) and works on sample t = step - section.  inLen + 2 steps of one section each instead of inLen steps of six.
+// Must be entered by all 64 lanes.  Phase 0 of channel n runs in lanes 0 - 2 of DPP row n, phase 1 in lanes 0 - 2 of row n + 2:
+// every cascade's first section is then lane 0 of a row -- the one lane row_shr:1 has no source for, which keeps the value the
+// register held before: the input sample.
+// A step is six vector instructions (round 3: seventeen, and an exec-mask branch around the store): shift-or-input in one DPP
+// move; the section's product as the high word of Y * (coef << 16) (silk_SMULWB in one v_mul_hi_i32); two three-operand adds; the
+// last sections store their 32-bit outputs as they are -- phase 0 over the input samples it has consumed, phase 1 into the row's
+// other half -- and the rounding to 16 bits is done afterwards by all 64 lanes at once; the inner sections, which have nothing
+// to store, write to a sink instead of branching.
+OG_DEV i32 og_add3(i32 a, i32 b, i32 c) {
+    i32 r;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 OG_DEV void silk_up2_rows(SilkState *st, int channels, int inLen) {
     SilkLds &L = SL();
     const int row = OG_LANE >> 4, j = OG_LANE & 15;
     if (row < channels) {
         SilkChannel *c = &st->ch[row];
         const i16 *in = &L.xq[row][1];
-        i16 *up = L.u.out.up[row];
         const int delay = c->rs_inputDelay;
-        if (j < 8) up[j] = c->rs_sFIR[j];
+        if (j < 8) L.u.out.up[row][j] = c->rs_sFIR[j];
         // the input stream [delayBuf | in] as 32-bit Q10 values, staged once (the sLTP_Q15 row of this channel is free by now)
-        i32 *in32 = L.u.core.sLTP_Q15[row], *raw1 = in32 + SILK_MAX_FRAME;
+        i32 *in32 = L.u.core.sLTP_Q15[row];
         if (j < delay) in32[j] = shl32((i32)c->rs_delayBuf[j], 10); // (delay is 0, 4 or 7: rom_silk_delay_dec)
         for (int t = j; t < inLen - delay; t += 16) in32[delay + t] = shl32((i32)in[t], 10);
-        OG_ROW_SYNC();
-        if (j < 6) {
-            const int ph = j >= 3, sec = j - 3 * ph;
-            const bool first = sec == 0, last = sec == 2;
-            const i32 coef = ph ? rom_silk_up2_hq1[sec] : rom_silk_up2_hq0[sec], coef16 = shl32(coef, 16);
-            const i32 m2 = last ? -1 : 0;
-            i32 S = c->rs_sIIR[j], out = 0;
-            i32 *const raw = ph ? raw1 : in32; // the last section's outputs, sample t at [t]
-            // Section `sec` handles input sample t = u - sec in step u.  The two steps that fill the pipeline and the two that drain it
-            // run the general body (a section without a sample keeps its state); the inLen - 2 steps in between have every section
-            // at work and carry no such bookkeeping.
-            auto edge_step = [&](int u) {
-                const i32 prev_out = __builtin_amdgcn_update_dpp(0, out, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
-                const int t = u - sec;
-                const bool live = (unsigned)t < (unsigned)inLen;
-                const i32 v = first ? in32[live ? t : 0] : prev_out;
-                const i32 Y = v - S;
-                const i32 X = smmul(Y, coef16) + (Y & m2);
-                const i32 o = S + X;
-                out = live ? o : out;
-                S = live ? v + X : S;
-                if (live && last) raw[t] = o;
-            };
-#define OG_UP2_STEP(in_u, slot)                                                                                  \
-    do {                                                                                                         \
-        const i32 prev_out = __builtin_amdgcn_update_dpp(0, out, 0x111 /* row_shr:1 */, 0xf, 0xf, true);         \
-        const i32 v = first ? (in_u) : prev_out;                                                                 \
-        const i32 Y = v - S;                                                                                     \
-        const i32 X = smmul(Y, coef16) + (Y & m2);                                                               \
-        out = S + X;                                                                                             \
-        S = v + X;                                                                                               \
-        wr[slot] = out;                                                                                          \
+    }
+    OG_SYNC();
+    const int ch = row & 1, ph = row >> 1;
+    if (ch < channels && j < 3) {
+        SilkChannel *c = &st->ch[ch];
+        const int sec = j;
+        const bool first = sec == 0, last = sec == 2;
+        const i32 coef = ph ? rom_silk_up2_hq1[sec] : rom_silk_up2_hq0[sec], coef16 = shl32(coef, 16);
+        const i32 m2 = last ? -1 : 0;
+        i32 S = c->rs_sIIR[3 * ph + sec], out = 0;
+        const i32 *in32 = L.u.core.sLTP_Q15[ch];
+        i32 *const raw = L.u.core.sLTP_Q15[ch] + ph * SILK_MAX_FRAME; // the last section's outputs, sample t at [t]
+        // Section `sec` handles input sample t = u - sec in step u.  The two steps that fill the pipeline and the two that drain it
+        // run the general body (a section without a sample keeps its state); the inLen - 2 steps in between have every section
+        // at work and carry no such bookkeeping.
+        auto edge_step = [&](int u) {
+            const i32 prev_out = __builtin_amdgcn_update_dpp(0, out, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+            const int t = u - sec;
+            const bool live = (unsigned)t < (unsigned)inLen;
+            const i32 v = first ? in32[live ? t : 0] : prev_out;
+            const i32 Y = v - S;
+            const i32 X = smmul(Y, coef16) + (Y & m2);
+            const i32 o = S + X;
+            out = live ? o : out;
+            S = live ? v + X : S;
+            if (live && last) raw[t] = o;
+        };
+#define OG_UP2_STEP(in_u, slot)                                                                                          \
+    do {                                                                                                                 \
+        const i32 v = __builtin_amdgcn_update_dpp((in_u), out, 0x111 /* row_shr:1 */, 0xf, 0xf, false);                  \
+        const i32 Y = v - S, P = smmul(Y, coef16), Ym = Y & m2;                                                          \
+        out = og_add3(S, P, Ym);                                                                                         \
+        S = og_add3(v, P, Ym);                                                                                           \
+        wr[slot] = out;                                                                                                  \
     } while (0)
-            edge_step(0);
-            edge_step(1);
-            {
-                // steps 2 .. inLen - 1 (inLen is 160, 240 or 320): two single ones, then four per trip with the trip's inputs read as
-                // one 16-byte word a trip ahead.  wr: where sample u - 2 goes -- only the last sections' pointer moves.
-                typedef i32 i32x4 __attribute__((ext_vector_type(4)));
-                i32 *wr = last ? raw : &L.u.out.sink[row][j - ph][0];
-                const int adv = last ? 4 : 0;
-                OG_UP2_STEP(in32[2], 0);
-                OG_UP2_STEP(in32[3], 1);
-                wr += adv >> 1;
-                i32x4 cur = *reinterpret_cast<const i32x4 *>(&in32[4]);
-                for (int u = 4; u < inLen; u += 4) {
-                    const i32x4 nxt = *reinterpret_cast<const i32x4 *>(&in32[u + 4 < inLen ? u + 4 : u]);
-                    OG_UP2_STEP(cur[0], 0);
-                    OG_UP2_STEP(cur[1], 1);
-                    OG_UP2_STEP(cur[2], 2);
-                    OG_UP2_STEP(cur[3], 3);
-                    wr += adv;
-                    cur = nxt;
-                }
+        edge_step(0);
+        edge_step(1);
+        {
+            // steps 2 .. inLen - 1 (inLen is 160, 240 or 320): two single ones, then four per trip with the trip's inputs read as
+            // one 16-byte word a trip ahead.  wr: where sample u - 2 goes -- only the last sections' pointer moves.
+            typedef i32 i32x4 __attribute__((ext_vector_type(4)));
+            i32 *wr = last ? raw : &L.u.out.sink[row][sec][0];
+            const int adv = last ? 4 : 0;
+            OG_UP2_STEP(in32[2], 0);
+            OG_UP2_STEP(in32[3], 1);
+            wr += adv >> 1;
+            i32x4 cur = *reinterpret_cast<const i32x4 *>(&in32[4]);
+            for (int u = 4; u < inLen; u += 4) {
+                const i32x4 nxt = *reinterpret_cast<const i32x4 *>(&in32[u + 4 < inLen ? u + 4 : u]);
+                OG_UP2_STEP(cur[0], 0);
+                OG_UP2_STEP(cur[1], 1);
+                OG_UP2_STEP(cur[2], 2);
+                OG_UP2_STEP(cur[3], 3);
+                wr += adv;
+                cur = nxt;
             }
-#undef OG_UP2_STEP
-            edge_step(inLen);
-            edge_step(inLen + 1);
-            c->rs_sIIR[j] = S;
         }
+#undef OG_UP2_STEP
+        edge_step(inLen);
+        edge_step(inLen + 1);
+        c->rs_sIIR[3 * ph + sec] = S;
     }
     OG_SYNC();
     // the 32-bit outputs to the FIR's 16-bit input rows, phases interleaved (silk.cpp:3515: silk_SAT16(silk_RSHIFT_ROUND(out, 10)))
