@@ -222,6 +222,7 @@ def prepare_pages_work(pkg, shard, ranks, ctx, n, frames, ingest="rank0", page_c
     return base, lay, stats, keep
 
 
+MIXED_FLOW = os.environ.get("BENCH_MIXED_FLOW", "keeps")  # mixed_pages_2m: keeps | substeps | inorder (see run_workload)
 RAW_PAGES = {}  # this rank's share of the raw pages, as prepare_pages_work (per-rank ingest) received it
 
 
@@ -238,14 +239,17 @@ def overlapped_end_to_end(pkg, ranks, ctx, n, d_pcm, d_res, threads):
     if len(lens) % n:
         raise SystemExit("raw pages are not whole batches of one page per stream")
     batches = [(blob, offs[q * n:(q + 1) * n], lens[q * n:(q + 1) * n], sids[q * n:(q + 1) * n]) for q in range(len(lens) // n)]
-    if os.environ.get("BENCH_E2E_SPLIT_FIRST", "1") != "0":
-        # the first batch's ingest is the one nothing hides: it goes in two halves (by page order), so that decoding starts after half of it
+    split = os.environ.get("BENCH_E2E_SPLIT_FIRST", "8")
+    if split != "0":
+        # the first batch's ingest is the one nothing hides: it goes in growing pieces (by page order: 1/8, 1/8, 1/4, 1/2 of the batch;
+        # "1": two halves), so that decoding starts after an eighth of it and every later piece is demuxed under the decode of the one before
         b0 = batches[0]
-        h = n // 2
-        batches = [(blob, b0[1][:h], b0[2][:h], b0[3][:h]), (blob, b0[1][h:], b0[2][h:], b0[3][h:])] + batches[1:]
+        cuts = [0, n // 8, n // 4, n // 2, n] if split != "1" else [0, n // 2, n]
+        batches = [(blob, b0[1][a:b], b0[2][a:b], b0[3][a:b]) for a, b in zip(cuts[:-1], cuts[1:])] + batches[1:]
     ctx.streams_reset(0, n)
     ctx.synchronize()
-    pipe = mod.OverlappedPageDecode(ctx, threads=int(os.environ.get("BENCH_E2E_THREADS", threads)), depth=int(os.environ.get("BENCH_E2E_DEPTH", "3")))
+    pipe = mod.OverlappedPageDecode(ctx, threads=int(os.environ.get("BENCH_E2E_THREADS", threads)), depth=int(os.environ.get("BENCH_E2E_DEPTH", "3")),
+                                    keeps_mode=MIXED_FLOW != "inorder", by_kind=MIXED_FLOW == "substeps")  # (a stream's mode is fixed in this workload)
     pipe.reserve(int(max(int(b[2].sum()) + 32 * len(b[2]) for b in batches)) + 4096)  # a service sets its slots up once, not per job
     ranks.barrier()
     st = pipe.run(batches, d_pcm, d_res)
@@ -381,8 +385,13 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
         if _keep is None:
             frees.append(base)
 
+        # a stream's mode is fixed in this workload, which is what OPUSGPU_STEP_KEEPS_MODE promises: every step -- frames of all three
+        # modes -- then runs its entropy kernels ahead, next to the arithmetic kernels of the step before (BENCH_MIXED_FLOW=substeps:
+        # every step as three declared sub-steps over the parts of its table; =inorder: no promise, in order in two halves)
+        keeps = args.pipeline == "on" and MIXED_FLOW != "inorder"
+
         def step(f):
-            ctx.decode_work_step(base, lay, f, d_pcm, d_res)
+            ctx.decode_work_step(base, lay, f, d_pcm, d_res, by_kind=keeps and MIXED_FLOW == "substeps", keeps_kind=keeps)
     else:
         # streams are sharded across ranks with no data-path exchange: each rank owns streams
         # [rank*n, (rank+1)*n) of the global id space (seeds differ per global stream id)
@@ -471,7 +480,11 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
         "value": value, "unit": "frames/s", "ms_per_step": dt / K * 1e3,
         "config": ({"workload": f"{name}: {n} streams/GPU, one Ogg page of {PACKETS_PER_PAGE} packets per stream and "
                                 f"10 steps, modes SILK-NB : hybrid FB : CELT FB = 1:1:1 across streams (TOC 0x0C / 0x7C / "
-                                f"0xFC, 40 / 120 / 160-byte LCG payloads), 48 kHz stereo, step tables grouped by mode",
+                                f"0xFC, 40 / 120 / 160-byte LCG payloads), 48 kHz stereo, step tables grouped by mode" +
+                                ("; steps carry OPUSGPU_STEP_KEEPS_MODE (a stream's mode is fixed) and are pipelined: the entropy "
+                                 "kernels of step k + 1 next to the arithmetic kernels of step k" +
+                                 (", three declared sub-steps per step" if MIXED_FLOW == "substeps" else "")
+                                 if keeps else "; undeclared steps, in order, in two halves"),
                     "streams_per_gpu": n,
                     "sharding": ("rank 0 ingests the pages (host demux) and scatters every rank's decode steps "
                                  if args.ingest == "rank0" else

@@ -64,6 +64,7 @@ class FrameDesc(C.Structure):
 
 
 HAS_SILK, HAS_HYBRID, HAS_CELT = 1, 2, 4  # opusgpu_decode_step_device_modes
+STEP_KEEPS_MODE = 8  # OPUSGPU_STEP_KEEPS_MODE: no stream of the step has decoded a frame of another mode since its last reset
 
 
 def toc_modes(toc):
@@ -418,12 +419,35 @@ class Context:
         self._chk(self.lib.opusgpu_output_stage_device(self.h, n_blocks, block_samples, d_pcm, pcm_stride, d_valid, valid_all,
                                                        d_cfgs, cfg, d_i2s, i2s_stride, stream), "opusgpu_output_stage_device")
 
-    def decode_work_step(self, base, layout, k, d_pcm, d_result):
+    def decode_step_by_kind(self, n_silk, n_hybrid, n_celt, d_descs, d_arena, d_pcm, d_result, keeps_kind=False, stream=None):
+        """One step whose table is grouped by mode (OPUSGPU_PAGES_GROUP_BY_MODE: SILK-only, hybrid, CELT-only frames in that
+        order), issued as up to three DECLARED sub-steps over the parts of the table, of d_pcm and of d_result: declared steps are
+        what opusgpu_set_pipeline lets run ahead.  keeps_kind: OPUSGPU_STEP_KEEPS_MODE (include/opusgpu.h) -- the caller's word that
+        a stream's mode never crosses between CELT-only and SILK-only / hybrid (config 5: it is fixed)."""
+        def at(p, off):
+            return C.c_void_p((p.value if isinstance(p, C.c_void_p) else int(p)) + off)
+        f0 = 0
+        extra = STEP_KEEPS_MODE if keeps_kind else 0
+        for cnt, mode in ((n_silk, HAS_SILK), (n_hybrid, HAS_HYBRID), (n_celt, HAS_CELT)):
+            if cnt:
+                self.decode_step_device(cnt, at(d_descs, 16 * f0), d_arena, at(d_pcm, f0 * 960 * self.channels * 2), at(d_result, 4 * f0),
+                                        stream=stream, modes=mode | extra)
+            f0 += cnt
+
+    def decode_work_step(self, base, layout, k, d_pcm, d_result, by_kind=False, keeps_kind=False):
         """Step k of a packed work buffer (shard.pack_work / shard.WorkLayout) resident in HBM at address `base`: the
-        step's descriptor table and the arena are used where they lie."""
+        step's descriptor table and the arena are used where they lie.  keeps_kind: OPUSGPU_STEP_KEEPS_MODE (a stream's mode is
+        fixed): the step -- frames of every mode -- runs ahead like a declared one; by_kind: as three declared sub-steps
+        (decode_step_by_kind), if the step's table is grouped by mode."""
         base = base.value if isinstance(base, C.c_void_p) else int(base)
-        self.decode_step_device(layout.counts[k], C.c_void_p(base + layout.desc_at[k]), C.c_void_p(base + layout.arena_at),
-                                d_pcm, d_result)
+        n = layout.counts[k]
+        ns, nh = layout.mode_counts[k] if by_kind else (-1, -1)
+        if ns >= 0:
+            self.decode_step_by_kind(ns, nh, n - ns - nh, C.c_void_p(base + layout.desc_at[k]), C.c_void_p(base + layout.arena_at),
+                                     d_pcm, d_result, keeps_kind=keeps_kind)
+        else:
+            self.decode_step_device(n, C.c_void_p(base + layout.desc_at[k]), C.c_void_p(base + layout.arena_at), d_pcm, d_result,
+                                    modes=(HAS_SILK | HAS_HYBRID | HAS_CELT | STEP_KEEPS_MODE) if keeps_kind else 0)
 
     def synchronize(self):
         self._chk(self.lib.opusgpu_synchronize(self.h), "opusgpu_synchronize")

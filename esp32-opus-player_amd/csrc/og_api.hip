@@ -652,8 +652,10 @@ struct opusgpu_ctx {
     hipEvent_t ev_part[OPUSGPU_COPY_PIECES] = {};
     int host_parts = 8; // OPUSGPU_HOST_PARTS=1: one batch, copy after the kernels (A/B measurements); 2, 4, 8, 16
     // parse records of the split CELT path (one per frame of a step), grown on demand
-    void *d_recs[3] = {}, *d_rout[3] = {}, *d_leaf[3] = {}; // (three sets: pipelined steps rotate)
-    size_t cap_recs[3] = {}, cap_rout[3] = {}, cap_leaf[3] = {};
+    // (five sets: pipelined CELT-only steps rotate through 0 - 2 -- in-order steps use 0 --, pipelined SILK-only / hybrid steps
+    // alternate 3 and 4: steps of the two kinds may be in flight together, OPUSGPU_STEP_KEEPS_MODE)
+    void *d_recs[5] = {}, *d_rout[5] = {}, *d_leaf[5] = {};
+    size_t cap_recs[5] = {}, cap_rout[5] = {}, cap_leaf[5] = {};
     void *d_handoff[2] = {}, *d_srecs[2] = {}; // (two sets: pipelined SILK-only steps alternate; everything else uses set 0)
     size_t cap_handoff[2] = {}, cap_srecs[2] = {};
     const void *last_srecs = nullptr; // the SILK records of the last step (opusgpu_debug_stage_taps)
@@ -770,11 +772,11 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     (void)hipFree(ctx->d_result);
     if (ctx->parse_stream) (void)hipStreamSynchronize(ctx->parse_stream);
     if (ctx->recon_stream) (void)hipStreamSynchronize(ctx->recon_stream);
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < 5; i++) {
         (void)hipFree(ctx->d_recs[i]);
         (void)hipFree(ctx->d_rout[i]);
         (void)hipFree(ctx->d_leaf[i]);
-        if (ctx->ev_post[i]) (void)hipEventDestroy(ctx->ev_post[i]);
+        if (i < 3 && ctx->ev_post[i]) (void)hipEventDestroy(ctx->ev_post[i]);
     }
     for (int i = 0; i < 2; i++) {
         (void)hipFree(ctx->d_handoff[i]);
@@ -962,8 +964,13 @@ static void launch_jitter() {
 // pipelined SILK-only steps happens from an idle device (their parse reads the stream state when it has no current copy of its
 // own, and whatever follows them reads what their last kernels write); every step of another kind ends the epoch of the parse
 // kernel's copies (it may write SILK state, or prev_mode, behind that kernel's back).
-static int enter_step_kind(opusgpu_ctx *ctx, int kind, hipStream_t s) {
-    if ((kind == 2) != (ctx->last_kind == 2)) {
+// keeps_kind (OPUSGPU_STEP_KEEPS_MODE): the caller's word that no stream of this step has decoded a frame of another mode (SILK-only,
+// hybrid, CELT-only) since its last reset.  Such a step shares no stream with anything of the other kind that is still in flight,
+// so going from one pipelined kind to the other needs no drain, and a CELT-only step leaves the SILK parse kernel's copies (of
+// other streams) as current as they were.
+static int enter_step_kind(opusgpu_ctx *ctx, int kind, hipStream_t s, bool keeps_kind = false) {
+    const bool disjoint = keeps_kind && kind != 0 && ctx->last_kind != 0;
+    if ((kind == 2) != (ctx->last_kind == 2) && !disjoint) {
         if (int rc = sync_in_flight(ctx)) return rc;
         HIPCHK(ctx, hipStreamSynchronize(s));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -971,7 +978,7 @@ static int enter_step_kind(opusgpu_ctx *ctx, int kind, hipStream_t s) {
         ctx->sdone_recorded[0] = ctx->sdone_recorded[1] = 0;
         ctx->last_silk_mask = 0;
     }
-    if (kind != 2) ctx->shadow_epoch++;
+    if (kind != 2 && !(keeps_kind && kind == 1)) ctx->shadow_epoch++;
     ctx->last_kind = kind;
     return OPUSGPU_OK;
 }
@@ -1050,6 +1057,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     }
     // `modes` (bit 0 SILK-only, 1 hybrid, 2 CELT-only frames may be present; 7 = not known): the kernels of modes the caller
     // rules out are not launched; k_celt_post reports a frame of such a mode as OPUSGPU_BAD_ARG
+    const bool keeps_kind = (modes & OPUSGPU_STEP_KEEPS_MODE) != 0;
     modes &= 7;
     if (!modes) modes = 7;
     const bool any_silk = (modes & 3) != 0, any_celt = (modes & 6) != 0;
@@ -1059,9 +1067,12 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     const bool pipe = ctx->pipeline && tables_resident && modes == 4;
     const bool window = pipe && next_n > 0; // the next step is queued by this very call: see PLACEMENT
     // ... and a step declared free of CELT-only frames runs its parse kernels ahead (PIPELINED SILK / HYBRID STEPS below)
-    const bool pipe_silk = ctx->pipeline && tables_resident && (modes & 4) == 0 && ctx->split_hybrid && !slices &&
+    // -- or, with the caller's word that no stream of the step ever changes its mode (OPUSGPU_STEP_KEEPS_MODE), a step of ANY mix with
+    // SILK-only / hybrid frames in it: its CELT-only frames' parse carries the band energies like a pipelined CELT-only step's, and a
+    // CELT-only frame cannot make another stream's SILK copy stale
+    const bool pipe_silk = ctx->pipeline && tables_resident && ((modes & 4) == 0 || keeps_kind) && (modes & 3) != 0 && ctx->split_hybrid && !slices &&
                            (modes == 1 ? og_debug().silk_pipeline : og_debug().hybrid_pipeline);
-    if (int rc = enter_step_kind(ctx, pipe ? 1 : pipe_silk ? 2 : 0, s)) return rc;
+    if (int rc = enter_step_kind(ctx, pipe ? 1 : pipe_silk ? 2 : 0, s, keeps_kind)) return rc;
     if (ctx->pipeline && ctx->last_step_stream && ctx->last_step_stream != s) {
         // consecutive steps on different streams: nothing orders them but the caller, so nothing may run ahead either
         HIPCHK(ctx, hipStreamSynchronize(ctx->last_step_stream));
@@ -1075,7 +1086,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     if (pipe) ctx->slot = (ctx->slot + 1) % 3;
     if (pipe_silk) ctx->silk_slot ^= 1;
     const int sset = pipe_silk ? ctx->silk_slot : 0; // the set of SILK records and hand-offs this step uses (and of CELT records with them)
-    const int par = pipe ? ctx->slot : sset, par2 = (par + 1) % 3; // this step's slot; the slot of the step two before it
+    const int par = pipe ? ctx->slot : pipe_silk ? 3 + sset : 0, par2 = (par + 1) % 3; // this step's slot; (pipelined CELT-only steps:) the slot of the step two before it
     if (int rc = grow_step_slot(ctx, par, (size_t)n, any_celt)) return rc; // (a window's slots were sized before its first launch)
     if (ctx->split_hybrid && any_silk) {
         int rc;
@@ -1164,7 +1175,8 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         // One thing of the step before is not entropy-side: a SILK-only frame right behind a hybrid one (Q4) decodes a 2.5 ms CELT
         // frame in the step's LAST kernel (the full kernel's second pass), which writes the band energies a hybrid frame's CELT parse
         // predicts from.  So a step that may hold hybrid frames does not run ahead of a step that may have held SILK-only ones.
-        if ((modes & 2) && (ctx->last_silk_mask & 1) && ctx->sdone_recorded[sset ^ 1])
+        // (a stream that keeps its mode has no such frame: OPUSGPU_STEP_KEEPS_MODE)
+        if (!keeps_kind && (modes & 2) && (ctx->last_silk_mask & 1) && ctx->sdone_recorded[sset ^ 1])
             HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_sdone[sset ^ 1], 0));
         ctx->last_silk_mask = modes;
         front(ctx->parse_stream, 0, n, (SilkShadow *)ctx->d_shadow, (u32)ctx->shadow_epoch);
@@ -1315,7 +1327,7 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
 }
 int opusgpu_decode_step_device_modes(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm,
                                      void *d_result, void *hip_stream, int modes) {
-    if (modes <= 0 || modes > 7) return OPUSGPU_BAD_ARG;
+    if ((modes & 7) == 0 || modes > 15) return OPUSGPU_BAD_ARG;
     return decode_step_impl(ctx, n, d_descs, d_arena, d_pcm, d_result, hip_stream, true, modes);
 }
 int opusgpu_decode_steps_device(opusgpu_ctx *ctx, int n_steps, const int32_t *n, const void *const *d_descs, const void *const *d_arena,
@@ -1489,6 +1501,12 @@ int opusgpu_stream_wait_event(opusgpu_ctx *ctx, void *event, void *hip_stream) {
     if (!ctx || !event) return OPUSGPU_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamWaitEvent(hip_stream ? (hipStream_t)hip_stream : ctx->stream, (hipEvent_t)event, 0));
+    // the context's own stream: the streams pipelined steps run ahead on wait too -- what is behind the event (an upload of step
+    // tables, opusgpu_upload_fence) is then as good as resident for every kernel of the steps queued after this call
+    if ((!hip_stream || (hipStream_t)hip_stream == ctx->stream) && ctx->parse_stream) {
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, (hipEvent_t)event, 0));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->recon_stream, (hipEvent_t)event, 0));
+    }
     return OPUSGPU_OK;
 }
 int opusgpu_event_synchronize(opusgpu_ctx *ctx, void *event) {

@@ -29,9 +29,13 @@ def _pad256(x):
 
 
 class OverlappedPageDecode:
-    def __init__(self, ctx, threads=1, depth=3, page_flags=None):
+    def __init__(self, ctx, threads=1, depth=3, page_flags=None, keeps_mode=False, by_kind=False):
+        """keeps_mode: no stream ever changes its mode (OPUSGPU_STEP_KEEPS_MODE): every step then carries that promise, which lets
+        opusgpu_set_pipeline run its entropy kernels ahead; by_kind (with it): a step whose table is grouped by mode goes as three
+        declared sub-steps instead of one step of all modes."""
         self.ctx, self.threads, self.depth = ctx, max(1, threads), max(2, depth)
         self.page_flags = page_flags
+        self.keeps_mode, self.by_kind = keeps_mode, by_kind
         self.dev = [None] * self.depth   # (device address, capacity)
         self.host = [None] * self.depth  # page-locked uint8 arrays
 
@@ -97,7 +101,12 @@ class OverlappedPageDecode:
                         host, dev = self._slot(i, e.need)
                         pb = PageBatch(blob, offs, lens, sids, threads=self.threads, out_mem=host, **kw)
                     t2 = time.perf_counter()
-                    counts = [len(pb.step(k)[0]) for k in range(pb.n_steps)]
+                    counts, mc = [], []
+                    for k in range(pb.n_steps):
+                        m = pb.step(k)[0]["flags"] & 3
+                        counts.append(len(m))
+                        grouped = len(m) < 2 or not (np.diff(m.astype(np.int8)) < 0).any()
+                        mc.append((int((m == 0).sum()), int((m == 1).sum())) if grouped else (-1, -1))
                     base = dev.value if isinstance(dev, C.c_void_p) else int(dev)
                     ctx.upload_async(C.c_void_p(base), pb.image)
                     fence = ctx.event()
@@ -108,7 +117,7 @@ class OverlappedPageDecode:
                     stats["slot_wait_s"].append(t1 - t0)
                     stats["demux_s"].append(t2 - t1)
                     stats["ingest_s"].append(time.perf_counter() - t1)
-                    ready.put((b, base, counts, arena_at, fence, good))
+                    ready.put((b, base, counts, arena_at, fence, good, mc))
             except BaseException as e:  # noqa: BLE001 -- handed to the caller's thread
                 err.append(e)
                 ready.put(None)
@@ -125,13 +134,18 @@ class OverlappedPageDecode:
                     raise err[0]
                 if first_wait is None:
                     first_wait = time.perf_counter() - t_start
-                _, base, counts, arena_at, fence, good = item
+                _, base, counts, arena_at, fence, good, mc = item
                 ctx.stream_wait_event(fence)
                 fences.append(fence)
                 at = 0
-                for n in counts:
+                for k, n in enumerate(counts):
                     if n:
-                        ctx.decode_step_device(n, C.c_void_p(base + at), C.c_void_p(base + arena_at), d_pcm, d_result)
+                        if self.keeps_mode and self.by_kind and mc[k][0] >= 0:  # declared sub-steps by kind (Context.decode_step_by_kind)
+                            ctx.decode_step_by_kind(mc[k][0], mc[k][1], n - mc[k][0] - mc[k][1], C.c_void_p(base + at),
+                                                    C.c_void_p(base + arena_at), d_pcm, d_result, keeps_kind=True)
+                        else:
+                            ctx.decode_step_device(n, C.c_void_p(base + at), C.c_void_p(base + arena_at), d_pcm, d_result,
+                                                   modes=15 if self.keeps_mode else 0)  # (15: frames of any mode + the promise)
                         stats["steps"] += 1
                     at += 16 * n
                 ctx.event_record(done_ev[b])

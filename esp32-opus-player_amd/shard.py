@@ -34,11 +34,22 @@ def usable_cpus():
 
 # ---- work queue: one rank's decode steps in one buffer ------------------------------------------------------
 # [ header: int64 x WORK_HEADER_WORDS | descriptor tables of all steps, back to back | packet arena ], every part
-# starting on a 256-byte boundary.  header = magic, n_steps, total descriptors, arena bytes, then one count per step.
-WORK_MAGIC = 0x4F475751
+# starting on a 256-byte boundary.  header = magic, n_steps, total descriptors, arena bytes, then one count per step, then --
+# tables grouped by mode (OPUSGPU_PAGES_GROUP_BY_MODE: SILK-only, hybrid, CELT-only frames in that order) -- per step the number
+# of SILK-only and of hybrid frames (-1, -1: the step's table is not grouped), so that the receiving rank can issue a step as
+# declared sub-steps (Context.decode_work_step) without reading the table back.
+WORK_MAGIC = 0x4F475752
 WORK_HEADER_WORDS = 1024
 WORK_HEADER_BYTES = 8 * WORK_HEADER_WORDS
-WORK_MAX_STEPS = WORK_HEADER_WORDS - 4
+WORK_MAX_STEPS = (WORK_HEADER_WORDS - 4) // 3
+
+
+def mode_counts(table):
+    """(SILK-only, hybrid) frame counts of a step table that is grouped by mode, (-1, -1) if it is not grouped."""
+    m = table["flags"] & 3
+    if len(m) > 1 and (np.diff(m.astype(np.int8)) < 0).any():
+        return -1, -1
+    return int((m == 0).sum()), int((m == 1).sum())
 
 
 def _pad256(n):
@@ -60,6 +71,7 @@ def pack_work(batch):
     hdr = buf[:WORK_HEADER_BYTES].view(np.int64)
     hdr[0:4] = (WORK_MAGIC, n_steps, total, arena.size)
     hdr[4:4 + n_steps] = counts
+    hdr[4 + n_steps:4 + 3 * n_steps] = np.array([mode_counts(t) for t in tables], dtype=np.int64).reshape(-1)
     at = desc_at
     for t in tables:
         buf[at:at + 16 * len(t)] = t.view(np.uint8).reshape(-1)
@@ -77,6 +89,8 @@ class WorkLayout:
             raise ValueError("not a packed work buffer")
         self.n_steps, self.total, self.arena_bytes = int(hdr[1]), int(hdr[2]), int(hdr[3])
         self.counts = [int(c) for c in hdr[4:4 + self.n_steps]]
+        mc = hdr[4 + self.n_steps:4 + 3 * self.n_steps].reshape(-1, 2)
+        self.mode_counts = [(int(a), int(b)) for a, b in mc]  # per step: (SILK-only, hybrid) frames, (-1, -1) = not grouped
         self.desc_at = []
         at = WORK_HEADER_BYTES
         for c in self.counts:

@@ -187,13 +187,22 @@ int opusgpu_memcpy_d2h(opusgpu_ctx *ctx, void *dst, const void *src, size_t byte
 int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm,
                                void *d_result, void *hip_stream);
 /* The same, for a caller that knows which kinds of frame the step contains (whoever framed the packets does: the TOC byte).
- * `modes`: bit 0 SILK-only, bit 1 hybrid, bit 2 CELT-only frames MAY be present (1 .. 7).  The kernels of modes ruled out are
+ * `modes`: bit 0 SILK-only, bit 1 hybrid, bit 2 CELT-only frames MAY be present (1 .. 7; plus OPUSGPU_STEP_KEEPS_MODE).  The kernels of modes ruled out are
  * not launched -- on a step of 65,536 frames the launches that find nothing to do cost 1 - 2 % -- and a pipelined step
  * (opusgpu_set_pipeline) without SILK-only and hybrid frames also starts its reconstruction while the previous step's
  * de-emphasis still runs.  A frame of a mode that was ruled out is reported as OPUSGPU_BAD_ARG in d_result and not decoded. */
 #define OPUSGPU_HAS_SILK 1
 #define OPUSGPU_HAS_HYBRID 2
 #define OPUSGPU_HAS_CELT 4
+/* May be OR-ed into `modes` of a pipelined step (opusgpu_set_pipeline): the caller's word that NO STREAM OF THIS STEP HAS DECODED A
+ * FRAME OF ANOTHER MODE (SILK-only, hybrid, CELT-only) SINCE ITS LAST RESET -- SURVEY 8d config 5: a stream's mode is fixed.  What it
+ * buys: (1) a step with frames of every mode (modes 7) runs ahead like a declared one -- its entropy kernels next to the arithmetic
+ * kernels of the step before -- where without the flag it runs in order: a CELT-only frame changes what the SILK half of the SAME
+ * stream's next frame must see, which the library cannot rule out by itself; (2) declared steps of the two pipelined kinds
+ * (CELT-only; SILK-only / hybrid) follow each other without the drain that a stream crossing from one to the other would need.
+ * Results with a true promise are bit-identical to the in-order flow; with a false one they are undefined for the streams that
+ * broke it (never for others). */
+#define OPUSGPU_STEP_KEEPS_MODE 8
 int opusgpu_decode_step_device_modes(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm,
                                      void *d_result, void *hip_stream, int modes);
 /* A WINDOW of consecutive decode steps in one call: step j has n[j] frames and the tables d_descs[j] / d_arena[j], and writes
@@ -215,7 +224,8 @@ int opusgpu_event_synchronize(opusgpu_ctx *ctx, void *event); /* the host waits 
 /* Uploads NEXT TO the decode (config 5: the ingest of the next batch of Ogg pages under the decode of this one).  The copy runs on
  * a stream of the context's own, not on the decode stream: one host thread demuxes batch b + 1 (opusgpu_pages_demux) and queues
  * its step tables and packet bytes with opusgpu_upload_async, then records a fence; the thread that decodes lets its stream wait
- * for that fence (opusgpu_stream_wait_event; hip_stream NULL = the context's stream) before batch b + 1's first step.  `src` must
+ * for that fence (opusgpu_stream_wait_event; hip_stream NULL = the context's stream -- and with it the streams pipelined steps run
+ * ahead on, so that tables behind the fence count as complete in device memory for opusgpu_set_pipeline) before batch b + 1's first step.  `src` must
  * stay valid until the fence has passed (opusgpu_event_synchronize).  These four calls may come from a second host thread. */
 int opusgpu_upload_async(opusgpu_ctx *ctx, void *dst, const void *src, size_t bytes);
 int opusgpu_upload_fence(opusgpu_ctx *ctx, void *event);

@@ -20,9 +20,12 @@ def _shard():
     return m
 
 
-def _run(pkg, oracle, ctx, n, pages_per_stream, packets_per_page, threads, pipeline=False):
+def _run(pkg, oracle, ctx, n, pages_per_stream, packets_per_page, threads, pipeline=False, by_kind=False, keeps=False):
     """pipeline: all steps queued back to back with opusgpu_set_pipeline on (each step's PCM and results in buffers of their
-    own), compared after one synchronisation -- the CELT-only third of every step parses ahead of the step before."""
+    own), compared after one synchronisation -- the CELT-only third of every step parses ahead of the step before.
+    keeps: every step carries OPUSGPU_STEP_KEEPS_MODE (a stream's mode is fixed here) -- a step of all three modes runs ahead like a
+    declared one; by_kind: with the promise, every step as three declared sub-steps: the sub-steps of both pipelined kinds run
+    ahead of each other, nothing drains between them."""
     shard = _shard()
     modes = ((pkg.TOC_SILK_NB_STEREO, 40), (pkg.TOC_HYBRID_FB_STEREO, 120), (pkg.TOC_CELT_FB_STEREO, 160))
     frames = pages_per_stream * packets_per_page
@@ -59,8 +62,10 @@ def _run(pkg, oracle, ctx, n, pages_per_stream, packets_per_page, threads, pipel
         ctx.h2d(d_work, work)
         if pipeline:
             ctx.set_pipeline(True)
+            if by_kind:
+                assert all(mc == (len(ids_of[0]), len(ids_of[1])) for mc in lay.mode_counts)
             for k in range(frames):
-                ctx.decode_work_step(d_work, lay, k, d_pcms[k], d_ress[k])
+                ctx.decode_work_step(d_work, lay, k, d_pcms[k], d_ress[k], by_kind=by_kind, keeps_kind=by_kind or keeps)
             ctx.synchronize()
         for k in range(frames):
             d_pcm, d_res = d_pcms[k % nbuf], d_ress[k % nbuf]
@@ -91,10 +96,23 @@ def _run(pkg, oracle, ctx, n, pages_per_stream, packets_per_page, threads, pipel
 def test_mixed_mode_pages_small(pkg, oracle, gpu_ctx):
     _run(pkg, oracle, gpu_ctx, 3 * 1024, 2, 5, threads=2)
     _run(pkg, oracle, gpu_ctx, 3 * 1024, 2, 5, threads=2, pipeline=True)
+    _run(pkg, oracle, gpu_ctx, 3 * 1024 + 1, 2, 5, threads=2, pipeline=True, by_kind=True)
+    _run(pkg, oracle, gpu_ctx, 3 * 1024 + 2, 2, 5, threads=2, pipeline=True, keeps=True)
 
 
 def test_mixed_mode_pages_c5_share_pipelined(pkg, oracle, gpu_ctx):
-    """The same share with pipelined steps, all ten queued back to back (what bench.py's mixed_pages_2m workload times)."""
+    """The same share with pipelined steps, all ten queued back to back, every step with the promise that its streams keep their
+    mode (what bench.py's mixed_pages_2m workload times)."""
+    _run(pkg, oracle, gpu_ctx, 262144, 1, 10, threads=16, pipeline=True, keeps=True)
+
+
+def test_mixed_mode_pages_c5_share_pipelined_substeps(pkg, oracle, gpu_ctx):
+    """... every step as three declared sub-steps by kind."""
+    _run(pkg, oracle, gpu_ctx, 262144, 1, 10, threads=16, pipeline=True, by_kind=True)
+
+
+def test_mixed_mode_pages_c5_share_pipelined_undeclared(pkg, oracle, gpu_ctx):
+    """... and as undeclared steps (in order, in two halves; only their CELT-only third would run ahead if it were declared)."""
     _run(pkg, oracle, gpu_ctx, 262144, 1, 10, threads=16, pipeline=True)
 
 
@@ -310,8 +328,9 @@ def _ingest_mod(pkg):
     return m
 
 
-@pytest.mark.parametrize("n,depth", [(3 * 2048, 2), (3 * 700, 3)])
-def test_overlapped_ingest_matches_the_oracle(pkg, oracle, gpu_ctx, n, depth):
+@pytest.mark.parametrize("n,depth,keeps_kind,by_kind", [(3 * 2048, 2, False, False), (3 * 700, 3, False, False), (3 * 2048 + 2, 3, True, False),
+                                                        (3 * 2048 + 1, 2, True, True)])
+def test_overlapped_ingest_matches_the_oracle(pkg, oracle, gpu_ctx, n, depth, keeps_kind, by_kind):
     """esp32-opus-player_amd/ingest.py: five batches of one page per stream, demuxed and uploaded by a second host thread on the copy
     stream while the batch before decodes (ring of `depth` device slots, so slots are reused); after every batch the PCM of its
     last step -- which depends on every step before it -- is compared with the oracle, every stream, every sample."""
@@ -335,7 +354,9 @@ def test_overlapped_ingest_matches_the_oracle(pkg, oracle, gpu_ctx, n, depth):
         batches.append((blob, offs, lens, np.concatenate([i for _, i in per_batch[q]])))
     ctx.streams_alloc(n, 2)
     d_pcm, d_res = ctx.dev_alloc(n * 960 * 2 * 2), ctx.dev_alloc(4 * n)
-    pipe = _ingest_mod(pkg).OverlappedPageDecode(ctx, threads=3, depth=depth)
+    # keeps_kind: pipelined steps that carry OPUSGPU_STEP_KEEPS_MODE (a stream's mode is fixed here); by_kind: as declared sub-steps
+    ctx.set_pipeline(keeps_kind)
+    pipe = _ingest_mod(pkg).OverlappedPageDecode(ctx, threads=3, depth=depth, keeps_mode=keeps_kind, by_kind=by_kind)
     seen = []
 
     def check(b):  # (called on the decoding thread between batches: reading back waits for the batch's steps)
@@ -355,6 +376,7 @@ def test_overlapped_ingest_matches_the_oracle(pkg, oracle, gpu_ctx, n, depth):
         st = pipe.run(batches, d_pcm, d_res, on_batch_done=check)
     finally:
         pipe.close()
+        ctx.set_pipeline(False)
         ctx.dev_free(d_pcm)
         ctx.dev_free(d_res)
     assert seen == list(range(nb)) and st["steps"] == frames and st["pages"] == nb * n
