@@ -50,6 +50,7 @@ struct SilkLds {
             i16 raw_tail[2 * SILK_MAX_FRAME];       // (the rest of sLTP_Q15: the up-sampler's 32-bit rows end here, see silk_up2_rows)
             i16 up[2][8 + 2 * SILK_MAX_FRAME + 8];  // FIR history + 2x up-sampled frame
             i32 sink[4][2][4];                      // where the up-sampler's inner sections "store" (silk_up2_rows)
+            u32 taps[48];                           // rom_silk_fir12_taps8 (a lane's phase is its own: a table read per output)
         } out;
     } u;
     SilkCtrl ctrl[2];
@@ -1561,6 +1562,7 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
 #else
         silk_up2_rows(s, channels, frame_length);
 #endif
+        OG_FOR_LANES(i, 48) L.u.out.taps[i] = rom_silk_fir12_taps8[i];
         OG_SYNC();
         OG_MARK(37);
         int out_total = 0;
@@ -1593,7 +1595,7 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
                     typedef u32 u32x4u __attribute__((ext_vector_type(4), aligned(2)));
                     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
                     const u32x4u x = *reinterpret_cast<const u32x4u *>(b);
-                    const u32x4 f = *reinterpret_cast<const u32x4 *>(&rom_silk_fir12_taps8[4 * t]);
+                    const u32x4 f = *reinterpret_cast<const u32x4 *>(&L.u.out.taps[4 * t]); // (from LDS: the ROM's latency was the loop's)
                     i32 res;
                     asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(res) : "v"(x[0]), "v"(f[0]));
                     asm("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(res) : "v"(x[1]), "v"(f[1]));

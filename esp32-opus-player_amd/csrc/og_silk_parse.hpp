@@ -229,6 +229,7 @@ OG_DEV void silk_parse_pulses(RcLane &rc, i16 *pulses, int signalType, int quant
     if (iter * 16 < frame_length) iter++;
     const int RateLevelIndex = rc_icdf_tab(rc, SILK_BLOB_rate_levels_icdf + 9 * (signalType >> 1), 9);
     const int cdf = SILK_BLOB_pulses_per_block_icdf + 18 * RateLevelIndex;
+    OG_MARK(46);
     for (int i = 0; i < iter; i++) {
         int nl = 0, sp = rc_icdf_tab(rc, cdf, 18);
         while (sp == 17) {
@@ -237,6 +238,7 @@ OG_DEV void silk_parse_pulses(RcLane &rc, i16 *pulses, int signalType, int quant
         }
         g_silk_blk[i][OG_LANE] = (u16)(sp | nl << 5);
     }
+    OG_MARK(47);
     for (int i = 0; i < iter; i++) {
         i16 *p0 = &pulses[i * 16];
         const int sp = g_silk_blk[i][OG_LANE] & 31;
@@ -261,6 +263,7 @@ OG_DEV void silk_parse_pulses(RcLane &rc, i16 *pulses, int signalType, int quant
             for (int j = 0; j < 16; j++) p0[j] = 0;
         }
     }
+    OG_MARK(48);
     for (int i = 0; i < iter; i++) {
         const int nLS = g_silk_blk[i][OG_LANE] >> 5;
         if (nLS > 0) {
@@ -275,6 +278,7 @@ OG_DEV void silk_parse_pulses(RcLane &rc, i16 *pulses, int signalType, int quant
             }
         }
     }
+    OG_MARK(49);
     const int icdf_ptr = SILK_BLOB_sign_icdf + 7 * (quantOffsetType + (signalType << 1));
     const int length = (frame_length + 8) >> 4;
     for (int i = 0; i < length; i++) {
@@ -364,6 +368,7 @@ OG_DEV void silk_parse_lane(const SilkPast &past, const u8 *payload, int len, in
     i32 MS_pred_Q13[2] = {0, 0};
     int decode_only_middle = 0;
     // regular decoding reads past the LBRR frames (silk.cpp:1590-1616); their content is discarded
+    OG_MARK(45);
     if (lbrr0) {
         if (channels == 2) {
             silk_parse_stereo_pred(rc, MS_pred_Q13);
@@ -371,11 +376,13 @@ OG_DEV void silk_parse_lane(const SilkPast &past, const u8 *payload, int len, in
         }
         silk_parse_indices(rc, &rec->ch[0], fs_kHz, vad0, 1, 0, ecType0, ecLag0);
         silk_parse_pulses(rc, rec->ch[0].pulses, rec->ch[0].signalType, rec->ch[0].quantOffsetType, frame_length);
+        OG_MARK(45);
     }
     if (channels == 2 && lbrr1) {
         silk_parse_indices(rc, &rec->ch[1], fs_kHz, vad1, 1, 0, ecType1, ecLag1);
         silk_parse_pulses(rc, rec->ch[1].pulses, rec->ch[1].signalType, rec->ch[1].quantOffsetType, frame_length);
     }
+    OG_MARK(50);
     if (channels == 2) {
         silk_parse_stereo_pred(rc, MS_pred_Q13);
         decode_only_middle = vad1 == 0 ? rc_icdf_tab(rc, SILK_BLOB_mid_only_icdf, 2) : 0;

@@ -23,7 +23,9 @@ NAMES = {0: "outside", 1: "stage record", 2: "leaf pass", 3: "band prologue", 4:
          63: "silk core: LPC recurrence + output scaling",
          40: "parse: stereo theta + band words", 41: "parse: tree descend (split theta)", 42: "parse: leaf bits2pulses", 43: "parse: leaf index (rc_uint)",
          44: "parse: tree ascend",
-         50: "silk parse: init + flags + LBRR + stereo", 51: "silk parse: indices", 52: "silk parse: pulses", 53: "silk parse: parameters",
+         45: "silk parse: LBRR skip-decode (indices; its pulses under 46-49)", 46: "silk parse: pulses per block", 47: "silk parse: shell tree",
+         48: "silk parse: LSBs", 49: "silk parse: signs",
+         50: "silk parse: init + flags + stereo", 51: "silk parse: indices", 52: "silk parse: rate level", 53: "silk parse: parameters",
          54: "silk parse: epilogue",
          30: "silk: flags + stereo pred + indices", 31: "silk: pulses", 32: "silk: parameters (NLSF->LPC, gains)", 33: "silk: bookkeeping",
          34: "silk: stage + core (LTP/LPC)", 35: "silk: outBuf + MS->LR", 36: "silk: up2 (serial)", 37: "silk: FIR to 48k", 38: "silk: epilogue"}
