@@ -159,7 +159,7 @@ def prepare_pages_work(pkg, shard, ranks, ctx, n, frames, ingest="rank0", page_c
                 buffers.append(shard.pack_pages(blob, lens, sids))
                 continue
             t0 = time.perf_counter()
-            batch = pkg.PageBatch(blob, offs, lens, sids, threads=threads)
+            batch = pkg.PageBatch(blob, offs, lens, sids, threads=threads, flags=pkg.PAGES_VERIFY_CRC | PAGE_ORDER)
             t_demux += time.perf_counter() - t0
             if not (batch.info["status"] > 0).all():
                 raise SystemExit("page demux rejected synthetic pages")
@@ -192,13 +192,13 @@ def prepare_pages_work(pkg, shard, ranks, ctx, n, frames, ingest="rank0", page_c
             # one page first: the checksum tables and the kernel's code are set up once per context, not per batch
             pkg.PageBatch.with_gpu_crc(ctx, d_blob, blob, offs[:1], lens[:1], sids[:1]).close()
             t0 = time.perf_counter()
-            batch = pkg.PageBatch.with_gpu_crc(ctx, d_blob, blob, offs, lens, sids, threads=threads)
+            batch = pkg.PageBatch.with_gpu_crc(ctx, d_blob, blob, offs, lens, sids, threads=threads, flags=PAGE_ORDER)
             t_local = time.perf_counter() - t0
             if d_raw is not None:
                 ctx.dev_free(d_raw)
         else:
             t0 = time.perf_counter()
-            batch = pkg.PageBatch(blob, offs, lens, sids, threads=threads)
+            batch = pkg.PageBatch(blob, offs, lens, sids, threads=threads, flags=pkg.PAGES_VERIFY_CRC | PAGE_ORDER)
             t_local = time.perf_counter() - t0
         if not (batch.info["status"] > 0).all():
             raise SystemExit("page demux rejected synthetic pages")
@@ -222,6 +222,9 @@ def prepare_pages_work(pkg, shard, ranks, ctx, n, frames, ingest="rank0", page_c
     return base, lay, stats, keep
 
 
+# mixed_pages_2m: how the demux orders a step's table -- grouped by mode, and (BENCH_ORDER_BY_HEADER=0: not) inside the SILK-only and
+# hybrid groups by the frames' LBRR flags (OPUSGPU_PAGES_ORDER_BY_HEADER)
+PAGE_ORDER = 2 | (4 if os.environ.get("BENCH_ORDER_BY_HEADER", "1") != "0" else 0)
 MIXED_FLOW = os.environ.get("BENCH_MIXED_FLOW", "keeps")  # mixed_pages_2m: keeps | substeps | inorder (see run_workload)
 RAW_PAGES = {}  # this rank's share of the raw pages, as prepare_pages_work (per-rank ingest) received it
 
@@ -249,7 +252,7 @@ def overlapped_end_to_end(pkg, ranks, ctx, n, d_pcm, d_res, threads):
     ctx.streams_reset(0, n)
     ctx.synchronize()
     pipe = mod.OverlappedPageDecode(ctx, threads=int(os.environ.get("BENCH_E2E_THREADS", threads)), depth=int(os.environ.get("BENCH_E2E_DEPTH", "3")),
-                                    keeps_mode=MIXED_FLOW != "inorder", by_kind=MIXED_FLOW == "substeps")  # (a stream's mode is fixed in this workload)
+                                    keeps_mode=MIXED_FLOW != "inorder", by_kind=MIXED_FLOW == "substeps", page_flags=1 | PAGE_ORDER)  # (a stream's mode is fixed in this workload)
     pipe.reserve(int(max(int(b[2].sum()) + 32 * len(b[2]) for b in batches)) + 4096)  # a service sets its slots up once, not per job
     ranks.barrier()
     st = pipe.run(batches, d_pcm, d_res)
@@ -397,8 +400,14 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
         # [rank*n, (rank+1)*n) of the global id space (seeds differ per global stream id)
         pay = pkg.lcg_payloads(n, K + W, L, seed_base=ranks.seed_base())
         d_arena, d_desc = [], []
+        # SILK-only / hybrid workloads: every step's table in the order of the frames' LBRR flags (the top bits of their first byte),
+        # so that the 32 frames of a parse wave agree on how many extra frames of side information they read past -- framing work,
+        # like grouping a page step's table by mode; BENCH_ORDER_BY_HEADER=0: stream order
+        by_header = os.environ.get("BENCH_ORDER_BY_HEADER", "1") != "0" and not (toc & 0x80)
+        last_slot_stream = None
         for f in range(K + W):
-            arena, descs = pkg.build_step(toc, pay[f])
+            arena, descs = pkg.build_step(toc, pay[f], order_by_header=by_header)
+            last_slot_stream = descs["stream"].astype(np.int64) if by_header else None
             a = ctx.dev_alloc(arena.nbytes + 16)
             d = ctx.dev_alloc(descs.nbytes)
             ctx.h2d(a, arena)
@@ -466,7 +475,7 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
                    "rank0": e2e_stats}
             del timed_pcm, e2e_pcm
     else:
-        parity = check_against_oracle(pkg, ctx, name, n, K + W, d_pcm, pay=pay)
+        parity = check_against_oracle(pkg, ctx, name, n, K + W, d_pcm, pay=pay, slot_stream=last_slot_stream)
 
     value, dt, total_frames = shard.aggregate_throughput(ranks, n * K, dt)
     for p in frees:
@@ -481,6 +490,7 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
         "config": ({"workload": f"{name}: {n} streams/GPU, one Ogg page of {PACKETS_PER_PAGE} packets per stream and "
                                 f"10 steps, modes SILK-NB : hybrid FB : CELT FB = 1:1:1 across streams (TOC 0x0C / 0x7C / "
                                 f"0xFC, 40 / 120 / 160-byte LCG payloads), 48 kHz stereo, step tables grouped by mode" +
+                                (" and, within the SILK-only and hybrid groups, ordered by the frames' LBRR flags" if PAGE_ORDER & 4 else "") +
                                 ("; steps carry OPUSGPU_STEP_KEEPS_MODE (a stream's mode is fixed) and are pipelined: the entropy "
                                  "kernels of step k + 1 next to the arithmetic kernels of step k" +
                                  (", three declared sub-steps per step" if MIXED_FLOW == "substeps" else "")
@@ -492,7 +502,10 @@ def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):
                                  ) + "(torch.distributed scatter = RCCL), before the timed region; no collective inside it"}
                    if mixed else
                    {"workload": f"{name}: {n} streams/GPU x 20 ms frames, 48 kHz stereo, "
-                                f"TOC 0x{toc:02X}, {L}-byte LCG payloads, state persistent across steps",
+                                f"TOC 0x{toc:02X}, {L}-byte LCG payloads, state persistent across steps" +
+                                ("; step tables ordered by the frames' LBRR flags (top bits of the first payload byte)" if by_header else "") +
+                                (f"; a window of {K} steps queued by one call, declared {'CELT-only' if toc & 0x80 else 'mode'} mask"
+                                 if windowed else ""),
                     "streams_per_gpu": n, "sharding": "streams partitioned across ranks, no data-path collective"}),
         "x_realtime_per_gpu": value / world / 50.0,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -77,7 +77,7 @@ DESC_DTYPE = np.dtype([("stream", "<i4"), ("offset", "<i4"), ("len", "<i4"), ("f
 PAGE_INFO_DTYPE = np.dtype([("status", "<i4"), ("packets", "<i4"), ("first_step", "<i4"), ("header_type", "<i4"),
                             ("serial", "<u4"), ("seqno", "<u4"), ("granulepos", "<i8")])
 PAGE_BAD_CAPTURE, PAGE_BAD_CRC, PAGE_SPANS, PAGE_BAD_PACKET, PAGE_BAD_STREAM = -200, -201, -202, -203, -204
-PAGES_VERIFY_CRC, PAGES_GROUP_BY_MODE = 1, 2
+PAGES_VERIFY_CRC, PAGES_GROUP_BY_MODE, PAGES_ORDER_BY_HEADER = 1, 2, 4
 
 _lib = None
 
@@ -553,9 +553,25 @@ def build_pages(toc, payloads, serials, seqno=2, granule_step=960):
     return pages
 
 
-def build_step(toc, payloads):
+def silk_header_key(first_payload_bytes, stereo):
+    """What a SILK-only / hybrid frame's header will make its decoder do, read off the frame's first byte: the VAD and LBRR flags
+    are the range coder's first symbols, each of probability 1/2 -- exactly the byte's top bits (reference src/silk.cpp:1568-1573:
+    VAD flag and LBRR flag of the mid channel, then of the side channel).  -> 2-bit key: bit 0 the mid channel carries an LBRR
+    frame, bit 1 the side channel does (each is a whole extra frame of side information and pulses that the decoder must read
+    past, src/silk.cpp:1590-1616).  Frames handed to the lane-per-frame parse kernel in key order make its waves uniform: a wave
+    whose 32 frames have no LBRR data skips those passes instead of idling through them."""
+    b = np.asarray(first_payload_bytes, dtype=np.uint8)
+    key = (b >> 6) & 1
+    if stereo:
+        key = key | (((b >> 4) & 1) << 1)
+    return key.astype(np.uint8)
+
+
+def build_step(toc, payloads, order_by_header=False):
     """Arena + descriptors for one decode step: payloads uint8 [n_streams, L], one code-0 packet each.
-    The arena holds TOC + payload per stream; descriptors point past the TOC byte."""
+    The arena holds TOC + payload per stream; descriptors point past the TOC byte.
+    order_by_header: the table in the order of silk_header_key (stable; SILK-only / hybrid TOCs only) -- slot j of the step's
+    PCM and results then belongs to stream descs["stream"][j]."""
     n, L = payloads.shape
     arena = np.empty((n, L + 1), dtype=np.uint8)
     arena[:, 0] = toc
@@ -573,4 +589,6 @@ def build_step(toc, payloads):
     descs["offset"] = np.arange(n, dtype=np.int32) * (L + 1) + 1
     descs["len"] = L
     descs["flags"] = flags
+    if order_by_header and mode != 2 and L > 0:
+        descs = descs[np.argsort(silk_header_key(payloads[:, 0], bool(toc & 4)), kind="stable")]
     return arena.reshape(-1), descs

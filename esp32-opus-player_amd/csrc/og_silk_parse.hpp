@@ -106,8 +106,16 @@ OG_DEV int rc_icdf_tab(RcLane &rc, int off, int n) {
 }
 
 // silk_decode_indices silk.cpp:708 (20 ms: nb_subfr == 4).  Indices go straight to the record.
+// STORE = false: the frame is read past, not decoded -- an LBRR frame in regular decoding (silk.cpp:1590-1616) -- the same symbols
+// leave the coder, nothing is kept but what later symbols depend on; `sig` returns signalType | quantOffsetType << 2.
+template <bool STORE = true>
 OG_DEV void silk_parse_indices(RcLane &rc, SilkRecCh *o, int fs_kHz, int vad, int decode_LBRR, int condCoding, i32 &ec_prevSignalType,
-                               i32 &ec_prevLagIndex) {
+                               i32 &ec_prevLagIndex, int *sig = nullptr) {
+#define OG_KEEP(field, value)                    \
+    do {                                         \
+        const int keep_ = (value);               \
+        if constexpr (STORE) o->field = keep_;   \
+    } while (0)
     const int wb = fs_kHz == 16, order = wb ? 16 : 10;
     const int CB1_iCDF = wb ? SILK_BLOB_wb_cb1_icdf : SILK_BLOB_nb_cb1_icdf, ec_sel = wb ? SILK_BLOB_wb_cb2_select : SILK_BLOB_nb_cb2_select;
     const int ec_iCDF = wb ? SILK_BLOB_wb_cb2_icdf : SILK_BLOB_nb_cb2_icdf;
@@ -117,18 +125,19 @@ OG_DEV void silk_parse_indices(RcLane &rc, SilkRecCh *o, int fs_kHz, int vad, in
     else
         Ix = rc_icdf_tab(rc, SILK_BLOB_type_novad_icdf, 2);
     const int signalType = Ix >> 1;
-    o->signalType = signalType;
-    o->quantOffsetType = Ix & 1;
+    OG_KEEP(signalType, signalType);
+    OG_KEEP(quantOffsetType, Ix & 1);
+    if (sig) *sig = signalType | (Ix & 1) << 2;
     if (condCoding == 2)
-        o->GainsIndices[0] = rc_icdf_tab(rc, SILK_BLOB_delta_gain_icdf, 41);
+        OG_KEEP(GainsIndices[0], rc_icdf_tab(rc, SILK_BLOB_delta_gain_icdf, 41));
     else {
         int g = rc_icdf_tab(rc, SILK_BLOB_gain_icdf + 8 * signalType, 8) << 3;
         g += rc_icdf_tab(rc, SILK_BLOB_uniform8_icdf, 8);
-        o->GainsIndices[0] = g;
+        OG_KEEP(GainsIndices[0], g);
     }
-    for (int i = 1; i < 4; i++) o->GainsIndices[i] = rc_icdf_tab(rc, SILK_BLOB_delta_gain_icdf, 41);
+    for (int i = 1; i < 4; i++) OG_KEEP(GainsIndices[i], rc_icdf_tab(rc, SILK_BLOB_delta_gain_icdf, 41));
     const int cb1 = rc_icdf_tab(rc, CB1_iCDF + (signalType >> 1) * 32, 32);
-    o->NLSFIndices[0] = cb1;
+    OG_KEEP(NLSFIndices[0], cb1);
     for (int i = 0; i < order; i++) { // silk_NLSF_unpack silk.cpp:2762: the entropy table of coefficient i
         const int entry = g_silk_tab[ec_sel + cb1 * order / 2 + (i >> 1)];
         const int ec_ix = ((entry >> (1 + 4 * (i & 1))) & 7) * 9;
@@ -137,9 +146,9 @@ OG_DEV void silk_parse_indices(RcLane &rc, SilkRecCh *o, int fs_kHz, int vad, in
             Ix -= rc_icdf_tab(rc, SILK_BLOB_nlsf_ext_icdf, 7);
         else if (Ix == 8)
             Ix += rc_icdf_tab(rc, SILK_BLOB_nlsf_ext_icdf, 7);
-        o->NLSFIndices[i + 1] = Ix - 4;
+        OG_KEEP(NLSFIndices[i + 1], Ix - 4);
     }
-    o->NLSFInterpCoef_Q2 = rc_icdf_tab(rc, SILK_BLOB_nlsf_interp_icdf, 5);
+    OG_KEEP(NLSFInterpCoef_Q2, rc_icdf_tab(rc, SILK_BLOB_nlsf_interp_icdf, 5));
     if (signalType == 2) {
         int decode_abs = 1, lagIndex = 0;
         const int lowbits = fs_kHz == 16 ? SILK_BLOB_uniform8_icdf : (fs_kHz == 12 ? SILK_BLOB_uniform6_icdf : SILK_BLOB_uniform4_icdf);
@@ -158,17 +167,18 @@ OG_DEV void silk_parse_indices(RcLane &rc, SilkRecCh *o, int fs_kHz, int vad, in
             lagIndex = tr16(rc_icdf_tab(rc, SILK_BLOB_pitch_lag_icdf, 32) * (fs_kHz >> 1));
             lagIndex = tr16(lagIndex + rc_icdf_tab(rc, lowbits, lowbits_n));
         }
-        o->lagIndex = lagIndex;
+        OG_KEEP(lagIndex, lagIndex);
         ec_prevLagIndex = lagIndex;
-        o->contourIndex = rc_icdf_tab(rc, contour, contour_n);
+        OG_KEEP(contourIndex, rc_icdf_tab(rc, contour, contour_n));
         const int per = rc_icdf_tab(rc, SILK_BLOB_ltp_per_icdf, 3);
-        o->PERIndex = per;
+        OG_KEEP(PERIndex, per);
         const int t = per == 0 ? SILK_BLOB_ltp_gain_icdf0 : (per == 1 ? SILK_BLOB_ltp_gain_icdf1 : SILK_BLOB_ltp_gain_icdf2);
-        for (int j = 0; j < 4; j++) o->LTPIndex[j] = rc_icdf_tab(rc, t, 8 << per);
-        o->LTP_scaleIndex = condCoding == 0 ? rc_icdf_tab(rc, SILK_BLOB_ltpscale_icdf, 3) : 0;
+        for (int j = 0; j < 4; j++) OG_KEEP(LTPIndex[j], rc_icdf_tab(rc, t, 8 << per));
+        OG_KEEP(LTP_scaleIndex, condCoding == 0 ? rc_icdf_tab(rc, SILK_BLOB_ltpscale_icdf, 3) : 0);
     }
     ec_prevSignalType = signalType;
-    o->Seed = rc_icdf_tab(rc, SILK_BLOB_uniform4_icdf, 4);
+    OG_KEEP(Seed, rc_icdf_tab(rc, SILK_BLOB_uniform4_icdf, 4));
+#undef OG_KEEP
 }
 
 OG_DEV void shell_split_tab(RcLane &rc, int &c1, int &c2, int p, int table) {
@@ -209,6 +219,7 @@ struct SilkParLds {
     union {
         i32 cosLSF[SILK_REC_LPC][OG_SP_LANES];
         i32 a32[SILK_REC_LPC][OG_SP_LANES];
+        u16 nzmask[SILK_REC_FRAME / 16][OG_SP_LANES]; // silk_skip_pulses: which of a block's 16 coefficients are not zero (dead before any parameter is dequantised)
     };
     union {
         struct {
@@ -311,6 +322,80 @@ OG_DEV void silk_parse_pulses(RcLane &rc, i16 *pulses, int signalType, int quant
     }
 }
 
+// The same symbols without the pulses: an LBRR frame that regular decoding only reads past (silk.cpp:1590-1616).  What the later
+// symbols depend on is kept and nothing else -- per block the pulse count and LSB depth (as above) and WHICH coefficients are not
+// zero (16 bits, in LDS): the LSB pass can only turn zeros into non-zeros, and the sign pass reads one symbol per non-zero
+// coefficient, all from the block's one table -- as many symbols as the mask has bits, not sixteen masked attempts.  Nothing goes to
+// HBM and nothing comes back.
+OG_DEV void silk_skip_pulses(RcLane &rc, int signalType, int quantOffsetType, int frame_length) {
+    int iter = frame_length >> 4;
+    if (iter * 16 < frame_length) iter++;
+    const int RateLevelIndex = rc_icdf_tab(rc, SILK_BLOB_rate_levels_icdf + 9 * (signalType >> 1), 9);
+    const int cdf = SILK_BLOB_pulses_per_block_icdf + 18 * RateLevelIndex;
+    OG_MARK(46);
+    for (int i = 0; i < iter; i++) {
+        int nl = 0, sp = rc_icdf_tab(rc, cdf, 18);
+        while (sp == 17) {
+            nl++;
+            sp = rc_icdf_tab(rc, SILK_BLOB_pulses_per_block_icdf + 18 * 9 + (nl == 10), 18 - (nl == 10));
+        }
+        g_silk_blk[i][OG_LANE] = (u16)(sp | nl << 5);
+    }
+    OG_MARK(47);
+    for (int i = 0; i < iter; i++) {
+        const int sp = g_silk_blk[i][OG_LANE] & 31;
+        u32 nz = 0;
+        if (sp > 0) {
+            int p3[2], p2[4], p1[8], a, b;
+            shell_split_tab(rc, p3[0], p3[1], sp, SILK_BLOB_shell3);
+            for (int h = 0; h < 2; h++) {
+                shell_split_tab(rc, p2[2 * h], p2[2 * h + 1], p3[h], SILK_BLOB_shell2);
+                for (int q = 0; q < 2; q++) {
+                    const int qi = 2 * h + q;
+                    shell_split_tab(rc, p1[2 * qi], p1[2 * qi + 1], p2[qi], SILK_BLOB_shell1);
+                    for (int e = 0; e < 2; e++) {
+                        const int ei = 2 * qi + e;
+                        shell_split_tab(rc, a, b, p1[ei], SILK_BLOB_shell0);
+                        nz |= (u32)(a > 0) << (2 * ei) | (u32)(b > 0) << (2 * ei + 1);
+                    }
+                }
+            }
+        }
+        g_silk_par.nzmask[i][OG_LANE] = (u16)nz;
+    }
+    OG_MARK(48);
+    for (int i = 0; i < iter; i++) {
+        const int nLS = g_silk_blk[i][OG_LANE] >> 5;
+        if (nLS > 0) {
+            u32 nz = g_silk_par.nzmask[i][OG_LANE];
+            for (int j = 0; j < 16; j++)
+                for (int b = 0; b < nLS; b++) nz |= (u32)rc_icdf_tab(rc, SILK_BLOB_lsb_icdf, 2) << j;
+            g_silk_par.nzmask[i][OG_LANE] = (u16)nz;
+        }
+    }
+    OG_MARK(49);
+    const int icdf_ptr = SILK_BLOB_sign_icdf + 7 * (quantOffsetType + (signalType << 1));
+    const int length = (frame_length + 8) >> 4;
+    for (int i = 0; i < length; i++) {
+        const int blk = g_silk_blk[i][OG_LANE];
+        if (blk > 0) {
+            const u32 ic0 = g_silk_tab[icdf_ptr + OG_MIN(blk & 0x1F, 6)];
+            for (int cnt = __builtin_popcount((u32)g_silk_par.nzmask[i][OG_LANE]); cnt > 0; cnt--) {
+                // two-symbol iCDF {ic0, 0}, ftb 8: the sign itself is not needed
+                u32 s = rc.rng, d = rc.val, r = s >> 8, t = s;
+                s = r * ic0;
+                if (d < s) {
+                    t = s;
+                    s = 0;
+                }
+                rc.val = d - s;
+                rc.rng = t - s;
+                rc_renorm(rc);
+            }
+        }
+    }
+}
+
 OG_DEV void silk_parse_stereo_pred(RcLane &rc, i32 pred_Q13[2]) { // silk_stereo_decode_pred silk.cpp:592
     int n = rc_icdf_tab(rc, SILK_BLOB_stereo_joint_icdf, 25);
     const int ix02 = n / 5, ix12 = n - 5 * ix02;
@@ -374,13 +459,15 @@ OG_DEV void silk_parse_lane(const SilkPast &past, const u8 *payload, int len, in
             silk_parse_stereo_pred(rc, MS_pred_Q13);
             if (lbrr1 == 0) decode_only_middle = rc_icdf_tab(rc, SILK_BLOB_mid_only_icdf, 2);
         }
-        silk_parse_indices(rc, &rec->ch[0], fs_kHz, vad0, 1, 0, ecType0, ecLag0);
-        silk_parse_pulses(rc, rec->ch[0].pulses, rec->ch[0].signalType, rec->ch[0].quantOffsetType, frame_length);
+        int sig;
+        silk_parse_indices<false>(rc, nullptr, fs_kHz, vad0, 1, 0, ecType0, ecLag0, &sig);
+        silk_skip_pulses(rc, sig & 3, sig >> 2, frame_length);
         OG_MARK(45);
     }
     if (channels == 2 && lbrr1) {
-        silk_parse_indices(rc, &rec->ch[1], fs_kHz, vad1, 1, 0, ecType1, ecLag1);
-        silk_parse_pulses(rc, rec->ch[1].pulses, rec->ch[1].signalType, rec->ch[1].quantOffsetType, frame_length);
+        int sig;
+        silk_parse_indices<false>(rc, nullptr, fs_kHz, vad1, 1, 0, ecType1, ecLag1, &sig);
+        silk_skip_pulses(rc, sig & 3, sig >> 2, frame_length);
     }
     OG_MARK(50);
     if (channels == 2) {

@@ -297,6 +297,9 @@ int opusgpu_debug_stage_taps(opusgpu_ctx *ctx, int slot, opusgpu_stage_taps *out
 
 #define OPUSGPU_PAGES_VERIFY_CRC 1
 #define OPUSGPU_PAGES_GROUP_BY_MODE 2 /* order each step's table SILK-only, hybrid, CELT-only (stable): uniform waves */
+#define OPUSGPU_PAGES_ORDER_BY_HEADER 4 /* (implies the grouping) within the SILK-only and the hybrid group: by the frames' LBRR flags -- bits 6 and
+                                          4 of a frame's first byte (src/silk.cpp:1568-1573) -- stable otherwise: the 32 frames of a parse wave
+                                          then agree on how many frames of forward-error-correction data they read past (:1590-1616) */
 
 typedef struct opusgpu_page_info { /* 32 bytes */
     int32_t status;      /* >= 0: 20 ms frames the page contributes; < 0: OPUSGPU_PAGE_* */

@@ -356,7 +356,8 @@ def test_overlapped_ingest_matches_the_oracle(pkg, oracle, gpu_ctx, n, depth, ke
     d_pcm, d_res = ctx.dev_alloc(n * 960 * 2 * 2), ctx.dev_alloc(4 * n)
     # keeps_kind: pipelined steps that carry OPUSGPU_STEP_KEEPS_MODE (a stream's mode is fixed here); by_kind: as declared sub-steps
     ctx.set_pipeline(keeps_kind)
-    pipe = _ingest_mod(pkg).OverlappedPageDecode(ctx, threads=3, depth=depth, keeps_mode=keeps_kind, by_kind=by_kind)
+    pipe = _ingest_mod(pkg).OverlappedPageDecode(ctx, threads=3, depth=depth, keeps_mode=keeps_kind, by_kind=by_kind,
+                                                 page_flags=pkg.PAGES_VERIFY_CRC | pkg.PAGES_GROUP_BY_MODE)  # (check() below knows the slots' streams from the page order)
     seen = []
 
     def check(b):  # (called on the decoding thread between batches: reading back waits for the batch's steps)

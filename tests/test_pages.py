@@ -53,6 +53,39 @@ def test_pages_to_steps_match_the_packet_split(pkg):
     b.close()
 
 
+def test_order_by_header_sorts_each_mode_group_by_the_lbrr_flags(pkg):
+    """OPUSGPU_PAGES_ORDER_BY_HEADER: per step the table is grouped by mode, and inside the SILK-only and the hybrid group the
+    frames come in the order of their LBRR flags (bits 6 and 4 of the first payload byte; bit 6 alone for a mono frame), pages in
+    input order among equals; the CELT-only group keeps input order; no frame is lost or changed."""
+    rng = random.Random(5)
+    pages, ids = [], []
+    for s in range(300):
+        toc = rng.choice([0x0C, 0x08, 0x7C, 0x78, 0xFC, 0x4C])
+        pages.append(ogg_util.page(100 + s, 2, 0, [_packet(rng, toc, rng.choice([0, 1, 30, 60])) for _ in range(rng.randrange(1, 4))]))
+        ids.append(s)
+    plain = _batch(pkg, pages, ids, flags=pkg.PAGES_VERIFY_CRC)
+    b = _batch(pkg, pages, ids, flags=pkg.PAGES_VERIFY_CRC | pkg.PAGES_ORDER_BY_HEADER, threads=3)
+    assert b.n_steps == plain.n_steps
+    for s in range(b.n_steps):
+        descs, slot_pages = b.step(s)
+        d0, p0 = plain.step(s)
+        frame = lambda bb, d: (int(d["stream"]), bytes(bb.arena[d["offset"]:d["offset"] + d["len"]]), int(d["flags"]))
+        assert sorted(frame(b, d) for d in descs) == sorted(frame(plain, d) for d in d0)
+        mode = descs["flags"] & 3
+        assert (np.diff(mode.astype(int)) >= 0).all()
+        for m in range(3):
+            sel = np.nonzero(mode == m)[0]
+            keys = []
+            for j in sel:
+                d = descs[j]
+                b0 = int(b.arena[d["offset"]]) if d["len"] > 0 else 0
+                keys.append((((b0 >> 6) & 1) | ((((b0 >> 4) & 1) << 1) if d["flags"] & 32 else 0)) if (m < 2 and d["len"] > 0) else 0)
+            order = list(zip(keys, slot_pages[sel]))
+            assert order == sorted(order), (s, m)  # by key, input order among equals
+    plain.close()
+    b.close()
+
+
 def test_bad_pages_are_reported_per_page(pkg):
     rng = random.Random(2)
     good = ogg_util.page(1, 0, 0, [_packet(rng, 0xFC, 50)])
