@@ -233,8 +233,21 @@ static_assert(SILK_REC_FRAME / 16 <= 2 * SILK_REC_LPC, "the pulse decoder's bloc
 OG_LDS SilkParLds g_silk_par;
 #define g_silk_blk g_silk_par.blk
 
-// silk_decode_pulses silk.cpp:898.  The pulses of a channel go to the record (HBM) as they are produced; the later
-// passes (LSBs, signs) re-read them, one value ahead of their use.
+// silk_decode_pulses silk.cpp:898.  A channel's pulses go to the record (HBM) block by block: 16 coefficients = 32 bytes.
+// Between the passes of the bitstream (all shell trees, then all LSBs, then all signs) a block waits in its own 32 bytes of the
+// record -- as 16 magnitudes of one byte each (they are at most 16), written with ONE 16-byte store and read back with one load,
+// where round 3 stored and re-read sixteen 2-byte values one by one (each a memory instruction whose 32 lanes touch 32 records);
+// only a block with LSBs (rare) is widened to 16 bits before the sign pass.  The sign pass reads one symbol per NON-ZERO
+// coefficient: it walks the bits of the block's non-zero mask -- the wave goes round as often as its busiest lane has non-zero
+// coefficients, not sixteen times -- and then builds the signed 16-bit values two at a time (packed 16-bit arithmetic).
+#ifndef OG_HOST_EMUL
+typedef u32 og_u32x4 __attribute__((ext_vector_type(4)));
+OG_DEV u32 og_pk_sub_i16(u32 a, u32 b) {
+    u32 r;
+    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#endif
 OG_DEV void silk_parse_pulses(RcLane &rc, i16 *pulses, int signalType, int quantOffsetType, int frame_length) {
     int iter = frame_length >> 4;
     if (iter * 16 < frame_length) iter++;
@@ -253,34 +266,55 @@ OG_DEV void silk_parse_pulses(RcLane &rc, i16 *pulses, int signalType, int quant
     for (int i = 0; i < iter; i++) {
         i16 *p0 = &pulses[i * 16];
         const int sp = g_silk_blk[i][OG_LANE] & 31;
+#ifdef OG_HOST_EMUL
+        u8 *pb = reinterpret_cast<u8 *>(p0);
+        for (int j = 0; j < 32; j++) pb[j] = 0;
+#else
+        u32 w[4] = {0, 0, 0, 0};
+#endif
         if (sp > 0) {
             // binary shell tree: 16 -> 8 -> 4 -> 2 -> 1, depth-first in the reference's order
             int p3[2], p2[4], p1[8], a, b;
             shell_split_tab(rc, p3[0], p3[1], sp, SILK_BLOB_shell3);
+#pragma unroll
             for (int h = 0; h < 2; h++) {
                 shell_split_tab(rc, p2[2 * h], p2[2 * h + 1], p3[h], SILK_BLOB_shell2);
+#pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const int qi = 2 * h + q;
                     shell_split_tab(rc, p1[2 * qi], p1[2 * qi + 1], p2[qi], SILK_BLOB_shell1);
+#pragma unroll
                     for (int e = 0; e < 2; e++) {
                         const int ei = 2 * qi + e;
                         shell_split_tab(rc, a, b, p1[ei], SILK_BLOB_shell0);
-                        p0[2 * ei] = (i16)a;
-                        p0[2 * ei + 1] = (i16)b;
+#ifdef OG_HOST_EMUL
+                        pb[2 * ei] = (u8)a;
+                        pb[2 * ei + 1] = (u8)b;
+#else
+                        w[ei >> 1] |= ((u32)a | (u32)b << 8) << (16 * (ei & 1));
+#endif
                     }
                 }
             }
-        } else {
-            for (int j = 0; j < 16; j++) p0[j] = 0;
         }
+#ifndef OG_HOST_EMUL
+        // (all 32 bytes: a block without pulses and without LSBs is final as it is -- zeros in either form)
+        og_u32x4 *dst = reinterpret_cast<og_u32x4 *>(p0);
+        const og_u32x4 lo = {w[0], w[1], w[2], w[3]}, zero = {0, 0, 0, 0};
+        dst[0] = lo;
+        if (sp == 0) dst[1] = zero;
+#endif
     }
     OG_MARK(48);
     for (int i = 0; i < iter; i++) {
         const int nLS = g_silk_blk[i][OG_LANE] >> 5;
-        if (nLS > 0) {
+        if (nLS > 0) { // widen the block, then its LSBs (from the last coefficient down: a value's 16 bits land on bytes not yet read)
             i16 *p = &pulses[i * 16];
+            const u8 *pb = reinterpret_cast<const u8 *>(p);
+            u8 mag[16];
+            for (int j = 0; j < 16; j++) mag[j] = pb[j];
             for (int j = 0; j < 16; j++) {
-                i32 abs_q = p[j];
+                i32 abs_q = mag[j];
                 for (int b = 0; b < nLS; b++) {
                     abs_q = shl32(abs_q, 1);
                     abs_q += rc_icdf_tab(rc, SILK_BLOB_lsb_icdf, 2);
@@ -298,26 +332,59 @@ OG_DEV void silk_parse_pulses(RcLane &rc, i16 *pulses, int signalType, int quant
         if (blk > 0) {
             const u32 ic0 = g_silk_tab[icdf_ptr + OG_MIN(blk & 0x1F, 6)];
             i16 *q = &pulses[i * 16];
-            i32 cur = q[0];
-            for (int j = 0; j < 16; j++) {
-                const i32 nxt = j < 15 ? q[j + 1] : 0; // requested one step ahead of its use
-                if (cur > 0) {
-                    // two-symbol iCDF {ic0, 0}, ftb 8
-                    u32 s = rc.rng, d = rc.val, r = s >> 8, t = s;
-                    int ret = 0;
-                    s = r * ic0;
-                    if (d < s) {
-                        t = s;
-                        s = 0;
-                        ret = 1;
-                    }
-                    rc.val = d - s;
-                    rc.rng = t - s;
-                    rc_renorm(rc);
-                    q[j] = (i16)(cur * ((ret << 1) - 1));
+            auto sign_symbol = [&]() -> int { // two-symbol iCDF {ic0, 0}, ftb 8
+                u32 s = rc.rng, d = rc.val, r = s >> 8, t = s;
+                int ret = 0;
+                s = r * ic0;
+                if (d < s) {
+                    t = s;
+                    s = 0;
+                    ret = 1;
                 }
-                cur = nxt;
+                rc.val = d - s;
+                rc.rng = t - s;
+                rc_renorm(rc);
+                return ret;
+            };
+            if ((blk >> 5) > 0) { // a widened block: sixteen 16-bit magnitudes
+                i32 cur = q[0];
+                for (int j = 0; j < 16; j++) {
+                    const i32 nxt = j < 15 ? q[j + 1] : 0; // requested one step ahead of its use
+                    if (cur > 0) q[j] = (i16)(cur * ((sign_symbol() << 1) - 1));
+                    cur = nxt;
+                }
+                continue;
             }
+#ifdef OG_HOST_EMUL
+            u8 mag[16];
+            for (int j = 0; j < 16; j++) mag[j] = reinterpret_cast<const u8 *>(q)[j];
+            for (int j = 0; j < 16; j++) q[j] = mag[j] > 0 ? (i16)((i32)mag[j] * ((sign_symbol() << 1) - 1)) : (i16)0;
+#else
+            const og_u32x4 w = *reinterpret_cast<const og_u32x4 *>(q);
+            // bit j of nz: magnitude j is not zero (a byte is at most 16: adding 0x7f carries into its top bit exactly then)
+            u32 nz = 0;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const u32 t = (w[d] + 0x7f7f7f7fu) & 0x80808080u;
+                nz |= (((t >> 7) | (t >> 14) | (t >> 21) | (t >> 28)) & 15u) << (4 * d);
+            }
+            u32 neg = 0; // bit j: coefficient j is negative
+            while (nz) {
+                const int j = __builtin_ctz(nz);
+                nz &= nz - 1;
+                neg |= (u32)(sign_symbol() ^ 1) << j;
+            }
+            og_u32x4 o[2];
+#pragma unroll
+            for (int pr = 0; pr < 8; pr++) { // coefficients 2 pr, 2 pr + 1 as two 16-bit lanes: (m ^ s) - s with s = 0 / -1
+                const u32 m2 = __builtin_amdgcn_perm(0u, w[pr >> 1], (pr & 1) ? 0x0c030c02u : 0x0c010c00u);
+                const u32 b2 = (neg >> (2 * pr)) & 3u, s2 = og_pk_sub_i16(0u, (b2 | b2 << 15) & 0x00010001u);
+                o[pr >> 2][pr & 3] = og_pk_sub_i16(m2 ^ s2, s2);
+            }
+            og_u32x4 *dst = reinterpret_cast<og_u32x4 *>(q);
+            dst[0] = o[0];
+            dst[1] = o[1];
+#endif
         }
     }
 }
