@@ -309,6 +309,7 @@ __global__ void __launch_bounds__(64, OG_SILK_WAVES) k_silk_synth(const FrameDes
     if (f >= n) return;
     const FrameDesc d = descs[f];
     int ret;
+    u32 prefetched = 0;
     if (d.stream < 0 || d.stream >= n_streams) {
         ret = BAD_ARG;
     } else if (desc_mode(d.flags) == MODE_CELT || desc_rfc(d.flags)) {
@@ -317,11 +318,25 @@ __global__ void __launch_bounds__(64, OG_SILK_WAVES) k_silk_synth(const FrameDes
 #ifdef OG_PROF_SSYNTH // profiling builds: time the sections of the SILK synthesis kernel
         OG_PROF_INIT();
 #endif
+#ifndef OG_NO_SYNTH_PREFETCH
+        // The frame's record (2 KB) and the stream's SILK state (1.7 KB) are read below in a dozen dependent steps, each behind a
+        // wave-level sync that keeps the compiler from asking early: every one of them paid a trip to HBM.  One load per lane --
+        // lane l touches the l-th 64 bytes of the state, lane 32 + l of the record -- brings all of it to the L2 now; its value is
+        // never used (the empty asm at the end keeps the register), the later reads find their lines on the way or there.
+        {
+            const int l = (int)threadIdx.x;
+            const char *p = l < 28 ? reinterpret_cast<const char *>(&st[d.stream].silk) + 64 * l
+                          : l < 32 ? reinterpret_cast<const char *>(&handoff[f]) + 16 * (l - 28)
+                                   : reinterpret_cast<const char *>(&srecs[f]) + 64 * (l - 32);
+            prefetched = *reinterpret_cast<const volatile u32 *>(p);
+        }
+#endif
         ret = decode_frame_wave<false>(&st[d.stream], arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
                                        desc_channels(d.flags), pcm + (size_t)f * pcm_stride, &handoff[f], &srecs[f]);
 #ifdef OG_PROF_SSYNTH
         OG_PROF_FLUSH();
 #endif
+        asm volatile("" ::"v"(prefetched));
         if (ret == CONTINUE_SPLIT || ret == CONTINUE_Q4) return;
     }
     if (threadIdx.x == 0) result[f] = ret;
