@@ -448,22 +448,25 @@ __global__ void __launch_bounds__(64) k_celt_post(const FrameDesc *__restrict__ 
                                                   const ReconOut *__restrict__ rout, i32 *__restrict__ result, i16 *pcm, int n,
                                                   int n_streams, int channels, int pcm_stride, const SilkHandoff *handoff,
                                                   int modes, int others_ran) {
-    // Fast path (two-channel decoder, every row of the wave live, ring positions on a 16-sample boundary): the 64 rows'
-    // next 16 samples are fetched as full 64-byte lines by the whole wave (lane = quarter line of a row), transposed
+    // Fast path (two-channel decoder, every row of the wave live, ring positions on a 32-sample boundary): the 64 rows'
+    // next 32 samples are fetched as full 128-byte lines by the whole wave (lane = an eighth of a row's line), transposed
     // through LDS to one row per lane for the recurrence, and the PCM goes out the same way (lane = 16 bytes of a frame's
-    // interleaved output).  Anything else takes the row-per-lane path with its 16-byte accesses (celt_post_lane).
+    // interleaved output, a frame's 128 bytes by eight neighbouring lanes; a hybrid frame's SILK PCM comes in likewise).  Anything
+    // else takes the row-per-lane path with its 16-byte accesses (celt_post_lane).
+    // (Round 3 moved 64-byte pieces: the memory system fetches 128-byte lines, and the other half of a row's line had left the L2
+    // again by the time its turn came -- 36 KB of traffic per hybrid frame for 15 KB needed, in a kernel that does nothing but move.)
     struct RowInfo {
         const i32 *ring;
         i16 *pcm;
         const i16 *silk;
         int pos, silk_n;
     };
+    constexpr int CS = 32, PCS = CS / 4, RSTEP = 64 / PCS; // samples per chunk and row; 16-byte pieces per row; rows between a lane's pieces
     __shared__ RowInfo rows[64];
     // (one buffer is enough: a chunk's rows are all read before the barrier that follows the PCM staging, the next chunk's are
-    // written behind it; a second one cost 5 KB of LDS, i.e. six resident workgroups per CU of a kernel that lives on memory
-    // latency hiding)
-    __shared__ __attribute__((aligned(16))) i32 tin[1][64][20]; // 16 samples per row, rows padded to 80 bytes
-    __shared__ __attribute__((aligned(16))) i16 tout[64][24];   // 16 outputs per row, rows padded to 48 bytes
+    // written behind it)
+    __shared__ __attribute__((aligned(16))) i32 tin[64][CS + 4];  // CS samples per row, rows padded by 16 bytes
+    __shared__ __attribute__((aligned(16))) i16 tout[64][CS + 8]; // CS outputs per row, rows padded by 16 bytes
     const int lane = (int)threadIdx.x;
     const int t = (int)blockIdx.x * 64 + lane;
     const int f = channels == 2 ? t >> 1 : t, c = channels == 2 ? t & 1 : 0;
@@ -497,7 +500,7 @@ __global__ void __launch_bounds__(64) k_celt_post(const FrameDesc *__restrict__ 
         }
     }
     i16 *out = pcm + (size_t)(f < n ? f : 0) * pcm_stride;
-    const bool fast = channels == 2 && __all(live && emit && (pos & 15) == 0);
+    const bool fast = channels == 2 && __all(live && emit && (pos & (CS - 1)) == 0);
     if (!fast) {
         if (live) celt_post_lane(&ss->celt, c, channels, 960, pos, emit ? out : nullptr, silk, silk_n);
         return;
@@ -508,55 +511,62 @@ __global__ void __launch_bounds__(64) k_celt_post(const FrameDesc *__restrict__ 
     rows[lane].pos = pos;
     rows[lane].silk_n = silk_n;
     __syncthreads();
-    // this lane's share of the cooperative traffic: quarter q of rows r0, r0 + 16, r0 + 32, r0 + 48
-    const int q = lane & 3, r0 = lane >> 2;
-    const i32 *src[4];
-    int spos[4];
-    for (int k = 0; k < 4; k++) {
-        src[k] = rows[r0 + 16 * k].ring;
-        spos[k] = rows[r0 + 16 * k].pos + 4 * q;
+    // this lane's share of the cooperative traffic: piece q of rows r0, r0 + RSTEP, ..
+    const int q = lane % PCS, r0 = lane / PCS;
+    const i32 *src[PCS];
+    int spos[PCS];
+#pragma unroll
+    for (int k = 0; k < PCS; k++) {
+        src[k] = rows[r0 + RSTEP * k].ring;
+        spos[k] = rows[r0 + RSTEP * k].pos + 4 * q;
     }
-    og_v4i v[4];
-    for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const og_v4i *>(src[k] + (spos[k] & RING_MASK));
+    og_v4i v[PCS];
+#pragma unroll
+    for (int k = 0; k < PCS; k++) v[k] = *reinterpret_cast<const og_v4i *>(src[k] + (spos[k] & RING_MASK));
     i32 m = ss->celt.deemph[c];
-    for (int ch = 0; ch < 60; ch++) {
-        const int b = 0;
-        for (int k = 0; k < 4; k++) *reinterpret_cast<og_v4i *>(&tin[b][r0 + 16 * k][4 * q]) = v[k];
-        if (ch + 1 < 60)
-            for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const og_v4i *>(src[k] + ((spos[k] + 16 * (ch + 1)) & RING_MASK));
+    for (int ch = 0; ch < 960 / CS; ch++) {
+#pragma unroll
+        for (int k = 0; k < PCS; k++) *reinterpret_cast<og_v4i *>(&tin[r0 + RSTEP * k][4 * q]) = v[k];
+        if (ch + 1 < 960 / CS) {
+#pragma unroll
+            for (int k = 0; k < PCS; k++) v[k] = *reinterpret_cast<const og_v4i *>(src[k] + ((spos[k] + CS * (ch + 1)) & RING_MASK));
+        }
         __syncthreads();
         // the recurrence on this lane's own row (celt.cpp:1965-2055, sig2word16 celt.h:413)
-        i16 o[16];
-        for (int g4 = 0; g4 < 4; g4++) {
-            const og_v4i sv = *reinterpret_cast<const og_v4i *>(&tin[b][lane][4 * g4]);
-            // (a hybrid frame's SILK PCM is added where the PCM leaves, below: there a frame's 16-byte pieces are read by
-            // neighbouring lanes as whole 64-byte lines; read here, one row per lane, every 16 bytes came from a line of
-            // their own -- 33 KB fetched per hybrid frame for 11.5 KB needed, and the kernel is HBM-bound)
-            i32 tt = sv.x + m;
-            m = mul16x32_q15(27853, tt);
-            o[4 * g4 + 0] = (i16)sat16(pshr32(tt, 12));
-            tt = sv.y + m;
-            m = mul16x32_q15(27853, tt);
-            o[4 * g4 + 1] = (i16)sat16(pshr32(tt, 12));
-            tt = sv.z + m;
-            m = mul16x32_q15(27853, tt);
-            o[4 * g4 + 2] = (i16)sat16(pshr32(tt, 12));
-            tt = sv.w + m;
-            m = mul16x32_q15(27853, tt);
-            o[4 * g4 + 3] = (i16)sat16(pshr32(tt, 12));
-        }
-        for (int g8 = 0; g8 < 2; g8++) {
+#pragma unroll
+        for (int g8 = 0; g8 < CS / 8; g8++) {
+            i16 o[8];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const og_v4i sv = *reinterpret_cast<const og_v4i *>(&tin[lane][8 * g8 + 4 * h]);
+                // (a hybrid frame's SILK PCM is added where the PCM leaves, below: there a frame's pieces are read by neighbouring
+                // lanes as whole lines; read here, one row per lane, every 16 bytes would come from a line of their own)
+                i32 tt = sv.x + m;
+                m = mul16x32_q15(27853, tt);
+                o[4 * h + 0] = (i16)sat16(pshr32(tt, 12));
+                tt = sv.y + m;
+                m = mul16x32_q15(27853, tt);
+                o[4 * h + 1] = (i16)sat16(pshr32(tt, 12));
+                tt = sv.z + m;
+                m = mul16x32_q15(27853, tt);
+                o[4 * h + 2] = (i16)sat16(pshr32(tt, 12));
+                tt = sv.w + m;
+                m = mul16x32_q15(27853, tt);
+                o[4 * h + 3] = (i16)sat16(pshr32(tt, 12));
+            }
             og_v4i w;
-            w.x = (i32)((u32)(u16)o[8 * g8 + 0] | (u32)(u16)o[8 * g8 + 1] << 16);
-            w.y = (i32)((u32)(u16)o[8 * g8 + 2] | (u32)(u16)o[8 * g8 + 3] << 16);
-            w.z = (i32)((u32)(u16)o[8 * g8 + 4] | (u32)(u16)o[8 * g8 + 5] << 16);
-            w.w = (i32)((u32)(u16)o[8 * g8 + 6] | (u32)(u16)o[8 * g8 + 7] << 16);
+            w.x = (i32)((u32)(u16)o[0] | (u32)(u16)o[1] << 16);
+            w.y = (i32)((u32)(u16)o[2] | (u32)(u16)o[3] << 16);
+            w.z = (i32)((u32)(u16)o[4] | (u32)(u16)o[5] << 16);
+            w.w = (i32)((u32)(u16)o[6] | (u32)(u16)o[7] << 16);
             *reinterpret_cast<og_v4i *>(&tout[lane][8 * g8]) = w;
         }
         __syncthreads();
-        // PCM: frame fr's 16 samples x 2 channels = 64 contiguous bytes; this lane writes piece q (samples 4q .. 4q+3)
-        for (int k = 0; k < 2; k++) {
-            const int fr = r0 + 16 * k; // frame within the wave: rows 2 fr (left) and 2 fr + 1 (right)
+        // PCM: frame fr's CS samples x 2 channels = 128 contiguous bytes; this lane writes piece q (samples 4q .. 4q+3) of frames
+        // r0, r0 + RSTEP, ..
+#pragma unroll
+        for (int k = 0; k < PCS / 2; k++) {
+            const int fr = r0 + RSTEP * k; // frame within the wave: rows 2 fr (left) and 2 fr + 1 (right)
             const og_v2u L = *reinterpret_cast<const og_v2u *>(&tout[2 * fr][4 * q]);
             const og_v2u R = *reinterpret_cast<const og_v2u *>(&tout[2 * fr + 1][4 * q]);
             og_v4i w;
@@ -564,7 +574,7 @@ __global__ void __launch_bounds__(64) k_celt_post(const FrameDesc *__restrict__ 
             w.y = (i32)(L.x >> 16 | (R.x & 0xffff0000u));
             w.z = (i32)((L.y & 0xffffu) | R.y << 16);
             w.w = (i32)(L.y >> 16 | (R.y & 0xffff0000u));
-            const int at = (16 * ch + 4 * q) * 2; // the piece's place in the frame's interleaved PCM -- and in its SILK PCM (Q3: by linear index)
+            const int at = (CS * ch + 4 * q) * 2; // the piece's place in the frame's interleaved PCM -- and in its SILK PCM (Q3: by linear index)
             const i16 *const sk = rows[2 * fr].silk;
             if (sk && at < rows[2 * fr].silk_n) { // SAT16(celt + silk), two samples per saturating packed add
                 const og_v4i a = *reinterpret_cast<const og_v4i *>(sk + at);
