@@ -314,9 +314,9 @@ def check_against_oracle(pkg, ctx, name, n, frames, d_pcm, pay=None, pages_seed=
 
 
 def traffic_for(name, n):
-    """HBM bytes per step from the committed PMC passes of THIS round's build (tools/prof_pmc.sh -> profiles/r03/), taken
+    """HBM bytes per step from the committed PMC passes of THIS round's build (tools/prof_pmc.sh -> profiles/r04/), taken
     at this batch size; null when no such file exists.  The file names the build it was measured on."""
-    for rnd in ("r03",):
+    for rnd in ("r04",):
         tpath = os.path.join(ROOT, "profiles", rnd, f"traffic_{name}.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
@@ -331,7 +331,7 @@ def valu_issue_for(name, n, step_ms):
     same committed PMC passes: vector-ALU wave-instructions of the step's kernels, the time the chip needs just to issue them
     (a wave64 vector instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz), and that time over the measured
     step.  None when no counters of this round exist for the workload."""
-    tpath = os.path.join(ROOT, "profiles", "r03", f"traffic_{name}.json")
+    tpath = os.path.join(ROOT, "profiles", "r04", f"traffic_{name}.json")
     if not os.path.exists(tpath):
         return None
     with open(tpath) as fh:
