@@ -263,6 +263,48 @@ def overlapped_end_to_end(pkg, ranks, ctx, n, d_pcm, d_res, threads):
     return st, out
 
 
+def run_host_path(args, ranks, pkg, ctx):
+    """The host-buffer entry (opusgpu_decode_packets, what opus_multistream_decode callers get): packets in host memory -> PCM in
+    host memory, 65,536 CELT-FB stereo packets per call, page-locked caller buffer.  PCIe-inclusive (10.6 MB in, 252 MB out per
+    call): reported beside the device-resident figures, never as the headline `value`.  -> dict (rank 0)."""
+    n, steps, L, toc = 65536, 6, 160, pkg.TOC_CELT_FB_STEREO
+    ctx.set_pipeline(False)
+    ctx.streams_alloc(n, 2)
+    pay = pkg.lcg_payloads(n, steps + 1, L, seed_base=ranks.seed_base())
+    arenas = [np.concatenate([np.full((n, 1), toc, dtype=np.uint8), pay[s]], axis=1).reshape(-1) for s in range(steps + 1)]
+    offs, lens, ids = np.arange(n, dtype=np.int64) * (L + 1), np.full(n, L + 1, dtype=np.int32), np.arange(n, dtype=np.int32)
+    raw = np.zeros(n * 960 * 2 + 4096, dtype=np.int16)
+    off = ((-raw.ctypes.data) % 4096) // 2
+    out = raw[off:off + n * 960 * 2].reshape(n, 960, 2)
+    ctx.host_register(out)
+    try:
+        ctx.decode_packets_arena(ids, arenas[0], offs, lens, pcm=out)  # warm-up (allocations)
+        ptrs = [(np.uint64(a.ctypes.data) + offs.astype(np.uint64)).astype(np.uint64) for a in arenas]  # (a C caller has its pointers)
+        res = np.zeros(n, dtype=np.int32)
+        ranks.barrier()
+        t0 = time.perf_counter()
+        for s in range(1, steps + 1):
+            ctx.decode_packets_raw(ids, ptrs[s], lens, out, res)
+        dt = ranks.max_over_ranks(time.perf_counter() - t0)
+        if not (res == 960).all():
+            raise SystemExit("host path: decode failed")
+        import oracle_py
+        pick = np.arange(0, n, n // 128)
+        ref, _ = oracle_py.load().batch_decode(2, toc, np.ascontiguousarray(pay[:, pick]))
+        if not np.array_equal(out[pick], ref[:, steps]):
+            raise SystemExit("host path: PCM differs from the CPU oracle")
+    finally:
+        ctx.host_unregister(out)
+        ctx.set_pipeline(args.pipeline == "on")
+    if ranks.rank != 0:
+        return None
+    return {"name": "host_path_64k", "value": n * steps * ranks.world / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3,
+            "config": {"workload": f"host_path_64k: opusgpu_decode_packets, {n} CELT-FB stereo packets of {L + 1} bytes per call from host memory, "
+                                   "PCM into a page-locked host buffer (PCIe-inclusive: 10.6 MB in, 251.7 MB out per call)", "streams_per_gpu": n},
+            "pcie_floor_ms": n * 3840 / 55.8e9 * 1e3,
+            "parity_check": {"streams_checked": len(pick), "frames_of_history": steps + 1, "result": "last call bit-exact vs the CPU oracle"}}
+
+
 def launch_ranks(args, argv):
     """--gpus N > 1 and no rank environment: start the N ranks as a child job (torch.distributed.run, one process per
     GPU) and relay its output.  Nothing in THIS process has touched HIP / torch.cuda: it only waits for the child."""
@@ -801,6 +843,9 @@ def main():
                 o["name"] = name
                 others.append(o)
         o = run_rfc_workload(args, ranks, pkg, ctx)
+        if o is not None:
+            others.append(o)
+        o = run_host_path(args, ranks, pkg, ctx)
         if o is not None:
             others.append(o)
         args.cpu_seconds = saved

@@ -365,6 +365,12 @@ class Context:
                   "opusgpu_decode_packets")
         return pcm, res
 
+    def decode_packets_raw(self, ids, ptrs, lens, pcm, res, frame_capacity=1):
+        """opusgpu_decode_packets with every table made by the caller beforehand (int32 ids / lens, uint64 packet addresses, int16
+        pcm, int32 res; all C-contiguous, one entry per packet): nothing but the call itself -- what a C caller pays."""
+        self._chk(self.lib.opusgpu_decode_packets(self.h, len(lens), ids.ctypes.data, ptrs.ctypes.data, lens.ctypes.data,
+                                                  pcm.ctypes.data, frame_capacity, res.ctypes.data), "opusgpu_decode_packets")
+
     # ---- device-resident path -------------------------------------------------------------------
     def dev_alloc(self, nbytes):
         p = C.c_void_p()
