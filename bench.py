@@ -734,6 +734,13 @@ def run_rfc_workload(args, ranks, pkg, ctx, n_override=0, cpu=True):
     value, dt, total_frames = shard.aggregate_throughput(ranks, n * K, dt)
     for p in frees:
         ctx.dev_free(p)
+    if os.environ.get("BENCH_PROF") and hasattr(pkg.load_lib(), "opusgpu_debug_prof"):  # (a -DOG_PROF build: section cycles of k_decode_rfc)
+        import ctypes
+        buf = (ctypes.c_ulonglong * 64)()
+        pkg.load_lib().opusgpu_debug_prof(buf, 1)
+        tot = sum(buf) or 1
+        sys.stderr.write("k_decode_rfc sections (OG_MARK id: cycles per frame, share):\n" + "".join(
+            f"  {i:2d} {buf[i] / (n * (K + W)):10.0f} {100.0 * buf[i] / tot:5.1f}%\n" for i in range(64) if buf[i]))
     ctx.set_mode(False)
     if rank != 0:
         return None

@@ -1406,9 +1406,11 @@ int opusgpu_decode_steps_device(opusgpu_ctx *ctx, int n_steps, const int32_t *n,
 #ifdef OG_PROF
 // profiling builds only: per-section wave-cycle totals of k_celt_recon (see OG_MARK), optionally cleared after the read
 extern "C" int og_recon_fb_prof(unsigned long long *out64, int reset);
+extern "C" int og_rfc_prof(unsigned long long *out64, int reset);
 int opusgpu_debug_prof(unsigned long long *out64, int reset) {
-    unsigned long long fb[64];
-    if (og_recon_fb_prof(fb, reset) != 0) return -1;
+    unsigned long long fb[64], rf[64];
+    if (og_recon_fb_prof(fb, reset) != 0 || og_rfc_prof(rf, reset) != 0) return -1;
+    for (int i = 0; i < 64; i++) fb[i] += rf[i];
     if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
     for (int i = 0; i < 64; i++) out64[i] += fb[i];
     if (reset) {

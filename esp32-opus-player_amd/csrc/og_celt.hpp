@@ -1428,6 +1428,7 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
     celt_parse_header(WaveArr(), rc, start, end, C, LM, h);
     const int silence = h.silence, transient = h.transient, spread = h.spread, pf_pitch = h.pf_pitch, pf_tapset = h.pf_tapset;
     const i32 pf_gain = h.pf_gain, intensity = h.intensity, dual_stereo = h.dual_stereo, balance = h.balance;
+    OG_MARK(26); // (single-kernel path: the band loop, quant_all_bands)
     const int shortBlocks = transient ? M : 0, anti_collapse_rsv = h.anti_collapse_rsv, codedBands = h.codedBands;
 #if defined(OG_ABLATE) && OG_ABLATE == 1
     return frame_size;
@@ -1435,6 +1436,7 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
     u32 seed = st->rng;
     decode_all_bands(rc, start, end, C, N, shortBlocks, spread, dual_stereo, intensity,
                      (i32)rc.storage * (8 << BITRES) - anti_collapse_rsv, balance, LM, codedBands, seed, disable_inv);
+    OG_MARK(27);
     int anti_collapse_on = 0;
     if (anti_collapse_rsv > 0) anti_collapse_on = (int)rc_bits(rc, 1);
     energy_finalise(WaveArr(), rc, start, end, (i32)rc.storage * 8 - rc_tell(rc), C);

@@ -21,13 +21,26 @@ __global__ void __launch_bounds__(64, OG_RFC_WAVES) k_decode_rfc(const FrameDesc
     if (f >= n) return;
     const FrameDesc d = descs[f];
     int ret;
+    OG_PROF_INIT();
     if (d.stream < 0 || d.stream >= n_streams || !desc_rfc(d.flags))
         ret = BAD_ARG; // (in RFC mode every descriptor carries the mode bit: opusgpu_packet_to_frames_mode)
     else
         ret = decode_frame_rfc(&st[d.stream], arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
                                desc_channels(d.flags), pcm + (size_t)f * pcm_stride, desc_frame_size(d.flags), desc_fec(d.flags));
     if (threadIdx.x == 0) result[f] = ret;
+    OG_PROF_FLUSH();
 }
+#ifdef OG_PROF
+// profiling builds only: this kernel's section counters (OG_MARK) -- every translation unit has its own copy
+extern "C" int og_rfc_prof(unsigned long long *out64, int reset) {
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[64] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" void og_launch_decode_rfc(hipStream_t s, const void *descs, const void *arena, void *streams, void *pcm, void *result, int n,
                                      int n_streams, int pcm_stride) {

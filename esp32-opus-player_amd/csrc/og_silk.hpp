@@ -836,30 +836,44 @@ OG_DEV i32 row_lane0(i32 v) { // lane 0 of every 16-lane row, in all lanes of th
     // keep lane 0's value, zero elsewhere, then sum over the row
     return row_sum16((OG_LANE & 15) == 0 ? v : 0);
 }
-OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const i16 *pulses0, const i16 *pulses1) {
+// `nb_subfr`: 4, or 2 for a 10 ms frame (RFC mode); `loss` (RFC mode): the stream's loss-concealment state -- the frame's excitation
+// is kept there for a later concealment (silk.cpp:1835), and the first two subframes after a voiced concealment are smoothed
+// (:1869-1876).
+OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const i16 *pulses0, const i16 *pulses1, int nb_subfr = 4,
+                                  LossState *loss = nullptr) {
     SilkLds &L = SL();
     const int row = OG_LANE >> 4, j = OG_LANE & 15;
     if (row >= channels) return;
     const int ch = row;
-    const int order = fs_kHz == 16 ? 16 : 10, subfr = 5 * fs_kHz, ltp_mem = 20 * fs_kHz, frame_length = 4 * subfr;
+    const int order = fs_kHz == 16 ? 16 : 10, subfr = 5 * fs_kHz, ltp_mem = 20 * fs_kHz, frame_length = nb_subfr * subfr;
     i16 *xq = &L.xq[ch][2];
     if (!L.ctrl[ch].coded) {
         for (int i = j; i < frame_length; i += 16) xq[i] = 0;
         return;
     }
     SilkChannel *c = &st->ch[ch];
-    const SilkCtrl &k = L.ctrl[ch];
+    SilkCtrl &k = L.ctrl[ch];
+    SilkLossChannel *const lc = loss ? &loss->silk[ch] : nullptr;
+    const int after_loss = lc && lc->lossCnt && c->prevSignalType == 2 && k.signalType != 2; // silk.cpp:1869
+    const int lag_prev = c->lagPrev;
     const i16 *pulses = ch ? pulses1 : pulses0;
     i32 *sLTP_Q15 = L.u.core.sLTP_Q15[ch];
     i16 *sLTP = L.u.core.sLTP[ch];
     const i32 offset_Q10 = rom_silk_quant_offsets_q10[(k.signalType >> 1) * 2 + k.quantOffsetType];
-    const int interp_flag = k.NLSFInterpCoef_Q2 < 4, voiced = k.signalType == 2;
+    const int interp_flag = k.NLSFInterpCoef_Q2 < 4, voiced_frame = k.signalType == 2;
     i32 sLPC = c->sLPC_Q14_buf[SILK_MAX_LPC - 1 - j]; // state sample (i-1-j)
     i32 rand_seed = k.Seed;
     i32 prev_gain_Q16 = c->prev_gain_Q16;
     int sLTP_buf_idx = ltp_mem, lag = 0, pos = 0;
-    for (int sf = 0; sf < 4; sf++) {
+    for (int sf = 0; sf < nb_subfr; sf++) {
         OG_MARK(60);
+        int voiced = voiced_frame;
+        if (after_loss && sf < 2) { // avoid an abrupt transition from voiced concealment to unvoiced decoding (silk.cpp:1869-1876)
+            if (j < 5) k.LTPCoef_Q14[sf * 5 + j] = (i16)(j == 2 ? 4096 : 0); // SILK_FIX_CONST(0.25, 14) on the centre tap
+            if (j == 0) k.pitchL[sf] = lag_prev;
+            voiced = 1;
+            OG_ROW_SYNC();
+        }
         const i16 *A_Q12 = k.PredCoef_Q12[sf >> 1];
         const i16 *B_Q14 = &k.LTPCoef_Q14[sf * 5];
         const i32 A_j = j < order ? (i32)A_Q12[j] : 0;
@@ -957,6 +971,7 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
                     if ((i32)r < 0) exc = -exc;
                     r += (u32)pl;
                     resb[i0 + t] = exc;
+                    if (lc) lc->exc_Q14[pos + i0 + t] = exc;
                 }
             }
         }
@@ -1038,7 +1053,7 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
     c->sLPC_Q14_buf[SILK_MAX_LPC - 1 - j] = sLPC;
     if (j == 0) {
         c->prev_gain_Q16 = prev_gain_Q16;
-        c->lagPrev = k.pitchL[3];
+        c->lagPrev = k.pitchL[nb_subfr - 1];
         c->prevSignalType = k.signalType;
         c->first_frame_after_reset = 0;
     }
@@ -1464,9 +1479,24 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
 #ifdef OG_HOST_EMUL
         OG_FOR_LANES(n, channels) lane_synth(n);
 #else
-        if (nb_subfr == 4 && !loss)
-            silk_decode_core_rows(s, fs_kHz, channels, pulse_row[0], pulse_row[1]);
-        else // 10 ms frames and everything loss-aware (RFC mode only): the one-lane-per-channel form
+        bool rows = true; // the row form takes decoded frames; a concealed channel (RFC mode: lost packets, missing LBRR data) the one-lane form
+        for (int n = 0; n < channels; n++) rows = rows && !(L.ctrl[n].coded && conceal[n]);
+        if (rows) {
+            silk_decode_core_rows(s, fs_kHz, channels, pulse_row[0], pulse_row[1], nb_subfr, loss);
+            if constexpr (!REC_ONLY) {
+                if (loss) { // silk_decode_frame silk.cpp:2008-2015: behind the core, silk_PLC(lost = 0), then lossCnt = 0
+                    OG_SYNC();
+                    OG_FOR_LANES(n, channels) {
+                        if (L.ctrl[n].coded) {
+                            SilkLossChannel *lc = &loss->silk[n];
+                            silk_plc_rate_check(lc, fs_kHz, frame_length);
+                            silk_plc_update_lane(lc, L.ctrl[n], fs_kHz, nb_subfr);
+                            lc->lossCnt = 0;
+                        }
+                    }
+                }
+            }
+        } else
             OG_FOR_LANES(n, channels) lane_synth(n);
 #endif
         OG_SYNC();
