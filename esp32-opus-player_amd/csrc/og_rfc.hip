@@ -12,6 +12,8 @@
 
 using namespace og;
 
+static_assert(offsetof(StreamState, loss) + offsetof(LossState, silk) + sizeof(SilkLossChannel) + offsetof(SilkLossChannel, cng_synth_state) + 6 * 64 <= sizeof(StreamState),
+              "the prefetch of k_decode_rfc stays inside the stream's record");
 #ifndef OG_RFC_WAVES
 #define OG_RFC_WAVES 2 // (294 registers unbounded = one wave per SIMD; bounded to 256: 107 -> 65 ms per step of the rfc_mixed workload; 3: no gain)
 #endif
@@ -22,11 +24,27 @@ __global__ void __launch_bounds__(64, OG_RFC_WAVES) k_decode_rfc(const FrameDesc
     const FrameDesc d = descs[f];
     int ret;
     OG_PROF_INIT();
+    u32 prefetched = 0;
     if (d.stream < 0 || d.stream >= n_streams || !desc_rfc(d.flags))
         ret = BAD_ARG; // (in RFC mode every descriptor carries the mode bit: opusgpu_packet_to_frames_mode)
-    else
+    else {
+#ifndef OG_NO_RFC_PREFETCH
+        // (as in k_silk_synth: one load per lane now brings to the L2 what the frame reads of the stream's state in many dependent
+        // steps later -- the SILK state, the scalars and energies behind the CELT history ring, the head of the loss state)
+        {
+            const int l = (int)threadIdx.x;
+            const StreamState *sp = &st[d.stream];
+            const char *p = l < 28 ? reinterpret_cast<const char *>(&sp->silk) + 64 * l
+                          : l < 40 ? reinterpret_cast<const char *>(&sp->celt.tail[0][0]) + 64 * (l - 28)
+                          : l < 52 ? reinterpret_cast<const char *>(&sp->loss.silk[(l - 40) / 6].cng_synth_state[0]) + 64 * ((l - 40) % 6)
+                                   : reinterpret_cast<const char *>(sp); // (six lines per channel end inside the record: static_assert below)
+            prefetched = *reinterpret_cast<const volatile u32 *>(p);
+        }
+#endif
         ret = decode_frame_rfc(&st[d.stream], arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
                                desc_channels(d.flags), pcm + (size_t)f * pcm_stride, desc_frame_size(d.flags), desc_fec(d.flags));
+    }
+    asm volatile("" ::"v"(prefetched));
     if (threadIdx.x == 0) result[f] = ret;
     OG_PROF_FLUSH();
 }
