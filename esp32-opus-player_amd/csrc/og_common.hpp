@@ -199,11 +199,18 @@ static constexpr i32 SIG_SAT = 300000000; // celt.h:234
 // ---- SILK flavour (src/silk.h) -------------------------------------------------------------------
 #if defined(OG_HOST_EMUL) || defined(OG_MUL64)
 OG_DEV i32 smulwb(i32 a, i32 b) { return (i32)(((i64)a * (i64)(i16)b) >> 16); }      // silk_SMULWB :447
-#else
+#elif defined(OG_SMULWB_MUL24)
 // (a * (i16)b) >> 16 with a = ah * 65536 + al (al unsigned 16 bit): ah * b + ((al * b) >> 16), exact, two 24-bit multiplies
 OG_DEV i32 smulwb(i32 a, i32 b) {                                                    // silk_SMULWB :447
     const i32 bs = (i32)(i16)b;
     return __mul24(a >> 16, bs) + (__mul24((i32)((u32)a & 0xffffu), bs) >> 16);
+}
+#else
+// (a * (i16)b) >> 16 = the HIGH word of a * (b << 16): one v_mul_hi_i32 (32-bit multiplies issue like 24-bit ones on gfx950,
+// profiles/r03/a_valu_issue_rates.txt) plus a shift that leaves the loop wherever b does not change -- where round 3 had two
+// 24-bit multiplies, two shifts / masks and an add
+OG_DEV i32 smulwb(i32 a, i32 b) {                                                    // silk_SMULWB :447
+    return __mulhi(a, (i32)((u32)(i32)(i16)b << 16));
 }
 #endif
 OG_DEV i32 smlawb(i32 acc, i32 a, i32 b) { return addw(acc, smulwb(a, b)); }         // silk_SMLAWB :450

@@ -839,8 +839,13 @@ OG_DEV i32 row_lane0(i32 v) { // lane 0 of every 16-lane row, in all lanes of th
 // `nb_subfr`: 4, or 2 for a 10 ms frame (RFC mode); `loss` (RFC mode): the stream's loss-concealment state -- the frame's excitation
 // is kept there for a later concealment (silk.cpp:1835), and the first two subframes after a voiced concealment are smoothed
 // (:1869-1876).
-OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const i16 *pulses0, const i16 *pulses1, int nb_subfr = 4,
-                                  LossState *loss = nullptr) {
+// (LOSS = false -- reference mode: no loss state, four subframes -- is a compile-time case of its own: written as run-time values
+// the kernel of the split path came out with 147 instead of 90 registers, three waves per SIMD instead of four)
+template <bool LOSS>
+OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const i16 *pulses0, const i16 *pulses1, int nb_subfr_arg = 4,
+                                  LossState *loss_arg = nullptr) {
+    const int nb_subfr = LOSS ? nb_subfr_arg : 4;
+    LossState *const loss = LOSS ? loss_arg : nullptr;
     SilkLds &L = SL();
     const int row = OG_LANE >> 4, j = OG_LANE & 15;
     if (row >= channels) return;
@@ -854,8 +859,8 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
     SilkChannel *c = &st->ch[ch];
     SilkCtrl &k = L.ctrl[ch];
     SilkLossChannel *const lc = loss ? &loss->silk[ch] : nullptr;
-    const int after_loss = lc && lc->lossCnt && c->prevSignalType == 2 && k.signalType != 2; // silk.cpp:1869
-    const int lag_prev = c->lagPrev;
+    const int after_loss = LOSS && lc && lc->lossCnt && c->prevSignalType == 2 && k.signalType != 2; // silk.cpp:1869
+    const int lag_prev = LOSS ? c->lagPrev : 0;
     const i16 *pulses = ch ? pulses1 : pulses0;
     i32 *sLTP_Q15 = L.u.core.sLTP_Q15[ch];
     i16 *sLTP = L.u.core.sLTP[ch];
@@ -1480,9 +1485,16 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
         OG_FOR_LANES(n, channels) lane_synth(n);
 #else
         bool rows = true; // the row form takes decoded frames; a concealed channel (RFC mode: lost packets, missing LBRR data) the one-lane form
-        for (int n = 0; n < channels; n++) rows = rows && !(L.ctrl[n].coded && conceal[n]);
-        if (rows) {
-            silk_decode_core_rows(s, fs_kHz, channels, pulse_row[0], pulse_row[1], nb_subfr, loss);
+        if constexpr (!REC_ONLY) // (the split path's synthesis kernel must not even reference the one-lane form: a call to it sizes
+                                 // the kernel's register file -- 147 instead of 90, three waves per SIMD instead of four)
+            for (int n = 0; n < channels; n++) rows = rows && !(L.ctrl[n].coded && conceal[n]);
+        if constexpr (REC_ONLY)
+            silk_decode_core_rows<false>(s, fs_kHz, channels, pulse_row[0], pulse_row[1]);
+        else if (rows) {
+            if (nb_subfr == 4 && !loss)
+                silk_decode_core_rows<false>(s, fs_kHz, channels, pulse_row[0], pulse_row[1]);
+            else
+                silk_decode_core_rows<true>(s, fs_kHz, channels, pulse_row[0], pulse_row[1], nb_subfr, loss);
             if constexpr (!REC_ONLY) {
                 if (loss) { // silk_decode_frame silk.cpp:2008-2015: behind the core, silk_PLC(lost = 0), then lossCnt = 0
                     OG_SYNC();

@@ -1,0 +1,70 @@
+"""Register budgets of the shipped kernels, read from the code objects inside libopusgpu.so (no GPU needed).
+
+A kernel's occupancy is decided at compile time -- waves per SIMD = 512 / its vector registers (in eights) -- and is easy to lose
+without noticing: in round 4 a run-time `if` kept a call to the one-lane SILK synthesis alive in k_silk_synth, whose register
+count is then the CALLEE's (147 instead of 90): three waves per SIMD instead of four, SILK-NB 1.05 -> 1.27 ms, every test green.
+The bounds below are the occupancy steps the measurements in DESIGN.md were taken at, not the exact counts."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "esp32-opus-player_amd", "libopusgpu.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+# kernel -> most vector registers it may use (the next occupancy step would be lost above it), scratch bytes allowed
+BUDGET = {
+    "k_silk_synth": (96, 0),       # five waves per SIMD by registers (its 10 KB of LDS allow four)
+    "k_celt_recon_fb": (96, 64),   # five waves per SIMD (launch bound), 7.4 KB of LDS
+    "k_silk_parse": (128, 64),     # four waves per SIMD (launch bound: a few spills)
+    "k_celt_parse64": (256, 64),   # two waves per SIMD by design
+    "k_celt_parse": (256, 64),
+    "k_celt_post": (128, 0),
+    "k_decode_rfc": (256, 1024),   # two waves per SIMD (launch bound; it spills)
+}
+
+
+def _kernel_metadata():
+    have = all(os.path.exists(os.path.join(LLVM, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf"))
+    if not have or not os.path.exists(LIB):
+        pytest.skip("LLVM tools or the library are not there")
+    import tempfile
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", LIB, fat])
+        data = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        at = [m.start() for m in re.finditer(re.escape(magic), data)]
+        for j, lo in enumerate(at):  # one bundle per translation unit
+            part = os.path.join(d, f"b{j}.bin")
+            open(part, "wb").write(data[lo:at[j + 1] if j + 1 < len(at) else len(data)])
+            co = os.path.join(d, f"b{j}.co")
+            subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={part}",
+                                   f"--output={co}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], stderr=subprocess.DEVNULL)
+            notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True)
+            for blk in notes.split("- .agpr_count:")[1:]:
+                name = re.search(r"\.name:\s+(\S+)", blk)
+                vg = re.search(r"\.vgpr_count:\s+(\d+)", blk)
+                priv = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+                lds = re.search(r"\.group_segment_fixed_size:\s+(\d+)", blk)
+                if name and vg:
+                    out[name.group(1)] = (int(vg.group(1)), int(priv.group(1)) if priv else 0, int(lds.group(1)) if lds else 0)
+    return out
+
+
+def test_kernels_keep_their_register_budgets():
+    meta = _kernel_metadata()
+    seen = {}
+    for mangled, (vgpr, scratch, lds) in meta.items():
+        for k in BUDGET:
+            if re.search(r"\d+" + k + r"(P|E|v|$)", mangled) or mangled == k:
+                seen[k] = (vgpr, scratch, lds)
+    missing = [k for k in BUDGET if k not in seen]
+    assert not missing, f"kernels not found in the library's code objects: {missing} (have {sorted(meta)[:6]}...)"
+    over = {k: seen[k] for k in BUDGET if seen[k][0] > BUDGET[k][0] or seen[k][1] > BUDGET[k][1]}
+    assert not over, f"over budget (vgpr, scratch bytes, lds bytes): {over}; budgets {({k: BUDGET[k] for k in over})}"
+    # LDS steps the occupancy figures in DESIGN.md rest on (granules of 1,280 bytes per workgroup)
+    assert seen["k_silk_synth"][2] <= 10240 and seen["k_celt_recon_fb"][2] <= 7680
