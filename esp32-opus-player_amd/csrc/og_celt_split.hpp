@@ -34,7 +34,7 @@ namespace og {
 // ---- the record ------------------------------------------------------------------------------------
 constexpr int REC_BAND_WORDS = 4;
 constexpr int REC_MAX_LEAVES = NBANDS * 2 * 16;                   // <= 16 leaves per band and channel (4 split levels)
-constexpr int REC_MAX_WORDS = NBANDS * (REC_BAND_WORDS + 2 * 33); // band words + per job: header + <= 16 leaves x 2 words
+constexpr int REC_MAX_WORDS = NBANDS * (REC_BAND_WORDS + 2 * 33) + 3 * NBANDS + 1; // band words + per job: header + <= 16 leaves x 2 words (+ up to 3 words of padding before a band's header)
 
 enum { // ParseRec.flags
     RF_SILENCE = 1, RF_TRANSIENT = 2, RF_LM_SHIFT = 2 /* 2 bits */, RF_STEREO = 16, RF_SPREAD_SHIFT = 5 /* 2 bits */,
@@ -86,12 +86,18 @@ struct ParseRec {
     u16 band_w[NBANDS];    // where each band's four header words start in words[] (its job words follow them)
     i8 tf_res[NBANDS];
     i8 pad[256 - 64 - 4 * NBANDS - 2 * NBANDS - 2 * NBANDS - NBANDS];
-    u32 leaf_idx[REC_MAX_LEAVES];  // PVQ codeword index
-    u32 leaf_geom[REC_MAX_LEAVES]; // x | N << 11 | K << 19 | (B - 1) << 27   (x: offset into S.v[V_X..])
-    u32 leaf_aux[REC_MAX_LEAVES];  // gain (product of the split gains above the leaf, Q15) | mask offset << 16 (4 bits) | where the
-                                   // leaf's coefficients start in the frame's packed leaf output (sum of N before it) << 20
-    u32 words[(REC_MAX_WORDS + 64) / 64 * 64]; // read in windows of 64 (REC_WORDS_CAP)
+    // A PVQ leaf is 16 bytes -- written by the parse lane with ONE store and fetched by the reconstruction's lane with one load
+    // (round 3 kept three arrays of words: three scattered 4-byte stores per leaf from every lane, each into a record of its own).
+    struct Leaf {
+        u32 idx;  // PVQ codeword index
+        u32 geom; // x | N << 11 | K << 19 | (B - 1) << 27   (x: offset into S.v[V_X..])
+        u32 aux;  // gain (product of the split gains above the leaf, Q15) | mask offset << 16 (4 bits) | where the leaf's
+                  // coefficients start in the frame's packed leaf output (sum of N before it) << 20
+        u32 pad;
+    } leaf[REC_MAX_LEAVES];
+    u32 words[(REC_MAX_WORDS + 64) / 64 * 64]; // read in windows of 64 (REC_WORDS_CAP); a band's four header words start on a multiple of four
 };
+static_assert(offsetof(ParseRec, leaf) % 16 == 0 && offsetof(ParseRec, words) % 16 == 0, "16-byte stores into the record");
 static_assert(sizeof(ParseRec) % 16 == 0, "record alignment");
 
 // What the leaf kernel (og_leaves.hip) leaves for the reconstruction kernel of 20 ms frames, per frame: the coefficients of the
@@ -224,12 +230,30 @@ struct RecWriter {
     }
     OG_MEMBER void leaf(int x, int N, int K, int B, i32 gain, int off, u32 idx) {
         if (nl < REC_MAX_LEAVES) {
-            rec->leaf_idx[nl] = idx;
-            rec->leaf_geom[nl] = (u32)x | (u32)N << 11 | (u32)K << 19 | (u32)(B - 1) << 27;
-            rec->leaf_aux[nl] = (u32)(gain & 0xffff) | (u32)off << 16 | (u32)ncoef << 20;
+            const u32 geom = (u32)x | (u32)N << 11 | (u32)K << 19 | (u32)(B - 1) << 27;
+            const u32 aux = (u32)(gain & 0xffff) | (u32)off << 16 | (u32)ncoef << 20;
+#ifdef OG_HOST_EMUL
+            rec->leaf[nl].idx = idx; rec->leaf[nl].geom = geom; rec->leaf[nl].aux = aux; rec->leaf[nl].pad = 0;
+#else
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<u32x4 *>(&rec->leaf[nl]) = u32x4{idx, geom, aux, 0u};
+#endif
         }
         nl++;
         ncoef += N;
+    }
+    // a band's four header words: on a multiple of four (up to three words skipped), one 16-byte store
+    OG_MEMBER int band_begin() { return nw = (nw + 3) & ~3; }
+    OG_MEMBER void words4(u32 w0, u32 w1, u32 w2, u32 w3) {
+        if (nw + 4 <= REC_MAX_WORDS) {
+#ifdef OG_HOST_EMUL
+            rec->words[nw] = w0; rec->words[nw + 1] = w1; rec->words[nw + 2] = w2; rec->words[nw + 3] = w3;
+#else
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<u32x4 *>(&rec->words[nw]) = u32x4{w0, w1, w2, w3};
+#endif
+        }
+        nw += 4;
     }
 };
 
@@ -365,7 +389,7 @@ OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C
     for (int i = start; i < end; i++) {
         const int eb0 = M * RomLds::eband(i), N = M * RomLds::eband(i + 1) - eb0;
         const int x = eb0, y = C == 2 ? N_ch + eb0 : -1;
-        out.rec->band_w[i] = (u16)OG_MIN(out.nw, REC_MAX_WORDS);
+        out.rec->band_w[i] = (u16)OG_MIN(out.band_begin(), REC_MAX_WORDS);
         const i32 tell = (i32)rc_tell_frac(rc);
         if (i != start) balance -= tell;
         i32 remaining_bits = total_bits - tell - 1, b;
@@ -407,10 +431,7 @@ OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C
                     remaining_bits -= 1 << BITRES;
                 }
             }
-            out.word(w0);
-            out.word(w1);
-            out.word(0);
-            out.word(0);
+            out.words4(w0, w1, 0, 0);
         } else {
             const int stereo = (y >= 0) && !dual_stereo;
             Split sc;
@@ -445,10 +466,7 @@ OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C
             } else if (dual_stereo)
                 njobs = 2;
             if (mid_first) w0 |= BW_MID_FIRST;
-            out.word(w0);
-            out.word(w1);
-            out.word(w2);
-            out.word((u32)(u16)tr16(celt_sqrt(shl32(N, 22)))); // scale of the folding history (celt.cpp:1617)
+            out.words4(w0, w1, w2, (u32)(u16)tr16(celt_sqrt(shl32(N, 22)))); // (w3: scale of the folding history, celt.cpp:1617)
             for (int jb = 0; jb < njobs; jb++) {
                 int jx, jlow = has_low, jsilent = 0;
                 i32 jbits, jgain = 32767;
@@ -1221,6 +1239,7 @@ OG_DEV void recon_all_bands(const u32 *words, u32 need_norm, const LcgTab &lcg, 
         OG_MARK(3);
         const int last = i == end - 1;
         u32 w0, w1, w2, w3;
+        cur.w = (cur.w + 3) & ~3; // (a band's header starts on a multiple of four: RecWriter::band_begin)
         rec_word4(cur, w0, w1, w2, w3);
         const int eb0 = (int)(w1 >> 11) & 2047, N = (int)(w1 >> 22) & 255;
         const int x = V_X + eb0, y = C == 2 ? V_X + N_ch + eb0 : -1;
@@ -1973,7 +1992,7 @@ OG_DEV void recon_leaves_own(const ParseRec *rec, const ReconCtx &rx, bool pre =
     { // the wave pays for its longest leaf: what does that leaf look like?
         int max_n = 0, k_at_max = 0, sum_n = 0;
         for (int t = 0; t < n_leaves; t++) {
-            const u32 g = rec->leaf_geom[t];
+            const u32 g = rec->leaf[t].geom;
             const int n = (int)(g >> 11) & 255, k = (int)(g >> 19) & 255;
             sum_n += n;
             if (n > max_n) { max_n = n; k_at_max = k; }
@@ -1985,9 +2004,9 @@ OG_DEV void recon_leaves_own(const ParseRec *rec, const ReconCtx &rx, bool pre =
     OG_MARK(2);
     OG_FOR_LANES(t, n_leaves) {
         const bool first = pre && t < OG_NLANES;
-        const u32 g = first ? g0 : rec->leaf_geom[t];
-        const u32 aux = first ? aux0 : rec->leaf_aux[t];
-        const u32 idx = first ? idx0 : rec->leaf_idx[t];
+        const u32 g = first ? g0 : rec->leaf[t].geom;
+        const u32 aux = first ? aux0 : rec->leaf[t].aux;
+        const u32 idx = first ? idx0 : rec->leaf[t].idx;
         leaf_masks()[t] = (u16)(pvq_leaf_lane(S.v, pvq_lds(), (int)(g >> 11) & 255, (int)(g >> 19) & 255, idx, V_X + (int)(g & 2047),
                                               (int)(g >> 27) + 1, (i32)(aux & 0xffff), spread)
                                 << ((aux >> 16) & 15));
@@ -2012,7 +2031,7 @@ OG_DEV void recon_leaves_fetch(const ParseRec *rec, const ReconCtx &rx, const Le
             *reinterpret_cast<og_v4i *>(&stage[j]) = *reinterpret_cast<const og_v4i *>(&lo->coef[c0 + j]);
         OG_SYNC();
         OG_FOR_LANES(t, n_leaves) {
-            const u32 g = t < OG_NLANES ? g0 : rec->leaf_geom[t], aux = t < OG_NLANES ? aux0 : rec->leaf_aux[t];
+            const u32 g = t < OG_NLANES ? g0 : rec->leaf[t].geom, aux = t < OG_NLANES ? aux0 : rec->leaf[t].aux;
             const int x = V_X + (int)(g & 2047), N = (int)(g >> 11) & 255, a = (int)(aux >> 20) - c0;
             const int j0 = OG_MAX(0, -a), j1 = OG_MIN(N, len - a); // the part of the leaf this chunk holds
             for (int j = j0; j < j1; j++) S.v[x + j] = stage[a + j];

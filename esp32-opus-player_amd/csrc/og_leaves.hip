@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(64 * LF, OG_LEAVES_WAVES * LF / 4) k_celt_leav
         u32 g = 0;
         int key = 0;
         if (have) {
-            g = rec->leaf_geom[t];
+            g = rec->leaf[t].geom;
             key = 63 - leaf_cost_class(g);
         }
         if (tid < 64) L.cnt[tid] = 0;
@@ -120,9 +120,9 @@ __global__ void __launch_bounds__(64 * LF, OG_LEAVES_WAVES * LF / 4) k_celt_leav
         __syncthreads();
         if (have) {
             const int slot = (int)(L.base[key] + mine);
-            L.idx[slot] = rec->leaf_idx[t];
+            L.idx[slot] = rec->leaf[t].idx;
             L.geom[slot] = g;
-            L.aux[slot] = rec->leaf_aux[t];
+            L.aux[slot] = rec->leaf[t].aux;
             L.meta[slot] = (u16)(wave | t << 3 | spread << 12);
         }
         __syncthreads();

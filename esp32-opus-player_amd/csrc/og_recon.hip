@@ -88,7 +88,7 @@ OG_DEV void leaf_pass_pooled(const ParseRec *rec, int n_leaves, int spread) {
         u32 g = 0;
         int key = 0;
         if (have) {
-            g = rec->leaf_geom[t];
+            g = rec->leaf[t].geom;
             key = 63 - leaf_cost_class(g);
         }
         if (tid < 64) pool_cnt()[tid] = 0;
@@ -110,9 +110,9 @@ OG_DEV void leaf_pass_pooled(const ParseRec *rec, int n_leaves, int spread) {
         __syncthreads();
         if (have) {
             const int slot = (int)(pool_base()[key] + mine);
-            pool_idx()[slot] = rec->leaf_idx[t];
+            pool_idx()[slot] = rec->leaf[t].idx;
             pool_geom()[slot] = g;
-            pool_aux()[slot] = rec->leaf_aux[t];
+            pool_aux()[slot] = rec->leaf[t].aux;
             pool_meta()[slot] = (u16)(wave | t << 2 | spread << 11);
         }
         __syncthreads();
@@ -156,9 +156,13 @@ __global__ void __launch_bounds__(64 * RG, OG_FAST_WAVES) k_celt_recon_fb(const 
         const FrameDesc d = descs[f];
         const int lane = OG_LANE;
         const i32 w_rec = reinterpret_cast<const i32 *>(rec)[lane < 16 ? lane : 15];
-        lg = rec->leaf_geom[lane];
-        la = rec->leaf_aux[lane];
-        li = rec->leaf_idx[lane];
+        {
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 lf = *reinterpret_cast<const u32x4 *>(&rec->leaf[lane]);
+            li = lf[0];
+            lg = lf[1];
+            la = lf[2];
+        }
         rx.pre_bandE = rec->bandE[lane < 2 * NBANDS ? lane : 0];
         rx.pre_pulses = rec->pulses[lane < NBANDS ? lane : 0];
         const int mode = desc_mode(d.flags);

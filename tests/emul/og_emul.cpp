@@ -24,12 +24,12 @@ static og::ParseRec rec; // the last frame's parse record (emu_last_leaf_geom)
 // the (position, n, k, blocks) words of the last CELT / hybrid frame's PVQ leaves, in the order the reconstruction takes them
 int emu_last_leaf_geom(unsigned *out, int cap) {
     const int n = rec.n_leaves < cap ? rec.n_leaves : cap;
-    for (int i = 0; i < n; i++) out[i] = rec.leaf_geom[i];
+    for (int i = 0; i < n; i++) out[i] = rec.leaf[i].geom;
     return rec.n_leaves;
 }
 int emu_last_leaf_idx(unsigned *out, int cap) { // ... and their codeword indices
     const int n = rec.n_leaves < cap ? rec.n_leaves : cap;
-    for (int i = 0; i < n; i++) out[i] = rec.leaf_idx[i];
+    for (int i = 0; i < n; i++) out[i] = rec.leaf[i].idx;
     return rec.n_leaves;
 }
 int emu_decode_frame(void *stv, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm) {
