@@ -40,9 +40,16 @@ class OverlappedPageDecode:
         self.host = [None] * self.depth  # page-locked uint8 arrays
 
     def reserve(self, nbytes):
-        """Make every slot at least nbytes large now (page-locking and hipMalloc then stay out of the run)."""
+        """Make every slot at least nbytes large now (page-locking and hipMalloc then stay out of the run) -- and let the copy stream
+        carry its first upload and fence here: creating the stream and the first transfer out of a slot cost milliseconds once."""
         for i in range(self.depth):
-            self._slot(i, nbytes)
+            host, dev = self._slot(i, nbytes)
+            base = dev.value if isinstance(dev, C.c_void_p) else int(dev)
+            self.ctx.upload_async(C.c_void_p(base), host[:4096])
+        e = self.ctx.event()
+        self.ctx.upload_fence(e)
+        self.ctx.event_synchronize(e)
+        self.ctx.event_destroy(e)
 
     def _slot(self, i, need):
         if self.host[i] is None or self.host[i].nbytes < need:
@@ -103,10 +110,14 @@ class OverlappedPageDecode:
                     t2 = time.perf_counter()
                     counts, mc = [], []
                     for k in range(pb.n_steps):
-                        m = pb.step(k)[0]["flags"] & 3
-                        counts.append(len(m))
-                        grouped = len(m) < 2 or not (np.diff(m.astype(np.int8)) < 0).any()
-                        mc.append((int((m == 0).sum()), int((m == 1).sum())) if grouped else (-1, -1))
+                        fl = pb.step(k)[0]["flags"]
+                        counts.append(len(fl))
+                        if self.keeps_mode and self.by_kind:  # (per-mode counts: only the sub-step flow reads them -- and this thread
+                            m = fl & 3                        #  shares the interpreter with the one that launches the decode steps)
+                            grouped = len(m) < 2 or not (np.diff(m.astype(np.int8)) < 0).any()
+                            mc.append((int((m == 0).sum()), int((m == 1).sum())) if grouped else (-1, -1))
+                        else:
+                            mc.append((-1, -1))
                     base = dev.value if isinstance(dev, C.c_void_p) else int(dev)
                     ctx.upload_async(C.c_void_p(base), pb.image)
                     fence = ctx.event()
