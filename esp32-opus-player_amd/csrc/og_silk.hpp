@@ -1027,7 +1027,12 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
             // 24-bit multiplies, a shift and an add stood; the shifted accumulator arrives through the add's own DPP operand.  Four
             // samples per trip (a subframe is 40, 60 or 80): their residuals come as one 16-byte read a trip ahead, their outputs
             // leave as one 16-byte write.  7 vector instructions per sample (12 before), in the kernel's longest serial loop.
+            // The rounding offset rides in the accumulators: every R_j carries it, and lane 15 -- whose shifted-in neighbour is the
+            // zero beyond the row -- gets it back through the product's 64-bit addend (v_mad_i64_i32: the high word of
+            // sn * A16 + (bias << 32) is mul_hi + bias), so the prediction needs no add of its own: 6 instructions per sample.
             const i32 A16 = shl32(A_j, 16);
+            const i64 bias_in = (i64)(j == 15 ? bias : 0) << 32;
+            R = addw(R, bias);
             typedef i32 i32x4 __attribute__((ext_vector_type(4)));
             i32x4 rq = *reinterpret_cast<const i32x4 *>(&resb[0]);
 #pragma unroll 2
@@ -1036,12 +1041,14 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
                 i32x4 sv;
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
-                    const i32 LPC_pred_Q10 = addw(R, bias);            // (lane 0's is the prediction)
-                    const i32 sn0 = __builtin_elementwise_add_sat(rq[t], lshift_sat32(LPC_pred_Q10, 4));
+                    const i32 sn0 = __builtin_elementwise_add_sat(rq[t], lshift_sat32(R, 4)); // (lane 0's R is the prediction, offset included)
                     const i32 sn = OG_ROW_BCAST(sn0, 0);
                     sv[t] = sn; // the residual is consumed: its slot keeps the sample (output scaling, next history); every lane
                                 // of the row stores the same value to the same word
-                    R = addw(__builtin_amdgcn_update_dpp(0, R, 0x101 /* row_shl:1 */, 0xf, 0xf, true), smmul(sn, A16));
+                    i64 prod;
+                    u64 carry;
+                    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(prod), "=s"(carry) : "v"(sn), "v"(A16), "v"(bias_in));
+                    R = addw(__builtin_amdgcn_update_dpp(0, R, 0x101 /* row_shl:1 */, 0xf, 0xf, true), (i32)(prod >> 32));
                 }
                 *reinterpret_cast<i32x4 *>(&resb[i]) = sv;
                 rq = nx;
