@@ -300,8 +300,14 @@ static int pages_demux_impl(int n_pages, const uint8_t *const *pages, const int3
         timer.mark("pass 2: chain streams");
         // slots: per step, pages in input order -- or grouped by mode first (three stable groups)
         const bool group = (flags & (OPUSGPU_PAGES_GROUP_BY_MODE | OPUSGPU_PAGES_ORDER_BY_HEADER)) != 0;
-        const int G = group ? 3 : 1;
-        RawBuf<uint8_t> mode_of; // mode (0..2) per frame of every page, only when grouping
+        // ORDER_BY_HEADER: within a step's SILK-only group and its hybrid group, frames in the order of their LBRR flags -- the range
+        // coder's second and fourth symbol, each of probability 1/2, i.e. bits 6 and 4 of the frame's first byte (reference
+        // src/silk.cpp:1568-1573; a mono frame has only the first) -- stable otherwise.  An LBRR frame is a whole extra frame of side
+        // information and pulses to read past (:1590-1616): 32 frames that agree on it make a parse wave that skips those passes
+        // together.  The flags are four sub-keys of the counting sort below (SILK 0..3, hybrid 4..7, CELT 8), not a pass of their own.
+        const bool by_header = (flags & OPUSGPU_PAGES_ORDER_BY_HEADER) != 0;
+        const int G = group ? (by_header ? 9 : 3) : 1;
+        RawBuf<uint8_t> mode_of; // sort key within a step (mode 0..2, or the nine keys above) per frame of every page, only when grouping
         std::vector<size_t> frame_at((size_t)n_pages + 1, 0);
         for (int i = 0; i < n_pages; i++) {
             frame_at[i + 1] = frame_at[i] + (scan[i].status > 0 ? scan[i].status : 0);
@@ -316,6 +322,19 @@ static int pages_demux_impl(int n_pages, const uint8_t *const *pages, const int3
             parallel_for(n_pages, threads, [&](int lo, int hi) {
                 for (int i = lo; i < hi; i++) {
                     if (scan[i].status <= 0) continue;
+                    if (by_header) { // the key needs every frame's first byte: the lacing walk again (no checksum this time)
+                        const uint8_t *body = pages[i] + scan[i].header_len;
+                        scan_page(pages[i], page_lens[i], 0, nullptr, [&](int k, int32_t off, int32_t len, int32_t fl) {
+                            const int mode = fl & 3;
+                            int key = mode == 2 ? 8 : 4 * mode;
+                            if (mode != 2 && len > 0) {
+                                const uint8_t b0 = body[off];
+                                key += (int)((b0 >> 6) & 1) | ((fl & 32) ? (int)((b0 >> 4) & 1) << 1 : 0);
+                            }
+                            mode_of[frame_at[i] + k] = (uint8_t)key;
+                        });
+                        continue;
+                    }
                     const int nf = scan[i].status < 32 ? scan[i].status : 32;
                     for (int k = 0; k < nf; k++) mode_of[frame_at[i] + k] = (uint8_t)((scan[i].modes >> (2 * k)) & 3);
                     if (scan[i].status > 32) // rare: scan the page again for the rest
@@ -402,38 +421,6 @@ static int pages_demux_impl(int n_pages, const uint8_t *const *pages, const int3
             }
         });
         timer.mark("pass 3: bodies + descriptors");
-        if (flags & OPUSGPU_PAGES_ORDER_BY_HEADER) {
-            // Within a step's SILK-only group and its hybrid group: frames in the order of their LBRR flags -- the range coder's second
-            // and fourth symbol, each of probability 1/2, i.e. bits 6 and 4 of the frame's first byte (reference src/silk.cpp:1568-1573;
-            // a mono frame has only the first) -- stable otherwise.  An LBRR frame is a whole extra frame of side information and
-            // pulses to read past (:1590-1616): 32 frames that agree on it make a parse wave that skips those passes together.
-            const uint8_t *arena = b->arena.data();
-            parallel_for(n_steps, threads, [&](int lo, int hi) {
-                std::vector<opusgpu_frame_desc> td;
-                std::vector<int32_t> tp;
-                for (int s = lo; s < hi; s++)
-                    for (int g = 0; g < 2; g++) {
-                        const size_t r0 = count[(size_t)s * G + g], r1 = count[(size_t)s * G + g + 1];
-                        if (r1 - r0 < 2) continue;
-                        auto key = [&](const opusgpu_frame_desc &d) {
-                            if (d.len <= 0) return 0;
-                            const uint8_t b0 = arena[d.offset];
-                            return (int)((b0 >> 6) & 1) | ((d.flags & 32) ? (int)((b0 >> 4) & 1) << 1 : 0);
-                        };
-                        size_t at[5] = {0, 0, 0, 0, 0};
-                        for (size_t j = r0; j < r1; j++) at[key(b->descs[j]) + 1]++;
-                        for (int k = 0; k < 4; k++) at[k + 1] += at[k];
-                        td.assign(b->descs.data() + r0, b->descs.data() + r1);
-                        tp.assign(b->slot_pages.data() + r0, b->slot_pages.data() + r1);
-                        for (size_t j = 0; j < r1 - r0; j++) {
-                            const size_t to = r0 + at[key(td[j])]++;
-                            b->descs[to] = td[j];
-                            b->slot_pages[to] = tp[j];
-                        }
-                    }
-            });
-            timer.mark("order by header");
-        }
         if (arena_bytes > 0x7fffffffu) { // descriptor offsets are 32-bit: split the call
             delete b;
             return OPUSGPU_BAD_ARG;
