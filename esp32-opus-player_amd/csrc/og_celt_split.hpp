@@ -63,14 +63,16 @@ enum {
 // Hybrid frames: the single-kernel path decodes the SILK half (wave per frame), then hands the live range decoder and
 // the SILK PCM over to the split path, which decodes the CELT half (bands 17..20) and mixes the two in k_celt_post.
 struct SilkHandoff {
+    // SILK output at 48 kHz, interleaved over the packet's channels; first and on a line boundary of the memory system: the
+    // synthesis kernel writes it and k_celt_post reads it in 128-byte pieces (at offset 48 of a 3,888-byte record every piece was two lines)
+    alignas(128) i16 pcm[1920];
     u32 valid; // 1: SILK half decoded, coder state below is live
     u32 storage, end_offs, end_window;
     i32 nend_bits, nbits_total;
     u32 offs, rng, val, ext;
     i32 rem, error;
-    i16 pcm[1920]; // SILK output at 48 kHz, interleaved over the packet's channels
 };
-static_assert(sizeof(SilkHandoff) % 16 == 0 && offsetof(SilkHandoff, pcm) % 16 == 0, "handoff alignment");
+static_assert(sizeof(SilkHandoff) % 128 == 0 && offsetof(SilkHandoff, pcm) == 0, "handoff alignment");
 
 struct ParseRec {
     i32 ret;       // samples per channel (960) -- or the negative code the frame ends with

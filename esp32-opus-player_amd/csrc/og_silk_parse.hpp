@@ -34,7 +34,7 @@ struct SilkRecCh {
     i16 pulses[SILK_REC_FRAME + 16];
 };
 constexpr int SILK_REC_CTRL_WORDS = 4 + 4 + SILK_REC_LPC + 10 + 1 + 8 + 4 + 4 + SILK_REC_LPC + 1;
-struct SilkRec {
+struct alignas(128) SilkRec { // (a record starts on a line boundary of the memory system: the synthesis wave fetches it whole)
     i32 ret; // 0, or the negative code the frame ends with (then nothing else is valid)
     i32 decode_only_middle;
     i32 MS_pred_Q13[2];

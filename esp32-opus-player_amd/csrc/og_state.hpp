@@ -18,7 +18,9 @@ constexpr int RING = 2048;
 constexpr int RING_MASK = RING - 1;
 
 struct CeltState {             // replaces CELTDecoder_t + trailing arrays (src/celt.h:150-171, celt.cpp:2202)
-    i32 ring[2][RING];         // comb-filtered synthesis output history (the live part of _decode_mem)
+    alignas(128) i32 ring[2][RING]; // comb-filtered synthesis output history (the live part of _decode_mem); on a line boundary of the
+                               // memory system: k_celt_post and the comb filter read it in 128-byte pieces (misaligned, every piece
+                               // was two lines: 12.8 KB fetched per frame for 7.7 KB read)
     i32 tail[2][64];           // IMDCT overlap tail out_syn[N..N+60) carried to the next frame
     i32 deemph[2];             // preemph_memD
     u32 rng;
