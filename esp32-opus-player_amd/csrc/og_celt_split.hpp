@@ -732,8 +732,8 @@ OG_DEV void rotate1_lane(i16 *xv, int x, int len, int stride, i32 c, i32 s) { //
 // U(a, b) for the leaf pass.  64 lanes walking 64 different leaves ask for 64 unrelated entries per step: from global
 // memory that is one cache line per lane and the texture path serialises them (measured: a third of the walk at best, with
 // the dense table evicted from L1 by the streaming traffic all the time).  Here rows 0..3 are closed forms and rows 4..14
-// sit in LDS, stored by ROW (rom_pvq_rr / rom_pvq_rb, 2.4 KB over the folding-history, pulse and scratch rows, none of
-// which is in use during the leaf pass): U(lo, hi) = rr[rb[lo] + hi].  Round 2 stored columns (one base per dimension n,
+// sit in LDS, stored by ROW with every column (rom_pvq_rr / rom_pvq_rb, 2.8 KB over the folding-history, pulse and scratch rows,
+// none of which is in use during the leaf pass): U(r, c) = rr[rb[r] + c] for r = 4 .. 14 and any c.  Round 2 stored columns (one base per dimension n,
 // fetched a step ahead); what the walk spends its time on since zero runs are skipped is the SEARCH for the next pulse's
 // dimension at a fixed number of pulses k, i.e. along rows k and k + 1: with rows, a probe is two independent reads off two
 // bases that change only when k does (a column base per probe made it two dependent round trips), a pulse's size candidates
@@ -772,10 +772,22 @@ OG_DEV u32 pvq_row_sel(int r, u32 v2, u32 v3) {
     v = r == 2 ? v2 : v;
     return r == 3 ? v3 : v;
 }
+// U(3, h) = 2 h (h - 1) + 1 and the integer root the k = 2 zero run needs.  On the GPU: one 24-bit multiply-add (the compiler's own
+// form of the expression is two masks and a full 32-bit multiply), and the bare v_sqrt_f32 -- one ulp, where the precise sqrtf is a
+// dozen instructions of rounding fix-ups: its argument is below 2^15 here (tq <= 176^2), where neighbouring integers' roots are
+// 0.0028 apart at least and a float's ulp is 2^-16, so the truncated result is the root's floor, or one less when the root is an
+// integer -- which the caller's upward correction covers.
 #ifdef OG_HOST_EMUL
-OG_DEV u32 pvq_mul(u32 a, u32 b) { return a * b; }
+OG_DEV u32 pvq_u3(u32 h) { return 2u * h * (h - 1u) + 1u; }
+OG_DEV int pvq_isqrt_near(u32 tq) { return (int)__builtin_sqrtf((float)tq); }
 #else
-OG_DEV u32 pvq_mul(u32 a, u32 b) { return __umul24(a, b); } // both below 256
+OG_DEV u32 pvq_u3(u32 h) { // h < 2^11
+    u32 r;
+    const u32 a = h << 1, b = h - 1u;
+    asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+OG_DEV int pvq_isqrt_near(u32 tq) { return (int)__builtin_amdgcn_sqrtf((float)tq); }
 #endif
 OG_DEV int pvq_row_base(const PvqLds &T, int r) { return (int)T.rb[r < 4 ? 4 : (r > 14 ? 14 : r)]; } // (rows outside 4..14 are not table rows)
 
@@ -801,7 +813,7 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
     int b0 = pvq_row_base(T, k), b1 = pvq_row_base(T, k + 1); // where rows k and k + 1 start (while they are table rows)
     while (n > 2) {
         if (k == 0) break; // every pulse is placed: what is left of the leaf stays zero
-        u32 h = (u32)n, v2 = 2u * h - 1u, v3 = 2u * pvq_mul(h, h - 1u) + 1u; // U(2, n), U(3, n)
+        u32 h = (u32)n, v2 = 2u * h - 1u, v3 = pvq_u3(h); // U(2, n), U(3, n)
         if (n > k) {
             u32 c0 = T.rr[k >= 4 ? b0 + n : 0], c1 = T.rr[k >= 3 ? b1 + n : 0];
             u32 p0 = k >= 4 ? c0 : pvq_row_sel(k, v2, v3), p1 = k >= 3 ? c1 : pvq_row_sel(k + 1, v2, v3); // U(k, n), U(k + 1, n)
@@ -820,45 +832,43 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
                 const u32 Vn = p0 + p1, t = Vn - i, m = i >= t ? i - t + 1u : t - i;
                 const int lo0 = k + 1 > 2 ? k + 1 : 2;
                 int a;
-                u32 Va;
+                u32 t0 = p0, t1 = p1; // U(k, a), U(k + 1, a) of the dimension a the run ends at: the step below needs no second look
                 if (k <= 2) { // V(a, 1) = 2 a and V(a, 2) = 2 a^2: solved, not searched (m <= V(n) <= 2 * 176^2)
                     const u32 tq = (m + 1u) >> 1;
                     int r = (int)tq;
                     if (k == 2) {
-                        r = (int)__builtin_sqrtf((float)tq); // within one of the root (tq < 2^24 is exact as a float): its ceiling after
-                        r += (u32)(r * r) < tq;              // the two corrections
-                        r -= r > 0 && (u32)((r - 1) * (r - 1)) >= tq;
+                        r = pvq_isqrt_near(tq);  // the root's floor, or one less (tq <= 176^2): its ceiling after
+                        r += (u32)(r * r) < tq; // the correction
                     }
                     a = r > lo0 ? r : lo0;
-                    Va = k == 1 ? 2u * (u32)a : 2u * (u32)(a * a);
+                    const u32 u2 = 2u * (u32)a - 1u;
+                    t0 = k == 1 ? 1u : u2;
+                    t1 = k == 1 ? u2 : pvq_u3((u32)a);
                 } else {
                     int lo = lo0, hi = n;
-                    Va = Vn;
                     while (lo < hi) {
                         const int mid = (lo + hi) >> 1;
                         const u32 m0 = T.rr[k >= 4 ? b0 + mid : 0], m1 = T.rr[b1 + mid];
-                        const u32 a0 = k >= 4 ? m0 : 2u * pvq_mul((u32)mid, (u32)mid - 1u) + 1u; // (row 3 in closed form)
-                        const u32 Vm = a0 + m1;
-                        if (Vm >= m) {
+                        const u32 a0 = k >= 4 ? m0 : pvq_u3((u32)mid); // (row 3 in closed form)
+                        if (a0 + m1 >= m) {
                             hi = mid;
-                            Va = Vm;
+                            t0 = a0;
+                            t1 = m1;
                         } else
                             lo = mid + 1;
                     }
                     a = lo;
                 }
                 if (a < n) {
-                    i -= (Vn - Va) >> 1;
+                    i -= (Vn - (t0 + t1)) >> 1;
                     pos += n - a;
                     n = a;
                     if (n <= 2) break;
                     h = (u32)n;
                     v2 = 2u * h - 1u;
-                    v3 = 2u * pvq_mul(h, h - 1u) + 1u;
-                    c0 = T.rr[k >= 4 ? b0 + n : 0];
-                    c1 = T.rr[k >= 3 ? b1 + n : 0];
-                    p0 = k >= 4 ? c0 : pvq_row_sel(k, v2, v3);
-                    p1 = k >= 3 ? c1 : pvq_row_sel(k + 1, v2, v3);
+                    v3 = pvq_u3(h);
+                    p0 = t0;
+                    p1 = t1;
                 }
             }
 #endif
@@ -902,12 +912,13 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
                 b0 = pvq_row_base(T, k);
                 b1 = pvq_row_base(T, k + 1);
             }
-        } else { // n <= k: U(n, k) and U(n, k + 1) are neighbours in row n (and the search runs along that row while k' >= n)
+        } else { // n <= k: everything this step reads lies in row n, whose columns are all in LDS (n == 3: U(3, c) = 2 c (c - 1) + 1)
             const u32 hk = (u32)k;
             const int bn = pvq_row_base(T, n);
-            const u32 a0 = T.rr[n >= 4 ? bn + k : 0], a1 = T.rr[n >= 4 ? bn + k + 1 : 0];
-            const u32 p0 = n >= 4 ? a0 : pvq_row_sel(n, 2u * hk - 1u, 2u * pvq_mul(hk, hk - 1u) + 1u);
-            const u32 p1 = n >= 4 ? a1 : pvq_row_sel(n, 2u * hk + 1u, 2u * pvq_mul(hk + 1u, hk) + 1u);
+            const bool tab = n >= 4;
+            const u32 a0 = T.rr[tab ? bn + k : 0], a1 = T.rr[tab ? bn + k + 1 : 0];
+            const u32 p0 = tab ? a0 : pvq_u3(hk);
+            const u32 p1 = tab ? a1 : pvq_u3(hk + 1u);
             const int s = -(int)(i >= p1);
             i -= p1 & (u32)s;
             if (p0 <= i && s == 0) {
@@ -917,11 +928,10 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
                 int lo = 0, hi = k - 1; // U(n, 0) = 0 <= i; U(n, k) > i here
                 u32 plo = 0;
                 while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    const int r = n < mid ? n : mid;
+                    const int mid = (lo + hi + 1) >> 1; // >= 1
                     const u32 hm = (u32)mid;
-                    const u32 tm = T.rr[r >= 4 ? (n < mid ? bn + mid : pvq_row_base(T, mid) + n) : 0];
-                    const u32 pm = r >= 4 ? tm : (n < mid ? pvq_row_sel(n, 2u * hm - 1u, 2u * pvq_mul(hm, hm - 1u) + 1u) : pvq_row_sel(mid, v2, v3));
+                    const u32 tm = T.rr[tab ? bn + mid : 0];
+                    const u32 pm = tab ? tm : pvq_u3(hm);
                     if (pm <= i) {
                         lo = mid;
                         plo = pm;

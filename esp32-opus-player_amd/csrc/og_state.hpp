@@ -190,7 +190,7 @@ constexpr int V_TMP = V_IY + 200;       // scratch row (Hadamard), 200 entries
 // anti-collapse and the start of the synthesis read.  (The synthesis buffer later runs over them: they are dead by then.)
 constexpr int V_LATE = V_IY;
 constexpr int V_WIN = V_TMP + 200;      // window of the record's word stream (64 x u32; fill jobs), where the PVQ table's end was
-constexpr int V_MASK = V_NORM + 1380;   // per-leaf collapse masks (416 x u16: jobs with both kinds of leaves read them while they
+constexpr int V_MASK = V_NORM + 1408;   // per-leaf collapse masks (416 x u16: jobs with both kinds of leaves read them while they
                                         // fill); later the synthesis gains
 constexpr int V_TOTAL = V_MASK + 416;
 constexpr int V_SYN = 960;              // the synthesis buffer: second channel's spectrum + 2432 bytes behind X

@@ -69,21 +69,25 @@ def pvq_u_table(rows=15, cols=177):
     return [U[n][k] & 0xFFFFFFFF for n in range(rows) for k in range(cols)]
 
 def pvq_u_rows():
-    """U(lo, hi) for lo = 4 .. 14 stored by ROW lo (columns hi = lo .. the last one whose entry fits 32 bits), rows back to back
-    behind 4 unused words: entry (lo, hi) is at RB[lo] + hi.  What the leaf walk of the split path searches at a fixed number of
-    pulses k -- the next pulse's dimension -- lies along rows k and k + 1, so a probe is two independent reads off two bases
-    that only change when k does; the candidates of a pulse's size (rows 4 .. 7 at one column) need no base look-up at all.
-    Rows 0..3 have closed forms (0 / 1 / 2h-1 / 2h(h-1)+1).  Returns (table, RB[0..15])."""
+    """U(lo, hi) for lo = 4 .. 14 stored by ROW lo, every column hi = 0 .. the last one whose entry fits 32 bits, rows back to back:
+    entry (lo, hi) is at RB[lo] + hi.  What the leaf walk of the split path searches at a fixed number of pulses k < n -- the next
+    pulse's dimension -- lies along rows k and k + 1, so a probe is two independent reads off two bases that only change when k
+    does; the candidates of a pulse's size (rows 4 .. 7 at one column) need no base look-up at all; and a leaf with n <= k
+    dimensions left searches its pulse's size along row n alone, which is why the rows are complete (U is symmetric: the columns
+    below lo repeat entries of earlier rows, 99 words).  Rows 0..3 have closed forms (0 / 1 / 2h-1 / 2h(h-1)+1).
+    Returns (table, RB[0..15])."""
     cols = 177
     U = [[0] * cols for _ in range(cols)]
     U[0][0] = 1
     for n in range(1, cols):
         for k in range(1, cols):
             U[n][k] = U[n - 1][k] + U[n][k - 1] + U[n - 1][k - 1]
-    tab, rb = [0, 0, 0, 0], [0] * 16
+    tab, rb = [], [0] * 16
     for lo in range(4, 15):
-        rb[lo] = len(tab) - lo
-        tab += [U[lo][hi] for hi in range(lo, cols) if U[lo][hi] < 2 ** 32]
+        rb[lo] = len(tab)
+        row = [U[lo][hi] for hi in range(cols)]
+        assert all(a <= b for a, b in zip(row, row[1:]))
+        tab += [v for v in row if v < 2 ** 32]
     for lo in range(4):
         rb[lo] = rb[4]
     rb[15] = rb[14]
