@@ -1051,6 +1051,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     if (!ctx || n < 0 || !ctx->d_streams) return OPUSGPU_BAD_ARG;
     if (n == 0) return OPUSGPU_OK;
     if (!d_descs || !d_arena || !d_pcm || !d_result) return OPUSGPU_BAD_ARG;
+    if ((uintptr_t)d_arena & 15) return OPUSGPU_BAD_ARG; // (the parse kernels fetch packets as aligned 16-byte pieces, og_range.hpp)
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
     const int pcm_stride = (ctx->mode == OPUSGPU_MODE_RFC ? OPUSGPU_RFC_FRAME_SAMPLES : OPUSGPU_FRAME_SAMPLES) * ctx->channels;
     ctx->last_descs = d_descs;

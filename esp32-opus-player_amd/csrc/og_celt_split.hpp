@@ -661,69 +661,120 @@ OG_DEV i32 rot_dot2(u32 pair, u32 coef, i32 half) {
     return r >> 15;
 }
 OG_DEV u32 rot_pack(i32 lo, i32 hi) { return __builtin_amdgcn_perm((u32)hi, (u32)lo, 0x05040100u); } // low halves of both
+// one chain r, r + stride, r + 2 stride, .. of exp_rotation1 (celt.cpp:684): forward, then backward
+OG_DEV void rotate_chain(i16 *const p0, int r, int len, int stride, u32 k_a, u32 k_b) {
+    const i32 half = 16384;
+    // forward along the chain: pairs (i, i + stride) while i < len - stride
+    int i = r, steps = 0;
+    i32 x1 = p0[i];
+    for (; i + 3 * stride < len - stride; i += 4 * stride, steps += 4) {
+        const i32 e1 = p0[i + stride], e2 = p0[i + 2 * stride], e3 = p0[i + 3 * stride], e4 = p0[i + 4 * stride];
+        u32 pk = rot_pack(x1, e1);
+        const i32 o0 = rot_dot2(pk, k_a, half);
+        x1 = rot_dot2(pk, k_b, half);
+        pk = rot_pack(x1, e2);
+        const i32 o1 = rot_dot2(pk, k_a, half);
+        x1 = rot_dot2(pk, k_b, half);
+        pk = rot_pack(x1, e3);
+        const i32 o2 = rot_dot2(pk, k_a, half);
+        x1 = rot_dot2(pk, k_b, half);
+        pk = rot_pack(x1, e4);
+        const i32 o3 = rot_dot2(pk, k_a, half);
+        x1 = rot_dot2(pk, k_b, half);
+        p0[i] = (i16)o0;
+        p0[i + stride] = (i16)o1;
+        p0[i + 2 * stride] = (i16)o2;
+        p0[i + 3 * stride] = (i16)o3;
+    }
+    for (; i < len - stride; i += stride, steps++) {
+        const u32 pk = rot_pack(x1, p0[i + stride]);
+        p0[i] = (i16)rot_dot2(pk, k_a, half);
+        x1 = rot_dot2(pk, k_b, half);
+    }
+    p0[i] = (i16)x1;
+    // backward: pairs (i, i + stride) from the chain's highest i <= len - 2 stride - 1 down to r -- one pair fewer than forward
+    if (steps >= 2) {
+        i -= 2 * stride; // (forward ended on the chain's last element, r + steps * stride)
+        i32 x2 = p0[i + stride];
+        for (; i - 3 * stride >= 0; i -= 4 * stride) {
+            const i32 e1 = p0[i], e2 = p0[i - stride], e3 = p0[i - 2 * stride], e4 = p0[i - 3 * stride];
+            u32 pk = rot_pack(e1, x2); // (x1, x2) = (element i, carried): second output goes to i + stride, first is carried down
+            const i32 o0 = rot_dot2(pk, k_b, half);
+            x2 = rot_dot2(pk, k_a, half);
+            pk = rot_pack(e2, x2);
+            const i32 o1 = rot_dot2(pk, k_b, half);
+            x2 = rot_dot2(pk, k_a, half);
+            pk = rot_pack(e3, x2);
+            const i32 o2 = rot_dot2(pk, k_b, half);
+            x2 = rot_dot2(pk, k_a, half);
+            pk = rot_pack(e4, x2);
+            const i32 o3 = rot_dot2(pk, k_b, half);
+            x2 = rot_dot2(pk, k_a, half);
+            p0[i + stride] = (i16)o0;
+            p0[i] = (i16)o1;
+            p0[i - stride] = (i16)o2;
+            p0[i - 2 * stride] = (i16)o3;
+        }
+        for (; i >= 0; i -= stride) {
+            const u32 pk = rot_pack(p0[i], x2);
+            p0[i + stride] = (i16)rot_dot2(pk, k_b, half);
+            x2 = rot_dot2(pk, k_a, half);
+        }
+        p0[r] = (i16)x2;
+    }
+}
 OG_DEV void rotate1_lane(i16 *xv, int x, int len, int stride, i32 c, i32 s) { // exp_rotation1 celt.cpp:684
     const u32 k_a = rot_pack(c, -s), k_b = rot_pack(s, c); // first output: c x1 - s x2; second (carried on): s x1 + c x2
-    const i32 half = 16384;
-    i16 *const p0 = xv + x;
     for (int r = 0; r < stride; r++) {
         if (r >= len - stride) break; // (the chains are in order: no later one has a pair either)
-        // forward along the chain r, r + stride, ..: pairs (i, i + stride) while i < len - stride
-        int i = r, steps = 0;
-        i32 x1 = p0[i];
-        for (; i + 3 * stride < len - stride; i += 4 * stride, steps += 4) {
-            const i32 e1 = p0[i + stride], e2 = p0[i + 2 * stride], e3 = p0[i + 3 * stride], e4 = p0[i + 4 * stride];
-            u32 pk = rot_pack(x1, e1);
-            const i32 o0 = rot_dot2(pk, k_a, half);
-            x1 = rot_dot2(pk, k_b, half);
-            pk = rot_pack(x1, e2);
-            const i32 o1 = rot_dot2(pk, k_a, half);
-            x1 = rot_dot2(pk, k_b, half);
-            pk = rot_pack(x1, e3);
-            const i32 o2 = rot_dot2(pk, k_a, half);
-            x1 = rot_dot2(pk, k_b, half);
-            pk = rot_pack(x1, e4);
-            const i32 o3 = rot_dot2(pk, k_a, half);
-            x1 = rot_dot2(pk, k_b, half);
-            p0[i] = (i16)o0;
-            p0[i + stride] = (i16)o1;
-            p0[i + 2 * stride] = (i16)o2;
-            p0[i + 3 * stride] = (i16)o3;
-        }
-        for (; i < len - stride; i += stride, steps++) {
-            const u32 pk = rot_pack(x1, p0[i + stride]);
-            p0[i] = (i16)rot_dot2(pk, k_a, half);
-            x1 = rot_dot2(pk, k_b, half);
-        }
-        p0[i] = (i16)x1;
-        // backward: pairs (i, i + stride) from the chain's highest i <= len - 2 stride - 1 down to r -- one pair fewer than forward
-        if (steps >= 2) {
-            i -= 2 * stride; // (forward ended on the chain's last element, r + steps * stride)
-            i32 x2 = p0[i + stride];
-            for (; i - 3 * stride >= 0; i -= 4 * stride) {
-                const i32 e1 = p0[i], e2 = p0[i - stride], e3 = p0[i - 2 * stride], e4 = p0[i - 3 * stride];
-                u32 pk = rot_pack(e1, x2); // (x1, x2) = (element i, carried): second output goes to i + stride, first is carried down
-                const i32 o0 = rot_dot2(pk, k_b, half);
-                x2 = rot_dot2(pk, k_a, half);
-                pk = rot_pack(e2, x2);
-                const i32 o1 = rot_dot2(pk, k_b, half);
-                x2 = rot_dot2(pk, k_a, half);
-                pk = rot_pack(e3, x2);
-                const i32 o2 = rot_dot2(pk, k_b, half);
-                x2 = rot_dot2(pk, k_a, half);
-                pk = rot_pack(e4, x2);
-                const i32 o3 = rot_dot2(pk, k_b, half);
-                x2 = rot_dot2(pk, k_a, half);
-                p0[i + stride] = (i16)o0;
-                p0[i] = (i16)o1;
-                p0[i - stride] = (i16)o2;
-                p0[i - 2 * stride] = (i16)o3;
+        rotate_chain(xv + x, r, len, stride, k_a, k_b);
+    }
+}
+
+// A leaf's spreading rotation, put off to the wave pass below (on == false: the leaf has none).
+struct RotJob {
+    int x, blen, logB, stride2; // first coefficient, block length, log2 of the block count, the wide stride (0: only stride 1)
+    i32 c, s;
+    bool on;
+};
+// The rotations of the (up to 64) leaves the lanes of a wave have just decoded, by the WHOLE wave.  One leaf per lane costs the wave
+// its largest rotated leaf's 4 N serial steps with eight lanes busy (a frame of the bench payloads rotates 8 of its 48 leaves:
+// 103 steps for the largest on average).  But exp_rotation (celt.cpp:707) is B independent blocks, and its wide-stride sweep
+// is `stride2` independent chains per block (rotate1_lane): here every (leaf, block, chain) of the wide sweeps gets a lane of its
+// own (6 steps for the longest chain instead of 50), then every (leaf, block) one for the stride-1 sweep, which is serial (47
+// steps).  How an item finds its leaf: the leaves' item counts are prefix-summed over the wave; a leaf's lane marks the first
+// of its items in a 64-byte row of LDS with its own number, a prefix maximum over that row names every item's leaf, and the
+// leaf's job comes over the lane crossbar.  All 64 lanes call this together.
+OG_DEV void pvq_rotate_wave(i16 *xv, const RotJob &j, u8 *marker) {
+    if (!__any(j.on)) return;
+    const int lane = OG_LANE;
+    const int w_geo = j.x | j.blen << 16, w_par = j.logB | j.stride2 << 8;
+    const int w_cs = (int)((u32)(u16)j.c | (u32)(u16)j.s << 16);
+    for (int pass = 0; pass < 2; pass++) { // the wide stride first (exp_rotation with dir = -1)
+        int chains = 0;
+        if (j.on) chains = pass == 0 ? (j.stride2 ? OG_MAX(0, OG_MIN(j.stride2, j.blen - j.stride2)) : 0) : (j.blen >= 2);
+        const int cnt = chains << j.logB; // items: chain r of block b is item r << logB | b
+        const int incl = wave_scan_add(cnt), excl = incl - cnt;
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        for (int base = 0; base < total; base += 64) {
+            marker[lane] = 0;
+            OG_SYNC();
+            if (cnt > 0 && excl < base + 64 && incl > base) marker[OG_MAX(excl - base, 0)] = (u8)(lane + 1);
+            OG_SYNC();
+            const int leaf = wave_scan_max((int)marker[lane]) - 1; // (>= 0: item `base` belongs to some leaf)
+            const int item = base + lane;
+            const bool work = item < total;
+            const int src = leaf < 0 ? lane : leaf;
+            const int g = __shfl(w_geo, src), q = __shfl(w_par, src), cs = __shfl(w_cs, src), first = __shfl(excl, src);
+            if (work) {
+                const int logB = q & 255, sub = item - first, b = sub & ((1 << logB) - 1), r = sub >> logB;
+                const int blen = g >> 16;
+                const i32 c = (i32)(i16)(cs & 0xffff), sn = (i32)(i16)(cs >> 16);
+                i16 *const p0 = xv + (g & 0xffff) + b * blen;
+                const i32 cc = pass == 0 ? sn : c, ss = pass == 0 ? c : sn; // exp_rotation1(.., stride2, s, c), then (.., 1, c, s)
+                rotate_chain(p0, r, blen, pass == 0 ? q >> 8 : 1, rot_pack(cc, -ss), rot_pack(ss, cc));
             }
-            for (; i >= 0; i -= stride) {
-                const u32 pk = rot_pack(p0[i], x2);
-                p0[i + stride] = (i16)rot_dot2(pk, k_b, half);
-                x2 = rot_dot2(pk, k_a, half);
-            }
-            p0[r] = (i16)x2;
+            OG_SYNC();
         }
     }
 }
@@ -799,7 +850,11 @@ OG_DEV int pvq_row_base(const PvqLds &T, int r) { return (int)T.rb[r < 4 ? 4 : (
 #endif
 // `xv`: the spectrum arena of the leaf's frame (the calling wave's own working set -- or another wave's when the leaves of the
 // workgroup's frames are pooled, og_recon.hip); `T`: the table copy to walk.
-OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos, int B, i32 gain, int spread) {
+#if defined(OG_HOST_EMUL) || defined(OG_LEAF_ROT_PLAIN)
+struct RotJob;
+#endif
+// `defer`: the leaf's rotation is not done here but described there, for pvq_rotate_wave (GPU; the caller cleared defer->on)
+OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos, int B, i32 gain, int spread, RotJob *defer = nullptr) {
     const int N = n, K = k, x = pos;
     const int logB = ilog2(B), blen = N >> logB; // B is a power of two
     i32 yy = 0;
@@ -999,6 +1054,18 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
             stride2 = 1;
             while ((stride2 * stride2 + stride2) * B + (B >> 2) < N) stride2++;
         }
+#if !defined(OG_HOST_EMUL) && !defined(OG_LEAF_ROT_PLAIN)
+        if (defer) {
+            defer->x = x;
+            defer->blen = blen;
+            defer->logB = logB;
+            defer->stride2 = stride2;
+            defer->c = c;
+            defer->s = s;
+            defer->on = true;
+            return cm;
+        }
+#endif
         for (int blk2 = 0; blk2 < B; blk2++) {
             if (stride2) rotate1_lane(xv, x + blk2 * blen, blen, stride2, s, c);
             rotate1_lane(xv, x + blk2 * blen, blen, 1, c, s);
@@ -2014,6 +2081,7 @@ OG_DEV void recon_leaves_own(const ParseRec *rec, const ReconCtx &rx, bool pre =
     }
 #endif
     OG_MARK(2);
+#if defined(OG_HOST_EMUL) || defined(OG_ROT_PER_LEAF) || defined(OG_LEAF_ROT_PLAIN)
     OG_FOR_LANES(t, n_leaves) {
         const bool first = pre && t < OG_NLANES;
         const u32 g = first ? g0 : rec->leaf[t].geom;
@@ -2024,6 +2092,29 @@ OG_DEV void recon_leaves_own(const ParseRec *rec, const ReconCtx &rx, bool pre =
                                 << ((aux >> 16) & 15));
     }
     OG_SYNC();
+#else
+    // rounds of 64 leaves: index -> pulses -> scaled, one leaf per lane; then the round's rotations by the whole wave
+    for (int t0 = 0; t0 < n_leaves; t0 += OG_NLANES) {
+        const int t = t0 + OG_LANE;
+        RotJob job;
+        job.x = job.blen = job.logB = job.stride2 = 0;
+        job.c = job.s = 0;
+        job.on = false;
+        if (t < n_leaves) {
+            const bool first = pre && t0 == 0;
+            const u32 g = first ? g0 : rec->leaf[t].geom;
+            const u32 aux = first ? aux0 : rec->leaf[t].aux;
+            const u32 idx = first ? idx0 : rec->leaf[t].idx;
+            leaf_masks()[t] = (u16)(pvq_leaf_lane(S.v, pvq_lds(), (int)(g >> 11) & 255, (int)(g >> 19) & 255, idx, V_X + (int)(g & 2047),
+                                                  (int)(g >> 27) + 1, (i32)(aux & 0xffff), spread, &job)
+                                    << ((aux >> 16) & 15));
+        }
+        OG_SYNC();
+        OG_MARK(60);
+        pvq_rotate_wave(S.v, job, S.rot_marker());
+    }
+    OG_SYNC();
+#endif
 }
 
 // ... or fetched: the leaf kernel decoded them (og_leaves.hip).  The frame's packed coefficients come in with 16-byte loads through

@@ -270,4 +270,36 @@ OG_DEV u32 wave_or(u32 v) {
     return v;
 }
 
+#ifndef OG_HOST_EMUL
+// Inclusive prefix sum / prefix maximum over the 64 lanes (all active; values >= 0 for the maximum): Hillis-Steele inside the
+// 16-lane rows with DPP row shifts (a lane without a source reads 0), then the rows' last lanes carried on with the two row
+// broadcasts (lane 15 of a row into the next row; lane 31 into the upper half).
+#define OG_DPP_SHR0(v, n) __builtin_amdgcn_update_dpp(0, (int)(v), 0x110 + (n), 0xf, 0xf, true)
+OG_DEV i32 wave_scan_add(i32 v) {
+    v += OG_DPP_SHR0(v, 1);
+    v += OG_DPP_SHR0(v, 2);
+    v += OG_DPP_SHR0(v, 4);
+    v += OG_DPP_SHR0(v, 8);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+OG_DEV i32 wave_scan_max(i32 v) {
+    i32 t;
+    t = OG_DPP_SHR0(v, 1);
+    v = t > v ? t : v;
+    t = OG_DPP_SHR0(v, 2);
+    v = t > v ? t : v;
+    t = OG_DPP_SHR0(v, 4);
+    v = t > v ? t : v;
+    t = OG_DPP_SHR0(v, 8);
+    v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    v = t > v ? t : v;
+    return v;
+}
+#endif
+
 } // namespace og

@@ -26,19 +26,28 @@ struct Rc {
 // Lane-private flavour for the one-frame-per-LANE parse kernel: the same coder state, packet bytes read from
 // HBM through a per-lane pointer (every rc_* function below is a template over the two).
 // On the GPU a byte fetch straight from HBM would put a full memory latency on the decoder's critical path at every
-// renormalisation, so the packet is read as aligned 32-bit words through two small windows -- one walking forward
-// from the first byte (range-coded data), one walking backward from the last (raw bits) -- each holding the current
-// word and, already requested, the next one in its direction.  Only words that overlap the packet are ever loaded.
+// renormalisation, so the packet is read through two small windows -- one walking forward from the first byte (range-coded
+// data), one walking backward from the last (raw bits) -- each holding the current piece and, already requested, the next one in
+// its direction.  Only pieces that overlap the packet are ever loaded.
+// The forward window moves in aligned 16-BYTE pieces (round 4; 4-byte words before).  The 64 lanes of a parse wave cross their
+// piece boundaries at 64 different moments, each crossing requests the lane's next piece, and the wait for a piece is a wait for
+// EVERY load of the wave in flight (the counter is the wave's, in order): with 4-byte pieces a wave of 160-byte packets crossed
+// 658 times per 64 frames, nearly every crossing waited for a load another lane had requested a moment before, and the parse
+// kernel sat in such waits for 47 % of its life (profiles/r04: SQ_WAIT_ANY 3,343 of 7,050 wave cycles per frame).  The backward
+// window (a few raw bits per band) keeps 4-byte words.
+typedef u32 og_u32x4 __attribute__((ext_vector_type(4)));
 struct RcLane : Rc {
     const u8 *buf;
 #ifndef OG_HOST_EMUL
-    // buf rounded down to a 4-byte boundary.  Explicitly a global-memory pointer: through a generic one these prefetches
+    // buf rounded down to a 16- / 4-byte boundary.  Explicitly global-memory pointers: through generic ones these prefetches
     // become flat loads, which also count against lgkmcnt -- every LDS wait would then wait for the prefetch as well.
+    const __attribute__((address_space(1))) og_u32x4 *chunks;
     const __attribute__((address_space(1))) u32 *words;
-    u32 shift;        // buf - (const u8 *)words
-    i32 last_word;    // index of the last word that overlaps the packet
-    u32 f_cur, f_next, b_cur, b_next;
-    i32 f_idx, b_idx; // word indices of f_cur / b_cur
+    u32 fshift, shift;            // buf - (const u8 *)chunks, buf - (const u8 *)words
+    i32 last_chunk, last_word;    // index of the last piece of either size that overlaps the packet
+    og_u32x4 f_cur, f_next;
+    u32 b_cur, b_next;
+    i32 f_idx, b_idx; // piece indices of f_cur / b_cur
 #endif
 };
 
@@ -56,38 +65,45 @@ OG_DEV int rc_next_byte(RcLane &rc) { return rc.offs < rc.storage ? rc.buf[rc.of
 OG_DEV int rc_next_byte_end(RcLane &rc) { return rc.end_offs < rc.storage ? rc.buf[rc.storage - ++rc.end_offs] : 0; }
 #else
 OG_DEV u32 rc_lane_word(const RcLane &rc, i32 w) { return (w >= 0 && w <= rc.last_word) ? rc.words[w] : 0u; }
+OG_DEV og_u32x4 rc_lane_chunk(const RcLane &rc, i32 w) { return (w >= 0 && w <= rc.last_chunk) ? rc.chunks[w] : og_u32x4{0u, 0u, 0u, 0u}; }
 OG_DEV void rc_lane_attach(RcLane &rc, const u8 *buf, u32 len) { // call before rc_init
     rc.buf = buf;
     const unsigned long long a = (unsigned long long)buf;
+    rc.chunks = (const __attribute__((address_space(1))) og_u32x4 *)(a & ~15ull);
     rc.words = (const __attribute__((address_space(1))) u32 *)(a & ~3ull);
+    rc.fshift = (u32)(a & 15ull);
     rc.shift = (u32)(a & 3ull);
+    rc.last_chunk = len ? (i32)((rc.fshift + len - 1) >> 4) : -1;
     rc.last_word = len ? (i32)((rc.shift + len - 1) >> 2) : -1;
     rc.f_idx = 0;
-    rc.f_cur = rc_lane_word(rc, 0);
-    rc.f_next = rc_lane_word(rc, 1);
+    rc.f_cur = rc_lane_chunk(rc, 0);
+    rc.f_next = rc_lane_chunk(rc, 1);
     rc.b_idx = rc.last_word;
     rc.b_cur = rc_lane_word(rc, rc.b_idx);
     rc.b_next = rc_lane_word(rc, rc.b_idx - 1);
 }
 // after the coder state (offs, end_offs, ...) was restored from elsewhere: re-position both windows
 OG_DEV void rc_lane_resume(RcLane &rc) {
-    rc.f_idx = (i32)((rc.offs + rc.shift) >> 2);
-    rc.f_cur = rc_lane_word(rc, rc.f_idx);
-    rc.f_next = rc_lane_word(rc, rc.f_idx + 1);
+    rc.f_idx = (i32)((rc.offs + rc.fshift) >> 4);
+    rc.f_cur = rc_lane_chunk(rc, rc.f_idx);
+    rc.f_next = rc_lane_chunk(rc, rc.f_idx + 1);
     rc.b_idx = rc.end_offs < rc.storage ? (i32)((rc.storage - rc.end_offs - 1 + rc.shift) >> 2) : rc.last_word;
     rc.b_cur = rc_lane_word(rc, rc.b_idx);
     rc.b_next = rc_lane_word(rc, rc.b_idx - 1);
 }
 OG_DEV int rc_next_byte(RcLane &rc) {
     if (rc.offs >= rc.storage) return 0;
-    const u32 pos = rc.offs++ + rc.shift;
-    const i32 w = (i32)(pos >> 2);
+    const u32 pos = rc.offs++ + rc.fshift;
+    const i32 w = (i32)(pos >> 4);
     if (w != rc.f_idx) { // sequential: w == f_idx + 1
         rc.f_cur = rc.f_next;
         rc.f_idx = w;
-        rc.f_next = rc_lane_word(rc, w + 1);
+        rc.f_next = rc_lane_chunk(rc, w + 1);
     }
-    return (int)((rc.f_cur >> (8 * (pos & 3))) & 255u);
+    // byte pos & 15 of the piece: the half it lies in, then one byte permute (selector 0x0c: a zero byte)
+    const bool up = (pos & 8u) != 0;
+    const u32 lo = up ? rc.f_cur.z : rc.f_cur.x, hi = up ? rc.f_cur.w : rc.f_cur.y;
+    return (int)__builtin_amdgcn_perm(hi, lo, 0x0c0c0c00u | (pos & 7u));
 }
 OG_DEV int rc_next_byte_end(RcLane &rc) {
     if (rc.end_offs >= rc.storage) return 0;

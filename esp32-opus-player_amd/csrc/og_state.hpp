@@ -159,8 +159,10 @@ struct FrameLds {
     OG_MEMBER u16 *leaf_mask_row() { return reinterpret_cast<u16 *>(&pkt[0]); }
 #ifndef OG_NO_SPLIT_LDS
     OG_MEMBER u32 *word_window() { return win; }
+    OG_MEMBER u8 *rot_marker() { return reinterpret_cast<u8 *>(win); } // (64 bytes of the leaf pass: the window is the band loop's)
 #else
     OG_MEMBER u32 *word_window() { return reinterpret_cast<u32 *>(pkt); } // (never called there)
+    OG_MEMBER u8 *rot_marker() { return pkt; }
 #endif
     OG_MEMBER i16 *dn_g_row() { return dn_g; }
     OG_MEMBER i16 *dn_shift_row() { return dn_shift; }
@@ -200,6 +202,7 @@ struct FrameLds {
 #ifdef OG_LDS_PAD /* occupancy experiments only: make the wave's LDS footprint larger */
     u8 pad_experiment[OG_LDS_PAD];
 #endif
+    u8 rot_marker_[64]; // the leaf pass's hand-out of rotation chains to lanes (pvq_rotate_wave)
     // (named by code that this layout never runs)
     u8 pkt[0];
     i32 fine_quant[0], fine_prio[0], tf_res[0], offsets[0], bits1[0], bits2[0];
@@ -210,6 +213,7 @@ struct FrameLds {
     OG_MEMBER i16 *logE2_row() { return &v[V_LATE + 24 + 6 * NBANDS]; }
     OG_MEMBER u16 *leaf_mask_row() { return reinterpret_cast<u16 *>(&v[V_MASK]); }
     OG_MEMBER u32 *word_window() { return reinterpret_cast<u32 *>(&v[V_WIN]); }
+    OG_MEMBER u8 *rot_marker() { return rot_marker_; }
     OG_MEMBER i16 *dn_g_row() { return &v[V_MASK]; }                               // synthesis only
     OG_MEMBER i16 *dn_shift_row() { return &v[V_MASK + 2 * NBANDS]; }
     OG_MEMBER u8 *bin2band_row() { return reinterpret_cast<u8 *>(&v[V_MASK + 4 * NBANDS]); }

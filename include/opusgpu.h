@@ -177,9 +177,9 @@ int opusgpu_memcpy_d2h(opusgpu_ctx *ctx, void *dst, const void *src, size_t byte
  * context's stream (or on `hip_stream` if not NULL: a hipStream_t).
  * The tables are in device memory and are NOT validated beyond what a frame's own kernel can see.  The caller guarantees:
  *   - a stream appears at most once in a step (frames of one stream are sequential: one step each);
- *   - 0 <= offset and offset + len lies inside the arena; d_arena is 4-byte aligned and the ALLOCATION extends at least
- *     to the next multiple of 4 past the last frame's end (the kernels fetch packets as aligned 32-bit words; allocating
- *     16 bytes more than the packed bytes, as every producer in this repository does, is enough);
+ *   - 0 <= offset and offset + len lies inside the arena; d_arena is 16-byte aligned (checked: OPUSGPU_BAD_ARG) and the
+ *     ALLOCATION extends at least to the next multiple of 16 past the last frame's end (the kernels fetch packets as aligned
+ *     16-byte pieces; allocating 16 bytes more than the packed bytes, as every producer in this repository does, is enough);
  *   - d_descs, d_arena, d_pcm and d_result stay valid and unmodified until the step has completed on its stream.
  * Checked on the device, per frame, and reported in d_result: stream index out of range -> OPUSGPU_BAD_ARG; len outside
  * 0..1275 -> OPUSGPU_BAD_ARG; every decode error the reference would return for the frame.

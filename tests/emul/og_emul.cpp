@@ -32,6 +32,7 @@ int emu_last_leaf_idx(unsigned *out, int cap) { // ... and their codeword indice
     for (int i = 0; i < n; i++) out[i] = rec.leaf[i].idx;
     return rec.n_leaves;
 }
+unsigned emu_last_rec_flags(void) { return rec.flags; } // ... and the frame's record flags (RF_*: the spread decision among them)
 int emu_decode_frame(void *stv, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm) {
     og::StreamState *st = (og::StreamState *)stv;
     static og::SilkHandoff handoff;
