@@ -713,11 +713,13 @@ struct opusgpu_ctx {
     u32 *d_started = nullptr; // [0] early-parse workgroups started, [16] every 64th reconstruction workgroup started
     u32 parse_started_total = 0, recon_started_total = 0;
     u32 window_parse_target = 0, window_recon_target = 0; // the counts the last queued step of an unfinished window waits for (0: none)
-    // (OPUSGPU_PARSE_GROUPS) groups of 32 frames per workgroup of the early parse: with two, half as many parse workgroups are
-    // resident for about twice as long, each group runs nearer to a lone wave's pace, and the reconstruction next to them has
-    // the LDS of the other half -- 1 / 2 / 3 / 4 groups: 2.545 / 2.50 / 2.52 / 2.97 ms per step on one box (at four the parse
-    // outlasts the reconstruction and the next step waits for it)
-    int parse_groups = 2;
+    // (OPUSGPU_PARSE_GROUPS) groups of frames per workgroup of the early parse, one after the other.  Round 2 measured two as the
+    // best (half as many parse workgroups resident for twice as long: 2.545 / 2.50 / 2.52 / 2.97 ms per step at 1 / 2 / 3 / 4).  Round 4:
+    // a group takes a parse wave 0.85 ms, so two groups are a chain of 1.7 ms -- which had become the step (a reconstruction doing
+    // 40 % of its work: still 1.69 ms).  With one group the parse is done after 1.0 ms of the step and what counts is how many of the
+    // reconstruction's waves fit a CU next to it: the parse kernel's LDS went from 46 KB to 25 KB per 128 frames for that
+    // (og_celt_split.hpp: ParseLds), 1.83 -> 1.74 ms.
+    int parse_groups = 1;
     // the last decode step's tables, for opusgpu_debug_stage_taps
     const void *last_descs = nullptr;
     int last_n = 0, last_had_silk_recs = 0;

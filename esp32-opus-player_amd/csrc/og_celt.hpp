@@ -28,6 +28,9 @@ struct WaveArr {
     OG_MEMBER i32 &bits1(int i) const { return S.bits1[i]; }
     OG_MEMBER i32 &bits2(int i) const { return S.bits2[i]; }
     OG_MEMBER i16 &bandE(int i) const { return S.bandE_row()[i]; }
+    // (where a provider's band energies and its allocation scratch share memory: celt_parse_header says when the energies rest)
+    OG_MEMBER void energies_rest() const {}
+    OG_MEMBER void energies_back() const {}
 };
 
 // ---- energies (src/celt.cpp:3613-3700) ------------------------------------------------------------
@@ -1055,6 +1058,7 @@ OG_DEV void celt_parse_header(A a, R &rc, int start, int end, int C, int LM, Cel
     const int intra = tell + 3 <= total_bits ? rc_bit_logp(rc, 3) : 0;
     OG_MARK(21);
     coarse_energy(a, rc, start, end, intra, C, LM);
+    a.energies_rest(); // (nothing reads or writes a band energy between here and fine_energy)
     OG_MARK(22);
     tf_decode(a, rc, start, end, transient, LM);
     tell = rc_tell(rc);
@@ -1116,6 +1120,7 @@ OG_DEV void celt_parse_header(A a, R &rc, int start, int end, int C, int LM, Cel
     OG_MARK(23);
     h.codedBands = compute_allocation(a, rc, start, end, alloc_trim, intensity, dual_stereo, bits, balance, C, LM);
     OG_MARK(24);
+    a.energies_back();
     fine_energy(a, rc, start, end, C);
     OG_MARK(25);
 

@@ -98,6 +98,11 @@ struct ParseRec {
         u32 pad;
     } leaf[REC_MAX_LEAVES];
     u32 words[(REC_MAX_WORDS + 64) / 64 * 64]; // read in windows of 64 (REC_WORDS_CAP); a band's four header words start on a multiple of four
+    // The parse lane's bits-per-band array while it works (32-bit: compute_allocation's intermediate values; `pulses` above gets the
+    // final ones).  Here and not in LDS: next to the reconstruction the parse kernel's LDS is what keeps that kernel's waves off the
+    // CU, and these 84 bytes per frame were a quarter of it.  Nothing reads this after the parse.
+    i32 work_pulses[NBANDS];
+    i32 work_pad[32 - NBANDS];
 };
 static_assert(offsetof(ParseRec, leaf) % 16 == 0 && offsetof(ParseRec, words) % 16 == 0, "16-byte stores into the record");
 static_assert(sizeof(ParseRec) % 16 == 0, "record alignment");
@@ -137,14 +142,15 @@ static_assert(sizeof(LeafOut) % 16 == 0, "leaf output alignment");
 #endif
 #define OG_PL_FRAMES (OG_PL_LANES * OG_PL_WAVES) // frames per workgroup
 struct ParseLds { // [element][lane]: lanes of a wave touch consecutive addresses, no bank conflicts
-    i32 pulses[NBANDS][OG_PL_LANES];
-    i16 bandE[2 * NBANDS][OG_PL_LANES];
     i8 fine_quant[NBANDS][OG_PL_LANES];
     i8 tf_prio[NBANDS][OG_PL_LANES]; // bits 0-3: tf_res (-3 .. 3, two's complement), bit 4: fine_prio
+    // Three tenants, one after the other (next to the reconstruction the kernel's LDS is what keeps that kernel's waves out: 16.1 KB
+    // per wave of 32 frames in round 2, 14.0 with the caps computed and tf_res / fine_prio in one byte, 11.3 now):
     union {
-        struct { // live until compute_allocation returns (the dynalloc boosts are made just before it), i.e. before
-                 // the first band is parsed: 14.0 KB per wave in all with the ROM tables (16.1 KB before the caps went and
-                 // tf_res / fine_prio shared a byte): in pipelined steps the kernel's LDS x time is what it costs
+        // the band energies while the header's energy stages and energy_finalise work on them (coarse energy .. , fine energy, the
+        // finalise pass); in between they rest in the frame's record (LaneArr::energies_rest / energies_back: 21 words each way)
+        i16 bandE[2 * NBANDS][OG_PL_LANES];
+        struct { // from the dynalloc boosts until compute_allocation returns, i.e. before the first band is parsed
             i16 offsets[NBANDS][OG_PL_LANES]; // (the bands' caps are computed where they are used: celt_band_cap)
             u16 bits1[NBANDS][OG_PL_LANES], bits2[NBANDS][OG_PL_LANES];
         } al;
@@ -156,7 +162,16 @@ struct ParseLds { // [element][lane]: lanes of a wave touch consecutive addresse
 };
 // One per wave.  The union below is private to a wave only because its lanes reconverge between compute_allocation and the band
 // walk; two waves of a workgroup do not, so they must not share rows of it.
+// OG_PARSE_DYN_LDS (og_parse64.hip): the parse kernel's LDS as DYNAMIC shared memory, sized at the launch.  The compiler derives
+// a kernel's occupancy -- and from it the register budget it allocates to -- from the LDS it can see, and with 46 KB per
+// workgroup it saw two waves per SIMD and took 219 of their 256 registers, whatever the kernel was told to aim for; a SIMD that
+// holds such a wave has registers left for three of the reconstruction's waves, not for five.
+#ifdef OG_PARSE_DYN_LDS
+extern __shared__ __attribute__((aligned(16))) unsigned char og_dyn_lds[];
+#define PLs (reinterpret_cast<ParseLds *>(og_dyn_lds))
+#else
 OG_LDS ParseLds PLs[OG_PL_WAVES];
+#endif
 #define PL PLs[OG_PWAVE]
 
 // LDS copy of the entropy-decoding ROM tables (see RomGlobal, og_celt_bands.hpp), loaded once per workgroup
@@ -166,7 +181,13 @@ struct ParseTabLds {
     u32 pulse_v[392]; // size of the PVQ codebook a leaf's index is decoded against, by pulse-cache index (rom_pulse_v)
     u8 pulse_bits[392], band_alloc[231], pulse_caps[168], log2_frac[24], eprob[336];
 };
+#ifdef OG_PARSE_DYN_LDS
+#define PT (*reinterpret_cast<ParseTabLds *>(og_dyn_lds + sizeof(ParseLds) * OG_PL_WAVES))
+#define OG_PARSE_LDS_BYTES (sizeof(ParseLds) * OG_PL_WAVES + sizeof(ParseTabLds))
+#else
 OG_LDS ParseTabLds PT;
+#define OG_PARSE_LDS_BYTES 0
+#endif
 struct RomLds {
     static OG_MEMBER i32 eband(int i) { return PT.eband[i]; }
     static OG_MEMBER i32 logn(int i) { return PT.logn[i]; }
@@ -204,14 +225,31 @@ struct FinePrioView {
 };
 struct LaneArr {
     typedef RomLds Rom;
-    OG_MEMBER i32 &pulses(int i) const { return PL.pulses[i][OG_PCOL]; }
+    i32 *pl;   // the bits-per-band array: in the frame's record (ParseRec::work_pulses), 32 bits (a frame whose budget went negative
+               // carries wrapped values here, as the reference does)
+    i16 *rest; // where the band energies rest while the allocation scratch / the partition stack have their LDS: the record's bandE
+    // (pairs of bands per 32-bit access; every load is requested before the first is used)
+    OG_MEMBER void energies_rest() const {
+        for (int i = 0; i < 2 * NBANDS; i += 2)
+            *reinterpret_cast<u32 *>(&rest[i]) = (u32)(u16)PL.u.bandE[i][OG_PCOL] | (u32)(u16)PL.u.bandE[i + 1][OG_PCOL] << 16;
+        for (int i = 0; i < NBANDS; i++) PL.u.al.offsets[i][OG_PCOL] = 0;
+    }
+    OG_MEMBER void energies_back() const {
+        u32 w[NBANDS];
+        for (int i = 0; i < NBANDS; i++) w[i] = *reinterpret_cast<const u32 *>(&rest[2 * i]);
+        for (int i = 0; i < NBANDS; i++) {
+            PL.u.bandE[2 * i][OG_PCOL] = (i16)(w[i] & 0xffff);
+            PL.u.bandE[2 * i + 1][OG_PCOL] = (i16)(w[i] >> 16);
+        }
+    }
+    OG_MEMBER i32 &pulses(int i) const { return pl[i]; }
     OG_MEMBER i8 &fine_quant(int i) const { return PL.fine_quant[i][OG_PCOL]; }
     OG_MEMBER FinePrioView fine_prio(int i) const { return FinePrioView{&PL.tf_prio[i][OG_PCOL]}; }
     OG_MEMBER TfResView tf_res(int i) const { return TfResView{&PL.tf_prio[i][OG_PCOL]}; }
     OG_MEMBER i16 &offsets(int i) const { return PL.u.al.offsets[i][OG_PCOL]; }
     OG_MEMBER u16 &bits1(int i) const { return PL.u.al.bits1[i][OG_PCOL]; }
     OG_MEMBER u16 &bits2(int i) const { return PL.u.al.bits2[i][OG_PCOL]; }
-    OG_MEMBER i16 &bandE(int i) const { return PL.bandE[i][OG_PCOL]; }
+    OG_MEMBER i16 &bandE(int i) const { return PL.u.bandE[i][OG_PCOL]; }
 };
 
 OG_DEV u32 pvq_u_rom(int a, int b) { // U(a,b) from the ROM table (lane-private lookups)
@@ -383,7 +421,7 @@ OG_DEV int parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits,
 // Returns the set of bands (bit i = band i) whose folding history some later band actually reads.
 OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C, int N_ch, int shortBlocks, int spread,
                            int dual_stereo, int intensity, i32 total_bits, i32 balance, int LM, int codedBands, int disable_inv) {
-    const LaneArr a;
+    const LaneArr a{out.rec->work_pulses, nullptr}; // (pulses and tf_res only: the band energies rest in the record while the bands are parsed)
     const int M = 1 << LM, B = shortBlocks ? M : 1;
     const int norm_offset = M * RomLds::eband(start);
     int lowband_offset = 0, update_lowband = 1;
@@ -525,7 +563,7 @@ OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C
 // stream state this half reads, so the parse of a stream's next frame depends on nothing but the parse of this one and may run
 // while this frame is still being reconstructed (opusgpu_set_pipeline, og_api.hip).
 OG_DEV void celt_parse_lane(StreamState *st, const u8 *payload, int len, int ch, ParseRec *rec, const SilkHandoff *handoff) {
-    const LaneArr a;
+    const LaneArr a{rec->work_pulses, rec->bandE};
     const int CC = st->channels, C = ch, LM = 3, frame_size = 960, start = handoff ? 17 : 0, end = NBANDS;
     rec->start = start;
     rec->n_leaves = 0;
@@ -554,15 +592,15 @@ OG_DEV void celt_parse_lane(StreamState *st, const u8 *payload, int len, int ch,
     for (int i = 0; i < 2 * NBANDS; i++) a.bandE(i) = st->celt.bandE[i];
     if (C == 1)
         for (int i = 0; i < NBANDS; i++) a.bandE(i) = (i16)OG_MAX((i32)a.bandE(i), (i32)a.bandE(NBANDS + i));
-    for (int i = 0; i < NBANDS; i++) {
+    for (int i = 0; i < NBANDS; i++) { // (the dynalloc offsets are cleared where the energies make room for them: energies_rest)
         a.pulses(i) = 0;
         a.fine_quant(i) = 0;
         a.fine_prio(i) = 0;
-        a.offsets(i) = 0;
     }
     CeltHeader h;
     OG_MARK(20);
     celt_parse_header(a, rc, start, end, C, LM, h);
+    a.energies_rest(); // the partition walk's stack takes their place
     RecWriter out;
     out.rec = rec;
     out.nw = 0;
@@ -579,6 +617,7 @@ OG_DEV void celt_parse_lane(StreamState *st, const u8 *payload, int len, int ch,
     OG_MARK(27);
     int anti_collapse_on = 0;
     if (h.anti_collapse_rsv > 0) anti_collapse_on = (int)rc_bits(rc, 1);
+    a.energies_back();
     energy_finalise(a, rc, start, end, (i32)rc.storage * 8 - rc_tell(rc), C);
     for (int i = 0; i < 2 * NBANDS; i++) rec->bandE[i] = a.bandE(i);
     u32 flags = (u32)LM << RF_LM_SHIFT | (u32)h.spread << RF_SPREAD_SHIFT;

@@ -14,7 +14,7 @@
 //   OPUSGPU_PARSE_WIDE        parse_wide       1        0: pipelined steps parse with 32 frames per wave like in-order steps (k_celt_parse instead of k_celt_parse64);
 //                                                       2: in-order steps use the wide kernel too (counter passes: --pmc serialises kernels, so only in-order steps can be counted)
 //   OPUSGPU_HALVES            halves           1        0: an in-order step with SILK-only / hybrid frames runs as ONE chain of kernels, not two
-//   OPUSGPU_PARSE_GROUPS      parse_groups     2        groups of 32 frames per workgroup of the early parse (1 .. 8)
+//   OPUSGPU_PARSE_GROUPS      parse_groups     1        groups of frames per workgroup of the early parse, one after the other (1 .. 8)
 //   OPUSGPU_PARSE_PRIORITY    parse_priority   1        0: the early parse's stream gets the LOWEST priority instead of the highest
 //   OPUSGPU_HOST_PARTS        host_parts       16       slices a large opusgpu_decode_packets call's PCM leaves in (1, 2, 4, 8, 16)
 //   OPUSGPU_HOST_SLICES       host_slices      1        0: the round-2 flow -- every part its own in-order step (A/B measurements)
@@ -26,7 +26,7 @@
 #include <stdlib.h>
 
 struct og_debug_knobs {
-    int split = 1, split_hybrid = 1, fast_recon = 1, leaf_kernel = 0, halves = 1, silk_pipeline = 1, hybrid_pipeline = 1, parse_wide = 1, parse_groups = 2, parse_priority = 1, host_parts = 16, host_slices = 1, host_timing = 0,
+    int split = 1, split_hybrid = 1, fast_recon = 1, leaf_kernel = 0, halves = 1, silk_pipeline = 1, hybrid_pipeline = 1, parse_wide = 1, parse_groups = 1, parse_priority = 1, host_parts = 16, host_slices = 1, host_timing = 0,
         pages_timing = 0, launch_delay_us = 0;
 };
 inline const og_debug_knobs &og_debug() {

@@ -7,11 +7,15 @@
 #endif
 #define OG_PL_WAVES OG_PL64_WAVES
 #define OG_PARSE_KERNEL_NAME k_celt_parse64
+#define OG_PARSE_DYN_LDS 1
+#ifndef OG_PARSE_WAVES_PER_SIMD
+#define OG_PARSE_WAVES_PER_SIMD 3 // the register budget: 168
+#endif
 #include "og_parse_kernel.hpp"
 
 extern "C" void og_launch_celt_parse64(hipStream_t s, int grid, const void *descs, const void *arena, void *streams, void *recs, int n,
                                        int n_streams, const void *handoff, int which, int groups, unsigned *started) {
-    hipLaunchKernelGGL(k_celt_parse64, dim3(grid), dim3(64 * OG_PL_WAVES), 0, s, (const FrameDesc *)descs, (const u8 *)arena, (StreamState *)streams,
+    hipLaunchKernelGGL(k_celt_parse64, dim3(grid), dim3(64 * OG_PL_WAVES), OG_PARSE_LDS_BYTES, s, (const FrameDesc *)descs, (const u8 *)arena, (StreamState *)streams,
                        (ParseRec *)recs, n, n_streams, (const SilkHandoff *)handoff, which, groups, started);
 }
 extern "C" int og_celt_parse64_frames(void) { return OG_PL_FRAMES; }

@@ -13,7 +13,10 @@ using namespace og;
 // `which`: PARSE_ALL, or one of the two launches of a pipelined step (opusgpu_set_pipeline): PARSE_CELT_ONLY runs ahead on the
 // library's own stream, PARSE_HYBRID_ONLY behind the step's k_silk_parse (it resumes the range decoder that kernel hands off).
 enum { PARSE_ALL = 0, PARSE_CELT_ONLY = 1, PARSE_HYBRID_ONLY = 2 };
-__global__ void __launch_bounds__(64 * OG_PL_WAVES, 2) OG_PARSE_KERNEL_NAME(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
+#ifndef OG_PARSE_WAVES_PER_SIMD
+#define OG_PARSE_WAVES_PER_SIMD 2 // (the register budget the compiler works to: 512 / this)
+#endif
+__global__ void __attribute__((amdgpu_waves_per_eu(OG_PARSE_WAVES_PER_SIMD, 8))) __launch_bounds__(64 * OG_PL_WAVES) OG_PARSE_KERNEL_NAME(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
                                                       StreamState *st, ParseRec *recs, int n, int n_streams,
                                                       const SilkHandoff *handoff, int which, int groups, u32 *started) {
     // `groups`: a workgroup parses that many groups of OG_PL_FRAMES frames one after the other (1: the grid covers the step once)
