@@ -2149,7 +2149,7 @@ OG_DEV void recon_leaves_own(const ParseRec *rec, const ReconCtx &rx, bool pre =
                                     << ((aux >> 16) & 15));
         }
         OG_SYNC();
-        OG_MARK(60);
+        OG_MARK(28);
         pvq_rotate_wave(S.v, job, S.rot_marker());
     }
     OG_SYNC();

@@ -17,7 +17,7 @@ NAMES = {0: "outside", 1: "stage record", 2: "leaf pass", 3: "band prologue", 4:
          6: "tree walk", 7: "leaf (fill)", 8: "band_mono post", 9: "lowband out", 10: "stereo merge", 11: "N==1 band",
          12: "anti-collapse", 13: "synth prologue", 14: "imdct", 15: "comb filter", 16: "ring write", 17: "epilogue",
          20: "parse: init", 21: "parse: flags", 22: "parse: coarse energy", 23: "parse: tf/spread/dynalloc", 24: "parse: allocation",
-         25: "parse: fine energy", 26: "parse: bands", 27: "parse: finalise",
+         25: "parse: fine energy", 26: "parse: bands", 27: "parse: finalise", 28: "leaf: rotations by the wave",
          56: "leaf: index walk (cwrsi)", 57: "leaf: collapse mask", 58: "leaf: scale", 59: "leaf: rotation",
          60: "silk core: subframe setup (gains, re-whitening)", 61: "silk core: excitation", 62: "silk core: LTP prediction",
          63: "silk core: LPC recurrence + output scaling",
