@@ -908,9 +908,14 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
     while (n > 2) {
         if (k == 0) break; // every pulse is placed: what is left of the leaf stays zero
         u32 h = (u32)n, v2 = 2u * h - 1u, v3 = pvq_u3(h); // U(2, n), U(3, n)
-        if (n > k) {
-            u32 c0 = T.rr[k >= 4 ? b0 + n : 0], c1 = T.rr[k >= 3 ? b1 + n : 0];
-            u32 p0 = k >= 4 ? c0 : pvq_row_sel(k, v2, v3), p1 = k >= 3 ? c1 : pvq_row_sel(k + 1, v2, v3); // U(k, n), U(k + 1, n)
+        const bool sparse = n > k;
+        u32 p0, p1;         // U(n, k), U(n, k + 1)
+        int bn = 0;         // (n <= k) where row n starts
+        bool tab = false;   // (n <= k) row n is a table row (n == 3: closed form)
+        if (sparse) {
+            const u32 c0 = T.rr[k >= 4 ? b0 + n : 0], c1 = T.rr[k >= 3 ? b1 + n : 0];
+            p0 = k >= 4 ? c0 : pvq_row_sel(k, v2, v3);
+            p1 = k >= 3 ? c1 : pvq_row_sel(k + 1, v2, v3);
 #ifndef OG_NO_ZERO_SKIP
             // A sparse leaf (many dimensions, few pulses) is mostly runs of zeros, and the wave waits for its longest leaf: the run is
             // skipped in one go.  With V(a) = U(a, k) + U(a, k + 1) the dimensions n, n-1, .., a+1 all decode to zero exactly when
@@ -953,7 +958,7 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
                     }
                     a = lo;
                 }
-                if (a < n) {
+                if (a < n) { // (a > k: the step below is still one with more dimensions than pulses)
                     i -= (Vn - (t0 + t1)) >> 1;
                     pos += n - a;
                     n = a;
@@ -966,26 +971,36 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
                 }
             }
 #endif
-            const int s = -(int)(i >= p1);
-            i -= p1 & (u32)s;
-            if (p0 <= i && s == 0) {
-                i -= p0;
-            } else {
-                // the largest k' < k with U(k', n) <= i: rows k' < k < n at column n
-                const int k0 = k;
-                u32 plo = 0;
-                int kk = 0;
-                if (k <= 8) { // all candidates at once (rows 1..3 computed, rows 4..7 at fixed bases)
+        } else { // n <= k: everything this step reads lies in row n, whose columns are all in LDS (n == 3: U(3, c) = 2 c (c - 1) + 1)
+            const u32 hk = (u32)k;
+            bn = pvq_row_base(T, n);
+            tab = n >= 4;
+            const u32 a0 = T.rr[tab ? bn + k : 0], a1 = T.rr[tab ? bn + k + 1 : 0];
+            p0 = tab ? a0 : pvq_u3(hk);
+            p1 = tab ? a1 : pvq_u3(hk + 1u);
+        }
+        const int s = -(int)(i >= p1);
+        i -= p1 & (u32)s;
+        if (p0 <= i && s == 0) {
+            i -= p0;
+        } else { // a pulse: the largest k' < k with U(n, k') <= i (U(n, 0) = 0 <= i; U(n, k) > i here)
+            u32 plo = 0;
+            int kk = 0;
+            if (sparse) { // rows k' < k < n at column n
+                if (k <= 8) {
+                    // all candidates at once (rows 1..3 computed, rows 4..7 at fixed bases); U(., n) grows with the row: the last one
+                    // that passes is k' (rows from k on are not looked at: a row ends where its entries leave 32 bits, and only
+                    // U(k, n) and the entries below it are known to exist)
                     const u32 c4 = T.rr[ROM_PVQ_RB4 + n], c5 = T.rr[ROM_PVQ_RB5 + n], c6 = T.rr[ROM_PVQ_RB6 + n], c7 = T.rr[ROM_PVQ_RB7 + n];
                     const u32 cand[7] = {1u, v2, v3, c4, c5, c6, c7};
 #pragma unroll
                     for (int r = 1; r <= 7; r++) {
-                        const bool ok = r < k && cand[r - 1] <= i; // (U(., n) grows with the row: the last `ok` is k')
+                        const bool ok = r < k && cand[r - 1] <= i;
                         kk = ok ? r : kk;
                         plo = ok ? cand[r - 1] : plo;
                     }
                 } else {
-                    int lo = 0, hi = k - 1; // U(0, n) = 0 <= i; U(k, n) > i here
+                    int lo = 0, hi = k - 1;
                     while (lo < hi) {
                         const int mid = (lo + hi + 1) >> 1;
                         const u32 tm = T.rr[mid >= 4 ? pvq_row_base(T, mid) + n : 0];
@@ -998,48 +1013,27 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
                     }
                     kk = lo;
                 }
-                k = kk;
-                i -= plo;
-                const int val = (k0 - k + s) ^ s;
-                xv[pos] = (i16)val;
-                yy += val * val;
-                b0 = pvq_row_base(T, k);
-                b1 = pvq_row_base(T, k + 1);
-            }
-        } else { // n <= k: everything this step reads lies in row n, whose columns are all in LDS (n == 3: U(3, c) = 2 c (c - 1) + 1)
-            const u32 hk = (u32)k;
-            const int bn = pvq_row_base(T, n);
-            const bool tab = n >= 4;
-            const u32 a0 = T.rr[tab ? bn + k : 0], a1 = T.rr[tab ? bn + k + 1 : 0];
-            const u32 p0 = tab ? a0 : pvq_u3(hk);
-            const u32 p1 = tab ? a1 : pvq_u3(hk + 1u);
-            const int s = -(int)(i >= p1);
-            i -= p1 & (u32)s;
-            if (p0 <= i && s == 0) {
-                i -= p0;
-            } else {
-                const int k0 = k;
-                int lo = 0, hi = k - 1; // U(n, 0) = 0 <= i; U(n, k) > i here
-                u32 plo = 0;
+            } else { // along row n
+                int lo = 0, hi = k - 1;
                 while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1; // >= 1
-                    const u32 hm = (u32)mid;
                     const u32 tm = T.rr[tab ? bn + mid : 0];
-                    const u32 pm = tab ? tm : pvq_u3(hm);
+                    const u32 pm = tab ? tm : pvq_u3((u32)mid);
                     if (pm <= i) {
                         lo = mid;
                         plo = pm;
                     } else
                         hi = mid - 1;
                 }
-                k = lo;
-                i -= plo;
-                const int val = (k0 - k + s) ^ s;
-                xv[pos] = (i16)val;
-                yy += val * val;
-                b0 = pvq_row_base(T, k); // (in case a later step has n > k)
-                b1 = pvq_row_base(T, k + 1);
+                kk = lo;
             }
+            const int val = (k - kk + s) ^ s;
+            k = kk;
+            i -= plo;
+            xv[pos] = (i16)val;
+            yy += val * val;
+            b0 = pvq_row_base(T, k); // (rows k and k + 1, for the steps with more dimensions than pulses)
+            b1 = pvq_row_base(T, k + 1);
         }
         pos++;
         n--;
