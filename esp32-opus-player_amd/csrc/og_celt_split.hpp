@@ -1188,6 +1188,64 @@ struct LcgTab {
     }
 };
 
+// anti_collapse (celt.cpp:1010) for the reconstruction kernel of 20 ms frames.  The shared form (og_celt_bands.hpp) derives a band's
+// noise amplitude r -- a division, an exp2, a reciprocal square root -- in every lane alike, up to 42 times one after the other (the
+// values come from LDS rows: vector work, not scalar), and steps the noise generator with its squaring loop per lane: a frame with
+// anti-collapse (one in sixteen of the bench payloads) cost the wave 60 % more than one without.  Here lane (channel, band) derives
+// its own r, one pass for all of them, into a scratch row; the fills read it back and jump the generator by the frame's table.
+OG_DEV void anti_collapse_pm(const LcgTab &lcg, int LM, int C, int size, int start, int end, u32 seed) {
+    i16 *const rrow = &S.v[V_TMP]; // (the band loop's scratch row: free by now)
+    OG_SYNC();
+    OG_FOR_LANES(l, C * NBANDS) {
+        const int c = l >= NBANDS ? 1 : 0, i = l - c * NBANDS;
+        i32 r = 0;
+        if (i >= start && i < end) {
+            const int N0 = rom_eband[i + 1] - rom_eband[i];
+            const int depth = (int)(udiv((u32)(1 + S.pulses_row()[i]), (u32)N0) >> LM);
+            const i32 thresh32 = celt_exp2(-shl16(depth, 10 - BITRES)) >> 1;
+            const i32 thresh = tr16(mul16x32_q15(16384, OG_MIN(32767, thresh32)));
+            i32 t = N0 << LM;
+            const int shift = ilog2(t) >> 1;
+            t = shl32(t, (7 - shift) << 1);
+            const i32 sqrt_1 = rsqrt_norm(t);
+            i32 prev1 = S.logE1_row()[c * NBANDS + i], prev2 = S.logE2_row()[c * NBANDS + i];
+            if (C == 1) {
+                prev1 = OG_MAX(prev1, (i32)S.logE1_row()[NBANDS + i]);
+                prev2 = OG_MAX(prev2, (i32)S.logE2_row()[NBANDS + i]);
+            }
+            i32 Ediff = (i32)S.bandE_row()[c * NBANDS + i] - OG_MIN(prev1, prev2);
+            Ediff = OG_MAX(0, Ediff);
+            if (Ediff < 16384) {
+                const i32 r32 = celt_exp2(-tr16(Ediff)) >> 1;
+                r = tr16(2 * OG_MIN(16383, r32));
+            }
+            if (LM == 3) r = tr16(mul16_q14(23170, OG_MIN(23169, r)));
+            r = tr16(OG_MIN(thresh, r) >> 1);
+            r = tr16(mul16_q15(sqrt_1, r) >> shift);
+        }
+        rrow[l] = (i16)r;
+    }
+    OG_SYNC();
+    for (int i = start; i < end; i++) {
+        const int N0 = rom_eband[i + 1] - rom_eband[i];
+        for (int c = 0; c < C; c++) {
+            const i32 r = (i32)OG_UNI(rrow[c * NBANDS + i]);
+            const int x = V_X + c * size + (rom_eband[i] << LM);
+            int renorm = 0;
+            const u32 mask = (u32)OG_UNI(S.cmask_row()[i * C + c]);
+            for (int k = 0; k < 1 << LM; k++) {
+                if (!(mask & (1u << k))) {
+                    OG_SYNC();
+                    OG_FOR_LANES(j, N0) S.v[x + (j << LM) + k] = (i16)((lcg.at(seed, j) & 0x8000) ? r : -r);
+                    seed = lcg_skip(seed, (u32)N0);
+                    renorm = 1;
+                }
+            }
+            if (renorm) renormalise(x, N0 << LM, 32767);
+        }
+    }
+}
+
 // The leaves of one job (quant_partition celt.cpp:1382 flattened by the parse kernel), vector half.  The leaves with
 // pulses are complete already (pvq_leaf_lane) and only contribute their collapse masks, stored pre-shifted by the leaf
 // pass: one wave-wide OR.  A leaf without pulses is zeroed, noise-filled or folded from the lower band
@@ -2231,7 +2289,7 @@ OG_DEV int recon_finish(StreamState *st, const ParseRec *rec, const ReconCtx &rx
             recon_all_bands(rec->words, rx.h.need_norm, lcg, start, end, C, N, transient ? M : 0, LM, seed);
 #endif
         OG_MARK(12);
-        if (flags & RF_ANTI_COLLAPSE) anti_collapse(LM, C, N, start, end, seed);
+        if (flags & RF_ANTI_COLLAPSE) anti_collapse_pm(lcg, LM, C, N, start, end, seed);
         if (silence) {
             OG_SYNC();
             OG_FOR_LANES(i, C * NBANDS) S.bandE_row()[i] = (i16)(-28 * 1024);
