@@ -717,7 +717,7 @@ struct opusgpu_ctx {
     // best (half as many parse workgroups resident for twice as long: 2.545 / 2.50 / 2.52 / 2.97 ms per step at 1 / 2 / 3 / 4).  Round 4:
     // a group takes a parse wave 0.85 ms, so two groups are a chain of 1.7 ms -- which had become the step (a reconstruction doing
     // 40 % of its work: still 1.69 ms).  With one group the parse is done after 1.0 ms of the step and what counts is how many of the
-    // reconstruction's waves fit a CU next to it: the parse kernel's LDS went from 46 KB to 25 KB per 128 frames for that
+    // reconstruction's waves fit a CU next to it: the parse kernel's LDS went from 46 KB to 36 KB per 128 frames for that
     // (og_celt_split.hpp: ParseLds), 1.83 -> 1.74 ms.
     int parse_groups = 1;
     // the last decode step's tables, for opusgpu_debug_stage_taps

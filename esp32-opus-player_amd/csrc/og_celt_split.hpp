@@ -98,9 +98,10 @@ struct ParseRec {
         u32 pad;
     } leaf[REC_MAX_LEAVES];
     u32 words[(REC_MAX_WORDS + 64) / 64 * 64]; // read in windows of 64 (REC_WORDS_CAP); a band's four header words start on a multiple of four
-    // The parse lane's bits-per-band array while it works (32-bit: compute_allocation's intermediate values; `pulses` above gets the
-    // final ones).  Here and not in LDS: next to the reconstruction the parse kernel's LDS is what keeps that kernel's waves off the
-    // CU, and these 84 bytes per frame were a quarter of it.  Nothing reads this after the parse.
+    // -DOG_PARSE_PULSES_REC: the parse lane's bits-per-band work array lives here and not in LDS (84 bytes a lane, a quarter of the
+    // kernel's LDS).  Measured: the pipelined CELT step 0.7 % faster (1.710 / 1.722 ms) -- and 2.9 KB more HBM traffic per frame, because
+    // a lane comes back to its line some twenty times and the record stream has pushed it out of the L2 every time (35.6 KB per
+    // frame = 1.64 x the algorithmic bytes against 32.8 KB = 1.52 x).  Off: the traffic is what the roofline is priced in.
     i32 work_pulses[NBANDS];
     i32 work_pad[32 - NBANDS];
 };
@@ -142,10 +143,14 @@ static_assert(sizeof(LeafOut) % 16 == 0, "leaf output alignment");
 #endif
 #define OG_PL_FRAMES (OG_PL_LANES * OG_PL_WAVES) // frames per workgroup
 struct ParseLds { // [element][lane]: lanes of a wave touch consecutive addresses, no bank conflicts
+#ifndef OG_PARSE_PULSES_REC
+    i32 pulses[NBANDS][OG_PL_LANES]; // the bits-per-band work array (32 bits: a frame whose budget went negative carries wrapped values here, as the
+                                     // reference does).  -DOG_PARSE_PULSES_REC keeps it in the record instead, see ParseRec::work_pulses
+#endif
     i8 fine_quant[NBANDS][OG_PL_LANES];
     i8 tf_prio[NBANDS][OG_PL_LANES]; // bits 0-3: tf_res (-3 .. 3, two's complement), bit 4: fine_prio
     // Three tenants, one after the other (next to the reconstruction the kernel's LDS is what keeps that kernel's waves out: 16.1 KB
-    // per wave of 32 frames in round 2, 14.0 with the caps computed and tf_res / fine_prio in one byte, 11.3 now):
+    // per wave of 32 frames in round 2, 14.0 with the caps computed and tf_res / fine_prio in one byte, 11.3 with the energies resting, 8.6 with OG_PARSE_PULSES_REC):
     union {
         // the band energies while the header's energy stages and energy_finalise work on them (coarse energy .. , fine energy, the
         // finalise pass); in between they rest in the frame's record (LaneArr::energies_rest / energies_back: 21 words each way)
@@ -242,7 +247,11 @@ struct LaneArr {
             PL.u.bandE[2 * i + 1][OG_PCOL] = (i16)(w[i] >> 16);
         }
     }
+#ifndef OG_PARSE_PULSES_REC
+    OG_MEMBER i32 &pulses(int i) const { return PL.pulses[i][OG_PCOL]; }
+#else
     OG_MEMBER i32 &pulses(int i) const { return pl[i]; }
+#endif
     OG_MEMBER i8 &fine_quant(int i) const { return PL.fine_quant[i][OG_PCOL]; }
     OG_MEMBER FinePrioView fine_prio(int i) const { return FinePrioView{&PL.tf_prio[i][OG_PCOL]}; }
     OG_MEMBER TfResView tf_res(int i) const { return TfResView{&PL.tf_prio[i][OG_PCOL]}; }
@@ -1152,16 +1161,19 @@ OG_DEV void rec_word4(RecCur &cur, u32 &w0, u32 &w1, u32 &w2, u32 &w3) {
 // The noise generator jumped ahead (lcg_skip) by n = lane + 1, lane + 65, lane + 129 steps: s -> a s + c.  Computed
 // once per frame; every noise / dither pass then costs one multiply-add per coefficient.
 struct LcgTab {
+#if !defined(OG_HOST_EMUL) && !defined(OG_NO_LCG_ROM)
+    // The jumps by 1 .. 192 steps are constants (rom_lcg_jump, tools/gen_rom_tables.py): a noise sample reads its pair from there.
+    // (Rounds 2 - 3 kept the wave's six values in this object; the compiler put the object in scratch memory and turned at()'s
+    // selects into indexed loads from it -- two trips to memory per sample where this is one, and the kernel's only scratch
+    // traffic: 2 KB per frame written and read back through HBM.)
+    OG_MEMBER void init() {}
+    OG_MEMBER u32 at(u32 seed, int j) const { // seed advanced by (j + 1) steps, 0 <= j < 192
+        const u32 a = rom_lcg_jump[2 * j], c = rom_lcg_jump[2 * j + 1];
+        return a * seed + c;
+    }
+#else
     u32 a[3], c[3];
     OG_MEMBER void init() {
-#if !defined(OG_HOST_EMUL) && !defined(OG_NO_LCG_ROM)
-        // (the jumps by 1 .. 192 steps are constants: rom_lcg_jump, tools/gen_rom_tables.py)
-        for (int k = 0; k < 3; k++) {
-            a[k] = rom_lcg_jump[2 * (OG_LANE + 64 * k)];
-            c[k] = rom_lcg_jump[2 * (OG_LANE + 64 * k) + 1];
-        }
-        return;
-#endif
         for (int k = 0; k < 3; k++) {
             u32 n = (u32)(OG_LANE + 64 * k + 1), ra = 1u, rc = 0u, ba = 1664525u, bc = 1013904223u;
             while (n) {
@@ -1186,6 +1198,7 @@ struct LcgTab {
         return (k == 0 ? a[0] : k == 1 ? a[1] : a[2]) * seed + (k == 0 ? c[0] : k == 1 ? c[1] : c[2]);
 #endif
     }
+#endif
 };
 
 // anti_collapse (celt.cpp:1010) for the reconstruction kernel of 20 ms frames.  The shared form (og_celt_bands.hpp) derives a band's
