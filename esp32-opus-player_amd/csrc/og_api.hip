@@ -1381,7 +1381,7 @@ int opusgpu_decode_steps_device(opusgpu_ctx *ctx, int n_steps, const int32_t *n,
     int max_n = 0;
     for (int k = 0; k < n_steps; k++) {
         if (n[k] < 0) return OPUSGPU_BAD_ARG;
-        if (n[k] > 0 && (!d_descs[k] || !d_arena[k] || !d_pcm[k] || !d_result[k])) return OPUSGPU_BAD_ARG;
+        if (n[k] > 0 && (!d_descs[k] || !d_arena[k] || ((uintptr_t)d_arena[k] & 15) || !d_pcm[k] || !d_result[k])) return OPUSGPU_BAD_ARG;
         max_n = OG_MAX(max_n, n[k]);
     }
     if (max_n == 0) return OPUSGPU_OK;

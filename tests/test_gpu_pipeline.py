@@ -163,6 +163,24 @@ def test_mode_mask_is_checked(pkg, oracle, gpu_ctx):
         assert ok.sum() > 500 and np.array_equal(pcm[ok], pcm0[ok])
 
 
+def test_arena_alignment_is_checked(pkg, gpu_ctx):
+    """opusgpu.h: d_arena is 16-byte aligned (the parse lanes fetch packets as aligned 16-byte pieces); a call with an arena that is
+    not comes back with OPUSGPU_BAD_ARG before anything is queued, for a single step and for a window."""
+    import ctypes as C
+    n = 64
+    gpu_ctx.streams_alloc(n, 2)
+    d_arena, d_desc, d_pcm, d_res = gpu_ctx.dev_alloc(4096), gpu_ctx.dev_alloc(16 * n), gpu_ctx.dev_alloc(n * 960 * 2 * 2), gpu_ctx.dev_alloc(4 * n)
+    base = d_arena.value if isinstance(d_arena, C.c_void_p) else int(d_arena)
+    for skew in (4, 8, 12):
+        with pytest.raises(pkg.OpusGpuError) as e:
+            gpu_ctx.decode_step_device(n, d_desc, C.c_void_p(base + skew), d_pcm, d_res)
+        assert e.value.code == -1
+        with pytest.raises(pkg.OpusGpuError) as e:
+            gpu_ctx.decode_steps_device([n, n], [d_desc, d_desc], [d_arena, C.c_void_p(base + skew)], [d_pcm, d_pcm], [d_res, d_res])
+        assert e.value.code == -1
+    gpu_ctx.synchronize()
+
+
 def test_pipeline_with_synchronisation_points_and_reset(pkg, oracle, gpu_ctx):
     """Synchronising between some steps and resetting the streams in the middle (OPUS_RESET_STATE keeps the band energies, Q5)
     changes nothing; neither does switching the option off and on between runs."""
