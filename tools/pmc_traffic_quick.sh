@@ -1,3 +1,7 @@
+#!/bin/bash
+# usage (GPU box): tools/pmc_traffic_quick.sh build_ab/lib_a.so build_ab/lib_b.so ...   -- HBM bytes per frame and CELT kernel of library
+# variants, two --pmc passes each (FETCH_SIZE, WRITE_SIZE; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 as in tools/prof_pmc.sh), in-order steps of the
+# headline workload with the 64-frame parse kernel: the quick form of collect_profiles.sh pmc for same-box comparisons.
 export TMPDIR=/tmp
 for lib in "$@"; do
   tag=$(basename $lib .so)
