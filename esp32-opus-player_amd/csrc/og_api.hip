@@ -934,7 +934,8 @@ int opusgpu_streams_alloc(opusgpu_ctx *ctx, int n_streams, int channels) {
 int opusgpu_dev_alloc(opusgpu_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return OPUSGPU_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipError_t e = hipMalloc(dptr, bytes ? bytes : 4);
+    // (16 bytes more than asked for: an arena made with this call then has the tail the kernels' 16-byte packet fetches may touch)
+    hipError_t e = hipMalloc(dptr, bytes + 16);
     if (e != hipSuccess) return fail(ctx, OPUSGPU_ALLOC_FAIL, "hipMalloc", e);
     return OPUSGPU_OK;
 }

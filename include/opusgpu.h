@@ -168,7 +168,7 @@ int opusgpu_packet_to_frames(const uint8_t *packet, int32_t len, int32_t stream,
 int opusgpu_packet_to_frames_mode(const uint8_t *packet, int32_t len, int32_t stream, int mode, opusgpu_frame_desc descs[48]);
 
 /* ---- device-resident path (inputs and outputs stay in HBM; used by bench.py and on-device consumers) -- */
-int opusgpu_dev_alloc(opusgpu_ctx *ctx, size_t bytes, void **dptr);
+int opusgpu_dev_alloc(opusgpu_ctx *ctx, size_t bytes, void **dptr); /* hipMalloc of bytes + 16: aligned and tailed as a packet arena must be */
 int opusgpu_dev_free(opusgpu_ctx *ctx, void *dptr);
 int opusgpu_memcpy_h2d(opusgpu_ctx *ctx, void *dst, const void *src, size_t bytes);
 int opusgpu_memcpy_d2h(opusgpu_ctx *ctx, void *dst, const void *src, size_t bytes);
