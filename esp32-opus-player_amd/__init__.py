@@ -28,6 +28,7 @@ EXPORTS = [
     "opusgpu_pages_demux", "opusgpu_pages_demux_into", "opusgpu_page_batch_arena_offset", "opusgpu_page_batch_steps", "opusgpu_page_batch_step", "opusgpu_page_batch_arena",
     "opusgpu_page_batch_free", "opusgpu_pages_crc_device", "opusgpu_output_stage_device",
     "opusgpu_set_mode", "opusgpu_get_mode", "opusgpu_set_pipeline", "opusgpu_get_pipeline", "opusgpu_packet_to_frames_mode",
+    "opusgpu_empty_packet_to_frames",
 ]
 
 
@@ -108,6 +109,7 @@ def load_lib():
     lib.opusgpu_decode_packets_fec.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]
     lib.opusgpu_packet_to_frames.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(FrameDesc)]
     lib.opusgpu_packet_to_frames_mode.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int, C.POINTER(FrameDesc)]
+    lib.opusgpu_empty_packet_to_frames.argtypes = [C.c_int32, C.c_int32, C.c_int, C.c_int, C.POINTER(FrameDesc)]
     lib.opusgpu_set_mode.argtypes = [vp, C.c_int]
     lib.opusgpu_get_mode.argtypes = [vp]
     lib.opusgpu_set_pipeline.argtypes = [vp, C.c_int]
@@ -164,6 +166,17 @@ def packet_to_frames(packet: bytes, stream: int = 0):
     lib = load_lib()
     d = (FrameDesc * 48)()
     n = lib.opusgpu_packet_to_frames(packet, len(packet), stream, d)
+    if n < 0:
+        return n
+    return [(d[i].offset, d[i].len, d[i].flags) for i in range(n)]
+
+
+def empty_packet_to_frames(last_flags, decoder_channels, frame_size, stream: int = 0):
+    """Host-only: the frames of an EMPTY packet in reference mode (opusgpu_empty_packet_to_frames): `last_flags` the flags of the
+    stream's last accepted packet, negative when it has had none since its reset.  List of (offset, len, flags) or a negative code."""
+    lib = load_lib()
+    d = (FrameDesc * 48)()
+    n = lib.opusgpu_empty_packet_to_frames(stream, last_flags, decoder_channels, frame_size, d)
     if n < 0:
         return n
     return [(d[i].offset, d[i].len, d[i].flags) for i in range(n)]
@@ -325,7 +338,9 @@ class Context:
 
     def decode_packets(self, stream_ids, packets, frame_capacity=1, _fn="opusgpu_decode_packets"):
         """Batched opus_multistream_decode: returns (pcm[n, cap*960, ch] int16, result[n] int32).
-        RFC mode: an empty (or None) packet is a LOST packet, concealed for as long as the stream's last packet was."""
+        RFC mode: an empty (or None) packet is a LOST packet, concealed for as long as the stream's last packet was.
+        Reference mode: an empty packet is what the reference makes of one (include/opusgpu.h "EMPTY PACKETS"): passes of an empty
+        frame in the stream's last mode, 960 samples each, frame_capacity of them or until one fails."""
         packets = [b"" if p is None else p for p in packets]
         n = len(packets)
         ids = np.ascontiguousarray(stream_ids, dtype=np.int32)
@@ -432,6 +447,8 @@ class Context:
         a stream's mode never crosses between CELT-only and SILK-only / hybrid (config 5: it is fixed)."""
         def at(p, off):
             return C.c_void_p((p.value if isinstance(p, C.c_void_p) else int(p)) + off)
+        if self.lib.opusgpu_get_mode(self.h) != 0:
+            raise OpusGpuError("decode_step_by_kind: reference mode only (a frame's PCM block is 960 samples here; RFC mode's is 2880)")
         f0 = 0
         extra = STEP_KEEPS_MODE if keeps_kind else 0
         for cnt, mode in ((n_silk, HAS_SILK), (n_hybrid, HAS_HYBRID), (n_celt, HAS_CELT)):
@@ -565,7 +582,8 @@ def silk_header_key(first_payload_bytes, stereo):
     VAD flag and LBRR flag of the mid channel, then of the side channel).  -> 2-bit key: bit 0 the mid channel carries an LBRR
     frame, bit 1 the side channel does (each is a whole extra frame of side information and pulses that the decoder must read
     past, src/silk.cpp:1590-1616).  Frames handed to the lane-per-frame parse kernel in key order make its waves uniform: a wave
-    whose 32 frames have no LBRR data skips those passes instead of idling through them."""
+    whose 32 frames have no LBRR data skips those passes instead of idling through them.  The bit positions are those of
+    a frame decoded as 20 ms -- every frame in reference mode (Q6), the only mode with such steps."""
     b = np.asarray(first_payload_bytes, dtype=np.uint8)
     key = (b >> 6) & 1
     if stereo:

@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const Fra
 #endif
             ret = decode_frame_wave<true>(s, arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
                                           desc_channels(d.flags), pcm + (size_t)f * pcm_stride, handoff ? &handoff[f] : nullptr,
-                                          srecs ? &srecs[f] : nullptr, q4_only);
+                                          srecs ? &srecs[f] : nullptr, q4_only, desc_mode_after(d.flags));
 #ifdef OG_PROF_SINGLE
             OG_PROF_FLUSH();
 #endif
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(64, OG_SPARSE_WAVES) k_silk_parse(const FrameD
     SilkShadow *const sh = shadow ? &shadow[d.stream] : nullptr;
     const SilkPast past(&st[d.stream], sh, epoch);
     silk_parse_lane(past, arena + d.offset, d.len, mode, desc_bandwidth(d.flags), desc_channels(d.flags), &srecs[f], &handoff[f]);
-    silk_params_lane(past, mode, desc_bandwidth(d.flags), desc_channels(d.flags), &srecs[f], sh, epoch);
+    silk_params_lane(past, mode, desc_bandwidth(d.flags), desc_channels(d.flags), &srecs[f], sh, epoch, desc_mode_after(d.flags));
 #ifdef OG_PROF_SPARSE
     OG_PROF_FLUSH();
 #endif
@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(64, OG_RECON_WAVES) k_celt_recon(const FrameDe
         OG_PROF_INIT();
 #endif
         const int pos = OG_UNI(st[d.stream].celt.ring_pos); // where the frame's first sample goes
-        const int ret = celt_recon_wave(&st[d.stream], &recs[f], mode, desc_channels(d.flags), rest_only ? RECON_REST_ONLY : RECON_ALL);
+        const int ret = celt_recon_wave(&st[d.stream], &recs[f], mode, desc_channels(d.flags), rest_only ? RECON_REST_ONLY : RECON_ALL, desc_mode_after(d.flags));
         if (ret != RECON_NOT_MINE && threadIdx.x == 0) rout[f] = ReconOut{ret, pos};
 #if !defined(OG_PROF_PARSE) && !defined(OG_PROF_SINGLE) && !defined(OG_PROF_SPARSE) && !defined(OG_PROF_SSYNTH)
         OG_PROF_FLUSH();
@@ -689,6 +689,7 @@ struct opusgpu_ctx {
     void *d_shadow = nullptr;
     unsigned shadow_epoch = 1; // advanced by everything else that may change a stream's SILK state: stale copies are ignored
     int silk_slot = 0, sdone_recorded[2] = {}, last_silk_mask = 0, last_kind = 0; // last_kind: 0 in order, 1 pipelined CELT-only, 2 pipelined SILK-only
+    bool last_kind2_celt = false; // the last step of kind 2 held CELT-only frames too (enter_step_kind)
     hipEvent_t ev_sparsed = nullptr, ev_sdone[2] = {};
     int leaf_kernel = 0; // OPUSGPU_LEAF_KERNEL=1: k_celt_leaves decodes the PVQ leaves ahead of the reconstruction (og_leaves.hip; measured slower)
     int split_celt = 1;   // OPUSGPU_SPLIT=0 forces the single-kernel path for every mode (A/B measurements)
@@ -935,6 +936,7 @@ int opusgpu_dev_alloc(opusgpu_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return OPUSGPU_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // (16 bytes more than asked for: an arena made with this call then has the tail the kernels' 16-byte packet fetches may touch)
+    if (bytes > SIZE_MAX - 16) return OPUSGPU_ALLOC_FAIL;
     hipError_t e = hipMalloc(dptr, bytes + 16);
     if (e != hipSuccess) return fail(ctx, OPUSGPU_ALLOC_FAIL, "hipMalloc", e);
     return OPUSGPU_OK;
@@ -996,8 +998,13 @@ static void launch_jitter() {
 // hybrid, CELT-only) since its last reset.  Such a step shares no stream with anything of the other kind that is still in flight,
 // so going from one pipelined kind to the other needs no drain, and a CELT-only step leaves the SILK parse kernel's copies (of
 // other streams) as current as they were.
-static int enter_step_kind(opusgpu_ctx *ctx, int kind, hipStream_t s, bool keeps_kind = false) {
-    const bool disjoint = keeps_kind && kind != 0 && ctx->last_kind != 0;
+// ... as long as the two kinds really are about different streams: a kind-2 step that carries CELT-only frames along (any mix under
+// OPUSGPU_STEP_KEEPS_MODE, `celt_frames`) reconstructs them on ITS stream, ordered only against other kind-2 steps, while a kind-1
+// step's reconstruction runs on recon_stream and waits only for kind-1 steps.  Next to each other the two would work on the same
+// CELT-only streams' state with nothing in between: that change of kind drains like an undeclared one.
+static int enter_step_kind(opusgpu_ctx *ctx, int kind, hipStream_t s, bool keeps_kind = false, bool celt_frames = false) {
+    const bool shares_celt = (kind == 1 && ctx->last_kind == 2 && ctx->last_kind2_celt) || (kind == 2 && celt_frames && ctx->last_kind == 1);
+    const bool disjoint = keeps_kind && kind != 0 && ctx->last_kind != 0 && !shares_celt;
     if ((kind == 2) != (ctx->last_kind == 2) && !disjoint) {
         if (int rc = sync_in_flight(ctx)) return rc;
         HIPCHK(ctx, hipStreamSynchronize(s));
@@ -1008,6 +1015,7 @@ static int enter_step_kind(opusgpu_ctx *ctx, int kind, hipStream_t s, bool keeps
     }
     if (kind != 2 && !(keeps_kind && kind == 1)) ctx->shadow_epoch++;
     ctx->last_kind = kind;
+    if (kind == 2) ctx->last_kind2_celt = celt_frames;
     return OPUSGPU_OK;
 }
 
@@ -1101,7 +1109,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     // CELT-only frame cannot make another stream's SILK copy stale
     const bool pipe_silk = ctx->pipeline && tables_resident && ((modes & 4) == 0 || keeps_kind) && (modes & 3) != 0 && ctx->split_hybrid && !slices &&
                            (modes == 1 ? og_debug().silk_pipeline : og_debug().hybrid_pipeline);
-    if (int rc = enter_step_kind(ctx, pipe ? 1 : pipe_silk ? 2 : 0, s, keeps_kind)) return rc;
+    if (int rc = enter_step_kind(ctx, pipe ? 1 : pipe_silk ? 2 : 0, s, keeps_kind, (modes & 4) != 0)) return rc;
     if (ctx->pipeline && ctx->last_step_stream && ctx->last_step_stream != s) {
         // consecutive steps on different streams: nothing orders them but the caller, so nothing may run ahead either
         HIPCHK(ctx, hipStreamSynchronize(ctx->last_step_stream));
@@ -1359,7 +1367,7 @@ int opusgpu_decode_step_device(opusgpu_ctx *ctx, int n, const void *d_descs, con
 }
 int opusgpu_decode_step_device_modes(opusgpu_ctx *ctx, int n, const void *d_descs, const void *d_arena, void *d_pcm,
                                      void *d_result, void *hip_stream, int modes) {
-    if ((modes & 7) == 0 || modes > 15) return OPUSGPU_BAD_ARG;
+    if (modes <= 0 || modes > 15 || (modes & 7) == 0) return OPUSGPU_BAD_ARG;
     return decode_step_impl(ctx, n, d_descs, d_arena, d_pcm, d_result, hip_stream, true, modes);
 }
 int opusgpu_decode_steps_device(opusgpu_ctx *ctx, int n_steps, const int32_t *n, const void *const *d_descs, const void *const *d_arena,
@@ -1678,6 +1686,15 @@ int opusgpu_packet_to_frames_mode(const uint8_t *packet, int32_t len, int32_t st
     return count;
 }
 
+int opusgpu_empty_packet_to_frames(int32_t stream, int32_t last_flags, int decoder_channels, int frame_size, opusgpu_frame_desc descs[48]) {
+    if (!descs || frame_size <= 0 || frame_size % 120 || (decoder_channels != 1 && decoder_channels != 2)) return OPUSGPU_BAD_ARG;
+    const int count = (frame_size + OPUSGPU_FRAME_SAMPLES - 1) / OPUSGPU_FRAME_SAMPLES;
+    if (count > 48) return OPUSGPU_BAD_ARG;
+    const int32_t flags = last_flags >= 0 ? (last_flags & 63) : ogh::empty_flags_no_packet_yet(decoder_channels);
+    for (int i = 0; i < count; i++) descs[i] = opusgpu_frame_desc{stream, 0, 0, flags};
+    return count;
+}
+
 static int grow_pinned(opusgpu_ctx *ctx, void **p, size_t *cap, size_t need) {
     if (*cap >= need) return OPUSGPU_OK;
     if (*p) HIPCHK(ctx, hipHostFree(*p));
@@ -1783,7 +1800,7 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
     };
     auto on_ranges = [&](auto &&f) { on_subranges(0, n, f); };
     std::vector<int> first(n + 1, 0), nframes(n, 0);
-    std::vector<uint8_t> is_lost(rfc ? n : 0, 0);
+    std::vector<uint8_t> is_lost(n, 0);
     // The common large call is REGULAR: every packet holds one frame (frame-count code 0) of a stream that exists, of a size and
     // duration the call has room for.  One look at the TOC bytes settles that, and then nothing of the first framing pass is
     // needed: packet i is frame i of the one step, its bytes lie at the running sum of the lengths, and the (only) framing pass
@@ -1801,6 +1818,8 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
                 }
                 result[i] = 0;
                 nframes[i] = 1;
+                ctx->last_count[stream_ids[i]] = 1; // (what an empty packet of this stream will be decoded as: below)
+                ctx->last_flags[stream_ids[i]] = ogh::toc_flags(p[0]);
             }
         });
         regular = irregular.load() == 0;
@@ -1815,7 +1834,13 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
             }
             if (!packets[i] || lens[i] == 0) {
                 if (!rfc) {
-                    result[i] = OPUSGPU_BAD_ARG; // no PLC in the reference: data==NULL/len==0 ends in an error (Q8)
+                    // The reference has no concealment, but opus_decode_native's empty-packet branch is live (src/opus_decoder.cpp:
+                    // 290-308): opus_decode_frame(st, NULL, 0) -- a frame of no bytes in the stream's LAST mode / bandwidth / channel
+                    // count, 960 samples per pass -- until frame_size (here frame_capacity x 960, a multiple of 120) is filled or a
+                    // pass fails: SILK-only decodes (the coder reads zeros), hybrid runs its SILK half and ends in CELT's -18
+                    // (src/celt.cpp:2225), CELT-only in -18; a stream without a packet since its reset is in mode 0 (descriptor bit 11)
+                    nframes[i] = frame_capacity;
+                    is_lost[i] = 1;
                     continue;
                 }
                 // RFC mode: a lost packet is concealed as long as the stream's last packet was (one 20 ms frame if there was none)
@@ -1865,10 +1890,11 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
                 continue;
             }
             nframes[i] = count;
-            if (rfc) { // (a stream appears at most once per call: no two threads write the same entry)
-                ctx->last_count[stream_ids[i]] = count;
-                ctx->last_flags[stream_ids[i]] = d[0].flags;
-            }
+            // what a later empty packet of the stream decodes / conceals as: st->mode, bandwidth, stream_channels (src/opus_decoder.cpp:
+            // 327-331: set once the packet has passed the checks above, whatever its frames return).  (A stream appears at most once
+            // per call: no two threads write the same entry.)
+            ctx->last_count[stream_ids[i]] = count;
+            ctx->last_flags[stream_ids[i]] = d[0].flags;
         }
     });
     timer.mark("framing pass 1 (counts)");
@@ -1876,7 +1902,7 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
     int max_frames = 0;
     for (int i = 0; i < n; i++) {
         first[i + 1] = first[i] + nframes[i];
-        base[i + 1] = base[i] + (nframes[i] && !(rfc && (is_lost[i] == 1 || is_lost[i] == 3)) ? (size_t)lens[i] : 0);
+        base[i + 1] = base[i] + (nframes[i] && !(is_lost[i] == 1 || is_lost[i] == 3) ? (size_t)lens[i] : 0);
         if (nframes[i] > max_frames) max_frames = nframes[i];
     }
     timer.mark("prefix sums");
@@ -1890,9 +1916,10 @@ static int decode_packets_impl(opusgpu_ctx *ctx, int n, const int32_t *stream_id
     auto place = [&](int lo, int hi) { // framing pass 2: descriptors and packet bytes of packets [lo, hi) to their places
         for (int i = lo; i < hi; i++) {
             if (!nframes[i]) continue;
-            if (rfc && is_lost[i] == 1) { // nothing to read: len 0, the flags of the stream's last packet (RFC bit and duration included)
-                const int32_t fl = ctx->last_count[stream_ids[i]] ? ctx->last_flags[stream_ids[i]]
-                                                                   : (int32_t)((ogh::MODE_CELT - ogh::MODE_SILK) | 4 << 2 | (CC == 2 ? 32 : 0) | 1 << 9);
+            if (is_lost[i] == 1) { // nothing to read: len 0, the flags of the stream's last packet (RFC mode: RFC bit and duration included)
+                const int32_t fresh = rfc ? (int32_t)((ogh::MODE_CELT - ogh::MODE_SILK) | 4 << 2 | (CC == 2 ? 32 : 0) | 1 << 9)
+                                          : ogh::empty_flags_no_packet_yet(CC);
+                const int32_t fl = ctx->last_count[stream_ids[i]] ? ctx->last_flags[stream_ids[i]] : fresh;
                 for (int k = 0; k < nframes[i]; k++) all[first[i] + k] = opusgpu_frame_desc{stream_ids[i], 0, 0, fl};
                 continue;
             }

@@ -2102,6 +2102,7 @@ struct ReconCtx {
     ReconHdr h;
     u32 flags, rng_final;
     int ret, mode, C;
+    int mode_after = -1; // what the frame leaves as prev_mode when it is not `mode` (desc_mode_after)
     bool leaves; // the frame has a leaf pass and a synthesis (its record is not a BAD_CELT one)
     bool fast;
     bool was_reset = false; // the stream's CELT state was reset at this frame (mode change)
@@ -2326,15 +2327,16 @@ OG_DEV int recon_finish(StreamState *st, const ParseRec *rec, const ReconCtx &rx
         if (flags & RF_TELL_OVERFLOW) result = INTERNAL_ERROR;
     }
     if (OG_LANE == 0) {
-        st->prev_mode = mode;
+        st->prev_mode = rx.mode_after >= 0 ? rx.mode_after : mode;
         st->frames_decoded = rx.h.frames_decoded + 1;
         st->range_final = rx.rng_final;
     }
     return result; // de-emphasis and PCM: celt_post_lane (k_celt_post), from the history ring
 }
 
-OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int ch, int role = RECON_ALL) {
+OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int ch, int role = RECON_ALL, int mode_after = -1) {
     ReconCtx rx;
+    rx.mode_after = mode_after;
     recon_hdr_load(st, rec, rx.h);
     if (!recon_begin(st, rec, mode, ch, role, rx)) return rx.ret;
     if (rx.leaves) {

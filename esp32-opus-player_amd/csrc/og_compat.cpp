@@ -72,14 +72,36 @@ static int dec_open(OpusDecoder *d, int32_t Fs, int channels) {
 }
 
 static int dec_decode(OpusDecoder *d, const uint8_t *data, int32_t len, int16_t *pcm, int frame_size) {
-    if (!d || !d->ctx || frame_size <= 0) return OPUS_BAD_ARG;
-    if (len <= 0 || data == nullptr) return OPUS_BAD_ARG; // no loss concealment in the reference (Q8)
+    if (!d || !d->ctx || frame_size <= 0) return OPUS_BAD_ARG; // src/opus_decoder.cpp:351
+    if (len == 0 || data == nullptr) {
+        // The reference's empty-packet branch (src/opus_decoder.cpp:290-308; include/opusgpu.h "EMPTY PACKETS"): passes of
+        // opus_decode_frame(NULL, 0) -- 960 samples each, in the decoder's last mode -- until frame_size is filled or one fails.
+        if (frame_size % 120) return OPUS_BAD_ARG; // :290
+        // A frame_size that is no multiple of 960 makes the reference write the whole last pass past what the caller offered and
+        // trip its assert (:306): refused here instead -- the one deliberate difference of this branch.
+        if (frame_size % 960) return OPUS_BUFFER_TOO_SMALL;
+        const int passes = frame_size / 960;
+        int32_t id = 0, res = 0, zero = 0;
+        const uint8_t *none = nullptr;
+        int16_t *buf = (int16_t *)malloc(sizeof(int16_t) * (size_t)passes * 960 * d->channels);
+        if (!buf) return OPUS_ALLOC_FAIL;
+        int rc = opusgpu_decode_packets(d->ctx, 1, &id, &none, &zero, buf, passes, &res);
+        if (rc != OPUSGPU_OK) res = OPUS_INTERNAL_ERROR;
+        if (res > 0) {
+            memcpy(pcm, buf, sizeof(int16_t) * (size_t)res * d->channels);
+            d->last_packet_duration = res; // :307
+        }
+        free(buf);
+        return res;
+    }
+    if (len < 0) return OPUS_BAD_ARG; // :309
     const int pfs = ogh::toc_samples_per_frame(data[0], 48000);
     uint8_t toc;
     int16_t size[48];
     const int count = ogh::parse_packet(data, len, 0, &toc, size, nullptr, nullptr);
     if (count < 0) return count;
     if (count * pfs > frame_size) return OPUS_BUFFER_TOO_SMALL;
+    d->bandwidth = ogh::toc_bandwidth(toc); // :328: with the packet accepted, whatever its frames return
     // the GPU path writes 960 samples per frame (Q6); decode into a scratch block sized for `count` frames
     int32_t id = 0, res = 0;
     const uint8_t *pk = data;
@@ -90,7 +112,6 @@ static int dec_decode(OpusDecoder *d, const uint8_t *data, int32_t len, int16_t 
     if (res > 0) {
         int n = res < frame_size ? res : frame_size;
         memcpy(pcm, buf, sizeof(int16_t) * (size_t)n * d->channels);
-        d->bandwidth = ogh::toc_bandwidth(toc);
         d->last_packet_duration = res;
     }
     free(buf);
@@ -197,9 +218,12 @@ OpusMSDecoder_t *opus_multistream_decoder_create(int32_t Fs, int channels, int s
 }
 
 int opus_multistream_decode(OpusMSDecoder_t *st, uint8_t *data, int32_t len, int16_t *pcm, int frame_size) {
+    // opus_multistream_decode_native (src/opus_decoder.cpp:826-913), one stream: frame_size <= 0 -> -1 (:836); frame_size capped at
+    // 120 ms (:841); len < 0 -> -1 (:848); len == 0 is the empty packet of opus_decode_native (do_plc, :847), len >= 1 passes
+    // :851's `len < 2 * nb_streams - 1`; opus_multistream_packet_validate's answers (:854-860) are those of dec_decode's own parse
+    // and size check; `ret <= 0` comes back as it is (:876)
     if (!st || frame_size <= 0 || len < 0) return OPUS_BAD_ARG;
     MSImpl *m = reinterpret_cast<MSImpl *>(st);
-    if (len == 0) return OPUS_BAD_ARG; // PLC path does not exist (Q8)
     if (frame_size > 5760) frame_size = 5760;
     const int dch = m->dec.channels;
     int16_t *buf = (int16_t *)malloc(sizeof(int16_t) * 2 * (size_t)frame_size);

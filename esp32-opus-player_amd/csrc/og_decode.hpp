@@ -54,8 +54,9 @@ OG_DEV void stream_reset(StreamState *st) {
 enum { CONTINUE_SPLIT = 1, CONTINUE_Q4 = 2 };
 template <bool WITH_CELT>
 OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mode, int bandwidth, int ch, i16 *pcm,
-                             SilkHandoff *handoff = nullptr, const SilkRec *srec = nullptr, int q4_resume = 0) {
+                             SilkHandoff *handoff = nullptr, const SilkRec *srec = nullptr, int q4_resume = 0, int mode_after = -1) {
     const int audiosize = 960;
+    if (mode_after < 0) mode_after = mode; // (what prev_mode becomes: desc_mode_after)
     const int CC = st->channels;
     if (len < 0 || len > 1275) return BAD_ARG;
     // (split path: the value the parse kernel saw when the step began; see SilkRec::prev_mode)
@@ -190,7 +191,7 @@ OG_DEV int decode_frame_wave(StreamState *st, const u8 *payload, int len, int mo
     }
 #endif
     if (OG_LANE == 0) {
-        st->prev_mode = mode;
+        st->prev_mode = mode_after;
         st->frames_decoded += 1;
         st->range_final = rc.rng;
     }

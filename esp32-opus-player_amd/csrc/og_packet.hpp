@@ -33,6 +33,13 @@ inline int toc_samples_per_frame(uint8_t toc, int32_t Fs) {
 inline int32_t toc_flags(uint8_t toc) {
     return (toc_mode(toc) - MODE_SILK) | ((toc_bandwidth(toc) - BW_NB) << 2) | ((toc & 4) ? 32 : 0);
 }
+// Reference mode, the descriptor flags of an EMPTY packet's frames for a stream that has had no packet since its reset: the
+// reference's decoder is in mode 0 then (src/opus_decoder.cpp:82 / :382 clear it), which opus_decode_frame runs like a hybrid
+// frame -- SILK at 16 kHz on st->channels channels (:175-201), then CELT, which refuses the empty frame -- except that prev_mode
+// stays 0 (:276).  Hybrid, bandwidth irrelevant (SWB), the decoder's channel count, bit 11 (og_state.hpp desc_mode_after).
+inline int32_t empty_flags_no_packet_yet(int decoder_channels) {
+    return (MODE_HYBRID - MODE_SILK) | 3 << 2 | (decoder_channels == 2 ? 32 : 0) | OPUSGPU_DESC_NO_MODE;
+}
 // RFC mode: the frame's duration (bits 6-8) and the mode bit (bit 9) on top of toc_flags
 inline int32_t toc_flags_rfc(uint8_t toc) {
     const int n = toc_samples_per_frame(toc, 48000);

@@ -305,6 +305,9 @@ static int pages_demux_impl(int n_pages, const uint8_t *const *pages, const int3
         // src/silk.cpp:1568-1573; a mono frame has only the first) -- stable otherwise.  An LBRR frame is a whole extra frame of side
         // information and pulses to read past (:1590-1616): 32 frames that agree on it make a parse wave that skips those passes
         // together.  The flags are four sub-keys of the counting sort below (SILK 0..3, hybrid 4..7, CELT 8), not a pass of their own.
+        // (Bits 6 and 4 are where a frame DECODED AS 20 ms has them: one VAD bit, then the LBRR flag, per channel.  Reference mode
+        // decodes every frame so, whatever duration its TOC names (Q6), and these steps exist in reference mode only; a 40 / 60 ms frame
+        // decoded at its true duration would have two / three VAD bits in front of the flag.  The order never changes a result.)
         const bool by_header = (flags & OPUSGPU_PAGES_ORDER_BY_HEADER) != 0;
         const int G = group ? (by_header ? 9 : 3) : 1;
         RawBuf<uint8_t> mode_of; // sort key within a step (mode 0..2, or the nine keys above) per frame of every page, only when grouping

@@ -645,7 +645,7 @@ static_assert(2 * SILK_MAX_FRAME * 4 * 2 >= 1920 * 2 && SILK_MAX_FRAME * 4 * 2 <
 // (silk_decode_packet: silk_init_state on a switch from CELT, silk_chan_init for a channel the packet adds, silk_set_fs, the
 // side channel's restart, the indices' history, the gain index, the stabilised NLSFs; decode_frame_wave: prev_mode).
 OG_DEV void silk_params_lane(const SilkPast &past, int mode, int bandwidth, int channels, SilkRec *rec, SilkShadow *shadow = nullptr,
-                             u32 epoch = 0) {
+                             u32 epoch = 0, int mode_after = -1) {
     if (rec->ret < 0) return; // (the frame ends in an error before anything of the state is touched: the past stays what it is)
     int internal_hz = 16000;
     if (mode == MODE_SILK) internal_hz = bandwidth == BW_NB ? 8000 : (bandwidth == BW_MB ? 12000 : 16000);
@@ -699,7 +699,7 @@ OG_DEV void silk_params_lane(const SilkPast &past, int mode, int bandwidth, int 
         o.first_frame_after_reset = ffar;
         for (int i = 0; i < SILK_REC_LPC; i++) o.prevNLSF_Q15[i] = nl[i];
     }
-    shadow->prev_mode = mode;
+    shadow->prev_mode = mode_after >= 0 ? mode_after : mode;
     shadow->nChannelsInternal = channels;
     shadow->prev_decode_only_middle = dom; // (0 for a mono packet: silk_decode_packet stores its local, which only stereo packets set)
     shadow->epoch = epoch;

@@ -109,10 +109,15 @@ struct FrameDesc {
     i32 flags;                 // bits 0-1: 0 SILK, 1 hybrid, 2 CELT; bits 2-4: bandwidth - 1101; bit 5: stereo;
                                // bits 6-8: frame duration (0: 20 ms, 1: 2.5, 2: 5, 3: 10, 4: 40, 5: 60); bit 9: RFC mode;
                                // bit 10 (RFC mode): decode the frame's forward error correction data (the frame before it)
+                               // bit 11 (reference mode, an EMPTY frame of a stream that has had no packet since its reset): the
+                               // reference's decoder is in mode 0 there, which opus_decode_frame runs like hybrid (SILK at 16 kHz,
+                               // then CELT's refusal of the empty frame) but leaves as prev_mode (src/opus_decoder.cpp:156,175,276)
 };
 OG_DEV int desc_mode(i32 f) { return MODE_SILK + (f & 3); }
 OG_DEV int desc_bandwidth(i32 f) { return BW_NB + ((f >> 2) & 7); }
 OG_DEV int desc_channels(i32 f) { return (f & 32) ? 2 : 1; }
+// what the frame leaves as the stream's prev_mode: its mode -- or 0 for the mode-0 frame (bit 11: coded as hybrid, see above)
+OG_DEV int desc_mode_after(i32 f) { return ((f >> 11) & 1) && (f & 3) == 1 ? 0 : desc_mode(f); }
 // RFC mode (opt-in, opusgpu_set_mode): the frame decodes at the duration its TOC names; reference mode: always 960 (Q6)
 OG_DEV int desc_rfc(i32 f) { return (f >> 9) & 1; }
 OG_DEV int desc_fec(i32 f) { return (f >> 10) & 1; }

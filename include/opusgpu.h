@@ -40,8 +40,26 @@ typedef struct opusgpu_ctx opusgpu_ctx;
 
 /* One frame of work for one stream in one decode step (16 bytes, device layout).
  * flags: bits 0-1 mode (0 SILK-only, 1 hybrid, 2 CELT-only); bits 2-4 bandwidth (0 NB .. 4 FB); bit 5 stereo;
- * bits 6-10: frame duration, the RFC bit and the FEC bit, zero in reference mode (see OPUSGPU_MODE_RFC).
- * These are the TOC fields opus_decode_native derives (src/opus_decoder.cpp:312-315). */
+ * bits 6-10: frame duration, the RFC bit and the FEC bit, zero in reference mode (see OPUSGPU_MODE_RFC);
+ * bit 11 OPUSGPU_DESC_NO_MODE: see EMPTY PACKETS below.
+ * These are the TOC fields opus_decode_native derives (src/opus_decoder.cpp:312-315).
+ *
+ * EMPTY PACKETS in reference mode (data == NULL or len == 0; src/opus_decoder.cpp:290-308).  The reference conceals nothing, but
+ * its branch for them is live: it calls opus_decode_frame(st, NULL, 0, ...) -- a frame of NO bytes in the decoder's LAST mode,
+ * bandwidth and channel count (what the last accepted packet's TOC set, :327-331), always 960 samples (:161) -- again and again
+ * until `frame_size` samples exist, and stops at the first pass that fails.  What a pass does follows from opus_decode_frame:
+ *   last packet SILK-only  -> the SILK decoder runs off a coder that reads zeros: 960 samples of PCM, the state moves on;
+ *   last packet hybrid     -> the SILK half runs (and its state moves on), then celt_decode_with_ec refuses the empty frame:
+ *                             ERR_OPUS_CELT_BAD_ARG = -18 (src/celt.cpp:2225); prev_mode is updated all the same (:276);
+ *   last packet CELT-only  -> -18, nothing but prev_mode touched;
+ *   no packet since the stream was created or reset -> st->mode is 0, which :175 / :249 run like hybrid (SILK at 16 kHz on the
+ *                             decoder's channel count, then -18), and prev_mode stays 0.
+ * Here: opusgpu_decode_packets takes packets[i] == NULL or lens[i] == 0 as such a packet with frame_size = frame_capacity x 960
+ * and returns in result[i] the samples produced or the failing pass's code (the library remembers every stream's last accepted
+ * TOC).  On the device path the caller passes, per pass, a descriptor with len 0 and the flags of the stream's last accepted
+ * packet -- or, before the stream's first packet, opusgpu_empty_packet_to_frames' flags (hybrid, the decoder's channel count,
+ * OPUSGPU_DESC_NO_MODE).  opusgpu_empty_packet_to_frames builds the descriptors either way. */
+#define OPUSGPU_DESC_NO_MODE (1 << 11)
 typedef struct opusgpu_frame_desc {
     int32_t stream;  /* stream index in the context */
     int32_t offset;  /* byte offset of the frame payload inside the packet arena */
@@ -68,7 +86,8 @@ const char *opusgpu_last_error(const opusgpu_ctx *ctx);
  * no libopus exists:
  * this mode is bit-exact to oracle/'s RFC mode (oc_decoder_set_rfc), which is PARITY-UNPINNED.
  * RFC-mode frames run on a kernel of their own (wave-uniform entropy decoding): the mode is for completeness, not speed.
- * LOSS PATH (the reference has none, Q8 -- in reference mode an empty packet stays OPUSGPU_BAD_ARG):
+ * LOSS PATH (the reference has none, Q8 -- in reference mode an empty packet does what the reference's
+ * empty-packet branch does, see EMPTY PACKETS above: no concealment):
  *   - opusgpu_decode_packets: packets[i] == NULL or lens[i] == 0 is a LOST packet: it is concealed for as long as the stream's
  *     last packet was (frame count x frame duration; 20 ms of zeros before the stream's first packet or after a reset), what
  *     opus_decode(data = NULL, frame_size = last duration) gives; result[i] = the samples concealed;
@@ -166,6 +185,14 @@ int opusgpu_packet_to_frames(const uint8_t *packet, int32_t len, int32_t stream,
 /* The same for a given mode (OPUSGPU_MODE_*): in RFC mode the descriptors carry the frames' duration (flags bits 6 - 8: 0 20 ms,
  * 1 2.5, 2 5, 3 10, 4 40, 5 60) and the RFC bit (bit 9). */
 int opusgpu_packet_to_frames_mode(const uint8_t *packet, int32_t len, int32_t stream, int mode, opusgpu_frame_desc descs[48]);
+/* (Both mirror opus_packet_parse_impl, whose answer to len == 0 is OPUS_INVALID_PACKET, src/opus_decoder.cpp:567: an empty
+ * packet has no TOC to take descriptors from.)  Reference mode, the frames of an EMPTY packet for the device path (EMPTY
+ * PACKETS above): `last_flags` = the flags of the stream's last accepted packet (descs[0].flags of opusgpu_packet_to_frames),
+ * or a negative value when the stream has had none since it was created / reset (`decoder_channels` then names the stream's
+ * channel count); `frame_size` as opus_decode's.  Writes ceil(frame_size / 960) descriptors of len 0 -- one per pass of the
+ * reference's loop, to be run one step each until a pass returns a negative code -- and returns their count; OPUSGPU_BAD_ARG
+ * when frame_size <= 0 or no multiple of 120 (:290, :351) or more than 48 passes. */
+int opusgpu_empty_packet_to_frames(int32_t stream, int32_t last_flags, int decoder_channels, int frame_size, opusgpu_frame_desc descs[48]);
 
 /* ---- device-resident path (inputs and outputs stay in HBM; used by bench.py and on-device consumers) -- */
 int opusgpu_dev_alloc(opusgpu_ctx *ctx, size_t bytes, void **dptr); /* hipMalloc of bytes + 16: aligned and tailed as a packet arena must be */

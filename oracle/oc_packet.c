@@ -432,7 +432,26 @@ int oc_decode(oc_decoder *d, const u8 *data, i32 len, i16 *pcm, int frame_size) 
         d->last_packet_duration = done;
         return done;
     }
-    if (len <= 0 || data == NULL) return OC_BAD_ARG; /* no PLC in the reference (Q8) */
+    /* opus_decoder.cpp:290-308: an empty packet.  The reference has no concealment, but this branch is live: it runs
+     * opus_decode_frame(st, NULL, 0, ...) -- a frame of NO bytes in the decoder's LAST mode / bandwidth / channel count (mode 0
+     * before the first packet and after OPUS_RESET_STATE, which :175 / :249 treat like hybrid: SILK at 16 kHz, then CELT) --
+     * 960 samples per pass (:161; the room left over is ignored) until frame_size is filled.  SILK-only: 960 samples of PCM per
+     * pass and the state moves on; hybrid or no mode yet: the SILK half runs, then celt_decode_with_ec refuses the empty frame
+     * (celt.cpp:2225, -18) with prev_mode updated all the same (:276); CELT-only: -18, nothing but prev_mode touched.
+     * The caller needs room for the whole passes: ceil(frame_size / 960) * 960 samples (the reference writes them too, and
+     * its assert at :306 fires when frame_size is no multiple of 960). */
+    if (len == 0 || data == NULL) {
+        int pcm_count = 0;
+        if (frame_size % 120) return OC_BAD_ARG; /* :290 */
+        do {
+            int ret = decode_frame(d, NULL, 0, pcm + pcm_count * d->channels, 0);
+            if (ret < 0) return ret;
+            pcm_count += ret;
+        } while (pcm_count < frame_size);
+        d->last_packet_duration = pcm_count;
+        return pcm_count;
+    }
+    if (len < 0) return OC_BAD_ARG; /* :309 */
     pmode = oc_packet_mode(data);
     pbw = oc_packet_bandwidth(data);
     pfs = oc_packet_samples_per_frame(data, 48000);

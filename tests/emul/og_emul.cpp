@@ -14,9 +14,17 @@ extern "C" {
 int emu_state_size(void) { return (int)sizeof(og::StreamState); }
 void emu_stream_init(void *st, int channels) { og::stream_init((og::StreamState *)st, channels); }
 void emu_stream_reset(void *st) { og::stream_reset((og::StreamState *)st); }
+// mode 0 = the empty frame of a stream that has had no packet yet (descriptor bit 11, og_state.hpp): coded as hybrid, prev_mode
+// stays 0.  Returns what to pass as mode_after (-1: the mode itself).
+static int emu_no_mode(int &mode) {
+    if (mode != 0) return -1;
+    mode = og::MODE_HYBRID;
+    return 0;
+}
 // the single-kernel path (every mode)
 int emu_decode_frame_single(void *st, const uint8_t *payload, int len, int mode, int bw, int ch, int16_t *pcm) {
-    return og::decode_frame_wave<true>((og::StreamState *)st, payload, len, mode, bw, ch, pcm);
+    const int after = emu_no_mode(mode);
+    return og::decode_frame_wave<true>((og::StreamState *)st, payload, len, mode, bw, ch, pcm, nullptr, nullptr, 0, after);
 }
 // what the library dispatches: CELT-only frames take the split path (parse per lane, reconstruct per wave, post per
 // channel); hybrid frames decode their SILK half on the single-kernel path and hand the CELT half over
@@ -38,6 +46,7 @@ int emu_decode_frame(void *stv, const uint8_t *payload, int len, int mode, int b
     static og::SilkHandoff handoff;
     static og::SilkRec srec;
     const og::SilkHandoff *h = nullptr;
+    const int after = emu_no_mode(mode);
     if (mode != og::MODE_CELT) { // SILK entropy half per lane, then the frame-per-wave kernel from the record
         og::silk_tables_load();
         const og::SilkPast past(st, nullptr, 0);
@@ -50,7 +59,7 @@ int emu_decode_frame(void *stv, const uint8_t *payload, int len, int mode, int b
     }
     og::parse_tables_load();
     og::celt_parse_lane(st, payload, len, ch, &rec, h);
-    const int ret = og::celt_recon_wave(st, &rec, mode, ch);
+    const int ret = og::celt_recon_wave(st, &rec, mode, ch, og::RECON_ALL, after);
     for (int c = 0; c < st->channels; c++) og::celt_post(st, &rec, ret, c, pcm, h ? h->pcm : nullptr, ch);
     return ret;
 }
@@ -61,16 +70,17 @@ int emu_decode_frame_shadowed(void *stv, void *shadow, unsigned epoch, const uin
     static og::SilkHandoff handoff;
     static og::SilkRec srec;
     if (mode == og::MODE_CELT) return -1000;
+    const int after = emu_no_mode(mode);
     og::silk_tables_load();
     const og::SilkPast past(st, (const og::SilkShadow *)shadow, epoch);
     og::silk_parse_lane(past, payload, len, mode, bw, ch, &srec, &handoff);
-    og::silk_params_lane(past, mode, bw, ch, &srec, (og::SilkShadow *)shadow, epoch);
+    og::silk_params_lane(past, mode, bw, ch, &srec, (og::SilkShadow *)shadow, epoch, after);
     int r = og::decode_frame_wave<false>(st, payload, len, mode, bw, ch, pcm, &handoff, &srec);
     if (r == og::CONTINUE_Q4) return og::decode_frame_wave<true>(st, payload, len, mode, bw, ch, pcm, &handoff, &srec, 1);
     if (r != og::CONTINUE_SPLIT) return r;
     og::parse_tables_load();
     og::celt_parse_lane(st, payload, len, ch, &rec, &handoff);
-    const int ret = og::celt_recon_wave(st, &rec, mode, ch);
+    const int ret = og::celt_recon_wave(st, &rec, mode, ch, og::RECON_ALL, after);
     for (int c = 0; c < st->channels; c++) og::celt_post(st, &rec, ret, c, pcm, handoff.pcm, ch);
     return ret;
 }

@@ -52,7 +52,13 @@ int opusgpu_decode_packets(opusgpu_ctx *c, int n, const int32_t *ids, const uint
     const size_t block = (size_t)frame_capacity * 960 * c->channels;
     for (int i = 0; i < n; i++) {
         result[i] = 0;
-        if (ids[i] < 0 || ids[i] >= (int)c->dec.size() || !packets[i] || lens[i] <= 0) { result[i] = OPUSGPU_BAD_ARG; continue; }
+        if (ids[i] < 0 || ids[i] >= (int)c->dec.size() || lens[i] < 0) { result[i] = OPUSGPU_BAD_ARG; continue; }
+        if (!packets[i] || lens[i] == 0) { // an empty packet: the reference's own branch for it (oc_decode, src/opus_decoder.cpp:290-308)
+            const int r = oc_decode(c->dec[ids[i]], nullptr, 0, tmp.data(), 960 * frame_capacity);
+            result[i] = r;
+            if (r > 0) memcpy(pcm + (size_t)i * block, tmp.data(), sizeof(int16_t) * (size_t)r * c->channels);
+            continue;
+        }
         int16_t size[48];
         uint8_t toc;
         const int count = ogh::parse_packet(packets[i], lens[i], 0, &toc, size, nullptr, nullptr);

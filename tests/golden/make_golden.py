@@ -78,6 +78,17 @@ def sequence_packets():
         tiny += [bytes([toc]) + _bytes(rng, 40), bytes([toc]), bytes([toc]) + _bytes(rng, 1), bytes([toc, 0xFF]), bytes([toc]) + _bytes(rng, 2),
                  bytes([toc]) + _bytes(rng, 45)]
     seqs["tiny_frames"] = (2, tiny)
+    # empty packets (len 0): the reference's opus_decode_native runs opus_decode_frame(NULL, 0) in the decoder's LAST mode, 960
+    # samples per pass, until frame_size (here CAP x 960) is filled or a pass fails (src/opus_decoder.cpp:290-308): mode 0 before the
+    # first packet (SILK runs, then CELT's -18), SILK-only decodes, hybrid advances SILK and ends in -18, CELT-only ends in -18;
+    # ordinary packets in between pin what each case leaves behind
+    e = [b""]
+    for toc, L in ((0x0C, 40), (0x7C, 70), (0xFC, 80), (0x4C, 50), (0x08, 30), (0x6C, 60)):
+        e += [bytes([toc]) + _bytes(rng, L), b"", bytes([toc]) + _bytes(rng, L)]
+    e += [b"", b""]
+    seqs["empty_packets"] = (2, e)
+    seqs["empty_packets_mono"] = (1, [b"", bytes([0x08]) + _bytes(rng, 30), b"", bytes([0x0C]) + _bytes(rng, 40), b"", bytes([0x78]) + _bytes(rng, 60), b"",
+                                      bytes([0x08]) + _bytes(rng, 35)])
     return seqs
 
 
@@ -87,9 +98,10 @@ def sequences(o):
         d = o.decoder(channels)
         d.init()
         calls = []
+        toc = 0x7C  # (an empty packet decodes in the mode of the last one; before the first: like hybrid)
         for p in packets:
             pcm, r = d.decode_cap(p, CAP)
-            toc = p[0]
+            toc = p[0] if p else toc
             silk_mono_in_stereo = channels == 2 and not (toc & 0x80) and (toc & 0x60) != 0x60 and not (toc & 4)
             h = None
             if r > 0 and not silk_mono_in_stereo:

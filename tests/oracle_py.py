@@ -153,7 +153,8 @@ class OracleDecoder:
     def __init__(self, o, channels):
         self.o, self.channels = o, channels
         self.h = o.lib.oc_decoder_create(channels)
-        self.buf = np.zeros((5760, channels), dtype=np.int16)
+        # (+ 960: a stereo packet in a mono decoder mixes 960 * 2 entries per frame, Q3 -- the last pass of an empty packet too)
+        self.buf = np.zeros((5760 + 960, channels), dtype=np.int16)
 
     def init(self):
         self.o.lib.oc_decoder_init(self.h, self.channels)

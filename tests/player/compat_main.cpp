@@ -31,12 +31,13 @@ int main(int argc, char **argv) {
         if (cmd == 'D') {
             uint32_t fs = 0, len = 0;
             if (fread(&fs, 4, 1, in) != 1 || fread(&len, 4, 1, in) != 1) return 2;
-            last.resize(len);
-            if (len && fread(last.data(), 1, len, in) != len) return 2;
+            std::vector<uint8_t> cur(len);
+            if (len && fread(cur.data(), 1, len, in) != len) return 2;
+            if (len) last = cur; // (the packet helpers of 'Q' look at the last packet that HAD bytes)
             const size_t room = (size_t)fs * 2, guard = 4096;
             std::vector<int16_t> a(room + guard, GUARD), b(room + guard, GUARD);
-            const int32_t ra = opus_decode(st, last.data(), (int32_t)len, a.data(), (int)fs);
-            const int32_t rb = opus_multistream_decode(ms, last.data(), (int32_t)len, b.data(), (int)fs);
+            const int32_t ra = opus_decode(st, cur.data(), (int32_t)len, a.data(), (int)fs);
+            const int32_t rb = opus_multistream_decode(ms, cur.data(), (int32_t)len, b.data(), (int)fs);
             for (size_t i = room; i < room + guard; i++) guards_ok &= a[i] == GUARD && b[i] == GUARD;
             fwrite(&ra, 4, 1, out);
             fwrite(&rb, 4, 1, out);

@@ -120,6 +120,18 @@ def test_opus_decoder_h_surface_on_gpu(tmp_path, oracle):
             steps.append(("D", 960, pkt))
             tiny[len(steps) - 1] = want
         steps.append(("D", 960, bytes([toc]) + body(50)))
+    # empty packets (len 0) through BOTH entry points -- hand-derived from src/opus_decoder.cpp:290-308, :351, :836-848 and
+    # src/celt.cpp:2225 (tests/test_empty_packets.py has the derivation): after SILK-only packets frame_size 960 -> 960, 1920 ->
+    # 1920, 961 -> -1; after hybrid / CELT-only / OPUS_RESET_STATE -> -18; and the decoder goes on afterwards
+    for toc, answers in ((0x0C, ((960, 960), (1920, 1920), (961, -1), (2880, 2880))), (0x7C, ((960, -18), (50, -1))), (0xFC, ((1920, -18),))):
+        steps.append(("D", 960, bytes([toc]) + body(50)))
+        for fs, want in answers:
+            steps.append(("D", fs, b""))
+            tiny[len(steps) - 1] = want
+        steps += [("Q",), ("D", 960, bytes([toc]) + body(50))]
+    steps += [("D", 960, bytes([0x0C]) + body(40)), ("R",), ("D", 960, b"")]
+    tiny[len(steps) - 1] = -18
+    steps += [("D", 960, bytes([0x0C]) + body(40))]
     script = b""
     for s in steps:
         script += s[0].encode() + (struct.pack("<II", s[1], len(s[2])) + s[2] if s[0] == "D" else b"")
@@ -141,15 +153,19 @@ def test_opus_decoder_h_surface_on_gpu(tmp_path, oracle):
                 assert ra == rb == tiny[k], (pkt.hex(), ra, rb, tiny[k])
             # the oracle with generous room decodes every frame (Q6: 960 samples each); with the caller's room it applies
             # the reference's size check
-            pcm, r = d.decode_cap(pkt, 6) if pkt is over_long else d.decode_cap(pkt, fs // 960)
-            assert ra == rb == r, (hex(pkt[0]), fs, ra, rb, r)
+            if not pkt:  # (frame_size as it is: the empty-packet branch looks at its remainders, src/opus_decoder.cpp:290)
+                r = oracle.lib.oc_decode(d.h, b"", 0, d.buf.ctypes.data, fs)
+                pcm = d.buf
+            else:
+                pcm, r = d.decode_cap(pkt, 6) if pkt is over_long else d.decode_cap(pkt, fs // 960)
+            assert ra == rb == r, (pkt[:1].hex(), fs, ra, rb, r)
             if r > 0:
                 n = min(r, fs)
                 out = np.frombuffer(got, dtype=np.int16, count=2 * n, offset=at).reshape(n, 2)
                 at += 4 * n
-                assert (out == pcm[:n]).all(), (hex(pkt[0]), fs)
+                assert (out == pcm[:n]).all(), (pkt[:1].hex(), fs)
                 last_ret = r
-            last = pkt
+            last = pkt or last
         else:
             v = struct.unpack_from("<8i", got, at)
             at += 32

@@ -67,7 +67,8 @@ def test_oracle_conceals_the_duration_asked_for(oracle):
             assert r == fs
         assert d.conceal(100)[1] < 0  # not a multiple of 2.5 ms
         d.set_rfc(False)
-        assert d.conceal(960)[1] < 0  # reference mode: no concealment (Q8)
+        assert d.conceal(960)[1] == -18  # reference mode: no concealment (Q8) -- the reference's empty-packet branch instead, which
+        #                                  after a CELT-only packet ends in celt_decode_with_ec's refusal (tests/test_empty_packets.py)
 
 
 def test_oracle_celt_concealment_decays(oracle):

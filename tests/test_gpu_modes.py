@@ -231,7 +231,7 @@ def test_packets_in_one_array_decode_like_a_list_of_packets(pkg, oracle, gpu_ctx
         if kind == 0:
             packets.append(bytes([toc | 1]) + body + body)          # two equal-size frames
         elif kind == 1:
-            packets.append(b"")                                      # no data: an error in the reference (Q8)
+            packets.append(b"")                                      # no data: the reference's empty-packet branch (tests/test_empty_packets.py)
         elif kind == 2:
             packets.append(bytes([toc | 3, 0]))                      # code 3 with zero frames: invalid
         else:
@@ -248,7 +248,7 @@ def test_packets_in_one_array_decode_like_a_list_of_packets(pkg, oracle, gpu_ctx
         out, res = gpu_ctx.decode_packets_arena(ids, arena, offs, lens, frame_capacity=cap, pcm=out)
         assert np.array_equal(res, want[rnd][1])
         ok = res > 0
-        assert ok.sum() > 300 and (res < 0).sum() >= 80 and (res == 1920).sum() >= 30
+        assert ok.sum() > 300 and (res < 0).sum() >= 70 and (res == 1920).sum() >= 30
         for i in np.nonzero(ok)[0]:
             assert np.array_equal(out[i, :res[i]], want[rnd][0][i, :res[i]]), (rnd, i)
     with pytest.raises(ValueError):

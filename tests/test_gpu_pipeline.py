@@ -33,12 +33,13 @@ def desc_flags(toc):
 
 
 def run_queued(pkg, ctx, channels, arena, offs, lens, toc, pipeline, sync_every=0, reset_at=None, modes=0, one_pcm=False, streams=None,
-               window=False):
+               window=False, flags=None):
     """All steps queued back to back (tables of every step resident before the first call).  Returns PCM [frames, n, 960*ch]
     and result codes [frames, n].  window: the steps go in ONE opusgpu_decode_steps_device call (cut where a reset or a
     synchronisation point is asked for) instead of one call per step."""
     frames, n = offs.shape
-    flags, _ = desc_flags(toc)
+    if flags is None:  # (given: descriptors that are not a packet's own -- the frames of empty packets, tests/test_empty_packets.py)
+        flags, _ = desc_flags(toc)
     ctx.streams_alloc(n, channels)
     ctx.set_pipeline(pipeline)
     frame_bytes = n * 960 * channels * 2
@@ -454,3 +455,60 @@ def test_pipelined_silk_only_steps_between_steps_of_other_kinds(pkg, oracle, gpu
         ctx.set_pipeline(False)
         for p in [d_arena] + bufs:
             ctx.dev_free(p)
+
+
+def test_keeps_mode_steps_of_both_kinds_on_the_same_celt_streams(pkg, oracle, gpu_ctx):
+    """OPUSGPU_STEP_KEEPS_MODE lets a step of ANY mix run as a pipelined SILK / hybrid step (its CELT-only frames reconstructed on
+    the step's own stream) and lets declared CELT-only steps (reconstruction on the library's stream) follow without a drain --
+    which is only safe while the two are about different streams.  Here they are not: every stream keeps its mode (the caller's
+    word is true), but mixed steps over ALL streams alternate with declared CELT-only steps over the SAME CELT-only streams and
+    declared SILK / hybrid steps over the others, everything queued back to back.  Every sample against the oracle."""
+    rng = np.random.default_rng(4242)
+    n = 3 * 1536
+    tocs = np.array([pkg.TOC_SILK_NB_STEREO, pkg.TOC_HYBRID_FB_STEREO, pkg.TOC_CELT_FB_STEREO], dtype=np.uint8)[np.arange(n) % 3]
+    L = np.array([40, 120, 160])[np.arange(n) % 3]
+    celt, rest, every = np.nonzero(np.arange(n) % 3 == 2)[0], np.nonzero(np.arange(n) % 3 != 2)[0], np.arange(n)
+    K = pkg.STEP_KEEPS_MODE
+    plan = [(every, 7 | K), (celt, 4 | K), (every, 7 | K), (celt, 4 | K), (celt, 4 | K), (rest, 3 | K), (every, 7 | K), (rest, 3 | K),
+            (celt, 4 | K), (every, 7 | K), (every, 7 | K), (celt, 4 | K)]
+    # per step: one packet for every stream of the step
+    flags, _ = desc_flags(tocs)
+    steps, per_stream = [], [[] for _ in range(n)]
+    for ids, modes in plan:
+        lens = L[ids]
+        offs = np.concatenate([[0], np.cumsum(lens + 1)[:-1]])
+        arena = rng.integers(0, 256, int((lens + 1).sum()) + 16, dtype=np.uint8)
+        arena[offs] = tocs[ids]
+        for j, s in enumerate(ids):
+            per_stream[s].append(arena[offs[j]:offs[j] + lens[j] + 1].tobytes())
+        descs = np.zeros(len(ids), dtype=pkg.DESC_DTYPE)
+        descs["stream"], descs["offset"], descs["len"], descs["flags"] = ids, offs + 1, lens, flags[ids]
+        steps.append((ids, modes, arena, descs))
+    ctx = gpu_ctx
+    ctx.streams_alloc(n, 2)
+    ctx.set_pipeline(True)
+    bufs = []
+    for ids, modes, arena, descs in steps:
+        d_arena, d_desc = ctx.dev_alloc(arena.size), ctx.dev_alloc(16 * len(ids))
+        d_pcm, d_res = ctx.dev_alloc(len(ids) * 960 * 2 * 2), ctx.dev_alloc(4 * len(ids))
+        ctx.h2d(d_arena, arena)
+        ctx.h2d(d_desc, descs)
+        bufs.append((d_arena, d_desc, d_pcm, d_res))
+    for (ids, modes, _, _), (d_arena, d_desc, d_pcm, d_res) in zip(steps, bufs):
+        ctx.decode_step_device(len(ids), d_desc, d_arena, d_pcm, d_res, modes=modes)
+    ctx.synchronize()
+    ref, rets = oracle.decode_streams(2, per_stream)
+    assert (rets[:, :min(len(p) for p in per_stream)] == 960).all()
+    seen = np.zeros(n, dtype=np.int64)
+    for (ids, _, _, _), (d_arena, d_desc, d_pcm, d_res) in zip(steps, bufs):
+        pcm, res = np.zeros((len(ids), 960, 2), dtype=np.int16), np.zeros(len(ids), dtype=np.int32)
+        ctx.d2h(pcm, d_pcm)
+        ctx.d2h(res, d_res)
+        assert (res == 960).all()
+        want = ref[ids, seen[ids]]
+        bad = np.nonzero((pcm != want).any(axis=(1, 2)))[0]
+        assert len(bad) == 0, (len(bad), ids[bad][:8])
+        seen[ids] += 1
+        for p in (d_arena, d_desc, d_pcm, d_res):
+            ctx.dev_free(p)
+    ctx.set_pipeline(False)

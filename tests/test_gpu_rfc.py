@@ -172,12 +172,14 @@ def test_rfc_loss_before_any_packet_and_after_reset(pkg, oracle, gpu_ctx):
         ctx.set_mode(False)
 
 
-def test_loss_is_an_error_in_reference_mode(pkg, gpu_ctx):
-    """the reference has no concealment: data == NULL / len == 0 ends in an error (Q8)"""
+def test_reference_mode_conceals_nothing(pkg, gpu_ctx):
+    """Reference mode has no concealment (Q8) -- an empty packet there is NOT a lost packet but what the reference's own
+    empty-packet branch makes of it (src/opus_decoder.cpp:290-308; tests/test_empty_packets.py has the known answers): a frame of
+    no bytes in the stream's last mode.  Fresh streams are in mode 0: SILK runs, CELT refuses (src/celt.cpp:2225)."""
     ctx = gpu_ctx
     ctx.streams_alloc(2, 2)
     pcm, res = ctx.decode_packets(np.arange(2), [b"", None])
-    assert (res == -1).all()  # OPUS_BAD_ARG
+    assert (res == -18).all()  # ERR_OPUS_CELT_BAD_ARG
 
 
 def test_reference_mode_unchanged_after_rfc(pkg, oracle, gpu_ctx):
