@@ -781,8 +781,31 @@ def run_rfc_workload(args, ranks, pkg, ctx, n_override=0, cpu=True):
     return out_line
 
 
+# The driver keeps the TAIL of what a run prints: the one JSON line has to fit it.  By default the line carries every number and
+# short texts only (COMPACT below); --verbose prints the explanatory strings as well (what a sample was, how a figure was taken).
+_DROP = {"traffic_source", "model", "source", "calibration", "serial_end_to_end_note", "what", "ingest_s_per_batch", "demux_s_per_batch",
+         "slot_wait_s_per_batch", "gpu_ms_between_batch_ends", "host_logical_cpus", "generate_s", "valu_wave_instructions_per_step",
+         "issue_ms", "demux_threads", "page_bytes", "work_bytes_per_rank", "pipeline", "window", "frames_of_history"}
+_CUT = {"workload": ":", "kernel": " (", "sample": ",", "result": " (", "sharding": ","}
+
+
+def compact(o, key=None, depth=0):
+    """The line without its prose: long strings cut at their first clause, explanatory keys dropped, floats to 6 digits."""
+    if isinstance(o, dict):
+        return {k: compact(v, k, depth + 1) for k, v in o.items() if k not in _DROP and not (k == "sharding" and depth > 1)}
+    if isinstance(o, list):
+        return [compact(v, key, depth + 1) for v in o]
+    if isinstance(o, float):
+        return float(f"{o:.6g}")
+    if isinstance(o, str) and key in _CUT and len(o) > 64:
+        return o.split(_CUT[key])[0][:96]
+    return o
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--verbose", action="store_true", help="the JSON line with its explanatory texts (default: numbers and short texts, "
+                                                           "so that the whole line fits the driver's tail)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)   # (pipelined steps: the first parse and the last de-emphasis of a run are not hidden)
     ap.add_argument("--warmup", type=int, default=4)
@@ -838,7 +861,7 @@ def main():
             o.update({"metric": "decoded 48 kHz stereo frames/sec/GPU, RFC mode (x real-time); HBM GB/s vs roofline", "n_gpus": world,
                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
                       "dtype": "int32 fixed-point (int16/int32 with 64-bit products)"})
-            print(json.dumps(o), flush=True)
+            print(json.dumps(o if args.verbose else compact(o), separators=(",", ":")), flush=True)
         ranks.close()
         ctx.close()
         return
@@ -885,7 +908,7 @@ def main():
                 line[k] = main_out[k]
         if others:
             line["other_configs"] = others
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line if args.verbose else compact(line), separators=(",", ":")), flush=True)
     ranks.close()
     ctx.close()
 

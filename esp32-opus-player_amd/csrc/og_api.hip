@@ -318,7 +318,6 @@ __global__ void __launch_bounds__(64, OG_SILK_WAVES) k_silk_synth(const FrameDes
 #ifdef OG_PROF_SSYNTH // profiling builds: time the sections of the SILK synthesis kernel
         OG_PROF_INIT();
 #endif
-#ifndef OG_NO_SYNTH_PREFETCH
         // The frame's record (2 KB) and the stream's SILK state (1.7 KB) are read below in a dozen dependent steps, each behind a
         // wave-level sync that keeps the compiler from asking early: every one of them paid a trip to HBM.  One load per lane --
         // lane l touches the l-th 64 bytes of the state, lane 32 + l of the record -- brings all of it to the L2 now; its value is
@@ -330,7 +329,6 @@ __global__ void __launch_bounds__(64, OG_SILK_WAVES) k_silk_synth(const FrameDes
                                    : reinterpret_cast<const char *>(&srecs[f]) + 64 * (l - 32);
             prefetched = *reinterpret_cast<const volatile u32 *>(p);
         }
-#endif
         ret = decode_frame_wave<false>(&st[d.stream], arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
                                        desc_channels(d.flags), pcm + (size_t)f * pcm_stride, &handoff[f], &srecs[f]);
 #ifdef OG_PROF_SSYNTH
@@ -381,11 +379,8 @@ extern "C" int og_celt_parse64_frames(void); // frames per group of that kernel
 // Split CELT path, second half: one frame per wave, driven by the parse record.
 // (20 ms CELT-only frames are reconstructed by k_celt_recon_fb, og_recon.hip; `rest_only`: skip what that kernel took)
 extern "C" void og_launch_celt_recon_fb(hipStream_t s, const void *descs, void *streams, const void *recs, void *rout, int n,
-                                        int n_streams, int hybrid, unsigned *started, const void *leaves);
+                                        int n_streams, int hybrid, unsigned *started);
 extern "C" int og_celt_recon_fb_signals(int n); // how often a launch over n frames bumps `started`
-// The PVQ leaves of those frames, one leaf per lane across frames in order of cost (og_leaves.hip), ahead of the kernel above
-extern "C" void og_launch_celt_leaves(hipStream_t s, const void *descs, const void *recs, void *leaf_out, int n, int n_streams, int hybrid);
-extern "C" size_t og_leaf_out_bytes(void);
 // RFC mode (opt-in): every frame of a step, at its true duration, incl. the loss path (og_rfc.hip)
 extern "C" void og_launch_decode_rfc(hipStream_t s, const void *descs, const void *arena, void *streams, void *pcm, void *result, int n,
                                      int n_streams, int pcm_stride);
@@ -679,8 +674,8 @@ struct opusgpu_ctx {
     // parse records of the split CELT path (one per frame of a step), grown on demand
     // (five sets: pipelined CELT-only steps rotate through 0 - 2 -- in-order steps use 0 --, pipelined SILK-only / hybrid steps
     // alternate 3 and 4: steps of the two kinds may be in flight together, OPUSGPU_STEP_KEEPS_MODE)
-    void *d_recs[5] = {}, *d_rout[5] = {}, *d_leaf[5] = {};
-    size_t cap_recs[5] = {}, cap_rout[5] = {}, cap_leaf[5] = {};
+    void *d_recs[5] = {}, *d_rout[5] = {};
+    size_t cap_recs[5] = {}, cap_rout[5] = {};
     void *d_handoff[2] = {}, *d_srecs[2] = {}; // (two sets: pipelined SILK-only steps alternate; everything else uses set 0)
     size_t cap_handoff[2] = {}, cap_srecs[2] = {};
     const void *last_srecs = nullptr; // the SILK records of the last step (opusgpu_debug_stage_taps)
@@ -691,7 +686,6 @@ struct opusgpu_ctx {
     int silk_slot = 0, sdone_recorded[2] = {}, last_silk_mask = 0, last_kind = 0; // last_kind: 0 in order, 1 pipelined CELT-only, 2 pipelined SILK-only
     bool last_kind2_celt = false; // the last step of kind 2 held CELT-only frames too (enter_step_kind)
     hipEvent_t ev_sparsed = nullptr, ev_sdone[2] = {};
-    int leaf_kernel = 0; // OPUSGPU_LEAF_KERNEL=1: k_celt_leaves decodes the PVQ leaves ahead of the reconstruction (og_leaves.hip; measured slower)
     int split_celt = 1;   // OPUSGPU_SPLIT=0 forces the single-kernel path for every mode (A/B measurements)
     int split_hybrid = 1; // OPUSGPU_SPLIT_HYBRID=0 keeps SILK-only and hybrid frames entirely on the single-kernel path
     int fast_recon = 1;   // OPUSGPU_FAST_RECON=0: every CELT frame through the general reconstruction kernel (A/B measurements)
@@ -778,7 +772,6 @@ int opusgpu_ctx_create(int device, opusgpu_ctx **out) {
     ctx->split_celt = og_debug().split; // (og_debug.hpp: A/B switches, read from the environment once per process)
     ctx->split_hybrid = og_debug().split_hybrid;
     ctx->fast_recon = og_debug().fast_recon;
-    ctx->leaf_kernel = og_debug().leaf_kernel;
     ctx->parse_groups = og_debug().parse_groups;
     ctx->host_parts = og_debug().host_parts;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -803,7 +796,6 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     for (int i = 0; i < 5; i++) {
         (void)hipFree(ctx->d_recs[i]);
         (void)hipFree(ctx->d_rout[i]);
-        (void)hipFree(ctx->d_leaf[i]);
         if (i < 3 && ctx->ev_post[i]) (void)hipEventDestroy(ctx->ev_post[i]);
     }
     for (int i = 0; i < 2; i++) {
@@ -1019,15 +1011,12 @@ static int enter_step_kind(opusgpu_ctx *ctx, int kind, hipStream_t s, bool keeps
     return OPUSGPU_OK;
 }
 
-// Records, reconstruction output and (leaf kernel) leaf output of slot `par` for a step of `need` frames.
-static int grow_step_slot(opusgpu_ctx *ctx, int par, size_t need, bool any_celt) {
+// Records and reconstruction output of slot `par` for a step of `need` frames.
+static int grow_step_slot(opusgpu_ctx *ctx, int par, size_t need) {
     int rc;
     if (ctx->cap_recs[par] < sizeof(ParseRec) * need && (rc = grow(ctx, &ctx->d_recs[par], &ctx->cap_recs[par], sizeof(ParseRec) * need)))
         return rc;
     if (ctx->cap_rout[par] < sizeof(ReconOut) * need && (rc = grow(ctx, &ctx->d_rout[par], &ctx->cap_rout[par], sizeof(ReconOut) * need)))
-        return rc;
-    if (ctx->fast_recon && ctx->leaf_kernel && any_celt && ctx->cap_leaf[par] < og_leaf_out_bytes() * need &&
-        (rc = grow(ctx, &ctx->d_leaf[par], &ctx->cap_leaf[par], og_leaf_out_bytes() * need)))
         return rc;
     return OPUSGPU_OK;
 }
@@ -1124,7 +1113,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     if (pipe_silk) ctx->silk_slot ^= 1;
     const int sset = pipe_silk ? ctx->silk_slot : 0; // the set of SILK records and hand-offs this step uses (and of CELT records with them)
     const int par = pipe ? ctx->slot : pipe_silk ? 3 + sset : 0, par2 = (par + 1) % 3; // this step's slot; (pipelined CELT-only steps:) the slot of the step two before it
-    if (int rc = grow_step_slot(ctx, par, (size_t)n, any_celt)) return rc; // (a window's slots were sized before its first launch)
+    if (int rc = grow_step_slot(ctx, par, (size_t)n)) return rc; // (a window's slots were sized before its first launch)
     if (ctx->split_hybrid && any_silk) {
         int rc;
         if (ctx->cap_handoff[sset] < sizeof(SilkHandoff) * (size_t)n || ctx->cap_srecs[sset] < sizeof(SilkRec) * (size_t)n) {
@@ -1180,11 +1169,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
             others = true;
         }
         if (any_celt) {
-            if (ctx->fast_recon) {
-                void *const leaves = ctx->leaf_kernel ? (void *)((uint8_t *)ctx->d_leaf[par] + og_leaf_out_bytes() * f0) : nullptr;
-                if (leaves) og_launch_celt_leaves(q, dd, recs + f0, leaves, cnt, ctx->n_streams, handoff ? 1 : 0);
-                og_launch_celt_recon_fb(q, dd, ctx->d_streams, recs + f0, rout + f0, cnt, ctx->n_streams, handoff ? 1 : 0, nullptr, leaves);
-            }
+            if (ctx->fast_recon) og_launch_celt_recon_fb(q, dd, ctx->d_streams, recs + f0, rout + f0, cnt, ctx->n_streams, handoff ? 1 : 0, nullptr);
             hipLaunchKernelGGL(k_celt_recon, dim3(ctx->fast_recon ? (cnt + 63) / 64 : cnt), dim3(64), 0, q, dd, ctx->d_streams,
                                (const ParseRec *)(recs + f0), rout + f0, cnt, ctx->n_streams, handoff ? 1 : 0, ctx->fast_recon);
         }
@@ -1333,9 +1318,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     // reconstruct (one frame per wave) ...
     if (ctx->fast_recon) {
         launch_jitter();
-        void *const leaves = ctx->leaf_kernel ? ctx->d_leaf[par] : nullptr;
-        if (leaves) og_launch_celt_leaves(back, d_descs, recs, leaves, n, ctx->n_streams, 0);
-        og_launch_celt_recon_fb(back, d_descs, ctx->d_streams, recs, rout, n, ctx->n_streams, 0, ctx->d_started + 16, leaves);
+        og_launch_celt_recon_fb(back, d_descs, ctx->d_streams, recs, rout, n, ctx->n_streams, 0, ctx->d_started + 16);
         ctx->recon_started_total += (u32)og_celt_recon_fb_signals(n);
     }
     hipLaunchKernelGGL(k_celt_recon, dim3(ctx->fast_recon ? (n + 63) / 64 : n), dim3(64), 0, back, (const FrameDesc *)d_descs, ctx->d_streams,
@@ -1401,7 +1384,7 @@ int opusgpu_decode_steps_device(opusgpu_ctx *ctx, int n_steps, const int32_t *n,
         // All three slots take the window's largest step now, while nothing of the window is queued.
         HIPCHK(ctx, hipSetDevice(ctx->device));
         for (int par = 0; par < 3; par++)
-            if (int rc = grow_step_slot(ctx, par, (size_t)max_n, true)) return rc;
+            if (int rc = grow_step_slot(ctx, par, (size_t)max_n)) return rc;
     }
     for (int k = 0; k < n_steps; k++) {
         const int next_n = k + 1 < n_steps ? n[k + 1] : 0;

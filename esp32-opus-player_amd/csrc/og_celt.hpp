@@ -734,11 +734,7 @@ OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int sh
     {
         OG_SYNC();
 #if defined(OG_RECON_TIGHT) && !defined(OG_HOST_EMUL)
-#ifdef OG_NO_LONG_FAST
-        const bool long_fast = false;
-#else
         const bool long_fast = B == 1 && !(CC == 1 && C == 2); // (a down-mix reads two spectra per coefficient: generic code)
-#endif
         if (long_fast) {
             const int c_src = (CC == 2 && C == 1) ? 0 : co;
             const i32 tail_l = OG_LANE < OVERLAP / 2 ? tail[OG_LANE] : 0; // (requested before the stages, stored behind them)
@@ -751,7 +747,7 @@ OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int sh
         } else {
 #endif
 #ifdef OG_RECON_TIGHT
-#if !defined(OG_HOST_EMUL) && !defined(OG_NO_LONG_FAST)
+#if !defined(OG_HOST_EMUL)
         // (short blocks: the coefficient's gain from the per-bin table of denorm_bins -- one look-up instead of three -- unless
         // this is a down-mix, which reads two spectra with two sets of gains)
         const bool bins = !(CC == 1 && C == 2);
@@ -1332,20 +1328,16 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
         OG_SYNC();
         OG_MARK(14);
 #if defined(OG_RECON_TIGHT) && !defined(OG_HOST_EMUL)
-#ifndef OG_NO_LONG_FAST
         if (!(CC == 1 && C == 2)) denorm_bins((CC == 2 && C == 1) ? 0 : c); // (from denorm_gains' rows)
-#endif
 #endif
         imdct_channel(st->tail[c], c, N, LM, B, shift, C, CC);
         OG_MARK(15);
         OG_TAP(2 + 16 * c); // IMDCT output
-#if !(defined(OG_ABLATE) && OG_ABLATE == 3)
         if (!p.lost) {
             comb_filter(st, c, 0, ppo, pp, 120, pgo, pg, pto, pt, pos);
             if (LM != 0) comb_filter(st, c, 120, pp, pf_pitch, N - 120, pg, pf_gain, pt, pf_tapset, pos);
         }
         OG_TAP(3 + 16 * c); // comb filter output
-#if !(defined(OG_ABLATE) && OG_ABLATE == 4)
         // de-emphasis (celt.cpp:1965-2055): a rounding IIR, serial; the PCM plane replaces a dead half of X
         OG_SYNC();
         if (p.inline_deemph && OG_LANE == 0) {
@@ -1363,8 +1355,6 @@ OG_DEV void celt_synthesis(CeltState *st, const CeltSynth &p) {
         OG_MARK(16);
         OG_FOR_LANES(i, N) st->ring[c][(pos + i) & RING_MASK] = SY[i];
         OG_FOR_LANES(i, OVERLAP / 2) st->tail[c][i] = SY[N + i];
-#endif
-#endif
     }
     OG_SYNC();
     if (OG_LANE == 0 && p.lost) {
@@ -1435,9 +1425,6 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
     const i32 pf_gain = h.pf_gain, intensity = h.intensity, dual_stereo = h.dual_stereo, balance = h.balance;
     OG_MARK(26); // (single-kernel path: the band loop, quant_all_bands)
     const int shortBlocks = transient ? M : 0, anti_collapse_rsv = h.anti_collapse_rsv, codedBands = h.codedBands;
-#if defined(OG_ABLATE) && OG_ABLATE == 1
-    return frame_size;
-#endif
     u32 seed = st->rng;
     decode_all_bands(rc, start, end, C, N, shortBlocks, spread, dual_stereo, intensity,
                      (i32)rc.storage * (8 << BITRES) - anti_collapse_rsv, balance, LM, codedBands, seed, disable_inv);
@@ -1450,9 +1437,6 @@ OG_DEV int celt_decode_frame(CeltState *st, Rc &rc, int frame_size, int C, int C
         for (int i = 0; i < C * NBANDS; i++) S.bandE_row()[i] = (i16)(-28 * 1024);
 
     OG_TAP(1); // X and bandE final
-#if defined(OG_ABLATE) && OG_ABLATE == 2
-    return frame_size;
-#endif
     CeltSynth sp;
     sp.N = N; sp.LM = LM; sp.C = C; sp.CC = CC; sp.start = start; sp.end = end; sp.silence = silence; sp.transient = transient;
     sp.pf_pitch = pf_pitch; sp.pf_tapset = pf_tapset; sp.pf_gain = pf_gain; sp.rng_final = rc.rng; sp.rc_error = rc.error; sp.inline_deemph = 1;

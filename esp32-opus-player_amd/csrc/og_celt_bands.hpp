@@ -409,21 +409,13 @@ OG_DEV u32 partition_leaf(Rc &rc, const PvqTab &T, int band, int spread, u32 &se
     }
     if (q != 0) {
         const int K = get_pulses(q);
-#ifdef OG_ABL_PVQ // timing experiment only (wrong output): skip the index -> pulse-vector conversion
-        const u32 idx = rc_uint(rc, T.u(N, K) + T.u(N, K + 1));
-        OG_FOR_LANES(j, N) S.v[V_IY + j] = (i16)(j == 0 ? K : 0);
-        const i32 Ryy = K * K + (i32)(idx & 0);
-#else
         const i32 Ryy = pvq_decode_index(T, N, K, rc_uint(rc, T.u(N, K) + T.u(N, K + 1)));
-#endif
         const int k = ilog2(Ryy) >> 1;
         const i32 t = vshr32(Ryy, 2 * (k - 7));
         const i32 g = tr16(mul16_p15(rsqrt_norm(t), gain));
         OG_SYNC();
         OG_FOR_LANES(j, N) S.v[x + j] = (i16)pshr32(mul16(g, S.v[V_IY + j]), k + 1); // normalise_residual :745
-#ifndef OG_ABL_ROT
         unspread(x, N, B, K, spread);
-#endif
         if (B <= 1) return 1;
         const u32 N0 = udiv((u32)N, (u32)B); // extract_collapse_mask :760
         u32 m = 0;

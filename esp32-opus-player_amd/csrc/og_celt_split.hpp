@@ -81,7 +81,7 @@ struct ParseRec {
     i32 intensity, pf_pitch, pf_gain, pf_tapset, start;
     i32 n_leaves, n_words;
     u32 need_norm; // bands whose folding history is read by a later band
-    i32 n_coef;    // coefficients in PVQ leaves (the sum of their N): how much the leaf kernel writes for this frame (LeafOut)
+    i32 n_coef;    // coefficients in PVQ leaves (the sum of their N)
     i32 reserved[4];
     i16 bandE[2 * NBANDS]; // final band energies (coarse + fine + finalise)
     i16 pulses[NBANDS];
@@ -98,25 +98,15 @@ struct ParseRec {
         u32 pad;
     } leaf[REC_MAX_LEAVES];
     u32 words[(REC_MAX_WORDS + 64) / 64 * 64]; // read in windows of 64 (REC_WORDS_CAP); a band's four header words start on a multiple of four
-    // -DOG_PARSE_PULSES_REC: the parse lane's bits-per-band work array lives here and not in LDS (84 bytes a lane, a quarter of the
-    // kernel's LDS).  Measured: the pipelined CELT step 0.7 % faster (1.710 / 1.722 ms) -- and 2.9 KB more HBM traffic per frame, because
-    // a lane comes back to its line some twenty times and the record stream has pushed it out of the L2 every time (35.6 KB per
-    // frame = 1.64 x the algorithmic bytes against 32.8 KB = 1.52 x).  Off: the traffic is what the roofline is priced in.
+    // (measured in round 4: the parse lane's bits-per-band work array here instead of in LDS -- 0.7 % faster, 2.9 KB more HBM
+    // traffic per frame; these words are unused)
     i32 work_pulses[NBANDS];
     i32 work_pad[32 - NBANDS];
 };
 static_assert(offsetof(ParseRec, leaf) % 16 == 0 && offsetof(ParseRec, words) % 16 == 0, "16-byte stores into the record");
 static_assert(sizeof(ParseRec) % 16 == 0, "record alignment");
 
-// What the leaf kernel (og_leaves.hip) leaves for the reconstruction kernel of 20 ms frames, per frame: the coefficients of the
-// frame's PVQ leaves packed in leaf order (leaf t at leaf_aux[t] >> 20, N entries: scaled, rotation undone) and the leaves'
-// collapse masks, shifted to their place in the job's mask.
 constexpr int FAST_MAX_LEAVES = 416; // (og_state.hpp: the most a 20 ms frame can have)
-struct LeafOut {
-    alignas(16) i16 coef[1600 + 8]; // (a stereo frame codes 2 x 800 coefficients; the reader fetches in groups of 8)
-    u16 mask[FAST_MAX_LEAVES];
-};
-static_assert(sizeof(LeafOut) % 16 == 0, "leaf output alignment");
 
 // =====================================================================================================
 //  parse: one frame per lane
@@ -143,10 +133,8 @@ static_assert(sizeof(LeafOut) % 16 == 0, "leaf output alignment");
 #endif
 #define OG_PL_FRAMES (OG_PL_LANES * OG_PL_WAVES) // frames per workgroup
 struct ParseLds { // [element][lane]: lanes of a wave touch consecutive addresses, no bank conflicts
-#ifndef OG_PARSE_PULSES_REC
     i32 pulses[NBANDS][OG_PL_LANES]; // the bits-per-band work array (32 bits: a frame whose budget went negative carries wrapped values here, as the
                                      // reference does).  -DOG_PARSE_PULSES_REC keeps it in the record instead, see ParseRec::work_pulses
-#endif
     i8 fine_quant[NBANDS][OG_PL_LANES];
     i8 tf_prio[NBANDS][OG_PL_LANES]; // bits 0-3: tf_res (-3 .. 3, two's complement), bit 4: fine_prio
     // Three tenants, one after the other (next to the reconstruction the kernel's LDS is what keeps that kernel's waves out: 16.1 KB
@@ -247,11 +235,7 @@ struct LaneArr {
             PL.u.bandE[2 * i + 1][OG_PCOL] = (i16)(w[i] >> 16);
         }
     }
-#ifndef OG_PARSE_PULSES_REC
     OG_MEMBER i32 &pulses(int i) const { return PL.pulses[i][OG_PCOL]; }
-#else
-    OG_MEMBER i32 &pulses(int i) const { return pl[i]; }
-#endif
     OG_MEMBER i8 &fine_quant(int i) const { return PL.fine_quant[i][OG_PCOL]; }
     OG_MEMBER FinePrioView fine_prio(int i) const { return FinePrioView{&PL.tf_prio[i][OG_PCOL]}; }
     OG_MEMBER TfResView tf_res(int i) const { return TfResView{&PL.tf_prio[i][OG_PCOL]}; }
@@ -667,7 +651,7 @@ OG_DEV void celt_parse_lane(StreamState *st, const u8 *payload, int len, int ch,
 // scaled to the leaf's gain (normalise_residual :745), spreading rotation undone (exp_rotation :707, dir = -1),
 // collapse mask (extract_collapse_mask :760).  Everything is a serial chain per leaf, so the frame's leaves run
 // one per lane; the result is written in place at S.v[pos .. pos+n).  Returns the collapse mask.
-#if defined(OG_HOST_EMUL) || defined(OG_LEAF_ROT_PLAIN)
+#ifdef OG_HOST_EMUL
 OG_DEV void rotate1_lane(i16 *xv, int x, int len, int stride, i32 c, i32 s) { // exp_rotation1 celt.cpp:684
     // The reference sweeps i = 0 .. len-stride-1 forward, then len-2*stride-1 .. 0 backward, over pairs (i, i+stride).
     // Pairs with different i mod stride never touch the same element, so each residue class ("chain") can be walked
@@ -898,7 +882,7 @@ OG_DEV int pvq_row_base(const PvqLds &T, int r) { return (int)T.rb[r < 4 ? 4 : (
 #endif
 // `xv`: the spectrum arena of the leaf's frame (the calling wave's own working set -- or another wave's when the leaves of the
 // workgroup's frames are pooled, og_recon.hip); `T`: the table copy to walk.
-#if defined(OG_HOST_EMUL) || defined(OG_LEAF_ROT_PLAIN)
+#ifdef OG_HOST_EMUL
 struct RotJob;
 #endif
 // `defer`: the leaf's rotation is not done here but described there, for pvq_rotate_wave (GPU; the caller cleared defer->on)
@@ -925,7 +909,6 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
             const u32 c0 = T.rr[k >= 4 ? b0 + n : 0], c1 = T.rr[k >= 3 ? b1 + n : 0];
             p0 = k >= 4 ? c0 : pvq_row_sel(k, v2, v3);
             p1 = k >= 3 ? c1 : pvq_row_sel(k + 1, v2, v3);
-#ifndef OG_NO_ZERO_SKIP
             // A sparse leaf (many dimensions, few pulses) is mostly runs of zeros, and the wave waits for its longest leaf: the run is
             // skipped in one go.  With V(a) = U(a, k) + U(a, k + 1) the dimensions n, n-1, .., a+1 all decode to zero exactly when
             //     V(n) - V(a) <= 2 i < V(n) + V(a)          (one comparison: V(a) >= m, see below)
@@ -979,7 +962,6 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
                     p1 = t1;
                 }
             }
-#endif
         } else { // n <= k: everything this step reads lies in row n, whose columns are all in LDS (n == 3: U(3, c) = 2 c (c - 1) + 1)
             const u32 hk = (u32)k;
             bn = pvq_row_base(T, n);
@@ -1062,9 +1044,6 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
         xv[pos] = (i16)val;
         yy += val * val;
     }
-#if defined(OG_LEAF_ABL) && OG_LEAF_ABL >= 2 /* timing experiments only (wrong output): the walk alone */
-    return 1;
-#endif
     // collapse mask from the pulses
     OG_MARK(57);
     u32 cm = 1;
@@ -1083,9 +1062,6 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
     const i32 g = tr16(mul16_p15(rsqrt_norm(t), gain));
     for (int j = 0; j < N; j++) xv[x + j] = (i16)pshr32(mul16(g, xv[x + j]), kk + 1);
     OG_MARK(59);
-#if defined(OG_LEAF_ABL) && OG_LEAF_ABL >= 1 /* ... without the rotation */
-    return cm;
-#endif
     if (2 * K < N && spread != 0) {
         const int factor = spread == 1 ? 15 : (spread == 2 ? 10 : 5);
         const i32 rg = tr16(mul32_q31(mul16(32767, N), celt_rcp(N + factor * K))); // celt_div celt.h:367
@@ -1096,7 +1072,7 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
             stride2 = 1;
             while ((stride2 * stride2 + stride2) * B + (B >> 2) < N) stride2++;
         }
-#if !defined(OG_HOST_EMUL) && !defined(OG_LEAF_ROT_PLAIN)
+#if !defined(OG_HOST_EMUL)
         if (defer) {
             defer->x = x;
             defer->blen = blen;
@@ -1161,7 +1137,7 @@ OG_DEV void rec_word4(RecCur &cur, u32 &w0, u32 &w1, u32 &w2, u32 &w3) {
 // The noise generator jumped ahead (lcg_skip) by n = lane + 1, lane + 65, lane + 129 steps: s -> a s + c.  Computed
 // once per frame; every noise / dither pass then costs one multiply-add per coefficient.
 struct LcgTab {
-#if !defined(OG_HOST_EMUL) && !defined(OG_NO_LCG_ROM)
+#if !defined(OG_HOST_EMUL)
     // The jumps by 1 .. 192 steps are constants (rom_lcg_jump, tools/gen_rom_tables.py): a noise sample reads its pair from there.
     // (Rounds 2 - 3 kept the wave's six values in this object; the compiler put the object in scratch memory and turned at()'s
     // selects into indexed loads from it -- two trips to memory per sample where this is one, and the kernel's only scratch
@@ -2186,7 +2162,7 @@ OG_DEV void recon_leaves_own(const ParseRec *rec, const ReconCtx &rx, bool pre =
     }
 #endif
     OG_MARK(2);
-#if defined(OG_HOST_EMUL) || defined(OG_ROT_PER_LEAF) || defined(OG_LEAF_ROT_PLAIN)
+#ifdef OG_HOST_EMUL
     OG_FOR_LANES(t, n_leaves) {
         const bool first = pre && t < OG_NLANES;
         const u32 g = first ? g0 : rec->leaf[t].geom;
@@ -2222,33 +2198,6 @@ OG_DEV void recon_leaves_own(const ParseRec *rec, const ReconCtx &rx, bool pre =
 #endif
 }
 
-// ... or fetched: the leaf kernel decoded them (og_leaves.hip).  The frame's packed coefficients come in with 16-byte loads through
-// the rows behind the spectrum (free until the band loop's tables are made), then every leaf's lane copies its N to their place;
-// the masks are a coalesced copy.  `g0`, `aux0`: leaf `lane`'s geometry and aux words, fetched by the caller already.
-#if defined(OG_RECON_TIGHT) && !defined(OG_HOST_EMUL)
-OG_DEV void recon_leaves_fetch(const ParseRec *rec, const ReconCtx &rx, const LeafOut *lo, u32 g0, u32 aux0) {
-    const int n_leaves = rx.h.n_leaves, n_coef = rx.h.n_coef;
-    constexpr int CH = (V_MASK - V_NORM) / 8 * 8; // coefficients per chunk (1376: one chunk unless the frame has > 1376 in leaves)
-    i16 *const stage = &S.v[V_NORM];
-    OG_MARK(2);
-    OG_FOR_LANES(t, n_leaves) leaf_masks()[t] = lo->mask[t];
-    for (int c0 = 0; c0 < n_coef; c0 += CH) {
-        const int len = OG_MIN(CH, n_coef - c0);
-        OG_SYNC();
-        for (int j = 8 * OG_LANE; j < len; j += 8 * OG_NLANES)
-            *reinterpret_cast<og_v4i *>(&stage[j]) = *reinterpret_cast<const og_v4i *>(&lo->coef[c0 + j]);
-        OG_SYNC();
-        OG_FOR_LANES(t, n_leaves) {
-            const u32 g = t < OG_NLANES ? g0 : rec->leaf[t].geom, aux = t < OG_NLANES ? aux0 : rec->leaf[t].aux;
-            const int x = V_X + (int)(g & 2047), N = (int)(g >> 11) & 255, a = (int)(aux >> 20) - c0;
-            const int j0 = OG_MAX(0, -a), j1 = OG_MIN(N, len - a); // the part of the leaf this chunk holds
-            for (int j = j0; j < j1; j++) S.v[x + j] = stage[a + j];
-        }
-    }
-    OG_SYNC();
-}
-#endif
-
 OG_DEV int recon_finish(StreamState *st, const ParseRec *rec, const ReconCtx &rx) {
     const u32 flags = rx.flags;
     const int mode = rx.mode, C = rx.C, CC = rx.h.channels;
@@ -2262,18 +2211,11 @@ OG_DEV int recon_finish(StreamState *st, const ParseRec *rec, const ReconCtx &rx
         lcg.init();
 #ifndef OG_RECON_TIGHT
         // the phase-major band loop takes every 20 ms frame whose record did not overflow (hybrid: from band 17)
-#if defined(OG_NO_PM)
-        const bool pm = false;
-#else
         const bool pm = rx.fast;
-#endif
         if (!pm) { // the band walk starts from an empty folding history (the PVQ table that was there is no longer needed)
             OG_FOR_LANES(i, 1248) S.v[V_NORM + i] = 0;
             OG_SYNC();
         }
-#endif
-#if defined(OG_RABL) && OG_RABL == 2
-        return result;
 #endif
         u32 seed = rx.h.rng;
 #ifdef OG_RECON_TIGHT
@@ -2309,9 +2251,6 @@ OG_DEV int recon_finish(StreamState *st, const ParseRec *rec, const ReconCtx &rx
             OG_FOR_LANES(i, C * NBANDS) S.bandE_row()[i] = (i16)(-28 * 1024);
         }
         OG_TAP(1);
-#if defined(OG_RABL) && OG_RABL == 3
-        return result;
-#endif
         CeltSynth sp;
         sp.N = N; sp.LM = LM; sp.C = C; sp.CC = CC; sp.start = start; sp.end = end; sp.silence = silence; sp.transient = transient;
         sp.pf_pitch = rx.h.pf_pitch; sp.pf_tapset = rx.h.pf_tapset; sp.pf_gain = rx.h.pf_gain;
@@ -2342,9 +2281,6 @@ OG_DEV int celt_recon_wave(StreamState *st, const ParseRec *rec, int mode, int c
     if (rx.leaves) {
         pvq_tab_load();
         OG_SYNC();
-#if defined(OG_RABL) && OG_RABL == 1
-        return rx.ret;
-#endif
         recon_leaves_own(rec, rx);
     }
     return recon_finish(st, rec, rx);

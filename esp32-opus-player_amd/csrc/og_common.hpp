@@ -55,16 +55,7 @@ extern "C" void og_emul_tap(int id); // stage taps for parity tests (host emulat
 #define OG_FULL_SYNC() __syncthreads()
 // LDS-only ordering between lanes of ONE wave: the LDS unit serves a wave's instructions in order, so only the
 // compiler has to be kept from moving LDS accesses across the point (no s_barrier, no s_waitcnt).
-#ifdef OG_LIGHT_SYNC
-#define OG_LSYNC()                                    \
-    do {                                              \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();              \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
-    } while (0)
-#else
 #define OG_LSYNC() __syncthreads()
-#endif
 // Every workgroup of this library is ONE wave, so a sync point only has to order that wave's own memory operations:
 // LDS instructions of a wave execute in order and LLVM's AMDGPU memory model needs no code for wavefront-scope fences.
 // OG_WAVE_SYNC: the compiler may not move memory accesses across the point; no s_waitcnt, no s_barrier.
@@ -74,14 +65,9 @@ extern "C" void og_emul_tap(int id); // stage taps for parity tests (host emulat
         __builtin_amdgcn_wave_barrier();                      \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
-// Measured with every OG_SYNC wave-scoped (-DOG_SYNC_WAVE -DOG_LIGHT_SYNC): GPU parity suite green, every kernel time
-// unchanged to three digits -- the waits are forced by data dependencies anyway.  The full barrier stays the default;
-// the wave-scoped form is what a workgroup of several waves would need for its wave-private sync points.
-#ifdef OG_SYNC_WAVE
-#define OG_SYNC() OG_WAVE_SYNC()
-#else
+// (Measured in round 2 with every OG_SYNC wave-scoped: GPU parity suite green, every kernel time unchanged to three digits --
+// the waits are forced by data dependencies anyway.  The full barrier is what OG_SYNC is.)
 #define OG_SYNC() OG_FULL_SYNC()
-#endif
 #define OG_LDS __shared__
 #define OPUS_ROM static __device__ const
 #define OG_CLZ(x) __clz(x)
@@ -155,9 +141,9 @@ OG_DEV i32 mul16(i32 a, i32 b) { return (i32)(i16)a * (i32)(i16)b; }            
 OG_DEV i32 mul16_q15(i32 a, i32 b) { return mul16(a, b) >> 15; }                     // :355
 OG_DEV i32 mul16_q14(i32 a, i32 b) { return mul16(a, b) >> 14; }                     // :354
 OG_DEV i32 mul16_p15(i32 a, i32 b) { return (16384 + mul16(a, b)) >> 15; }           // :359
-#if defined(OG_HOST_EMUL) || defined(OG_MUL64)
+#ifdef OG_HOST_EMUL
 OG_DEV i32 mul16x32_q15(i32 a, i32 b) { return (i32)(((i64)(i16)a * (i64)b) >> 15); } // MULT16_32_Q15 :263
-#elif !defined(OG_NO_MAD64)
+#else
 // The 64-bit product in one instruction.  Measured on gfx950 (profiles/r03/a_valu_issue_rates.txt): v_mad_i64_i32 issues at the
 // rate of a 24-bit multiply -- 32-bit multiplies are not quarter rate here -- so product + v_alignbit_b32 is two instructions
 // against four.  Written as inline assembly because the compiler, given the C expression above in these kernels, expands the
@@ -167,13 +153,6 @@ OG_DEV i32 mul16x32_q15(i32 a, i32 b) { // MULT16_32_Q15 :263
     u64 carry;
     asm("v_mad_i64_i32 %0, %1, %2, %3, 0" : "=v"(p), "=s"(carry) : "v"((i32)(i16)a), "v"(b));
     return (i32)(p >> 15);
-}
-#else
-// Same value without a 64-bit product (v_mul_hi/lo are quarter-rate): with b = bh * 65536 + bl (bl unsigned 16 bit),
-// (a * b) >> 15 = 2 * (a * bh) + ((a * bl) >> 15) exactly, and both partial products fit 24 x 24 -> 32 bit multiplies.
-OG_DEV i32 mul16x32_q15(i32 a, i32 b) { // MULT16_32_Q15 :263
-    const i32 as = (i32)(i16)a;
-    return (i32)(((u32)__mul24(as, b >> 16) << 1) + (u32)(__mul24(as, (i32)((u32)b & 0xffffu)) >> 15));
 }
 #endif
 OG_DEV i32 mul32_q31(i32 a, i32 b) { return (i32)(((i64)a * (i64)b) >> 31); }        // :266
@@ -197,14 +176,8 @@ OG_DEV u32 udiv(u32 n, u32 d) { return n / d; }                                 
 static constexpr i32 SIG_SAT = 300000000; // celt.h:234
 
 // ---- SILK flavour (src/silk.h) -------------------------------------------------------------------
-#if defined(OG_HOST_EMUL) || defined(OG_MUL64)
+#ifdef OG_HOST_EMUL
 OG_DEV i32 smulwb(i32 a, i32 b) { return (i32)(((i64)a * (i64)(i16)b) >> 16); }      // silk_SMULWB :447
-#elif defined(OG_SMULWB_MUL24)
-// (a * (i16)b) >> 16 with a = ah * 65536 + al (al unsigned 16 bit): ah * b + ((al * b) >> 16), exact, two 24-bit multiplies
-OG_DEV i32 smulwb(i32 a, i32 b) {                                                    // silk_SMULWB :447
-    const i32 bs = (i32)(i16)b;
-    return __mul24(a >> 16, bs) + (__mul24((i32)((u32)a & 0xffffu), bs) >> 16);
-}
 #else
 // (a * (i16)b) >> 16 = the HIGH word of a * (b << 16): one v_mul_hi_i32 (32-bit multiplies issue like 24-bit ones on gfx950,
 // profiles/r03/a_valu_issue_rates.txt) plus a shift that leaves the loop wherever b does not change -- where round 3 had two

@@ -7,8 +7,6 @@
 //   OPUSGPU_SPLIT             split            1        0: every frame through the single kernel k_decode_step (round 1's design)
 //   OPUSGPU_SPLIT_HYBRID      split_hybrid     1        0: SILK-only and hybrid frames stay on the single kernel
 //   OPUSGPU_FAST_RECON        fast_recon       1        0: every CELT frame through the general reconstruction kernel
-//   OPUSGPU_LEAF_KERNEL       leaf_kernel      0        1: the PVQ leaves of 20 ms frames are decoded by k_celt_leaves (og_leaves.hip: one leaf per
-//                                                       lane across frames, sorted by cost) ahead of the reconstruction kernel -- measured slower
 //   OPUSGPU_SILK_PIPELINE     silk_pipeline    1        0: steps declared SILK-only run in order even with pipelining on (A/B measurements)
 //   OPUSGPU_HYBRID_PIPELINE   hybrid_pipeline  1        0: the same for steps declared hybrid (or SILK-only + hybrid)
 //   OPUSGPU_PARSE_WIDE        parse_wide       1        0: pipelined steps parse with 32 frames per wave like in-order steps (k_celt_parse instead of k_celt_parse64);
@@ -26,7 +24,7 @@
 #include <stdlib.h>
 
 struct og_debug_knobs {
-    int split = 1, split_hybrid = 1, fast_recon = 1, leaf_kernel = 0, halves = 1, silk_pipeline = 1, hybrid_pipeline = 1, parse_wide = 1, parse_groups = 1, parse_priority = 1, host_parts = 16, host_slices = 1, host_timing = 0,
+    int split = 1, split_hybrid = 1, fast_recon = 1, halves = 1, silk_pipeline = 1, hybrid_pipeline = 1, parse_wide = 1, parse_groups = 1, parse_priority = 1, host_parts = 16, host_slices = 1, host_timing = 0,
         pages_timing = 0, launch_delay_us = 0;
 };
 inline const og_debug_knobs &og_debug() {
@@ -44,7 +42,6 @@ inline const og_debug_knobs &og_debug() {
         flag("OPUSGPU_SPLIT", v.split);
         flag("OPUSGPU_SPLIT_HYBRID", v.split_hybrid);
         flag("OPUSGPU_FAST_RECON", v.fast_recon);
-        flag("OPUSGPU_LEAF_KERNEL", v.leaf_kernel);
         flag("OPUSGPU_HALVES", v.halves);
         flag("OPUSGPU_SILK_PIPELINE", v.silk_pipeline);
         flag("OPUSGPU_HYBRID_PIPELINE", v.hybrid_pipeline);

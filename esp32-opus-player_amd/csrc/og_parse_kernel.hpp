@@ -23,9 +23,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(OG_PARSE_WAVES_PER_SIMD, 8)))
     // `started` (steps queued as a window, opusgpu_decode_steps_device): every workgroup counts itself in when it starts -- the
     // reconstruction of the step before is held (a stream memory wait) until this launch's workgroups have their places
     if (started && threadIdx.x == 0) __hip_atomic_fetch_add(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#ifdef OG_PARSE_PRIO
-    __builtin_amdgcn_s_setprio(OG_PARSE_PRIO);
-#endif
     const bool lane_on = (int)(threadIdx.x & 63) < OG_PL_LANES;
     const int f0 = (int)blockIdx.x * groups * OG_PL_FRAMES + OG_PWAVE * OG_PL_LANES + OG_PCOL;
     if (which != PARSE_ALL) { // a launch that finds none of its frames among the workgroup's leaves without loading the tables

@@ -9,13 +9,7 @@
 
 namespace og {
 
-#if defined(OG_RECON_TIGHT) && defined(OG_RECON_FRAMES) && OG_RECON_FRAMES > 1
-// several frames per workgroup (og_recon.hip): one working set per wave; S names the calling wave's own
-OG_LDS FrameLds Sx[OG_RECON_FRAMES];
-#define S Sx[OG_WAVE]
-#else
 OG_LDS FrameLds S; // the wave's LDS working set (one workgroup == one wave == one frame)
-#endif
 
 struct Rc {
     u32 storage, end_offs, end_window;

@@ -28,7 +28,6 @@ __global__ void __launch_bounds__(64, OG_RFC_WAVES) k_decode_rfc(const FrameDesc
     if (d.stream < 0 || d.stream >= n_streams || !desc_rfc(d.flags))
         ret = BAD_ARG; // (in RFC mode every descriptor carries the mode bit: opusgpu_packet_to_frames_mode)
     else {
-#ifndef OG_NO_RFC_PREFETCH
         // (as in k_silk_synth: one load per lane now brings to the L2 what the frame reads of the stream's state in many dependent
         // steps later -- the SILK state, the scalars and energies behind the CELT history ring, the head of the loss state)
         {
@@ -40,7 +39,6 @@ __global__ void __launch_bounds__(64, OG_RFC_WAVES) k_decode_rfc(const FrameDesc
                                    : reinterpret_cast<const char *>(sp); // (six lines per channel end inside the record: static_assert below)
             prefetched = *reinterpret_cast<const volatile u32 *>(p);
         }
-#endif
         ret = decode_frame_rfc(&st[d.stream], arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
                                desc_channels(d.flags), pcm + (size_t)f * pcm_stride, desc_frame_size(d.flags), desc_fec(d.flags));
     }

@@ -153,9 +153,6 @@ struct FrameLds {
     i16 dn_g[2 * NBANDS], dn_shift[2 * NBANDS];
     u8 cmask[2 * NBANDS];
     u8 bin2band[120];
-#ifdef OG_LDS_PAD /* occupancy experiments only: make the wave's LDS footprint larger */
-    u8 pad_experiment[OG_LDS_PAD];
-#endif
     OG_MEMBER i16 *bandE_row() { return bandE; }
     OG_MEMBER i16 *logE1_row() { return logE1; }
     OG_MEMBER i16 *logE2_row() { return logE2; }
@@ -204,9 +201,6 @@ constexpr int V_SYN = 960;              // the synthesis buffer: second channel'
 constexpr int SYN_LEN = 1088;
 struct FrameLds {
     alignas(16) i16 v[V_TOTAL];
-#ifdef OG_LDS_PAD /* occupancy experiments only: make the wave's LDS footprint larger */
-    u8 pad_experiment[OG_LDS_PAD];
-#endif
     u8 rot_marker_[64]; // the leaf pass's hand-out of rotation chains to lanes (pvq_rotate_wave)
     // (named by code that this layout never runs)
     u8 pkt[0];
@@ -229,9 +223,7 @@ static_assert((V_MASK + 4 * NBANDS) * 2 + 120 <= (V_MASK + 144) * 2 && (V_MASK +
               "synthesis tables fit behind the buffer: the gains per band, bin -> band, then the long block's gains per bin (og_celt.hpp)");
 static_assert(V_LATE + 24 + 8 * NBANDS <= V_MASK && (V_LATE + 24) % 2 == 0, "the late-staged arrays fit the scratch rows");
 static_assert(V_MASK % 2 == 0 && V_NORM % 8 == 0 && V_IY % 8 == 0 && V_WIN % 2 == 0 && V_WIN + 128 <= V_MASK, "alignment of the overlays");
-#ifndef OG_LDS_PAD
 static_assert(sizeof(FrameLds) <= 7680, "six 1280-byte LDS granules: 21 workgroups per CU");
-#endif
 #endif
 
 } // namespace og

@@ -2,6 +2,7 @@
 // opus_decode / opus_multistream_decode / the ctls / the packet helpers would do, driven by a script file so that the
 // Python test can compare every result with the CPU oracle.
 //   script:  records  'D' u32 frame_size u32 len bytes   decode (single-stream decoder and multistream wrapper, both)
+//                     'N' i32 frame_size                  decode the last packet's bytes with len = -1 (both)
 //                     'R'                                 OPUS_RESET_STATE on both
 //                     'Q'                                 ctl queries + packet helpers of the last packet
 //   output:  per 'D': i32 ret_single, i32 ret_ms, then min(ret, frame_size) * 2 int16 of the single-stream PCM if ret > 0
@@ -29,12 +30,13 @@ int main(int argc, char **argv) {
     int cmd, guards_ok = 1, decodes = 0;
     while ((cmd = fgetc(in)) != EOF) {
         if (cmd == 'D') {
-            uint32_t fs = 0, len = 0;
+            int32_t fs = 0; // (as it is: zero and negative frame sizes are calls too)
+            uint32_t len = 0;
             if (fread(&fs, 4, 1, in) != 1 || fread(&len, 4, 1, in) != 1) return 2;
             std::vector<uint8_t> cur(len);
             if (len && fread(cur.data(), 1, len, in) != len) return 2;
             if (len) last = cur; // (the packet helpers of 'Q' look at the last packet that HAD bytes)
-            const size_t room = (size_t)fs * 2, guard = 4096;
+            const size_t room = fs > 0 ? (size_t)fs * 2 : 0, guard = 4096;
             std::vector<int16_t> a(room + guard, GUARD), b(room + guard, GUARD);
             const int32_t ra = opus_decode(st, cur.data(), (int32_t)len, a.data(), (int)fs);
             const int32_t rb = opus_multistream_decode(ms, cur.data(), (int32_t)len, b.data(), (int)fs);
@@ -47,6 +49,13 @@ int main(int argc, char **argv) {
                 if (rb != ra || memcmp(a.data(), b.data(), n * 2) != 0) { fprintf(stderr, "single-stream and multistream disagree\n"); return 1; }
             }
             decodes++;
+        } else if (cmd == 'N') {
+            int32_t fs = 0;
+            if (fread(&fs, 4, 1, in) != 1) return 2;
+            std::vector<int16_t> a(5760 * 2 + 64, GUARD);
+            const int32_t ra = opus_decode(st, last.data(), -1, a.data(), fs), rb = opus_multistream_decode(ms, last.data(), -1, a.data(), fs);
+            fwrite(&ra, 4, 1, out);
+            fwrite(&rb, 4, 1, out);
         } else if (cmd == 'R') {
             if (opus_decoder_ctl(st, OPUS_RESET_STATE) != OPUS_OK || opus_multistream_decoder_ctl(ms, OPUS_RESET_STATE) != OPUS_OK) return 1;
         } else if (cmd == 'Q') {

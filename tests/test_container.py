@@ -96,12 +96,7 @@ def test_opus_decoder_h_surface_on_gpu(tmp_path, oracle):
     single- and multi-frame packets in all modes, OPUS_RESET_STATE (the reference's partial reset, Q5), the ctl queries and
     the packet helpers, against the oracle; and the over-long packet (Q6) -- more short frames than the caller's frame_size
     has room for at 960 samples each: the reference's return value, only frame_size samples written, guard region intact."""
-    import struct
-    src = os.path.join(ROOT, "tests", "player", "compat_main.cpp")
-    exe = str(tmp_path / "compat")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), src,
-                           "-L", os.path.join(ROOT, "esp32-opus-player_amd"), "-lopusgpu",
-                           "-Wl,-rpath," + os.path.join(ROOT, "esp32-opus-player_amd"), "-o", exe])
+    import compat_util
     rng = np.random.default_rng(31)
     body = lambda n: rng.integers(0, 256, n, dtype=np.uint8).tobytes()
     steps = []  # ('D', frame_size, packet) | ('R',) | ('Q',)
@@ -132,23 +127,16 @@ def test_opus_decoder_h_surface_on_gpu(tmp_path, oracle):
     steps += [("D", 960, bytes([0x0C]) + body(40)), ("R",), ("D", 960, b"")]
     tiny[len(steps) - 1] = -18
     steps += [("D", 960, bytes([0x0C]) + body(40))]
-    script = b""
-    for s in steps:
-        script += s[0].encode() + (struct.pack("<II", s[1], len(s[2])) + s[2] if s[0] == "D" else b"")
-    (tmp_path / "script.bin").write_bytes(script)
-    log = subprocess.check_output([exe, str(tmp_path / "script.bin"), str(tmp_path / "out.bin")], text=True)
-    assert "guards=intact" in log, log
-    got = (tmp_path / "out.bin").read_bytes()
+    results = compat_util.run(tmp_path, steps)
     d = oracle.decoder(2)
     d.init()
-    at, last, last_ret = 0, None, 0
-    for k, s in enumerate(steps):
+    last, last_ret = None, 0
+    for k, (s, got) in enumerate(zip(steps, results)):
         if s[0] == "R":
             d.reset()
         elif s[0] == "D":
             fs, pkt = s[1], s[2]
-            ra, rb = struct.unpack_from("<ii", got, at)
-            at += 8
+            ra, rb, out = got
             if k in tiny:
                 assert ra == rb == tiny[k], (pkt.hex(), ra, rb, tiny[k])
             # the oracle with generous room decodes every frame (Q6: 960 samples each); with the caller's room it applies
@@ -161,18 +149,14 @@ def test_opus_decoder_h_surface_on_gpu(tmp_path, oracle):
             assert ra == rb == r, (pkt[:1].hex(), fs, ra, rb, r)
             if r > 0:
                 n = min(r, fs)
-                out = np.frombuffer(got, dtype=np.int16, count=2 * n, offset=at).reshape(n, 2)
-                at += 4 * n
                 assert (out == pcm[:n]).all(), (pkt[:1].hex(), fs)
                 last_ret = r
             last = pkt or last
         else:
-            v = struct.unpack_from("<8i", got, at)
-            at += 32
+            v = got
             toc = last[0]
             bw = 1101 + ((toc >> 5) & 3) if not toc & 0x80 and (toc & 0x60) != 0x60 else (
                 (1105 if toc & 0x10 else 1104) if not toc & 0x80 else {0: 1101, 1: 1103, 2: 1104, 3: 1105}[(toc >> 5) & 3])
             assert v[0] == 48000 and v[2] == last_ret
             assert v[5] == (2 if toc & 4 else 1) and v[6] == bw
             assert v[3] == (1 if toc & 3 == 0 else 2 if toc & 3 != 3 else last[1] & 63) and v[4] == v[3] * v[7]
-    assert at == len(got)

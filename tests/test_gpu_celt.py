@@ -102,14 +102,14 @@ def test_device_path_reports_bad_descriptors(pkg, oracle, gpu_ctx):
 
 
 def test_optional_kernels_in_child_processes(pkg):
-    """Code paths that og_debug.hpp's switches select (read once per process): the separate PVQ leaf kernel (OPUSGPU_LEAF_KERNEL=1,
-    og_leaves.hip) ahead of the reconstruction, the general reconstruction kernel for every frame (OPUSGPU_FAST_RECON=0).  Each runs
+    """Code paths that og_debug.hpp's switches select (read once per process): the general reconstruction kernel for every frame
+    (OPUSGPU_FAST_RECON=0), the single-kernel path for every frame (OPUSGPU_SPLIT=0: round 1's design, and what Q4 frames run on).  Each runs
     tests/pipeline_knob_worker.py -- 8 steps of 8,192 CELT-FB streams, pipelined, as a window and call by call, every sample
     against the oracle -- in a child process."""
     import os
     import subprocess
     import sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pipeline_knob_worker.py")
-    for env in ({"OPUSGPU_LEAF_KERNEL": "1"}, {"OPUSGPU_FAST_RECON": "0"}):
+    for env in ({"OPUSGPU_FAST_RECON": "0"}, {"OPUSGPU_SPLIT": "0"}):
         out = subprocess.run([sys.executable, worker], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "knob worker ok" in out.stdout, (env, out.stdout[-400:], out.stderr[-400:])
