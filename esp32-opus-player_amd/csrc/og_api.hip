@@ -362,11 +362,37 @@ __global__ void __launch_bounds__(64, OG_SPARSE_WAVES) k_silk_parse(const FrameD
 #endif
     SilkShadow *const sh = shadow ? &shadow[d.stream] : nullptr;
     const SilkPast past(&st[d.stream], sh, epoch);
-    silk_parse_lane(past, arena + d.offset, d.len, mode, desc_bandwidth(d.flags), desc_channels(d.flags), &srecs[f], &handoff[f]);
-    silk_params_lane(past, mode, desc_bandwidth(d.flags), desc_channels(d.flags), &srecs[f], sh, epoch, desc_mode_after(d.flags));
+    silk_parse_lane(past, arena + d.offset, d.len, mode, desc_bandwidth(d.flags), desc_channels(d.flags), &srecs[f], &handoff[f], sh, epoch,
+                    desc_mode_after(d.flags));
 #ifdef OG_PROF_SPARSE
     OG_PROF_FLUSH();
 #endif
+}
+
+// ... and their parameter half (silk_decode_parameters), ONE (FRAME, CHANNEL) PER LANE: lane l of workgroup g takes channel l / 32
+// of frame 32 g + l % 32 -- the record's indices in, the dequantised parameters out, and for pipelined steps the entropy half's
+// past of the stream's next frame (`shadow`).  Behind k_silk_parse on the same stream.
+#ifndef OG_SPARAMS_WAVES
+#define OG_SPARAMS_WAVES 4
+#endif
+__global__ void __launch_bounds__(64, OG_SPARAMS_WAVES) k_silk_params(const FrameDesc *__restrict__ descs, const StreamState *st, SilkRec *srecs,
+                                                                       int n, int n_streams, SilkShadow *shadow, u32 epoch) {
+    constexpr int FR = OG_PAR_LANES / 2;
+    const int ch = (int)threadIdx.x / FR, f = (int)blockIdx.x * FR + (int)threadIdx.x % FR;
+    bool act = f < n;
+    FrameDesc d = {0, 0, 0, 0};
+    if (act) {
+        d = descs[f];
+        act = !(d.stream < 0 || d.stream >= n_streams || desc_mode(d.flags) == MODE_CELT || desc_rfc(d.flags));
+    }
+    SilkShadow *const sh = act && shadow ? &shadow[d.stream] : nullptr;
+    const SilkParPast past(act ? &st[d.stream] : st, sh, epoch);
+    const int mode = desc_mode(d.flags), channels = desc_channels(d.flags);
+    SilkParTask t;
+    t.skip = 1;
+    if (act) silk_params_channel(past, mode, desc_bandwidth(d.flags), channels, &srecs[f], ch, t);
+    OG_FULL_SYNC(); // every lane has read what it needs of the past: now the lanes of a frame may overwrite it
+    if (act) silk_params_shadow(past, t, channels, &srecs[f], ch, sh, epoch);
 }
 
 #define OG_PARSE_KERNEL_NAME k_celt_parse
@@ -685,7 +711,7 @@ struct opusgpu_ctx {
     unsigned shadow_epoch = 1; // advanced by everything else that may change a stream's SILK state: stale copies are ignored
     int silk_slot = 0, sdone_recorded[2] = {}, last_silk_mask = 0, last_kind = 0; // last_kind: 0 in order, 1 pipelined CELT-only, 2 pipelined SILK-only
     bool last_kind2_celt = false; // the last step of kind 2 held CELT-only frames too (enter_step_kind)
-    hipEvent_t ev_sparsed = nullptr, ev_sdone[2] = {};
+    hipEvent_t ev_sparsed = nullptr, ev_sdone[2] = {}, ev_sp = nullptr, ev_spar = nullptr; // ev_sp: a step's SILK parse is done; ev_spar: its parameter half
     int split_celt = 1;   // OPUSGPU_SPLIT=0 forces the single-kernel path for every mode (A/B measurements)
     int split_hybrid = 1; // OPUSGPU_SPLIT_HYBRID=0 keeps SILK-only and hybrid frames entirely on the single-kernel path
     int fast_recon = 1;   // OPUSGPU_FAST_RECON=0: every CELT frame through the general reconstruction kernel (A/B measurements)
@@ -804,6 +830,8 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
         if (ctx->ev_sdone[i]) (void)hipEventDestroy(ctx->ev_sdone[i]);
     }
     if (ctx->ev_sparsed) (void)hipEventDestroy(ctx->ev_sparsed);
+    if (ctx->ev_sp) (void)hipEventDestroy(ctx->ev_sp);
+    if (ctx->ev_spar) (void)hipEventDestroy(ctx->ev_spar);
     (void)hipFree(ctx->d_shadow);
     (void)hipHostFree(ctx->h_pcm);
     (void)hipHostFree(ctx->h_res);
@@ -1138,11 +1166,21 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     ctx->last_had_silk_recs = srecs != nullptr;
     const dim3 parse_block(64 * OG_PL_WAVES);
     // The in-order chain of frames [f0, f0 + cnt) of the step, in two halves: the ENTROPY kernels (one frame per lane) ...
-    auto front = [&](hipStream_t q, size_t f0, int cnt, SilkShadow *shadow = nullptr, u32 epoch = 0) {
+    // `pq` (pipelined SILK / hybrid steps): the stream the parameter half runs on -- behind this step's SILK parse and the parameter
+    // half of the step before, but off the entropy chain: the parse of the next step does not wait for it (SilkShadow's two sides)
+    auto front = [&](hipStream_t q, size_t f0, int cnt, SilkShadow *shadow = nullptr, u32 epoch = 0, hipStream_t pq = nullptr) {
         const FrameDesc *dd = (const FrameDesc *)d_descs + f0;
-        if (srecs)
+        if (srecs) {
             hipLaunchKernelGGL(k_silk_parse, dim3((cnt + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, q, dd, (const u8 *)d_arena,
                                (const StreamState *)ctx->d_streams, srecs + f0, handoff + f0, cnt, ctx->n_streams, shadow, epoch);
+            if (pq && pq != q) {
+                (void)hipEventRecord(ctx->ev_sp, q);
+                (void)hipStreamWaitEvent(pq, ctx->ev_sp, 0);
+            }
+            hipLaunchKernelGGL(k_silk_params, dim3((cnt + OG_PAR_LANES / 2 - 1) / (OG_PAR_LANES / 2)), dim3(64), 0, pq ? pq : q, dd,
+                               (const StreamState *)ctx->d_streams, srecs + f0, cnt, ctx->n_streams, shadow, epoch);
+            if (pq && pq != q) (void)hipEventRecord(ctx->ev_spar, pq);
+        }
         if (any_celt && ((shadow && og_debug().parse_wide) || og_debug().parse_wide == 2)) { // (a pipelined step: the wide parse, like pipelined CELT-only steps)
             const int fr = og_celt_parse64_frames();
             og_launch_celt_parse64(q, (cnt + fr - 1) / fr, dd, d_arena, ctx->d_streams, recs + f0, cnt, ctx->n_streams,
@@ -1191,6 +1229,8 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         // last reader -- and with it for every write to the state of streams it may have no current copy of).
         if (!ctx->ev_sparsed) {
             HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_sparsed, hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_sp, hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_spar, hipEventDisableTiming));
             for (int i = 0; i < 2; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_sdone[i], hipEventDisableTiming));
         }
         if (ctx->sdone_recorded[sset]) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_sdone[sset], 0));
@@ -1204,9 +1244,10 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         // (Tried: the step's frames in chunks, the CELT parse of chunk c on the reconstruction's idle stream next to the SILK parse of
         // chunk c + 1, so that the two entropy kernels do not run one after the other: hybrid-256k 12.7 -> 13.1 / 13.3 / 18.7 ms with
         // 2 / 4 / 8 chunks.  The step is bound by what all its kernels issue together, not by the length of the entropy chain.)
-        front(ctx->parse_stream, 0, n, (SilkShadow *)ctx->d_shadow, (u32)ctx->shadow_epoch);
+        front(ctx->parse_stream, 0, n, (SilkShadow *)ctx->d_shadow, (u32)ctx->shadow_epoch, og_debug().silk_params_aside ? ctx->recon_stream : nullptr);
         HIPCHK(ctx, hipEventRecord(ctx->ev_sparsed, ctx->parse_stream));
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_sparsed, 0));
+        if (og_debug().silk_params_aside) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_spar, 0));
         back_half(s, 0, n);
         HIPCHK(ctx, hipEventRecord(ctx->ev_sdone[sset], s));
         ctx->sdone_recorded[sset] = 1;

@@ -105,9 +105,12 @@ static int dec_decode(OpusDecoder *d, const uint8_t *data, int32_t len, int16_t 
     // the GPU path writes 960 samples per frame (Q6); decode into a scratch block sized for `count` frames
     int32_t id = 0, res = 0;
     const uint8_t *pk = data;
-    int16_t *buf = (int16_t *)malloc(sizeof(int16_t) * (size_t)count * 960 * d->channels);
+    // (room, in 20 ms blocks, for what the C ABI checks: the frames at 960 samples each AND the duration the TOC names -- a 60 ms
+    // TOC passes :323 with frame_size 2880 and then decodes 960 samples)
+    const int cap = count * pfs > count * 960 ? (count * pfs + 959) / 960 : count;
+    int16_t *buf = (int16_t *)malloc(sizeof(int16_t) * (size_t)cap * 960 * d->channels);
     if (!buf) return OPUS_ALLOC_FAIL;
-    int rc = opusgpu_decode_packets(d->ctx, 1, &id, &pk, &len, buf, count, &res);
+    int rc = opusgpu_decode_packets(d->ctx, 1, &id, &pk, &len, buf, cap, &res);
     if (rc != OPUSGPU_OK) res = OPUS_INTERNAL_ERROR;
     if (res > 0) {
         int n = res < frame_size ? res : frame_size;

@@ -620,8 +620,8 @@ OG_DEV void silk_decode_parameters(const i16 *prevNLSF_Q15, K &k, int fs_kHz, in
 
 // ---- lane-private parameter decoding for the parse kernel (scratch: SilkParLds, og_silk_parse.hpp) -----------------
 struct SilkParLane {
-    typedef ArrV<i16, OG_SP_LANES> A16;
-    typedef ArrV<i32, OG_SP_LANES> A32;
+    typedef ArrV<i16, OG_PAR_LANES> A16;
+    typedef ArrV<i32, OG_PAR_LANES> A32;
     static OG_MEMBER A16 nlsf() { A16 r = {&g_silk_par.nlsf[0][OG_LANE]}; return r; }
     static OG_MEMBER A16 nlsf0() { A16 r = {&g_silk_par.nlsf0[0][OG_LANE]}; return r; }
     static OG_MEMBER A16 res_Q10() { A16 r = {&g_silk_par.res_Q10[0][OG_LANE]}; return r; }
@@ -635,74 +635,82 @@ struct SilkParLane {
 static_assert(sizeof(SilkCtrl) == 4 * (SILK_REC_CTRL_WORDS + 1), "SilkRecCh mirrors SilkCtrl");
 static_assert(2 * SILK_MAX_FRAME * 4 * 2 >= 1920 * 2 && SILK_MAX_FRAME * 4 * 2 <= 1920 * 2 + 0 * 1, "up-sampler input staging sits under pcm");
 
-// Second half of the parse kernel's lane: silk_decode_parameters for the coded channels, from the indices just
-// written to the record.  The inputs that live in the stream state (LastGainIndex, first_frame_after_reset, previous
-// NLSFs) are taken as the wave kernel will see them after its own (re-)initialisations: decoder init on a CELT ->
+// The parameter half of a SILK-only / hybrid frame on the split path: silk_decode_parameters for the coded channels, from the
+// indices the parse lane wrote to the record.  The inputs that live in the stream state (LastGainIndex, first_frame_after_reset,
+// previous NLSFs) are taken as the wave kernel will see them after its own (re-)initialisations: decoder init on a CELT ->
 // SILK/hybrid switch, channel 1 init when the packet adds a channel, silk_decoder_set_fs on a rate change, side-channel
-// restart after a mid-only frame (silk.cpp:1639).  Nothing but the record is written.
-// `shadow` (pipelined SILK-only steps, see SilkShadow): where the lane leaves what the NEXT frame's entropy half needs -- the
-// values the synthesis kernel will have written to the stream's state by the time it is through with this frame
-// (silk_decode_packet: silk_init_state on a switch from CELT, silk_chan_init for a channel the packet adds, silk_set_fs, the
-// side channel's restart, the indices' history, the gain index, the stabilised NLSFs; decode_frame_wave: prev_mode).
-OG_DEV void silk_params_lane(const SilkPast &past, int mode, int bandwidth, int channels, SilkRec *rec, SilkShadow *shadow = nullptr,
-                             u32 epoch = 0, int mode_after = -1) {
-    if (rec->ret < 0) return; // (the frame ends in an error before anything of the state is touched: the past stays what it is)
+// restart after a mid-only frame (silk.cpp:1639).  Nothing but the record is written -- and, for pipelined SILK / hybrid steps
+// (`shadow`, see SilkShadow), what the NEXT frame's entropy half needs: the values the synthesis kernel will have written to the
+// stream's state by the time it is through with this frame (silk_decode_packet: silk_init_state on a switch from CELT,
+// silk_chan_init for a channel the packet adds, silk_set_fs, the side channel's restart, the indices' history, the gain index, the
+// stabilised NLSFs; decode_frame_wave: prev_mode).
+// In two parts per channel, so that k_silk_params can give every (frame, channel) a lane of its own: silk_params_channel READS
+// the past and writes the record, silk_params_shadow WRITES the parameter side of the next frame's past -- every read of all lanes
+// before any write (a barrier between the two in the kernel; one after the other here for a caller that does both channels itself).
+// What the parameter half needs of the ENTROPY side's past comes from the record (SilkRec::par_flags, fs_past), not from the shadow:
+// the parse of the stream's next frame may have moved that side on already.
+struct SilkParTask {
+    int skip;   // the frame ended in an error before anything of the state was touched: the past stays what it is
+    int fs_kHz, order, fresh, coded;
+    i32 lastGain_past, ffar_past; // the channel's past as the next frame would see it if this one left it alone
+};
+OG_DEV void silk_params_channel(const SilkParPast &past, int mode, int bandwidth, int channels, SilkRec *rec, int n, SilkParTask &t) {
+    t.skip = rec->ret < 0;
+    if (t.skip) return;
     int internal_hz = 16000;
     if (mode == MODE_SILK) internal_hz = bandwidth == BW_NB ? 8000 : (bandwidth == BW_MB ? 12000 : 16000);
     const int fs_kHz = (internal_hz >> 10) + 1, order = fs_kHz == 16 ? 16 : 10;
-    const int fresh_all = past.prev_mode() == MODE_CELT, fresh_ch1 = channels > past.nChannelsInternal();
-    const int prev_dom = fresh_all ? 0 : past.prev_dom(), dom = rec->decode_only_middle;
-    for (int n = 0; n < channels; n++) {
-        if (n == 1 && dom) continue; // no side channel this frame
-        const int fresh = fresh_all || (n == 1 && fresh_ch1), changed = fresh || past.fs_kHz(n) != fs_kHz;
-        i32 lastGain = changed ? 10 : past.lastGain(n);
-        int ffar = changed ? 1 : past.ffar(n);
-        if (n == 1 && channels == 2 && dom == 0 && prev_dom == 1) {
-            lastGain = 10;
+    const int pf = rec->par_flags, fresh_all = pf & 1, fresh_ch1 = (pf >> 1) & 1, prev_dom = (pf >> 2) & 1, dom = rec->decode_only_middle;
+    const int fresh = fresh_all || (n == 1 && fresh_ch1); // the channel was (re-)initialised: everything zero, first frame after a reset
+    t.fs_kHz = fs_kHz; t.order = order; t.fresh = fresh;
+    t.coded = n < channels && !(n == 1 && dom); // (no side channel in a mid-only frame)
+    t.lastGain_past = fresh ? 0 : past.lastGain(n);
+    t.ffar_past = fresh ? 1 : past.ffar(n);
+    if (!t.coded) return;
+    const int changed = fresh || rec->fs_past[n] != fs_kHz;
+    i32 lastGain = changed ? 10 : past.lastGain(n);
+    int ffar = changed ? 1 : past.ffar(n);
+    if (n == 1 && channels == 2 && dom == 0 && prev_dom == 1) {
+        lastGain = 10;
+        ffar = 1;
+    }
+    SilkRecCh &k = rec->ch[n];
+    OG_MARK(53);
+    silk_decode_parameters<SilkParLane>(past.prevNLSF(n), k, fs_kHz, 0, lastGain, ffar);
+    k.LastGainIndex = lastGain;
+    const SilkParLane::A16 nl = SilkParLane::nlsf();
+    for (int i = 0; i < order; i++) k.nlsf[i] = nl[i];
+}
+// the parameter side of the stream's next frame's past (the entropy side: silk_parse_lane)
+OG_DEV void silk_params_shadow(const SilkParPast &past, const SilkParTask &t, int channels, const SilkRec *rec, int n, SilkShadow *shadow,
+                               u32 epoch) {
+    if (t.skip || !shadow) return;
+    i32 lastGain = t.lastGain_past, ffar = t.ffar_past;
+    i16 nl[SILK_REC_LPC];
+    for (int i = 0; i < SILK_REC_LPC; i++) nl[i] = t.fresh ? (i16)0 : past.prevNLSF(n)[i];
+    if (n < channels) {
+        if (rec->fs_past[n] != t.fs_kHz) { // silk_set_fs
             ffar = 1;
+            lastGain = 10;
         }
-        SilkRecCh &k = rec->ch[n];
-        OG_MARK(53);
-        silk_decode_parameters<SilkParLane>(past.prevNLSF(n), k, fs_kHz, 0, lastGain, ffar);
-        k.LastGainIndex = lastGain;
-        const SilkParLane::A16 nl = SilkParLane::nlsf();
-        for (int i = 0; i < order; i++) k.nlsf[i] = nl[i];
-    }
-    if (!shadow) return;
-    // ---- the past of the next frame (written over the one just read: every input above has been consumed)
-    for (int n = 0; n < 2; n++) {
-        const int fresh = fresh_all || (n == 1 && fresh_ch1); // the channel was (re-)initialised: everything zero, first frame after a reset
-        // (the indices' history: what the entropy half ended with -- a frame's LBRR copies move it on even for a channel whose
-        // regular frame is not coded, and the synthesis stores both channels' values whatever the packet's channel count)
-        const i32 ecType = rec->ch[n].ec_prevSignalType, ecLag = rec->ch[n].ec_prevLagIndex;
-        i32 fs = fresh ? 0 : past.fs_kHz(n);
-        i32 lastGain = fresh ? 0 : past.lastGain(n), ffar = fresh ? 1 : past.ffar(n);
-        i16 nl[SILK_REC_LPC];
-        for (int i = 0; i < SILK_REC_LPC; i++) nl[i] = fresh ? (i16)0 : past.prevNLSF(n)[i];
-        if (n < channels) {
-            if (fs != fs_kHz) { // silk_set_fs
-                ffar = 1;
-                lastGain = 10;
-                fs = fs_kHz;
-            }
-            if (n == 0 || !dom) { // a coded frame
-                lastGain = rec->ch[n].LastGainIndex;
-                ffar = 0;
-                for (int i = 0; i < order; i++) nl[i] = rec->ch[n].nlsf[i];
-            }
+        if (t.coded) {
+            lastGain = rec->ch[n].LastGainIndex;
+            ffar = 0;
+            for (int i = 0; i < t.order; i++) nl[i] = rec->ch[n].nlsf[i];
         }
-        SilkShadow::Ch &o = shadow->ch[n];
-        o.ec_prevSignalType = ecType;
-        o.ec_prevLagIndex = ecLag;
-        o.fs_kHz = fs;
-        o.LastGainIndex = lastGain;
-        o.first_frame_after_reset = ffar;
-        for (int i = 0; i < SILK_REC_LPC; i++) o.prevNLSF_Q15[i] = nl[i];
     }
-    shadow->prev_mode = mode_after >= 0 ? mode_after : mode;
-    shadow->nChannelsInternal = channels;
-    shadow->prev_decode_only_middle = dom; // (0 for a mono packet: silk_decode_packet stores its local, which only stereo packets set)
-    shadow->epoch = epoch;
+    SilkShadow::Ch &o = shadow->ch[n];
+    o.LastGainIndex = lastGain;
+    o.first_frame_after_reset = ffar;
+    for (int i = 0; i < SILK_REC_LPC; i++) o.prevNLSF_Q15[i] = nl[i];
+    if (n == 0) shadow->par_epoch = epoch;
+}
+// both channels by one caller (host emulation; the kernel's lanes take one channel each)
+OG_DEV void silk_params_lane(const SilkParPast &past, int mode, int bandwidth, int channels, SilkRec *rec, SilkShadow *shadow = nullptr,
+                             u32 epoch = 0) {
+    SilkParTask t[2];
+    for (int n = 0; n < 2; n++) silk_params_channel(past, mode, bandwidth, channels, rec, n, t[n]);
+    for (int n = 1; n >= 0; n--) silk_params_shadow(past, t[n], channels, rec, n, shadow, epoch); // (the epoch last)
 }
 
 // ---- synthesis: one lane per channel (silk_decode_core silk.cpp:1806, LPC analysis filter :2268) --------------

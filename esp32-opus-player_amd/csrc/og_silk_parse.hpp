@@ -40,7 +40,12 @@ struct alignas(128) SilkRec { // (a record starts on a line boundary of the memo
     i32 MS_pred_Q13[2];
     // The stream's prev_mode when the step began.  The synthesis kernel takes it from here, not from the stream state: on
     // a hybrid frame the CELT reconstruction kernel -- which may run concurrently -- writes the new value there.
-    i32 prev_mode, pad_[3];
+    i32 prev_mode;
+    // What the parameter half (k_silk_params) needs of the stream's past besides its own values, left here by the entropy half --
+    // whose run for the stream's NEXT frame may overwrite them in the shadow before the parameter half of this one has run:
+    // bit 0 the SILK decoder is re-initialised at this frame (the frame before was CELT-only), bit 1 channel 1 is (the packet adds
+    // it), bit 2 the frame before was mid-only; and the channels' internal rate before this frame (0 after a re-initialisation)
+    i32 par_flags, fs_past[2];
     SilkRecCh ch[2];
 };
 static_assert(sizeof(SilkRec) % 16 == 0, "record alignment");
@@ -52,6 +57,10 @@ static_assert(sizeof(SilkRec) % 16 == 0, "record alignment");
 // `epoch`: the copy counts only if it carries the context's current epoch -- every step that is not such a pipelined step, every
 // reset and mode change advances the epoch on the host (whatever they do to the state, the copy is then stale by definition),
 // and the parse falls back to the state itself, which nothing in flight is writing then.
+// Two writers since round 5: k_silk_parse keeps the ENTROPY side (epoch, prev_mode, nChannelsInternal, prev_decode_only_middle,
+// the channels' indices history and rate), k_silk_params the PARAMETER side (LastGainIndex, first_frame_after_reset, the
+// stabilised NLSFs; `par_epoch` says whether that side is current) -- so that the parse of step k + 1 waits for the parse of
+// step k only, not for its parameter half.
 struct SilkShadow {
     u32 epoch;
     i32 prev_mode, nChannelsInternal, prev_decode_only_middle;
@@ -59,7 +68,8 @@ struct SilkShadow {
         i32 ec_prevSignalType, ec_prevLagIndex, fs_kHz, LastGainIndex, first_frame_after_reset;
         i16 prevNLSF_Q15[SILK_REC_LPC];
     } ch[2];
-    i32 pad[2];
+    u32 par_epoch;
+    i32 pad[1];
 };
 static_assert(sizeof(SilkShadow) == 128, "one shadow per 128 bytes");
 
@@ -74,6 +84,12 @@ struct SilkPast {
     OG_MEMBER i32 ecType(int n) const { return sh ? sh->ch[n].ec_prevSignalType : st->silk.ch[n].ec_prevSignalType; }
     OG_MEMBER i32 ecLag(int n) const { return sh ? sh->ch[n].ec_prevLagIndex : st->silk.ch[n].ec_prevLagIndex; }
     OG_MEMBER i32 fs_kHz(int n) const { return sh ? sh->ch[n].fs_kHz : st->silk.ch[n].fs_kHz; }
+};
+// ... and the parameter half's: the shadow's parameter side when THAT is current
+struct SilkParPast {
+    const StreamState *st;
+    const SilkShadow *sh;
+    OG_MEMBER SilkParPast(const StreamState *st_, const SilkShadow *shadow, u32 epoch) : st(st_), sh(shadow && shadow->par_epoch == epoch ? shadow : nullptr) {}
     OG_MEMBER i32 lastGain(int n) const { return sh ? sh->ch[n].LastGainIndex : st->silk.ch[n].LastGainIndex; }
     OG_MEMBER i32 ffar(int n) const { return sh ? sh->ch[n].first_frame_after_reset : st->silk.ch[n].first_frame_after_reset; }
     OG_MEMBER const i16 *prevNLSF(int n) const { return sh ? sh->ch[n].prevNLSF_Q15 : st->silk.ch[n].prevNLSF_Q15; }
@@ -90,15 +106,23 @@ OG_DEV void silk_tables_load() {      // cooperative, whole workgroup; ends with
 // inverse-CDF symbol from the LDS table blob (ec_dec_icdf celt.cpp:2727, ftb = 8 throughout SILK).  `n`: entries of
 // the table including its terminating 0.  The reference scans linearly; the table is monotone, so the same symbol is
 // found by bisection -- log2(n) dependent LDS reads, and (almost) the same trip count in every lane of the wave.
+// The two products the update needs -- r * icdf[symbol] and r * icdf[symbol - 1] -- are the last ones the search compared on either
+// side, so they are kept instead of read again (two dependent LDS round trips less per symbol than in round 4).
 OG_DEV int rc_icdf_tab(RcLane &rc, int off, int n) {
     const u32 d = rc.val, r = rc.rng >> 8;
     int lo = 0, hi = n - 1; // smallest index with val >= r * icdf[index]; the last entry (0) always qualifies
+    u32 s = 0, t = rc.rng;  // r * icdf[hi] (the last entry is 0), r * icdf[lo - 1] (or the whole range at lo == 0)
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (d >= r * (u32)g_silk_tab[off + mid]) hi = mid; else lo = mid + 1;
+        const u32 p = r * (u32)g_silk_tab[off + mid];
+        if (d >= p) {
+            hi = mid;
+            s = p;
+        } else {
+            lo = mid + 1;
+            t = p;
+        }
     }
-    const u32 s = r * (u32)g_silk_tab[off + lo];
-    const u32 t = lo ? r * (u32)g_silk_tab[off + lo - 1] : rc.rng;
     rc.val = d - s;
     rc.rng = t - s;
     rc_renorm(rc);
@@ -195,43 +219,43 @@ OG_DEV void shell_split_tab(RcLane &rc, int &c1, int &c2, int p, int table) {
 #ifndef OG_SP_LANES
 #define OG_SP_LANES (OG_NLANES >= 32 ? 32 : OG_NLANES) // measured: 64 / 32 / 16 frames per wave, see DESIGN.md section 6
 #endif
-// Lane-private scratch of the parse kernel, [element][lane].  Arrays that are never live together share storage -- 9,156
-// bytes per workgroup with the table blob instead of 13,520: 8 instead of 11 LDS granules of 1,280 bytes, 16 instead of 11
-// workgroups per CU (what the kernel's time on large batches depends on: its waves wait, they do not compute) --
-//   blk      per-lane block bookkeeping of the pulse decoder (sum_pulses | nLshifts << 5 per 16-sample block): the pulses of
-//            a frame are all read before its parameters are dequantised, so it lies over the NLSF rows;
+// Lane-private scratch, [element][lane]: a lane's walk along its column and the wave's access to a row fall on different banks.
+// k_silk_parse keeps only the pulse decoder's block bookkeeping here (2.5 KB per 32 frames; with the table blob 5.4 KB per workgroup):
+//   blk      sum_pulses | nLshifts << 5 per 16-sample block;
+//   nzmask   silk_skip_pulses: which of a block's 16 coefficients are not zero.
+struct SilkBlkLds {
+    u16 blk[SILK_REC_FRAME / 16][OG_SP_LANES];
+    u16 nzmask[SILK_REC_FRAME / 16][OG_SP_LANES];
+};
+OG_LDS SilkBlkLds g_silk_blkl;
+#define g_silk_blk g_silk_blkl.blk
+// The parameter dequantisation (silk_decode_parameters: NLSF decode and stabilisation, NLSF -> LPC, gains, pitch, LTP) is a kernel
+// of its own since round 5, k_silk_params: ONE (FRAME, CHANNEL) PER LANE -- 32 frames x 2 channels per wave, every lane busy on a
+// stereo frame, where the parse kernel's lane did its two channels one after the other with the wave's upper half idle.  Its
+// scratch, arrays that are never live together sharing storage:
 //   res_Q10  belongs to silk_nlsf_decode and is dead when the interpolated NLSFs (nlsf0) are made;
 //   pred_Q8  belongs to silk_nlsf_decode too and is dead when silk_nlsf2a starts; cosLSF is dead once P and Q are formed,
 //            P and Q once a32 is, and Atmp is only used after that (silk_inverse_pred_gain, at the end of silk_nlsf2a).
-// Every array keeps the [row][lane] shape with rows of OG_SP_LANES elements of its size, so an element of one array and
-// the element of another that shares its bytes always belong to the same lane.
+#define OG_PAR_LANES (OG_NLANES >= 64 ? 64 : OG_NLANES)
 struct SilkParLds {
+    i16 nlsf[SILK_REC_LPC][OG_PAR_LANES];
     union {
-        struct {
-            i16 nlsf[SILK_REC_LPC][OG_SP_LANES];
-            union {
-                i16 nlsf0[SILK_REC_LPC][OG_SP_LANES];
-                i16 res_Q10[SILK_REC_LPC][OG_SP_LANES];
-            };
-        };
-        u16 blk[SILK_REC_FRAME / 16][OG_SP_LANES];
+        i16 nlsf0[SILK_REC_LPC][OG_PAR_LANES];
+        i16 res_Q10[SILK_REC_LPC][OG_PAR_LANES];
     };
     union {
-        i32 cosLSF[SILK_REC_LPC][OG_SP_LANES];
-        i32 a32[SILK_REC_LPC][OG_SP_LANES];
-        u16 nzmask[SILK_REC_FRAME / 16][OG_SP_LANES]; // silk_skip_pulses: which of a block's 16 coefficients are not zero (dead before any parameter is dequantised)
+        i32 cosLSF[SILK_REC_LPC][OG_PAR_LANES];
+        i32 a32[SILK_REC_LPC][OG_PAR_LANES];
     };
     union {
         struct {
-            i32 P[SILK_REC_LPC / 2 + 1][OG_SP_LANES], Q[SILK_REC_LPC / 2 + 1][OG_SP_LANES];
+            i32 P[SILK_REC_LPC / 2 + 1][OG_PAR_LANES], Q[SILK_REC_LPC / 2 + 1][OG_PAR_LANES];
         };
-        i32 pred_Q8[SILK_REC_LPC][OG_SP_LANES];
-        i32 Atmp[SILK_REC_LPC][OG_SP_LANES];
+        i32 pred_Q8[SILK_REC_LPC][OG_PAR_LANES];
+        i32 Atmp[SILK_REC_LPC][OG_PAR_LANES];
     };
 };
-static_assert(SILK_REC_FRAME / 16 <= 2 * SILK_REC_LPC, "the pulse decoder's block row fits over the two NLSF arrays");
 OG_LDS SilkParLds g_silk_par;
-#define g_silk_blk g_silk_par.blk
 
 // silk_decode_pulses silk.cpp:898.  A channel's pulses go to the record (HBM) block by block: 16 coefficients = 32 bytes.
 // Between the passes of the bitstream (all shell trees, then all LSBs, then all signs) a block waits in its own 32 bytes of the
@@ -254,6 +278,7 @@ OG_DEV void silk_parse_pulses(RcLane &rc, i16 *pulses, int signalType, int quant
     const int RateLevelIndex = rc_icdf_tab(rc, SILK_BLOB_rate_levels_icdf + 9 * (signalType >> 1), 9);
     const int cdf = SILK_BLOB_pulses_per_block_icdf + 18 * RateLevelIndex;
     OG_MARK(46);
+    u32 lsb_blocks = 0; // bit i: block i has LSBs (rare: the lane's own list -- the wave does not go through every block for them)
     for (int i = 0; i < iter; i++) {
         int nl = 0, sp = rc_icdf_tab(rc, cdf, 18);
         while (sp == 17) {
@@ -261,6 +286,7 @@ OG_DEV void silk_parse_pulses(RcLane &rc, i16 *pulses, int signalType, int quant
             sp = rc_icdf_tab(rc, SILK_BLOB_pulses_per_block_icdf + 18 * 9 + (nl == 10), 18 - (nl == 10));
         }
         g_silk_blk[i][OG_LANE] = (u16)(sp | nl << 5);
+        lsb_blocks |= (u32)(nl > 0) << i;
     }
     OG_MARK(47);
     for (int i = 0; i < iter; i++) {
@@ -306,21 +332,21 @@ OG_DEV void silk_parse_pulses(RcLane &rc, i16 *pulses, int signalType, int quant
 #endif
     }
     OG_MARK(48);
-    for (int i = 0; i < iter; i++) {
+    while (lsb_blocks) { // widen the block, then its LSBs
+        const int i = __builtin_ctz(lsb_blocks);
+        lsb_blocks &= lsb_blocks - 1;
         const int nLS = g_silk_blk[i][OG_LANE] >> 5;
-        if (nLS > 0) { // widen the block, then its LSBs (from the last coefficient down: a value's 16 bits land on bytes not yet read)
-            i16 *p = &pulses[i * 16];
-            const u8 *pb = reinterpret_cast<const u8 *>(p);
-            u8 mag[16];
-            for (int j = 0; j < 16; j++) mag[j] = pb[j];
-            for (int j = 0; j < 16; j++) {
-                i32 abs_q = mag[j];
-                for (int b = 0; b < nLS; b++) {
-                    abs_q = shl32(abs_q, 1);
-                    abs_q += rc_icdf_tab(rc, SILK_BLOB_lsb_icdf, 2);
-                }
-                p[j] = (i16)abs_q;
+        i16 *p = &pulses[i * 16];
+        const u8 *pb = reinterpret_cast<const u8 *>(p);
+        u8 mag[16];
+        for (int j = 0; j < 16; j++) mag[j] = pb[j];
+        for (int j = 0; j < 16; j++) {
+            i32 abs_q = mag[j];
+            for (int b = 0; b < nLS; b++) {
+                abs_q = shl32(abs_q, 1);
+                abs_q += rc_icdf_tab(rc, SILK_BLOB_lsb_icdf, 2);
             }
+            p[j] = (i16)abs_q;
         }
     }
     OG_MARK(49);
@@ -400,6 +426,7 @@ OG_DEV void silk_skip_pulses(RcLane &rc, int signalType, int quantOffsetType, in
     const int RateLevelIndex = rc_icdf_tab(rc, SILK_BLOB_rate_levels_icdf + 9 * (signalType >> 1), 9);
     const int cdf = SILK_BLOB_pulses_per_block_icdf + 18 * RateLevelIndex;
     OG_MARK(46);
+    u32 lsb_blocks = 0;
     for (int i = 0; i < iter; i++) {
         int nl = 0, sp = rc_icdf_tab(rc, cdf, 18);
         while (sp == 17) {
@@ -407,6 +434,7 @@ OG_DEV void silk_skip_pulses(RcLane &rc, int signalType, int quantOffsetType, in
             sp = rc_icdf_tab(rc, SILK_BLOB_pulses_per_block_icdf + 18 * 9 + (nl == 10), 18 - (nl == 10));
         }
         g_silk_blk[i][OG_LANE] = (u16)(sp | nl << 5);
+        lsb_blocks |= (u32)(nl > 0) << i;
     }
     OG_MARK(47);
     for (int i = 0; i < iter; i++) {
@@ -428,17 +456,17 @@ OG_DEV void silk_skip_pulses(RcLane &rc, int signalType, int quantOffsetType, in
                 }
             }
         }
-        g_silk_par.nzmask[i][OG_LANE] = (u16)nz;
+        g_silk_blkl.nzmask[i][OG_LANE] = (u16)nz;
     }
     OG_MARK(48);
-    for (int i = 0; i < iter; i++) {
+    while (lsb_blocks) {
+        const int i = __builtin_ctz(lsb_blocks);
+        lsb_blocks &= lsb_blocks - 1;
         const int nLS = g_silk_blk[i][OG_LANE] >> 5;
-        if (nLS > 0) {
-            u32 nz = g_silk_par.nzmask[i][OG_LANE];
-            for (int j = 0; j < 16; j++)
-                for (int b = 0; b < nLS; b++) nz |= (u32)rc_icdf_tab(rc, SILK_BLOB_lsb_icdf, 2) << j;
-            g_silk_par.nzmask[i][OG_LANE] = (u16)nz;
-        }
+        u32 nz = g_silk_blkl.nzmask[i][OG_LANE];
+        for (int j = 0; j < 16; j++)
+            for (int b = 0; b < nLS; b++) nz |= (u32)rc_icdf_tab(rc, SILK_BLOB_lsb_icdf, 2) << j;
+        g_silk_blkl.nzmask[i][OG_LANE] = (u16)nz;
     }
     OG_MARK(49);
     const int icdf_ptr = SILK_BLOB_sign_icdf + 7 * (quantOffsetType + (signalType << 1));
@@ -447,7 +475,7 @@ OG_DEV void silk_skip_pulses(RcLane &rc, int signalType, int quantOffsetType, in
         const int blk = g_silk_blk[i][OG_LANE];
         if (blk > 0) {
             const u32 ic0 = g_silk_tab[icdf_ptr + OG_MIN(blk & 0x1F, 6)];
-            for (int cnt = __builtin_popcount((u32)g_silk_par.nzmask[i][OG_LANE]); cnt > 0; cnt--) {
+            for (int cnt = __builtin_popcount((u32)g_silk_blkl.nzmask[i][OG_LANE]); cnt > 0; cnt--) {
                 // two-symbol iCDF {ic0, 0}, ftb 8: the sign itself is not needed
                 u32 s = rc.rng, d = rc.val, r = s >> 8, t = s;
                 s = r * ic0;
@@ -487,8 +515,12 @@ OG_DEV void silk_parse_stereo_pred(RcLane &rc, i32 pred_Q13[2]) { // silk_stereo
 
 // The entropy half of one SILK-only or hybrid frame, lane-private (decode_frame_wave's head + silk_Decode's).
 // Reads the stream's state, writes only the record and the hand-off.
+// `shadow` (pipelined SILK / hybrid steps): where the lane leaves the entropy side of the stream's NEXT frame's past -- what the
+// synthesis kernel will have written to the state by the time it is through with this frame (silk_decode_packet: silk_init_state on
+// a switch from CELT, silk_chan_init for a channel the packet adds, silk_set_fs, the indices' history; decode_frame_wave: prev_mode
+// -- `mode_after`) -- over the one it has just read; nothing is written for a frame that ends in an error (the past stays).
 OG_DEV void silk_parse_lane(const SilkPast &past, const u8 *payload, int len, int mode, int bandwidth, int channels, SilkRec *rec,
-                            SilkHandoff *handoff) {
+                            SilkHandoff *handoff, SilkShadow *shadow = nullptr, u32 epoch = 0, int mode_after = -1) {
     handoff->valid = 0;
     rec->prev_mode = past.prev_mode();
     if (len < 0 || len > 1275) {
@@ -510,6 +542,10 @@ OG_DEV void silk_parse_lane(const SilkPast &past, const u8 *payload, int len, in
     // entropy-side state, as the wave kernel will see it after its own (re-)initialisations:
     // silk_init_state on a CELT -> SILK/hybrid switch, channel 1 init when the packet adds a channel
     const int fresh_all = past.prev_mode() == MODE_CELT, fresh_ch1 = channels > past.nChannelsInternal();
+    const i32 fs_past0 = fresh_all ? 0 : past.fs_kHz(0), fs_past1 = (fresh_all || fresh_ch1) ? 0 : past.fs_kHz(1);
+    rec->par_flags = fresh_all | fresh_ch1 << 1 | ((fresh_all ? 0 : past.prev_dom()) != 0) << 2;
+    rec->fs_past[0] = fs_past0;
+    rec->fs_past[1] = fs_past1;
     i32 ecType0 = fresh_all ? 0 : past.ecType(0), ecLag0 = fresh_all ? 0 : past.ecLag(0);
     i32 ecType1 = (fresh_all || fresh_ch1) ? 0 : past.ecType(1), ecLag1 = (fresh_all || fresh_ch1) ? 0 : past.ecLag(1);
     int vad0 = rc_bit_logp(rc, 1), lbrr0 = rc_bit_logp(rc, 1), vad1 = 0, lbrr1 = 0;
@@ -569,6 +605,18 @@ OG_DEV void silk_parse_lane(const SilkPast &past, const u8 *payload, int len, in
     handoff->nend_bits = rc.nend_bits; handoff->nbits_total = rc.nbits_total; handoff->offs = rc.offs;
     handoff->rng = rc.rng; handoff->val = rc.val; handoff->ext = rc.ext; handoff->rem = rc.rem; handoff->error = rc.error;
     handoff->valid = 1;
+    if (shadow) { // (every input of the past has been consumed)
+        shadow->ch[0].ec_prevSignalType = ecType0;
+        shadow->ch[0].ec_prevLagIndex = ecLag0;
+        shadow->ch[1].ec_prevSignalType = ecType1;
+        shadow->ch[1].ec_prevLagIndex = ecLag1;
+        shadow->ch[0].fs_kHz = fs_kHz;                                // silk_set_fs for the packet's channels
+        shadow->ch[1].fs_kHz = channels == 2 ? fs_kHz : fs_past1;
+        shadow->prev_mode = mode_after >= 0 ? mode_after : mode;
+        shadow->nChannelsInternal = channels;
+        shadow->prev_decode_only_middle = decode_only_middle; // (0 for a mono packet: silk_decode_packet stores its local, which only stereo packets set)
+        shadow->epoch = epoch;
+    }
 }
 
 } // namespace og

@@ -51,7 +51,7 @@ int emu_decode_frame(void *stv, const uint8_t *payload, int len, int mode, int b
         og::silk_tables_load();
         const og::SilkPast past(st, nullptr, 0);
         og::silk_parse_lane(past, payload, len, mode, bw, ch, &srec, &handoff);
-        og::silk_params_lane(past, mode, bw, ch, &srec);
+        og::silk_params_lane(og::SilkParPast(st, nullptr, 0), mode, bw, ch, &srec);
         int r = og::decode_frame_wave<false>(st, payload, len, mode, bw, ch, pcm, &handoff, &srec);
         if (r == og::CONTINUE_Q4) return og::decode_frame_wave<true>(st, payload, len, mode, bw, ch, pcm, &handoff, &srec, 1);
         if (r != og::CONTINUE_SPLIT) return r;
@@ -73,8 +73,9 @@ int emu_decode_frame_shadowed(void *stv, void *shadow, unsigned epoch, const uin
     const int after = emu_no_mode(mode);
     og::silk_tables_load();
     const og::SilkPast past(st, (const og::SilkShadow *)shadow, epoch);
-    og::silk_parse_lane(past, payload, len, mode, bw, ch, &srec, &handoff);
-    og::silk_params_lane(past, mode, bw, ch, &srec, (og::SilkShadow *)shadow, epoch, after);
+    const og::SilkParPast par_past(st, (const og::SilkShadow *)shadow, epoch); // (chosen before the parse moves the entropy side on)
+    og::silk_parse_lane(past, payload, len, mode, bw, ch, &srec, &handoff, (og::SilkShadow *)shadow, epoch, after);
+    og::silk_params_lane(par_past, mode, bw, ch, &srec, (og::SilkShadow *)shadow, epoch);
     int r = og::decode_frame_wave<false>(st, payload, len, mode, bw, ch, pcm, &handoff, &srec);
     if (r == og::CONTINUE_Q4) return og::decode_frame_wave<true>(st, payload, len, mode, bw, ch, pcm, &handoff, &srec, 1);
     if (r != og::CONTINUE_SPLIT) return r;

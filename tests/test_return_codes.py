@@ -116,14 +116,18 @@ def test_opus_decoder_h_return_code_known_answers(tmp_path, oracle):
         assert ra == rb == ret, (name, ra, rb, ret, why)
     assert got[-5][0] == got[-5][1] == 5760   # frame_size 20000: six frames fit whatever the cap
     assert got[-2] == (-1, -1) and got[-1] == (-1, -1)
-    # and the PCM of the rows that decode, against the oracle
-    for k, (name, ret, why) in want.items():
-        if ret > 0:
-            d = oracle.decoder(2)
-            d.init()
-            fs, pkt = steps[k][1], steps[k][2]
-            oracle.lib.oc_decode(d.h, pkt, len(pkt), d.buf.ctypes.data, fs)
+    # and the PCM of the rows that decode, against the oracle driven the same way (OPUS_RESET_STATE is the reference's PARTIAL
+    # reset, Q5: what it keeps of the CELT state carries from row to row)
+    d = oracle.decoder(2)
+    d.init()
+    for k, s in enumerate(steps):
+        if s[0] == "R":
+            d.reset()
+        elif s[0] == "D":
+            fs, pkt = s[1], s[2]
+            r = oracle.lib.oc_decode(d.h, pkt, len(pkt), d.buf.ctypes.data, min(fs, 5760))
+            assert got[k][0] == r, (k, got[k][0], r)
             toc = pkt[0]
-            if not (not toc & 0x80 and (toc & 0x60) != 0x60 and not toc & 4):  # (Q3: mono SILK-only in a stereo decoder)
-                n = min(ret, fs)
-                assert np.array_equal(got[k][2], d.buf[:n]), name
+            if r > 0 and not (not toc & 0x80 and (toc & 0x60) != 0x60 and not toc & 4):  # (Q3: mono SILK-only in a stereo decoder)
+                n = min(r, fs)
+                assert np.array_equal(got[k][2], d.buf[:n]), (k, want.get(k))

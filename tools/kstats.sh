@@ -15,7 +15,7 @@ for l in open('gpurun_out/ks_$tag.log'):
         d = json.loads(l); line += '%.3f ms/step |' % d['ms_per_step']
 for f in glob.glob('gpurun_out/ks_$tag/**/*kernel_stats.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if float(r['AverageNs']) > 5e4 and 'init' not in r['Name']: line += ' %s %.3f' % (r['Name'].split('(')[0][2:], float(r['AverageNs'])/1e6)
+        if float(r['AverageNs']) > 1e4 and 'init' not in r['Name']: line += ' %s %.3f' % (r['Name'].split('(')[0][2:], float(r['AverageNs'])/1e6)
 print(line)
 PY
 done
