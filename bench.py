@@ -361,9 +361,9 @@ def check_against_oracle(pkg, ctx, name, n, frames, d_pcm, pay=None, pages_seed=
 
 
 def traffic_for(name, n):
-    """HBM bytes per step from the committed PMC passes of THIS round's build (tools/prof_pmc.sh -> profiles/r04/), taken
+    """HBM bytes per step from the committed PMC passes of THIS round's build (tools/prof_pmc.sh -> profiles/r05/), taken
     at this batch size; null when no such file exists.  The file names the build it was measured on."""
-    for rnd in ("r04",):
+    for rnd in ("r05",):
         tpath = os.path.join(ROOT, "profiles", rnd, f"traffic_{name}.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
@@ -378,7 +378,7 @@ def valu_issue_for(name, n, step_ms):
     same committed PMC passes: vector-ALU wave-instructions of the step's kernels, the time the chip needs just to issue them
     (a wave64 vector instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz), and that time over the measured
     step.  None when no counters of this round exist for the workload."""
-    tpath = os.path.join(ROOT, "profiles", "r04", f"traffic_{name}.json")
+    tpath = os.path.join(ROOT, "profiles", "r05", f"traffic_{name}.json")
     if not os.path.exists(tpath):
         return None
     with open(tpath) as fh:
@@ -401,12 +401,12 @@ def kernels_of(name):
     split = os.environ.get("OPUSGPU_SPLIT", "1") != "0"
     split_silk = split and os.environ.get("OPUSGPU_SPLIT_HYBRID", "1") != "0"
     if name == "mixed_pages_2m":
-        return "k_silk_parse + k_celt_parse + k_silk_synth + k_celt_recon + k_celt_post + k_decode_step (Q4 pass)"
+        return "k_silk_parse + k_silk_params + k_celt_parse + k_silk_synth + k_celt_recon + k_celt_post + k_decode_step (Q4 pass)"
     if name.startswith("celt"):
         return "k_celt_parse + k_celt_recon + k_celt_post" if split else "k_decode_step"
     if name.startswith("silk"):
-        return "k_silk_parse + k_silk_synth" if split_silk else "k_decode_step"
-    return "k_silk_parse + k_silk_synth + k_celt_parse + k_celt_recon + k_celt_post" if split_silk else "k_decode_step"
+        return "k_silk_parse + k_silk_params + k_silk_synth" if split_silk else "k_decode_step"
+    return "k_silk_parse + k_silk_params + k_silk_synth + k_celt_parse + k_celt_recon + k_celt_post" if split_silk else "k_decode_step"
 
 
 def run_workload(name, args, ranks, pkg, ctx, n_override=0, cpu=True):

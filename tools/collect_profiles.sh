@@ -16,9 +16,9 @@ if [ "$part" = pmc ]; then
 else
   timeout -k 10 900 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
   timeout -k 10 300 python bench.py > $out/bench_default.json 2> $out/bench_default.err || tail -3 $out/bench_default.err
-  mkdir -p build_exp; g++ -O2 -std=c++17 -pthread tools/host_path_rate.cpp -Iinclude -Lesp32-opus-player_amd -lopusgpu -Wl,-rpath,'$ORIGIN/../esp32-opus-player_amd' -o build_exp/host_path_rate
+  mkdir -p build_ab; g++ -O2 -std=c++17 -pthread tools/host_path_rate.cpp -Iinclude -Lesp32-opus-player_amd -lopusgpu -Wl,-rpath,'$ORIGIN/../esp32-opus-player_amd' -o build_ab/host_path_rate
   { for cfg in "0 8 1" "1 8 1" "0 8 1" "1 8 1" "1 2 0" "1 4 1" "1 16 1"; do set -- $cfg
-      echo "page-locked PCM $1, slices $2 (OPUSGPU_HOST_PARTS), sliced flow $3 (OPUSGPU_HOST_SLICES): $(OPUSGPU_HOST_PARTS=$2 OPUSGPU_HOST_SLICES=$3 timeout -k 5 120 build_exp/host_path_rate 65536 14 $1 1 | tail -1)"
+      echo "page-locked PCM $1, slices $2 (OPUSGPU_HOST_PARTS), sliced flow $3 (OPUSGPU_HOST_SLICES): $(OPUSGPU_HOST_PARTS=$2 OPUSGPU_HOST_SLICES=$3 timeout -k 5 120 build_ab/host_path_rate 65536 14 $1 1 | tail -1)"
     done; } > $out/host_path_rate.txt 2>&1
   tools/host_path_timeline.sh collect/host_timeline 65536 6 1 1 > $out/host_path_timeline.txt 2>&1
   timeout -k 10 300 python tools/launch_jitter.py > $out/launch_jitter.txt 2>&1

@@ -1,11 +1,11 @@
 #!/bin/bash
-# usage (GPU box): tools/host_path_timeline.sh <tag> [host_path_rate args...]   -- kernel + memory-copy trace of build_exp/host_path_rate
+# usage (GPU box): tools/host_path_timeline.sh <tag> [host_path_rate args...]   -- kernel + memory-copy trace of build_ab/host_path_rate
 # (build it first, see its header) and the device timeline of the LAST opusgpu_decode_packets call: uploads, kernels, PCM pieces.
 tag=$1; shift
 export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $out -o t -- build_exp/host_path_rate "$@" > $out/run.log 2>&1 || { tail -5 $out/run.log; exit 1; }
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $out -o t -- build_ab/host_path_rate "$@" > $out/run.log 2>&1 || { tail -5 $out/run.log; exit 1; }
 tail -1 $out/run.log
 python3 - <<PY
 import csv
