@@ -340,19 +340,21 @@ __global__ void __launch_bounds__(64, OG_SILK_WAVES) k_silk_synth(const FrameDes
     if (threadIdx.x == 0) result[f] = ret;
 }
 
-// SILK-only and hybrid frames, entropy half: ONE FRAME PER LANE (og_silk_parse.hpp).  Lane l of workgroup g decodes the
-// side information and pulses of frame OG_SP_LANES g + l (l < OG_SP_LANES = 32; the upper lanes idle) into srecs[frame] and leaves the coder state in handoff[frame].
+// SILK-only and hybrid frames, entropy half: ONE FRAME PER LANE (og_silk_parse.hpp).  Lane l < LANES of workgroup g decodes the side
+// information and pulses of frame LANES g + l into srecs[frame] and leaves the coder state in handoff[frame].  Twice, like the CELT
+// parse: k_silk_parse with 32 frames per wave (the upper lanes idle) for small in-order steps, k_silk_parse64 with 64 for pipelined
+// steps and large batches (og_silk_parse.hpp, OG_SP_LANES).
 #ifndef OG_SPARSE_WAVES
-#define OG_SPARSE_WAVES 4 // (9,156 B of LDS per workgroup allow 16 per CU; 128 VGPRs: 5 spilled. hybrid-256k: 4.80 -> 3.99 ms)
+#define OG_SPARSE_WAVES 4
 #endif
 // `shadow` (null in in-order steps): the per-stream copies of what the entropy half needs of the past, kept by this kernel for
-// pipelined SILK-only steps (SilkShadow, og_silk_parse.hpp); `epoch`: the context's current one.
-__global__ void __launch_bounds__(64, OG_SPARSE_WAVES) k_silk_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
-                                                      const StreamState *st, SilkRec *srecs, SilkHandoff *handoff, int n,
-                                                      int n_streams, SilkShadow *shadow, u32 epoch) {
+// pipelined SILK / hybrid steps (SilkShadow, og_silk_parse.hpp); `epoch`: the context's current one.
+template <int LANES>
+OG_DEV void silk_parse_kernel_body(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena, const StreamState *st, SilkRec *srecs,
+                                   SilkHandoff *handoff, int n, int n_streams, SilkShadow *shadow, u32 epoch) {
     silk_tables_load();
-    if ((int)threadIdx.x >= OG_SP_LANES) return;
-    const int f = (int)blockIdx.x * OG_SP_LANES + (int)threadIdx.x;
+    if ((int)threadIdx.x >= LANES) return;
+    const int f = (int)blockIdx.x * LANES + (int)threadIdx.x;
     if (f >= n) return;
     const FrameDesc d = descs[f];
     const int mode = desc_mode(d.flags);
@@ -367,6 +369,16 @@ __global__ void __launch_bounds__(64, OG_SPARSE_WAVES) k_silk_parse(const FrameD
 #ifdef OG_PROF_SPARSE
     OG_PROF_FLUSH();
 #endif
+}
+__global__ void __launch_bounds__(64, OG_SPARSE_WAVES) k_silk_parse(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
+                                                      const StreamState *st, SilkRec *srecs, SilkHandoff *handoff, int n,
+                                                      int n_streams, SilkShadow *shadow, u32 epoch) {
+    silk_parse_kernel_body<32>(descs, arena, st, srecs, handoff, n, n_streams, shadow, epoch);
+}
+__global__ void __launch_bounds__(64, OG_SPARSE_WAVES) k_silk_parse64(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
+                                                        const StreamState *st, SilkRec *srecs, SilkHandoff *handoff, int n,
+                                                        int n_streams, SilkShadow *shadow, u32 epoch) {
+    silk_parse_kernel_body<64>(descs, arena, st, srecs, handoff, n, n_streams, shadow, epoch);
 }
 
 // ... and their parameter half (silk_decode_parameters), ONE (FRAME, CHANNEL) PER LANE: lane l of workgroup g takes channel l / 32
@@ -999,6 +1011,9 @@ int opusgpu_memcpy_d2h(opusgpu_ctx *ctx, void *dst, const void *src, size_t byte
 // such a step does not run ahead of anything.
 // OPUSGPU_LAUNCH_DELAY_US (og_debug.hpp): the host dawdles before the launches of a decode step -- what a loaded host, a slow
 // event hop or another thread's launches would do -- so that tools/launch_jitter.py can show the step time does not depend on it
+#ifndef OG_SILK_PARSE_WIDE_MIN
+#define OG_SILK_PARSE_WIDE_MIN 98304 // frames of an in-order launch from which the SILK parse runs with 64 frames per wave
+#endif
 #ifndef OG_HALVES_MIN
 #define OG_HALVES_MIN 4096 // frames per half below which an in-order step with SILK frames is not cut in two
 #endif
@@ -1171,8 +1186,14 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     auto front = [&](hipStream_t q, size_t f0, int cnt, SilkShadow *shadow = nullptr, u32 epoch = 0, hipStream_t pq = nullptr) {
         const FrameDesc *dd = (const FrameDesc *)d_descs + f0;
         if (srecs) {
-            hipLaunchKernelGGL(k_silk_parse, dim3((cnt + OG_SP_LANES - 1) / OG_SP_LANES), dim3(64), 0, q, dd, (const u8 *)d_arena,
-                               (const StreamState *)ctx->d_streams, srecs + f0, handoff + f0, cnt, ctx->n_streams, shadow, epoch);
+            // (64 frames per wave where the kernel's issue slots are what counts: pipelined steps, large batches; 32 for a small
+            // in-order step, whose time is the latency of one wave's serial chain -- same-box: SILK-NB in order 1.36 / 1.41 ms)
+            if (shadow || cnt >= OG_SILK_PARSE_WIDE_MIN || og_debug().parse_wide == 2)
+                hipLaunchKernelGGL(k_silk_parse64, dim3((cnt + 63) / 64), dim3(64), 0, q, dd, (const u8 *)d_arena,
+                                   (const StreamState *)ctx->d_streams, srecs + f0, handoff + f0, cnt, ctx->n_streams, shadow, epoch);
+            else
+                hipLaunchKernelGGL(k_silk_parse, dim3((cnt + 31) / 32), dim3(64), 0, q, dd, (const u8 *)d_arena,
+                                   (const StreamState *)ctx->d_streams, srecs + f0, handoff + f0, cnt, ctx->n_streams, shadow, epoch);
             if (pq && pq != q) {
                 (void)hipEventRecord(ctx->ev_sp, q);
                 (void)hipStreamWaitEvent(pq, ctx->ev_sp, 0);

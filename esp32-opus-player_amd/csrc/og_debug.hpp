@@ -10,7 +10,7 @@
 //   OPUSGPU_SILK_PIPELINE     silk_pipeline    1        0: steps declared SILK-only run in order even with pipelining on (A/B measurements)
 //   OPUSGPU_HYBRID_PIPELINE   hybrid_pipeline  1        0: the same for steps declared hybrid (or SILK-only + hybrid)
 //   OPUSGPU_PARSE_WIDE        parse_wide       1        0: pipelined steps parse with 32 frames per wave like in-order steps (k_celt_parse instead of k_celt_parse64);
-//                                                       2: in-order steps use the wide kernel too (counter passes: --pmc serialises kernels, so only in-order steps can be counted)
+//                                                       2: in-order steps use the wide kernels too, k_silk_parse64 included (counter passes: --pmc serialises kernels, so only in-order steps can be counted)
 //   OPUSGPU_SILK_PARAMS_ASIDE silk_params_aside 1       0: pipelined SILK / hybrid steps keep the parameter half (k_silk_params) on the entropy chain's stream
 //   OPUSGPU_HALVES            halves           1        0: an in-order step with SILK-only / hybrid frames runs as ONE chain of kernels, not two
 //   OPUSGPU_PARSE_GROUPS      parse_groups     1        groups of frames per workgroup of the early parse, one after the other (1 .. 8)

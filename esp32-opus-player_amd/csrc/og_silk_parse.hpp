@@ -215,9 +215,13 @@ OG_DEV void shell_split_tab(RcLane &rc, int &c1, int &c2, int p, int table) {
     }
 }
 
-// Frames per SILK parse wave (see OG_PL_LANES, og_celt_split.hpp): width of the [element][lane] arrays of k_silk_parse.
+// Width of the [element][lane] arrays of the SILK parse kernels: a wave's 64 lanes.  k_silk_parse64 fills them -- 64 frames per
+// wave, for pipelined steps and large batches, where the kernel's ISSUE SLOTS are what the step pays (a wave's instruction stream
+// is nearly the same for 64 frames as for 32) -- k_silk_parse uses the first 32 columns: 32 frames per wave for small in-order
+// steps, where the latency of a wave's serial chain is what the step pays and more, shorter-lived waves hide it better.  (Round 4
+// measured 64 frames per wave as a wash; with the parameter half gone -- 77 registers, 7.8 KB of LDS -- it wins: DESIGN.md 6e.)
 #ifndef OG_SP_LANES
-#define OG_SP_LANES (OG_NLANES >= 32 ? 32 : OG_NLANES) // measured: 64 / 32 / 16 frames per wave, see DESIGN.md section 6
+#define OG_SP_LANES (OG_NLANES >= 64 ? 64 : OG_NLANES)
 #endif
 // Lane-private scratch, [element][lane]: a lane's walk along its column and the wave's access to a row fall on different banks.
 // k_silk_parse keeps only the pulse decoder's block bookkeeping here (2.5 KB per 32 frames; with the table blob 5.4 KB per workgroup):

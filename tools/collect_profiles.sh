@@ -8,9 +8,9 @@ out=gpurun_out/collect
 mkdir -p $out
 if [ "$part" = pmc ]; then
   PROF_PARSE_WIDE=2 tools/prof_pmc.sh collect/celt > $out/celt.log 2>&1 || { tail -5 $out/celt.log; exit 1; }
-  tools/prof_pmc.sh collect/silk_nb --workload silk_nb_stereo_64k > $out/silk_nb.log 2>&1 || { tail -5 $out/silk_nb.log; exit 1; }
+  PROF_PARSE_WIDE=2 tools/prof_pmc.sh collect/silk_nb --workload silk_nb_stereo_64k > $out/silk_nb.log 2>&1 || { tail -5 $out/silk_nb.log; exit 1; }
   PROF_PARSE_WIDE=2 PROF_FRAMES=262144 PROF_PASS_TIMEOUT=240 tools/prof_pmc.sh collect/hybrid --workload hybrid_fb_stereo_256k > $out/hybrid.log 2>&1 || { tail -5 $out/hybrid.log; exit 1; }
-  PROF_FRAMES=262144 PROF_PASS_TIMEOUT=240 tools/prof_pmc.sh collect/mixed --workload mixed_pages_2m > $out/mixed.log 2>&1 || { tail -5 $out/mixed.log; exit 1; }
+  PROF_PARSE_WIDE=2 PROF_FRAMES=262144 PROF_PASS_TIMEOUT=240 tools/prof_pmc.sh collect/mixed --workload mixed_pages_2m > $out/mixed.log 2>&1 || { tail -5 $out/mixed.log; exit 1; }
   rm -rf $out/*/pmc*/ $out/*/trace/*/*_trace.csv   # (keep the summaries and kernel stats; the raw counter files are large)
   ls $out
 else
