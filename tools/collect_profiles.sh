@@ -15,7 +15,7 @@ if [ "$part" = pmc ]; then
   ls $out
 else
   timeout -k 10 900 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
-  timeout -k 10 300 python bench.py > $out/bench_default.json 2> $out/bench_default.err || tail -3 $out/bench_default.err
+  timeout -k 10 400 python bench.py --verbose > $out/bench_default.json 2> $out/bench_default.err || tail -3 $out/bench_default.err
   mkdir -p build_ab; g++ -O2 -std=c++17 -pthread tools/host_path_rate.cpp -Iinclude -Lesp32-opus-player_amd -lopusgpu -Wl,-rpath,'$ORIGIN/../esp32-opus-player_amd' -o build_ab/host_path_rate
   { for cfg in "0 8 1" "1 8 1" "0 8 1" "1 8 1" "1 2 0" "1 4 1" "1 16 1"; do set -- $cfg
       echo "page-locked PCM $1, slices $2 (OPUSGPU_HOST_PARTS), sliced flow $3 (OPUSGPU_HOST_SLICES): $(OPUSGPU_HOST_PARTS=$2 OPUSGPU_HOST_SLICES=$3 timeout -k 5 120 build_ab/host_path_rate 65536 14 $1 1 | tail -1)"
