@@ -58,7 +58,10 @@ typedef struct opusgpu_ctx opusgpu_ctx;
  * and returns in result[i] the samples produced or the failing pass's code (the library remembers every stream's last accepted
  * TOC).  On the device path the caller passes, per pass, a descriptor with len 0 and the flags of the stream's last accepted
  * packet -- or, before the stream's first packet, opusgpu_empty_packet_to_frames' flags (hybrid, the decoder's channel count,
- * OPUSGPU_DESC_NO_MODE).  opusgpu_empty_packet_to_frames builds the descriptors either way. */
+ * OPUSGPU_DESC_NO_MODE).  opusgpu_empty_packet_to_frames builds the descriptors either way.  (The library's memory of a stream's
+ * last accepted TOC is kept by opusgpu_decode_packets and cleared by opusgpu_streams_alloc / _reset: a caller that decodes a
+ * stream through the device path keeps that stream's last flags itself, and should not mix the two paths on one stream around an
+ * empty packet.) */
 #define OPUSGPU_DESC_NO_MODE (1 << 11)
 typedef struct opusgpu_frame_desc {
     int32_t stream;  /* stream index in the context */
