@@ -347,6 +347,7 @@ OG_DEV int decode_frame_rfc(StreamState *st, const u8 *payload, int len, int mod
 #ifndef OG_NO_SILK
     if (mode != MODE_CELT) {
         if (prev_mode == MODE_CELT) silk_init_state(&st->silk, &st->loss);
+        silk_wave_tab_load(); // (og_rfc.hip: the entropy decoder's tables into LDS, over rows that nothing uses until the CELT layer)
         int internal_hz = 16000;
         if (mode == MODE_SILK) internal_hz = bandwidth == BW_NB ? 8000 : (bandwidth == BW_MB ? 12000 : 16000);
         int base = 0; // linear position of the internal frame in the packet's SILK PCM

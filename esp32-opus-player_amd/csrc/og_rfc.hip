@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #define OG_NO_SPLIT_LDS // the record window of the split path's reconstruction: 256 bytes this kernel does not need -- with them it is
                         // 8 bytes over the 20,480 that eight workgroups per CU (two waves per SIMD, what its 256 registers allow) have
+#define OG_SILK_TABLES_LDS // SILK's entropy tables in LDS (og_silk.hpp SILK_TAB): the wave-uniform decoder reads one per symbol
 #include "og_decode.hpp"
 
 using namespace og;

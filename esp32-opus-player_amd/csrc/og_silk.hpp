@@ -146,6 +146,27 @@ OG_DEV i32 silk_log2lin(i32 inLog_Q7) {
     return out + (out >> 7) * t;
 }
 
+// The byte tables of the WAVE-UNIFORM entropy decoder (below) and of the codebooks: in ROM -- or, for a translation unit that says so
+// (OG_SILK_TABLES_LDS: og_rfc.hip), in an LDS copy of rom_silk_u8_blob that lies over the CELT working set's folding-history rows,
+// which are dead whenever SILK's entropy half runs (silk_wave_tab_load before it).  The wave-uniform decoder reads a table entry per
+// lane and symbol, a dependent read each: from ROM that is a trip through the vector memory path per symbol, 1,100 - 3,300 of them
+// per packet, and it was what RFC mode's step consisted of.
+#if defined(OG_SILK_TABLES_LDS) && !defined(OG_HOST_EMUL)
+static_assert((V_TOTAL - V_NORM) * 2 >= SILK_BLOB_SIZE + 64, "the table copy (and the 64 entries a symbol's lanes read) fits behind X");
+OG_DEV const u8 *silk_wave_tab() { return reinterpret_cast<const u8 *>(&S.v[V_NORM]); }
+OG_DEV void silk_wave_tab_load() { // the whole wave; ends with a sync
+    OG_SYNC();
+    const u32 *src = reinterpret_cast<const u32 *>(rom_silk_u8_blob);
+    u32 *dst = reinterpret_cast<u32 *>(&S.v[V_NORM]);
+    OG_FOR_LANES(i, SILK_BLOB_SIZE / 4) dst[i] = src[i];
+    OG_SYNC();
+}
+#define SILK_TAB(name) (silk_wave_tab() + SILK_BLOB_##name)
+#else
+OG_DEV void silk_wave_tab_load() {}
+#define SILK_TAB(name) rom_silk_##name
+#endif
+
 // ---- codebooks (silk_NLSF_CB_struct instances silk.cpp:384-427) -------------------------------------------
 struct NlsfCb {
     int order;
@@ -158,22 +179,22 @@ OG_DEV NlsfCb nlsf_cb(int wb) {
     if (wb) {
         cb.order = 16;
         cb.quantStepSize_Q16 = 9830;
-        cb.CB1_NLSF_Q8 = rom_silk_wb_cb1_q8;
+        cb.CB1_NLSF_Q8 = SILK_TAB(wb_cb1_q8);
         cb.CB1_Wght_Q9 = rom_silk_wb_cb1_wght_q9;
-        cb.CB1_iCDF = rom_silk_wb_cb1_icdf;
-        cb.pred_Q8 = rom_silk_wb_pred_q8;
-        cb.ec_sel = rom_silk_wb_cb2_select;
-        cb.ec_iCDF = rom_silk_wb_cb2_icdf;
+        cb.CB1_iCDF = SILK_TAB(wb_cb1_icdf);
+        cb.pred_Q8 = SILK_TAB(wb_pred_q8);
+        cb.ec_sel = SILK_TAB(wb_cb2_select);
+        cb.ec_iCDF = SILK_TAB(wb_cb2_icdf);
         cb.deltaMin_Q15 = rom_silk_wb_delta_min_q15;
     } else {
         cb.order = 10;
         cb.quantStepSize_Q16 = 11796;
-        cb.CB1_NLSF_Q8 = rom_silk_nb_cb1_q8;
+        cb.CB1_NLSF_Q8 = SILK_TAB(nb_cb1_q8);
         cb.CB1_Wght_Q9 = rom_silk_nb_cb1_wght_q9;
-        cb.CB1_iCDF = rom_silk_nb_cb1_icdf;
-        cb.pred_Q8 = rom_silk_nb_pred_q8;
-        cb.ec_sel = rom_silk_nb_cb2_select;
-        cb.ec_iCDF = rom_silk_nb_cb2_icdf;
+        cb.CB1_iCDF = SILK_TAB(nb_cb1_icdf);
+        cb.pred_Q8 = SILK_TAB(nb_pred_q8);
+        cb.ec_sel = SILK_TAB(nb_cb2_select);
+        cb.ec_iCDF = SILK_TAB(nb_cb2_icdf);
         cb.deltaMin_Q15 = rom_silk_nb_delta_min_q15;
     }
     return cb;
@@ -200,36 +221,36 @@ OG_DEV void silk_decode_indices(SilkChannel *c, SilkCtrl &k, Rc &rc, int fs_kHz,
     const NlsfCb cb = nlsf_cb(fs_kHz == 16);
     int Ix;
     if (decode_LBRR || vad)
-        Ix = rc_icdf(rc, rom_silk_type_vad_icdf, 8) + 2;
+        Ix = rc_icdf(rc, SILK_TAB(type_vad_icdf), 8) + 2;
     else
-        Ix = rc_icdf(rc, rom_silk_type_novad_icdf, 8);
+        Ix = rc_icdf(rc, SILK_TAB(type_novad_icdf), 8);
     k.signalType = Ix >> 1;
     k.quantOffsetType = Ix & 1;
     if (condCoding == 2)
-        k.GainsIndices[0] = rc_icdf(rc, rom_silk_delta_gain_icdf, 8);
+        k.GainsIndices[0] = rc_icdf(rc, SILK_TAB(delta_gain_icdf), 8);
     else {
-        k.GainsIndices[0] = rc_icdf(rc, rom_silk_gain_icdf + 8 * k.signalType, 8) << 3;
-        k.GainsIndices[0] += rc_icdf(rc, rom_silk_uniform8_icdf, 8);
+        k.GainsIndices[0] = rc_icdf(rc, SILK_TAB(gain_icdf) + 8 * k.signalType, 8) << 3;
+        k.GainsIndices[0] += rc_icdf(rc, SILK_TAB(uniform8_icdf), 8);
     }
-    for (int i = 1; i < nb_subfr; i++) k.GainsIndices[i] = rc_icdf(rc, rom_silk_delta_gain_icdf, 8);
+    for (int i = 1; i < nb_subfr; i++) k.GainsIndices[i] = rc_icdf(rc, SILK_TAB(delta_gain_icdf), 8);
     k.NLSFIndices[0] = rc_icdf(rc, &cb.CB1_iCDF[(k.signalType >> 1) * 32], 8);
     nlsf_unpack(cb, k.NLSFIndices[0]);
     for (int i = 0; i < cb.order; i++) {
         Ix = rc_icdf(rc, &cb.ec_iCDF[L.ec_ix[i]], 8);
         if (Ix == 0)
-            Ix -= rc_icdf(rc, rom_silk_nlsf_ext_icdf, 8);
+            Ix -= rc_icdf(rc, SILK_TAB(nlsf_ext_icdf), 8);
         else if (Ix == 8)
-            Ix += rc_icdf(rc, rom_silk_nlsf_ext_icdf, 8);
+            Ix += rc_icdf(rc, SILK_TAB(nlsf_ext_icdf), 8);
         k.NLSFIndices[i + 1] = Ix - 4;
     }
-    k.NLSFInterpCoef_Q2 = nb_subfr == 4 ? rc_icdf(rc, rom_silk_nlsf_interp_icdf, 8) : 4; // silk.cpp:771-776
+    k.NLSFInterpCoef_Q2 = nb_subfr == 4 ? rc_icdf(rc, SILK_TAB(nlsf_interp_icdf), 8) : 4; // silk.cpp:771-776
     if (k.signalType == 2) {
         int decode_abs = 1;
-        const u8 *lowbits = fs_kHz == 16 ? rom_silk_uniform8_icdf : (fs_kHz == 12 ? rom_silk_uniform6_icdf : rom_silk_uniform4_icdf);
-        const u8 *contour = fs_kHz == 8 ? (nb_subfr == 4 ? rom_silk_pitch_contour_nb_icdf : rom_silk_pitch_contour_10ms_nb_icdf)
-                                         : (nb_subfr == 4 ? rom_silk_pitch_contour_icdf : rom_silk_pitch_contour_10ms_icdf);
+        const u8 *lowbits = fs_kHz == 16 ? SILK_TAB(uniform8_icdf) : (fs_kHz == 12 ? SILK_TAB(uniform6_icdf) : SILK_TAB(uniform4_icdf));
+        const u8 *contour = fs_kHz == 8 ? (nb_subfr == 4 ? SILK_TAB(pitch_contour_nb_icdf) : SILK_TAB(pitch_contour_10ms_nb_icdf))
+                                         : (nb_subfr == 4 ? SILK_TAB(pitch_contour_icdf) : SILK_TAB(pitch_contour_10ms_icdf));
         if (condCoding == 2 && ec_prevSignalType == 2) {
-            int delta = rc_icdf(rc, rom_silk_pitch_delta_icdf, 8);
+            int delta = rc_icdf(rc, SILK_TAB(pitch_delta_icdf), 8);
             if (delta > 0) {
                 delta -= 9;
                 k.lagIndex = tr16(ec_prevLagIndex + delta);
@@ -237,24 +258,24 @@ OG_DEV void silk_decode_indices(SilkChannel *c, SilkCtrl &k, Rc &rc, int fs_kHz,
             }
         }
         if (decode_abs) {
-            k.lagIndex = tr16(rc_icdf(rc, rom_silk_pitch_lag_icdf, 8) * (fs_kHz >> 1));
+            k.lagIndex = tr16(rc_icdf(rc, SILK_TAB(pitch_lag_icdf), 8) * (fs_kHz >> 1));
             k.lagIndex = tr16(k.lagIndex + rc_icdf(rc, lowbits, 8));
         }
         ec_prevLagIndex = k.lagIndex;
         k.contourIndex = rc_icdf(rc, contour, 8);
-        k.PERIndex = rc_icdf(rc, rom_silk_ltp_per_icdf, 8);
-        const u8 *t = k.PERIndex == 0 ? rom_silk_ltp_gain_icdf0 : (k.PERIndex == 1 ? rom_silk_ltp_gain_icdf1 : rom_silk_ltp_gain_icdf2);
+        k.PERIndex = rc_icdf(rc, SILK_TAB(ltp_per_icdf), 8);
+        const u8 *t = k.PERIndex == 0 ? SILK_TAB(ltp_gain_icdf0) : (k.PERIndex == 1 ? SILK_TAB(ltp_gain_icdf1) : SILK_TAB(ltp_gain_icdf2));
         for (int j = 0; j < nb_subfr; j++) k.LTPIndex[j] = rc_icdf(rc, t, 8);
-        k.LTP_scaleIndex = condCoding == 0 ? rc_icdf(rc, rom_silk_ltpscale_icdf, 8) : 0;
+        k.LTP_scaleIndex = condCoding == 0 ? rc_icdf(rc, SILK_TAB(ltpscale_icdf), 8) : 0;
     }
     ec_prevSignalType = k.signalType;
-    k.Seed = rc_icdf(rc, rom_silk_uniform4_icdf, 8);
+    k.Seed = rc_icdf(rc, SILK_TAB(uniform4_icdf), 8);
 }
 
 // ---- excitation pulses (silk_decode_pulses :898, silk_shell_decoder :1162, silk_decode_signs :1436) ----------
 OG_DEV void shell_split(Rc &rc, int &c1, int &c2, int p, const u8 *table) {
     if (p > 0) {
-        c1 = rc_icdf(rc, &table[rom_silk_shell_offsets[p]], 8);
+        c1 = rc_icdf(rc, &table[SILK_TAB(shell_offsets)[p]], 8);
         c2 = p - c1;
     } else {
         c1 = 0;
@@ -267,13 +288,13 @@ OG_DEV void silk_decode_pulses(Rc &rc, int ch, int signalType, int quantOffsetTy
     i16 *pulses = L.pulses[ch];
     int iter = frame_length >> 4;
     if (iter * 16 < frame_length) iter++;
-    const int RateLevelIndex = rc_icdf(rc, rom_silk_rate_levels_icdf + 9 * (signalType >> 1), 8);
-    const u8 *cdf = rom_silk_pulses_per_block_icdf + 18 * RateLevelIndex;
+    const int RateLevelIndex = rc_icdf(rc, SILK_TAB(rate_levels_icdf) + 9 * (signalType >> 1), 8);
+    const u8 *cdf = SILK_TAB(pulses_per_block_icdf) + 18 * RateLevelIndex;
     for (int i = 0; i < iter; i++) {
         int nl = 0, sp = rc_icdf(rc, cdf, 8);
         while (sp == 17) {
             nl++;
-            sp = rc_icdf(rc, rom_silk_pulses_per_block_icdf + 18 * 9 + (nl == 10), 8);
+            sp = rc_icdf(rc, SILK_TAB(pulses_per_block_icdf) + 18 * 9 + (nl == 10), 8);
         }
         L.nLshifts[i] = nl;
         L.sum_pulses[i] = sp;
@@ -284,15 +305,15 @@ OG_DEV void silk_decode_pulses(Rc &rc, int ch, int signalType, int quantOffsetTy
         if (sp > 0) {
             // binary shell tree: 16 -> 8 -> 4 -> 2 -> 1, depth-first in the reference's order
             int p3[2], p2[4], p1[8], a, b;
-            shell_split(rc, p3[0], p3[1], sp, rom_silk_shell3);
+            shell_split(rc, p3[0], p3[1], sp, SILK_TAB(shell3));
             for (int h = 0; h < 2; h++) {
-                shell_split(rc, p2[2 * h], p2[2 * h + 1], p3[h], rom_silk_shell2);
+                shell_split(rc, p2[2 * h], p2[2 * h + 1], p3[h], SILK_TAB(shell2));
                 for (int q = 0; q < 2; q++) {
                     const int qi = 2 * h + q;
-                    shell_split(rc, p1[2 * qi], p1[2 * qi + 1], p2[qi], rom_silk_shell1);
+                    shell_split(rc, p1[2 * qi], p1[2 * qi + 1], p2[qi], SILK_TAB(shell1));
                     for (int e = 0; e < 2; e++) {
                         const int ei = 2 * qi + e;
-                        shell_split(rc, a, b, p1[ei], rom_silk_shell0);
+                        shell_split(rc, a, b, p1[ei], SILK_TAB(shell0));
                         p0[2 * ei] = (i16)a;
                         p0[2 * ei + 1] = (i16)b;
                     }
@@ -310,14 +331,14 @@ OG_DEV void silk_decode_pulses(Rc &rc, int ch, int signalType, int quantOffsetTy
                 i32 abs_q = p[j];
                 for (int b = 0; b < nLS; b++) {
                     abs_q = shl32(abs_q, 1);
-                    abs_q += rc_icdf(rc, rom_silk_lsb_icdf, 8);
+                    abs_q += rc_icdf(rc, SILK_TAB(lsb_icdf), 8);
                 }
                 p[j] = (i16)abs_q;
             }
             L.sum_pulses[i] |= nLS << 5;
         }
     }
-    const u8 *icdf_ptr = &rom_silk_sign_icdf[7 * (quantOffsetType + (signalType << 1))];
+    const u8 *icdf_ptr = &SILK_TAB(sign_icdf)[7 * (quantOffsetType + (signalType << 1))];
     const int length = (frame_length + 8) >> 4;
     for (int i = 0; i < length; i++) {
         const int p = L.sum_pulses[i];
