@@ -723,7 +723,7 @@ struct opusgpu_ctx {
     unsigned shadow_epoch = 1; // advanced by everything else that may change a stream's SILK state: stale copies are ignored
     int silk_slot = 0, sdone_recorded[2] = {}, last_silk_mask = 0, last_kind = 0; // last_kind: 0 in order, 1 pipelined CELT-only, 2 pipelined SILK-only
     bool last_kind2_celt = false; // the last step of kind 2 held CELT-only frames too (enter_step_kind)
-    hipEvent_t ev_sparsed = nullptr, ev_sdone[2] = {}, ev_sp = nullptr, ev_spar = nullptr; // ev_sp: a step's SILK parse is done; ev_spar: its parameter half
+    hipEvent_t ev_sparsed = nullptr, ev_sdone[2] = {}, ev_sp = nullptr, ev_spar = nullptr, ev_hrecon = nullptr; // ev_sp: a step's SILK parse is done; ev_spar: its parameter half; ev_hrecon: its CELT reconstruction
     int split_celt = 1;   // OPUSGPU_SPLIT=0 forces the single-kernel path for every mode (A/B measurements)
     int split_hybrid = 1; // OPUSGPU_SPLIT_HYBRID=0 keeps SILK-only and hybrid frames entirely on the single-kernel path
     int fast_recon = 1;   // OPUSGPU_FAST_RECON=0: every CELT frame through the general reconstruction kernel (A/B measurements)
@@ -844,6 +844,7 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     if (ctx->ev_sparsed) (void)hipEventDestroy(ctx->ev_sparsed);
     if (ctx->ev_sp) (void)hipEventDestroy(ctx->ev_sp);
     if (ctx->ev_spar) (void)hipEventDestroy(ctx->ev_spar);
+    if (ctx->ev_hrecon) (void)hipEventDestroy(ctx->ev_hrecon);
     (void)hipFree(ctx->d_shadow);
     (void)hipHostFree(ctx->h_pcm);
     (void)hipHostFree(ctx->h_res);
@@ -1212,7 +1213,11 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
                                (int)PARSE_ALL, 1, (u32 *)nullptr);
     };
     // ... and the ARITHMETIC ones (one frame per wave), which also write the PCM and the result codes
-    auto back_half = [&](hipStream_t q, size_t f0, int cnt) {
+    // `rq` (pipelined SILK / hybrid steps): the stream the CELT reconstruction runs on, NEXT TO the SILK synthesis instead of behind
+    // it -- a hybrid frame's two halves share nothing until the de-emphasis adds them (the synthesis takes prev_mode from the record,
+    // SilkRec::prev_mode), and the reconstruction of step k touches nothing the de-emphasis of step k - 1 still reads (it appends to
+    // the history ring; k_celt_post reads at the position the reconstruction recorded, as in pipelined CELT-only steps)
+    auto back_half = [&](hipStream_t q, size_t f0, int cnt, hipStream_t rq = nullptr) {
         const FrameDesc *dd = (const FrameDesc *)d_descs + f0;
         i16 *pp = (i16 *)d_pcm + f0 * (size_t)pcm_stride;
         i32 *rr = (i32 *)d_result + f0;
@@ -1228,9 +1233,15 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
             others = true;
         }
         if (any_celt) {
-            if (ctx->fast_recon) og_launch_celt_recon_fb(q, dd, ctx->d_streams, recs + f0, rout + f0, cnt, ctx->n_streams, handoff ? 1 : 0, nullptr);
-            hipLaunchKernelGGL(k_celt_recon, dim3(ctx->fast_recon ? (cnt + 63) / 64 : cnt), dim3(64), 0, q, dd, ctx->d_streams,
+            hipStream_t const r = rq ? rq : q;
+            if (rq) (void)hipStreamWaitEvent(rq, ctx->ev_sparsed, 0); // (this step's CELT parse)
+            if (ctx->fast_recon) og_launch_celt_recon_fb(r, dd, ctx->d_streams, recs + f0, rout + f0, cnt, ctx->n_streams, handoff ? 1 : 0, nullptr);
+            hipLaunchKernelGGL(k_celt_recon, dim3(ctx->fast_recon ? (cnt + 63) / 64 : cnt), dim3(64), 0, r, dd, ctx->d_streams,
                                (const ParseRec *)(recs + f0), rout + f0, cnt, ctx->n_streams, handoff ? 1 : 0, ctx->fast_recon);
+            if (rq) {
+                (void)hipEventRecord(ctx->ev_hrecon, rq);
+                (void)hipStreamWaitEvent(q, ctx->ev_hrecon, 0);
+            }
         }
         if (any_celt || !others || modes != 7)
             hipLaunchKernelGGL(k_celt_post, dim3((cnt * ctx->channels + 63) / 64), dim3(64), 0, q, dd, ctx->d_streams, (const ParseRec *)(recs + f0),
@@ -1252,6 +1263,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
             HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_sparsed, hipEventDisableTiming));
             HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_sp, hipEventDisableTiming));
             HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_spar, hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_hrecon, hipEventDisableTiming));
             for (int i = 0; i < 2; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_sdone[i], hipEventDisableTiming));
         }
         if (ctx->sdone_recorded[sset]) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_sdone[sset], 0));
@@ -1269,7 +1281,9 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         HIPCHK(ctx, hipEventRecord(ctx->ev_sparsed, ctx->parse_stream));
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_sparsed, 0));
         if (og_debug().silk_params_aside) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_spar, 0));
-        back_half(s, 0, n);
+        // (for steps without CELT-only frames: hybrid-256k 9.50 -> 9.35 ms; with them -- a mixed step's reconstruction is three times
+        // the work -- next to the synthesis it loses: mixed pages 7.02 -> 7.22 ms)
+        back_half(s, 0, n, og_debug().hybrid_recon_aside && (modes & 6) == 2 ? ctx->recon_stream : nullptr);
         HIPCHK(ctx, hipEventRecord(ctx->ev_sdone[sset], s));
         ctx->sdone_recorded[sset] = 1;
         HIPCHK(ctx, hipGetLastError());

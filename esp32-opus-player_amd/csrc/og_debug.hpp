@@ -11,6 +11,7 @@
 //   OPUSGPU_HYBRID_PIPELINE   hybrid_pipeline  1        0: the same for steps declared hybrid (or SILK-only + hybrid)
 //   OPUSGPU_PARSE_WIDE        parse_wide       1        0: pipelined steps parse with 32 frames per wave like in-order steps (k_celt_parse instead of k_celt_parse64);
 //                                                       2: in-order steps use the wide kernels too, k_silk_parse64 included (counter passes: --pmc serialises kernels, so only in-order steps can be counted)
+//   OPUSGPU_HYBRID_RECON_ASIDE hybrid_recon_aside 1     0: pipelined steps with hybrid but no CELT-only frames reconstruct the CELT layer behind the SILK synthesis, on the step's stream, not next to it
 //   OPUSGPU_SILK_PARAMS_ASIDE silk_params_aside 1       0: pipelined SILK / hybrid steps keep the parameter half (k_silk_params) on the entropy chain's stream
 //   OPUSGPU_HALVES            halves           1        0: an in-order step with SILK-only / hybrid frames runs as ONE chain of kernels, not two
 //   OPUSGPU_PARSE_GROUPS      parse_groups     1        groups of frames per workgroup of the early parse, one after the other (1 .. 8)
@@ -25,7 +26,7 @@
 #include <stdlib.h>
 
 struct og_debug_knobs {
-    int split = 1, split_hybrid = 1, fast_recon = 1, silk_params_aside = 1, halves = 1, silk_pipeline = 1, hybrid_pipeline = 1, parse_wide = 1, parse_groups = 1, parse_priority = 1, host_parts = 16, host_slices = 1, host_timing = 0,
+    int split = 1, split_hybrid = 1, fast_recon = 1, hybrid_recon_aside = 1, silk_params_aside = 1, halves = 1, silk_pipeline = 1, hybrid_pipeline = 1, parse_wide = 1, parse_groups = 1, parse_priority = 1, host_parts = 16, host_slices = 1, host_timing = 0,
         pages_timing = 0, launch_delay_us = 0;
 };
 inline const og_debug_knobs &og_debug() {
@@ -43,6 +44,7 @@ inline const og_debug_knobs &og_debug() {
         flag("OPUSGPU_SPLIT", v.split);
         flag("OPUSGPU_SPLIT_HYBRID", v.split_hybrid);
         flag("OPUSGPU_FAST_RECON", v.fast_recon);
+        flag("OPUSGPU_HYBRID_RECON_ASIDE", v.hybrid_recon_aside);
         flag("OPUSGPU_SILK_PARAMS_ASIDE", v.silk_params_aside);
         flag("OPUSGPU_HALVES", v.halves);
         flag("OPUSGPU_SILK_PIPELINE", v.silk_pipeline);
