@@ -682,6 +682,9 @@ struct HostPool {
     }
 };
 
+#ifndef OG_SILK_SETS
+#define OG_SILK_SETS 3 // sets of SILK records and hand-offs that pipelined SILK / hybrid steps rotate through
+#endif
 struct opusgpu_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -712,18 +715,21 @@ struct opusgpu_ctx {
     // parse records of the split CELT path (one per frame of a step), grown on demand
     // (five sets: pipelined CELT-only steps rotate through 0 - 2 -- in-order steps use 0 --, pipelined SILK-only / hybrid steps
     // alternate 3 and 4: steps of the two kinds may be in flight together, OPUSGPU_STEP_KEEPS_MODE)
-    void *d_recs[5] = {}, *d_rout[5] = {};
-    size_t cap_recs[5] = {}, cap_rout[5] = {};
-    void *d_handoff[2] = {}, *d_srecs[2] = {}; // (two sets: pipelined SILK-only steps alternate; everything else uses set 0)
-    size_t cap_handoff[2] = {}, cap_srecs[2] = {};
+    void *d_recs[6] = {}, *d_rout[6] = {}; // (sets 0 - 2: pipelined CELT-only steps and everything in order; 3 - 5: pipelined SILK / hybrid steps)
+    size_t cap_recs[6] = {}, cap_rout[6] = {};
+    // (OG_SILK_SETS sets: pipelined SILK / hybrid steps rotate; everything else uses set 0.  Three since round 5: with two the parse
+    // of step k + 1 had to wait for the synthesis of step k - 1 to let go of its set, and the chain parse -> parameters of a small
+    // step -- 0.58 + 0.45 ms at 65,536 SILK-NB frames -- was then longer than the synthesis it should have hidden under)
+    void *d_handoff[OG_SILK_SETS] = {}, *d_srecs[OG_SILK_SETS] = {};
+    size_t cap_handoff[OG_SILK_SETS] = {}, cap_srecs[OG_SILK_SETS] = {};
     const void *last_srecs = nullptr; // the SILK records of the last step (opusgpu_debug_stage_taps)
     // Pipelined SILK-only steps (a step the caller declares SILK-only): the parse kernel keeps what its next run needs of the past
     // in d_shadow (SilkShadow per stream, og_silk_parse.hpp) and runs for step k + 1 on parse_stream next to step k's synthesis.
     void *d_shadow = nullptr;
     unsigned shadow_epoch = 1; // advanced by everything else that may change a stream's SILK state: stale copies are ignored
-    int silk_slot = 0, sdone_recorded[2] = {}, last_silk_mask = 0, last_kind = 0; // last_kind: 0 in order, 1 pipelined CELT-only, 2 pipelined SILK-only
+    int silk_slot = 0, sdone_recorded[OG_SILK_SETS] = {}, last_silk_mask = 0, last_kind = 0; // last_kind: 0 in order, 1 pipelined CELT-only, 2 pipelined SILK-only
     bool last_kind2_celt = false; // the last step of kind 2 held CELT-only frames too (enter_step_kind)
-    hipEvent_t ev_sparsed = nullptr, ev_sdone[2] = {}, ev_sp = nullptr, ev_spar = nullptr, ev_hrecon = nullptr; // ev_sp: a step's SILK parse is done; ev_spar: its parameter half; ev_hrecon: its CELT reconstruction
+    hipEvent_t ev_sparsed = nullptr, ev_sdone[OG_SILK_SETS] = {}, ev_sp = nullptr, ev_spar = nullptr, ev_hrecon = nullptr; // ev_sp: a step's SILK parse is done; ev_spar: its parameter half; ev_hrecon: its CELT reconstruction
     int split_celt = 1;   // OPUSGPU_SPLIT=0 forces the single-kernel path for every mode (A/B measurements)
     int split_hybrid = 1; // OPUSGPU_SPLIT_HYBRID=0 keeps SILK-only and hybrid frames entirely on the single-kernel path
     int fast_recon = 1;   // OPUSGPU_FAST_RECON=0: every CELT frame through the general reconstruction kernel (A/B measurements)
@@ -831,12 +837,12 @@ void opusgpu_ctx_destroy(opusgpu_ctx *ctx) {
     (void)hipFree(ctx->d_result);
     if (ctx->parse_stream) (void)hipStreamSynchronize(ctx->parse_stream);
     if (ctx->recon_stream) (void)hipStreamSynchronize(ctx->recon_stream);
-    for (int i = 0; i < 5; i++) {
+    for (int i = 0; i < 6; i++) {
         (void)hipFree(ctx->d_recs[i]);
         (void)hipFree(ctx->d_rout[i]);
         if (i < 3 && ctx->ev_post[i]) (void)hipEventDestroy(ctx->ev_post[i]);
     }
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < OG_SILK_SETS; i++) {
         (void)hipFree(ctx->d_handoff[i]);
         (void)hipFree(ctx->d_srecs[i]);
         if (ctx->ev_sdone[i]) (void)hipEventDestroy(ctx->ev_sdone[i]);
@@ -902,7 +908,7 @@ int opusgpu_set_pipeline(opusgpu_ctx *ctx, int on) {
     if ((on != 0) != (ctx->pipeline != 0)) { // switching: from an idle device (steps of either kind may be queued on any stream)
         HIPCHK(ctx, hipDeviceSynchronize());
         ctx->front_recorded = ctx->post_recorded[0] = ctx->post_recorded[1] = ctx->post_recorded[2] = 0;
-        ctx->sdone_recorded[0] = ctx->sdone_recorded[1] = 0;
+        for (int i = 0; i < OG_SILK_SETS; i++) ctx->sdone_recorded[i] = 0;
         ctx->last_kind = 0;
         ctx->shadow_epoch++;
     }
@@ -924,7 +930,7 @@ int opusgpu_streams_reset(opusgpu_ctx *ctx, int first, int count, int full) {
         if (ctx->last_step_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->last_step_stream));
     }
     ctx->front_recorded = ctx->post_recorded[0] = ctx->post_recorded[1] = ctx->post_recorded[2] = 0; // (the reset below is synchronous)
-    ctx->sdone_recorded[0] = ctx->sdone_recorded[1] = 0;
+    for (int i = 0; i < OG_SILK_SETS; i++) ctx->sdone_recorded[i] = 0;
     ctx->shadow_epoch++; // (the parse kernel's copies of these streams' past are stale now)
     hipLaunchKernelGGL(k_stream_init, dim3(count), dim3(64), 0, ctx->stream, ctx->d_streams, first, count, ctx->channels,
                        full ? 1 : 0);
@@ -1046,7 +1052,7 @@ static int enter_step_kind(opusgpu_ctx *ctx, int kind, hipStream_t s, bool keeps
         HIPCHK(ctx, hipStreamSynchronize(s));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         ctx->front_recorded = ctx->post_recorded[0] = ctx->post_recorded[1] = ctx->post_recorded[2] = 0;
-        ctx->sdone_recorded[0] = ctx->sdone_recorded[1] = 0;
+        for (int i = 0; i < OG_SILK_SETS; i++) ctx->sdone_recorded[i] = 0;
         ctx->last_silk_mask = 0;
     }
     if (kind != 2 && !(keeps_kind && kind == 1)) ctx->shadow_epoch++;
@@ -1154,7 +1160,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
     // The records, the reconstruction's per-frame output and the hand-off buffers only grow; growing frees the old one, which
     // waits for the device to go idle.  Records and reconstruction output exist twice: pipelined steps alternate.
     if (pipe) ctx->slot = (ctx->slot + 1) % 3;
-    if (pipe_silk) ctx->silk_slot ^= 1;
+    if (pipe_silk) ctx->silk_slot = (ctx->silk_slot + 1) % OG_SILK_SETS;
     const int sset = pipe_silk ? ctx->silk_slot : 0; // the set of SILK records and hand-offs this step uses (and of CELT records with them)
     const int par = pipe ? ctx->slot : pipe_silk ? 3 + sset : 0, par2 = (par + 1) % 3; // this step's slot; (pipelined CELT-only steps:) the slot of the step two before it
     if (int rc = grow_step_slot(ctx, par, (size_t)n)) return rc; // (a window's slots were sized before its first launch)
@@ -1264,15 +1270,16 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
             HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_sp, hipEventDisableTiming));
             HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_spar, hipEventDisableTiming));
             HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_hrecon, hipEventDisableTiming));
-            for (int i = 0; i < 2; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_sdone[i], hipEventDisableTiming));
+            for (int i = 0; i < OG_SILK_SETS; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_sdone[i], hipEventDisableTiming));
         }
         if (ctx->sdone_recorded[sset]) HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_sdone[sset], 0));
         // One thing of the step before is not entropy-side: a SILK-only frame right behind a hybrid one (Q4) decodes a 2.5 ms CELT
         // frame in the step's LAST kernel (the full kernel's second pass), which writes the band energies a hybrid frame's CELT parse
         // predicts from.  So a step that may hold hybrid frames does not run ahead of a step that may have held SILK-only ones.
         // (a stream that keeps its mode has no such frame: OPUSGPU_STEP_KEEPS_MODE)
-        if (!keeps_kind && (modes & 2) && (ctx->last_silk_mask & 1) && ctx->sdone_recorded[sset ^ 1])
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_sdone[sset ^ 1], 0));
+        const int prev_set = (sset + OG_SILK_SETS - 1) % OG_SILK_SETS; // (the step before this one)
+        if (!keeps_kind && (modes & 2) && (ctx->last_silk_mask & 1) && ctx->sdone_recorded[prev_set])
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->parse_stream, ctx->ev_sdone[prev_set], 0));
         ctx->last_silk_mask = modes;
         // (Tried: the step's frames in chunks, the CELT parse of chunk c on the reconstruction's idle stream next to the SILK parse of
         // chunk c + 1, so that the two entropy kernels do not run one after the other: hybrid-256k 12.7 -> 13.1 / 13.3 / 18.7 ms with
