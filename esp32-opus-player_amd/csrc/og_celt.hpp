@@ -556,8 +556,13 @@ OG_DEV void pcm_store(i16 *pcm, int n, int C, int CC) {
 // before the first store in program order, and the wave executes them in order.
 typedef i32 og_v2i __attribute__((ext_vector_type(2)));
 typedef i32 og_v4i __attribute__((ext_vector_type(4)));
-// 120 words behind denorm_gains' rows (og_state.hpp: 288 of the 832 bytes at V_MASK): g (Q15) | right shift << 16 | left shift << 24
-OG_DEV u32 *binpar_row() { return reinterpret_cast<u32 *>(S.dn_g_row() + 144); }
+// 120 words, g (Q15) | right shift << 16 | left shift << 24 per 5 ms bin -- INSIDE the synthesis buffer, in its last 120 words (the
+// overlap tail, SY[960 .. 1080)): the table is written (denorm_bins) when the buffer holds nothing -- before the first channel's
+// transform, and after the second-to-last channel's output has gone to the history ring -- and a transform has read every gain,
+// like every coefficient of a spectrum the buffer lies over, before it stores its first word (imdct_long_front; the short blocks'
+// pre-rotation held in registers, imdct_channel).  og_state.hpp: what that saves the kernel's LDS.
+OG_DEV u32 *binpar_row() { return reinterpret_cast<u32 *>(&S.v[V_SYN]) + 960; }
+static_assert(960 + 120 <= SYN_LEN, "the per-bin gains lie inside the synthesis buffer");
 // denormalise_bands' per-band gain (celt.cpp:948-1007) of coded channel c -- as denorm_gains left it: the band energies it read
 // lie inside the synthesis buffer and are gone once the first channel's transform has run -- laid out per 5 ms bin = per group
 // of 8 coefficients of a 20 ms frame; bins 100 .. 119 (coefficients the mode does not code) scale to zero
@@ -756,10 +761,15 @@ OG_DEVN void imdct_channel(const i32 *tail, int co, int N, int LM, int B, int sh
 #else
 #define OG_FREQ(j) freq_out(co, (j), N, LM, C, CC)
 #endif
-        // The buffer starts inside X, over the second channel's spectrum (og_state.hpp).  A channel that reads that spectrum
-        // has every coefficient read, and rotated, before the first word of the buffer is written: 480 rotations, 8 per lane,
-        // held in registers across the barrier.  The other channel (synthesised second) reads what the buffer does not touch.
+        // The buffer starts inside X, over the second channel's spectrum, and its last words hold the per-bin gains (og_state.hpp,
+        // binpar_row).  A channel that reads either has every coefficient read, and rotated, before the first word of the buffer
+        // is written: 480 rotations, 8 per lane, held in registers across the barrier.  (In host emulation the other channel,
+        // synthesised second, reads what the buffer does not touch -- the gains come from denorm_gains' rows there.)
+#if !defined(OG_HOST_EMUL)
+        const bool reads_buffer = bins || (C == 2 && (co == 1 || CC == 1));
+#else
         const bool reads_buffer = (C == 2 && (co == 1 || CC == 1));
+#endif
         if (!reads_buffer) {
             for (int b = 0; b < B; b++) // (a loop per block: splitting one index by N4 costs a software division per element)
             OG_FOR_LANES(i, N4) {

@@ -93,8 +93,8 @@ struct ParseRec {
     struct Leaf {
         u32 idx;  // PVQ codeword index
         u32 geom; // x | N << 11 | K << 19 | (B - 1) << 27   (x: offset into S.v[V_X..])
-        u32 aux;  // gain (product of the split gains above the leaf, Q15) | mask offset << 16 (4 bits) | where the leaf's
-                  // coefficients start in the frame's packed leaf output (sum of N before it) << 20
+        u32 aux;  // gain (product of the split gains above the leaf, Q15) | mask offset << 16 (4 bits) | the leaf's job << 20
+                  // (2 x band + decode slot: whose collapse mask the leaf's mask goes into, S.job_mask_row())
         u32 pad;
     } leaf[REC_MAX_LEAVES];
     u32 words[(REC_MAX_WORDS + 64) / 64 * 64]; // read in windows of 64 (REC_WORDS_CAP); a band's four header words start on a multiple of four
@@ -253,6 +253,7 @@ OG_DEV u32 pvq_u_rom(int a, int b) { // U(a,b) from the ROM table (lane-private 
 struct RecWriter {
     ParseRec *rec;
     int nw, nl, ncoef = 0;
+    int job = 0; // the job whose leaves are being written (2 x band + decode slot)
     OG_MEMBER void word(u32 w) {
         if (nw < REC_MAX_WORDS) rec->words[nw] = w;
         nw++;
@@ -264,7 +265,7 @@ struct RecWriter {
     OG_MEMBER void leaf(int x, int N, int K, int B, i32 gain, int off, u32 idx) {
         if (nl < REC_MAX_LEAVES) {
             const u32 geom = (u32)x | (u32)N << 11 | (u32)K << 19 | (u32)(B - 1) << 27;
-            const u32 aux = (u32)(gain & 0xffff) | (u32)off << 16 | (u32)ncoef << 20;
+            const u32 aux = (u32)(gain & 0xffff) | (u32)off << 16 | (u32)job << 20;
 #ifdef OG_HOST_EMUL
             rec->leaf[nl].idx = idx; rec->leaf[nl].geom = geom; rec->leaf[nl].aux = aux; rec->leaf[nl].pad = 0;
 #else
@@ -540,6 +541,7 @@ OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C
                     N_B >>= 1;
                     tfc++;
                 }
+                out.job = 2 * i + jb;
                 if (parse_tree(rc, out, i, remaining_bits, jx, N, jbits, Bj, LM, jgain, jlow, jsilent)) need_norm |= fold_bands;
             }
         }
@@ -821,20 +823,37 @@ OG_DEV void pvq_rotate_wave(i16 *xv, const RotJob &j, u8 *marker) {
 // dimension at a fixed number of pulses k, i.e. along rows k and k + 1: with rows, a probe is two independent reads off two
 // bases that change only when k does (a column base per probe made it two dependent round trips), a pulse's size candidates
 // (rows 4..7 at column n) need no base at all, and the two entries of a step with n <= k are neighbours in row n.
-struct PvqLds {
-    u32 rr[ROM_PVQ_RR_LEN];
-    u16 rb[16];
-};
 #ifdef OG_RECON_TIGHT
-static_assert(sizeof(PvqLds) <= (V_MASK - V_NORM) * 2, "the PVQ table overlays the band loop's tables and scratch rows");
+// (og_state.hpp: rows 4 - 8 behind X, rows 9 - 11 and 12 - 14 in the two 320-byte tops of the spectrum that no band reaches -- a row's
+// base is an offset from the table's first word, negative for those)
+constexpr int PVQ_MAIN_LEN = ROM_PVQ_RB9, PVQ_TOP0_OFF = (X_TOP0 - V_NORM) / 2, PVQ_TOP1_OFF = (X_TOP1 - V_NORM) / 2;
+static_assert((ROM_PVQ_RB12 - ROM_PVQ_RB9) * 2 <= 160 && (ROM_PVQ_RR_LEN - ROM_PVQ_RB12) * 2 + 32 <= 160, "the short rows (and the rotation marker) fit the tops");
+#else
+constexpr int PVQ_MAIN_LEN = ROM_PVQ_RR_LEN;
+#endif
+struct PvqLds {
+    u32 rr[PVQ_MAIN_LEN];
+    i16 rb[16];
+    OG_MEMBER u32 at(int i) const { return reinterpret_cast<const u32 *>(this)[i]; } // entry i of the table (row base + column)
+};
+OG_DEV int pvq_lds_index(int t) { // where entry t of rom_pvq_rr lies, as an index from the table's first word
+#ifdef OG_RECON_TIGHT
+    return t < ROM_PVQ_RB9 ? t : t < ROM_PVQ_RB12 ? t - ROM_PVQ_RB9 + PVQ_TOP0_OFF : t - ROM_PVQ_RB12 + PVQ_TOP1_OFF;
+#else
+    return t;
+#endif
+}
+#ifdef OG_RECON_TIGHT
+static_assert(sizeof(PvqLds) <= (V_JOBM - V_NORM) * 2, "the PVQ table's long rows end before the jobs' collapse masks");
 #else
 static_assert(sizeof(PvqLds) <= (V_TOTAL - V_NORM) * 2, "the PVQ table overlays the folding-history, pulse and scratch rows");
 #endif
 OG_DEV PvqLds &pvq_lds() { return *reinterpret_cast<PvqLds *>(&S.v[V_NORM]); }
 OG_DEV void pvq_tab_load() { // (the caller synchronises)
+    u32 *const dst = reinterpret_cast<u32 *>(&pvq_lds());
 #ifdef OG_HOST_EMUL
-    OG_FOR_LANES(t, ROM_PVQ_RR_LEN) pvq_lds().rr[t] = rom_pvq_rr[t];
-    OG_FOR_LANES(t, 16) pvq_lds().rb[t] = rom_pvq_rb[t];
+    OG_FOR_LANES(t, ROM_PVQ_RR_LEN) dst[pvq_lds_index(t)] = rom_pvq_rr[t];
+    OG_FOR_LANES(t, 16) pvq_lds().rb[t] = (i16)pvq_lds_index(rom_pvq_rb[t]);
 #else
     // every load requested before the first store waits for its data (a load - wait - store loop pays the L2's latency per pass)
     constexpr int NRR = (ROM_PVQ_RR_LEN + OG_NLANES - 1) / OG_NLANES;
@@ -844,8 +863,8 @@ OG_DEV void pvq_tab_load() { // (the caller synchronises)
     const u16 rb = rom_pvq_rb[OG_LANE & 15];
 #pragma unroll
     for (int k = 0; k < NRR; k++)
-        if (OG_LANE + k * OG_NLANES < ROM_PVQ_RR_LEN) pvq_lds().rr[OG_LANE + k * OG_NLANES] = rr[k];
-    if (OG_LANE < 16) pvq_lds().rb[OG_LANE] = rb;
+        if (OG_LANE + k * OG_NLANES < ROM_PVQ_RR_LEN) dst[pvq_lds_index(OG_LANE + k * OG_NLANES)] = rr[k];
+    if (OG_LANE < 16) pvq_lds().rb[OG_LANE] = (i16)pvq_lds_index((int)rb);
 #endif
 }
 // U(r, h) for a row r <= 3 (<= h), given U(2, h) and U(3, h); written without branches on purpose: the lanes of a wave
@@ -906,7 +925,7 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
         int bn = 0;         // (n <= k) where row n starts
         bool tab = false;   // (n <= k) row n is a table row (n == 3: closed form)
         if (sparse) {
-            const u32 c0 = T.rr[k >= 4 ? b0 + n : 0], c1 = T.rr[k >= 3 ? b1 + n : 0];
+            const u32 c0 = T.at(k >= 4 ? b0 + n : 0), c1 = T.at(k >= 3 ? b1 + n : 0);
             p0 = k >= 4 ? c0 : pvq_row_sel(k, v2, v3);
             p1 = k >= 3 ? c1 : pvq_row_sel(k + 1, v2, v3);
             // A sparse leaf (many dimensions, few pulses) is mostly runs of zeros, and the wave waits for its longest leaf: the run is
@@ -939,7 +958,7 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
                     int lo = lo0, hi = n;
                     while (lo < hi) {
                         const int mid = (lo + hi) >> 1;
-                        const u32 m0 = T.rr[k >= 4 ? b0 + mid : 0], m1 = T.rr[b1 + mid];
+                        const u32 m0 = T.at(k >= 4 ? b0 + mid : 0), m1 = T.at(b1 + mid);
                         const u32 a0 = k >= 4 ? m0 : pvq_u3((u32)mid); // (row 3 in closed form)
                         if (a0 + m1 >= m) {
                             hi = mid;
@@ -966,7 +985,7 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
             const u32 hk = (u32)k;
             bn = pvq_row_base(T, n);
             tab = n >= 4;
-            const u32 a0 = T.rr[tab ? bn + k : 0], a1 = T.rr[tab ? bn + k + 1 : 0];
+            const u32 a0 = T.at(tab ? bn + k : 0), a1 = T.at(tab ? bn + k + 1 : 0);
             p0 = tab ? a0 : pvq_u3(hk);
             p1 = tab ? a1 : pvq_u3(hk + 1u);
         }
@@ -982,7 +1001,7 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
                     // all candidates at once (rows 1..3 computed, rows 4..7 at fixed bases); U(., n) grows with the row: the last one
                     // that passes is k' (rows from k on are not looked at: a row ends where its entries leave 32 bits, and only
                     // U(k, n) and the entries below it are known to exist)
-                    const u32 c4 = T.rr[ROM_PVQ_RB4 + n], c5 = T.rr[ROM_PVQ_RB5 + n], c6 = T.rr[ROM_PVQ_RB6 + n], c7 = T.rr[ROM_PVQ_RB7 + n];
+                    const u32 c4 = T.at(ROM_PVQ_RB4 + n), c5 = T.at(ROM_PVQ_RB5 + n), c6 = T.at(ROM_PVQ_RB6 + n), c7 = T.at(ROM_PVQ_RB7 + n);
                     const u32 cand[7] = {1u, v2, v3, c4, c5, c6, c7};
 #pragma unroll
                     for (int r = 1; r <= 7; r++) {
@@ -994,7 +1013,7 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
                     int lo = 0, hi = k - 1;
                     while (lo < hi) {
                         const int mid = (lo + hi + 1) >> 1;
-                        const u32 tm = T.rr[mid >= 4 ? pvq_row_base(T, mid) + n : 0];
+                        const u32 tm = T.at(mid >= 4 ? pvq_row_base(T, mid) + n : 0);
                         const u32 pm = mid >= 4 ? tm : pvq_row_sel(mid, v2, v3);
                         if (pm <= i) {
                             lo = mid;
@@ -1008,7 +1027,7 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
                 int lo = 0, hi = k - 1;
                 while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1; // >= 1
-                    const u32 tm = T.rr[tab ? bn + mid : 0];
+                    const u32 tm = T.at(tab ? bn + mid : 0);
                     const u32 pm = tab ? tm : pvq_u3((u32)mid);
                     if (pm <= i) {
                         lo = mid;
@@ -1092,9 +1111,16 @@ OG_DEV u32 pvq_leaf_lane(i16 *xv, const PvqLds &T, int n, int k, u32 i, int pos,
     return cm;
 }
 
-// Collapse masks of the frame's PVQ leaves, in decode order (LDS: the packet staging area is unused on this path).
-OG_DEV u16 *leaf_masks() { return S.leaf_mask_row(); } // room for MAX_LEAF_MASKS (og_state.hpp)
-static_assert(MAX_LEAF_MASKS <= REC_MAX_LEAVES, "leaf mask row");
+// The collapse mask of a PVQ leaf goes, pre-shifted, into its JOB's word (S.job_mask_row(): 2 x band + decode slot; cleared by
+// recon_begin) -- a job's mask is the OR of its leaves' (cm(job) |= cm(leaf) << off, see parse_tree).  Round 5: a row of one mask
+// per LEAF (416 x u16) was a tenth of the reconstruction kernel's LDS; the lanes of a round's leaves OR into the row together.
+OG_DEV void job_mask_or(int job, u32 m) {
+#ifdef OG_HOST_EMUL
+    S.job_mask_row()[job] |= m;
+#else
+    __hip_atomic_fetch_or(&S.job_mask_row()[job], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
 
 // The record's word stream is consumed strictly in order: a 64-word window in LDS, refilled by one coalesced load.
 constexpr int REC_WORDS_CAP = (REC_MAX_WORDS + 64) / 64 * 64; // size of ParseRec::words
@@ -1236,17 +1262,12 @@ OG_DEV void anti_collapse_pm(const LcgTab &lcg, int LM, int C, int size, int sta
 }
 
 // The leaves of one job (quant_partition celt.cpp:1382 flattened by the parse kernel), vector half.  The leaves with
-// pulses are complete already (pvq_leaf_lane) and only contribute their collapse masks, stored pre-shifted by the leaf
-// pass: one wave-wide OR.  A leaf without pulses is zeroed, noise-filled or folded from the lower band
+// pulses are complete already (pvq_leaf_lane) and only contribute their collapse masks, which the leaf pass ORed, pre-shifted,
+// into the job's word of S.job_mask_row() (`job`: 2 x band + decode slot).  A leaf without pulses is zeroed, noise-filled or folded from the lower band
 // (celt.cpp:1481-1520).  `jw`: the job's header word.  Returns the job's collapse mask.
-OG_DEV u32 recon_job_leaves(RecCur &cur, const LcgTab &lcg, u32 jw, u32 &seed_io, int x_job, int low_job, i32 fill_job) {
-    const int n_fill = (int)(jw & 31), n_pvq = (int)(jw >> JW_NPVQ_SHIFT) & 31, first = (int)(jw >> JW_FIRST_SHIFT) & 1023;
-    u32 cm_job = 0;
-    if (n_pvq) {
-        u32 m = 0;
-        OG_FOR_LANES(l, n_pvq) m |= leaf_masks()[first + l];
-        cm_job = wave_or(m);
-    }
+OG_DEV u32 recon_job_leaves(RecCur &cur, const LcgTab &lcg, u32 jw, u32 &seed_io, int x_job, int low_job, i32 fill_job, int job) {
+    const int n_fill = (int)(jw & 31), n_pvq = (int)(jw >> JW_NPVQ_SHIFT) & 31;
+    u32 cm_job = n_pvq ? (u32)OG_UNI(S.job_mask_row()[job]) : 0u;
     for (int f = 0; f < n_fill; f++) {
         OG_MARK(7);
         const u32 w = rec_word(cur), w1 = rec_word(cur);
@@ -1312,7 +1333,7 @@ OG_DEV void hadamard_p2(int x, int N0, int log_stride, int hadamard, int dir) {
 
 // quant_band celt.cpp:1526, vector half; N > 1.  `scale`: sqrt(N) for the folding history (from the record).
 OG_DEV u32 recon_band_mono(RecCur &cur, u32 jw, const LcgTab &lcg, int tf_change, u32 &seed, int x, int N, int B, int low, int low_out,
-                           i32 scale, int low_scratch, i32 fill) {
+                           i32 scale, int low_scratch, i32 fill, int job) {
     const int N0 = N, longBlocks = B == 1;
     int logB = ilog2(B), time_divide = 0, recombine = 0;
     int N_B = N >> logB;
@@ -1349,7 +1370,7 @@ OG_DEV u32 recon_band_mono(RecCur &cur, u32 jw, const LcgTab &lcg, int tf_change
     const int logB0 = logB, N_B0 = N_B, B0 = 1 << logB0;
     if (B0 > 1 && low >= 0) hadamard_p2(low, N_B >> recombine, logB0 + recombine, longBlocks, 0);
     OG_MARK(6);
-    u32 cm = recon_job_leaves(cur, lcg, jw, seed, x, low, fill);
+    u32 cm = recon_job_leaves(cur, lcg, jw, seed, x, low, fill, job);
     OG_MARK(8);
     if (B0 > 1) hadamard_p2(x, N_B >> recombine, logB0 + recombine, longBlocks, 1);
     OG_STAT(7, B0 > 1);                             // jobs that undo a Hadamard interleave on x
@@ -1489,7 +1510,7 @@ OG_DEV void recon_all_bands(const u32 *words, u32 need_norm, const LcgTab &lcg, 
                 }
                 OG_MARK(5);
                 const u32 jw = rec_word(cur);
-                const u32 cmj = recon_band_mono(cur, jw, lcg, tf_change, seed, jx, N, B, jlow, jout, scale, jscr, jfill);
+                const u32 cmj = recon_band_mono(cur, jw, lcg, tf_change, seed, jx, N, B, jlow, jout, scale, jscr, jfill, 2 * i + jb);
                 if (jb == 0) cm0 = cmj; else cm1 = cmj;
             }
             OG_MARK(10);
@@ -1562,7 +1583,7 @@ struct PmLds { // overlays the folding-history rows S.v[V_NORM ..], which this p
 };
 #ifdef OG_RECON_TIGHT
 constexpr int V_PART = V_IY; // the stereo merges' partial sums take the two scratch rows (the fill jobs are done by then)
-static_assert(sizeof(PmLds) <= sizeof(i16) * (V_IY - V_NORM) && 800 <= sizeof(i16) * (V_MASK - V_IY), "the phase-major tables");
+static_assert(sizeof(PmLds) <= sizeof(i16) * (V_IY - V_NORM) && 800 <= sizeof(i16) * (V_WIN - V_IY), "the phase-major tables");
 #else
 constexpr int V_PART = V_NORM + 600;
 static_assert(sizeof(PmLds) <= sizeof(i16) * 600 && 600 + 400 <= 1248, "the phase-major tables overlay the folding-history rows");
@@ -1662,7 +1683,7 @@ OG_DEV u32 pm_setup_jobs(const ParseRec *rec, int C, int B, u32 &fill_lo, u32 &f
         const int jpos = (coded ? rec->band_w[band] : 0) + 4 + (jb ? 1 + 2 * (int)(jw0 & 31) : 0);
         u32 jw = jw0;
         if (jb && exists) jw = rec->words[OG_MIN(jpos, REC_WORDS_CAP - 1)];
-        const int n_fill = (int)(jw & 31), n_pvq = (int)(jw >> JW_NPVQ_SHIFT) & 31, first = (int)(jw >> JW_FIRST_SHIFT) & 1023;
+        const int n_fill = (int)(jw & 31), n_pvq = (int)(jw >> JW_NPVQ_SHIFT) & 31;
         P.jaux[l] = (u32)jpos | (u32)ch << 16 | (u32)exists << 17 | (u32)(exists && n_fill > 0) << 18 | (u32)(n_pvq > 0) << 19;
         if (exists) {
             // the job's time-frequency bookkeeping (quant_band celt.cpp:1548-1580), as in recon_band_mono
@@ -1692,8 +1713,7 @@ OG_DEV u32 pm_setup_jobs(const ParseRec *rec, int C, int B, u32 &fill_lo, u32 &f
                 }
                 // the collapse mask of a job whose leaves all carry pulses: the leaves' masks, then what the way back
                 // up does to a mask (celt.cpp:1596-1611)
-                u32 cm = 0;
-                for (int t = 0; t < n_pvq; t++) cm |= leaf_masks()[first + t];
+                u32 cm = n_pvq ? S.job_mask_row()[l] : 0u;
                 for (int k = 0; k < time_divide; k++) {
                     logB--;
                     cm |= cm >> (1 << logB);
@@ -1885,7 +1905,7 @@ OG_DEV void pm_fill_jobs(const u32 *words, const LcgTab &lcg, u32 fill_lo, u32 f
             pm_make_lowband(V_IY, (int)(w1 & 2047), N, i, dual && ch, dual_end, norm_offset, dup_n1, dup);
             low = V_IY;
         }
-        const u32 cm = recon_band_mono(cur, jw, lcg, tf_change, seed, V_X + 960 * ch + eb0, N, B, low, -1, 0, -1, jfill);
+        const u32 cm = recon_band_mono(cur, jw, lcg, tf_change, seed, V_X + 960 * ch + eb0, N, B, low, -1, 0, -1, jfill, l);
         if (OG_LANE == 0) P.jcm[2 * i + ch] = (u16)cm;
         OG_SYNC();
     }
@@ -2082,6 +2102,7 @@ struct ReconCtx {
     bool leaves; // the frame has a leaf pass and a synthesis (its record is not a BAD_CELT one)
     bool fast;
     bool was_reset = false; // the stream's CELT state was reset at this frame (mode change)
+    bool booked = false;    // recon_bookkeeping has run already (og_recon.hip: right behind recon_begin)
     // what recon_finish stages late, fetched early by the caller (per lane: entry `lane` of the record's band energies and
     // pulses, of the stream's two energy histories as they were BEFORE a reset), or not (pre == false: read there)
     bool pre = false;
@@ -2135,6 +2156,7 @@ OG_DEV bool recon_begin(StreamState *st, const ParseRec *rec, int mode, int ch, 
             S.tf_res[i] = rec->tf_res[i];
         }
 #endif
+        OG_FOR_LANES(i, 2 * NBANDS) S.job_mask_row()[i] = 0;
 #ifdef OG_HOST_EMUL
         OG_FOR_LANES(i, 2 * 960) S.v[V_X + i] = 0;
 #else
@@ -2168,9 +2190,9 @@ OG_DEV void recon_leaves_own(const ParseRec *rec, const ReconCtx &rx, bool pre =
         const u32 g = first ? g0 : rec->leaf[t].geom;
         const u32 aux = first ? aux0 : rec->leaf[t].aux;
         const u32 idx = first ? idx0 : rec->leaf[t].idx;
-        leaf_masks()[t] = (u16)(pvq_leaf_lane(S.v, pvq_lds(), (int)(g >> 11) & 255, (int)(g >> 19) & 255, idx, V_X + (int)(g & 2047),
-                                              (int)(g >> 27) + 1, (i32)(aux & 0xffff), spread)
-                                << ((aux >> 16) & 15));
+        job_mask_or((int)(aux >> 20) & 63, (pvq_leaf_lane(S.v, pvq_lds(), (int)(g >> 11) & 255, (int)(g >> 19) & 255, idx, V_X + (int)(g & 2047),
+                                                          (int)(g >> 27) + 1, (i32)(aux & 0xffff), spread)
+                                            << ((aux >> 16) & 15)) & 0xffffu);
     }
     OG_SYNC();
 #else
@@ -2186,9 +2208,9 @@ OG_DEV void recon_leaves_own(const ParseRec *rec, const ReconCtx &rx, bool pre =
             const u32 g = first ? g0 : rec->leaf[t].geom;
             const u32 aux = first ? aux0 : rec->leaf[t].aux;
             const u32 idx = first ? idx0 : rec->leaf[t].idx;
-            leaf_masks()[t] = (u16)(pvq_leaf_lane(S.v, pvq_lds(), (int)(g >> 11) & 255, (int)(g >> 19) & 255, idx, V_X + (int)(g & 2047),
-                                                  (int)(g >> 27) + 1, (i32)(aux & 0xffff), spread, &job)
-                                    << ((aux >> 16) & 15));
+            job_mask_or((int)(aux >> 20) & 63, (pvq_leaf_lane(S.v, pvq_lds(), (int)(g >> 11) & 255, (int)(g >> 19) & 255, idx, V_X + (int)(g & 2047),
+                                                              (int)(g >> 27) + 1, (i32)(aux & 0xffff), spread, &job)
+                                                << ((aux >> 16) & 15)) & 0xffffu);
         }
         OG_SYNC();
         OG_MARK(28);
@@ -2198,6 +2220,17 @@ OG_DEV void recon_leaves_own(const ParseRec *rec, const ReconCtx &rx, bool pre =
 #endif
 }
 
+// What the frame leaves in the stream's header words, and the frame's result code -- all known once recon_begin has run (nothing
+// in between reads these words).  The 20 ms kernel calls this THERE: carried to the end of the frame the three values were two
+// spilled registers at its 80.
+OG_DEV int recon_result(const ReconCtx &rx) { return (rx.leaves && (rx.flags & RF_TELL_OVERFLOW)) ? INTERNAL_ERROR : rx.ret; }
+OG_DEV void recon_bookkeeping(StreamState *st, const ReconCtx &rx) {
+    if (OG_LANE == 0) {
+        st->prev_mode = rx.mode_after >= 0 ? rx.mode_after : rx.mode;
+        st->frames_decoded = rx.h.frames_decoded + 1;
+        st->range_final = rx.rng_final;
+    }
+}
 OG_DEV int recon_finish(StreamState *st, const ParseRec *rec, const ReconCtx &rx) {
     const u32 flags = rx.flags;
     const int mode = rx.mode, C = rx.C, CC = rx.h.channels;
@@ -2265,11 +2298,7 @@ OG_DEV int recon_finish(StreamState *st, const ParseRec *rec, const ReconCtx &rx
         OG_MARK(17);
         if (flags & RF_TELL_OVERFLOW) result = INTERNAL_ERROR;
     }
-    if (OG_LANE == 0) {
-        st->prev_mode = rx.mode_after >= 0 ? rx.mode_after : mode;
-        st->frames_decoded = rx.h.frames_decoded + 1;
-        st->range_final = rx.rng_final;
-    }
+    if (!rx.booked) recon_bookkeeping(st, rx);
     return result; // de-emphasis and PCM: celt_post_lane (k_celt_post), from the history ring
 }
 

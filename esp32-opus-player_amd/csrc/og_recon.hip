@@ -1,11 +1,13 @@
-// og_recon.hip -- the reconstruction kernel of 20 ms CELT-only frames with an 8 KB LDS working set per frame (five waves per SIMD).
+// og_recon.hip -- the reconstruction kernel of 20 ms frames (CELT-only ones, and the CELT layer of hybrid ones) with a 6.2 KB LDS working
+// set per frame: five granules of LDS and 80 registers, six waves per SIMD.
 //
 // A translation unit of its own because the working set is ONE __shared__ object (FrameLds, og_state.hpp) whose layout
 // is chosen at compile time: here OG_RECON_TIGHT selects the layout without the folding-history rows, the packet buffer and
 // the entropy-decoding arrays, with the synthesis buffer starting inside X.  Only the phase-major band loop and the
 // synthesis run from this layout; frames it does not take (recon_fast_eligible, og_celt_split.hpp) are left to the general
 // kernel k_celt_recon in og_api.hip, which is launched right behind this one and skips the frames done here.
-// Why: measured on the 10 KB layout, k_celt_recon's time goes with 1 / (waves per SIMD) -- 2.69 ms at three, 2.09 ms at four.
+// Why: measured on the 10 KB layout, k_celt_recon's time goes with 1 / (waves per SIMD) -- 2.69 ms at three, 2.09 ms at four; and
+// in pipelined steps the kernel shares its CUs' LDS with the parse kernel's workgroups (og_state.hpp).
 //
 // One frame per workgroup of one wave, the frame's PVQ leaves one per lane.  (Round 3 measured the alternatives and they lost: the
 // leaves of two / four frames pooled in one workgroup and dealt out by cost, and a kernel of its own for the leaves: DESIGN.md 6c.)
@@ -16,7 +18,7 @@
 using namespace og;
 
 #ifndef OG_FAST_WAVES
-#define OG_FAST_WAVES 5
+#define OG_FAST_WAVES 6 // (80 registers; the working set is five LDS granules: og_state.hpp)
 #endif
 
 
@@ -70,6 +72,11 @@ __global__ void __launch_bounds__(64, OG_FAST_WAVES) k_celt_recon_fb(const Frame
         if (ok) {
             pos = rx.h.ring_pos; // where the frame's first sample goes
             mine = recon_begin(sp, rec, mode, desc_channels(d.flags), RECON_FAST_ONLY, rx);
+            if (mine) { // (the frame's result and what it leaves in the stream's header words: known here, see recon_bookkeeping)
+                if (OG_LANE == 0) rout[f] = ReconOut{recon_result(rx), pos};
+                recon_bookkeeping(sp, rx);
+                rx.booked = true;
+            }
         }
     }
     if (mine && rx.leaves) {
@@ -77,10 +84,7 @@ __global__ void __launch_bounds__(64, OG_FAST_WAVES) k_celt_recon_fb(const Frame
         OG_SYNC();
         recon_leaves_own(rec, rx, true, lg, la, li);
     }
-    if (mine) {
-        const int ret = recon_finish(sp, rec, rx);
-        if (OG_LANE == 0) rout[f] = ReconOut{ret, pos};
-    }
+    if (mine) recon_finish(sp, rec, rx);
     OG_PROF_FLUSH();
 }
 

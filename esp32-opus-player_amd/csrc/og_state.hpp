@@ -143,7 +143,7 @@ constexpr int SYN_LEN = 1088;  // 960 + 120 (+8 pad)
 // goes to a half of the (by then dead) X region as a plane of 960 samples.
 struct FrameLds {
     alignas(16) i16 v[V_TOTAL];
-    u8 pkt[1344];              // packet bytes (<= 1275); the split path keeps its per-leaf collapse masks here
+    u8 pkt[1344];              // packet bytes (<= 1275); the split path keeps its jobs' collapse masks here
 #ifndef OG_NO_SPLIT_LDS        // (og_rfc.hip: a translation unit that never instantiates the split path's reconstruction)
     u32 win[64];               // split path: window of the parse record's word stream
 #endif
@@ -158,7 +158,7 @@ struct FrameLds {
     OG_MEMBER i16 *logE2_row() { return logE2; }
     OG_MEMBER u8 *cmask_row() { return cmask; }
     OG_MEMBER i32 *pulses_row() { return pulses; }
-    OG_MEMBER u16 *leaf_mask_row() { return reinterpret_cast<u16 *>(&pkt[0]); }
+    OG_MEMBER u32 *job_mask_row() { return reinterpret_cast<u32 *>(&pkt[0]); } // 2 * NBANDS words
 #ifndef OG_NO_SPLIT_LDS
     OG_MEMBER u32 *word_window() { return win; }
     OG_MEMBER u8 *rot_marker() { return reinterpret_cast<u8 *>(win); } // (64 bytes of the leaf pass: the window is the band loop's)
@@ -170,38 +170,46 @@ struct FrameLds {
     OG_MEMBER i16 *dn_shift_row() { return dn_shift; }
     OG_MEMBER u8 *bin2band_row() { return bin2band; }
 };
-constexpr int MAX_LEAF_MASKS = 672;
 static_assert((V_TOTAL - V_NORM) * 2 + 1344 >= SYN_LEN * 4, "the synthesis buffer overlays norm | iy | tmp | pkt");
 #else
-// The working set of the reconstruction kernel of 20 ms CELT-only frames (og_recon.hip), cut to 7.5 KB so that FIVE waves
-// fit a SIMD: LDS is handed out in granules of 1280 bytes (measured with a residency census: 9968 B -> 16 workgroups per
-// CU, 8080 B -> 18, 6000 B -> 25), so 7680 B = 6 granules is the step that gives 21.  On the 10 KB layout above
-// k_celt_recon's time goes with 1 / (waves per SIMD): 2.69 ms at three, 2.09 ms at four.  What makes it fit:
+// The working set of the reconstruction kernel of 20 ms frames (og_recon.hip): 6,312 bytes = FIVE 1280-byte granules of LDS, so
+// that SIX waves fit a SIMD (its 80 registers allow as many) -- and, what counts in pipelined steps, thirteen instead of eleven
+// such workgroups fit a CU next to two of the parse kernel's.  LDS is handed out in granules of 1280 bytes (measured with a
+// residency census: 9968 B -> 16 workgroups per CU, 8080 B -> 18, 6000 B -> 25).  Measured by padding: the 10 KB layout above went
+// with 1 / (waves per SIMD) (2.69 ms at three, 2.09 at four); round 4's 7,552 bytes (six granules) padded by one granule cost the
+// CELT step 7 % (round 5).  What makes it fit:
 //   * the folding history is made on demand (phase-major band loop), so the bytes behind X hold, one after the other, the
 //     PVQ table (leaf pass), the band loop's tables + two 200-entry scratch rows, the synthesis buffer;
 //   * the synthesis buffer of a channel starts INSIDE X, over the second channel's spectrum: that channel is synthesised
 //     first, its spectrum read into registers before the buffer is written (og_celt.hpp), and the first channel's
 //     spectrum is still in place when its turn comes;
-//   * a 20 ms frame has at most 416 PVQ leaves (a band of N coefficients splits into at most min(16, N / 2) leaves);
+//   * the mode codes 800 of a channel's 960 coefficients (eband[21] = 100 bins of 8): the top 160 entries of each channel's
+//     spectrum are never written by a leaf or a band and only ever read with a gain of zero (the IMDCT's front), so they are
+//     320 bytes of storage each -- the PVQ table's short rows 9 - 14 and the leaf pass's rotation marker while the leaves are
+//     decoded, the synthesis' per-band gains (which must outlive the first channel's transform) afterwards;
+//   * the leaves' collapse masks are ORed into one word per JOB (168 bytes) instead of kept per leaf (832);
+//   * the synthesis' per-bin gain table (480 bytes) lies INSIDE the buffer, in its last 120 words: a channel's transform has
+//     read every gain (and every coefficient) before it stores its first word (og_celt.hpp);
 //   * arrays only the entropy-decoding half needs are gone (zero-length here: the code that names them is never run from
 //     this layout, see og_recon.hip).
 constexpr int V_X = 0;
-constexpr int V_NORM = 1920;            // the band loop's tables (PmLds) -- or the PVQ table during the leaf pass
+constexpr int X_TOP0 = 800;             // 160 entries no band reaches: first channel (see above)
+constexpr int X_TOP1 = 960 + 800;       // ... second channel
+constexpr int V_NORM = 1920;            // the band loop's tables (PmLds) -- or the PVQ table's rows 4 - 8 during the leaf pass
 constexpr int V_IY = V_NORM + 576;      // scratch row (folding source), 200 entries
 constexpr int V_TMP = V_IY + 200;       // scratch row (Hadamard), 200 entries
 // Once the stereo merges are done the two scratch rows hold the frame's small arrays: the bands' collapse masks, and --
 // staged from the record and the stream state only now -- pulses, band energies and the two energy histories, which
 // anti-collapse and the start of the synthesis read.  (The synthesis buffer later runs over them: they are dead by then.)
 constexpr int V_LATE = V_IY;
-constexpr int V_WIN = V_TMP + 200;      // window of the record's word stream (64 x u32; fill jobs), where the PVQ table's end was
-constexpr int V_MASK = V_NORM + 1408;   // per-leaf collapse masks (416 x u16: jobs with both kinds of leaves read them while they
-                                        // fill); later the synthesis gains
-constexpr int V_TOTAL = V_MASK + 416;
-constexpr int V_SYN = 960;              // the synthesis buffer: second channel's spectrum + 2432 bytes behind X
+constexpr int V_WIN = V_TMP + 200;      // window of the record's word stream (64 x u32; fill jobs)
+constexpr int V_JOBM = V_NORM + 1152;   // the jobs' collapse masks (2 * NBANDS x u32), from the leaf pass to the band loop: behind
+                                        // the PVQ table's rows 4 - 8 + row bases (1134 + 16 entries) and behind the window
+constexpr int V_TOTAL = V_JOBM + 4 * NBANDS;
+constexpr int V_SYN = 960;              // the synthesis buffer: second channel's spectrum + what lies behind X
 constexpr int SYN_LEN = 1088;
 struct FrameLds {
     alignas(16) i16 v[V_TOTAL];
-    u8 rot_marker_[64]; // the leaf pass's hand-out of rotation chains to lanes (pvq_rotate_wave)
     // (named by code that this layout never runs)
     u8 pkt[0];
     i32 fine_quant[0], fine_prio[0], tf_res[0], offsets[0], bits1[0], bits2[0];
@@ -210,20 +218,18 @@ struct FrameLds {
     OG_MEMBER i16 *bandE_row() { return &v[V_LATE + 24 + 2 * NBANDS]; }
     OG_MEMBER i16 *logE1_row() { return &v[V_LATE + 24 + 4 * NBANDS]; }
     OG_MEMBER i16 *logE2_row() { return &v[V_LATE + 24 + 6 * NBANDS]; }
-    OG_MEMBER u16 *leaf_mask_row() { return reinterpret_cast<u16 *>(&v[V_MASK]); }
+    OG_MEMBER u32 *job_mask_row() { return reinterpret_cast<u32 *>(&v[V_JOBM]); }
     OG_MEMBER u32 *word_window() { return reinterpret_cast<u32 *>(&v[V_WIN]); }
-    OG_MEMBER u8 *rot_marker() { return rot_marker_; }
-    OG_MEMBER i16 *dn_g_row() { return &v[V_MASK]; }                               // synthesis only
-    OG_MEMBER i16 *dn_shift_row() { return &v[V_MASK + 2 * NBANDS]; }
-    OG_MEMBER u8 *bin2band_row() { return reinterpret_cast<u8 *>(&v[V_MASK + 4 * NBANDS]); }
+    OG_MEMBER u8 *rot_marker() { return reinterpret_cast<u8 *>(&v[X_TOP1 + 104]); }  // 64 bytes behind the PVQ table's rows 12 - 14 (leaf pass)
+    OG_MEMBER i16 *dn_g_row() { return &v[X_TOP0]; }                                  // synthesis only: 2 * NBANDS each
+    OG_MEMBER i16 *dn_shift_row() { return &v[X_TOP0 + 2 * NBANDS]; }
+    OG_MEMBER u8 *bin2band_row() { return reinterpret_cast<u8 *>(&v[X_TOP0 + 4 * NBANDS]); } // 120 bytes
 };
-constexpr int MAX_LEAF_MASKS = 416;
-static_assert(V_SYN * 2 + SYN_LEN * 4 <= V_MASK * 2, "the synthesis buffer ends before the synthesis gains");
-static_assert((V_MASK + 4 * NBANDS) * 2 + 120 <= (V_MASK + 144) * 2 && (V_MASK + 144) * 2 + 480 <= V_TOTAL * 2,
-              "synthesis tables fit behind the buffer: the gains per band, bin -> band, then the long block's gains per bin (og_celt.hpp)");
-static_assert(V_LATE + 24 + 8 * NBANDS <= V_MASK && (V_LATE + 24) % 2 == 0, "the late-staged arrays fit the scratch rows");
-static_assert(V_MASK % 2 == 0 && V_NORM % 8 == 0 && V_IY % 8 == 0 && V_WIN % 2 == 0 && V_WIN + 128 <= V_MASK, "alignment of the overlays");
-static_assert(sizeof(FrameLds) <= 7680, "six 1280-byte LDS granules: 21 workgroups per CU");
+static_assert(V_SYN * 2 + SYN_LEN * 4 <= V_TOTAL * 2, "the synthesis buffer fits");
+static_assert(X_TOP0 + 4 * NBANDS + 60 <= 960, "the synthesis' per-band gains and the bin -> band table fit the first channel's unused top");
+static_assert(V_LATE + 24 + 8 * NBANDS <= V_WIN && (V_LATE + 24) % 2 == 0, "the late-staged arrays fit the scratch rows");
+static_assert(V_NORM % 8 == 0 && V_IY % 8 == 0 && V_WIN % 2 == 0 && V_WIN + 128 <= V_JOBM && V_JOBM % 2 == 0 && X_TOP1 % 8 == 0, "alignment of the overlays");
+static_assert(sizeof(FrameLds) <= 6400, "five 1280-byte LDS granules: 25 workgroups per CU");
 #endif
 
 } // namespace og

@@ -155,6 +155,7 @@ oc_decoder *oc_decoder_create(int channels);             /* fresh state == opus_
 void oc_decoder_destroy(oc_decoder *d);
 void oc_decoder_init(oc_decoder *d, int channels);       /* opus_decoder_init opus_decoder.cpp:82 */
 void oc_decoder_reset(oc_decoder *d);                    /* OPUS_RESET_STATE  opus_decoder.cpp:382 */
+u32 oc_decoder_final_range(const oc_decoder *d);          /* OPUS_GET_FINAL_RANGE opus_decoder.cpp:375-380 */
 /* RFC mode (PARITY UNPINNED -- the reference cannot do this and no libopus exists in the image): frames decode
  * at the duration their TOC names (CELT 2.5 / 5 / 10 / 20 ms, SILK 10 / 20 / 40 / 60 ms, hybrid 10 / 20 ms), multi-frame
  * packets accordingly; CELT's last band follows the bandwidth (13 / 17 / 19 / 21: Q1 fixed); a SILK-only frame after a hybrid

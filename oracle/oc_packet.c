@@ -177,6 +177,8 @@ void oc_decoder_reset(oc_decoder *d) { /* opus_decoder.cpp:382 */
     d->frame_size = 48000 / 400;
 }
 
+u32 oc_decoder_final_range(const oc_decoder *d) { return d->range_final; } /* st->rangeFinal, opus_decoder.cpp:375-380 */
+
 oc_decoder *oc_decoder_create(int channels) {
     oc_decoder *d = (oc_decoder *)calloc(1, sizeof(*d));
     if (!d) return NULL;

@@ -5,8 +5,9 @@
 //                     'N' i32 frame_size                  decode the last packet's bytes with len = -1 (both)
 //                     'R'                                 OPUS_RESET_STATE on both
 //                     'Q'                                 ctl queries + packet helpers of the last packet
+//                     'F'                                 OPUS_GET_FINAL_RANGE of both decoders
 //   output:  per 'D': i32 ret_single, i32 ret_ms, then min(ret, frame_size) * 2 int16 of the single-stream PCM if ret > 0
-//            per 'Q': 8 x i32
+//            per 'Q': 8 x i32;  per 'F': 2 x u32
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -58,6 +59,10 @@ int main(int argc, char **argv) {
             fwrite(&rb, 4, 1, out);
         } else if (cmd == 'R') {
             if (opus_decoder_ctl(st, OPUS_RESET_STATE) != OPUS_OK || opus_multistream_decoder_ctl(ms, OPUS_RESET_STATE) != OPUS_OK) return 1;
+        } else if (cmd == 'F') {
+            uint32_t v[2] = {0xdeadbeefu, 0xdeadbeefu};
+            if (opus_decoder_ctl(st, OPUS_GET_FINAL_RANGE_REQUEST, &v[0]) != OPUS_OK || opus_multistream_decoder_ctl(ms, OPUS_GET_FINAL_RANGE_REQUEST, &v[1]) != OPUS_OK) return 1;
+            fwrite(v, 4, 2, out);
         } else if (cmd == 'Q') {
             int32_t v[8] = {0};
             opus_decoder_ctl(st, OPUS_GET_SAMPLE_RATE_REQUEST, &v[0]);
