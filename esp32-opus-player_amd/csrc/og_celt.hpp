@@ -21,6 +21,9 @@ namespace og {
 struct WaveArr {
     typedef RomGlobal Rom;
     OG_MEMBER i32 &pulses(int i) const { return S.pulses_row()[i]; }
+    // (the bits-per-band array WHILE compute_allocation works on it, and where a provider puts it afterwards: the same array here)
+    OG_MEMBER i32 &alloc_bits(int i) const { return S.pulses_row()[i]; }
+    OG_MEMBER void pulses_rest(int, int) const {}
     OG_MEMBER i32 &fine_quant(int i) const { return S.fine_quant[i]; }
     OG_MEMBER i32 &fine_prio(int i) const { return S.fine_prio[i]; }
     OG_MEMBER i32 &tf_res(int i) const { return S.tf_res[i]; }
@@ -240,7 +243,7 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
             else
                 done = 1;
             tmp = OG_MIN(tmp, celt_band_cap<T>(j, LM, C));
-            a.pulses(j) = tmp;
+            a.alloc_bits(j) = tmp;
             psum += tmp;
         }
     }
@@ -256,20 +259,20 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
         left -= (T::eband(codedBands) - T::eband(start)) * percoeff;
         i32 rem = OG_MAX(left - (T::eband(j) - T::eband(start)), 0);
         i32 band_width = T::eband(codedBands) - T::eband(j);
-        i32 band_bits = a.pulses(j) + percoeff * band_width + rem;
+        i32 band_bits = a.alloc_bits(j) + percoeff * band_width + rem;
         if (band_bits >= OG_MAX(thresh_of(j), alloc_floor + (1 << BITRES))) {
             if (rc_bit_logp(rc, 1)) break;
             psum += 1 << BITRES;
             band_bits -= 1 << BITRES;
         }
-        psum -= a.pulses(j) + intensity_rsv;
+        psum -= a.alloc_bits(j) + intensity_rsv;
         if (intensity_rsv > 0) intensity_rsv = T::log2_frac(j - start);
         psum += intensity_rsv;
         if (band_bits >= alloc_floor) {
             psum += alloc_floor;
-            a.pulses(j) = alloc_floor;
+            a.alloc_bits(j) = alloc_floor;
         } else
-            a.pulses(j) = 0;
+            a.alloc_bits(j) = 0;
     }
     if (intensity_rsv > 0)
         intensity = start + (i32)rc_uint(rc, codedBands + 1 - start);
@@ -284,17 +287,17 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
     i32 left = total - psum;
     i32 percoeff = (i32)udiv((u32)left, (u32)(T::eband(codedBands) - T::eband(start)));
     left -= (T::eband(codedBands) - T::eband(start)) * percoeff;
-    for (int j = start; j < codedBands; j++) a.pulses(j) += percoeff * (T::eband(j + 1) - T::eband(j));
+    for (int j = start; j < codedBands; j++) a.alloc_bits(j) += percoeff * (T::eband(j + 1) - T::eband(j));
     for (int j = start; j < codedBands; j++) {
         i32 tmp = OG_MIN(left, (i32)(T::eband(j + 1) - T::eband(j)));
-        a.pulses(j) += tmp;
+        a.alloc_bits(j) += tmp;
         left -= tmp;
     }
     i32 balance = 0;
     int j;
     for (j = start; j < codedBands; j++) {
         i32 N0 = T::eband(j + 1) - T::eband(j), N = N0 << LM, excess;
-        i32 bit = a.pulses(j) + balance, bj, ej, fp;
+        i32 bit = a.alloc_bits(j) + balance, bj, ej, fp;
         if (N > 1) {
             excess = OG_MAX(bit - celt_band_cap<T>(j, LM, C), 0);
             bj = bit - excess;
@@ -326,15 +329,15 @@ OG_DEV int compute_allocation(A a, R &rc, int start, int end, int alloc_trim, i3
             excess -= extra_bits;
         }
         balance = excess;
-        a.pulses(j) = bj;
+        a.alloc_bits(j) = bj;
         a.fine_quant(j) = ej;
         a.fine_prio(j) = fp;
     }
     balance_out = balance;
     for (; j < end; j++) {
-        i32 ej = a.pulses(j) >> stereo >> BITRES;
+        i32 ej = a.alloc_bits(j) >> stereo >> BITRES;
         a.fine_quant(j) = ej;
-        a.pulses(j) = 0;
+        a.alloc_bits(j) = 0;
         a.fine_prio(j) = ej < 1;
     }
     return codedBands;
@@ -1125,6 +1128,7 @@ OG_DEV void celt_parse_header(A a, R &rc, int start, int end, int C, int LM, Cel
     i32 intensity = 0, dual_stereo = 0, balance = 0;
     OG_MARK(23);
     h.codedBands = compute_allocation(a, rc, start, end, alloc_trim, intensity, dual_stereo, bits, balance, C, LM);
+    a.pulses_rest(start, end); // (a provider whose allocation scratch holds the bits per band moves them out before the energies come back)
     OG_MARK(24);
     a.energies_back();
     fine_energy(a, rc, start, end, C);

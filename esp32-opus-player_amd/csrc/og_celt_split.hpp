@@ -98,12 +98,14 @@ struct ParseRec {
         u32 pad;
     } leaf[REC_MAX_LEAVES];
     u32 words[(REC_MAX_WORDS + 64) / 64 * 64]; // read in windows of 64 (REC_WORDS_CAP); a band's four header words start on a multiple of four
-    // (measured in round 4: the parse lane's bits-per-band work array here instead of in LDS -- 0.7 % faster, 2.9 KB more HBM
-    // traffic per frame; these words are unused)
+    // the parse lane's bits per band (32 bits: see ParseLds) from the end of its allocation on -- written once (LaneArr::pulses_rest,
+    // 16-byte stores: the pad below is written too), read once per band by the band walk.  (Round 4 measured the array here for the
+    // allocation's passes as well: 2.9 KB more HBM traffic per frame; those passes work in LDS, on the words of the two vectors.)
     i32 work_pulses[NBANDS];
     i32 work_pad[32 - NBANDS];
 };
-static_assert(offsetof(ParseRec, leaf) % 16 == 0 && offsetof(ParseRec, words) % 16 == 0, "16-byte stores into the record");
+static_assert(offsetof(ParseRec, leaf) % 16 == 0 && offsetof(ParseRec, words) % 16 == 0 && offsetof(ParseRec, work_pulses) % 16 == 0 &&
+              offsetof(ParseRec, work_pad) == offsetof(ParseRec, work_pulses) + 4 * NBANDS && NBANDS + 3 <= 32, "16-byte stores into the record");
 static_assert(sizeof(ParseRec) % 16 == 0, "record alignment");
 
 constexpr int FAST_MAX_LEAVES = 416; // (og_state.hpp: the most a 20 ms frame can have)
@@ -133,8 +135,6 @@ constexpr int FAST_MAX_LEAVES = 416; // (og_state.hpp: the most a 20 ms frame ca
 #endif
 #define OG_PL_FRAMES (OG_PL_LANES * OG_PL_WAVES) // frames per workgroup
 struct ParseLds { // [element][lane]: lanes of a wave touch consecutive addresses, no bank conflicts
-    i32 pulses[NBANDS][OG_PL_LANES]; // the bits-per-band work array (32 bits: a frame whose budget went negative carries wrapped values here, as the
-                                     // reference does).  -DOG_PARSE_PULSES_REC keeps it in the record instead, see ParseRec::work_pulses
     i8 fine_quant[NBANDS][OG_PL_LANES];
     i8 tf_prio[NBANDS][OG_PL_LANES]; // bits 0-3: tf_res (-3 .. 3, two's complement), bit 4: fine_prio
     // Three tenants, one after the other (next to the reconstruction the kernel's LDS is what keeps that kernel's waves out: 16.1 KB
@@ -145,7 +145,13 @@ struct ParseLds { // [element][lane]: lanes of a wave touch consecutive addresse
         i16 bandE[2 * NBANDS][OG_PL_LANES];
         struct { // from the dynalloc boosts until compute_allocation returns, i.e. before the first band is parsed
             i16 offsets[NBANDS][OG_PL_LANES]; // (the bands' caps are computed where they are used: celt_band_cap)
-            u16 bits1[NBANDS][OG_PL_LANES], bits2[NBANDS][OG_PL_LANES];
+            // One word per band: the two allocation vectors' entries (bits1 | bits2 << 16) while compute_allocation interpolates
+            // between them, then -- written over them band by band by the pass that settles the interpolation -- the band's bits
+            // (32 bits: a frame whose budget went negative carries wrapped values here, as the reference does).  When the allocation
+            // is done they move to the frame's record (LaneArr::pulses_rest), where the band walk reads one per band.  Round 5: the
+            // bits had an array of their own here, a third of the kernel's LDS -- which is what keeps the reconstruction's waves
+            // off the CUs the parse kernel runs on.
+            u32 bw[NBANDS][OG_PL_LANES];
         } al;
         i32 stack[5][6][OG_PL_LANES]; // split frames of the partition walk: [depth][word][lane]
     } u;
@@ -218,9 +224,9 @@ struct FinePrioView {
 };
 struct LaneArr {
     typedef RomLds Rom;
-    i32 *pl;   // the bits-per-band array: in the frame's record (ParseRec::work_pulses), 32 bits (a frame whose budget went negative
-               // carries wrapped values here, as the reference does)
+    i32 *pl;   // the bits-per-band array once compute_allocation is done: in the frame's record (ParseRec::work_pulses)
     i16 *rest; // where the band energies rest while the allocation scratch / the partition stack have their LDS: the record's bandE
+    i16 *pk;   // the record's 16-bit copy of the bits per band (ParseRec::pulses: what the reconstruction's anti-collapse reads)
     // (pairs of bands per 32-bit access; every load is requested before the first is used)
     OG_MEMBER void energies_rest() const {
         for (int i = 0; i < 2 * NBANDS; i += 2)
@@ -235,13 +241,28 @@ struct LaneArr {
             PL.u.bandE[2 * i + 1][OG_PCOL] = (i16)(w[i] >> 16);
         }
     }
-    OG_MEMBER i32 &pulses(int i) const { return PL.pulses[i][OG_PCOL]; }
+    typedef u16 __attribute__((may_alias)) u16a;
+    typedef i32 __attribute__((may_alias)) i32a;
+    OG_MEMBER i32 &pulses(int i) const { return pl[i]; }
+    OG_MEMBER i32a &alloc_bits(int i) const { return *reinterpret_cast<i32a *>(&PL.u.al.bw[i][OG_PCOL]); }
+    // the allocation is done: bands start .. end - 1 to the record (zero outside), four words per store
+    OG_MEMBER void pulses_rest(int start, int end) const {
+        i32 v[24];
+        for (int i = 0; i < 24; i++) v[i] = (i >= start && i < end) ? (i32)PL.u.al.bw[i < NBANDS ? i : 0][OG_PCOL] : 0;
+#ifdef OG_HOST_EMUL
+        for (int i = 0; i < NBANDS; i++) pl[i] = v[i];
+#else
+        typedef i32 i32x4 __attribute__((ext_vector_type(4)));
+        for (int i = 0; i < 24; i += 4) *reinterpret_cast<i32x4 *>(&pl[i]) = i32x4{v[i], v[i + 1], v[i + 2], v[i + 3]};
+#endif
+        for (int i = 0; i < NBANDS; i++) pk[i] = (i16)v[i];
+    }
     OG_MEMBER i8 &fine_quant(int i) const { return PL.fine_quant[i][OG_PCOL]; }
     OG_MEMBER FinePrioView fine_prio(int i) const { return FinePrioView{&PL.tf_prio[i][OG_PCOL]}; }
     OG_MEMBER TfResView tf_res(int i) const { return TfResView{&PL.tf_prio[i][OG_PCOL]}; }
     OG_MEMBER i16 &offsets(int i) const { return PL.u.al.offsets[i][OG_PCOL]; }
-    OG_MEMBER u16 &bits1(int i) const { return PL.u.al.bits1[i][OG_PCOL]; }
-    OG_MEMBER u16 &bits2(int i) const { return PL.u.al.bits2[i][OG_PCOL]; }
+    OG_MEMBER u16a &bits1(int i) const { return reinterpret_cast<u16a *>(&PL.u.al.bw[i][OG_PCOL])[0]; }
+    OG_MEMBER u16a &bits2(int i) const { return reinterpret_cast<u16a *>(&PL.u.al.bw[i][OG_PCOL])[1]; }
     OG_MEMBER i16 &bandE(int i) const { return PL.u.bandE[i][OG_PCOL]; }
 };
 
@@ -415,19 +436,21 @@ OG_DEV int parse_tree(RcLane &rc, RecWriter &out, int band, i32 &remaining_bits,
 // Returns the set of bands (bit i = band i) whose folding history some later band actually reads.
 OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C, int N_ch, int shortBlocks, int spread,
                            int dual_stereo, int intensity, i32 total_bits, i32 balance, int LM, int codedBands, int disable_inv) {
-    const LaneArr a{out.rec->work_pulses, nullptr}; // (pulses and tf_res only: the band energies rest in the record while the bands are parsed)
+    const LaneArr a{out.rec->work_pulses, nullptr, nullptr}; // (pulses and tf_res only: the band energies rest in the record while the bands are parsed)
     const int M = 1 << LM, B = shortBlocks ? M : 1;
     const int norm_offset = M * RomLds::eband(start);
     int lowband_offset = 0, update_lowband = 1;
     u32 need_norm = 0;
+    i32 pulses_next = a.pulses(start); // (from the record: the next band's is requested a band ahead)
     for (int i = start; i < end; i++) {
+        const i32 pulses_i = pulses_next;
+        pulses_next = a.pulses(i + 1 < end ? i + 1 : i);
         const int eb0 = M * RomLds::eband(i), N = M * RomLds::eband(i + 1) - eb0;
         const int x = eb0, y = C == 2 ? N_ch + eb0 : -1;
         out.rec->band_w[i] = (u16)OG_MIN(out.band_begin(), REC_MAX_WORDS);
         const i32 tell = (i32)rc_tell_frac(rc);
         if (i != start) balance -= tell;
         i32 remaining_bits = total_bits - tell - 1, b;
-        const i32 pulses_i = a.pulses(i);
         if (i <= codedBands - 1) {
             const i32 curr_balance = balance / OG_MIN(3, codedBands - i);
             b = OG_MAX(0, OG_MIN(16383, OG_MIN(remaining_bits + 1, pulses_i + curr_balance)));
@@ -558,7 +581,7 @@ OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C
 // stream state this half reads, so the parse of a stream's next frame depends on nothing but the parse of this one and may run
 // while this frame is still being reconstructed (opusgpu_set_pipeline, og_api.hip).
 OG_DEV void celt_parse_lane(StreamState *st, const u8 *payload, int len, int ch, ParseRec *rec, const SilkHandoff *handoff) {
-    const LaneArr a{rec->work_pulses, rec->bandE};
+    const LaneArr a{rec->work_pulses, rec->bandE, rec->pulses};
     const int CC = st->channels, C = ch, LM = 3, frame_size = 960, start = handoff ? 17 : 0, end = NBANDS;
     rec->start = start;
     rec->n_leaves = 0;
@@ -587,8 +610,8 @@ OG_DEV void celt_parse_lane(StreamState *st, const u8 *payload, int len, int ch,
     for (int i = 0; i < 2 * NBANDS; i++) a.bandE(i) = st->celt.bandE[i];
     if (C == 1)
         for (int i = 0; i < NBANDS; i++) a.bandE(i) = (i16)OG_MAX((i32)a.bandE(i), (i32)a.bandE(NBANDS + i));
-    for (int i = 0; i < NBANDS; i++) { // (the dynalloc offsets are cleared where the energies make room for them: energies_rest)
-        a.pulses(i) = 0;
+    for (int i = 0; i < NBANDS; i++) { // (the dynalloc offsets are cleared where the energies make room for them: energies_rest;
+                                       // the bits per band outside start .. end where they leave the allocation scratch: pulses_rest)
         a.fine_quant(i) = 0;
         a.fine_prio(i) = 0;
     }
@@ -601,11 +624,8 @@ OG_DEV void celt_parse_lane(StreamState *st, const u8 *payload, int len, int ch,
     out.nw = 0;
     out.nl = 0;
     const int M = 1 << LM, N = M * 120;
-    // tf_res and pulses are needed by the reconstruction (and pulses changes meaning nowhere after this point)
-    for (int i = 0; i < NBANDS; i++) {
-        rec->pulses[i] = (i16)a.pulses(i);
-        rec->tf_res[i] = a.tf_res(i);
-    }
+    // tf_res and pulses are needed by the reconstruction (pulses_rest wrote those; they change meaning nowhere after the header)
+    for (int i = 0; i < NBANDS; i++) rec->tf_res[i] = a.tf_res(i);
     OG_MARK(26);
     rec->need_norm = parse_all_bands(rc, out, start, end, C, N, h.transient ? M : 0, h.spread, h.dual_stereo, h.intensity,
                                      (i32)rc.storage * (8 << BITRES) - h.anti_collapse_rsv, h.balance, LM, h.codedBands, disable_inv);
