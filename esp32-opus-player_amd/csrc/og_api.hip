@@ -304,7 +304,9 @@ __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const Fra
 // SILK-only and hybrid frames on the split path, arithmetic half: one frame per wave, no CELT code (see decode_frame_wave).
 __global__ void __launch_bounds__(64, OG_SILK_WAVES) k_silk_synth(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
                                                                    StreamState *st, i16 *pcm, i32 *result, int n, int n_streams,
-                                                                   int pcm_stride, SilkHandoff *handoff, const SilkRec *srecs) {
+                                                                   int pcm_stride, SilkHandoff *handoff, const SilkRec *srecs, int nb_elsewhere) {
+    // `nb_elsewhere`: the step's narrowband SILK-only frames are k_silk_synth_nb's (og_silk_nb.hip: the same code with a working set
+    // sized for them), launched just before this kernel
     const int f = (int)blockIdx.x;
     if (f >= n) return;
     const FrameDesc d = descs[f];
@@ -312,7 +314,7 @@ __global__ void __launch_bounds__(64, OG_SILK_WAVES) k_silk_synth(const FrameDes
     u32 prefetched = 0;
     if (d.stream < 0 || d.stream >= n_streams) {
         ret = BAD_ARG;
-    } else if (desc_mode(d.flags) == MODE_CELT || desc_rfc(d.flags)) {
+    } else if (desc_mode(d.flags) == MODE_CELT || desc_rfc(d.flags) || (nb_elsewhere && desc_silk_nb_only(d.flags))) {
         return;
     } else {
 #ifdef OG_PROF_SSYNTH // profiling builds: time the sections of the SILK synthesis kernel
@@ -419,6 +421,9 @@ extern "C" int og_celt_parse64_frames(void); // frames per group of that kernel
 extern "C" void og_launch_celt_recon_fb(hipStream_t s, const void *descs, void *streams, const void *recs, void *rout, int n,
                                         int n_streams, int hybrid, unsigned *started);
 extern "C" int og_celt_recon_fb_signals(int n); // how often a launch over n frames bumps `started`
+// the SILK synthesis of narrowband SILK-only frames (og_silk_nb.hip)
+extern "C" void og_launch_silk_synth_nb(hipStream_t s, const void *descs, const void *arena, void *streams, void *pcm, void *result, int n,
+                                        int n_streams, int pcm_stride, void *handoff, const void *srecs);
 // RFC mode (opt-in): every frame of a step, at its true duration, incl. the loss path (og_rfc.hip)
 extern "C" void og_launch_decode_rfc(hipStream_t s, const void *descs, const void *arena, void *streams, void *pcm, void *result, int n,
                                      int n_streams, int pcm_stride);
@@ -1230,8 +1235,11 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         const SilkHandoff *hh = handoff ? handoff + f0 : nullptr;
         bool others = false; // (the kernels that report stream-index errors for every mode)
         if (srecs) { // SILK-only frames and the SILK half of hybrid frames
+            // (a step that may hold SILK-only frames: the narrowband ones in the kernel whose LDS is sized for them, og_silk_nb.hip)
+            const int nb = (modes & 1) && og_debug().silk_nb_kernel;
+            if (nb) og_launch_silk_synth_nb(q, dd, d_arena, ctx->d_streams, pp, rr, cnt, ctx->n_streams, pcm_stride, handoff + f0, srecs + f0);
             hipLaunchKernelGGL(k_silk_synth, dim3(cnt), dim3(64), 0, q, dd, (const u8 *)d_arena, ctx->d_streams, pp, rr, cnt, ctx->n_streams,
-                               pcm_stride, handoff + f0, (const SilkRec *)(srecs + f0));
+                               pcm_stride, handoff + f0, (const SilkRec *)(srecs + f0), nb);
             others = true;
         } else if (any_silk) { // every frame that is not CELT-only (OPUSGPU_SPLIT_HYBRID=0)
             hipLaunchKernelGGL(k_decode_step, dim3(cnt), dim3(64), 0, q, dd, (const u8 *)d_arena, ctx->d_streams, pp, rr, cnt, ctx->n_streams,

@@ -13,6 +13,7 @@
 //                                                       2: in-order steps use the wide kernels too, k_silk_parse64 included (counter passes: --pmc serialises kernels, so only in-order steps can be counted)
 //   OPUSGPU_HYBRID_RECON_ASIDE hybrid_recon_aside 1     0: pipelined steps with hybrid but no CELT-only frames reconstruct the CELT layer behind the SILK synthesis, on the step's stream, not next to it
 //   OPUSGPU_SILK_PARAMS_ASIDE silk_params_aside 1       0: pipelined SILK / hybrid steps keep the parameter half (k_silk_params) on the entropy chain's stream
+//   OPUSGPU_SILK_NB_KERNEL    silk_nb_kernel   1        0: narrowband SILK-only frames stay in k_silk_synth (no k_silk_synth_nb launch)
 //   OPUSGPU_HALVES            halves           1        0: an in-order step with SILK-only / hybrid frames runs as ONE chain of kernels, not two
 //   OPUSGPU_PARSE_GROUPS      parse_groups     1        groups of frames per workgroup of the early parse, one after the other (1 .. 8)
 //   OPUSGPU_PARSE_PRIORITY    parse_priority   1        0: the early parse's stream gets the LOWEST priority instead of the highest
@@ -26,7 +27,7 @@
 #include <stdlib.h>
 
 struct og_debug_knobs {
-    int split = 1, split_hybrid = 1, fast_recon = 1, hybrid_recon_aside = 1, silk_params_aside = 1, halves = 1, silk_pipeline = 1, hybrid_pipeline = 1, parse_wide = 1, parse_groups = 1, parse_priority = 1, host_parts = 16, host_slices = 1, host_timing = 0,
+    int split = 1, split_hybrid = 1, fast_recon = 1, hybrid_recon_aside = 1, silk_params_aside = 1, silk_nb_kernel = 1, halves = 1, silk_pipeline = 1, hybrid_pipeline = 1, parse_wide = 1, parse_groups = 1, parse_priority = 1, host_parts = 16, host_slices = 1, host_timing = 0,
         pages_timing = 0, launch_delay_us = 0;
 };
 inline const og_debug_knobs &og_debug() {
@@ -46,6 +47,7 @@ inline const og_debug_knobs &og_debug() {
         flag("OPUSGPU_FAST_RECON", v.fast_recon);
         flag("OPUSGPU_HYBRID_RECON_ASIDE", v.hybrid_recon_aside);
         flag("OPUSGPU_SILK_PARAMS_ASIDE", v.silk_params_aside);
+        flag("OPUSGPU_SILK_NB_KERNEL", v.silk_nb_kernel);
         flag("OPUSGPU_HALVES", v.halves);
         flag("OPUSGPU_SILK_PIPELINE", v.silk_pipeline);
         flag("OPUSGPU_HYBRID_PIPELINE", v.hybrid_pipeline);

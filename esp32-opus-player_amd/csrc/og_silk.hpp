@@ -23,6 +23,15 @@ namespace og {
 
 constexpr int SILK_MAX_LPC = 16;
 constexpr int SILK_MAX_FRAME = 320;
+// The longest frame the synthesis' LDS buffers hold.  og_silk_nb.hip builds the synthesis kernel of narrowband frames with 160:
+// 6.7 KB instead of 10.2 (six instead of eight LDS granules: five frames per SIMD instead of four -- the kernel waits on its frames'
+// serial chains, so frames in flight are what it is short of), and per-subframe loops of three instead of five samples per lane.
+#ifdef OG_SILK_LDS_FRAME
+constexpr int SILK_LDS_FRAME = OG_SILK_LDS_FRAME;
+#else
+constexpr int SILK_LDS_FRAME = SILK_MAX_FRAME;
+#endif
+static_assert(SILK_LDS_FRAME % 80 == 0 && SILK_LDS_FRAME <= SILK_MAX_FRAME, "20 ms at 8, 12 or 16 kHz");
 
 struct SilkCtrl { // silk_decoder_control_t (src/silk.h:747) + the frame's side information (:588)
     i32 pitchL[4], Gains_Q16[4];
@@ -35,28 +44,29 @@ struct SilkCtrl { // silk_decoder_control_t (src/silk.h:747) + the frame's side 
 };
 
 struct SilkLds {
-    i16 xq[2][SILK_MAX_FRAME + 8];      // [0..2) look-back slots, frame at +2 (samplesOut1_tmp, silk.cpp:1657)
+    i16 xq[2][SILK_LDS_FRAME + 8];      // [0..2) look-back slots, frame at +2 (samplesOut1_tmp, silk.cpp:1657)
     // Two phases share these bytes: the synthesis recurrence (LTP state, whitened history, staged outBuf) and, once
     // that is done, the resampler (48 kHz PCM of both channels, 2x up-sampled signals).  The up-sampler's staged
-    // 32-bit input lives in sLTP_Q15[ch][0..320), i.e. under `pcm`, and is dead before the FIR writes `pcm`.
+    // 32-bit input lives in sLTP_Q15[ch][0..frame), i.e. under `pcm`, and is dead before the FIR writes `pcm`.
     union {
         struct {
-            i32 sLTP_Q15[2][2 * SILK_MAX_FRAME];
-            i16 sLTP[2][SILK_MAX_FRAME];
-            i16 hist[2][SILK_MAX_FRAME + 160]; // outBuf staged from HBM (+ 2 subframes for the mid-frame re-whitening)
+            i32 sLTP_Q15[2][2 * SILK_LDS_FRAME];
+            i16 sLTP[2][SILK_LDS_FRAME];
+            i16 hist[2][SILK_LDS_FRAME + SILK_LDS_FRAME / 2]; // outBuf staged from HBM (+ 2 subframes for the mid-frame re-whitening)
         } core;
         struct {
             i16 pcm[1920];                          // SILK output at 48 kHz, interleaved over the packet's channels
-            i16 raw_tail[2 * SILK_MAX_FRAME];       // (the rest of sLTP_Q15: the up-sampler's 32-bit rows end here, see silk_up2_rows)
-            i16 up[2][8 + 2 * SILK_MAX_FRAME + 8];  // FIR history + 2x up-sampled frame
+            // (the rest of sLTP_Q15 where it is longer than `pcm`: the up-sampler's 32-bit rows end there, see silk_up2_rows)
+            i16 raw_tail[16 * SILK_LDS_FRAME > 3840 ? (16 * SILK_LDS_FRAME - 3840) / 2 : 0];
+            i16 up[2][8 + 2 * SILK_LDS_FRAME + 8];  // FIR history + 2x up-sampled frame
             i32 sink[4][2][4];                      // where the up-sampler's inner sections "store" (silk_up2_rows)
             u32 taps[48];                           // rom_silk_fir12_taps8 (a lane's phase is its own: a table read per output)
         } out;
     } u;
     SilkCtrl ctrl[2];
 };
-static_assert(sizeof(((SilkLds *)0)->u.out) <= sizeof(((SilkLds *)0)->u.core) && 2 * (1920 + 2 * SILK_MAX_FRAME) == 4 * 2 * 2 * SILK_MAX_FRAME,
-              "the resampler's buffers lie over the synthesis core's; `up` starts where sLTP_Q15 ends");
+static_assert(offsetof(SilkLds, u.out.up) - offsetof(SilkLds, u.out.pcm) >= sizeof(((SilkLds *)0)->u.core.sLTP_Q15),
+              "the resampler's 16-bit rows start behind the up-sampler's 32-bit rows (sLTP_Q15), which lie under `pcm` (and `raw_tail`)");
 // SILK's working set is its own LDS object: only the kernels that run SILK pay for it.
 OG_LDS SilkLds g_silk_lds;
 OG_DEV SilkLds &SL() { return g_silk_lds; }
@@ -654,7 +664,7 @@ struct SilkParLane {
     static OG_MEMBER A32 Atmp() { A32 r = {&g_silk_par.Atmp[0][OG_LANE]}; return r; }
 };
 static_assert(sizeof(SilkCtrl) == 4 * (SILK_REC_CTRL_WORDS + 1), "SilkRecCh mirrors SilkCtrl");
-static_assert(2 * SILK_MAX_FRAME * 4 * 2 >= 1920 * 2 && SILK_MAX_FRAME * 4 * 2 <= 1920 * 2 + 0 * 1, "up-sampler input staging sits under pcm");
+static_assert(SILK_LDS_FRAME * 4 * 2 <= 1920 * 2, "up-sampler input staging sits under pcm");
 
 // The parameter half of a SILK-only / hybrid frame on the split path: silk_decode_parameters for the coded channels, from the
 // indices the parse lane wrote to the record.  The inputs that live in the stream state (LastGainIndex, first_frame_after_reset,
@@ -954,7 +964,7 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
         //     lane again keeps the samples it owns; the output scaling happens after the loop, in parallel.
         OG_MARK(61);
         i32 *resb = reinterpret_cast<i32 *>(sLTP); // residuals of this subframe (the whitened history is dead by now)
-        enum { OWN = (SILK_MAX_FRAME / 4 + 15) / 16 };
+        enum { OWN = (SILK_LDS_FRAME / 4 + 15) / 16 };
         {
             // The dither seed: r <- a r + c, used for the sign, then r <- r + pulse: one affine map mod 2^32 per sample, and
             // affine maps compose exactly.  Lane j folds its own `per` consecutive samples into one map, an inclusive scan
@@ -1199,7 +1209,7 @@ OG_DEV void silk_up2_rows(SilkState *st, int channels, int inLen) {
         const i32 m2 = last ? -1 : 0;
         i32 S = c->rs_sIIR[3 * ph + sec], out = 0;
         const i32 *in32 = L.u.core.sLTP_Q15[ch];
-        i32 *const raw = L.u.core.sLTP_Q15[ch] + ph * SILK_MAX_FRAME; // the last section's outputs, sample t at [t]
+        i32 *const raw = L.u.core.sLTP_Q15[ch] + ph * SILK_LDS_FRAME; // the last section's outputs, sample t at [t]
         // Section `sec` handles input sample t = u - sec in step u.  The two steps that fill the pipeline and the two that drain it
         // run the general body (a section without a sample keeps its state); the inLen - 2 steps in between have every section
         // at work and carry no such bookkeeping.
@@ -1255,7 +1265,7 @@ OG_DEV void silk_up2_rows(SilkState *st, int channels, int inLen) {
     for (int n = 0; n < channels; n++) {
         const i32 *in32 = L.u.core.sLTP_Q15[n];
         i16 *up = &L.u.out.up[n][8];
-        OG_FOR_LANES(m, 2 * inLen) up[m] = (i16)sat16(rshift_round(in32[(m & 1) * SILK_MAX_FRAME + (m >> 1)], 10));
+        OG_FOR_LANES(m, 2 * inLen) up[m] = (i16)sat16(rshift_round(in32[(m & 1) * SILK_LDS_FRAME + (m >> 1)], 10));
     }
     OG_SYNC();
     if (row < channels) {
@@ -1603,7 +1613,7 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
             const i32 delta0 = rshift_round(smulbb(MS_pred_Q13[0] - pp0, denom_Q16), 16);
             const i32 delta1 = rshift_round(smulbb(MS_pred_Q13[1] - pp1, denom_Q16), 16);
             OG_SYNC();
-            i32 side_new[(SILK_MAX_FRAME + OG_NLANES - 1) / OG_NLANES]; // each lane holds its own results until every lane has read the old side signal
+            i32 side_new[(SILK_LDS_FRAME + OG_NLANES - 1) / OG_NLANES]; // each lane holds its own results until every lane has read the old side signal
             int cnt = 0;
             OG_FOR_LANES(n, frame_length) {
                 const i32 p0 = n < 8 * fs_kHz ? pp0 + (n + 1) * delta0 : MS_pred_Q13[0];

@@ -116,6 +116,8 @@ struct FrameDesc {
 OG_DEV int desc_mode(i32 f) { return MODE_SILK + (f & 3); }
 OG_DEV int desc_bandwidth(i32 f) { return BW_NB + ((f >> 2) & 7); }
 OG_DEV int desc_channels(i32 f) { return (f & 32) ? 2 : 1; }
+// a SILK-only frame at 8 kHz: the frames of k_silk_synth_nb (og_silk_nb.hip)
+OG_DEV bool desc_silk_nb_only(i32 f) { return (f & 3) == 0 && ((f >> 2) & 7) == 0; }
 // what the frame leaves as the stream's prev_mode: its mode -- or 0 for the mode-0 frame (bit 11: coded as hybrid, see above)
 OG_DEV int desc_mode_after(i32 f) { return ((f >> 11) & 1) && (f & 3) == 1 ? 0 : desc_mode(f); }
 // RFC mode (opt-in, opusgpu_set_mode): the frame decodes at the duration its TOC names; reference mode: always 960 (Q6)
