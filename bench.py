@@ -401,11 +401,11 @@ def kernels_of(name):
     split = os.environ.get("OPUSGPU_SPLIT", "1") != "0"
     split_silk = split and os.environ.get("OPUSGPU_SPLIT_HYBRID", "1") != "0"
     if name == "mixed_pages_2m":
-        return "k_silk_parse + k_silk_params + k_celt_parse + k_silk_synth + k_celt_recon + k_celt_post + k_decode_step (Q4 pass)"
+        return "k_silk_parse + k_silk_params + k_celt_parse + k_silk_synth (narrowband SILK-only frames: k_silk_synth_nb) + k_celt_recon + k_celt_post + k_decode_step (Q4 pass)"
     if name.startswith("celt"):
         return "k_celt_parse + k_celt_recon + k_celt_post" if split else "k_decode_step"
     if name.startswith("silk"):
-        return "k_silk_parse + k_silk_params + k_silk_synth" if split_silk else "k_decode_step"
+        return "k_silk_parse + k_silk_params + k_silk_synth_nb (narrowband; k_silk_synth otherwise)" if split_silk else "k_decode_step"
     return "k_silk_parse + k_silk_params + k_silk_synth + k_celt_parse + k_celt_recon + k_celt_post" if split_silk else "k_decode_step"
 
 

@@ -301,46 +301,12 @@ __global__ void __launch_bounds__(64, OG_WAVES_PER_SIMD) k_decode_step(const Fra
     }
 }
 
-// SILK-only and hybrid frames on the split path, arithmetic half: one frame per wave, no CELT code (see decode_frame_wave).
-__global__ void __launch_bounds__(64, OG_SILK_WAVES) k_silk_synth(const FrameDesc *__restrict__ descs, const u8 *__restrict__ arena,
-                                                                   StreamState *st, i16 *pcm, i32 *result, int n, int n_streams,
-                                                                   int pcm_stride, SilkHandoff *handoff, const SilkRec *srecs, int nb_elsewhere) {
-    // `nb_elsewhere`: the step's narrowband SILK-only frames are k_silk_synth_nb's (og_silk_nb.hip: the same code with a working set
-    // sized for them), launched just before this kernel
-    const int f = (int)blockIdx.x;
-    if (f >= n) return;
-    const FrameDesc d = descs[f];
-    int ret;
-    u32 prefetched = 0;
-    if (d.stream < 0 || d.stream >= n_streams) {
-        ret = BAD_ARG;
-    } else if (desc_mode(d.flags) == MODE_CELT || desc_rfc(d.flags) || (nb_elsewhere && desc_silk_nb_only(d.flags))) {
-        return;
-    } else {
-#ifdef OG_PROF_SSYNTH // profiling builds: time the sections of the SILK synthesis kernel
-        OG_PROF_INIT();
-#endif
-        // The frame's record (2 KB) and the stream's SILK state (1.7 KB) are read below in a dozen dependent steps, each behind a
-        // wave-level sync that keeps the compiler from asking early: every one of them paid a trip to HBM.  One load per lane --
-        // lane l touches the l-th 64 bytes of the state, lane 32 + l of the record -- brings all of it to the L2 now; its value is
-        // never used (the empty asm at the end keeps the register), the later reads find their lines on the way or there.
-        {
-            const int l = (int)threadIdx.x;
-            const char *p = l < 28 ? reinterpret_cast<const char *>(&st[d.stream].silk) + 64 * l
-                          : l < 32 ? reinterpret_cast<const char *>(&handoff[f]) + 16 * (l - 28)
-                                   : reinterpret_cast<const char *>(&srecs[f]) + 64 * (l - 32);
-            prefetched = *reinterpret_cast<const volatile u32 *>(p);
-        }
-        ret = decode_frame_wave<false>(&st[d.stream], arena + d.offset, d.len, desc_mode(d.flags), desc_bandwidth(d.flags),
-                                       desc_channels(d.flags), pcm + (size_t)f * pcm_stride, &handoff[f], &srecs[f]);
-#ifdef OG_PROF_SSYNTH
-        OG_PROF_FLUSH();
-#endif
-        asm volatile("" ::"v"(prefetched));
-        if (ret == CONTINUE_SPLIT || ret == CONTINUE_Q4) return;
-    }
-    if (threadIdx.x == 0) result[f] = ret;
-}
+// SILK-only and hybrid frames on the split path, arithmetic half: k_silk_synth (og_silk_synth.hip) and, for narrowband SILK-only
+// frames, k_silk_synth_nb (og_silk_nb.hip) -- translation units of their own: their LDS working set has a layout of its own
+extern "C" void og_launch_silk_synth(hipStream_t s, const void *descs, const void *arena, void *streams, void *pcm, void *result, int n,
+                                     int n_streams, int pcm_stride, void *handoff, const void *srecs, int nb_elsewhere);
+extern "C" void og_launch_silk_synth_nb(hipStream_t s, const void *descs, const void *arena, void *streams, void *pcm, void *result, int n,
+                                        int n_streams, int pcm_stride, void *handoff, const void *srecs, int nb_elsewhere);
 
 // SILK-only and hybrid frames, entropy half: ONE FRAME PER LANE (og_silk_parse.hpp).  Lane l < LANES of workgroup g decodes the side
 // information and pulses of frame LANES g + l into srecs[frame] and leaves the coder state in handoff[frame].  Twice, like the CELT
@@ -421,9 +387,6 @@ extern "C" int og_celt_parse64_frames(void); // frames per group of that kernel
 extern "C" void og_launch_celt_recon_fb(hipStream_t s, const void *descs, void *streams, const void *recs, void *rout, int n,
                                         int n_streams, int hybrid, unsigned *started);
 extern "C" int og_celt_recon_fb_signals(int n); // how often a launch over n frames bumps `started`
-// the SILK synthesis of narrowband SILK-only frames (og_silk_nb.hip)
-extern "C" void og_launch_silk_synth_nb(hipStream_t s, const void *descs, const void *arena, void *streams, void *pcm, void *result, int n,
-                                        int n_streams, int pcm_stride, void *handoff, const void *srecs);
 // RFC mode (opt-in): every frame of a step, at its true duration, incl. the loss path (og_rfc.hip)
 extern "C" void og_launch_decode_rfc(hipStream_t s, const void *descs, const void *arena, void *streams, void *pcm, void *result, int n,
                                      int n_streams, int pcm_stride);
@@ -1237,9 +1200,8 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         if (srecs) { // SILK-only frames and the SILK half of hybrid frames
             // (a step that may hold SILK-only frames: the narrowband ones in the kernel whose LDS is sized for them, og_silk_nb.hip)
             const int nb = (modes & 1) && og_debug().silk_nb_kernel;
-            if (nb) og_launch_silk_synth_nb(q, dd, d_arena, ctx->d_streams, pp, rr, cnt, ctx->n_streams, pcm_stride, handoff + f0, srecs + f0);
-            hipLaunchKernelGGL(k_silk_synth, dim3(cnt), dim3(64), 0, q, dd, (const u8 *)d_arena, ctx->d_streams, pp, rr, cnt, ctx->n_streams,
-                               pcm_stride, handoff + f0, (const SilkRec *)(srecs + f0), nb);
+            if (nb) og_launch_silk_synth_nb(q, dd, d_arena, ctx->d_streams, pp, rr, cnt, ctx->n_streams, pcm_stride, handoff + f0, srecs + f0, 1);
+            og_launch_silk_synth(q, dd, d_arena, ctx->d_streams, pp, rr, cnt, ctx->n_streams, pcm_stride, handoff + f0, srecs + f0, nb);
             others = true;
         } else if (any_silk) { // every frame that is not CELT-only (OPUSGPU_SPLIT_HYBRID=0)
             hipLaunchKernelGGL(k_decode_step, dim3(cnt), dim3(64), 0, q, dd, (const u8 *)d_arena, ctx->d_streams, pp, rr, cnt, ctx->n_streams,
@@ -1493,9 +1455,15 @@ int opusgpu_decode_steps_device(opusgpu_ctx *ctx, int n_steps, const int32_t *n,
 // profiling builds only: per-section wave-cycle totals of k_celt_recon (see OG_MARK), optionally cleared after the read
 extern "C" int og_recon_fb_prof(unsigned long long *out64, int reset);
 extern "C" int og_rfc_prof(unsigned long long *out64, int reset);
+extern "C" int og_ssynth_prof(unsigned long long *out64, int reset);
+extern "C" int og_ssynth_nb_prof(unsigned long long *out64, int reset);
 int opusgpu_debug_prof(unsigned long long *out64, int reset) {
     unsigned long long fb[64], rf[64];
     if (og_recon_fb_prof(fb, reset) != 0 || og_rfc_prof(rf, reset) != 0) return -1;
+    for (int i = 0; i < 64; i++) fb[i] += rf[i];
+    if (og_ssynth_prof(rf, reset) != 0) return -1;
+    for (int i = 0; i < 64; i++) fb[i] += rf[i];
+    if (og_ssynth_nb_prof(rf, reset) != 0) return -1;
     for (int i = 0; i < 64; i++) fb[i] += rf[i];
     if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
     for (int i = 0; i < 64; i++) out64[i] += fb[i];

@@ -45,7 +45,7 @@ struct PlcC {
 };
 constexpr size_t PLC_A_AT = offsetof(SilkLds, u) + sizeof(i16) * 1920; // behind u.out.pcm
 static_assert(offsetof(SilkLds, u) % 8 == 0 && PLC_A_AT % 8 == 0, "scratch alignment");
-#ifndef OG_SILK_LDS_FRAME // (og_silk_nb.hip sizes SilkLds for narrowband frames: no concealment runs from that layout)
+#if !defined(OG_SILK_LDS_FRAME) && !defined(OG_SILK_TIGHT) // (the synthesis kernels of the split path size SilkLds for themselves: no concealment runs from those layouts)
 static_assert(PLC_A_AT + sizeof(PlcA) <= sizeof(SilkLds), "piece A: behind the SILK PCM");
 static_assert(sizeof(PlcB) <= offsetof(SilkLds, u), "piece B: in front of the SILK PCM");
 #endif

@@ -43,6 +43,7 @@ struct SilkCtrl { // silk_decoder_control_t (src/silk.h:747) + the frame's side 
     i32 coded; // channel has a coded frame this step
 };
 
+#ifndef OG_SILK_TIGHT
 struct SilkLds {
     i16 xq[2][SILK_LDS_FRAME + 8];      // [0..2) look-back slots, frame at +2 (samplesOut1_tmp, silk.cpp:1657)
     // Two phases share these bytes: the synthesis recurrence (LTP state, whitened history, staged outBuf) and, once
@@ -67,9 +68,58 @@ struct SilkLds {
 };
 static_assert(offsetof(SilkLds, u.out.up) - offsetof(SilkLds, u.out.pcm) >= sizeof(((SilkLds *)0)->u.core.sLTP_Q15),
               "the resampler's 16-bit rows start behind the up-sampler's 32-bit rows (sLTP_Q15), which lie under `pcm` (and `raw_tail`)");
+#else
+// OG_SILK_TIGHT (og_silk_synth.hip, og_silk_nb.hip: the split path's synthesis kernels -- reference mode, one 20 ms frame from the parse
+// kernel's record, no loss path): the same working set in 8,936 instead of 10,184 bytes, SEVEN LDS granules instead of eight (the
+// narrowband kernel: 6,056 instead of 6,728, five instead of six).  The kernel waits on its frames' serial chains, LDS is what limits the
+// frames in flight, and a granule is worth 3 - 5 % of a step.  What is different:
+//   * ONE row per channel for the output history and the frame's output, the frame right behind the history (at [ltp_mem]): the
+//     mid-frame re-whitening reads the frame's first two subframes where they lie (the copy behind the history is gone), and the
+//     look-back slots of the stereo un-mixing are the history's last two entries, dead by then;
+//   * once the up-sampler has staged the frame as its 32-bit input, that row is the FIR's input row (`up`: 8 + 2 x frame + 8);
+//   * the re-whitening scales its outputs into the LTP state as it makes them (no whitened-history buffer; the subframe's
+//     residuals, which lay over it, have 320 bytes of their own per channel).
+// The arrays of length zero are named by code that never runs from this layout (the loss path, the one-lane forms).
+struct SilkLds {
+    i16 hx[2][2 * SILK_LDS_FRAME + 16];
+    union {
+        struct {
+            i32 sLTP_Q15[2][2 * SILK_LDS_FRAME];
+            i32 resb[2][SILK_LDS_FRAME / 4];
+            i16 sLTP[2][0], hist[2][0];
+        } core;
+        struct {
+            i16 pcm[1920];
+            i16 raw_tail[16 * SILK_LDS_FRAME > 3840 ? (16 * SILK_LDS_FRAME - 3840) / 2 : 0];
+            i32 sink[4][2][4];
+            u32 taps[48];
+            i16 up[2][0];
+        } out;
+    } u;
+    SilkCtrl ctrl[2];
+    i16 xq[2][0];
+};
+static_assert(offsetof(SilkLds, u.out.sink) - offsetof(SilkLds, u.out.pcm) >= sizeof(((SilkLds *)0)->u.core.sLTP_Q15),
+              "the up-sampler's sink and the FIR's taps lie behind its 32-bit rows (sLTP_Q15), which lie under `pcm` (and `raw_tail`)");
+static_assert(sizeof(SilkLds) <= (SILK_LDS_FRAME == 320 ? 8960 : 6400), "seven LDS granules (narrowband: five)");
+#endif
 // SILK's working set is its own LDS object: only the kernels that run SILK pay for it.
 OG_LDS SilkLds g_silk_lds;
 OG_DEV SilkLds &SL() { return g_silk_lds; }
+// A channel's rows by what they hold (the two layouts above place them differently).  `ltp_mem`: 20 ms at the frame's rate -- the
+// frame's length in the tight layout, which only sees 20 ms frames.
+//   silk_xq_row    the frame's output: [0..2) look-back slots of the stereo un-mixing, the frame at +2
+//   silk_hist_row  the last 20 ms of the channel's output (outBuf), staged for the re-whitening
+//   silk_up_row    the FIR interpolator's input: 8 samples of history, the 2x up-sampled frame
+#ifdef OG_SILK_TIGHT
+OG_DEV i16 *silk_xq_row(int ch, int ltp_mem) { return &SL().hx[ch][ltp_mem - 2]; }
+OG_DEV i16 *silk_hist_row(int ch) { return SL().hx[ch]; }
+OG_DEV i16 *silk_up_row(int ch) { return SL().hx[ch]; }
+#else
+OG_DEV i16 *silk_xq_row(int ch, int) { return SL().xq[ch]; }
+OG_DEV i16 *silk_hist_row(int ch) { return SL().u.core.hist[ch]; }
+OG_DEV i16 *silk_up_row(int ch) { return SL().u.out.up[ch]; }
+#endif
 // What only the wave-uniform ENTROPY half needs -- the pulse row it decodes into, the scratch of the pulse decoder and of
 // the NLSF -> LPC conversion -- is an object of its own: the synthesis kernel of the split path (silk_decode_20ms<true>:
 // everything from the parse kernel's record, pulses read where they lie in HBM) never names it, and its LDS footprint
@@ -890,7 +940,7 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
     if (row >= channels) return;
     const int ch = row;
     const int order = fs_kHz == 16 ? 16 : 10, subfr = 5 * fs_kHz, ltp_mem = 20 * fs_kHz, frame_length = nb_subfr * subfr;
-    i16 *xq = &L.xq[ch][2];
+    i16 *xq = silk_xq_row(ch, ltp_mem) + 2;
     if (!L.ctrl[ch].coded) {
         for (int i = j; i < frame_length; i += 16) xq[i] = 0;
         return;
@@ -902,7 +952,9 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
     const int lag_prev = LOSS ? c->lagPrev : 0;
     const i16 *pulses = ch ? pulses1 : pulses0;
     i32 *sLTP_Q15 = L.u.core.sLTP_Q15[ch];
+#ifndef OG_SILK_TIGHT
     i16 *sLTP = L.u.core.sLTP[ch];
+#endif
     const i32 offset_Q10 = rom_silk_quant_offsets_q10[(k.signalType >> 1) * 2 + k.quantOffsetType];
     const int interp_flag = k.NLSFInterpCoef_Q2 < 4, voiced_frame = k.signalType == 2;
     i32 sLPC = c->sLPC_Q14_buf[SILK_MAX_LPC - 1 - j]; // state sample (i-1-j)
@@ -933,7 +985,22 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
             lag = k.pitchL[sf];
             if (sf == 0 || (sf == 2 && interp_flag)) { // re-whitening: a FIR, one output per lane and step
                 const int start_idx = ltp_mem - lag - order - 2;
-                i16 *hist = L.u.core.hist[ch];
+                i16 *hist = silk_hist_row(ch);
+#ifdef OG_SILK_TIGHT
+                // (the frame's first two subframes lie right behind the history: hist[ltp_mem + i] IS xq[i].)  Of the filter's
+                // lag + order + 2 outputs the LTP state takes the last lag + 2, scaled: output ix (>= order) goes to
+                // sLTP_Q15[sLTP_buf_idx - (lag + order + 2) + ix] as it is made -- the same values the two passes over a buffer of
+                // whitened history left there (silk.cpp:1893-1905)
+                const i16 *in = &hist[start_idx + sf * subfr];
+                if (sf == 0) inv_gain_Q31 = shl32(smulwb(inv_gain_Q31, k.LTP_scale_Q14), 2);
+                i32 *const dst = sLTP_Q15 + (sLTP_buf_idx - (lag + order + 2));
+                for (int ix = order + j; ix < lag + order + 2; ix += 16) {
+                    i32 acc = 0;
+                    for (int t = 0; t < order; t++) acc = smlabb(acc, in[ix - 1 - t], A_Q12[t]);
+                    dst[ix] = smulwb(inv_gain_Q31, sat16(rshift_round(subw(shl32((i32)in[ix], 12), acc), 12)));
+                }
+                OG_ROW_SYNC();
+#else
                 if (sf == 2) {
                     for (int i = j; i < 2 * subfr; i += 16) hist[ltp_mem + i] = xq[i];
                     OG_ROW_SYNC();
@@ -949,6 +1016,7 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
                 OG_ROW_SYNC();
                 for (int i = j; i < lag + 2; i += 16) sLTP_Q15[sLTP_buf_idx - i - 1] = smulwb(inv_gain_Q31, sLTP[ltp_mem - i - 1]);
                 OG_ROW_SYNC();
+#endif
             } else if (gain_adj_Q16 != 1 << 16) {
                 for (int i = j; i < lag + 2; i += 16) sLTP_Q15[sLTP_buf_idx - i - 1] = smulww(gain_adj_Q16, sLTP_Q15[sLTP_buf_idx - i - 1]);
                 OG_ROW_SYNC();
@@ -963,7 +1031,11 @@ OG_DEV void silk_decode_core_rows(SilkState *st, int fs_kHz, int channels, const
         //     the saturating update stay on the dependent chain.  The row sum leaves the same value in every lane, so each
         //     lane again keeps the samples it owns; the output scaling happens after the loop, in parallel.
         OG_MARK(61);
+#ifdef OG_SILK_TIGHT
+        i32 *resb = L.u.core.resb[ch]; // residuals of this subframe
+#else
         i32 *resb = reinterpret_cast<i32 *>(sLTP); // residuals of this subframe (the whitened history is dead by now)
+#endif
         enum { OWN = (SILK_LDS_FRAME / 4 + 15) / 16 };
         {
             // The dither seed: r <- a r + c, used for the sign, then r <- r + pulse: one affine map mod 2^32 per sample, and
@@ -1191,13 +1263,15 @@ OG_DEV void silk_up2_rows(SilkState *st, int channels, int inLen) {
     const int row = OG_LANE >> 4, j = OG_LANE & 15;
     if (row < channels) {
         SilkChannel *c = &st->ch[row];
-        const i16 *in = &L.xq[row][1];
+        const i16 *in = silk_xq_row(row, inLen) + 1; // (the tight layout only sees 20 ms frames: inLen is its ltp_mem)
         const int delay = c->rs_inputDelay;
-        if (j < 8) L.u.out.up[row][j] = c->rs_sFIR[j];
+        if (j < 8) silk_up_row(row)[j] = c->rs_sFIR[j];
         // the input stream [delayBuf | in] as 32-bit Q10 values, staged once (the sLTP_Q15 row of this channel is free by now)
         i32 *in32 = L.u.core.sLTP_Q15[row];
         if (j < delay) in32[j] = shl32((i32)c->rs_delayBuf[j], 10); // (delay is 0, 4 or 7: rom_silk_delay_dec)
         for (int t = j; t < inLen - delay; t += 16) in32[delay + t] = shl32((i32)in[t], 10);
+        // (the next frame's delay line, taken now: in the tight layout the FIR's input rows are written over the frame below)
+        if (j < delay) c->rs_delayBuf[j] = in[inLen - delay + j];
     }
     OG_SYNC();
     const int ch = row & 1, ph = row >> 1;
@@ -1264,16 +1338,14 @@ OG_DEV void silk_up2_rows(SilkState *st, int channels, int inLen) {
     // the 32-bit outputs to the FIR's 16-bit input rows, phases interleaved (silk.cpp:3515: silk_SAT16(silk_RSHIFT_ROUND(out, 10)))
     for (int n = 0; n < channels; n++) {
         const i32 *in32 = L.u.core.sLTP_Q15[n];
-        i16 *up = &L.u.out.up[n][8];
+        i16 *up = silk_up_row(n) + 8;
         OG_FOR_LANES(m, 2 * inLen) up[m] = (i16)sat16(rshift_round(in32[(m & 1) * SILK_LDS_FRAME + (m >> 1)], 10));
     }
     OG_SYNC();
     if (row < channels) {
         SilkChannel *c = &st->ch[row];
-        const i16 *in = &L.xq[row][1], *up = L.u.out.up[row];
-        const int delay = c->rs_inputDelay;
+        const i16 *up = silk_up_row(row);
         if (j < 8) c->rs_sFIR[j] = up[2 * inLen + j];
-        if (j < delay) c->rs_delayBuf[j] = in[inLen - delay + j];
     }
 }
 #endif
@@ -1503,12 +1575,12 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
             pulse_row[1] = rec ? rec->ch[1].pulses : PW().pulses[1];
         }
         for (int n = 0; n < channels; n++)
-            if (L.ctrl[n].coded) OG_FOR_LANES(i, ltp_mem) L.u.core.hist[n][i] = s->ch[n].outBuf[i];
+            if (L.ctrl[n].coded) OG_FOR_LANES(i, ltp_mem) silk_hist_row(n)[i] = s->ch[n].outBuf[i];
         OG_SYNC();
         // one lane per channel: the decoded frame's synthesis, or a lost frame's concealment
         auto lane_synth = [&](int n) {
             if (!L.ctrl[n].coded) {
-                for (int i = 0; i < frame_length; i++) L.xq[n][2 + i] = 0;
+                for (int i = 0; i < frame_length; i++) silk_xq_row(n, ltp_mem)[2 + i] = 0;
                 return;
             }
             if constexpr (!REC_ONLY) {
@@ -1565,7 +1637,7 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
         for (int n = 0; n < channels; n++)
             if (L.ctrl[n].coded) {
                 const int keep = ltp_mem - frame_length;
-                OG_FOR_LANES(i, ltp_mem) s->ch[n].outBuf[i] = i < keep ? L.u.core.hist[n][frame_length + i] : L.xq[n][2 + i - keep];
+                OG_FOR_LANES(i, ltp_mem) s->ch[n].outBuf[i] = i < keep ? silk_hist_row(n)[frame_length + i] : silk_xq_row(n, ltp_mem)[2 + i - keep];
             }
         OG_SYNC();
         if constexpr (!REC_ONLY) {
@@ -1601,7 +1673,7 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
         }
         // ---- stereo un-mixing (silk_stereo_MS_to_LR silk.cpp:4028) or mono look-back buffering (:1705)
         if (channels == 2) {
-            i16 *x1 = L.xq[0], *x2 = L.xq[1];
+            i16 *x1 = silk_xq_row(0, ltp_mem), *x2 = silk_xq_row(1, ltp_mem);
             if (OG_LANE == 0) {
                 x1[0] = s->sMid[0]; x1[1] = s->sMid[1];
                 x2[0] = s->sSide[0]; x2[1] = s->sSide[1];
@@ -1637,7 +1709,7 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
             OG_SYNC();
         } else {
             if (OG_LANE == 0) {
-                i16 *x1 = L.xq[0];
+                i16 *x1 = silk_xq_row(0, ltp_mem);
                 x1[0] = s->sMid[0]; x1[1] = s->sMid[1];
                 s->sMid[0] = x1[frame_length]; s->sMid[1] = x1[frame_length + 1];
             }
@@ -1666,7 +1738,7 @@ OG_DEV int silk_decode_packet(SilkState *s, Rc &rc, int channels, int internal_h
                 OG_FOR_LANES(m, count) {
                     const i32 index_Q16 = m * inv;
                     const int t = smulwb(index_Q16 & 0xFFFF, 12);
-                    const i16 *b = &L.u.out.up[n][2 * t0 + (index_Q16 >> 16)];
+                    const i16 *b = silk_up_row(n) + 2 * t0 + (index_Q16 >> 16);
 #ifdef OG_HOST_EMUL
                     const i16 *f0 = &rom_silk_frac_fir12[4 * t], *f1 = &rom_silk_frac_fir12[4 * (11 - t)];
                     i32 res = smulbb(b[0], f0[0]);

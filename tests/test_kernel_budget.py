@@ -16,9 +16,9 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 # kernel -> most vector registers it may use (the next occupancy step would be lost above it), scratch bytes allowed
 BUDGET = {
-    "k_silk_synth": (96, 0),       # five waves per SIMD by registers (its 10 KB of LDS allow four)
+    "k_silk_synth": (80, 0),       # six waves per SIMD by registers (its seven granules of LDS allow 17 workgroups per CU)
     "k_celt_recon_fb": (80, 0),    # six waves per SIMD (launch bound), five granules of LDS (6.2 KB, round 5); no scratch (round 4: its noise generator's table had been there)
-    "k_silk_synth_nb": (96, 0),    # the synthesis of narrowband SILK-only frames: five waves per SIMD, six granules of LDS
+    "k_silk_synth_nb": (80, 0),    # the synthesis of narrowband SILK-only frames: 75 registers (its allocation is raised to five waves per SIMD on purpose), five granules of LDS
     "k_silk_parse": (84, 0),       # round 5, without the parameter half: 82 registers, no spills (round 4: 128 and a few spills), six waves per SIMD
     "k_silk_parse64": (84, 0),     # the same with 64 frames per wave (pipelined steps, large batches)
     "k_silk_params": (128, 0),     # one (frame, channel) per lane: 100 registers, four waves per SIMD
@@ -70,6 +70,6 @@ def test_kernels_keep_their_register_budgets():
     over = {k: seen[k] for k in BUDGET if seen[k][0] > BUDGET[k][0] or seen[k][1] > BUDGET[k][1]}
     assert not over, f"over budget (vgpr, scratch bytes, lds bytes): {over}; budgets {({k: BUDGET[k] for k in over})}"
     # LDS steps the occupancy figures in DESIGN.md rest on (granules of 1,280 bytes per workgroup)
-    assert seen["k_silk_synth"][2] <= 10240 and seen["k_silk_synth_nb"][2] <= 7680 and seen["k_celt_recon_fb"][2] <= 6400
+    assert seen["k_silk_synth"][2] <= 8960 and seen["k_silk_synth_nb"][2] <= 6400 and seen["k_celt_recon_fb"][2] <= 6400
     assert seen["k_silk_parse"][2] <= 8192 and seen["k_silk_params"][2] <= 12800  # (7.8 KB: the table blob and the pulse decoder's block rows, 64 columns)
     assert seen["k_celt_parse"][2] <= 11520  # the in-order parse kernel: nine granules (its 64-frame twin sizes its LDS at the launch)

@@ -4,5 +4,5 @@
 name=$1; shift
 cd "$(dirname "$0")/.." && mkdir -p build_ab
 C=esp32-opus-player_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $C/og_api.hip $C/og_recon.hip $C/og_parse64.hip $C/og_rfc.hip $C/og_silk_nb.hip $C/og_compat.cpp $C/og_pages.cpp -I include -pthread \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $C/og_api.hip $C/og_recon.hip $C/og_parse64.hip $C/og_rfc.hip $C/og_silk_nb.hip $C/og_silk_synth.hip $C/og_compat.cpp $C/og_pages.cpp -I include -pthread \
   $(cat $C/BUILD_FLAGS) "$@" -o build_ab/lib_$name.so

@@ -10,7 +10,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
-kernels = ["k_celt_parse", "k_celt_parse64", "k_celt_recon_fb", "k_celt_recon", "k_celt_post", "k_decode_step", "k_silk_parse", "k_silk_parse64", "k_silk_params", "k_silk_synth"]
+kernels = ["k_celt_parse", "k_celt_parse64", "k_celt_recon_fb", "k_celt_recon", "k_celt_post", "k_decode_step", "k_silk_parse", "k_silk_parse64", "k_silk_params", "k_silk_synth", "k_silk_synth_nb"]
 for f in sorted(glob.glob(root + "/trace/**/*kernel_stats.csv", recursive=True)):
     with open(f) as fh:
         for row in csv.DictReader(fh):
