@@ -468,6 +468,7 @@ __global__ void __launch_bounds__(64) k_celt_post(const FrameDesc *__restrict__ 
     // written behind it)
     __shared__ __attribute__((aligned(16))) i32 tin[64][CS + 4];  // CS samples per row, rows padded by 16 bytes
     __shared__ __attribute__((aligned(16))) i16 tout[64][CS + 8]; // CS outputs per row, rows padded by 16 bytes
+    // (16 KB per workgroup next to kernels that are short of LDS: measured by padding, 5 KB more cost the CELT step 0.8 %, mixed pages 0.6 %)
     const int lane = (int)threadIdx.x;
     const int t = (int)blockIdx.x * 64 + lane;
     const int f = channels == 2 ? t >> 1 : t, c = channels == 2 ? t & 1 : 0;

@@ -441,10 +441,28 @@ OG_DEV u32 parse_all_bands(RcLane &rc, RecWriter &out, int start, int end, int C
     const int norm_offset = M * RomLds::eband(start);
     int lowband_offset = 0, update_lowband = 1;
     u32 need_norm = 0;
-    i32 pulses_next = a.pulses(start); // (from the record: the next band's is requested a band ahead)
+    // the bands' bits from the record (LaneArr::pulses_rest), FOUR bands per 16-byte load, requested four bands ahead: one load per
+    // band went to HBM every time -- the record's line does not survive in the L2 from one band to the next (21 read requests and
+    // 2.7 KB of traffic per frame, round 5's counters)
+#ifdef OG_HOST_EMUL
+    i32 p4[4] = {0, 0, 0, 0}, n4[4] = {0, 0, 0, 0};
+    auto fetch4 = [&](int b, i32 *o) { for (int k = 0; k < 4; k++) o[k] = b + k < NBANDS ? a.pulses(b + k) : 0; };
+    fetch4(start & ~3, n4);
+#else
+    typedef i32 i32x4p __attribute__((ext_vector_type(4)));
+    i32x4p p4 = {0, 0, 0, 0}, n4 = *reinterpret_cast<const i32x4p *>(&a.pulses(start & ~3)); // (work_pulses is padded to 32 words)
+#endif
     for (int i = start; i < end; i++) {
-        const i32 pulses_i = pulses_next;
-        pulses_next = a.pulses(i + 1 < end ? i + 1 : i);
+        if (i == start || (i & 3) == 0) {
+#ifdef OG_HOST_EMUL
+            for (int k = 0; k < 4; k++) p4[k] = n4[k];
+            fetch4((i & ~3) + 4, n4);
+#else
+            p4 = n4;
+            n4 = *reinterpret_cast<const i32x4p *>(&a.pulses((i & ~3) + 4));
+#endif
+        }
+        const i32 pulses_i = (i & 3) == 0 ? p4[0] : (i & 3) == 1 ? p4[1] : (i & 3) == 2 ? p4[2] : p4[3];
         const int eb0 = M * RomLds::eband(i), N = M * RomLds::eband(i + 1) - eb0;
         const int x = eb0, y = C == 2 ? N_ch + eb0 : -1;
         out.rec->band_w[i] = (u16)OG_MIN(out.band_begin(), REC_MAX_WORDS);
