@@ -1261,7 +1261,7 @@ static int decode_step_impl(opusgpu_ctx *ctx, int n, const void *d_descs, const 
         if (og_debug().silk_params_aside) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_spar, 0));
         // (for steps without CELT-only frames: hybrid-256k 9.50 -> 9.35 ms; with them -- a mixed step's reconstruction is three times
         // the work -- next to the synthesis it loses: mixed pages 7.02 -> 7.22 ms)
-        back_half(s, 0, n, og_debug().hybrid_recon_aside && (modes & 6) == 2 ? ctx->recon_stream : nullptr);
+        back_half(s, 0, n, (og_debug().hybrid_recon_aside == 2 || (og_debug().hybrid_recon_aside && (modes & 6) == 2)) ? ctx->recon_stream : nullptr);
         HIPCHK(ctx, hipEventRecord(ctx->ev_sdone[sset], s));
         ctx->sdone_recorded[sset] = 1;
         HIPCHK(ctx, hipGetLastError());

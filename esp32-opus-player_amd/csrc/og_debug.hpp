@@ -11,7 +11,7 @@
 //   OPUSGPU_HYBRID_PIPELINE   hybrid_pipeline  1        0: the same for steps declared hybrid (or SILK-only + hybrid)
 //   OPUSGPU_PARSE_WIDE        parse_wide       1        0: pipelined steps parse with 32 frames per wave like in-order steps (k_celt_parse instead of k_celt_parse64);
 //                                                       2: in-order steps use the wide kernels too, k_silk_parse64 included (counter passes: --pmc serialises kernels, so only in-order steps can be counted)
-//   OPUSGPU_HYBRID_RECON_ASIDE hybrid_recon_aside 1     0: pipelined steps with hybrid but no CELT-only frames reconstruct the CELT layer behind the SILK synthesis, on the step's stream, not next to it
+//   OPUSGPU_HYBRID_RECON_ASIDE hybrid_recon_aside 1     0: pipelined steps with hybrid but no CELT-only frames reconstruct the CELT layer behind the SILK synthesis, on the step's stream, not next to it; 2: steps with CELT-only frames next to it too (measurements)
 //   OPUSGPU_SILK_PARAMS_ASIDE silk_params_aside 1       0: pipelined SILK / hybrid steps keep the parameter half (k_silk_params) on the entropy chain's stream
 //   OPUSGPU_SILK_NB_KERNEL    silk_nb_kernel   1        0: narrowband SILK-only frames stay in k_silk_synth (no k_silk_synth_nb launch)
 //   OPUSGPU_HALVES            halves           1        0: an in-order step with SILK-only / hybrid frames runs as ONE chain of kernels, not two
@@ -45,7 +45,7 @@ inline const og_debug_knobs &og_debug() {
         flag("OPUSGPU_SPLIT", v.split);
         flag("OPUSGPU_SPLIT_HYBRID", v.split_hybrid);
         flag("OPUSGPU_FAST_RECON", v.fast_recon);
-        flag("OPUSGPU_HYBRID_RECON_ASIDE", v.hybrid_recon_aside);
+        number("OPUSGPU_HYBRID_RECON_ASIDE", v.hybrid_recon_aside, 0, 2);
         flag("OPUSGPU_SILK_PARAMS_ASIDE", v.silk_params_aside);
         flag("OPUSGPU_SILK_NB_KERNEL", v.silk_nb_kernel);
         flag("OPUSGPU_HALVES", v.halves);
