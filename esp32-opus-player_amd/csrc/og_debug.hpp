@@ -14,7 +14,7 @@
 //   OPUSGPU_HYBRID_RECON_ASIDE hybrid_recon_aside 1     0: pipelined steps with hybrid but no CELT-only frames reconstruct the CELT layer behind the SILK synthesis, on the step's stream, not next to it; 2: steps with CELT-only frames next to it too (measurements)
 //   OPUSGPU_SILK_PARAMS_ASIDE silk_params_aside 1       0: pipelined SILK / hybrid steps keep the parameter half (k_silk_params) on the entropy chain's stream
 //   OPUSGPU_SILK_NB_KERNEL    silk_nb_kernel   1        0: narrowband SILK-only frames stay in k_silk_synth (no k_silk_synth_nb launch)
-//   OPUSGPU_HALVES            halves           1        0: an in-order step with SILK-only / hybrid frames runs as ONE chain of kernels, not two
+//   OPUSGPU_HALVES            halves           1        0: an in-order step runs as ONE chain of kernels, not two
 //   OPUSGPU_PARSE_GROUPS      parse_groups     1        groups of frames per workgroup of the early parse, one after the other (1 .. 8)
 //   OPUSGPU_PARSE_PRIORITY    parse_priority   1        0: the early parse's stream gets the LOWEST priority instead of the highest
 //   OPUSGPU_HOST_PARTS        host_parts       16       slices a large opusgpu_decode_packets call's PCM leaves in (1, 2, 4, 8, 16)
