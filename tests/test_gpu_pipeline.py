@@ -265,6 +265,18 @@ def test_placement_knobs_change_no_result(pkg, oracle):
         assert out.returncode == 0 and "knob worker ok" in out.stdout, (env, out.stdout[-400:], out.stderr[-400:])
 
 
+def test_narrowband_frames_in_either_synthesis_kernel():
+    """Narrowband SILK-only frames run in k_silk_synth_nb (og_silk_nb.hip) -- or, with OPUSGPU_SILK_NB_KERNEL=0, in k_silk_synth like
+    every other SILK frame: both against the oracle, each setting in a child process (tests/silk_nb_knob_worker.py)."""
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "silk_nb_knob_worker.py")
+    for env in ({"OPUSGPU_SILK_NB_KERNEL": "0"}, {"OPUSGPU_SILK_NB_KERNEL": "1"}):
+        out = subprocess.run([sys.executable, worker], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "silk nb knob worker ok" in out.stdout, (env, out.stdout[-400:], out.stderr[-600:])
+
+
 def test_windows_that_grow_on_a_fresh_context():
     """Buffer growth under queued windows (tests/window_growth_worker.py): every other test here shares a context whose record
     slots the full-size tests have already grown.  In a child process with a timeout, so that a host deadlock fails the test."""
