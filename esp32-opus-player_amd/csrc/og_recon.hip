@@ -25,7 +25,9 @@ using namespace og;
 // `hybrid`: the step's hybrid frames come through the split path too (their SILK half by k_silk_parse / k_silk_synth): this
 // kernel then also takes their CELT half
 // (measured, round 5: capping this kernel at five / four waves per SIMD -- room for the parse kernel's 168-register waves -- costs the
-// CELT step 6 % / 15 %, mixed pages 2 % / 9 %; the SILK synthesis of narrowband frames is the kernel such a cap pays for, og_silk_nb.hip)
+// CELT step 6 % / 15 %, mixed pages 2 % / 9 %; the SILK synthesis of narrowband frames is the kernel such a cap pays for, og_silk_nb.hip.
+// A twin of this kernel held to four waves per SIMD for the steps in which it runs next to the SILK synthesis: hybrid-256k 8.94 -> 8.89 ms,
+// inside the spread of the runs -- not kept)
 __global__ void __launch_bounds__(64, OG_FAST_WAVES) k_celt_recon_fb(const FrameDesc *__restrict__ descs, StreamState *st,
                                                                            const ParseRec *recs, ReconOut *rout, int n, int n_streams,
                                                                            int hybrid, u32 *started) {

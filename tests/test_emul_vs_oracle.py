@@ -111,3 +111,34 @@ def test_entropy_half_past_kept_by_the_parse_matches_the_state(emu, oracle, seed
                 ncmp = 960 * pch if (m == 1000 and pch < channels) else 960 * channels
                 assert np.array_equal(out.reshape(-1)[:ncmp], ref[:960].reshape(-1)[:ncmp]), (stream, f, hex(toc))
     assert shadowed > 300
+
+
+def test_silk_working_set_sized_for_narrowband(oracle):
+    """og_silk_nb.hip builds the SILK synthesis with OG_SILK_LDS_FRAME = 160 (buffers for 20 ms at 8 kHz).  The same sizing in host
+    emulation, array bounds trapped (-fsanitize=bounds): narrowband SILK-only streams, mono and stereo, against the oracle.
+    (The GPU kernel's tight LAYOUT of those buffers is GPU-only code: tests/test_gpu_pipeline.py, test_gpu_modes.py.)"""
+    lib_path = os.path.join(os.path.dirname(EMUL), "libog_emul_nb.so")
+    subprocess.check_call(["make", "-C", os.path.dirname(EMUL), "-s", "libog_emul_nb.so"])
+    lib = C.CDLL(lib_path)
+    lib.emu_state_size.restype = C.c_int
+    lib.emu_stream_init.argtypes = [C.c_void_p, C.c_int]
+    lib.emu_decode_frame.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(160)
+    out = np.zeros((960, 2), dtype=np.int16)
+    for s in range(60):
+        channels = int(rng.integers(1, 3))
+        d = oracle.decoder(channels)
+        d.init()
+        st = C.create_string_buffer(lib.emu_state_size())
+        lib.emu_stream_init(st, channels)
+        for f in range(8):
+            stereo = (channels == 2) if rng.random() < 0.8 else bool(rng.integers(2))
+            toc = (1 << 3) | (4 if stereo else 0)  # SILK-only NB 20 ms
+            L = int(rng.choice([0, 1, 2, 7, 20, 40, 80, 160, 400]))
+            body = rng.integers(0, 256, L, dtype=np.uint8).tobytes()
+            ref, r = d.decode(bytes([toc]) + body)
+            out[:] = 0
+            r2 = lib.emu_decode_frame(st, body, L, 1000, 1101, 2 if stereo else 1, out.ctypes.data)
+            assert r == r2 == 960, (s, f, r, r2)
+            k = 960 * channels if (stereo or channels == 1) else 960  # (a mono packet in a stereo decoder defines 960 entries, Q3)
+            assert np.array_equal(ref.reshape(-1)[:k], out.reshape(-1)[:k]), (s, f)
