@@ -23,7 +23,7 @@ EXPORTS = [
     "opusgpu_stream_state_bytes", "opusgpu_debug_stage_taps", "opusgpu_decode_packets", "opusgpu_decode_packets_fec", "opusgpu_packet_to_frames",
     "opusgpu_dev_alloc", "opusgpu_dev_free", "opusgpu_memcpy_h2d", "opusgpu_memcpy_d2h",
     "opusgpu_decode_step_device", "opusgpu_decode_step_device_modes", "opusgpu_decode_steps_device", "opusgpu_synchronize", "opusgpu_event_create", "opusgpu_event_record",
-    "opusgpu_event_elapsed_ms", "opusgpu_event_destroy", "opusgpu_event_synchronize", "opusgpu_stream_state_get",
+    "opusgpu_event_elapsed_ms", "opusgpu_event_destroy", "opusgpu_event_synchronize", "opusgpu_stream_state_get", "opusgpu_stream_pitch_get",
     "opusgpu_upload_async", "opusgpu_upload_fence", "opusgpu_stream_wait_event", "opusgpu_host_register", "opusgpu_host_unregister",
     "opusgpu_pages_demux", "opusgpu_pages_demux_into", "opusgpu_page_batch_arena_offset", "opusgpu_page_batch_steps", "opusgpu_page_batch_step", "opusgpu_page_batch_arena",
     "opusgpu_page_batch_free", "opusgpu_pages_crc_device", "opusgpu_output_stage_device",
@@ -133,6 +133,7 @@ def load_lib():
     lib.opusgpu_host_register.argtypes = [vp, vp, C.c_size_t]
     lib.opusgpu_host_unregister.argtypes = [vp, vp]
     lib.opusgpu_stream_state_get.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.opusgpu_stream_pitch_get.argtypes = [vp, C.c_int, vp]
     lib.opusgpu_debug_stage_taps.argtypes = [vp, C.c_int, vp]
     lib.opusgpu_pages_demux.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     lib.opusgpu_pages_demux_into.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(vp)]

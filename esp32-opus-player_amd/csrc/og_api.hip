@@ -1633,6 +1633,21 @@ int opusgpu_stream_state_get(opusgpu_ctx *ctx, int index, void *dst, size_t byte
     return opusgpu_memcpy_d2h(ctx, dst, &ctx->d_streams[index], bytes);
 }
 
+int opusgpu_stream_pitch_get(opusgpu_ctx *ctx, int index, int32_t out[4]) {
+    if (!ctx || !out || index < 0 || index >= ctx->n_streams) return OPUSGPU_BAD_ARG;
+    int32_t head[2], ch0[3]; // (channels, prev_mode); (lagPrev .. fs_kHz are not adjacent: three small copies, one synchronisation)
+    if (int rc = opusgpu_memcpy_d2h(ctx, head, &ctx->d_streams[index], sizeof(head))) return rc;
+    const SilkChannel *c = &ctx->d_streams[index].silk.ch[0];
+    HIPCHK(ctx, hipMemcpy(&ch0[0], &c->prevSignalType, 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(&ch0[1], &c->lagPrev, 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(&ch0[2], &c->fs_kHz, 4, hipMemcpyDeviceToHost));
+    out[0] = head[1];
+    out[1] = ch0[0];
+    out[2] = ch0[1];
+    out[3] = ch0[2];
+    return OPUSGPU_OK;
+}
+
 int opusgpu_debug_stage_taps(opusgpu_ctx *ctx, int slot, opusgpu_stage_taps *out) {
     if (!ctx || !out || slot < 0 || slot >= ctx->last_n || !ctx->last_descs) return OPUSGPU_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));

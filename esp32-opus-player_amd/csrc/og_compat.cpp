@@ -51,7 +51,20 @@ struct OpusDecoder {
     int32_t Fs;
     int decode_gain;
     int bandwidth, last_packet_duration;
+    // silk_DecControlStruct::prevPitchLag as the reference keeps it: exported at the end of every silk_Decode (src/silk.cpp:1764-1769)
+    // and by nothing else -- OPUS_RESET_STATE leaves it, so what OPUS_GET_PITCH reports after a reset is the last value.  Read from
+    // the device when asked (or before a reset), if a decode call has run since.
+    int32_t prev_pitch_lag;
+    bool pitch_stale;
 };
+
+static void pitch_refresh(OpusDecoder *d) {
+    if (!d->pitch_stale) return;
+    int32_t v[4];
+    if (opusgpu_stream_pitch_get(d->ctx, 0, v) == OPUSGPU_OK && (v[3] == 8 || v[3] == 12 || v[3] == 16))
+        d->prev_pitch_lag = v[1] == 2 ? v[2] * (v[3] == 8 ? 6 : v[3] == 12 ? 4 : 3) : 0; // the lag at 48 kHz (mult_tab, silk.cpp:1765)
+    d->pitch_stale = false;
+}
 
 static int dec_open(OpusDecoder *d, int32_t Fs, int channels) {
     if ((Fs != 48000 && Fs != 24000 && Fs != 16000 && Fs != 12000 && Fs != 8000) || (channels != 1 && channels != 2))
@@ -87,6 +100,7 @@ static int dec_decode(OpusDecoder *d, const uint8_t *data, int32_t len, int16_t 
         if (!buf) return OPUS_ALLOC_FAIL;
         int rc = opusgpu_decode_packets(d->ctx, 1, &id, &none, &zero, buf, passes, &res);
         if (rc != OPUSGPU_OK) res = OPUS_INTERNAL_ERROR;
+        d->pitch_stale = true;
         if (res > 0) {
             memcpy(pcm, buf, sizeof(int16_t) * (size_t)res * d->channels);
             d->last_packet_duration = res; // :307
@@ -112,6 +126,7 @@ static int dec_decode(OpusDecoder *d, const uint8_t *data, int32_t len, int16_t 
     if (!buf) return OPUS_ALLOC_FAIL;
     int rc = opusgpu_decode_packets(d->ctx, 1, &id, &pk, &len, buf, cap, &res);
     if (rc != OPUSGPU_OK) res = OPUS_INTERNAL_ERROR;
+    d->pitch_stale = true; // (frames may have run a SILK decode, whatever they returned)
     if (res > 0) {
         int n = res < frame_size ? res : frame_size;
         memcpy(pcm, buf, sizeof(int16_t) * (size_t)n * d->channels);
@@ -129,14 +144,30 @@ static int dec_ctl(OpusDecoder *d, int request, va_list ap) {
         case OPUS_SET_GAIN_REQUEST: { int32_t v = va_arg(ap, int32_t); if (v < -32768 || v > 32767) return OPUS_BAD_ARG; d->decode_gain = v; return OPUS_OK; } // stored, never applied (Q7)
         case OPUS_GET_LAST_PACKET_DURATION_REQUEST: { int32_t *v = va_arg(ap, int32_t *); if (!v) return OPUS_BAD_ARG; *v = d->last_packet_duration; return OPUS_OK; }
         case OPUS_GET_FINAL_RANGE_REQUEST: {
+            // The reference's OpusDecoder::rangeFinal is declared (src/opus_decoder.cpp:58), cleared with the struct (:90) and
+            // returned here (:375-380) -- and never assigned: opus_decode_frame ends at :276 without the `rangeFinal = dec.rng ^
+            // redundant_rng` of RFC 6716's decoder.  The ctl reports 0, always; so does this.  (The range decoder's last range of a
+            // stream is in its state record all the same -- opusgpu_stream_state_get, word 3 -- and parity tests compare it.)
             uint32_t *v = va_arg(ap, uint32_t *);
             if (!v) return OPUS_BAD_ARG;
-            int32_t head[4]; // channels, prev_mode, frames_decoded, range_final
-            if (opusgpu_stream_state_get(d->ctx, 0, head, sizeof(head)) != OPUSGPU_OK) return OPUS_INTERNAL_ERROR;
-            *v = (uint32_t)head[3];
+            *v = 0;
+            return OPUS_OK;
+        }
+        case OPUS_GET_PITCH_REQUEST: {
+            // src/opus_decoder.cpp:399-407.  After a CELT-only frame the reference calls celt_decoder_ctl with the POINTER as the
+            // request number: no case of that switch is a pointer's value, it answers OPUS_UNIMPLEMENTED (src/celt.cpp:2532-2541).
+            // Otherwise -- SILK-only / hybrid, or no frame yet -- the SILK decoder's last exported pitch lag at 48 kHz.
+            int32_t *v = va_arg(ap, int32_t *);
+            if (!v) return OPUS_BAD_ARG;
+            int32_t st[4];
+            if (opusgpu_stream_pitch_get(d->ctx, 0, st) != OPUSGPU_OK) return OPUS_INTERNAL_ERROR;
+            if (st[0] == MODE_CELT_ONLY) return OPUS_UNIMPLEMENTED;
+            pitch_refresh(d);
+            *v = d->prev_pitch_lag;
             return OPUS_OK;
         }
         case OPUS_RESET_STATE:
+            pitch_refresh(d); // (what the reset does not clear: see prev_pitch_lag)
             d->bandwidth = 0;
             d->last_packet_duration = 0;
             return opusgpu_streams_reset(d->ctx, 0, 1, 0) == OPUSGPU_OK ? OPUS_OK : OPUS_INTERNAL_ERROR;
@@ -190,6 +221,7 @@ int opus_multistream_decoder_init(OpusMSDecoder_t *st, int32_t Fs, int channels,
     }
     const int dch = coupled_streams ? 2 : 1;
     if (m->dec.ctx && m->dec.channels == dch) { // re-init of an existing object: fresh codec state
+        pitch_refresh(&m->dec); // (the SILK control structure is not part of what an init clears)
         if (opusgpu_streams_reset(m->dec.ctx, 0, 1, 1) != OPUSGPU_OK) return OPUS_INTERNAL_ERROR;
         m->dec.bandwidth = m->dec.last_packet_duration = 0;
     } else {
@@ -260,7 +292,9 @@ int opus_multistream_decoder_ctl(OpusMSDecoder_t *st, int request, ...) {
         OpusDecoder **v = va_arg(ap, OpusDecoder **);
         if (id != 0 || !v) r = OPUS_BAD_ARG;
         else { *v = &m->dec; r = OPUS_OK; }
-    } else
+    } else if (request == OPUS_GET_PITCH_REQUEST)
+        r = OPUS_UNIMPLEMENTED; // (not among the requests the reference's multistream ctl passes on, src/opus_decoder.cpp:945-1026)
+    else
         r = dec_ctl(&m->dec, request, ap);
     va_end(ap);
     return r;

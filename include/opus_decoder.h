@@ -22,8 +22,8 @@
 #define OPUS_GET_BANDWIDTH_REQUEST 4009
 #define OPUS_RESET_STATE 4028
 #define OPUS_GET_SAMPLE_RATE_REQUEST 4029
-#define OPUS_GET_FINAL_RANGE_REQUEST 4031
-#define OPUS_GET_PITCH_REQUEST 4033
+#define OPUS_GET_FINAL_RANGE_REQUEST 4031 /* reports 0, always, as the reference does: its rangeFinal is never assigned (src/opus_decoder.cpp:58, :375-380) */
+#define OPUS_GET_PITCH_REQUEST 4033       /* OPUS_UNIMPLEMENTED after a CELT-only frame and through the multistream ctl; else the SILK decoder's last lag at 48 kHz (:399-407) */
 #define OPUS_SET_GAIN_REQUEST 4034
 #define OPUS_GET_GAIN_REQUEST 4045 /* sic: the reference's value */
 #define OPUS_GET_LAST_PACKET_DURATION_REQUEST 4039

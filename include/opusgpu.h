@@ -265,6 +265,11 @@ int opusgpu_host_register(opusgpu_ctx *ctx, void *ptr, size_t bytes);
 int opusgpu_host_unregister(opusgpu_ctx *ctx, void *ptr);
 /* Copies stream `index`'s raw state record to the host (tests / checkpointing). */
 int opusgpu_stream_state_get(opusgpu_ctx *ctx, int index, void *dst, size_t bytes);
+/* What the reference's OPUS_GET_PITCH ctl looks at (src/opus_decoder.cpp:399-407, src/silk.cpp:1764-1769), for stream `index`:
+ * out[0] = prev_mode (0 before the first frame, else 1000 / 1001 / 1002), out[1] = the first SILK channel's prevSignalType
+ * (2 = voiced), out[2] = its lagPrev, out[3] = its internal rate in kHz (0 before the first SILK frame).  include/opus_decoder.h's
+ * ctl is built on it (csrc/og_compat.cpp).  Synchronises the context's stream. */
+int opusgpu_stream_pitch_get(opusgpu_ctx *ctx, int index, int32_t out[4]);
 
 /* TEST / DEBUG ENTRY: what the kernels of the last opusgpu_decode_step_device call (reference mode, split path) left BETWEEN
  * the stages, for slot `slot` of that step and the stream it belongs to -- so that a parity test can tell which kernel a

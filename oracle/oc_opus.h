@@ -155,7 +155,15 @@ oc_decoder *oc_decoder_create(int channels);             /* fresh state == opus_
 void oc_decoder_destroy(oc_decoder *d);
 void oc_decoder_init(oc_decoder *d, int channels);       /* opus_decoder_init opus_decoder.cpp:82 */
 void oc_decoder_reset(oc_decoder *d);                    /* OPUS_RESET_STATE  opus_decoder.cpp:382 */
-u32 oc_decoder_final_range(const oc_decoder *d);          /* OPUS_GET_FINAL_RANGE opus_decoder.cpp:375-380 */
+/* TEST TAP, not the reference's ctl: the range decoder's last range (^ a redundant frame's in RFC mode), what RFC 6716's decoder
+ * reports as its final range.  The reference's OPUS_GET_FINAL_RANGE (opus_decoder.cpp:375-380) returns OpusDecoder::rangeFinal,
+ * which nothing ever assigns: 0, always (oc_decoder_ctl_final_range). */
+u32 oc_decoder_final_range(const oc_decoder *d);
+u32 oc_decoder_ctl_final_range(const oc_decoder *d);      /* OPUS_GET_FINAL_RANGE as the reference answers it: 0 */
+/* OPUS_GET_PITCH (opus_decoder.cpp:399-407): after a CELT-only frame the reference hands the POINTER to celt_decoder_ctl as the
+ * request number and gets OPUS_UNIMPLEMENTED (-5: returned here); else the SILK decoder's last exported lag at 48 kHz in *value */
+int oc_decoder_ctl_pitch(const oc_decoder *d, i32 *value);
+i32 oc_silk_prev_pitch_lag(const oc_silk *s);
 /* RFC mode (PARITY UNPINNED -- the reference cannot do this and no libopus exists in the image): frames decode
  * at the duration their TOC names (CELT 2.5 / 5 / 10 / 20 ms, SILK 10 / 20 / 40 / 60 ms, hybrid 10 / 20 ms), multi-frame
  * packets accordingly; CELT's last band follows the bandwidth (13 / 17 / 19 / 21: Q1 fixed); a SILK-only frame after a hybrid

@@ -177,7 +177,13 @@ void oc_decoder_reset(oc_decoder *d) { /* opus_decoder.cpp:382 */
     d->frame_size = 48000 / 400;
 }
 
-u32 oc_decoder_final_range(const oc_decoder *d) { return d->range_final; } /* st->rangeFinal, opus_decoder.cpp:375-380 */
+u32 oc_decoder_final_range(const oc_decoder *d) { return d->range_final; } /* (a tap of the range decoder; see oc_opus.h) */
+u32 oc_decoder_ctl_final_range(const oc_decoder *d) { (void)d; return 0; } /* st->rangeFinal: declared :58, cleared :90, returned :380, never assigned */
+int oc_decoder_ctl_pitch(const oc_decoder *d, i32 *value) { /* opus_decoder.cpp:399-407 */
+    if (d->prev_mode == OC_MODE_CELT) return -5; /* celt_decoder_ctl((int32_t)value): no such request, celt.cpp:2532-2541 */
+    *value = oc_silk_prev_pitch_lag(d->silk);
+    return 0;
+}
 
 oc_decoder *oc_decoder_create(int channels) {
     oc_decoder *d = (oc_decoder *)calloc(1, sizeof(*d));

@@ -75,6 +75,7 @@ struct oc_silk {
     i16 pred_prev_Q13[2], sMid[2], sSide[2];
     i32 nChannelsAPI, nChannelsInternal, prev_decode_only_middle;
     ctrl_t ctrl;
+    i32 prev_pitch_lag; /* silk_DecControlStruct::prevPitchLag (silk.cpp:1764-1769): exported by every decode call; silk_InitDecoder does not touch it */
 };
 
 int oc_silk_sizeof(void) { return (int)sizeof(struct oc_silk); }
@@ -1362,9 +1363,12 @@ int oc_silk_decode_ex(oc_silk *s, oc_rc *rc, int channels, int internal_hz, int 
         else
             memcpy(out, rs_out, *n_out * sizeof(i16));
     }
+    /* the pitch lag at 48 kHz, for OPUS_GET_PITCH (silk.cpp:1764-1769) */
+    s->prev_pitch_lag = s->ch[0].prevSignalType == 2 ? s->ch[0].lagPrev * (s->ch[0].fs_kHz == 8 ? 6 : s->ch[0].fs_kHz == 12 ? 4 : 3) : 0;
     if (lostFlag == 1) /* silk.cpp:1772-1776: no gain clamping across a loss */
         for (i = 0; i < s->nChannelsInternal; i++) s->ch[i].LastGainIndex = 10;
     else
         s->prev_decode_only_middle = decode_only_middle;
     return 0;
 }
+i32 oc_silk_prev_pitch_lag(const oc_silk *s) { return s->prev_pitch_lag; }

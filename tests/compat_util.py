@@ -9,9 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run(tmp_path, steps):
-    """steps: ('D', frame_size, packet bytes) | ('N', frame_size): the last packet with len = -1 | ('R',) | ('Q',) | ('F',).  -> one entry per step: for 'D' (ret of opus_decode, ret of
+    """steps: ('D', frame_size, packet bytes) | ('N', frame_size): the last packet with len = -1 | ('R',) | ('Q',) | ('F',) | ('P',).  -> one entry per step: for 'D' (ret of opus_decode, ret of
     opus_multistream_decode, PCM int16 [min(ret, frame_size), 2] or None), for 'Q' the 8 int32 of the ctl queries and packet
-    helpers, for 'F' the two decoders' final range, for 'R' None.  The program itself checks that both entry points agree on the PCM and that no call writes past
+    helpers, for 'F' the two decoders' final range, for 'P' (ret of the single-stream OPUS_GET_PITCH, its value, ret of the multistream one), for 'R' None.  The program itself checks that both entry points agree on the PCM and that no call writes past
     frame_size samples (guard region)."""
     src = os.path.join(ROOT, "tests", "player", "compat_main.cpp")
     exe = str(tmp_path / "compat")
@@ -45,6 +45,9 @@ def run(tmp_path, steps):
         elif s[0] == "F":
             out.append(struct.unpack_from("<2I", got, at))
             at += 8
+        elif s[0] == "P":
+            out.append(struct.unpack_from("<3i", got, at))
+            at += 12
         else:
             out.append(None)
     assert at == len(got)

@@ -37,6 +37,10 @@ class Oracle:
         lib.oc_decode.restype = C.c_int
         lib.oc_decoder_final_range.argtypes = [vp]
         lib.oc_decoder_final_range.restype = C.c_uint32
+        lib.oc_decoder_ctl_final_range.argtypes = [vp]
+        lib.oc_decoder_ctl_final_range.restype = C.c_uint32
+        lib.oc_decoder_ctl_pitch.argtypes = [vp, C.POINTER(C.c_int32)]
+        lib.oc_decoder_ctl_pitch.restype = C.c_int
         lib.oc_decoder_set_rfc.argtypes = [vp, C.c_int]
         lib.oc_decoder_set_rfc.restype = None
         lib.oc_batch_decode.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]

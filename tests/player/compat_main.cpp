@@ -6,8 +6,9 @@
 //                     'R'                                 OPUS_RESET_STATE on both
 //                     'Q'                                 ctl queries + packet helpers of the last packet
 //                     'F'                                 OPUS_GET_FINAL_RANGE of both decoders
+//                     'P'                                 OPUS_GET_PITCH of both decoders
 //   output:  per 'D': i32 ret_single, i32 ret_ms, then min(ret, frame_size) * 2 int16 of the single-stream PCM if ret > 0
-//            per 'Q': 8 x i32;  per 'F': 2 x u32
+//            per 'Q': 8 x i32;  per 'F': 2 x u32;  per 'P': i32 ret_single, i32 value, i32 ret_ms
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -63,6 +64,12 @@ int main(int argc, char **argv) {
             uint32_t v[2] = {0xdeadbeefu, 0xdeadbeefu};
             if (opus_decoder_ctl(st, OPUS_GET_FINAL_RANGE_REQUEST, &v[0]) != OPUS_OK || opus_multistream_decoder_ctl(ms, OPUS_GET_FINAL_RANGE_REQUEST, &v[1]) != OPUS_OK) return 1;
             fwrite(v, 4, 2, out);
+        } else if (cmd == 'P') {
+            int32_t v[3] = {0, -777, 0};
+            v[0] = opus_decoder_ctl(st, OPUS_GET_PITCH_REQUEST, &v[1]);
+            int32_t unused = -777;
+            v[2] = opus_multistream_decoder_ctl(ms, OPUS_GET_PITCH_REQUEST, &unused);
+            fwrite(v, 4, 3, out);
         } else if (cmd == 'Q') {
             int32_t v[8] = {0};
             opus_decoder_ctl(st, OPUS_GET_SAMPLE_RATE_REQUEST, &v[0]);

@@ -1,5 +1,5 @@
-"""The one frame whose PCM and final range can be DERIVED BY HAND from the reference's source lines: a CELT-only frame whose payload
-is all 0xFF -- the silence flag.  (Known answers read off the oracle pin nothing: oracle and kernels share an author, DESIGN.md
+"""The one frame whose PCM and range-decoder state can be DERIVED BY HAND from the reference's source lines: a CELT-only frame whose
+payload is all 0xFF -- the silence flag.  (Known answers read off the oracle pin nothing: oracle and kernels share an author, DESIGN.md
 section 5; tests/test_return_codes.py does the same for the packet layer's return values.)
 
 The derivation, for a payload of n >= 2 bytes 0xFF behind a CELT-only 20 ms TOC:
@@ -15,7 +15,12 @@ The derivation, for a payload of n >= 2 bytes 0xFF behind a CELT-only 20 ms TOC:
     IMDCT of zeros onto a fresh decoder's zero overlap, a comb filter with all gains 0 and a de-emphasis with zero memory leave
     zeros: the PCM is 960 x channels zeros, and the state is what it was (except the energies), so the next such frame gives
     zeros again.
-  * opus_decode_frame (src/opus_decoder.cpp:276): rangeFinal = dec.rng ^ redundant_rng = 2^24 = 0x01000000 (len > 1); returns 960.
+  * celt_decode_with_ec stores that range (:2436, s_celtDec->rng = s_ec.rng: what celt_decoder_ctl(OPUS_GET_FINAL_RANGE) reports,
+    :2513-2517); opus_decode_frame returns 960.  The Opus decoder's own OPUS_GET_FINAL_RANGE is another matter: it returns
+    OpusDecoder::rangeFinal (src/opus_decoder.cpp:375-380), a field that is declared (:58), cleared with the struct (:90) and NEVER
+    ASSIGNED -- opus_decode_frame ends at :276 without RFC 6716's `rangeFinal = dec.rng ^ redundant_rng` -- so that ctl reports 0
+    after any packet.  Both are asserted below: the range decoder's state (oracle tap, opusgpu_stream_state_get) is 2^24, the ctl
+    of include/opus_decoder.h is 0.
 """
 import numpy as np
 import pytest
@@ -38,6 +43,7 @@ def test_oracle_silence_frame_known_answer(oracle):
                     assert r == 960, (hex(toc), channels, n, r)
                     assert not d.buf[:960].any(), (hex(toc), channels, n)
                     assert oracle.lib.oc_decoder_final_range(d.h) == FINAL_RANGE, (hex(toc), channels, n)
+                    assert oracle.lib.oc_decoder_ctl_final_range(d.h) == 0
     # two such frames in a code-1 packet: 1920 samples of zeros
     d = oracle.decoder(2)
     d.init()
@@ -66,7 +72,8 @@ def test_gpu_silence_frame_known_answer(pkg, gpu_ctx, channels):
 
 @pytest.mark.gpu
 def test_opus_decoder_h_silence_frame_known_answer(tmp_path):
-    """through opus_decode / opus_multistream_decode / OPUS_GET_FINAL_RANGE of include/opus_decoder.h (the GPU behind it)"""
+    """through opus_decode / opus_multistream_decode of include/opus_decoder.h (the GPU behind it); OPUS_GET_FINAL_RANGE there is the
+    reference's: 0"""
     import compat_util
     steps = []
     for toc in TOCS:
@@ -78,7 +85,7 @@ def test_opus_decoder_h_silence_frame_known_answer(tmp_path):
             assert g[0] == g[1] == s[1], (s, g[:2])
             assert not g[2].any(), s
         elif s[0] == "F":
-            assert g == (FINAL_RANGE, FINAL_RANGE), [hex(x) for x in g]
+            assert g == (0, 0), [hex(x) for x in g]  # (never assigned in the reference: see the module's docstring)
 
 
 @pytest.mark.gpu
@@ -103,3 +110,46 @@ def test_gpu_final_range_matches_the_oracle_in_every_mode(pkg, gpu_ctx, oracle):
                     assert r == res[s], (hex(toc), channels, k, s, r, int(res[s]))
                     assert gpu_ctx.lib.opusgpu_stream_state_get(gpu_ctx.h, s, head, 16) == 0
                     assert (head[3] & 0xFFFFFFFF) == oracle.lib.oc_decoder_final_range(decs[s].h), (hex(toc), channels, k, s)
+
+
+@pytest.mark.gpu
+def test_opus_decoder_h_ctls_the_reference_answers_oddly(tmp_path, oracle):
+    """Two ctls of include/opus_decoder.h whose answers follow from reading the reference's lines, not from RFC 6716's decoder:
+    OPUS_GET_FINAL_RANGE is 0 after ANY packet (rangeFinal is never assigned, src/opus_decoder.cpp:58, :90, :375-380), in both
+    decoders; OPUS_GET_PITCH (:399-407) is OPUS_UNIMPLEMENTED after a CELT-only frame (the pointer goes to celt_decoder_ctl as the
+    request number), else the SILK decoder's last exported lag at 48 kHz (src/silk.cpp:1764-1769) -- which OPUS_RESET_STATE does not
+    clear -- and OPUS_UNIMPLEMENTED through the multistream ctl (not among the requests it passes on, :945-1026).  The pitch values
+    against the oracle driven the same way; the rest are known answers."""
+    import compat_util
+    rng = np.random.default_rng(99)
+    P = lambda toc, n: bytes([toc]) + rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+    steps = [("P",)]                                                   # before any packet: no CELT frame yet -> a value (0)
+    for toc in (0x0C, 0x4C, 0x7C, 0x0C, 0x0C, 0x2C, 0x7C):             # SILK-only NB / WB, hybrid: some frames voiced
+        for _ in range(4):
+            steps += [("D", 960, P(toc, 60)), ("P",), ("F",)]
+    steps += [("D", 960, P(0xFC, 60)), ("P",), ("F",)]                 # after a CELT-only frame: OPUS_UNIMPLEMENTED
+    steps += [("D", 960, P(0x4C, 60)), ("P",), ("R",), ("P",)]         # a reset keeps the last exported lag
+    steps += [("D", 960, P(0x0C, 50)), ("P",)]
+    got = compat_util.run(tmp_path, steps)
+    d = oracle.decoder(2)
+    d.init()
+    import ctypes as C
+    seen = set()
+    for s, g in zip(steps, got):
+        if s[0] == "D":
+            r = oracle.lib.oc_decode(d.h, s[2], len(s[2]), d.buf.ctypes.data, s[1])
+            assert g[0] == g[1] == r
+        elif s[0] == "R":
+            d.reset()
+        elif s[0] == "F":
+            assert g == (0, 0)
+        elif s[0] == "P":
+            v = C.c_int32(-777)
+            r = oracle.lib.oc_decoder_ctl_pitch(d.h, C.byref(v))
+            assert g[0] == r and g[2] == -5, (g, r)
+            if r == 0:
+                assert g[1] == v.value, (g, v.value)
+                seen.add(v.value)
+            else:
+                assert r == -5 and g[1] == -777  # (the value is left alone)
+    assert len(seen) > 2  # (the walk saw voiced frames: the comparison is not one of zeros)
