@@ -30,8 +30,12 @@ int opus_packet_get_nb_samples(uint8_t packet[], int32_t len, int32_t Fs) {
 }
 int opus_packet_parse(uint8_t *data, int32_t len, unsigned char *out_toc, uint8_t *frames[48], int16_t size[48],
                       int *payload_offset) {
+    return opus_packet_parse_impl(data, len, 0, out_toc, frames, size, payload_offset, nullptr);
+}
+int opus_packet_parse_impl(uint8_t *data, int32_t len, int self_delimited, unsigned char *out_toc, uint8_t *frames[48],
+                           int16_t size[48], int *payload_offset, int32_t *packet_offset) { // src/opus_decoder.cpp:559-680
     int off = 0;
-    int n = ogh::parse_packet(data, len, 0, out_toc, size, &off, nullptr);
+    int n = ogh::parse_packet(data, len, self_delimited, out_toc, size, &off, packet_offset);
     if (n < 0) return n;
     if (payload_offset) *payload_offset = off;
     if (frames) {
@@ -177,6 +181,26 @@ static int dec_ctl(OpusDecoder *d, int request, va_list ap) {
 
 int opus_decoder_get_size(int channels) { return (channels < 1 || channels > 2) ? 0 : (int)sizeof(OpusDecoder); }
 int opus_decoder_init(OpusDecoder *st, int32_t Fs, int channels) { return st ? dec_open(st, Fs, channels) : OPUS_BAD_ARG; }
+int opus_decode_native(OpusDecoder *st, uint8_t *data, int32_t len, int16_t *pcm, int frame_size, int self_delimited,
+                       int32_t *packet_offset) { // src/opus_decoder.cpp:280-348 (no check of frame_size here: opus_decode's, :351)
+    if (self_delimited) return OPUS_UNIMPLEMENTED;
+    if (frame_size <= 0) { // (opus_decode refuses these, :351; here the reference goes on: a packet fails its size check, :323 -- after
+                           // its parse, :318 -- and an empty packet's loop would run into memory it was not given: refused)
+        if (len == 0 || data == nullptr || len < 0) return OPUS_BAD_ARG;
+        uint8_t toc;
+        int16_t size[48];
+        const int count = ogh::parse_packet(data, len, 0, &toc, size, nullptr, nullptr);
+        return count < 0 ? count : OPUS_BUFFER_TOO_SMALL;
+    }
+    const int ret = dec_decode(st, data, len, pcm, frame_size);
+    if (packet_offset && len > 0 && data) { // what opus_packet_parse_impl reports for the packet (:676-677): all of it
+        uint8_t toc;
+        int16_t size[48];
+        int32_t po = 0;
+        if (ogh::parse_packet(data, len, 0, &toc, size, nullptr, &po) >= 0) *packet_offset = po;
+    }
+    return ret;
+}
 int opus_decode(OpusDecoder *st, uint8_t *data, int32_t len, int16_t *pcm, int frame_size) {
     return dec_decode(st, data, len, pcm, frame_size);
 }
@@ -252,40 +276,51 @@ OpusMSDecoder_t *opus_multistream_decoder_create(int32_t Fs, int channels, int s
     return &m->pub;
 }
 
+static void copy_channel_out_short(void *dst, int dst_stride, int dst_channel, const int16_t *src, int src_stride, int frame_size,
+                                   void *) { // opus_copy_channel_out_short, src/opus_decoder.cpp:916-928
+    int16_t *d = (int16_t *)dst;
+    for (int i = 0; i < frame_size; i++) d[i * dst_stride + dst_channel] = src ? src[i * src_stride] : (int16_t)0;
+}
 int opus_multistream_decode(OpusMSDecoder_t *st, uint8_t *data, int32_t len, int16_t *pcm, int frame_size) {
+    return opus_multistream_decode_native(st, data, len, pcm, copy_channel_out_short, frame_size);
+}
+int opus_multistream_decode_native(OpusMSDecoder_t *st, uint8_t *data, int32_t len, void *pcm, opus_copy_channel_out_func copy_channel_out,
+                                   int frame_size) {
     // opus_multistream_decode_native (src/opus_decoder.cpp:826-913), one stream: frame_size <= 0 -> -1 (:836); frame_size capped at
     // 120 ms (:841); len < 0 -> -1 (:848); len == 0 is the empty packet of opus_decode_native (do_plc, :847), len >= 1 passes
     // :851's `len < 2 * nb_streams - 1`; opus_multistream_packet_validate's answers (:854-860) are those of dec_decode's own parse
     // and size check; `ret <= 0` comes back as it is (:876)
-    if (!st || frame_size <= 0 || len < 0) return OPUS_BAD_ARG;
+    if (!st || !copy_channel_out || frame_size <= 0 || len < 0) return OPUS_BAD_ARG;
     MSImpl *m = reinterpret_cast<MSImpl *>(st);
     if (frame_size > 5760) frame_size = 5760;
     const int dch = m->dec.channels;
     int16_t *buf = (int16_t *)malloc(sizeof(int16_t) * 2 * (size_t)frame_size);
     if (!buf) return OPUS_ALLOC_FAIL;
     int ret = dec_decode(&m->dec, data, len, buf, frame_size);
-    if (ret > 0) { // opus_copy_channel_out_short by mapping (src/opus_decoder.cpp:881-910)
+    if (ret > 0) { // the caller's copy function by mapping (src/opus_decoder.cpp:881-910: left, right / mono, then the muted channels)
         // A packet of more short frames than frame_size has room for at 960 samples each returns more than frame_size
         // (Q6): only what the caller has room for -- and what `buf` holds -- is handed out (dec_decode did the same).
         const int n = ret < frame_size ? ret : frame_size;
-        for (int c = 0; c < st->nb_channels; c++) {
-            const int mp = st->mapping[c];
-            for (int i = 0; i < n; i++) {
-                int16_t v = 0;
-                if (mp != 255) v = (dch == 2) ? buf[2 * i + (mp & 1)] : buf[i];
-                pcm[i * st->nb_channels + c] = v;
-            }
-        }
+        for (int side = 0; side < (dch == 2 ? 2 : 1); side++)
+            for (int c = 0; c < st->nb_channels; c++)
+                if (st->mapping[c] == side) copy_channel_out(pcm, st->nb_channels, c, buf + side, dch, n, nullptr);
+        for (int c = 0; c < st->nb_channels; c++)
+            if (st->mapping[c] == 255) copy_channel_out(pcm, st->nb_channels, c, nullptr, 0, n, nullptr);
     }
     free(buf);
     return ret;
 }
 
 int opus_multistream_decoder_ctl(OpusMSDecoder_t *st, int request, ...) {
-    if (!st) return OPUS_BAD_ARG;
-    MSImpl *m = reinterpret_cast<MSImpl *>(st);
     va_list ap;
     va_start(ap, request);
+    const int r = opus_multistream_decoder_ctl_va_list(st, request, ap);
+    va_end(ap);
+    return r;
+}
+int opus_multistream_decoder_ctl_va_list(OpusMSDecoder_t *st, int request, va_list ap) { // src/opus_decoder.cpp:936-1030
+    if (!st) return OPUS_BAD_ARG;
+    MSImpl *m = reinterpret_cast<MSImpl *>(st);
     int r;
     if (request == OPUS_MULTISTREAM_GET_DECODER_STATE_REQUEST) {
         int32_t id = va_arg(ap, int32_t);
@@ -296,7 +331,6 @@ int opus_multistream_decoder_ctl(OpusMSDecoder_t *st, int request, ...) {
         r = OPUS_UNIMPLEMENTED; // (not among the requests the reference's multistream ctl passes on, src/opus_decoder.cpp:945-1026)
     else
         r = dec_ctl(&m->dec, request, ap);
-    va_end(ap);
     return r;
 }
 

@@ -52,6 +52,8 @@ typedef struct OpusMSDecoder { // public layout of the reference (src/opus_decod
 // ---- packet helpers (host only; reference src/opus_decoder.cpp:460-509, :541-556, :683) ------------------
 int opus_packet_parse(uint8_t *data, int32_t len, unsigned char *out_toc, uint8_t *frames[48], int16_t size[48],
                       int *payload_offset);
+int opus_packet_parse_impl(uint8_t *data, int32_t len, int self_delimited, unsigned char *out_toc, uint8_t *frames[48],
+                           int16_t size[48], int *payload_offset, int32_t *packet_offset); // reference src/opus_decoder.h:202-204
 int opus_packet_get_bandwidth(uint8_t *data);
 int opus_packet_get_samples_per_frame(uint8_t *data, int32_t Fs);
 int opus_packet_get_nb_channels(uint8_t *data);
@@ -63,6 +65,10 @@ int opus_decoder_get_nb_samples(const OpusDecoder *dec, uint8_t packet[], int32_
 int opus_decoder_get_size(int channels);
 int opus_decoder_init(OpusDecoder *st, int32_t Fs, int channels);
 int opus_decode(OpusDecoder *st, uint8_t *data, int32_t len, int16_t *pcm, int frame_size);
+// (reference src/opus_decoder.h:182: what opus_decode and the multistream wrapper call.  self_delimited != 0 -- the framing of all
+// but the last stream of a multistream packet -- answers OPUS_UNIMPLEMENTED here, like a multistream decoder of more than one stream)
+int opus_decode_native(OpusDecoder *st, uint8_t *data, int32_t len, int16_t *pcm, int frame_size, int self_delimited,
+                       int32_t *packet_offset);
 int opus_decoder_ctl(OpusDecoder *st, int request, ...);
 void opus_decoder_destroy(OpusDecoder *st);
 
@@ -73,5 +79,11 @@ OpusMSDecoder_t *opus_multistream_decoder_create(int32_t Fs, int channels, int s
 int opus_multistream_decoder_init(OpusMSDecoder_t *st, int32_t Fs, int channels, int streams, int coupled_streams,
                                   const uint8_t *mapping);
 int opus_multistream_decode(OpusMSDecoder_t *st, uint8_t *data, int32_t len, int16_t *pcm, int frame_size);
+// (reference src/opus_decoder.h:153, :205-207)
+typedef void (*opus_copy_channel_out_func)(void *dst, int dst_stride, int dst_channel, const int16_t *src, int src_stride,
+                                           int frame_size, void *user_data);
+int opus_multistream_decode_native(OpusMSDecoder_t *st, uint8_t *data, int32_t len, void *pcm,
+                                   opus_copy_channel_out_func copy_channel_out, int frame_size);
+int opus_multistream_decoder_ctl_va_list(OpusMSDecoder_t *st, int request, va_list ap);
 int opus_multistream_decoder_ctl(OpusMSDecoder_t *st, int request, ...);
 void opus_multistream_decoder_destroy(OpusMSDecoder_t *st);

@@ -7,8 +7,9 @@
 //                     'Q'                                 ctl queries + packet helpers of the last packet
 //                     'F'                                 OPUS_GET_FINAL_RANGE of both decoders
 //                     'P'                                 OPUS_GET_PITCH of both decoders
+//                     'X'                                 the lower-level entry points on the last packet (see below)
 //   output:  per 'D': i32 ret_single, i32 ret_ms, then min(ret, frame_size) * 2 int16 of the single-stream PCM if ret > 0
-//            per 'Q': 8 x i32;  per 'F': 2 x u32;  per 'P': i32 ret_single, i32 value, i32 ret_ms
+//            per 'Q': 8 x i32;  per 'F': 2 x u32;  per 'P': i32 ret_single, i32 value, i32 ret_ms;  per 'X': 6 x i32
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -64,6 +65,45 @@ int main(int argc, char **argv) {
             uint32_t v[2] = {0xdeadbeefu, 0xdeadbeefu};
             if (opus_decoder_ctl(st, OPUS_GET_FINAL_RANGE_REQUEST, &v[0]) != OPUS_OK || opus_multistream_decoder_ctl(ms, OPUS_GET_FINAL_RANGE_REQUEST, &v[1]) != OPUS_OK) return 1;
             fwrite(v, 4, 2, out);
+        } else if (cmd == 'X') {
+            // opus_packet_parse_impl (not self-delimited: count, payload offset, packet offset), opus_decode_native with self_delimited
+            // 1 (unimplemented here) and with frame_size 0 on the last packet, opus_multistream_decode_native through a copy function
+            // of the caller's that negates what it copies (on two fresh decoders, so that the two under test keep their state)
+            int32_t v[6] = {0, 0, 0, 0, 0, 0};
+            if (!last.empty()) {
+                unsigned char toc = 0;
+                int16_t size[48];
+                uint8_t *frames[48];
+                int payload_offset = -1;
+                int32_t packet_offset = -1;
+                v[0] = opus_packet_parse_impl(last.data(), (int32_t)last.size(), 0, &toc, frames, size, &payload_offset, &packet_offset);
+                v[1] = payload_offset;
+                v[2] = packet_offset;
+                std::vector<int16_t> a(5760 * 2 + 64, GUARD);
+                int32_t po = -1;
+                v[3] = opus_decode_native(st, last.data(), (int32_t)last.size(), a.data(), 960, 1, &po);
+                v[4] = opus_decode_native(st, last.data(), (int32_t)last.size(), a.data(), 0, 0, &po);
+                // (two FRESH decoders: OPUS_RESET_STATE is the reference's partial reset, Q5 -- a decoder that has decoded the packet once
+                // does not decode it the same way again)
+                int e2 = 1, e3 = 1;
+                OpusMSDecoder_t *ms2 = opus_multistream_decoder_create(48000, 2, 1, 1, mapping, &e2);
+                OpusMSDecoder_t *ms3 = opus_multistream_decoder_create(48000, 2, 1, 1, mapping, &e3);
+                if (!ms2 || !ms3) return 1;
+                auto neg = [](void *dst, int dst_stride, int dst_channel, const int16_t *src, int src_stride, int frame_size, void *) {
+                    int16_t *d = (int16_t *)dst;
+                    for (int i = 0; i < frame_size; i++) d[i * dst_stride + dst_channel] = src ? (int16_t)~src[i * src_stride] : (int16_t)0;
+                };
+                std::vector<int16_t> b(5760 * 2 + 64, GUARD), c(5760 * 2 + 64, GUARD);
+                const int32_t r1 = opus_multistream_decode_native(ms2, last.data(), (int32_t)last.size(), b.data(), neg, 5760);
+                const int32_t r2 = opus_multistream_decode(ms3, last.data(), (int32_t)last.size(), c.data(), 5760);
+                opus_multistream_decoder_destroy(ms2);
+                opus_multistream_decoder_destroy(ms3);
+                v[5] = r1;
+                if (r1 != r2) v[5] = -9999;
+                for (int i = 0; r1 > 0 && i < 2 * r1; i++)
+                    if (b[i] != (int16_t)~c[i]) v[5] = -9998;
+            }
+            fwrite(v, 4, 6, out);
         } else if (cmd == 'P') {
             int32_t v[3] = {0, -777, 0};
             v[0] = opus_decoder_ctl(st, OPUS_GET_PITCH_REQUEST, &v[1]);

@@ -131,3 +131,32 @@ def test_opus_decoder_h_return_code_known_answers(tmp_path, oracle):
             if r > 0 and not (not toc & 0x80 and (toc & 0x60) != 0x60 and not toc & 4):  # (Q3: mono SILK-only in a stereo decoder)
                 n = min(r, fs)
                 assert np.array_equal(got[k][2], d.buf[:n]), (k, want.get(k))
+
+
+@pytest.mark.gpu
+def test_opus_decoder_h_lower_level_entry_points(tmp_path):
+    """The entry points the reference's header declares below opus_decode / opus_multistream_decode (src/opus_decoder.h:182,
+    :202-207): opus_packet_parse_impl's count, payload offset and packet offset -- known answers from :559-680 --,
+    opus_decode_native with self_delimited = 1 (OPUS_UNIMPLEMENTED here: one elementary stream) and with frame_size 0 (:323: a packet
+    that parses fails the size check), opus_multistream_decode_native with a copy function of the caller's."""
+    import compat_util
+    rows = [
+        # packet, count, payload offset, packet offset (:676-677: pad + what the frames take = the whole packet), ret at frame_size 0
+        (b"\xfc" + P(50), 1, 1, 51, -2),
+        (b"\xfd" + P(100), 2, 1, 101, -2),
+        (b"\xfe\x28" + P(40 + 70), 2, 2, 112, -2),
+        (b"\xff\x41\x02" + P(10) + b"\0\0", 1, 3, 15, -2),
+        (b"\xff\x82\x05" + P(15), 2, 3, 18, -2),
+        (b"\xfe\x0a" + P(5), -4, -1, -1, -4),
+    ]
+    steps = []
+    for pkt, *_ in rows:
+        steps += [("R",), ("D", 5760, pkt), ("X",)]
+    got = compat_util.run(tmp_path, steps)
+    for k, (pkt, count, poff, koff, r0) in enumerate(rows):
+        x = got[3 * k + 2]
+        assert x[0] == count, (k, x)
+        if count > 0:
+            assert x[1] == poff and x[2] == koff, (k, x)
+        assert x[3] == -5 and x[4] == r0, (k, x)
+        assert x[5] == (960 * count if count > 0 else count), (k, x)  # (and the program compared the PCM: -9998 / -9999 on a difference)
