@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run(tmp_path, steps):
-    """steps: ('D', frame_size, packet bytes) | ('N', frame_size): the last packet with len = -1 | ('R',) | ('Q',) | ('F',) | ('P',) | ('X',).  -> one entry per step: for 'D' (ret of opus_decode, ret of
+    """steps: ('D', frame_size, packet bytes) | ('N', frame_size): the last packet with len = -1 | ('R',) | ('Q',) | ('F',) | ('P',) | ('X',) | ('V',).  -> one entry per step: for 'D' (ret of opus_decode, ret of
     opus_multistream_decode, PCM int16 [min(ret, frame_size), 2] or None), for 'Q' the 8 int32 of the ctl queries and packet
     helpers, for 'F' the two decoders' final range, for 'P' (ret of the single-stream OPUS_GET_PITCH, its value, ret of the multistream one), for 'R' None.  The program itself checks that both entry points agree on the PCM and that no call writes past
     frame_size samples (guard region)."""
@@ -51,6 +51,9 @@ def run(tmp_path, steps):
         elif s[0] == "X":
             out.append(struct.unpack_from("<6i", got, at))
             at += 24
+        elif s[0] == "V":
+            out.append(struct.unpack_from("<19i", got, at))
+            at += 76
         else:
             out.append(None)
     assert at == len(got)

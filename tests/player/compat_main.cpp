@@ -8,6 +8,7 @@
 //                     'F'                                 OPUS_GET_FINAL_RANGE of both decoders
 //                     'P'                                 OPUS_GET_PITCH of both decoders
 //                     'X'                                 the lower-level entry points on the last packet (see below)
+//                     'V'                                 the argument checks of the create / init / get_size functions: 19 x i32
 //   output:  per 'D': i32 ret_single, i32 ret_ms, then min(ret, frame_size) * 2 int16 of the single-stream PCM if ret > 0
 //            per 'Q': 8 x i32;  per 'F': 2 x u32;  per 'P': i32 ret_single, i32 value, i32 ret_ms;  per 'X': 6 x i32
 #include <cstdint>
@@ -65,6 +66,38 @@ int main(int argc, char **argv) {
             uint32_t v[2] = {0xdeadbeefu, 0xdeadbeefu};
             if (opus_decoder_ctl(st, OPUS_GET_FINAL_RANGE_REQUEST, &v[0]) != OPUS_OK || opus_multistream_decoder_ctl(ms, OPUS_GET_FINAL_RANGE_REQUEST, &v[1]) != OPUS_OK) return 1;
             fwrite(v, 4, 2, out);
+        } else if (cmd == 'V') {
+            int32_t v[19];
+            int k = 0;
+            auto create = [&](int32_t Fs, int channels, int streams, int coupled, const uint8_t *map) {
+                int e = 12345;
+                OpusMSDecoder_t *d = opus_multistream_decoder_create(Fs, channels, streams, coupled, map, &e);
+                if (d) opus_multistream_decoder_destroy(d);
+                return d ? (e == OPUS_OK ? 0 : -9999) : (e == OPUS_OK ? -9998 : e);
+            };
+            const uint8_t m01[2] = {0, 1}, m02[2] = {0, 2}, m0m[2] = {0, 255}, m0[1] = {0};
+            v[k++] = create(48000, 0, 1, 1, m01);    // channels < 1
+            v[k++] = create(48000, 256, 1, 1, m01);  // channels > 255
+            v[k++] = create(48000, 2, 0, 0, m01);    // streams < 1
+            v[k++] = create(48000, 2, 1, 2, m01);    // coupled_streams > streams
+            v[k++] = create(48000, 2, 1, -1, m01);   // coupled_streams < 0
+            v[k++] = create(48000, 2, 1, 1, m02);    // validate_layout: a channel mapped past the decoded ones
+            v[k++] = create(48000, 2, 1, 1, m0m);    // a muted channel is fine
+            v[k++] = create(48000, 1, 1, 0, m0);     // one mono stream
+            v[k++] = create(44100, 2, 1, 1, m01);    // opus_decoder_init's rate check
+            v[k++] = create(24000, 2, 1, 1, m01);    // (this library: 48 kHz only)
+            v[k++] = create(48000, 2, 2, 0, m01);    // (this library: one elementary stream)
+            v[k++] = opus_multistream_decoder_get_size(0, 0);
+            v[k++] = opus_multistream_decoder_get_size(1, 2);
+            v[k++] = opus_multistream_decoder_get_size(1, -1);
+            v[k++] = opus_multistream_decoder_get_size(1, 1) > 0;
+            v[k++] = opus_decoder_get_size(0);
+            v[k++] = opus_decoder_get_size(3);
+            v[k++] = opus_decoder_get_size(1) > 0 && opus_decoder_get_size(2) > 0;
+            OpusDecoder *bad = (OpusDecoder *)malloc((size_t)opus_decoder_get_size(2));
+            v[k++] = opus_decoder_init(bad, 48000, 3); // channels
+            free(bad);
+            fwrite(v, 4, 19, out);
         } else if (cmd == 'X') {
             // opus_packet_parse_impl (not self-delimited: count, payload offset, packet offset), opus_decode_native with self_delimited
             // 1 (unimplemented here) and with frame_size 0 on the last packet, opus_multistream_decode_native through a copy function

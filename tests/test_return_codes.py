@@ -160,3 +160,19 @@ def test_opus_decoder_h_lower_level_entry_points(tmp_path):
             assert x[1] == poff and x[2] == koff, (k, x)
         assert x[3] == -5 and x[4] == r0, (k, x)
         assert x[5] == (960 * count if count > 0 else count), (k, x)  # (and the program compared the PCM: -9998 / -9999 on a difference)
+
+
+@pytest.mark.gpu
+def test_opus_decoder_h_argument_checks(tmp_path):
+    """opus_multistream_decoder_create / _init (src/opus_decoder.cpp:757-821), validate_layout (:688-697), the get_size functions
+    (:66-71, :740-750) and opus_decoder_init (:82-88): known answers from those lines -- and the two cases this library answers
+    differently on purpose (output rates other than 48 kHz, more than one elementary stream: OPUS_UNIMPLEMENTED)."""
+    import compat_util
+    (v,) = compat_util.run(tmp_path, [("V",)])
+    assert v[:6] == (-1, -1, -1, -1, -1, -1), v    # :805-810 five times, then :774 (validate_layout)
+    assert v[6:8] == (0, 0), v                      # a muted channel (255) and a mono stream are layouts
+    assert v[8] == -1, v                            # :86: 44,100 Hz is not a rate
+    assert v[9:11] == (-5, -5), v                   # (this library's two: INTEGRATION.md)
+    assert v[11:15] == (0, 0, 0, 1), v              # :744
+    assert v[15:18] == (0, 0, 1), v                 # :70
+    assert v[18] == -1, v                           # :87: channels
