@@ -792,7 +792,9 @@ _CUT = {"workload": ":", "kernel": " (", "sample": ",", "result": " (", "shardin
 def compact(o, key=None, depth=0):
     """The line without its prose: long strings cut at their first clause, explanatory keys dropped, floats to 6 digits."""
     if isinstance(o, dict):
-        return {k: compact(v, k, depth + 1) for k, v in o.items() if k not in _DROP and not (k == "sharding" and depth > 1)}
+        # (below the line's own objects -- the other configurations' -- what repeats the headline's: the peak, its unit, the bound)
+        return {k: compact(v, k, depth + 1) for k, v in o.items()
+                if k not in _DROP and not (depth > 1 and k in ("sharding", "peak", "bound", "frames_per_launch"))}
     if isinstance(o, list):
         return [compact(v, key, depth + 1) for v in o]
     if isinstance(o, float):
